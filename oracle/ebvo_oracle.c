@@ -1,0 +1,606 @@
+/*
+ * ebvo_oracle.c -- CPU restatement of the reference's edge-extraction-and-matching hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY (see ebvo_oracle.h).  Plain C99 + OpenMP, IEEE double, no FMA
+ * (build with -O2 -ffp-contract=off and no -march flags, like the reference's
+ * CMAKE_CXX_FLAGS_RELEASE "-O2 -DNDEBUG", CMakeLists.txt:23).
+ *
+ * Citations are file:line in Brown-LEMS/Edge_Based_Visual_Odometry.
+ *
+ * Arithmetic that the reference leaves to third-party code (OpenCV reductions in
+ * src/utility.cpp:165-179) is fixed here to one canonical order that the HIP kernels
+ * reproduce bit for bit:
+ *   - a 49-term reduction is 7 row sums, each accumulated left to right in double, then
+ *     combined as ((s0+s1)+(s2+s3)) + ((s4+s5)+(s6+0)) -- the 8-lane xor-butterfly;
+ *   - patch - mean, squares, and the normalisation run in float (CV_32F element ops),
+ *     reductions in double (what cv::mean / cv::sum / Mat::dot do for CV_32F).
+ */
+#include "ebvo_oracle.h"
+
+#include <math.h>
+#include <omp.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../edge_based_visual_odometry_amd/csrc/ebvo_math.h"
+
+/* ------------------------------------------------------------------------------------ */
+/* TOED filter taps: sigma = 2 Gaussian and its derivatives, 19 entries each.            */
+/* Values are the literals of src/toed/cpu_toed.cpp:143-146 (integer grid) and :157-160   */
+/* (half-pixel shifted grid).  Index [d] = derivative order 0..3.                         */
+/* ------------------------------------------------------------------------------------ */
+static const double TAP_INT[4][19] = {
+    {7.99187055345274e-06, 6.69151128824427e-05, 0.000436341347522880, 0.00221592420596900,
+     0.00876415024678427, 0.0269954832565940, 0.0647587978329459, 0.120985362259572, 0.176032663382150,
+     0.199471140200716, 0.176032663382150, 0.120985362259572, 0.0647587978329459, 0.0269954832565940,
+     0.00876415024678427, 0.00221592420596900, 0.000436341347522880, 6.69151128824427e-05,
+     7.99187055345274e-06},
+    {1.79817087452687e-05, 0.000133830225764885, 0.000763597358165040, 0.00332388630895351,
+     0.0109551878084803, 0.0269954832565940, 0.0485690983747094, 0.0604926811297858, 0.0440081658455374, 0,
+     -0.0440081658455374, -0.0604926811297858, -0.0485690983747094, -0.0269954832565940,
+     -0.0109551878084803, -0.00332388630895351, -0.000763597358165040, -0.000133830225764885,
+     -1.79817087452687e-05},
+    {3.84608770384913e-05, 0.000250931673309160, 0.00122721003990810, 0.00443184841193801,
+     0.0115029471989044, 0.0202466124424455, 0.0202371243227956, 0, -0.0330061243841531,
+     -0.0498677850501791, -0.0330061243841531, 0, 0.0202371243227956, 0.0202466124424455,
+     0.0115029471989044, 0.00443184841193801, 0.00122721003990810, 0.000250931673309160,
+     3.84608770384913e-05},
+    {7.75461189639711e-05, 0.000434948233735878, 0.00176581889075666, 0.00498582946343026,
+     0.00890109009439027, 0.00674887081414851, -0.00910670594525801, -0.0302463405648929,
+     -0.0302556140188070, 0, 0.0302556140188070, 0.0302463405648929, 0.00910670594525801,
+     -0.00674887081414851, -0.00890109009439027, -0.00498582946343026, -0.00176581889075666,
+     -0.000434948233735878, -7.75461189639711e-05},
+};
+static const double TAP_HALF[4][19] = {
+    {2.38593182706025e-05, 0.000176297841183723, 0.00101452402864988, 0.00454678125079553,
+     0.0158698259178337, 0.0431386594132558, 0.0913245426945110, 0.150568716077402, 0.193334058401425,
+     0.193334058401425, 0.150568716077402, 0.0913245426945110, 0.0431386594132558, 0.0158698259178337,
+     0.00454678125079553, 0.00101452402864988, 0.000176297841183723, 2.38593182706025e-05,
+     2.51475364429622e-06},
+    {5.07010513250303e-05, 0.000330558452219480, 0.00164860154655606, 0.00625182421984385,
+     0.0178535541575629, 0.0377463269865988, 0.0570778391840694, 0.0564632685290258, 0.0241667573001781,
+     -0.0241667573001781, -0.0564632685290258, -0.0570778391840694, -0.0377463269865988,
+     -0.0178535541575629, -0.00625182421984385, -0.00164860154655606, -0.000330558452219480,
+     -5.07010513250303e-05, -5.97253990520353e-06},
+    {0.000101774904498039, 0.000575722637615595, 0.00242534650599113, 0.00745956298958641,
+     0.0161177919477999, 0.0222433712599600, 0.0128425138164156, -0.0164684533209659,
+     -0.0453126699378339, -0.0453126699378339, -0.0164684533209659, 0.0128425138164156,
+     0.0222433712599600, 0.0161177919477999, 0.00745956298958641, 0.00242534650599113,
+     0.000575722637615595, 0.000101774904498039, 1.35560938637843e-05},
+    {0.000190921146395817, 0.000914200719419500, 0.00311688729895755, 0.00713098700075939,
+     0.00920573886249338, 0.000589786359165606, -0.0205123484567749, -0.0344073042598751,
+     -0.0177474623923183, 0.0177474623923183, 0.0344073042598751, 0.0205123484567749,
+     -0.000589786359165606, -0.00920573886249338, -0.00713098700075939, -0.00311688729895755,
+     -0.000914200719419500, -0.000190921146395817, -2.92094529738860e-05},
+};
+
+/* The nine responses in the reference's order fx fy fxx fxy fyy fxxy fxyy fxxx fyyy:
+ * derivative order along x (column taps, index q) and along y (row taps, index p). */
+static const int RESP_DX[9] = {1, 0, 2, 1, 0, 2, 1, 3, 0};
+static const int RESP_DY[9] = {0, 1, 0, 1, 2, 1, 2, 0, 3};
+
+/*
+ * One sub-pixel phase of the convolution at input pixel (i, j).
+ * sx / sy: half-pixel shift along x / y.  src/toed/cpu_toed.cpp:199-218 (integer phase,
+ * 17x17), :243-262, :287-306, :331-350 (shifted phases, 19x19).  Taps are visited p ascending,
+ * q ascending; samples outside the image are skipped (:204).
+ */
+static void conv_phase(const double *img, int h, int w, int i, int j, int sx, int sy, double f[9])
+{
+    const double(*colk)[19] = sx ? TAP_HALF : TAP_INT;
+    const double(*rowk)[19] = sy ? TAP_HALF : TAP_INT;
+    const int integer_phase = !sx && !sy;
+    const int half = integer_phase ? 8 : 9;
+    for (int r = 0; r < 9; r++)
+        f[r] = 0;
+    for (int p = -half; p <= half; p++)
+    {
+        const int ii = i - p;
+        if (ii < 0 || ii >= h)
+            continue;
+        for (int q = -half; q <= half; q++)
+        {
+            const int jj = j - q;
+            if (jj < 0 || jj >= w)
+                continue;
+            const double v = img[(size_t)ii * w + jj];
+            int r = 0;
+            if (integer_phase)
+            {
+                /* :207-208 -- the two tap factors are multiplied first */
+                f[0] += v * (colk[1][q + 9] * rowk[0][p + 9]);
+                f[1] += v * (colk[0][q + 9] * rowk[1][p + 9]);
+                r = 2;
+            }
+            for (; r < 9; r++) /* :210-216, :251-260 ... -- (v * col tap) * row tap */
+                f[r] += v * colk[RESP_DX[r]][q + 9] * rowk[RESP_DY[r]][p + 9];
+        }
+    }
+}
+
+/* Third-order orientation vector, src/toed/cpu_toed.cpp:224-228 (same expression trees). */
+static void third_order_dir(const double f[9], double *tx, double *ty)
+{
+    const double fx = f[0], fy = f[1], fxx = f[2], fxy = f[3], fyy = f[4], fxxy = f[5], fxyy = f[6],
+                 fxxx = f[7], fyyy = f[8];
+    double TO_Ix = fx * (2 * fxx * fxx + 2 * fxy * fxy) + fy * (2 * fxx * fxy + 2 * fyy * fxy) +
+                   2 * fx * fy * fxxy + fy * fy * fxyy + fx * fx * fxxx;
+    double TO_Iy = fx * (2 * fxx * fxy + 2 * fyy * fxy) + fy * (2 * fyy * fyy + 2 * fxy * fxy) +
+                   2 * fx * fy * fxyy + fx * fx * fxxy + fy * fy * fyyy;
+    double TO_mag = sqrt(TO_Ix * TO_Ix + TO_Iy * TO_Iy);
+    *tx = TO_Ix / TO_mag;
+    *ty = TO_Iy / TO_mag;
+}
+
+static double orient_of(double tx, double ty, int math_mode)
+{
+    /* src/toed/cpu_toed.cpp:229: atan2(TO_Ix, -TO_Iy) */
+    return math_mode == ORC_MATH_LIBM ? atan2(tx, -ty) : ebvo_atan2(tx, -ty);
+}
+
+/* Neighbour offsets (di, dj) of the two magnitudes interpolated on the "plus" side for the
+ * eight gradient sectors of src/toed/cpu_toed.cpp:418-477; the "minus" side negates both. */
+static const int NMS_P1[8][2] = {{0, 1}, {1, 0}, {1, 0}, {0, -1}, {0, -1}, {-1, 0}, {-1, 0}, {0, 1}};
+static const int NMS_P2[8][2] = {{1, 1}, {1, 1}, {1, -1}, {1, -1}, {-1, -1}, {-1, -1}, {-1, 1}, {-1, 1}};
+
+/*
+ * NMS + parabola sub-pixel fit at interpolated pixel (i, j): src/toed/cpu_toed.cpp:406-511.
+ * Returns 1 and fills (pos_x, pos_y, sub-pixel magnitude) if it is an accepted maximum.
+ */
+static int nms_pixel(const double *Ix, const double *Iy, const double *M, int W2, int i, int j,
+                     double *pos_x, double *pos_y, double *smag)
+{
+    const size_t o = (size_t)i * W2 + j;
+    const double m = M[o];
+    if (m <= 2) /* :406 */
+        return 0;
+    const double gx = Ix[o], gy = Iy[o];
+    if (fabs(gx) < 10e-6 && fabs(gy) < 10e-6) /* :410 */
+        return 0;
+    const double nx = gx / m, ny = gy / m; /* :414-415 */
+    int sector;
+    double slope;
+    if (gx >= 0 && gy >= 0)
+    {
+        if (gx >= gy) { sector = 0; slope = ny / nx; }
+        else { sector = 1; slope = nx / ny; }
+    }
+    else if (gx < 0 && gy >= 0)
+    {
+        if (fabs(gx) < gy) { sector = 2; slope = -nx / ny; }
+        else { sector = 3; slope = -ny / nx; }
+    }
+    else if (gx < 0 && gy < 0)
+    {
+        if (fabs(gx) >= fabs(gy)) { sector = 4; slope = ny / nx; }
+        else { sector = 5; slope = nx / ny; }
+    }
+    else if (gx >= 0 && gy < 0)
+    {
+        if (gx < fabs(gy)) { sector = 6; slope = -nx / ny; }
+        else { sector = 7; slope = -ny / nx; }
+    }
+    else
+        return 0; /* NaN gradient: cannot happen when m > 2 */
+    const int a1 = NMS_P1[sector][0], b1 = NMS_P1[sector][1];
+    const int a2 = NMS_P2[sector][0], b2 = NMS_P2[sector][1];
+    const double fp = M[(size_t)(i + a1) * W2 + (j + b1)] * (1 - slope) + M[(size_t)(i + a2) * W2 + (j + b2)] * slope;
+    const double fm = M[(size_t)(i - a1) * W2 + (j - b1)] * (1 - slope) + M[(size_t)(i - a2) * W2 + (j - b2)] * slope;
+    const double s = sqrt(1 + slope * slope); /* :480 */
+    if (!((m > fm && m > fp) || (m > fm && m >= fp) || (m >= fm && m > fp))) /* :481-483 */
+        return 0;
+    const double A = (fm + fp - 2 * m) / (2 * s * s); /* :487-489 */
+    const double B = (fp - fm) / (2 * s);
+    const double C = m;
+    const double s_star = -B / (2 * A);                     /* :491 */
+    const double max_f = A * s_star * s_star + B * s_star + C; /* :492 */
+    if (!(fabs(s_star) <= sqrt(2.0)))                       /* :494 */
+        return 0;
+    const double sgx = max_f * nx, sgy = max_f * ny; /* :498-502 */
+    *smag = sqrt(sgx * sgx + sgy * sgy);
+    *pos_x = j + s_star * nx; /* :505-506 */
+    *pos_y = i + s_star * ny;
+    return 1;
+}
+
+int orc_toed(const uint8_t *img8, int h, int w, ptrdiff_t stride, int math_mode, int nthreads,
+             orc_edge *kept, int cap_kept, double *all4, int cap_all, int *n_kept, int *n_total,
+             double *maps, double *t_conv, double *t_nms)
+{
+    const int H2 = 2 * h, W2 = 2 * w;
+    const size_t np2 = (size_t)H2 * W2;
+    if (nthreads <= 0)
+        nthreads = omp_get_num_procs(); /* src/toed/cpu_toed.cpp:43 */
+    double *img = (double *)malloc(sizeof(double) * (size_t)h * w);
+    double *own = maps ? NULL : (double *)malloc(sizeof(double) * np2 * 5);
+    double *Ix = maps ? maps : own, *Iy = Ix + np2, *M = Iy + np2, *TX = M + np2, *TY = TX + np2;
+    double *px = (double *)malloc(sizeof(double) * np2 * 3), *py = px + np2, *pm = py + np2;
+    uint8_t *flag = (uint8_t *)calloc(np2, 1);
+    if (!img || !Ix || !px || !flag)
+    {
+        free(img); free(own); free(px); free(flag);
+        return -2;
+    }
+    for (int i = 0; i < h; i++) /* :89-95 */
+        for (int j = 0; j < w; j++)
+            img[(size_t)i * w + j] = (double)img8[(size_t)i * stride + j];
+
+    double t0 = omp_get_wtime();
+#pragma omp parallel for schedule(dynamic) num_threads(nthreads) /* :180-182 */
+    for (int i = 0; i < h; i++)
+        for (int j = 0; j < w; j++)
+            for (int sy = 0; sy < 2; sy++)
+                for (int sx = 0; sx < 2; sx++)
+                {
+                    double f[9], tx, ty;
+                    conv_phase(img, h, w, i, j, sx, sy, f);
+                    const size_t o = (size_t)(2 * i + sy) * W2 + (2 * j + sx);
+                    Ix[o] = f[0]; /* :220-222 */
+                    Iy[o] = f[1];
+                    M[o] = sqrt(f[0] * f[0] + f[1] * f[1]);
+                    third_order_dir(f, &tx, &ty);
+                    TX[o] = tx;
+                    TY[o] = ty;
+                }
+    double t1 = omp_get_wtime();
+
+#pragma omp parallel for schedule(dynamic) num_threads(nthreads) /* :400-403 */
+    for (int j = 10; j < W2 - 10; j++)
+        for (int i = 10; i < H2 - 10; i++)
+        {
+            const size_t o = (size_t)i * W2 + j;
+            if (nms_pixel(Ix, Iy, M, W2, i, j, &px[o], &py[o], &pm[o]))
+                flag[o] = 1;
+        }
+
+    /* raster compaction, src/toed/cpu_toed.cpp:526-575 */
+    int total = 0, nk = 0;
+    for (int i = 10; i < H2 - 10; i++)
+        for (int j = 10; j < W2 - 10; j++)
+        {
+            const size_t o = (size_t)i * W2 + j;
+            if (!flag[o])
+                continue;
+            const double x = (px[o] - 1) / 2, y = (py[o] - 1) / 2; /* :538,542 */
+            const double th = orient_of(TX[o], TY[o], math_mode);
+            if (all4 && total < cap_all)
+            {
+                all4[(size_t)total * 4 + 0] = x;
+                all4[(size_t)total * 4 + 1] = y;
+                all4[(size_t)total * 4 + 2] = th;
+                all4[(size_t)total * 4 + 3] = pm[o];
+            }
+            if (x > 10 && x < w - 10 && y > 10 && y < h - 10) /* :553-554 */
+            {
+                if (kept && nk < cap_kept)
+                {
+                    kept[nk].x = x;
+                    kept[nk].y = y;
+                    kept[nk].theta = th;
+                    kept[nk].index = nk; /* :562 */
+                    kept[nk].pad = 0;
+                }
+                nk++;
+            }
+            total++;
+        }
+    double t2 = omp_get_wtime();
+    if (t_conv) *t_conv = t1 - t0;
+    if (t_nms) *t_nms = t2 - t1;
+    *n_kept = nk;
+    *n_total = total;
+    free(img); free(own); free(px); free(flag);
+    if ((kept && nk > cap_kept) || (all4 && total > cap_all))
+        return -1;
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* Candidate search + geometric filters                                                  */
+/* ------------------------------------------------------------------------------------ */
+
+/* src/Stereo_Matches.cpp:10-20.  The reference leaves the evaluation order of the 3x3 * 3
+ * product to Eigen; this library takes the lines as an input of the path, and when asked to
+ * form them itself it uses (F_i0*x + F_i1*y) + F_i2, left to right. */
+void orc_epipolar_lines(const double *F, const orc_edge *e, int n, double *lines)
+{
+    for (int k = 0; k < n; k++)
+        for (int r = 0; r < 3; r++)
+            lines[(size_t)k * 3 + r] = (F[r * 3 + 0] * e[k].x + F[r * 3 + 1] * e[k].y) + F[r * 3 + 2];
+}
+
+static int pair_passes(const orc_edge *l, const orc_edge *r, const double *ln, double epi_thr,
+                       double max_disp, double orient_thr_deg, int mask)
+{
+    if (mask & ORC_STAGE_EPIPOLAR)
+    { /* src/Stereo_Matches.cpp:99-101 */
+        double d = fabs(ln[0] * r->x + ln[1] * r->y + ln[2]) / sqrt((ln[0] * ln[0]) + (ln[1] * ln[1]));
+        if (!(d < epi_thr))
+            return 0;
+    }
+    if (mask & ORC_STAGE_DISPARITY)
+    { /* :545-546, cv::norm(Point2d) = sqrt(x*x + y*y) */
+        double dx = l->x - r->x, dy = l->y - r->y;
+        double disp = sqrt(dx * dx + dy * dy);
+        if (!(disp <= max_disp))
+            return 0;
+    }
+    if (mask & ORC_STAGE_ORIENTATION)
+    { /* :887-901, rad_to_deg = theta * (180.0 / M_PI), include/utility.h:288-291 */
+        double od = fabs((l->theta - r->theta) * (180.0 / M_PI));
+        if (od > 180.0)
+            od = 360.0 - od;
+        if (!(od < orient_thr_deg || fabs(od - 180.0) < orient_thr_deg))
+            return 0;
+    }
+    return 1;
+}
+
+int orc_epi_candidates(const orc_edge *L, int nL, const orc_edge *R, int nR, const double *lines,
+                       double epi_thr, double max_disp, double orient_thr_deg, int stage_mask,
+                       int nthreads, int32_t *row_ptr, int32_t *col_idx, int64_t cap, int64_t *n_pairs)
+{
+    if (nthreads <= 0)
+        nthreads = omp_get_num_procs();
+    int32_t *cnt = (int32_t *)calloc((size_t)nL + 1, sizeof(int32_t));
+#pragma omp parallel for schedule(dynamic, 16) num_threads(nthreads) /* :395-398 */
+    for (int i = 0; i < nL; i++)
+    {
+        int c = 0;
+        for (int k = 0; k < nR; k++)
+            c += pair_passes(&L[i], &R[k], lines + (size_t)i * 3, epi_thr, max_disp, orient_thr_deg, stage_mask);
+        cnt[i] = c;
+    }
+    int64_t tot = 0;
+    for (int i = 0; i < nL; i++)
+    {
+        row_ptr[i] = (int32_t)tot;
+        tot += cnt[i];
+    }
+    row_ptr[nL] = (int32_t)tot;
+    *n_pairs = tot;
+    free(cnt);
+    if (tot > cap || !col_idx)
+        return tot > cap ? -1 : 0;
+#pragma omp parallel for schedule(dynamic, 16) num_threads(nthreads)
+    for (int i = 0; i < nL; i++)
+    {
+        int32_t o = row_ptr[i];
+        for (int k = 0; k < nR; k++) /* ascending right index, :95-106 */
+            if (pair_passes(&L[i], &R[k], lines + (size_t)i * 3, epi_thr, max_disp, orient_thr_deg, stage_mask))
+                col_idx[o++] = k;
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* Patch sampling + NCC                                                                  */
+/* ------------------------------------------------------------------------------------ */
+
+/* include/utility.h:81-104 on a u8 image viewed as doubles (convertTo(CV_64F) is exact).
+ * NaN when a corner is outside the image (:95-99) or a coordinate is an exact integer (0/0). */
+static double bilinear_nan(const uint8_t *img, int rows, int cols, ptrdiff_t stride, double x, double y)
+{
+    const double x1 = floor(x), x2 = ceil(x); /* Q11.x / Q21.x */
+    const double yc = ceil(y), yf = floor(y); /* Q11.y (= "y1") / Q12.y (= "y2") */
+    if (x1 < 0 || yc < 0 || x2 >= cols || yc >= rows || yf < 0 || !(x == x) || !(y == y))
+        return NAN;
+    const double I11 = img[(ptrdiff_t)yc * stride + (ptrdiff_t)x1];
+    const double I21 = img[(ptrdiff_t)yc * stride + (ptrdiff_t)x2];
+    const double I12 = img[(ptrdiff_t)yf * stride + (ptrdiff_t)x1];
+    const double I22 = img[(ptrdiff_t)yf * stride + (ptrdiff_t)x2];
+    const double f1 = ((x2 - x) / (x2 - x1)) * I11 + ((x - x1) / (x2 - x1)) * I21; /* :101 */
+    const double f2 = ((x2 - x) / (x2 - x1)) * I12 + ((x - x1) / (x2 - x1)) * I22; /* :102 */
+    return ((yf - y) / (yf - yc)) * f1 + ((y - yc) / (yf - yc)) * f2;               /* :103 */
+}
+
+/* One edge -> (plus, minus) patches, row-major 7x7 floats.
+ * src/utility.cpp:82-93 (centres), :141-161 (rotated grid, i = row offset outer, j = column
+ * offset inner), :206-209 (double -> float). */
+static void edge_patches_one(const uint8_t *img, int rows, int cols, ptrdiff_t stride, const orc_edge *e,
+                             int math_mode, float *out /* 2 x 49 */)
+{
+    double sn, cs;
+    if (math_mode == ORC_MATH_LIBM)
+    {
+        sn = sin(e->theta);
+        cs = cos(e->theta);
+    }
+    else
+        ebvo_sincos(e->theta, &sn, &cs);
+    const double cx[2] = {e->x + 5 * (sn), e->x + 5 * (-sn)};
+    const double cy[2] = {e->y + 5 * (-cs), e->y + 5 * (cs)};
+    for (int side = 0; side < 2; side++)
+        for (int i = -3; i <= 3; i++)
+            for (int j = -3; j <= 3; j++)
+            {
+                const double x = cs * (i)-sn * (j) + cx[side];
+                const double y = sn * (i) + cs * (j) + cy[side];
+                out[side * 49 + (i + 3) * 7 + (j + 3)] = (float)bilinear_nan(img, rows, cols, stride, x, y);
+            }
+}
+
+void orc_edge_patches(const uint8_t *img, int h, int w, ptrdiff_t stride, const orc_edge *edges, int n,
+                      int math_mode, int nthreads, float *patches)
+{
+    if (nthreads <= 0)
+        nthreads = omp_get_num_procs();
+#pragma omp parallel for schedule(static) num_threads(nthreads)
+    for (int k = 0; k < n; k++)
+        edge_patches_one(img, h, w, stride, &edges[k], math_mode, patches + (size_t)k * 98);
+}
+
+/* canonical 49-term reduction (see file header) */
+static double reduce49(const double t[49])
+{
+    double s[8];
+    for (int r = 0; r < 7; r++)
+    {
+        double a = t[r * 7];
+        for (int c = 1; c < 7; c++)
+            a += t[r * 7 + c];
+        s[r] = a;
+    }
+    s[7] = 0.0;
+    return ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+}
+
+/* mean-centred patch d (float) and its sum of squares, src/utility.cpp:165-168 */
+static double centre49(const float *p, float d[49])
+{
+    double t[49];
+    for (int k = 0; k < 49; k++)
+        t[k] = (double)p[k];
+    const double mean = reduce49(t) / 49.0;
+    const float m = (float)mean;
+    for (int k = 0; k < 49; k++)
+    {
+        d[k] = p[k] - m;
+        const float q = d[k] * d[k];
+        t[k] = (double)q;
+    }
+    return reduce49(t);
+}
+
+/* src/utility.cpp:163-180 */
+double orc_patch_similarity(const float *a, const float *b)
+{
+    float da[49], db[49];
+    const double ssa = centre49(a, da), ssb = centre49(b, db);
+    if (ssa < 1e-10 || ssb < 1e-10) /* :170-172, false for NaN */
+        return -1.0;
+    const float ia = (float)(1.0 / sqrt(ssa)), ib = (float)(1.0 / sqrt(ssb));
+    double t[49];
+    for (int k = 0; k < 49; k++)
+    {
+        const float na = da[k] * ia, nb = db[k] * ib;
+        t[k] = (double)na * (double)nb;
+    }
+    return reduce49(t);
+}
+
+void orc_ncc_patches(const float *A, const float *B, int n, int nthreads, double *sim)
+{
+    if (nthreads <= 0)
+        nthreads = omp_get_num_procs();
+#pragma omp parallel for schedule(static) num_threads(nthreads)
+    for (int k = 0; k < n; k++)
+        sim[k] = orc_patch_similarity(A + (size_t)k * 49, B + (size_t)k * 49);
+}
+
+/* std::max({a, b, c, d}): first maximum under operator<, NaN-transparent as in libstdc++ */
+static double max4(double a, double b, double c, double d)
+{
+    double m = a;
+    if (m < b) m = b;
+    if (m < c) m = c;
+    if (m < d) m = d;
+    return m;
+}
+
+/* src/Stereo_Matches.cpp:573-615 */
+void orc_ncc_pairs(const uint8_t *imgL, const uint8_t *imgR, int h, int w, ptrdiff_t strideL,
+                   ptrdiff_t strideR, const orc_edge *L, int nL, const orc_edge *Rc,
+                   const int32_t *row_ptr, int math_mode, int nthreads, double thr,
+                   float *left_patches, double *sims, double *best, uint8_t *keep)
+{
+    if (nthreads <= 0)
+        nthreads = omp_get_num_procs();
+#pragma omp parallel for schedule(dynamic, 64) num_threads(nthreads)
+    for (int i = 0; i < nL; i++)
+    {
+        float lp[98], rp[98];
+        edge_patches_one(imgL, h, w, strideL, &L[i], math_mode, lp); /* :578 */
+        if (left_patches)
+            memcpy(left_patches + (size_t)i * 98, lp, sizeof lp);
+        for (int32_t k = row_ptr[i]; k < row_ptr[i + 1]; k++)
+        {
+            edge_patches_one(imgR, h, w, strideR, &Rc[k], math_mode, rp); /* :589 */
+            const double pp = orc_patch_similarity(lp, rp);                /* :592-595 */
+            const double nn = orc_patch_similarity(lp + 49, rp + 49);
+            const double pn = orc_patch_similarity(lp, rp + 49);
+            const double npv = orc_patch_similarity(lp + 49, rp);
+            const double b = max4(pp, nn, pn, npv); /* :596 */
+            if (sims)
+            {
+                sims[(size_t)k * 4 + 0] = pp;
+                sims[(size_t)k * 4 + 1] = nn;
+                sims[(size_t)k * 4 + 2] = pn;
+                sims[(size_t)k * 4 + 3] = npv;
+            }
+            if (best) best[k] = b;
+            if (keep) keep[k] = b > thr; /* :597 */
+        }
+    }
+}
+
+/* src/Temporal_Matches.cpp:440-452 */
+void orc_ncc_quads(const float *kfL, const float *kfR, const float *cfL, const float *cfR, int n,
+                   int nthreads, double thr, double *sim_left, double *sim_right, uint8_t *keep)
+{
+    if (nthreads <= 0)
+        nthreads = omp_get_num_procs();
+#pragma omp parallel for schedule(dynamic, 64) num_threads(nthreads) /* :426 */
+    for (int k = 0; k < n; k++)
+    {
+        const float *a = kfL + (size_t)k * 98, *b = cfL + (size_t)k * 98;
+        const double sl = max4(orc_patch_similarity(a, b), orc_patch_similarity(a, b + 49),
+                               orc_patch_similarity(a + 49, b), orc_patch_similarity(a + 49, b + 49));
+        a = kfR + (size_t)k * 98;
+        b = cfR + (size_t)k * 98;
+        const double sr = max4(orc_patch_similarity(a, b), orc_patch_similarity(a, b + 49),
+                               orc_patch_similarity(a + 49, b), orc_patch_similarity(a + 49, b + 49));
+        sim_left[k] = sl;
+        sim_right[k] = sr;
+        if (keep) keep[k] = (sl > thr && sr > thr);
+    }
+}
+
+void orc_atan2_v(const double *y, const double *x, int n, int math_mode, double *out)
+{
+    for (int k = 0; k < n; k++)
+        out[k] = math_mode == ORC_MATH_LIBM ? atan2(y[k], x[k]) : ebvo_atan2(y[k], x[k]);
+}
+
+void orc_sincos_v(const double *t, int n, int math_mode, double *s, double *c)
+{
+    for (int k = 0; k < n; k++)
+    {
+        if (math_mode == ORC_MATH_LIBM)
+        {
+            s[k] = sin(t[k]);
+            c[k] = cos(t[k]);
+        }
+        else
+            ebvo_sincos(t[k], &s[k], &c[k]);
+    }
+}
+
+uint64_t orc_fnv1a64(const uint8_t *b, size_t n)
+{
+    uint64_t h = 1469598103934665603ull;
+    for (size_t k = 0; k < n; k++)
+    {
+        h ^= b[k];
+        h *= 1099511628211ull;
+    }
+    return h;
+}
+
+uint64_t orc_edge_hash(const orc_edge *e, int n, int with_theta)
+{
+    uint64_t h = 1469598103934665603ull;
+    for (int k = 0; k < n; k++)
+    {
+        const uint8_t *b = (const uint8_t *)&e[k];
+        const int nb = with_theta ? 24 : 16;
+        for (int t = 0; t < nb; t++)
+        {
+            h ^= b[t];
+            h *= 1099511628211ull;
+        }
+        h ^= (uint64_t)(int64_t)e[k].index;
+        h *= 1099511628211ull;
+    }
+    return h;
+}

@@ -1,0 +1,105 @@
+/*
+ * ebvo_oracle.h -- CPU restatement of the reference hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+ * library; the product (edge_based_visual_odometry_amd/) never does.
+ *
+ * Every function cites the file:line of Brown-LEMS/Edge_Based_Visual_Odometry it follows.
+ * Parity pin: the TOED restatement reproduces, in math_mode = ORC_MATH_LIBM, every
+ * known-answer hash recorded from the unmodified reference source in SURVEY.md section 8(c)
+ * (tests/test_oracle_kat.py); the NCC restatement reproduces the reference fixture
+ * test/ncc_debug_frame1_edge8 (tests/test_oracle_ncc_fixture.py) to its 8-bit precision.
+ */
+#ifndef EBVO_ORACLE_H
+#define EBVO_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Same layout as ebvo_edge in include/ebvo_hip.h (struct Edge, include/toed/cpu_toed.hpp:26-48). */
+typedef struct
+{
+    double x, y, theta;
+    int32_t index;
+    int32_t pad;
+} orc_edge;
+
+enum
+{
+    ORC_MATH_PORTABLE = 0, /* csrc/ebvo_math.h atan2 / sincos: bit-identical to the HIP path */
+    ORC_MATH_LIBM = 1      /* glibc atan2 / sin / cos, exactly what the reference calls */
+};
+
+enum
+{
+    ORC_STAGE_EPIPOLAR = 1,
+    ORC_STAGE_DISPARITY = 2,
+    ORC_STAGE_ORIENTATION = 4,
+    ORC_STAGE_ALL = 7
+};
+
+/*
+ * Third-order edge detection of one H x W u8 image.
+ *   kept/cap_kept   : edges inside the 10-px border, Edge::index = position (may be NULL to count only)
+ *   all4/cap_all    : every NMS maximum as (x, y, theta, subpixel magnitude) rows (may be NULL)
+ *   maps            : optional 5 planes of 2H x 2W doubles: Ix, Iy, |grad|, TOx/|TO|, TOy/|TO|
+ *   t_conv, t_nms   : seconds (may be NULL)
+ * Returns 0, or -1 if a capacity is too small (n_kept / n_total still hold the required sizes).
+ */
+int orc_toed(const uint8_t *img, int h, int w, ptrdiff_t stride, int math_mode, int nthreads,
+             orc_edge *kept, int cap_kept, double *all4, int cap_all, int *n_kept, int *n_total,
+             double *maps, double *t_conv, double *t_nms);
+
+/* l = F * (x, y, 1) for each edge; F row-major 3x3; lines = n x 3. */
+void orc_epipolar_lines(const double *F, const orc_edge *edges, int n, double *lines);
+
+/*
+ * Candidate search + geometric filters, brute force exactly as the reference.
+ * row_ptr has nL + 1 entries; col_idx receives right indices in ascending order per row.
+ * Returns 0, or -1 if cap is too small (*n_pairs = required size).
+ */
+int orc_epi_candidates(const orc_edge *L, int nL, const orc_edge *R, int nR, const double *lines,
+                       double epi_thr, double max_disp, double orient_thr_deg, int stage_mask,
+                       int nthreads, int32_t *row_ptr, int32_t *col_idx, int64_t cap, int64_t *n_pairs);
+
+/* (plus, minus) 7x7 float patches of n edges: patches = n x 2 x 49. */
+void orc_edge_patches(const uint8_t *img, int h, int w, ptrdiff_t stride, const orc_edge *edges, int n,
+                      int math_mode, int nthreads, float *patches);
+
+/* NCC of two 7x7 float patches (canonical arithmetic, see ebvo_oracle.c). */
+double orc_patch_similarity(const float *a, const float *b);
+
+/* NCC over explicit pairs of stored patches: sim[k] = ncc(A[k], B[k]). */
+void orc_ncc_patches(const float *A, const float *B, int n, int nthreads, double *sim);
+
+/*
+ * Stereo NCC scoring: for CSR rows i (left edge L[i]) and pairs k in [row_ptr[i], row_ptr[i+1]),
+ * candidate edge Rc[k] (explicit edges).  sims = n_pairs x 4 (pp, nn, pn, np), best = n_pairs,
+ * keep[k] = best > thr.  left_patches (nL x 2 x 49 floats) may be NULL.
+ */
+void orc_ncc_pairs(const uint8_t *imgL, const uint8_t *imgR, int h, int w, ptrdiff_t strideL,
+                   ptrdiff_t strideR, const orc_edge *L, int nL, const orc_edge *Rc,
+                   const int32_t *row_ptr, int math_mode, int nthreads, double thr,
+                   float *left_patches, double *sims, double *best, uint8_t *keep);
+
+/* Temporal quad scorer: left = max of 4, right = max of 4 over stored patches (n x 2 x 49 each). */
+void orc_ncc_quads(const float *kfL, const float *kfR, const float *cfL, const float *cfR, int n,
+                   int nthreads, double thr, double *sim_left, double *sim_right, uint8_t *keep);
+
+/* element-wise math in the chosen mode (for tests of ebvo_math.h) */
+void orc_atan2_v(const double *y, const double *x, int n, int math_mode, double *out);
+void orc_sincos_v(const double *t, int n, int math_mode, double *s, double *c);
+
+/* FNV-1a-64 helpers used by the known-answer tests. */
+uint64_t orc_fnv1a64(const uint8_t *bytes, size_t n);
+/* with_theta != 0: "xy-theta-i" hash (24 raw bytes + index); else "xyi" (16 raw bytes + index). */
+uint64_t orc_edge_hash(const orc_edge *e, int n, int with_theta);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
