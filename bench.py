@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""bench.py -- stereo pairs/s of the edge-extraction-and-matching hot path on MI355X.
+
+A "step" is one pass of the whole hot path over one synthetic KITTI-shaped stereo pair that is
+already resident in HBM: TOED(left) + TOED(right) + epipolar/disparity/orientation candidate
+search + NCC scoring (ebvo_stereo_run).  One process per GPU, one sequence per GPU, no
+collective on the data path (torch.distributed is used only for the barrier and the max over
+ranks of the timed region).
+
+Prints ONE JSON line on rank 0 (see the contract in the task description): metric/value/unit,
+ms_per_step, `roofline` for the dominant kernel (toed_conv) measured live with HIP events on the
+library's own stream, and `cpu_baseline` (the CPU oracle timed on this box's host cores, N=1).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from edge_based_visual_odometry_amd import synth  # noqa: E402
+from edge_based_visual_odometry_amd.api import Context  # noqa: E402
+
+H, W = synth.SHAPES["kitti"]
+TOED_FLOPS_PER_PX = 37044            # 1,372 taps x 9 responses x 3 flops, as written in the reference
+HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: HBM3E spec
+FP64_VALU_PEAK_NOFMA_TF = 39.3       # 78.6 TFLOP/s vendor FP64 vector peak (FMA) / 2: mul and add are separate ops
+
+
+def algorithmic_bytes_per_pair(n_left, n_right, n_pairs):
+    """SURVEY.md 8(d) 'Algorithmic bytes': 2P (u8 images in) + 32(NL+NR) edges out + 32(NL+NR)
+    edges into matching + 8 Npairs (CSR) + 40 Npairs (4 sims + best)."""
+    return 2 * H * W + 64 * (n_left + n_right) + 48 * n_pairs
+
+
+def cpu_baseline(left, right, F):
+    """The CPU oracle (a port of the reference's path) on this box's host cores; bounded sample."""
+    from tests import oracle as orc
+    cores = os.cpu_count() or 1
+    t0 = time.perf_counter()
+    rl = orc.toed(left, math_mode=orc.LIBM)
+    rr = orc.toed(right, math_mode=orc.LIBM)
+    t_toed = time.perf_counter() - t0
+    L, R = rl["edges"], rr["edges"]
+    stride = 16                                      # brute force is O(NL*NR): 1/16 of the left edges, scaled
+    Ls = L[::stride]
+    lines = orc.epipolar_lines(F, Ls)
+    t0 = time.perf_counter()
+    rp, ci = orc.epi_candidates(Ls, R, lines)
+    t_cand = (time.perf_counter() - t0) * stride
+    t0 = time.perf_counter()
+    orc.ncc_pairs(left, right, Ls, R[ci], rp, math_mode=orc.LIBM)
+    t_ncc = (time.perf_counter() - t0) * stride
+    total = t_toed + t_cand + t_ncc
+    return {
+        "value": 1.0 / total, "unit": "stereo pairs/s", "cores": cores, "kind": "port",
+        "sample": (f"oracle/ (C + OpenMP restatement, -O2 no FMA, {cores} threads) on the same 1241x376 S2 pair: "
+                   f"TOED both images {t_toed:.2f}s; candidate search + NCC on every {stride}th left edge, scaled x{stride}: "
+                   f"{t_cand:.2f}s + {t_ncc:.2f}s (the reference runs NCC and the disparity filter serially; "
+                   f"the port uses all cores)"),
+        "seconds_per_pair": total,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    import torch
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    # one sequence per GPU: its own scene and noise seeds
+    left, right = synth.stereo_pair("s2", H, W, scene=7 + rank, noise_base=100 * rank, disparity=12)
+    cal = synth.CALIB["kitti"]
+    F = synth.fundamental_21(cal["K"], cal["K"], cal["R21"], cal["T21"])
+
+    ctx = Context(H, W, device=local_rank)
+    ctx.stereo_upload(left, right)
+    params = ctx.default_params(F)
+    for _ in range(args.warmup):
+        counts = ctx.stereo_run(params)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    ctx.profile_reset()
+    ctx.profile_enable(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        counts = ctx.stereo_run(params)          # synchronous: returns after the last kernel of the pair
+    barrier()
+    dt = time.perf_counter() - t0
+    ctx.profile_enable(False)
+    prof = ctx.profile_get()
+
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        conv_ms, conv_n = prof["toed_conv"]
+        conv_avg_s = conv_ms * 1e-3 / max(1, conv_n)
+        alg_bytes = algorithmic_bytes_per_pair(counts.n_left, counts.n_right, counts.n_pairs)
+        achieved_gbs = alg_bytes / conv_avg_s / 1e9
+        conv_tf = 2 * H * W * TOED_FLOPS_PER_PX / conv_avg_s / 1e12
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "conv_pmc.json")
+        if os.path.exists(pmc_path):
+            traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
+        kernels = {k: {"ms_per_step": v[0] / args.steps, "launches_per_step": v[1] / args.steps}
+                   for k, v in prof.items() if v[1]}
+        out = {
+            "metric": "stereo pairs/sec (TOED+NCC match) on KITTI 1241x376; achieved HBM GB/s",
+            "value": world * args.steps / dt,
+            "unit": "stereo pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "configs[1]: single KITTI-shaped stereo pair 1241x376 (generator S2, scene 7+rank, "
+                                   "12 px disparity), TOED both images (strict direct-form fp64, no FMA) + epipolar/"
+                                   "disparity/orientation candidate search + NCC, resident in HBM, replayed",
+                       "edges_left": counts.n_left, "edges_right": counts.n_right,
+                       "candidate_pairs": counts.n_pairs, "ncc_matches": counts.n_matches,
+                       "parallelism": f"{world} independent sequence(s), one per GPU, no collective"},
+            "roofline": {"bound": "hbm", "kernel": "toed_conv_kernel", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": conv_avg_s * 1e3,
+                         "note": "this path is FP64-VALU-bound, not HBM-bound (SURVEY.md 8(d)); see roofline_fp64"},
+            "roofline_fp64": {"bound": "valu_fp64_no_fma", "kernel": "toed_conv_kernel", "achieved": conv_tf,
+                              "peak": FP64_VALU_PEAK_NOFMA_TF, "unit": "TFLOP/s", "frac": conv_tf / FP64_VALU_PEAK_NOFMA_TF,
+                              "flops_per_launch": 2 * H * W * TOED_FLOPS_PER_PX,
+                              "note": "flops counted as the reference writes them (37,044/px); peak = 78.6/2"},
+            "kernels": kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(left, right, F)
+            out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

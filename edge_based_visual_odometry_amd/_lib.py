@@ -1,0 +1,115 @@
+"""ctypes binding of the C ABI in include/ebvo_hip.h (libebvo_hip.so, built in-tree by hipcc).
+
+There is no CPU fallback: if the shared library is missing this module raises, and if no HIP
+device is usable ``ebvo_ctx_create`` fails and :class:`EbvoError` is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libebvo_hip.so")
+
+EDGE_DTYPE = np.dtype([("x", "<f8"), ("y", "<f8"), ("theta", "<f8"), ("index", "<i4"), ("pad", "<i4")])
+assert EDGE_DTYPE.itemsize == 32
+
+EBVO_OK = 0
+EBVO_ERR_ARG = -1
+EBVO_ERR_CAPACITY = -2
+EBVO_ERR_HIP = -3
+EBVO_ERR_NOMEM = -4
+EBVO_ERR_STATE = -5
+
+STAGE_EPIPOLAR = 1
+STAGE_DISPARITY = 2
+STAGE_ORIENTATION = 4
+STAGE_ALL = 7
+
+MAX_KERNELS = 16
+
+# every symbol include/ebvo_hip.h declares (checked by tests/test_abi_symbols.py)
+ABI_SYMBOLS = (
+    "ebvo_strerror", "ebvo_last_error", "ebvo_abi_version", "ebvo_ctx_create", "ebvo_ctx_destroy",
+    "ebvo_toed", "ebvo_toed_pair", "ebvo_epipolar_lines", "ebvo_epi_candidates", "ebvo_ncc_pairs",
+    "ebvo_edge_patches", "ebvo_ncc_patches", "ebvo_ncc_quads", "ebvo_stereo_default_params",
+    "ebvo_stereo_upload", "ebvo_stereo_run", "ebvo_stereo_fetch", "ebvo_profile_enable",
+    "ebvo_profile_reset", "ebvo_profile_get", "ebvo_fp64_peak",
+)
+
+
+class StereoParams(C.Structure):
+    _fields_ = [("F21", C.c_double * 9), ("epi_thr", C.c_double), ("max_disp", C.c_double),
+                ("orient_thr_deg", C.c_double), ("ncc_thr", C.c_double), ("stage_mask", C.c_int),
+                ("reserved", C.c_int)]
+
+
+class StereoCounts(C.Structure):
+    _fields_ = [("n_left", C.c_int32), ("n_right", C.c_int32), ("n_total_left", C.c_int32),
+                ("n_total_right", C.c_int32), ("n_pairs", C.c_int64), ("n_matches", C.c_int64)]
+
+
+class KernelTime(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("ms", C.c_double), ("launches", C.c_int64)]
+
+
+class EbvoError(RuntimeError):
+    def __init__(self, status: int, where: str, detail: str = ""):
+        self.status = status
+        super().__init__(f"{where}: status {status}" + (f" ({detail})" if detail else ""))
+
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """dlopen libebvo_hip.so (raises if it was not built) and declare the prototypes."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with __graft_entry__.build() or "
+            "`make -C edge_based_visual_odometry_amd/csrc` (hipcc --offload-arch=gfx950). "
+            "There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64, dbl = C.c_void_p, C.c_int, C.c_int64, C.c_double
+    ssz = C.c_ssize_t
+    lib.ebvo_strerror.restype = C.c_char_p
+    lib.ebvo_strerror.argtypes = [i32]
+    lib.ebvo_last_error.restype = C.c_char_p
+    lib.ebvo_last_error.argtypes = [vp]
+    lib.ebvo_abi_version.restype = i32
+    lib.ebvo_ctx_create.argtypes = [i32, i32, i32, C.POINTER(vp)]
+    lib.ebvo_ctx_destroy.restype = None
+    lib.ebvo_ctx_destroy.argtypes = [vp]
+    lib.ebvo_toed.argtypes = [vp, vp, i32, i32, ssz, vp, i32, C.POINTER(i32), C.POINTER(i32), vp, i32,
+                              C.POINTER(dbl), C.POINTER(dbl)]
+    lib.ebvo_toed_pair.argtypes = [vp, vp, vp, i32, i32, ssz, ssz, vp, vp, i32, C.POINTER(i32), C.POINTER(i32)]
+    lib.ebvo_epipolar_lines.argtypes = [vp, vp, i32, vp]
+    lib.ebvo_epi_candidates.argtypes = [vp, vp, i32, vp, i32, vp, dbl, dbl, dbl, i32, vp, vp, i64,
+                                        C.POINTER(i64)]
+    lib.ebvo_ncc_pairs.argtypes = [vp, vp, vp, i32, i32, ssz, ssz, vp, i32, vp, vp, dbl, vp, vp, vp, vp]
+    lib.ebvo_edge_patches.argtypes = [vp, vp, i32, i32, ssz, vp, i32, vp]
+    lib.ebvo_ncc_patches.argtypes = [vp, vp, vp, i32, vp]
+    lib.ebvo_ncc_quads.argtypes = [vp, vp, vp, vp, vp, i32, dbl, vp, vp, vp]
+    lib.ebvo_stereo_default_params.restype = None
+    lib.ebvo_stereo_default_params.argtypes = [C.POINTER(StereoParams)]
+    lib.ebvo_stereo_upload.argtypes = [vp, vp, vp, i32, i32, ssz, ssz]
+    lib.ebvo_stereo_run.argtypes = [vp, C.POINTER(StereoParams), C.POINTER(StereoCounts)]
+    lib.ebvo_stereo_fetch.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.ebvo_profile_enable.argtypes = [vp, i32]
+    lib.ebvo_profile_reset.argtypes = [vp]
+    lib.ebvo_profile_get.argtypes = [vp, C.POINTER(KernelTime), C.POINTER(i32)]
+    lib.ebvo_fp64_peak.argtypes = [vp, i32, C.POINTER(dbl), C.POINTER(dbl)]
+    _lib = lib
+    return lib
+
+
+def ptr(a):
+    """void* of a numpy array (None -> NULL)."""
+    if a is None:
+        return None
+    return a.ctypes.data_as(C.c_void_p)

@@ -1,0 +1,225 @@
+"""Thin Python view of the C ABI, used by the tests and by bench.py.
+
+The product's host side is C++ (include/ebvo/*.hpp adapters mirroring the reference classes);
+this module only marshals numpy arrays to the same entry points, so that the parity tests read
+like calls to the reference: ``get_Third_Order_Edges``, ``apply_NCC_Filtering`` ...
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib
+from ._lib import EDGE_DTYPE, EbvoError, StereoCounts, StereoParams, ptr
+
+
+def _u8(img: np.ndarray) -> np.ndarray:
+    if img.dtype != np.uint8 or img.ndim != 2:
+        raise TypeError("image must be a 2-D uint8 array (CV_8UC1)")
+    if img.strides[1] != 1:
+        img = np.ascontiguousarray(img)
+    return img
+
+
+def _edges(e: np.ndarray) -> np.ndarray:
+    return np.ascontiguousarray(e, dtype=EDGE_DTYPE)
+
+
+@dataclass
+class ToedResult:
+    edges: np.ndarray      # EDGE_DTYPE, toed_edges
+    n_total: int           # Total_Num_Of_TOED
+    all4: np.ndarray | None  # subpix_edge_pts_final rows (x, y, theta, mag)
+    time_conv: float
+    time_nms: float
+
+
+class Context:
+    """One HIP device workspace (``ebvo_ctx``).  Not thread-safe; one per process and GPU."""
+
+    def __init__(self, max_h: int, max_w: int, device: int = 0):
+        self.lib = _lib.load_library()
+        self._ctx = C.c_void_p()
+        rc = self.lib.ebvo_ctx_create(device, max_h, max_w, C.byref(self._ctx))
+        if rc != 0:
+            raise EbvoError(rc, "ebvo_ctx_create", self.lib.ebvo_strerror(rc).decode())
+        self.max_h, self.max_w, self.device = max_h, max_w, device
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self.lib.ebvo_ctx_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc: int, where: str):
+        if rc != 0:
+            raise EbvoError(rc, where, self.lib.ebvo_strerror(rc).decode() + "; " +
+                            self.lib.ebvo_last_error(self._ctx).decode())
+
+    # -- ThirdOrderEdgeDetectionCPU::get_Third_Order_Edges ---------------------------------
+    def toed(self, img: np.ndarray, want_all: bool = False, cap: int | None = None) -> ToedResult:
+        img = _u8(img)
+        h, w = img.shape
+        cap = h * w if cap is None else cap
+        out = np.zeros(cap, dtype=EDGE_DTYPE)
+        all4 = np.zeros((cap, 4), dtype=np.float64) if want_all else None
+        nk, nt = C.c_int(), C.c_int()
+        tc, tn = C.c_double(), C.c_double()
+        rc = self.lib.ebvo_toed(self._ctx, ptr(img), h, w, img.strides[0], ptr(out), cap, C.byref(nk),
+                                C.byref(nt), ptr(all4), cap if want_all else 0, C.byref(tc), C.byref(tn))
+        if rc == _lib.EBVO_ERR_CAPACITY:
+            raise EbvoError(rc, f"ebvo_toed (need kept={nk.value}, total={nt.value})")
+        self._check(rc, "ebvo_toed")
+        return ToedResult(out[: nk.value].copy(), nt.value,
+                          all4[: nt.value].copy() if want_all else None, tc.value, tn.value)
+
+    def toed_pair(self, left: np.ndarray, right: np.ndarray):
+        left, right = _u8(left), _u8(right)
+        h, w = left.shape
+        assert right.shape == (h, w)
+        cap = h * w
+        ol, orr = np.zeros(cap, dtype=EDGE_DTYPE), np.zeros(cap, dtype=EDGE_DTYPE)
+        nk, nt = (C.c_int * 2)(), (C.c_int * 2)()
+        rc = self.lib.ebvo_toed_pair(self._ctx, ptr(left), ptr(right), h, w, left.strides[0], right.strides[0],
+                                     ptr(ol), ptr(orr), cap, nk, nt)
+        self._check(rc, "ebvo_toed_pair")
+        return ol[: nk[0]].copy(), orr[: nk[1]].copy(), (nt[0], nt[1])
+
+    # -- Stereo_Matches::CalculateEpipolarLine ----------------------------------------------
+    def epipolar_lines(self, F: np.ndarray, edges: np.ndarray) -> np.ndarray:
+        F = np.ascontiguousarray(F, dtype=np.float64).reshape(9)
+        edges = _edges(edges)
+        lines = np.zeros((len(edges), 3), dtype=np.float64)
+        self._check(self.lib.ebvo_epipolar_lines(ptr(F), ptr(edges), len(edges), ptr(lines)), "ebvo_epipolar_lines")
+        return lines
+
+    # -- apply_Epipolar_Line_Distance_Filtering / Disparity / orientation -------------------
+    def epi_candidates(self, L, R, lines, epi_thr=0.5, max_disp=25.0, orient_thr_deg=10.0,
+                       stage_mask=_lib.STAGE_ALL):
+        L, R = _edges(L), _edges(R)
+        lines = np.ascontiguousarray(lines, dtype=np.float64).reshape(-1, 3)
+        assert len(lines) == len(L)
+        row_ptr = np.zeros(len(L) + 1, dtype=np.int32)
+        n = C.c_int64()
+        rc = self.lib.ebvo_epi_candidates(self._ctx, ptr(L), len(L), ptr(R), len(R), ptr(lines), epi_thr, max_disp,
+                                          orient_thr_deg, stage_mask, ptr(row_ptr), None, 0, C.byref(n))
+        self._check(rc, "ebvo_epi_candidates(size)")
+        col = np.zeros(max(1, n.value), dtype=np.int32)
+        rc = self.lib.ebvo_epi_candidates(self._ctx, ptr(L), len(L), ptr(R), len(R), ptr(lines), epi_thr, max_disp,
+                                          orient_thr_deg, stage_mask, ptr(row_ptr), ptr(col), len(col), C.byref(n))
+        self._check(rc, "ebvo_epi_candidates")
+        return row_ptr, col[: n.value].copy()
+
+    # -- Stereo_Matches::apply_NCC_Filtering --------------------------------------------------
+    def ncc_pairs(self, imgL, imgR, L, Rc, row_ptr, thr=0.6, want_left_patches=False):
+        imgL, imgR = _u8(imgL), _u8(imgR)
+        h, w = imgL.shape
+        L, Rc = _edges(L), _edges(Rc)
+        row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int32)
+        npairs = int(row_ptr[-1]) if len(row_ptr) else 0
+        assert len(Rc) == npairs
+        sims = np.zeros((npairs, 4), dtype=np.float64)
+        best = np.zeros(npairs, dtype=np.float64)
+        keep = np.zeros(npairs, dtype=np.uint8)
+        lp = np.zeros((len(L), 2, 49), dtype=np.float32) if want_left_patches else None
+        rc = self.lib.ebvo_ncc_pairs(self._ctx, ptr(imgL), ptr(imgR), h, w, imgL.strides[0], imgR.strides[0], ptr(L),
+                                     len(L), ptr(Rc), ptr(row_ptr), thr, ptr(lp), ptr(sims), ptr(best), ptr(keep))
+        self._check(rc, "ebvo_ncc_pairs")
+        return sims, best, keep, lp
+
+    # -- Utility::get_edge_patches ------------------------------------------------------------
+    def edge_patches(self, img, edges) -> np.ndarray:
+        img = _u8(img)
+        h, w = img.shape
+        edges = _edges(edges)
+        out = np.zeros((len(edges), 2, 49), dtype=np.float32)
+        self._check(self.lib.ebvo_edge_patches(self._ctx, ptr(img), h, w, img.strides[0], ptr(edges), len(edges),
+                                               ptr(out)), "ebvo_edge_patches")
+        return out
+
+    # -- Utility::get_patch_similarity / MatlabNCCComputer::computeNCC -----------------------
+    def ncc_patches(self, A, B) -> np.ndarray:
+        A = np.ascontiguousarray(A, dtype=np.float32).reshape(-1, 49)
+        B = np.ascontiguousarray(B, dtype=np.float32).reshape(-1, 49)
+        assert A.shape == B.shape
+        sim = np.zeros(len(A), dtype=np.float64)
+        self._check(self.lib.ebvo_ncc_patches(self._ctx, ptr(A), ptr(B), len(A), ptr(sim)), "ebvo_ncc_patches")
+        return sim
+
+    # -- Temporal_Matches::apply_NCC_filtering_quads ------------------------------------------
+    def ncc_quads(self, kfL, kfR, cfL, cfR, thr=0.8):
+        arrs = [np.ascontiguousarray(a, dtype=np.float32).reshape(-1, 98) for a in (kfL, kfR, cfL, cfR)]
+        n = len(arrs[0])
+        sl, sr = np.zeros(n), np.zeros(n)
+        keep = np.zeros(n, dtype=np.uint8)
+        self._check(self.lib.ebvo_ncc_quads(self._ctx, *[ptr(a) for a in arrs], n, thr, ptr(sl), ptr(sr), ptr(keep)),
+                    "ebvo_ncc_quads")
+        return sl, sr, keep
+
+    # -- device-resident pipeline --------------------------------------------------------------
+    def default_params(self, F21=None) -> StereoParams:
+        p = StereoParams()
+        self.lib.ebvo_stereo_default_params(C.byref(p))
+        if F21 is not None:
+            F = np.ascontiguousarray(F21, dtype=np.float64).reshape(9)
+            for k in range(9):
+                p.F21[k] = float(F[k])
+        return p
+
+    def stereo_upload(self, left, right):
+        left, right = _u8(left), _u8(right)
+        h, w = left.shape
+        assert right.shape == (h, w)
+        self._check(self.lib.ebvo_stereo_upload(self._ctx, ptr(left), ptr(right), h, w, left.strides[0],
+                                                right.strides[0]), "ebvo_stereo_upload")
+
+    def stereo_run(self, params: StereoParams) -> StereoCounts:
+        c = StereoCounts()
+        self._check(self.lib.ebvo_stereo_run(self._ctx, C.byref(params), C.byref(c)), "ebvo_stereo_run")
+        return c
+
+    def stereo_fetch(self, counts: StereoCounts, patches: bool = False):
+        nL, nR, npairs = counts.n_left, counts.n_right, counts.n_pairs
+        left = np.zeros(nL, dtype=EDGE_DTYPE)
+        right = np.zeros(nR, dtype=EDGE_DTYPE)
+        row_ptr = np.zeros(nL + 1, dtype=np.int32)
+        col = np.zeros(npairs, dtype=np.int32)
+        sims = np.zeros((npairs, 4))
+        best = np.zeros(npairs)
+        keep = np.zeros(npairs, dtype=np.uint8)
+        lp = np.zeros((nL, 2, 49), dtype=np.float32) if patches else None
+        self._check(self.lib.ebvo_stereo_fetch(self._ctx, ptr(left), ptr(right), ptr(row_ptr), ptr(col), ptr(sims),
+                                               ptr(best), ptr(keep), ptr(lp)), "ebvo_stereo_fetch")
+        return dict(left=left, right=right, row_ptr=row_ptr, col_idx=col, sims=sims, best=best, keep=keep,
+                    left_patches=lp)
+
+    # -- profiling -----------------------------------------------------------------------------
+    def profile_enable(self, on: bool = True):
+        self._check(self.lib.ebvo_profile_enable(self._ctx, int(on)), "ebvo_profile_enable")
+
+    def profile_reset(self):
+        self._check(self.lib.ebvo_profile_reset(self._ctx), "ebvo_profile_reset")
+
+    def profile_get(self) -> dict:
+        arr = (_lib.KernelTime * _lib.MAX_KERNELS)()
+        n = C.c_int()
+        self._check(self.lib.ebvo_profile_get(self._ctx, arr, C.byref(n)), "ebvo_profile_get")
+        return {arr[k].name.decode(): (arr[k].ms, arr[k].launches) for k in range(n.value)}
+
+    def fp64_peak(self, iters: int = 20):
+        a, b = C.c_double(), C.c_double()
+        self._check(self.lib.ebvo_fp64_peak(self._ctx, iters, C.byref(a), C.byref(b)), "ebvo_fp64_peak")
+        return a.value, b.value

@@ -1,0 +1,793 @@
+// match_kernels.hip -- epipolar candidate search, geometric filters and NCC patch scoring on gfx950.
+//
+// Replaces, in the reference:
+//   Stereo_Matches::CalculateEpipolarLine                      src/Stereo_Matches.cpp:10-20
+//   extract_Epipolar_Edge_Indices / apply_Epipolar_Line_...    src/Stereo_Matches.cpp:91-109, :381-419
+//   apply_Disparity_Filtering / apply_orientation_filter       src/Stereo_Matches.cpp:534-553, :863-915
+//   Utility::get_edge_patches / get_patch_similarity           src/utility.cpp:182-212, :163-180
+//   Bilinear_Interpolation<double>                             include/utility.h:81-104
+//   Stereo_Matches::apply_NCC_Filtering                        src/Stereo_Matches.cpp:555-616
+//   Temporal_Matches::apply_NCC_filtering_quads (scoring)      src/Temporal_Matches.cpp:426-468
+//
+// Candidate search.  The reference scans all N_R right edges for each of the N_L left edges
+// (O(N_L * N_R) fp64 predicates).  Here the right edges are summarised by two levels of bounding
+// boxes over consecutive index ranges (32 edges per chunk, 32 chunks per group); a left edge
+// visits only the boxes that can intersect {epipolar band} ∩ {disparity square}, in index order,
+// and evaluates the reference's exact predicates on the survivors.  The boxes are a conservative
+// pre-filter only: the result (set AND order, ascending right index) is identical to the brute
+// force for any input order; TOED's raster order just makes the boxes tight.
+//
+// NCC.  16 lanes cooperate on one (left edge, candidate) pair: lanes 0-6 hold the rows of the
+// "plus" patch, lanes 8-14 the rows of the "minus" patch (lanes 7 and 15 carry +0.0).  A 49-term
+// reduction is a left-to-right row sum in each lane followed by a 3-step xor butterfly over the
+// 8 lanes -- exactly the canonical order of the CPU path (oracle/ebvo_oracle.c: reduce49).
+// Element-wise patch arithmetic is float (CV_32F), reductions are double.
+//
+// Compiled with -ffp-contract=off: no FMA anywhere.
+#include "ebvo_internal.h"
+#include "ebvo_math.h"
+
+namespace
+{
+
+constexpr int CHUNK = 32;  // edges per chunk box
+constexpr int GROUP = 32;  // chunks per group box
+constexpr double BOX_SLACK = 1e-6;
+
+struct Box
+{
+    double x0, x1, y0, y1;
+};
+
+struct CandParams
+{
+    double epi_thr, max_disp, orient_thr;
+    int mask, nL, nR, nchunks, ngroups;
+};
+
+// ------------------------------------------------------------------------------------------
+__global__ void lines_kernel(const double *__restrict__ F, const ebvo_edge *__restrict__ e, int n,
+                             double *__restrict__ lines)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n)
+        return;
+    const double x = e[k].x, y = e[k].y;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+        lines[(size_t)k * 3 + r] = (F[r * 3 + 0] * x + F[r * 3 + 1] * y) + F[r * 3 + 2];
+}
+
+__global__ void chunk_boxes_kernel(const ebvo_edge *__restrict__ R, int nR, int nchunks, Box *__restrict__ cb)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nchunks)
+        return;
+    const int k0 = c * CHUNK, k1 = min(nR, k0 + CHUNK);
+    Box b;
+    b.x0 = b.x1 = R[k0].x;
+    b.y0 = b.y1 = R[k0].y;
+    for (int k = k0 + 1; k < k1; ++k)
+    {
+        const double x = R[k].x, y = R[k].y;
+        b.x0 = fmin(b.x0, x);
+        b.x1 = fmax(b.x1, x);
+        b.y0 = fmin(b.y0, y);
+        b.y1 = fmax(b.y1, y);
+    }
+    cb[c] = b;
+}
+
+__global__ void group_boxes_kernel(const Box *__restrict__ cb, int nchunks, int ngroups, Box *__restrict__ gb)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= ngroups)
+        return;
+    const int c0 = g * GROUP, c1 = min(nchunks, c0 + GROUP);
+    Box b = cb[c0];
+    for (int c = c0 + 1; c < c1; ++c)
+    {
+        b.x0 = fmin(b.x0, cb[c].x0);
+        b.x1 = fmax(b.x1, cb[c].x1);
+        b.y0 = fmin(b.y0, cb[c].y0);
+        b.y1 = fmax(b.y1, cb[c].y1);
+    }
+    gb[g] = b;
+}
+
+// Can any point of the box satisfy the enabled epipolar / disparity predicates?  Conservative.
+__device__ inline bool box_may_match(const Box &bx, double xl, double yl, double ah, double bh, double ch,
+                                     double D, double band, int mask)
+{
+    double x0 = bx.x0, x1 = bx.x1, y0 = bx.y0, y1 = bx.y1;
+    if (mask & EBVO_STAGE_DISPARITY)
+    {
+        x0 = fmax(x0, xl - D);
+        x1 = fmin(x1, xl + D);
+        y0 = fmax(y0, yl - D);
+        y1 = fmin(y1, yl + D);
+        if (x0 > x1 || y0 > y1)
+            return false;
+    }
+    if (mask & EBVO_STAGE_EPIPOLAR)
+    {
+        const double gx0 = ah * x0, gx1 = ah * x1, gy0 = bh * y0, gy1 = bh * y1;
+        const double gmin = fmin(gx0, gx1) + fmin(gy0, gy1) + ch;
+        const double gmax = fmax(gx0, gx1) + fmax(gy0, gy1) + ch;
+        if (gmin > band || gmax < -band)
+            return false;
+    }
+    return true;
+}
+
+// The reference's predicates, in its arithmetic.
+__device__ inline bool pair_passes(double lx, double ly, double lth, double rx, double ry, double rth, double a,
+                                   double b, double c, double nrm, const CandParams &P)
+{
+    if (P.mask & EBVO_STAGE_EPIPOLAR)
+    { // src/Stereo_Matches.cpp:99-101
+        const double d = fabs(a * rx + b * ry + c) / nrm;
+        if (!(d < P.epi_thr))
+            return false;
+    }
+    if (P.mask & EBVO_STAGE_DISPARITY)
+    { // :545-546
+        const double dx = lx - rx, dy = ly - ry;
+        const double disp = sqrt(dx * dx + dy * dy);
+        if (!(disp <= P.max_disp))
+            return false;
+    }
+    if (P.mask & EBVO_STAGE_ORIENTATION)
+    { // :887-901
+        double od = fabs((lth - rth) * 0x1.ca5dc1a63c1f8p+5 /* 180.0 / M_PI */);
+        if (od > 180.0)
+            od = 360.0 - od;
+        if (!(od < P.orient_thr || fabs(od - 180.0) < P.orient_thr))
+            return false;
+    }
+    return true;
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void candidates_kernel(const ebvo_edge *__restrict__ L,
+                                                         const ebvo_edge *__restrict__ R,
+                                                         const double *__restrict__ lines,
+                                                         const Box *__restrict__ cb, const Box *__restrict__ gb,
+                                                         CandParams P, int32_t *__restrict__ cnt,
+                                                         const int32_t *__restrict__ row_ptr,
+                                                         int32_t *__restrict__ col_idx,
+                                                         unsigned long long *__restrict__ total)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.nL)
+        return;
+    const double lx = L[i].x, ly = L[i].y, lth = L[i].theta;
+    const double a = lines[(size_t)i * 3], b = lines[(size_t)i * 3 + 1], c = lines[(size_t)i * 3 + 2];
+    const double nrm = sqrt((a * a) + (b * b)); // src/Stereo_Matches.cpp:99
+    const double ah = a / nrm, bh = b / nrm, ch = c / nrm;
+    const double D = P.max_disp + BOX_SLACK, band = P.epi_thr + BOX_SLACK;
+    int n = 0;
+    int32_t o = FILL ? row_ptr[i] : 0;
+    for (int g = 0; g < P.ngroups; ++g)
+    {
+        if (!box_may_match(gb[g], lx, ly, ah, bh, ch, D, band, P.mask))
+            continue;
+        const int c1 = min(P.nchunks, (g + 1) * GROUP);
+        for (int cc = g * GROUP; cc < c1; ++cc)
+        {
+            if (!box_may_match(cb[cc], lx, ly, ah, bh, ch, D, band, P.mask))
+                continue;
+            const int k1 = min(P.nR, (cc + 1) * CHUNK);
+            for (int k = cc * CHUNK; k < k1; ++k)
+            {
+                const double rx = R[k].x, ry = R[k].y;
+                if (P.mask & EBVO_STAGE_DISPARITY)
+                    if (fabs(lx - rx) > D || fabs(ly - ry) > D)
+                        continue;
+                if (pair_passes(lx, ly, lth, rx, ry, R[k].theta, a, b, c, nrm, P))
+                {
+                    if (FILL)
+                        col_idx[o++] = k;
+                    else
+                        ++n;
+                }
+            }
+        }
+    }
+    if (!FILL)
+    {
+        cnt[i] = n;
+        // 64-bit total guards the int32 CSR offsets
+        unsigned long long s = (unsigned long long)n;
+        for (int d = 32; d > 0; d >>= 1)
+            s += __shfl_down(s, d);
+        if ((threadIdx.x & 63) == 0 && s)
+            atomicAdd(total, s);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// exclusive scan of int32 (two-level, recursive on the block sums)
+constexpr int SCAN_ITEMS = 4;
+constexpr int SCAN_BLOCK = 256;
+constexpr int SCAN_TILE = SCAN_ITEMS * SCAN_BLOCK;
+
+__global__ __launch_bounds__(SCAN_BLOCK) void scan_tile_kernel(const int32_t *__restrict__ in,
+                                                               int32_t *__restrict__ out, int n,
+                                                               int32_t *__restrict__ sums)
+{
+    __shared__ int32_t wsum[SCAN_BLOCK / 64];
+    const int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    int32_t v[SCAN_ITEMS];
+    int32_t s = 0;
+#pragma unroll
+    for (int t = 0; t < SCAN_ITEMS; ++t)
+    {
+        v[t] = (base + t < n) ? in[base + t] : 0;
+        s += v[t];
+    }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    int32_t incl = s;
+    for (int d = 1; d < 64; d <<= 1)
+    {
+        const int32_t t = __shfl_up(incl, d);
+        if (lane >= d)
+            incl += t;
+    }
+    if (lane == 63)
+        wsum[wid] = incl;
+    __syncthreads();
+    int32_t pre = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_BLOCK / 64; ++k)
+    {
+        if (k < wid)
+            pre += wsum[k];
+        tot += wsum[k];
+    }
+    int32_t run = pre + incl - s;
+#pragma unroll
+    for (int t = 0; t < SCAN_ITEMS; ++t)
+    {
+        if (base + t < n)
+            out[base + t] = run;
+        run += v[t];
+    }
+    if (threadIdx.x == 0 && sums)
+        sums[blockIdx.x] = tot;
+}
+
+__global__ void scan_add_kernel(int32_t *__restrict__ out, int n, const int32_t *__restrict__ offs)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n)
+        out[k] += offs[k / SCAN_TILE];
+}
+
+__global__ void gather_edges_kernel(const ebvo_edge *__restrict__ R, const int32_t *__restrict__ idx, int64_t n,
+                                    ebvo_edge *__restrict__ out)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n)
+        out[k] = R[idx[k]];
+}
+
+// ------------------------------------------------------------------------------------------
+// Bilinear_Interpolation<double> on the u8 image (include/utility.h:81-104): NaN when a corner
+// is outside the image or a coordinate is an exact integer (0/0).
+__device__ inline double bilinear_nan(const uint8_t *__restrict__ img, int rows, int cols, int pitch, double x,
+                                      double y)
+{
+    const double x1 = floor(x), x2 = ceil(x);
+    const double yc = ceil(y), yf = floor(y);
+    if (x1 < 0 || yc < 0 || x2 >= cols || yc >= rows || yf < 0 || !(x == x) || !(y == y))
+        return __builtin_nan("");
+    const double I11 = (double)img[(int)yc * pitch + (int)x1];
+    const double I21 = (double)img[(int)yc * pitch + (int)x2];
+    const double I12 = (double)img[(int)yf * pitch + (int)x1];
+    const double I22 = (double)img[(int)yf * pitch + (int)x2];
+    const double f1 = ((x2 - x) / (x2 - x1)) * I11 + ((x - x1) / (x2 - x1)) * I21;
+    const double f2 = ((x2 - x) / (x2 - x1)) * I12 + ((x - x1) / (x2 - x1)) * I22;
+    return ((yf - y) / (yf - yc)) * f1 + ((y - yc) / (yf - yc)) * f2;
+}
+
+// 8-lane xor butterfly: ((s0+s1)+(s2+s3)) + ((s4+s5)+(s6+s7)) on every lane of the group
+__device__ inline double butterfly8(double s)
+{
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    s += __shfl_xor(s, 4);
+    return s;
+}
+
+// One lane's row (7 samples) of one side of an edge's patch pair.
+// src/utility.cpp:82-93 (centres), :141-161 (grid), :206-209 (to float).
+__device__ inline void sample_row(const uint8_t *__restrict__ img, int h, int w, int pitch, double ex, double ey,
+                                  double eth, int side, int row, float p[7])
+{
+    double sn, cs;
+    ebvo_sincos(eth, &sn, &cs);
+    const double cx = side ? ex + 5 * (-sn) : ex + 5 * (sn);
+    const double cy = side ? ey + 5 * (cs) : ey + 5 * (-cs);
+    const int i = row - 3;
+#pragma unroll
+    for (int c = 0; c < 7; ++c)
+    {
+        const int j = c - 3;
+        const double x = cs * (i)-sn * (j) + cx;
+        const double y = sn * (i) + cs * (j) + cy;
+        p[c] = (float)bilinear_nan(img, h, w, pitch, x, y);
+    }
+}
+
+// mean-centre, sum of squares and normalisation of a patch spread over an 8-lane group
+// (src/utility.cpp:165-168, :174-178).  Returns the sentinel flag (ss < 1e-10).
+__device__ inline bool normalise_rows(bool active, const float p[7], float nrm[7])
+{
+    double rs = 0.0;
+    if (active)
+    {
+        rs = (double)p[0];
+#pragma unroll
+        for (int c = 1; c < 7; ++c)
+            rs += (double)p[c];
+    }
+    const double mean = butterfly8(rs) / 49.0;
+    const float m = (float)mean;
+    float d[7];
+    double qs = 0.0;
+    if (active)
+    {
+#pragma unroll
+        for (int c = 0; c < 7; ++c)
+        {
+            d[c] = p[c] - m;
+            const float q = d[c] * d[c];
+            qs = (c == 0) ? (double)q : qs + (double)q;
+        }
+    }
+    const double ss = butterfly8(qs);
+    const float inv = (float)(1.0 / sqrt(ss));
+#pragma unroll
+    for (int c = 0; c < 7; ++c)
+        nrm[c] = active ? d[c] * inv : 0.0f;
+    return ss < 1e-10;
+}
+
+__device__ inline double dot_rows(bool active, const float a[7], const float b[7])
+{
+    double s = 0.0;
+    if (active)
+    {
+        s = (double)a[0] * (double)b[0];
+#pragma unroll
+        for (int c = 1; c < 7; ++c)
+            s += (double)a[c] * (double)b[c];
+    }
+    return butterfly8(s);
+}
+
+__device__ inline double max4(double a, double b, double c, double d)
+{
+    double m = a; // std::max({a,b,c,d}): first maximum under operator<
+    if (m < b) m = b;
+    if (m < c) m = c;
+    if (m < d) m = d;
+    return m;
+}
+
+// Patches of n edges: raw floats (n x 2 x 49), optionally the normalised patches and sentinel flags.
+// 16 lanes per edge.
+__global__ __launch_bounds__(256) void patches_kernel(const uint8_t *__restrict__ img, int h, int w, int pitch,
+                                                      const ebvo_edge *__restrict__ edges, int n,
+                                                      float *__restrict__ raw, float *__restrict__ norm,
+                                                      uint8_t *__restrict__ flag)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int e = t >> 4, g = t & 15, side = g >> 3, row = g & 7;
+    const bool valid = e < n; // uniform per 16-lane group
+    const bool active = valid && row < 7;
+    float p[7], nr[7];
+#pragma unroll
+    for (int c = 0; c < 7; ++c)
+        p[c] = 0.0f;
+    if (active)
+        sample_row(img, h, w, pitch, edges[e].x, edges[e].y, edges[e].theta, side, row, p);
+    const bool sent = normalise_rows(active, p, nr);
+    if (active)
+    {
+        const size_t o = (size_t)e * 98 + side * 49 + row * 7;
+#pragma unroll
+        for (int c = 0; c < 7; ++c)
+        {
+            if (raw) raw[o + c] = p[c];
+            if (norm) norm[o + c] = nr[c];
+        }
+        if (flag && row == 0)
+            flag[(size_t)e * 2 + side] = sent ? 1 : 0;
+    }
+}
+
+// NCC of (left edge i, candidate k) pairs; 16 lanes per pair.  src/Stereo_Matches.cpp:585-608.
+__global__ __launch_bounds__(256) void ncc_pairs_kernel(const uint8_t *__restrict__ imgR, int h, int w,
+                                                        int pitch, const ebvo_edge *__restrict__ Rc,
+                                                        const int32_t *__restrict__ pair_left, int64_t n_pairs,
+                                                        const float *__restrict__ left_norm,
+                                                        const uint8_t *__restrict__ left_flag, double thr,
+                                                        double *__restrict__ sims, double *__restrict__ best,
+                                                        uint8_t *__restrict__ keep, int32_t *__restrict__ match_cnt)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t k = t >> 4;
+    const int g = (int)(t & 15), side = g >> 3, row = g & 7;
+    const bool valid = k < n_pairs;
+    const bool active = valid && row < 7;
+    float p[7], rn[7];
+#pragma unroll
+    for (int c = 0; c < 7; ++c)
+        p[c] = 0.0f;
+    int li = 0;
+    if (valid)
+        li = pair_left[k];
+    if (active)
+        sample_row(imgR, h, w, pitch, Rc[k].x, Rc[k].y, Rc[k].theta, side, row, p);
+    const bool rsent = normalise_rows(active, p, rn);
+    // this lane's row of the left plus / minus normalised patches
+    float lp[7], lm[7];
+#pragma unroll
+    for (int c = 0; c < 7; ++c)
+        lp[c] = lm[c] = 0.0f;
+    bool lsent_p = false, lsent_m = false;
+    if (active)
+    {
+        const float *ln = left_norm + (size_t)li * 98 + row * 7;
+#pragma unroll
+        for (int c = 0; c < 7; ++c)
+        {
+            lp[c] = ln[c];
+            lm[c] = ln[49 + c];
+        }
+    }
+    if (valid)
+    {
+        lsent_p = left_flag[(size_t)li * 2] != 0;
+        lsent_m = left_flag[(size_t)li * 2 + 1] != 0;
+    }
+    // side 0 lanes hold R+: (L+ . R+) = pp, (L- . R+) = np;  side 1 lanes hold R-: (L+ . R-) = pn, (L- . R-) = nn
+    const double d_lp = dot_rows(active, lp, rn);
+    const double d_lm = dot_rows(active, lm, rn);
+    const double o_lp = __shfl_xor(d_lp, 8), o_lm = __shfl_xor(d_lm, 8);
+    const int rs_i = rsent ? 1 : 0;
+    const int rs_o = __shfl_xor(rs_i, 8);
+    bool is_match = false;
+    if (valid && g == 0)
+    {
+        const bool rsent_p = rs_i != 0, rsent_m = rs_o != 0;
+        const double pp = (lsent_p || rsent_p) ? -1.0 : d_lp; // src/utility.cpp:170-172
+        const double np = (lsent_m || rsent_p) ? -1.0 : d_lm;
+        const double pn = (lsent_p || rsent_m) ? -1.0 : o_lp;
+        const double nn = (lsent_m || rsent_m) ? -1.0 : o_lm;
+        const double b = max4(pp, nn, pn, np); // src/Stereo_Matches.cpp:596
+        if (sims)
+        {
+            sims[k * 4 + 0] = pp;
+            sims[k * 4 + 1] = nn;
+            sims[k * 4 + 2] = pn;
+            sims[k * 4 + 3] = np;
+        }
+        if (best)
+            best[k] = b;
+        is_match = b > thr; // :597
+        if (keep)
+            keep[k] = is_match ? 1 : 0;
+    }
+    if (match_cnt)
+    {
+        const unsigned long long m = __ballot(is_match);
+        if ((threadIdx.x & 63) == 0 && m)
+            atomicAdd(match_cnt, __popcll(m));
+    }
+}
+
+// pair -> left row index (CSR expansion), one thread per left edge
+__global__ void expand_rows_kernel(const int32_t *__restrict__ row_ptr, int nL, int32_t *__restrict__ pair_left)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nL)
+        return;
+    for (int32_t k = row_ptr[i]; k < row_ptr[i + 1]; ++k)
+        pair_left[k] = i;
+}
+
+// NCC of stored patch pairs (src/utility.cpp:163-180); 16 lanes per pair: side 0 = A, side 1 = B.
+__global__ __launch_bounds__(256) void ncc_stored_kernel(const float *__restrict__ A, const float *__restrict__ B,
+                                                         int n, double *__restrict__ sim)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int k = t >> 4, g = t & 15, side = g >> 3, row = g & 7;
+    const bool valid = k < n;
+    const bool active = valid && row < 7;
+    float p[7], nr[7], other[7];
+#pragma unroll
+    for (int c = 0; c < 7; ++c)
+        p[c] = 0.0f;
+    if (active)
+    {
+        const float *src = (side ? B : A) + (size_t)k * 49 + row * 7;
+#pragma unroll
+        for (int c = 0; c < 7; ++c)
+            p[c] = src[c];
+    }
+    const bool sent = normalise_rows(active, p, nr);
+#pragma unroll
+    for (int c = 0; c < 7; ++c)
+        other[c] = __shfl_xor(nr[c], 8);
+    const int s_i = sent ? 1 : 0, s_o = __shfl_xor(s_i, 8);
+    const double d = dot_rows(active, nr, other); // side 0: A row . B row
+    if (valid && g == 0)
+        sim[k] = (s_i || s_o) ? -1.0 : d;
+}
+
+// ------------------------------------------------------------------------------------------
+// FP64 vector-ALU peak: 16 independent chains of (mul, add) or fma per thread.
+template <bool FMA>
+__global__ __launch_bounds__(256) void fp64_peak_kernel(double *out, int iters, double m, double a)
+{
+    double v[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+        v[t] = (double)(threadIdx.x + t) * 1e-3;
+    for (int it = 0; it < iters; ++it)
+    {
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+        {
+            if (FMA)
+                v[t] = __builtin_fma(v[t], m, a);
+            else
+                v[t] = v[t] * m + a; // contraction is off: v_mul_f64 + v_add_f64
+        }
+    }
+    double s = 0;
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+        s += v[t];
+    out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+int device_exclusive_scan(ebvo_ctx *ctx, const int32_t *in, int32_t *out, int n, GrowBuf &tmp_a, GrowBuf &tmp_b)
+{
+    // level 0
+    const int nb0 = (n + SCAN_TILE - 1) / SCAN_TILE;
+    if (nb0 <= 1)
+    {
+        hipLaunchKernelGGL(scan_tile_kernel, dim3(1), dim3(SCAN_BLOCK), 0, ctx->stream, in, out, n,
+                           (int32_t *)nullptr);
+        return EBVO_OK;
+    }
+    const int nb1 = (nb0 + SCAN_TILE - 1) / SCAN_TILE;
+    int rc = ebvo_grow(ctx, tmp_a, sizeof(int32_t) * (size_t)(2 * nb0 + 2 * nb1 + 16));
+    if (rc)
+        return rc;
+    int32_t *sums0 = (int32_t *)tmp_a.p, *offs0 = sums0 + nb0, *sums1 = offs0 + nb0, *offs1 = sums1 + nb1;
+    hipLaunchKernelGGL(scan_tile_kernel, dim3(nb0), dim3(SCAN_BLOCK), 0, ctx->stream, in, out, n, sums0);
+    if (nb1 <= 1)
+    {
+        hipLaunchKernelGGL(scan_tile_kernel, dim3(1), dim3(SCAN_BLOCK), 0, ctx->stream, (const int32_t *)sums0,
+                           offs0, nb0, (int32_t *)nullptr);
+    }
+    else
+    {
+        if (nb1 > SCAN_TILE)
+            return EBVO_ERR_ARG; // > 1e9 elements
+        hipLaunchKernelGGL(scan_tile_kernel, dim3(nb1), dim3(SCAN_BLOCK), 0, ctx->stream, (const int32_t *)sums0,
+                           offs0, nb0, sums1);
+        hipLaunchKernelGGL(scan_tile_kernel, dim3(1), dim3(SCAN_BLOCK), 0, ctx->stream, (const int32_t *)sums1,
+                           offs1, nb1, (int32_t *)nullptr);
+        hipLaunchKernelGGL(scan_add_kernel, dim3((nb0 + 255) / 256), dim3(256), 0, ctx->stream, offs0, nb0,
+                           (const int32_t *)offs1);
+    }
+    hipLaunchKernelGGL(scan_add_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, out, n,
+                       (const int32_t *)offs0);
+    (void)tmp_b;
+    return EBVO_OK;
+}
+
+} // namespace
+
+int match_lines_device(ebvo_ctx *ctx, const double *d_F, const ebvo_edge *d_edges, int n, double *d_lines)
+{
+    if (n <= 0)
+        return EBVO_OK;
+    ProfScope ps(ctx, K_LINES);
+    hipLaunchKernelGGL(lines_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_F, d_edges, n, d_lines);
+    EBVO_HIP(ctx, hipGetLastError());
+    return EBVO_OK;
+}
+
+int match_candidates_device(ebvo_ctx *ctx, const ebvo_edge *d_L, int nL, const ebvo_edge *d_R, int nR,
+                            const double *d_lines, double epi_thr, double max_disp, double orient_thr_deg,
+                            int stage_mask, int64_t *n_pairs)
+{
+    *n_pairs = 0;
+    int rc;
+    if ((rc = ebvo_grow(ctx, ctx->row_ptr, sizeof(int32_t) * ((size_t)nL + 1))))
+        return rc;
+    if (nL <= 0 || nR <= 0)
+    {
+        EBVO_HIP(ctx, hipMemsetAsync(ctx->row_ptr.p, 0, sizeof(int32_t) * ((size_t)nL + 1), ctx->stream));
+        EBVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return EBVO_OK;
+    }
+    CandParams P;
+    P.epi_thr = epi_thr;
+    P.max_disp = max_disp;
+    P.orient_thr = orient_thr_deg;
+    P.mask = stage_mask;
+    P.nL = nL;
+    P.nR = nR;
+    P.nchunks = (nR + CHUNK - 1) / CHUNK;
+    P.ngroups = (P.nchunks + GROUP - 1) / GROUP;
+    if ((rc = ebvo_grow(ctx, ctx->boxes_chunk, sizeof(Box) * (size_t)P.nchunks)))
+        return rc;
+    if ((rc = ebvo_grow(ctx, ctx->boxes_group, sizeof(Box) * (size_t)P.ngroups)))
+        return rc;
+    if ((rc = ebvo_grow(ctx, ctx->cand_cnt, sizeof(int32_t) * ((size_t)nL + 1) + 16)))
+        return rc;
+    Box *cb = (Box *)ctx->boxes_chunk.p, *gb = (Box *)ctx->boxes_group.p;
+    int32_t *cnt = (int32_t *)ctx->cand_cnt.p;
+    // 64-bit total lives right after the counts (8-byte aligned)
+    unsigned long long *total =
+        (unsigned long long *)((char *)cnt + ((sizeof(int32_t) * ((size_t)nL + 1) + 7) & ~(size_t)7));
+    {
+        ProfScope ps(ctx, K_BOXES);
+        hipLaunchKernelGGL(chunk_boxes_kernel, dim3((P.nchunks + 255) / 256), dim3(256), 0, ctx->stream, d_R, nR,
+                           P.nchunks, cb);
+        hipLaunchKernelGGL(group_boxes_kernel, dim3((P.ngroups + 255) / 256), dim3(256), 0, ctx->stream,
+                           (const Box *)cb, P.nchunks, P.ngroups, gb);
+    }
+    EBVO_HIP(ctx, hipMemsetAsync(cnt + nL, 0, sizeof(int32_t), ctx->stream));
+    EBVO_HIP(ctx, hipMemsetAsync(total, 0, sizeof(unsigned long long), ctx->stream));
+    {
+        ProfScope ps(ctx, K_CAND_COUNT);
+        hipLaunchKernelGGL(candidates_kernel<false>, dim3((nL + 255) / 256), dim3(256), 0, ctx->stream, d_L, d_R,
+                           d_lines, (const Box *)cb, (const Box *)gb, P, cnt, (const int32_t *)nullptr,
+                           (int32_t *)nullptr, total);
+    }
+    {
+        ProfScope ps(ctx, K_SCAN);
+        if ((rc = device_exclusive_scan(ctx, cnt, (int32_t *)ctx->row_ptr.p, nL + 1, ctx->scan_tmp, ctx->scan_tmp)))
+            return rc;
+    }
+    EBVO_HIP(ctx, hipGetLastError());
+    unsigned long long h_total = 0;
+    EBVO_HIP(ctx, hipMemcpyAsync(&h_total, total, sizeof(h_total), hipMemcpyDeviceToHost, ctx->stream));
+    EBVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (h_total > 0x7fffffffull)
+    {
+        ctx->last_error = "candidate list exceeds 2^31-1 pairs";
+        return EBVO_ERR_CAPACITY;
+    }
+    *n_pairs = (int64_t)h_total;
+    if (h_total == 0)
+        return EBVO_OK;
+    if ((rc = ebvo_grow(ctx, ctx->col_idx, sizeof(int32_t) * (size_t)h_total)))
+        return rc;
+    {
+        ProfScope ps(ctx, K_CAND_FILL);
+        hipLaunchKernelGGL(candidates_kernel<true>, dim3((nL + 255) / 256), dim3(256), 0, ctx->stream, d_L, d_R,
+                           d_lines, (const Box *)cb, (const Box *)gb, P, (int32_t *)nullptr,
+                           (const int32_t *)ctx->row_ptr.p, (int32_t *)ctx->col_idx.p,
+                           (unsigned long long *)nullptr);
+    }
+    EBVO_HIP(ctx, hipGetLastError());
+    return EBVO_OK;
+}
+
+int match_gather_edges_device(ebvo_ctx *ctx, const ebvo_edge *d_R, const int32_t *d_col_idx, int64_t n,
+                              ebvo_edge *d_out)
+{
+    if (n <= 0)
+        return EBVO_OK;
+    ProfScope ps(ctx, K_MISC);
+    hipLaunchKernelGGL(gather_edges_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_R,
+                       d_col_idx, n, d_out);
+    EBVO_HIP(ctx, hipGetLastError());
+    return EBVO_OK;
+}
+
+int match_patches_device(ebvo_ctx *ctx, const uint8_t *d_img, int h, int w, int pitch, const ebvo_edge *d_edges,
+                         int n, float *d_raw, float *d_norm, uint8_t *d_flag)
+{
+    if (n <= 0)
+        return EBVO_OK;
+    ProfScope ps(ctx, K_PATCHES);
+    const int64_t threads = (int64_t)n * 16;
+    hipLaunchKernelGGL(patches_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, d_img, h,
+                       w, pitch, d_edges, n, d_raw, d_norm, d_flag);
+    EBVO_HIP(ctx, hipGetLastError());
+    return EBVO_OK;
+}
+
+int match_ncc_pairs_device(ebvo_ctx *ctx, const uint8_t *d_imgR, int h, int w, int pitchR, const ebvo_edge *d_Rc,
+                           const int32_t *d_row_ptr, int nL, int64_t n_pairs, const float *d_left_norm,
+                           const uint8_t *d_left_flag, double thr, double *d_sims, double *d_best,
+                           uint8_t *d_keep, int32_t *d_match_cnt)
+{
+    if (d_match_cnt)
+        EBVO_HIP(ctx, hipMemsetAsync(d_match_cnt, 0, sizeof(int32_t), ctx->stream));
+    if (n_pairs <= 0 || nL <= 0)
+        return EBVO_OK;
+    int rc;
+    if ((rc = ebvo_grow(ctx, ctx->scratch_a, sizeof(int32_t) * (size_t)n_pairs)))
+        return rc;
+    int32_t *pair_left = (int32_t *)ctx->scratch_a.p;
+    {
+        ProfScope ps(ctx, K_MISC);
+        hipLaunchKernelGGL(expand_rows_kernel, dim3((nL + 255) / 256), dim3(256), 0, ctx->stream, d_row_ptr, nL,
+                           pair_left);
+    }
+    {
+        ProfScope ps(ctx, K_NCC_PAIRS);
+        const int64_t threads = n_pairs * 16;
+        hipLaunchKernelGGL(ncc_pairs_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream,
+                           d_imgR, h, w, pitchR, d_Rc, (const int32_t *)pair_left, n_pairs, d_left_norm,
+                           d_left_flag, thr, d_sims, d_best, d_keep, d_match_cnt);
+    }
+    EBVO_HIP(ctx, hipGetLastError());
+    return EBVO_OK;
+}
+
+int match_ncc_stored_device(ebvo_ctx *ctx, const float *d_A, const float *d_B, int n, double *d_sim)
+{
+    if (n <= 0)
+        return EBVO_OK;
+    ProfScope ps(ctx, K_NCC_STORED);
+    const int64_t threads = (int64_t)n * 16;
+    hipLaunchKernelGGL(ncc_stored_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, d_A,
+                       d_B, n, d_sim);
+    EBVO_HIP(ctx, hipGetLastError());
+    return EBVO_OK;
+}
+
+int misc_fp64_peak(ebvo_ctx *ctx, int iters, double *tf_muladd, double *tf_fma)
+{
+    const int blocks = 256 * 8, threads = 256, inner = 4096;
+    double *d_out = nullptr;
+    EBVO_HIP(ctx, hipMalloc(&d_out, sizeof(double) * (size_t)blocks * threads));
+    hipEvent_t e0, e1;
+    EBVO_HIP(ctx, hipEventCreate(&e0));
+    EBVO_HIP(ctx, hipEventCreate(&e1));
+    for (int mode = 0; mode < 2; ++mode)
+    {
+        // warm-up
+        if (mode == 0)
+            hipLaunchKernelGGL(fp64_peak_kernel<false>, dim3(blocks), dim3(threads), 0, ctx->stream, d_out, inner,
+                               1.0000001, 1e-9);
+        else
+            hipLaunchKernelGGL(fp64_peak_kernel<true>, dim3(blocks), dim3(threads), 0, ctx->stream, d_out, inner,
+                               1.0000001, 1e-9);
+        EBVO_HIP(ctx, hipEventRecord(e0, ctx->stream));
+        for (int it = 0; it < iters; ++it)
+        {
+            if (mode == 0)
+                hipLaunchKernelGGL(fp64_peak_kernel<false>, dim3(blocks), dim3(threads), 0, ctx->stream, d_out,
+                                   inner, 1.0000001, 1e-9);
+            else
+                hipLaunchKernelGGL(fp64_peak_kernel<true>, dim3(blocks), dim3(threads), 0, ctx->stream, d_out,
+                                   inner, 1.0000001, 1e-9);
+        }
+        EBVO_HIP(ctx, hipEventRecord(e1, ctx->stream));
+        EBVO_HIP(ctx, hipEventSynchronize(e1));
+        float ms = 0;
+        EBVO_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+        const double flops = 2.0 * 16.0 * (double)inner * (double)blocks * threads * iters;
+        const double tf = flops / (ms * 1e-3) / 1e12;
+        if (mode == 0 && tf_muladd) *tf_muladd = tf;
+        if (mode == 1 && tf_fma) *tf_fma = tf;
+    }
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    hipFree(d_out);
+    return EBVO_OK;
+}

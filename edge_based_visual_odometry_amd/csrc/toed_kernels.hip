@@ -1,0 +1,547 @@
+// toed_kernels.hip -- third-order edge detection on gfx950 (MI355X).
+//
+// Replaces ThirdOrderEdgeDetectionCPU::{preprocessing, convolve_img, non_maximum_suppresion}
+// (src/toed/cpu_toed.cpp:82-120, :122-376, :386-582 of the reference).
+//
+// Arithmetic contract (bit parity with the CPU path): IEEE double, separate multiply and add
+// (this file is compiled with -ffp-contract=off), every accumulator receives its addends in the
+// reference's order (p ascending, q ascending), each addend has the reference's shape:
+//   integer phase   fx += v*(Gx[q]*G[p]),  fy += v*(G[q]*Gx[p]),  others (v*Kcol[q])*Krow[p]
+//   shifted phases  all nine (v*Kcol[q])*Krow[p]
+// Common sub-expressions (v*Kcol[q] feeds several responses and two phases) are formed once;
+// that does not change any rounded value.  Out-of-image taps are fed as +0.0 from a zero-padded
+// LDS tile instead of being skipped: x + (+-0.0) == x for every running sum that started at +0.0.
+//
+// Kernels
+//   toed_conv_kernel     K1: LDS-staged fp64 tile (8 x 32 pixels + 9-pixel halo), one thread per
+//                            input pixel, all four sub-pixel phases (36 fp64 accumulators) in
+//                            registers, filter taps as scalar (SGPR) operands from constant memory
+//   toed_nms_kernel      K2: NMS + parabola fit per interpolated pixel, flags + per-row counts
+//   toed_rowscan_kernel  K3a: exclusive scan of the per-row counts
+//   toed_compact_kernel  K3b: ordered (raster) stream compaction of the flagged pixels
+//   toed_finalize_kernel K3c: dense per-edge epilogue (sub-pixel position, atan2, records)
+#include "ebvo_internal.h"
+#include "ebvo_math.h"
+
+namespace
+{
+
+// sigma = 2 Gaussian-derivative taps (values: src/toed/cpu_toed.cpp:143-146 and :157-160).
+// [d][k]: derivative order d = 0..3, tap k = offset + 9.
+const double h_TAP_INT[4][19] = {
+    {7.99187055345274e-06, 6.69151128824427e-05, 0.000436341347522880, 0.00221592420596900,
+     0.00876415024678427, 0.0269954832565940, 0.0647587978329459, 0.120985362259572, 0.176032663382150,
+     0.199471140200716, 0.176032663382150, 0.120985362259572, 0.0647587978329459, 0.0269954832565940,
+     0.00876415024678427, 0.00221592420596900, 0.000436341347522880, 6.69151128824427e-05,
+     7.99187055345274e-06},
+    {1.79817087452687e-05, 0.000133830225764885, 0.000763597358165040, 0.00332388630895351,
+     0.0109551878084803, 0.0269954832565940, 0.0485690983747094, 0.0604926811297858, 0.0440081658455374, 0,
+     -0.0440081658455374, -0.0604926811297858, -0.0485690983747094, -0.0269954832565940,
+     -0.0109551878084803, -0.00332388630895351, -0.000763597358165040, -0.000133830225764885,
+     -1.79817087452687e-05},
+    {3.84608770384913e-05, 0.000250931673309160, 0.00122721003990810, 0.00443184841193801,
+     0.0115029471989044, 0.0202466124424455, 0.0202371243227956, 0, -0.0330061243841531,
+     -0.0498677850501791, -0.0330061243841531, 0, 0.0202371243227956, 0.0202466124424455,
+     0.0115029471989044, 0.00443184841193801, 0.00122721003990810, 0.000250931673309160,
+     3.84608770384913e-05},
+    {7.75461189639711e-05, 0.000434948233735878, 0.00176581889075666, 0.00498582946343026,
+     0.00890109009439027, 0.00674887081414851, -0.00910670594525801, -0.0302463405648929,
+     -0.0302556140188070, 0, 0.0302556140188070, 0.0302463405648929, 0.00910670594525801,
+     -0.00674887081414851, -0.00890109009439027, -0.00498582946343026, -0.00176581889075666,
+     -0.000434948233735878, -7.75461189639711e-05},
+};
+const double h_TAP_HALF[4][19] = {
+    {2.38593182706025e-05, 0.000176297841183723, 0.00101452402864988, 0.00454678125079553,
+     0.0158698259178337, 0.0431386594132558, 0.0913245426945110, 0.150568716077402, 0.193334058401425,
+     0.193334058401425, 0.150568716077402, 0.0913245426945110, 0.0431386594132558, 0.0158698259178337,
+     0.00454678125079553, 0.00101452402864988, 0.000176297841183723, 2.38593182706025e-05,
+     2.51475364429622e-06},
+    {5.07010513250303e-05, 0.000330558452219480, 0.00164860154655606, 0.00625182421984385,
+     0.0178535541575629, 0.0377463269865988, 0.0570778391840694, 0.0564632685290258, 0.0241667573001781,
+     -0.0241667573001781, -0.0564632685290258, -0.0570778391840694, -0.0377463269865988,
+     -0.0178535541575629, -0.00625182421984385, -0.00164860154655606, -0.000330558452219480,
+     -5.07010513250303e-05, -5.97253990520353e-06},
+    {0.000101774904498039, 0.000575722637615595, 0.00242534650599113, 0.00745956298958641,
+     0.0161177919477999, 0.0222433712599600, 0.0128425138164156, -0.0164684533209659,
+     -0.0453126699378339, -0.0453126699378339, -0.0164684533209659, 0.0128425138164156,
+     0.0222433712599600, 0.0161177919477999, 0.00745956298958641, 0.00242534650599113,
+     0.000575722637615595, 0.000101774904498039, 1.35560938637843e-05},
+    {0.000190921146395817, 0.000914200719419500, 0.00311688729895755, 0.00713098700075939,
+     0.00920573886249338, 0.000589786359165606, -0.0205123484567749, -0.0344073042598751,
+     -0.0177474623923183, 0.0177474623923183, 0.0344073042598751, 0.0205123484567749,
+     -0.000589786359165606, -0.00920573886249338, -0.00713098700075939, -0.00311688729895755,
+     -0.000914200719419500, -0.000190921146395817, -2.92094529738860e-05},
+};
+
+__constant__ double c_TAP_INT[4][19];
+__constant__ double c_TAP_HALF[4][19];
+// integer-phase products formed before touching the pixel (src/toed/cpu_toed.cpp:207-208):
+// c_PROD_FX[p+8][q+8] = Gx[q]*G[p],  c_PROD_FY[p+8][q+8] = G[q]*Gx[p]
+__constant__ double c_PROD_FX[17][17];
+__constant__ double c_PROD_FY[17][17];
+
+constexpr int TILE_W = 32;
+constexpr int TILE_H = 8;
+constexpr int HALO = 9;
+constexpr int LDS_W = TILE_W + 2 * HALO; // 50
+constexpr int LDS_H = TILE_H + 2 * HALO; // 26
+constexpr int MAX_BATCH = 2;
+
+struct ImgBatch
+{
+    const uint8_t *img[MAX_BATCH];
+    double *maps[MAX_BATCH];
+    uint8_t *flag[MAX_BATCH];
+    int32_t *row_cnt[MAX_BATCH];
+    int32_t *row_off[MAX_BATCH];
+    int32_t *counts[MAX_BATCH];
+    int32_t *src[MAX_BATCH];
+    ebvo_edge *edges[MAX_BATCH];
+    double *all4[MAX_BATCH];
+};
+
+// nine responses: fx fy fxx fxy fyy fxxy fxyy fxxx fyyy -> (x-derivative order, y-derivative order)
+#define EBVO_ACCUM9(acc, cp, rp)  \
+    acc[0] += cp[1] * rp[0];      \
+    acc[1] += cp[0] * rp[1];      \
+    acc[2] += cp[2] * rp[0];      \
+    acc[3] += cp[1] * rp[1];      \
+    acc[4] += cp[0] * rp[2];      \
+    acc[5] += cp[2] * rp[1];      \
+    acc[6] += cp[1] * rp[2];      \
+    acc[7] += cp[3] * rp[0];      \
+    acc[8] += cp[0] * rp[3];
+
+// third-order orientation vector, src/toed/cpu_toed.cpp:224-228
+__device__ inline void third_order_dir(const double *f, double &tx, double &ty)
+{
+    const double fx = f[0], fy = f[1], fxx = f[2], fxy = f[3], fyy = f[4], fxxy = f[5], fxyy = f[6],
+                 fxxx = f[7], fyyy = f[8];
+    double TO_Ix = fx * (2 * fxx * fxx + 2 * fxy * fxy) + fy * (2 * fxx * fxy + 2 * fyy * fxy) +
+                   2 * fx * fy * fxxy + fy * fy * fxyy + fx * fx * fxxx;
+    double TO_Iy = fx * (2 * fxx * fxy + 2 * fyy * fxy) + fy * (2 * fyy * fyy + 2 * fxy * fxy) +
+                   2 * fx * fy * fxyy + fx * fx * fxxy + fy * fy * fyyy;
+    double TO_mag = sqrt(TO_Ix * TO_Ix + TO_Iy * TO_Iy);
+    tx = TO_Ix / TO_mag;
+    ty = TO_Iy / TO_mag;
+}
+
+__device__ inline void store_pair(double *plane, size_t o, double a, double b)
+{
+    double2 v;
+    v.x = a;
+    v.y = b;
+    *reinterpret_cast<double2 *>(plane + o) = v;
+}
+
+// K1 ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void toed_conv_kernel(ImgBatch B, int h, int w)
+{
+    __shared__ double tile[LDS_H][LDS_W];
+    const uint8_t *__restrict__ img = B.img[blockIdx.z];
+    double *__restrict__ maps = B.maps[blockIdx.z];
+    const int j0 = blockIdx.x * TILE_W, i0 = blockIdx.y * TILE_H;
+
+    for (int t = threadIdx.x; t < LDS_H * LDS_W; t += 256)
+    {
+        const int r = t / LDS_W, c = t - r * LDS_W;
+        const int ii = i0 + r - HALO, jj = j0 + c - HALO;
+        double v = 0.0;
+        if (ii >= 0 && ii < h && jj >= 0 && jj < w)
+            v = (double)img[(size_t)ii * w + jj];
+        tile[r][c] = v;
+    }
+    __syncthreads();
+
+    const int tx = threadIdx.x & (TILE_W - 1), ty = threadIdx.x >> 5;
+    const int i = i0 + ty, j = j0 + tx;
+    if (i >= h || j >= w)
+        return;
+
+    double a00[9], a01[9], a10[9], a11[9]; // phase (sy, sx)
+#pragma unroll
+    for (int r = 0; r < 9; ++r)
+        a00[r] = a01[r] = a10[r] = a11[r] = 0.0;
+
+#pragma unroll 1
+    for (int p = -HALO; p <= HALO; ++p)
+    {
+        double ru[4], rs[4]; // row taps: integer grid / half-pixel grid (wave-uniform -> SGPRs)
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+        {
+            ru[d] = c_TAP_INT[d][p + 9];
+            rs[d] = c_TAP_HALF[d][p + 9];
+        }
+        const bool row00 = (p >= -8) && (p <= 8);
+        const int pr = row00 ? p + 8 : 0;
+        const double *__restrict__ trow = &tile[ty + HALO - p][tx + HALO];
+#pragma unroll 1
+        for (int q = -HALO; q <= HALO; ++q)
+        {
+            const double v = trow[-q];
+            double cu[4], cs[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+            {
+                cu[d] = v * c_TAP_INT[d][q + 9];
+                cs[d] = v * c_TAP_HALF[d][q + 9];
+            }
+            if (row00 && q >= -8 && q <= 8) // wave-uniform
+            {
+                a00[0] += v * c_PROD_FX[pr][q + 8];
+                a00[1] += v * c_PROD_FY[pr][q + 8];
+                a00[2] += cu[2] * ru[0];
+                a00[3] += cu[1] * ru[1];
+                a00[4] += cu[0] * ru[2];
+                a00[5] += cu[2] * ru[1];
+                a00[6] += cu[1] * ru[2];
+                a00[7] += cu[3] * ru[0];
+                a00[8] += cu[0] * ru[3];
+            }
+            EBVO_ACCUM9(a01, cs, ru) // shifted in x only
+            EBVO_ACCUM9(a10, cu, rs) // shifted in y only
+            EBVO_ACCUM9(a11, cs, rs) // shifted in both
+        }
+    }
+
+    const int W2 = 2 * w;
+    const size_t plane = (size_t)(2 * h) * W2;
+    double tx0, ty0, tx1, ty1;
+    {
+        const size_t o = (size_t)(2 * i) * W2 + 2 * j;
+        store_pair(maps + PL_IX * plane, o, a00[0], a01[0]);
+        store_pair(maps + PL_IY * plane, o, a00[1], a01[1]);
+        store_pair(maps + PL_MAG * plane, o, sqrt(a00[0] * a00[0] + a00[1] * a00[1]),
+                   sqrt(a01[0] * a01[0] + a01[1] * a01[1]));
+        third_order_dir(a00, tx0, ty0);
+        third_order_dir(a01, tx1, ty1);
+        store_pair(maps + PL_TOX * plane, o, tx0, tx1);
+        store_pair(maps + PL_TOY * plane, o, ty0, ty1);
+    }
+    {
+        const size_t o = (size_t)(2 * i + 1) * W2 + 2 * j;
+        store_pair(maps + PL_IX * plane, o, a10[0], a11[0]);
+        store_pair(maps + PL_IY * plane, o, a10[1], a11[1]);
+        store_pair(maps + PL_MAG * plane, o, sqrt(a10[0] * a10[0] + a10[1] * a10[1]),
+                   sqrt(a11[0] * a11[0] + a11[1] * a11[1]));
+        third_order_dir(a10, tx0, ty0);
+        third_order_dir(a11, tx1, ty1);
+        store_pair(maps + PL_TOX * plane, o, tx0, tx1);
+        store_pair(maps + PL_TOY * plane, o, ty0, ty1);
+    }
+}
+
+// NMS + parabola fit at interpolated pixel (i, j): src/toed/cpu_toed.cpp:406-511.
+__device__ inline bool nms_eval(const double *__restrict__ Ix, const double *__restrict__ Iy,
+                                const double *__restrict__ M, int W2, int i, int j, double &pos_x,
+                                double &pos_y, double &smag)
+{
+    const size_t o = (size_t)i * W2 + j;
+    const double m = M[o];
+    if (m <= 2) // :406
+        return false;
+    const double gx = Ix[o], gy = Iy[o];
+    if (fabs(gx) < 10e-6 && fabs(gy) < 10e-6) // :410
+        return false;
+    const double nx = gx / m, ny = gy / m;
+    // sector -> (di, dj) of the axis neighbour and of the diagonal neighbour on the plus side
+    int a1, b1, a2, b2;
+    double slope;
+    if (gx >= 0 && gy >= 0)
+    {
+        if (gx >= gy) { slope = ny / nx; a1 = 0; b1 = 1; a2 = 1; b2 = 1; }
+        else { slope = nx / ny; a1 = 1; b1 = 0; a2 = 1; b2 = 1; }
+    }
+    else if (gx < 0 && gy >= 0)
+    {
+        if (fabs(gx) < gy) { slope = -nx / ny; a1 = 1; b1 = 0; a2 = 1; b2 = -1; }
+        else { slope = -ny / nx; a1 = 0; b1 = -1; a2 = 1; b2 = -1; }
+    }
+    else if (gx < 0 && gy < 0)
+    {
+        if (fabs(gx) >= fabs(gy)) { slope = ny / nx; a1 = 0; b1 = -1; a2 = -1; b2 = -1; }
+        else { slope = nx / ny; a1 = -1; b1 = 0; a2 = -1; b2 = -1; }
+    }
+    else if (gx >= 0 && gy < 0)
+    {
+        if (gx < fabs(gy)) { slope = -nx / ny; a1 = -1; b1 = 0; a2 = -1; b2 = 1; }
+        else { slope = -ny / nx; a1 = 0; b1 = 1; a2 = -1; b2 = 1; }
+    }
+    else
+        return false;
+    const double fp = M[(size_t)(i + a1) * W2 + (j + b1)] * (1 - slope) + M[(size_t)(i + a2) * W2 + (j + b2)] * slope;
+    const double fm = M[(size_t)(i - a1) * W2 + (j - b1)] * (1 - slope) + M[(size_t)(i - a2) * W2 + (j - b2)] * slope;
+    const double s = sqrt(1 + slope * slope);
+    if (!((m > fm && m > fp) || (m > fm && m >= fp) || (m >= fm && m > fp))) // :481-483
+        return false;
+    const double A = (fm + fp - 2 * m) / (2 * s * s);
+    const double Bc = (fp - fm) / (2 * s);
+    const double C = m;
+    const double s_star = -Bc / (2 * A);
+    const double max_f = A * s_star * s_star + Bc * s_star + C;
+    if (!(fabs(s_star) <= sqrt(2.0))) // :494
+        return false;
+    const double sgx = max_f * nx, sgy = max_f * ny;
+    smag = sqrt(sgx * sgx + sgy * sgy);
+    pos_x = j + s_star * nx;
+    pos_y = i + s_star * ny;
+    return true;
+}
+
+// K2 ---------------------------------------------------------------------------------------
+// grid (ceil((W2-20)/64), ceil((H2-20)/4), n_img), block (64, 4): one wave per row segment.
+__global__ __launch_bounds__(256) void toed_nms_kernel(ImgBatch B, int h, int w)
+{
+    const int W2 = 2 * w, H2 = 2 * h;
+    const size_t plane = (size_t)H2 * W2;
+    const double *maps = B.maps[blockIdx.z];
+    const int j = 10 + blockIdx.x * 64 + threadIdx.x;
+    const int i = 10 + blockIdx.y * 4 + threadIdx.y;
+    if (i >= H2 - 10) // wave-uniform
+        return;
+    int f = 0;
+    if (j < W2 - 10)
+    {
+        double px, py, sm;
+        if (nms_eval(maps + PL_IX * plane, maps + PL_IY * plane, maps + PL_MAG * plane, W2, i, j, px, py, sm))
+        {
+            const double x = (px - 1) / 2, y = (py - 1) / 2; // :538,542
+            f = (x > 10 && x < w - 10 && y > 10 && y < h - 10) ? 3 : 1; // :553-554
+        }
+        B.flag[blockIdx.z][(size_t)i * W2 + j] = (uint8_t)f;
+    }
+    const unsigned long long any = __ballot(f != 0), kept = __ballot(f == 3);
+    if (threadIdx.x == 0 && any)
+    {
+        atomicAdd(&B.row_cnt[blockIdx.z][i], __popcll(any));
+        atomicAdd(&B.row_cnt[blockIdx.z][H2 + i], __popcll(kept));
+    }
+}
+
+// K3a --------------------------------------------------------------------------------------
+// one wave per image: exclusive scan of both per-row counters; totals to counts[0..1].
+__global__ __launch_bounds__(64) void toed_rowscan_kernel(ImgBatch B, int H2)
+{
+    const int32_t *cnt = B.row_cnt[blockIdx.x];
+    int32_t *off = B.row_off[blockIdx.x];
+    const int lane = threadIdx.x;
+    const int per = (H2 + 63) / 64;
+    for (int which = 0; which < 2; ++which)
+    {
+        const int32_t *c = cnt + which * H2;
+        int32_t *o = off + which * (H2 + 1);
+        const int beg = lane * per, end = min(H2, beg + per);
+        int s = 0;
+        for (int r = beg; r < end; ++r)
+            s += c[r];
+        int incl = s;
+        for (int d = 1; d < 64; d <<= 1)
+        {
+            const int t = __shfl_up(incl, d);
+            if (lane >= d)
+                incl += t;
+        }
+        int run = incl - s;
+        for (int r = beg; r < end; ++r)
+        {
+            o[r] = run;
+            run += c[r];
+        }
+        if (lane == 63)
+        {
+            o[H2] = incl;
+            B.counts[blockIdx.x][which] = incl;
+        }
+    }
+}
+
+// K3b --------------------------------------------------------------------------------------
+// one block per interpolated row; ordered compaction of the flagged pixels of that row.
+__global__ __launch_bounds__(256) void toed_compact_kernel(ImgBatch B, int h, int w, int cap)
+{
+    const int W2 = 2 * w, H2 = 2 * h;
+    const int i = 10 + blockIdx.x;
+    if (i >= H2 - 10)
+        return;
+    const uint8_t *flag = B.flag[blockIdx.y] + (size_t)i * W2;
+    const int32_t *off = B.row_off[blockIdx.y];
+    int32_t *src = B.src[blockIdx.y];
+    int base_all = off[i], base_kept = off[(H2 + 1) + i];
+    __shared__ int w_all[4], w_kept[4];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    for (int j0 = 10; j0 < W2 - 10; j0 += 256)
+    {
+        const int j = j0 + threadIdx.x;
+        const int f = (j < W2 - 10) ? flag[j] : 0;
+        const unsigned long long m_all = __ballot(f != 0), m_kept = __ballot(f == 3);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if (lane == 0)
+        {
+            w_all[wid] = __popcll(m_all);
+            w_kept[wid] = __popcll(m_kept);
+        }
+        __syncthreads();
+        int pre_all = 0, pre_kept = 0, tot_all = 0, tot_kept = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+        {
+            if (k < wid)
+            {
+                pre_all += w_all[k];
+                pre_kept += w_kept[k];
+            }
+            tot_all += w_all[k];
+            tot_kept += w_kept[k];
+        }
+        if (f)
+        {
+            const int r_all = base_all + pre_all + __popcll(m_all & below);
+            const int r_kept = (f == 3) ? base_kept + pre_kept + __popcll(m_kept & below) : -1;
+            if (r_all < cap)
+            {
+                src[2 * r_all] = i * W2 + j;
+                src[2 * r_all + 1] = r_kept;
+            }
+        }
+        base_all += tot_all;
+        base_kept += tot_kept;
+        __syncthreads();
+    }
+}
+
+// K3c --------------------------------------------------------------------------------------
+// dense epilogue: one thread per NMS maximum (grid-stride; the count lives in device memory).
+__global__ __launch_bounds__(256) void toed_finalize_kernel(ImgBatch B, int h, int w, int cap)
+{
+    const int W2 = 2 * w, H2 = 2 * h;
+    const size_t plane = (size_t)H2 * W2;
+    const double *maps = B.maps[blockIdx.y];
+    const int32_t *src = B.src[blockIdx.y];
+    ebvo_edge *edges = B.edges[blockIdx.y];
+    double *all4 = B.all4[blockIdx.y];
+    const int n = min(B.counts[blockIdx.y][0], cap);
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x)
+    {
+        const int o = src[2 * t], kr = src[2 * t + 1];
+        const int i = o / W2, j = o - i * W2;
+        double px = 0, py = 0, sm = 0;
+        nms_eval(maps + PL_IX * plane, maps + PL_IY * plane, maps + PL_MAG * plane, W2, i, j, px, py, sm);
+        const double x = (px - 1) / 2, y = (py - 1) / 2;
+        // src/toed/cpu_toed.cpp:229: atan2(TO_Ix, -TO_Iy)
+        const double th = ebvo_atan2(maps[PL_TOX * plane + o], -maps[PL_TOY * plane + o]);
+        all4[(size_t)t * 4 + 0] = x;
+        all4[(size_t)t * 4 + 1] = y;
+        all4[(size_t)t * 4 + 2] = th;
+        all4[(size_t)t * 4 + 3] = sm;
+        if (kr >= 0 && kr < cap)
+        {
+            ebvo_edge e;
+            e.x = x;
+            e.y = y;
+            e.theta = th;
+            e.index = kr; // src/toed/cpu_toed.cpp:562
+            e.pad = 0;
+            edges[kr] = e;
+        }
+    }
+}
+
+} // namespace
+
+int toed_init_constants(ebvo_ctx *ctx)
+{
+    double fxp[17][17], fyp[17][17];
+    for (int p = -8; p <= 8; ++p)
+        for (int q = -8; q <= 8; ++q)
+        {
+            fxp[p + 8][q + 8] = h_TAP_INT[1][q + 9] * h_TAP_INT[0][p + 9];
+            fyp[p + 8][q + 8] = h_TAP_INT[0][q + 9] * h_TAP_INT[1][p + 9];
+        }
+    EBVO_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(c_TAP_INT), h_TAP_INT, sizeof(h_TAP_INT)));
+    EBVO_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(c_TAP_HALF), h_TAP_HALF, sizeof(h_TAP_HALF)));
+    EBVO_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(c_PROD_FX), fxp, sizeof(fxp)));
+    EBVO_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(c_PROD_FY), fyp, sizeof(fyp)));
+    return EBVO_OK;
+}
+
+int toed_run_device(ebvo_ctx *ctx, int n_img, int h, int w, float *ms_conv, float *ms_nms)
+{
+    if (n_img < 1 || n_img > MAX_BATCH)
+        return EBVO_ERR_ARG;
+    const int H2 = 2 * h, W2 = 2 * w;
+    ImgBatch B{};
+    for (int k = 0; k < n_img; ++k)
+    {
+        ImageWS &ws = ctx->im[k];
+        B.img[k] = ws.img;
+        B.maps[k] = ws.maps;
+        B.flag[k] = ws.flag;
+        B.row_cnt[k] = ws.row_cnt;
+        B.row_off[k] = ws.row_off;
+        B.counts[k] = ws.counts;
+        B.src[k] = ws.src;
+        B.edges[k] = ws.edges;
+        B.all4[k] = ws.all4;
+        EBVO_HIP(ctx, hipMemsetAsync(ws.row_cnt, 0, sizeof(int32_t) * 2 * H2, ctx->stream));
+    }
+    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+    const bool timed = ms_conv || ms_nms;
+    if (timed)
+    {
+        EBVO_HIP(ctx, hipEventCreate(&e0));
+        EBVO_HIP(ctx, hipEventCreate(&e1));
+        EBVO_HIP(ctx, hipEventCreate(&e2));
+        EBVO_HIP(ctx, hipEventRecord(e0, ctx->stream));
+    }
+    {
+        ProfScope ps(ctx, K_CONV);
+        dim3 grid((w + TILE_W - 1) / TILE_W, (h + TILE_H - 1) / TILE_H, n_img);
+        hipLaunchKernelGGL(toed_conv_kernel, grid, dim3(256), 0, ctx->stream, B, h, w);
+    }
+    if (timed)
+        EBVO_HIP(ctx, hipEventRecord(e1, ctx->stream));
+    {
+        ProfScope ps(ctx, K_NMS);
+        dim3 grid((W2 - 20 + 63) / 64, (H2 - 20 + 3) / 4, n_img);
+        hipLaunchKernelGGL(toed_nms_kernel, grid, dim3(64, 4), 0, ctx->stream, B, h, w);
+    }
+    {
+        ProfScope ps(ctx, K_ROWSCAN);
+        hipLaunchKernelGGL(toed_rowscan_kernel, dim3(n_img), dim3(64), 0, ctx->stream, B, H2);
+    }
+    {
+        ProfScope ps(ctx, K_COMPACT);
+        hipLaunchKernelGGL(toed_compact_kernel, dim3(H2 - 20, n_img), dim3(256), 0, ctx->stream, B, h, w,
+                           ctx->cap_edges);
+    }
+    {
+        ProfScope ps(ctx, K_FINALIZE);
+        hipLaunchKernelGGL(toed_finalize_kernel, dim3(512, n_img), dim3(256), 0, ctx->stream, B, h, w,
+                           ctx->cap_edges);
+    }
+    if (timed)
+        EBVO_HIP(ctx, hipEventRecord(e2, ctx->stream));
+    EBVO_HIP(ctx, hipGetLastError());
+    for (int k = 0; k < n_img; ++k)
+        EBVO_HIP(ctx, hipMemcpyAsync(ctx->h_small + 2 * k, ctx->im[k].counts, 2 * sizeof(int32_t),
+                                     hipMemcpyDeviceToHost, ctx->stream));
+    EBVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < n_img; ++k)
+    {
+        ctx->im[k].n_total = ctx->h_small[2 * k];
+        ctx->im[k].n_kept = ctx->h_small[2 * k + 1];
+    }
+    if (timed)
+    {
+        float a = 0, b = 0;
+        EBVO_HIP(ctx, hipEventElapsedTime(&a, e0, e1));
+        EBVO_HIP(ctx, hipEventElapsedTime(&b, e1, e2));
+        if (ms_conv) *ms_conv = a;
+        if (ms_nms) *ms_nms = b;
+        hipEventDestroy(e0);
+        hipEventDestroy(e1);
+        hipEventDestroy(e2);
+    }
+    return EBVO_OK;
+}

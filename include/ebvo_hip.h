@@ -1,0 +1,208 @@
+/*
+ * ebvo_hip.h -- C ABI of the MI355X-native edge-extraction-and-matching hot path.
+ *
+ * Drop-in boundary for Brown-LEMS/Edge_Based_Visual_Odometry (C++17, no FFI of its own): the
+ * reference reaches this path through three C++ objects held by Pipeline
+ * (include/Pipeline.h:193-195).  Each entry point below names the reference interface it
+ * replaces (file:line); INTEGRATION.md shows the adapter classes a maintainer drops in.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; the caller owns every buffer, the library owns the ctx;
+ *   - return 0 (EBVO_OK) or a negative ebvo_status; nothing throws, nothing is retained
+ *     across calls; numeric sentinels of the reference are reproduced (NaN for out-of-image
+ *     or integer-coordinate bilinear samples, -1.0 for a zero-variance NCC patch);
+ *   - one ctx per host thread and per GPU; a ctx is not thread-safe; calls are synchronous
+ *     for the caller (internally ordered on the ctx's HIP stream);
+ *   - there is NO CPU fallback: without a usable HIP device ebvo_ctx_create fails.
+ *
+ * Arithmetic contract: IEEE double, separate multiply and add (no FMA), the reference's
+ * operation order; atan2 / sin / cos are the correctly rounding routines of
+ * csrc/ebvo_math.h.  Edge positions and indices, candidate lists and match-pair IDs are
+ * bit-exact against the CPU path; orientations are the correctly rounded value (glibc differs
+ * from it by 1 ulp on ~0.06 % of inputs).
+ */
+#ifndef EBVO_HIP_H
+#define EBVO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EBVO_ABI_VERSION 1
+
+typedef struct ebvo_ctx ebvo_ctx;
+
+/* struct Edge (include/toed/cpu_toed.hpp:26-48) without the cv:: type: location, orientation,
+ * index.  b_isEmpty / frame_source are filled by the adapter exactly as TOED leaves them. */
+typedef struct ebvo_edge
+{
+    double x, y, theta;
+    int32_t index;
+    int32_t pad;
+} ebvo_edge;
+
+typedef enum ebvo_status
+{
+    EBVO_OK = 0,
+    EBVO_ERR_ARG = -1,      /* null pointer, non-positive size, size above the ctx maximum */
+    EBVO_ERR_CAPACITY = -2, /* an output buffer is too small; the required size is reported */
+    EBVO_ERR_HIP = -3,      /* a HIP call failed; see ebvo_last_error */
+    EBVO_ERR_NOMEM = -4,
+    EBVO_ERR_STATE = -5     /* call made before the data it needs exists */
+} ebvo_status;
+
+/* stage_mask bits of ebvo_epi_candidates */
+enum
+{
+    EBVO_STAGE_EPIPOLAR = 1,    /* apply_Epipolar_Line_Distance_Filtering, src/Stereo_Matches.cpp:381-419 */
+    EBVO_STAGE_DISPARITY = 2,   /* apply_Disparity_Filtering, :534-553 */
+    EBVO_STAGE_ORIENTATION = 4, /* apply_orientation_filter, :863-915 */
+    EBVO_STAGE_ALL = 7
+};
+
+/* Defaults = the reference's compile-time macros (include/definitions.h:17-24). */
+#define EBVO_EPIPOLAR_LINE_DIST_THRESH 0.5
+#define EBVO_MAX_DISPARITY 25.0
+#define EBVO_ORIENT_THRESH_DEG 10.0
+#define EBVO_NCC_THRESH 0.6
+#define EBVO_NCC_THRESH_TEMPORAL 0.8
+#define EBVO_PATCH_SIZE 7
+#define EBVO_PATCH_ELEMS 49
+
+const char *ebvo_strerror(int status);
+const char *ebvo_last_error(const ebvo_ctx *ctx); /* text of the last HIP failure, "" if none */
+int ebvo_abi_version(void);
+
+/* Replaces ThirdOrderEdgeDetectionCPU::ThirdOrderEdgeDetectionCPU(int H, int W) and its
+ * destructor (src/toed/cpu_toed.cpp:24-64, :649-663): device workspace for images up to
+ * max_h x max_w on HIP device `device`. */
+int ebvo_ctx_create(int device, int max_h, int max_w, ebvo_ctx **out);
+void ebvo_ctx_destroy(ebvo_ctx *ctx);
+
+/*
+ * Replaces ThirdOrderEdgeDetectionCPU::get_Third_Order_Edges(cv::Mat)
+ * (src/toed/cpu_toed.cpp:66-77: preprocessing + convolve_img + non_maximum_suppresion), called
+ * by Pipeline::ProcessEdges (src/Pipeline.cpp:24-29).
+ *   img/h/w/stride : CV_8UC1 image (stride in bytes)
+ *   out/cap        : toed_edges -- edges inside the 10-px border, raster order, index = position
+ *   n_kept         : toed_edges.size();  n_total : Total_Num_Of_TOED (all NMS maxima)
+ *   all4/cap_all   : optional subpix_edge_pts_final rows (x, y, theta, sub-pixel magnitude)
+ *   t_conv/t_nms   : optional time_conv / time_nms in seconds (device time)
+ * On EBVO_ERR_CAPACITY n_kept / n_total hold the required sizes.
+ */
+int ebvo_toed(ebvo_ctx *ctx, const uint8_t *img, int h, int w, ptrdiff_t stride, ebvo_edge *out, int cap,
+              int *n_kept, int *n_total, double *all4, int cap_all, double *t_conv, double *t_nms);
+
+/* Two images of one size in one launch (left + right of a stereo frame, src/Pipeline.cpp:93,97). */
+int ebvo_toed_pair(ebvo_ctx *ctx, const uint8_t *img_left, const uint8_t *img_right, int h, int w,
+                   ptrdiff_t stride_left, ptrdiff_t stride_right, ebvo_edge *out_left, ebvo_edge *out_right,
+                   int cap, int n_kept[2], int n_total[2]);
+
+/* Replaces Stereo_Matches::CalculateEpipolarLine (src/Stereo_Matches.cpp:10-20): l = F (x, y, 1),
+ * F row-major, evaluated (F_i0*x + F_i1*y) + F_i2.  Host-side helper (3 flops per line); the
+ * adapter may instead pass the lines Eigen produced. */
+int ebvo_epipolar_lines(const double F[9], const ebvo_edge *edges, int n, double *lines /* n x 3 */);
+
+/*
+ * Replaces extract_Epipolar_Edge_Indices + apply_Epipolar_Line_Distance_Filtering
+ * (src/Stereo_Matches.cpp:91-109, :381-419), apply_Disparity_Filtering (:534-553) and
+ * apply_orientation_filter (:863-915); stage_mask selects which predicates apply, so the
+ * adapter can expose the three stages separately or fused.
+ *   L/nL, R/nR : focused (left) edges and candidate (right) edges
+ *   lines      : nL x 3 epipolar line coefficients (a, b, c) of the left edges
+ *   row_ptr    : nL + 1 CSR offsets;  col_idx/cap : right-edge indices, ascending per row
+ *   n_pairs    : number of pairs (required cap on EBVO_ERR_CAPACITY)
+ * col_idx may be NULL with cap 0 to size the output.
+ */
+int ebvo_epi_candidates(ebvo_ctx *ctx, const ebvo_edge *L, int nL, const ebvo_edge *R, int nR,
+                        const double *lines, double epi_thr, double max_disp, double orient_thr_deg,
+                        int stage_mask, int32_t *row_ptr, int32_t *col_idx, int64_t cap, int64_t *n_pairs);
+
+/*
+ * Replaces Stereo_Matches::apply_NCC_Filtering (src/Stereo_Matches.cpp:555-616) and under it
+ * Utility::get_edge_patches / get_patch_similarity (src/utility.cpp:182-212, :163-180).
+ *   imgL/imgR     : the raw left / right CV_8UC1 images (:562-563)
+ *   L/nL          : left edges;  row_ptr : nL + 1 CSR offsets into the pair arrays
+ *   Rc            : one explicit candidate edge per pair (a TOED edge in the first pass, a
+ *                   cluster centre in the second, :588)
+ *   left_patches  : optional nL x 2 x 49 floats (plus, minus) -- left_edge_patches (:578)
+ *   sims          : optional n_pairs x 4 doubles (pp, nn, pn, np) (:592-595)
+ *   best          : optional n_pairs doubles, std::max of the four (:596)
+ *   keep          : optional n_pairs bytes, best > thr (:597)
+ */
+int ebvo_ncc_pairs(ebvo_ctx *ctx, const uint8_t *imgL, const uint8_t *imgR, int h, int w,
+                   ptrdiff_t strideL, ptrdiff_t strideR, const ebvo_edge *L, int nL, const ebvo_edge *Rc,
+                   const int32_t *row_ptr, double thr, float *left_patches, double *sims, double *best,
+                   uint8_t *keep);
+
+/* Utility::get_edge_patches for n edges on one image: patches = n x 2 x 49 floats
+ * (src/utility.cpp:182-212; used again by finalize_stereo_edge_mates, src/Stereo_Matches.cpp:1622). */
+int ebvo_edge_patches(ebvo_ctx *ctx, const uint8_t *img, int h, int w, ptrdiff_t stride,
+                      const ebvo_edge *edges, int n, float *patches);
+
+/* Utility::get_patch_similarity over n explicit pairs of stored 7x7 float patches
+ * (src/utility.cpp:163-180); also the MatlabNCCComputer::computeNCC-shaped entry
+ * (include/MatlabNCCComputer.h:41): sim[k] = ncc(A[k], B[k]). */
+int ebvo_ncc_patches(ebvo_ctx *ctx, const float *A, const float *B, int n, double *sim);
+
+/* Replaces the scoring loop of Temporal_Matches::apply_NCC_filtering_quads
+ * (src/Temporal_Matches.cpp:426-468): per quad k, stored (plus, minus) patches of the keyframe
+ * mate and the current-frame mate on the left and on the right (n x 2 x 49 floats each);
+ * sim_left / sim_right = max of the four NCCs in the order (:441-450); keep = both > thr. */
+int ebvo_ncc_quads(ebvo_ctx *ctx, const float *kfL, const float *kfR, const float *cfL, const float *cfR,
+                   int n, double thr, double *sim_left, double *sim_right, uint8_t *keep);
+
+/* ---------------------------------------------------------------------------------------- */
+/* Device-resident stereo pipeline: TOED(left) + TOED(right) + candidates + NCC of one pair,  */
+/* images and every intermediate in HBM.  This is what bench.py times.                        */
+/* ---------------------------------------------------------------------------------------- */
+
+typedef struct ebvo_stereo_params
+{
+    double F21[9]; /* row-major fundamental matrix, Dataset::get_fund_mat_21 */
+    double epi_thr, max_disp, orient_thr_deg, ncc_thr;
+    int stage_mask;
+    int reserved;
+} ebvo_stereo_params;
+
+typedef struct ebvo_stereo_counts
+{
+    int32_t n_left, n_right;             /* toed_edges.size() of each image */
+    int32_t n_total_left, n_total_right; /* Total_Num_Of_TOED of each image */
+    int64_t n_pairs;                     /* candidates after the geometric filters */
+    int64_t n_matches;                   /* pairs with max NCC > ncc_thr */
+} ebvo_stereo_counts;
+
+void ebvo_stereo_default_params(ebvo_stereo_params *p);
+/* copy one stereo pair into HBM (not part of the timed region) */
+int ebvo_stereo_upload(ebvo_ctx *ctx, const uint8_t *img_left, const uint8_t *img_right, int h, int w,
+                       ptrdiff_t stride_left, ptrdiff_t stride_right);
+/* run the whole hot path on the resident pair */
+int ebvo_stereo_run(ebvo_ctx *ctx, const ebvo_stereo_params *p, ebvo_stereo_counts *counts);
+/* fetch the results of the last ebvo_stereo_run; any pointer may be NULL */
+int ebvo_stereo_fetch(ebvo_ctx *ctx, ebvo_edge *left, ebvo_edge *right, int32_t *row_ptr, int32_t *col_idx,
+                      double *sims, double *best, uint8_t *keep, float *left_patches);
+
+/* Per-kernel device timing (HIP events on the ctx stream). */
+#define EBVO_MAX_KERNELS 16
+typedef struct ebvo_kernel_time
+{
+    const char *name;
+    double ms;        /* accumulated */
+    int64_t launches; /* accumulated */
+} ebvo_kernel_time;
+int ebvo_profile_enable(ebvo_ctx *ctx, int on);
+int ebvo_profile_reset(ebvo_ctx *ctx);
+int ebvo_profile_get(ebvo_ctx *ctx, ebvo_kernel_time *out /* EBVO_MAX_KERNELS */, int *n);
+
+/* Raw FP64 vector-ALU microbenchmark (mul + add, no FMA) used to anchor the compute roofline:
+ * returns achieved TFLOP/s over `iters` launches. */
+int ebvo_fp64_peak(ebvo_ctx *ctx, int iters, double *tflops_muladd, double *tflops_fma);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EBVO_HIP_H */

@@ -1,0 +1,145 @@
+"""ctypes view of oracle/libebvo_oracle.so -- the CPU restatement of the reference (checker only)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB = os.path.join(ORACLE_DIR, "libebvo_oracle.so")
+
+EDGE_DTYPE = np.dtype([("x", "<f8"), ("y", "<f8"), ("theta", "<f8"), ("index", "<i4"), ("pad", "<i4")])
+PORTABLE, LIBM = 0, 1
+STAGE_EPIPOLAR, STAGE_DISPARITY, STAGE_ORIENTATION, STAGE_ALL = 1, 2, 4, 7
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            subprocess.check_call(["make", "-C", ORACLE_DIR])
+        L = C.CDLL(LIB)
+        L.orc_edge_hash.restype = C.c_uint64
+        L.orc_fnv1a64.restype = C.c_uint64
+        L.orc_patch_similarity.restype = C.c_double
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def toed(img, math_mode=PORTABLE, nthreads=0, want_all=False, want_maps=False):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w = img.shape
+    cap = h * w
+    kept = np.zeros(cap, dtype=EDGE_DTYPE)
+    all4 = np.zeros((cap, 4)) if want_all else None
+    maps = np.zeros((5, 2 * h, 2 * w)) if want_maps else None
+    nk, nt = C.c_int(), C.c_int()
+    tc, tn = C.c_double(), C.c_double()
+    rc = lib().orc_toed(_p(img), h, w, C.c_ssize_t(img.strides[0]), math_mode, nthreads, _p(kept), cap, _p(all4),
+                        cap if want_all else 0, C.byref(nk), C.byref(nt), _p(maps), C.byref(tc), C.byref(tn))
+    assert rc == 0, rc
+    return dict(edges=kept[: nk.value].copy(), n_total=nt.value, all4=None if all4 is None else all4[: nt.value].copy(),
+                maps=maps, t_conv=tc.value, t_nms=tn.value)
+
+
+def edge_hash(edges, with_theta):
+    e = np.ascontiguousarray(edges, dtype=EDGE_DTYPE)
+    return f"{lib().orc_edge_hash(_p(e), len(e), int(with_theta)):016x}"
+
+
+def epipolar_lines(F, edges):
+    F = np.ascontiguousarray(F, dtype=np.float64).reshape(9)
+    e = np.ascontiguousarray(edges, dtype=EDGE_DTYPE)
+    out = np.zeros((len(e), 3))
+    lib().orc_epipolar_lines(_p(F), _p(e), len(e), _p(out))
+    return out
+
+
+def epi_candidates(L, R, lines, epi_thr=0.5, max_disp=25.0, orient_thr_deg=10.0, stage_mask=STAGE_ALL, nthreads=0):
+    L = np.ascontiguousarray(L, dtype=EDGE_DTYPE)
+    R = np.ascontiguousarray(R, dtype=EDGE_DTYPE)
+    lines = np.ascontiguousarray(lines, dtype=np.float64)
+    row_ptr = np.zeros(len(L) + 1, dtype=np.int32)
+    n = C.c_int64()
+    f = lib().orc_epi_candidates
+    args = (_p(L), len(L), _p(R), len(R), _p(lines), C.c_double(epi_thr), C.c_double(max_disp),
+            C.c_double(orient_thr_deg), stage_mask, nthreads, _p(row_ptr))
+    f(*args, None, C.c_int64(0), C.byref(n))
+    col = np.zeros(max(1, n.value), dtype=np.int32)
+    rc = f(*args, _p(col), C.c_int64(len(col)), C.byref(n))
+    assert rc == 0
+    return row_ptr, col[: n.value].copy()
+
+
+def edge_patches(img, edges, math_mode=PORTABLE, nthreads=0):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w = img.shape
+    e = np.ascontiguousarray(edges, dtype=EDGE_DTYPE)
+    out = np.zeros((len(e), 2, 49), dtype=np.float32)
+    lib().orc_edge_patches(_p(img), h, w, C.c_ssize_t(img.strides[0]), _p(e), len(e), math_mode, nthreads, _p(out))
+    return out
+
+
+def patch_similarity(a, b):
+    a = np.ascontiguousarray(a, dtype=np.float32).reshape(49)
+    b = np.ascontiguousarray(b, dtype=np.float32).reshape(49)
+    return lib().orc_patch_similarity(_p(a), _p(b))
+
+
+def ncc_patches(A, B, nthreads=0):
+    A = np.ascontiguousarray(A, dtype=np.float32).reshape(-1, 49)
+    B = np.ascontiguousarray(B, dtype=np.float32).reshape(-1, 49)
+    out = np.zeros(len(A))
+    lib().orc_ncc_patches(_p(A), _p(B), len(A), nthreads, _p(out))
+    return out
+
+
+def ncc_pairs(imgL, imgR, L, Rc, row_ptr, thr=0.6, math_mode=PORTABLE, nthreads=0):
+    imgL = np.ascontiguousarray(imgL, dtype=np.uint8)
+    imgR = np.ascontiguousarray(imgR, dtype=np.uint8)
+    h, w = imgL.shape
+    L = np.ascontiguousarray(L, dtype=EDGE_DTYPE)
+    Rc = np.ascontiguousarray(Rc, dtype=EDGE_DTYPE)
+    row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int32)
+    n = int(row_ptr[-1])
+    lp = np.zeros((len(L), 2, 49), dtype=np.float32)
+    sims = np.zeros((n, 4))
+    best = np.zeros(n)
+    keep = np.zeros(n, dtype=np.uint8)
+    lib().orc_ncc_pairs(_p(imgL), _p(imgR), h, w, C.c_ssize_t(imgL.strides[0]), C.c_ssize_t(imgR.strides[0]), _p(L),
+                        len(L), _p(Rc), _p(row_ptr), math_mode, nthreads, C.c_double(thr), _p(lp), _p(sims), _p(best),
+                        _p(keep))
+    return sims, best, keep, lp
+
+
+def ncc_quads(kfL, kfR, cfL, cfR, thr=0.8, nthreads=0):
+    arrs = [np.ascontiguousarray(a, dtype=np.float32).reshape(-1, 98) for a in (kfL, kfR, cfL, cfR)]
+    n = len(arrs[0])
+    sl, sr = np.zeros(n), np.zeros(n)
+    keep = np.zeros(n, dtype=np.uint8)
+    lib().orc_ncc_quads(*[_p(a) for a in arrs], n, nthreads, C.c_double(thr), _p(sl), _p(sr), _p(keep))
+    return sl, sr, keep
+
+
+def atan2_v(y, x, math_mode):
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.zeros(len(y))
+    lib().orc_atan2_v(_p(y), _p(x), len(y), math_mode, _p(out))
+    return out
+
+
+def sincos_v(t, math_mode):
+    t = np.ascontiguousarray(t, dtype=np.float64)
+    s, c = np.zeros(len(t)), np.zeros(len(t))
+    lib().orc_sincos_v(_p(t), len(t), math_mode, _p(s), _p(c))
+    return s, c

@@ -1,0 +1,89 @@
+"""GPU parity of the third-order edge detector, through the C ABI (ebvo_toed / ebvo_toed_pair).
+
+Bar: bit-exact (x, y, theta, index), counts and the sub-pixel magnitude list against the CPU
+oracle in portable-math mode; the reference's own known-answer "xyi" hashes at full size."""
+import numpy as np
+import pytest
+
+from edge_based_visual_odometry_amd import synth
+from tests import oracle as orc
+from tests.util import assert_bit_equal, assert_edges_equal, case_id, kat_cases, kat_image
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("case", kat_cases(), ids=case_id)
+def test_toed_matches_reference_known_answers(ctx, case):
+    """x, y, index of every edge hash to the value recorded from the reference source."""
+    img = kat_image(case)
+    assert synth.img_fnv(img) == case["img_fnv"]
+    r = ctx.toed(img)
+    assert len(r.edges) == case["kept"]
+    assert r.n_total == case["total"]
+    assert orc.edge_hash(r.edges, False) == case["xyi"]
+    if "e0" in case:
+        assert (r.edges[0]["x"], r.edges[0]["y"]) == tuple(case["e0"][:2])
+        assert abs(r.edges[0]["theta"] - case["e0"][2]) <= 1e-15 * abs(case["e0"][2]) * 4
+
+
+@pytest.mark.parametrize("shape,kind", [((48, 64), "s1"), ((48, 64), "s2"), ((100, 131), "s2"), ((33, 37), "s2"),
+                                        ((376, 1241), "s2"), ((480, 752), "s1")])
+def test_toed_bit_exact_vs_oracle(ctx, shape, kind):
+    h, w = shape
+    img = synth.s1_image(h, w, 5, 3) if kind == "s1" else synth.s2_image(h, w, 11, 4, 2)
+    ref = orc.toed(img, math_mode=orc.PORTABLE, want_all=True)
+    got = ctx.toed(img, want_all=True)
+    assert got.n_total == ref["n_total"]
+    assert_edges_equal(got.edges, ref["edges"])
+    assert_bit_equal(got.all4, ref["all4"], "subpix_edge_pts_final")
+    assert got.time_conv > 0 and got.time_nms > 0
+
+
+def test_toed_pair_equals_two_single_calls(ctx):
+    l, r = synth.stereo_pair("s2", 120, 200)
+    el, er, nt = ctx.toed_pair(l, r)
+    a, b = ctx.toed(l), ctx.toed(r)
+    assert_edges_equal(el, a.edges, "left")
+    assert_edges_equal(er, b.edges, "right")
+    assert nt == (a.n_total, b.n_total)
+
+
+def test_toed_flat_and_saturated_images_have_no_edges(ctx):
+    for v in (0, 255, 77):
+        r = ctx.toed(np.full((64, 96), v, dtype=np.uint8))
+        assert len(r.edges) == 0 and r.n_total == 0
+
+
+def test_toed_strided_input(ctx):
+    big = synth.s2_image(80, 160, 3, 9, 0)
+    view = big[:, 16:144]            # stride 160, width 128
+    assert not view.flags["C_CONTIGUOUS"]
+    a = ctx.toed(view)
+    b = ctx.toed(np.ascontiguousarray(view))
+    assert_edges_equal(a.edges, b.edges)
+
+
+def test_toed_capacity_error_reports_required_size(ctx):
+    from edge_based_visual_odometry_amd._lib import EbvoError, EBVO_ERR_CAPACITY
+    img = synth.s2_image(64, 96, 7, 1, 0)
+    full = ctx.toed(img)
+    assert len(full.edges) > 4
+    with pytest.raises(EbvoError) as ei:
+        ctx.toed(img, cap=3)
+    assert ei.value.status == EBVO_ERR_CAPACITY
+    assert f"kept={len(full.edges)}" in str(ei.value)
+
+
+def test_toed_rejects_bad_sizes(ctx):
+    from edge_based_visual_odometry_amd._lib import EbvoError, EBVO_ERR_ARG
+    with pytest.raises(EbvoError) as ei:
+        ctx.toed(np.zeros((ctx.max_h + 1, 64), dtype=np.uint8))
+    assert ei.value.status == EBVO_ERR_ARG
+    with pytest.raises(EbvoError):
+        ctx.toed(np.zeros((16, 16), dtype=np.uint8))
+
+
+def test_toed_idempotent(ctx):
+    img = synth.s2_image(376, 1241, 7, 1, 0)
+    a, b = ctx.toed(img), ctx.toed(img)
+    assert_edges_equal(a.edges, b.edges)
