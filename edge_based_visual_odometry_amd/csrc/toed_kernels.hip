@@ -20,6 +20,8 @@
 //   toed_rowscan_kernel  K3a: exclusive scan of the per-row counts
 //   toed_compact_kernel  K3b: ordered (raster) stream compaction of the flagged pixels
 //   toed_finalize_kernel K3c: dense per-edge epilogue (sub-pixel position, atan2, records)
+#include <cstring>
+
 #include "ebvo_internal.h"
 #include "ebvo_math.h"
 
@@ -73,12 +75,19 @@ const double h_TAP_HALF[4][19] = {
      -0.000914200719419500, -0.000190921146395817, -2.92094529738860e-05},
 };
 
-__constant__ double c_TAP_INT[4][19];
-__constant__ double c_TAP_HALF[4][19];
-// integer-phase products formed before touching the pixel (src/toed/cpu_toed.cpp:207-208):
-// c_PROD_FX[p+8][q+8] = Gx[q]*G[p],  c_PROD_FY[p+8][q+8] = G[q]*Gx[p]
-__constant__ double c_PROD_FX[17][17];
-__constant__ double c_PROD_FY[17][17];
+// Filter tables in device memory, passed to the kernel as one pointer (a kernel argument keeps
+// the base address in SGPRs; __constant__ symbols are reached through the GOT under -fPIC and
+// the compiler re-loads that address inside the tap loop).  Wave-uniform indices -> s_load.
+//   INT[4][19], HALF[4][19], then the integer-phase products formed before touching the pixel
+//   (src/toed/cpu_toed.cpp:207-208): PROD_FX[p+8][q+8] = Gx[q]*G[p], PROD_FY[p+8][q+8] = G[q]*Gx[p]
+struct ToedTables
+{
+    double tap_int[4][19];
+    double tap_half[4][19];
+    double prod_fx[17][17];
+    double prod_fy[17][17];
+};
+ToedTables *g_tables_dev[16] = {nullptr}; // per HIP device
 
 constexpr int TILE_W = 32;
 constexpr int TILE_H = 8;
@@ -135,7 +144,8 @@ __device__ inline void store_pair(double *plane, size_t o, double a, double b)
 }
 
 // K1 ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void toed_conv_kernel(ImgBatch B, int h, int w)
+__global__ __launch_bounds__(256) void toed_conv_kernel(ImgBatch B, const ToedTables *__restrict__ T, int h,
+                                                        int w)
 {
     __shared__ double tile[LDS_H][LDS_W];
     const uint8_t *__restrict__ img = B.img[blockIdx.z];
@@ -170,27 +180,50 @@ __global__ __launch_bounds__(256) void toed_conv_kernel(ImgBatch B, int h, int w
 #pragma unroll
         for (int d = 0; d < 4; ++d)
         {
-            ru[d] = c_TAP_INT[d][p + 9];
-            rs[d] = c_TAP_HALF[d][p + 9];
+            ru[d] = T->tap_int[d][p + 9];
+            rs[d] = T->tap_half[d][p + 9];
         }
         const bool row00 = (p >= -8) && (p <= 8);
         const int pr = row00 ? p + 8 : 0;
         const double *__restrict__ trow = &tile[ty + HALO - p][tx + HALO];
+        // software pipeline: the pixel and the column taps of tap q+1 are fetched while tap q is
+        // being accumulated, so the LDS / scalar-cache latency hides behind ~80 fp64 VALU ops
+        double vn = trow[HALO];
+        double kun[4], ksn[4], pxn, pyn;
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+        {
+            kun[d] = T->tap_int[d][0];
+            ksn[d] = T->tap_half[d][0];
+        }
+        pxn = T->prod_fx[pr][0];
+        pyn = T->prod_fy[pr][0];
 #pragma unroll 1
         for (int q = -HALO; q <= HALO; ++q)
         {
-            const double v = trow[-q];
+            const double v = vn, px = pxn, py = pyn;
             double cu[4], cs[4];
 #pragma unroll
             for (int d = 0; d < 4; ++d)
             {
-                cu[d] = v * c_TAP_INT[d][q + 9];
-                cs[d] = v * c_TAP_HALF[d][q + 9];
+                cu[d] = v * kun[d];
+                cs[d] = v * ksn[d];
             }
+            const int qn = min(q + 1, HALO);
+            const int qp = min(max(qn + 8, 0), 16);
+            vn = trow[-qn];
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+            {
+                kun[d] = T->tap_int[d][qn + 9];
+                ksn[d] = T->tap_half[d][qn + 9];
+            }
+            pxn = T->prod_fx[pr][qp];
+            pyn = T->prod_fy[pr][qp];
             if (row00 && q >= -8 && q <= 8) // wave-uniform
             {
-                a00[0] += v * c_PROD_FX[pr][q + 8];
-                a00[1] += v * c_PROD_FY[pr][q + 8];
+                a00[0] += v * px;
+                a00[1] += v * py;
                 a00[2] += cu[2] * ru[0];
                 a00[3] += cu[1] * ru[1];
                 a00[4] += cu[0] * ru[2];
@@ -451,17 +484,24 @@ __global__ __launch_bounds__(256) void toed_finalize_kernel(ImgBatch B, int h, i
 
 int toed_init_constants(ebvo_ctx *ctx)
 {
-    double fxp[17][17], fyp[17][17];
+    static ToedTables host;
+    memcpy(host.tap_int, h_TAP_INT, sizeof(h_TAP_INT));
+    memcpy(host.tap_half, h_TAP_HALF, sizeof(h_TAP_HALF));
     for (int p = -8; p <= 8; ++p)
         for (int q = -8; q <= 8; ++q)
         {
-            fxp[p + 8][q + 8] = h_TAP_INT[1][q + 9] * h_TAP_INT[0][p + 9];
-            fyp[p + 8][q + 8] = h_TAP_INT[0][q + 9] * h_TAP_INT[1][p + 9];
+            host.prod_fx[p + 8][q + 8] = h_TAP_INT[1][q + 9] * h_TAP_INT[0][p + 9];
+            host.prod_fy[p + 8][q + 8] = h_TAP_INT[0][q + 9] * h_TAP_INT[1][p + 9];
         }
-    EBVO_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(c_TAP_INT), h_TAP_INT, sizeof(h_TAP_INT)));
-    EBVO_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(c_TAP_HALF), h_TAP_HALF, sizeof(h_TAP_HALF)));
-    EBVO_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(c_PROD_FX), fxp, sizeof(fxp)));
-    EBVO_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(c_PROD_FY), fyp, sizeof(fyp)));
+    if (ctx->device < 0 || ctx->device >= 16)
+        return EBVO_ERR_ARG;
+    if (!g_tables_dev[ctx->device])
+    {
+        ToedTables *d = nullptr;
+        EBVO_HIP(ctx, hipMalloc(&d, sizeof(ToedTables)));
+        EBVO_HIP(ctx, hipMemcpy(d, &host, sizeof(ToedTables), hipMemcpyHostToDevice));
+        g_tables_dev[ctx->device] = d; // lives for the process; shared by every ctx on the device
+    }
     return EBVO_OK;
 }
 
@@ -497,7 +537,8 @@ int toed_run_device(ebvo_ctx *ctx, int n_img, int h, int w, float *ms_conv, floa
     {
         ProfScope ps(ctx, K_CONV);
         dim3 grid((w + TILE_W - 1) / TILE_W, (h + TILE_H - 1) / TILE_H, n_img);
-        hipLaunchKernelGGL(toed_conv_kernel, grid, dim3(256), 0, ctx->stream, B, h, w);
+        hipLaunchKernelGGL(toed_conv_kernel, grid, dim3(256), 0, ctx->stream, B,
+                           (const ToedTables *)g_tables_dev[ctx->device], h, w);
     }
     if (timed)
         EBVO_HIP(ctx, hipEventRecord(e1, ctx->stream));

@@ -123,7 +123,7 @@ def test_ncc_stored_patches_and_quads(ctx):
     q = [(rng.integers(0, 256, (n, 2, 49)) + rng.random((n, 2, 49))).astype(np.float32) for _ in range(2)]
     kfL, kfR = q
     cfL = (kfL[:, ::-1] * 0.8 + rng.normal(0, 10, kfL.shape)).astype(np.float32)
-    cfR = (kfR * 0.9 + rng.normal(0, 30, kfR.shape)).astype(np.float32)
+    cfR = (kfR * 0.9 + rng.normal(0, 1, kfR.shape) * rng.uniform(5, 150, (n, 1, 1))).astype(np.float32)
     sl, sr, keep = ctx.ncc_quads(kfL, kfR, cfL, cfR, 0.8)
     osl, osr, okeep = orc.ncc_quads(kfL, kfR, cfL, cfR, 0.8)
     assert_bit_equal(sl, osl, "sim_left")
