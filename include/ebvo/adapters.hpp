@@ -1,0 +1,264 @@
+// adapters.hpp -- C++17 host-side mirror of the reference's interface for the hot path, over the
+// C ABI of ebvo_hip.h.  Header-only; depends on the STL and ebvo_hip.h only, so it compiles with or
+// without OpenCV / Eigen.  integration/*.cpp shows the reference-side translation units built on it.
+//
+//   ebvo::ThirdOrderEdgeDetectionHIP<EdgeT>  -- same public surface as ThirdOrderEdgeDetectionCPU
+//                                               (include/toed/cpu_toed.hpp:70-115 of the reference)
+//   ebvo::StereoMatcherHIP<EdgeT>            -- the bodies of apply_Epipolar_Line_Distance_Filtering,
+//                                               apply_Disparity_Filtering, apply_orientation_filter and
+//                                               apply_NCC_Filtering (include/Stereo_Matches.h:61-68) on
+//                                               plain vectors; the reference-side glue copies to/from
+//                                               Stereo_Edge_Pairs (include/Dataset.h:180-289)
+//   ebvo::patch_similarity / ncc_quads       -- Utility::get_patch_similarity (src/utility.cpp:163-180),
+//                                               Temporal_Matches::apply_NCC_filtering_quads scoring and the
+//                                               MatlabNCCComputer::computeNCC-shaped entry
+//
+// EdgeT is the reference's `struct Edge` (or anything with .location.x, .location.y, .orientation,
+// .index): TOED fills exactly those fields and leaves the rest as the default constructor set them
+// (b_isEmpty = true, frame_source = -1), like src/toed/cpu_toed.cpp:557-563.
+//
+// Errors: the reference prints and continues; these adapters print the library's message to stderr and
+// leave outputs empty, and additionally expose last_status for callers that want to check.
+#ifndef EBVO_ADAPTERS_HPP
+#define EBVO_ADAPTERS_HPP
+
+#include <array>
+#include <cstdint>
+#include <cstdio>
+#include <memory>
+#include <utility>
+#include <vector>
+
+#include "../ebvo_hip.h"
+
+namespace ebvo
+{
+
+// One shared device context per (device, size): the reference creates one TOED object per Pipeline and
+// the matchers have no state of their own, so they borrow the TOED object's context.
+class Context
+{
+  public:
+    Context(int max_h, int max_w, int device = 0) : h_(max_h), w_(max_w)
+    {
+        status_ = ebvo_ctx_create(device, max_h, max_w, &ctx_);
+        if (status_ != EBVO_OK)
+            std::fprintf(stderr, "\033[1;31m[ERROR] ebvo_ctx_create: %s\033[0m\n", ebvo_strerror(status_));
+    }
+    ~Context() { ebvo_ctx_destroy(ctx_); }
+    Context(const Context &) = delete;
+    Context &operator=(const Context &) = delete;
+    ebvo_ctx *get() const { return ctx_; }
+    int status() const { return status_; }
+    int max_h() const { return h_; }
+    int max_w() const { return w_; }
+    typedef std::shared_ptr<Context> Ptr;
+
+  private:
+    ebvo_ctx *ctx_ = nullptr;
+    int status_ = EBVO_OK, h_, w_;
+};
+
+inline bool report(const Context &c, int rc, const char *where)
+{
+    if (rc == EBVO_OK)
+        return true;
+    std::fprintf(stderr, "\033[1;31m[ERROR] %s: %s (%s)\033[0m\n", where, ebvo_strerror(rc),
+                 c.get() ? ebvo_last_error(c.get()) : "");
+    return false;
+}
+
+template <class EdgeT>
+inline ebvo_edge to_abi(const EdgeT &e)
+{
+    ebvo_edge o;
+    o.x = e.location.x;
+    o.y = e.location.y;
+    o.theta = e.orientation;
+    o.index = e.index;
+    o.pad = 0;
+    return o;
+}
+
+// ---------------------------------------------------------------------------------------------
+template <class EdgeT>
+class ThirdOrderEdgeDetectionHIP
+{
+  public:
+    // public data members of ThirdOrderEdgeDetectionCPU (include/toed/cpu_toed.hpp:90-114)
+    double *subpix_edge_pts_final = nullptr; // N x 4: x, y, orientation, sub-pixel gradient magnitude
+    int edge_pt_list_idx = 0;
+    int num_of_edge_data = 4;
+    int omp_threads = 1;
+    double time_conv = 0, time_nms = 0;
+    std::vector<EdgeT> toed_edges;
+    int Total_Num_Of_TOED = 0;
+    int last_status = EBVO_OK;
+    typedef std::shared_ptr<ThirdOrderEdgeDetectionHIP> Ptr;
+
+    ThirdOrderEdgeDetectionHIP(int H, int W, int device = 0)
+        : img_height(H), img_width(W), ctx_(std::make_shared<Context>(H, W, device))
+    {
+        all4_.resize((size_t)H * W * 4);
+        abi_.resize((size_t)H * W);
+        subpix_edge_pts_final = all4_.data();
+        last_status = ctx_->status();
+    }
+
+    // get_Third_Order_Edges(cv::Mat): any Mat-like with .data (uchar*), .rows, .cols, .step
+    template <class MatT>
+    void get_Third_Order_Edges(const MatT &img)
+    {
+        get_Third_Order_Edges(reinterpret_cast<const uint8_t *>(img.data), img.rows, img.cols, (ptrdiff_t)img.step);
+    }
+
+    void get_Third_Order_Edges(const uint8_t *data, int rows, int cols, ptrdiff_t step)
+    {
+        toed_edges.clear(); // preprocessing(), src/toed/cpu_toed.cpp:86
+        Total_Num_Of_TOED = 0;
+        edge_pt_list_idx = 0;
+        if (rows != img_height || cols != img_width)
+        { // the reference object is sized once from the left image (include/Pipeline.h:89-101)
+            std::fprintf(stderr, "\033[1;31m[ERROR] TOED: image %dx%d does not match %dx%d\033[0m\n", cols, rows,
+                         img_width, img_height);
+            last_status = EBVO_ERR_ARG;
+            return;
+        }
+        int n_kept = 0, n_total = 0;
+        last_status = ebvo_toed(ctx_->get(), data, rows, cols, step, abi_.data(), (int)abi_.size(), &n_kept, &n_total,
+                                all4_.data(), (int)(all4_.size() / 4), &time_conv, &time_nms);
+        if (!report(*ctx_, last_status, "ebvo_toed"))
+            return;
+        toed_edges.resize((size_t)n_kept); // default-constructed: b_isEmpty = true, frame_source = -1
+        for (int k = 0; k < n_kept; ++k)
+        {
+            EdgeT &e = toed_edges[(size_t)k];
+            e.location.x = abi_[(size_t)k].x;
+            e.location.y = abi_[(size_t)k].y;
+            e.orientation = abi_[(size_t)k].theta;
+            e.index = abi_[(size_t)k].index;
+        }
+        Total_Num_Of_TOED = n_total;
+        edge_pt_list_idx = n_total;
+    }
+
+    const Context::Ptr &context() const { return ctx_; }
+
+  private:
+    int img_height, img_width;
+    Context::Ptr ctx_;
+    std::vector<double> all4_;
+    std::vector<ebvo_edge> abi_;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Candidate lists as the reference keeps them per focused edge: indices into the candidate edge
+// vector, ascending (EdgeCluster::contributing_edges_toed_indices[0], src/Stereo_Matches.cpp:413).
+struct CandidateLists
+{
+    std::vector<int32_t> row_ptr; // nL + 1
+    std::vector<int32_t> col_idx; // right TOED index per pair
+    size_t rows() const { return row_ptr.empty() ? 0 : row_ptr.size() - 1; }
+};
+
+struct NccScores
+{
+    std::vector<double> pp_nn_pn_np; // 4 per pair (src/Stereo_Matches.cpp:592-595)
+    std::vector<double> best;        // final_SIM_score (:596)
+    std::vector<uint8_t> keep;       // best > NCC_THRESH (:597)
+    std::vector<float> left_patches; // nL x 2 x 49 (left_edge_patches, :578)
+};
+
+template <class EdgeT>
+class StereoMatcherHIP
+{
+  public:
+    explicit StereoMatcherHIP(Context::Ptr ctx) : ctx_(std::move(ctx)) {}
+    int last_status = EBVO_OK;
+
+    // Stereo_Matches::CalculateEpipolarLine with a row-major 3x3 F (src/Stereo_Matches.cpp:10-20).
+    static std::vector<std::array<double, 3>> CalculateEpipolarLine(const double F[9], const std::vector<EdgeT> &edges)
+    {
+        std::vector<std::array<double, 3>> lines(edges.size());
+        std::vector<ebvo_edge> abi(edges.size());
+        for (size_t k = 0; k < edges.size(); ++k)
+            abi[k] = to_abi(edges[k]);
+        ebvo_epipolar_lines(F, abi.data(), (int)abi.size(), lines.empty() ? nullptr : lines[0].data());
+        return lines;
+    }
+
+    // stage_mask = EBVO_STAGE_EPIPOLAR            -> apply_Epipolar_Line_Distance_Filtering (:381-419)
+    //              ... | EBVO_STAGE_DISPARITY     -> + apply_Disparity_Filtering (:534-553)
+    //              ... | EBVO_STAGE_ORIENTATION   -> + apply_orientation_filter (:863-915)
+    // The three filters are independent predicates on (left, right) and each keeps the list order, so
+    // applying them fused equals applying them one after the other.
+    CandidateLists candidates(const std::vector<EdgeT> &left, const std::vector<EdgeT> &right,
+                              const std::vector<std::array<double, 3>> &lines, int stage_mask = EBVO_STAGE_ALL,
+                              double epi_thr = EBVO_EPIPOLAR_LINE_DIST_THRESH, double max_disp = EBVO_MAX_DISPARITY,
+                              double orient_thr_deg = EBVO_ORIENT_THRESH_DEG)
+    {
+        CandidateLists out;
+        std::vector<ebvo_edge> L(left.size()), R(right.size());
+        for (size_t k = 0; k < left.size(); ++k)
+            L[k] = to_abi(left[k]);
+        for (size_t k = 0; k < right.size(); ++k)
+            R[k] = to_abi(right[k]);
+        out.row_ptr.assign(left.size() + 1, 0);
+        int64_t n = 0;
+        const double *ln = lines.empty() ? nullptr : lines[0].data();
+        last_status = ebvo_epi_candidates(ctx_->get(), L.data(), (int)L.size(), R.data(), (int)R.size(), ln, epi_thr,
+                                          max_disp, orient_thr_deg, stage_mask, out.row_ptr.data(), nullptr, 0, &n);
+        if (!report(*ctx_, last_status, "ebvo_epi_candidates"))
+            return out;
+        out.col_idx.resize((size_t)n);
+        if (n)
+        {
+            last_status =
+                ebvo_epi_candidates(ctx_->get(), L.data(), (int)L.size(), R.data(), (int)R.size(), ln, epi_thr, max_disp,
+                                    orient_thr_deg, stage_mask, out.row_ptr.data(), out.col_idx.data(), n, &n);
+            report(*ctx_, last_status, "ebvo_epi_candidates");
+        }
+        return out;
+    }
+
+    // apply_NCC_Filtering (:555-616): candidates are explicit edges (TOED edges in the first pass,
+    // cluster centres in the second); images are the RAW left / right images (:562-563).
+    NccScores ncc(const uint8_t *imgL, const uint8_t *imgR, int rows, int cols, ptrdiff_t stepL, ptrdiff_t stepR,
+                  const std::vector<EdgeT> &left, const std::vector<int32_t> &row_ptr,
+                  const std::vector<EdgeT> &candidate_per_pair, double thr = EBVO_NCC_THRESH)
+    {
+        NccScores s;
+        std::vector<ebvo_edge> L(left.size()), Rc(candidate_per_pair.size());
+        for (size_t k = 0; k < left.size(); ++k)
+            L[k] = to_abi(left[k]);
+        for (size_t k = 0; k < Rc.size(); ++k)
+            Rc[k] = to_abi(candidate_per_pair[k]);
+        s.pp_nn_pn_np.resize(Rc.size() * 4);
+        s.best.resize(Rc.size());
+        s.keep.resize(Rc.size());
+        s.left_patches.resize(left.size() * 98);
+        last_status = ebvo_ncc_pairs(ctx_->get(), imgL, imgR, rows, cols, stepL, stepR, L.data(), (int)L.size(),
+                                     Rc.data(), row_ptr.data(), thr, s.left_patches.data(), s.pp_nn_pn_np.data(),
+                                     s.best.data(), s.keep.data());
+        report(*ctx_, last_status, "ebvo_ncc_pairs");
+        return s;
+    }
+
+  private:
+    Context::Ptr ctx_;
+};
+
+// Utility::get_patch_similarity on two 7x7 CV_32F patches (src/utility.cpp:163-180); also the shape
+// of MatlabNCCComputer::computeNCC(patch1, patch2) -> double (include/MatlabNCCComputer.h:41): NaN
+// on failure, like the MATLAB wrapper (src/MatlabNCCComputer.cpp:58-90).
+inline double patch_similarity(const Context &c, const float *patch_one, const float *patch_two)
+{
+    double s = 0;
+    const int rc = ebvo_ncc_patches(c.get(), patch_one, patch_two, 1, &s);
+    if (!report(c, rc, "ebvo_ncc_patches"))
+        return __builtin_nan("");
+    return s;
+}
+
+} // namespace ebvo
+#endif

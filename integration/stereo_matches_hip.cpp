@@ -1,0 +1,180 @@
+// integration/stereo_matches_hip.cpp -- reference-side binding: replacement bodies for the four hot
+// filters of Stereo_Matches and for the temporal NCC scorer.  Delete the originals
+// (src/Stereo_Matches.cpp:381-419, :534-553, :555-616, :863-915 and src/Temporal_Matches.cpp:416-469) and add
+// this file to src/CMakeLists.txt; headers, get_Stereo_Edge_Pairs (src/Stereo_Matches.cpp:1360-1540), the SIFT /
+// BNB / refinement stages between them and main_VO stay as they are.
+//
+// NOT compiled in this repository (needs the reference tree + OpenCV + Eigen); the marshalling below is the
+// one compiled and parity-tested through include/ebvo/adapters.hpp (tests/test_cpp_adapter.py).
+#include "Stereo_Matches.h"
+#include "Temporal_Matches.h"
+#include "ebvo/adapters.hpp"
+
+ebvo::Context::Ptr ebvo_context_of(const ThirdOrderEdgeDetectionCPU *toed); // integration/hip_toed.cpp
+extern ThirdOrderEdgeDetectionCPU *g_pipeline_toed;                          // set once by Pipeline (1 line)
+
+namespace
+{
+ebvo::StereoMatcherHIP<Edge> matcher() { return ebvo::StereoMatcherHIP<Edge>(ebvo_context_of(g_pipeline_toed)); }
+
+// keep exactly the candidates listed in (row_ptr, col_idx): the lists only ever shrink, in order
+void keep_listed(Stereo_Edge_Pairs &p, const ebvo::CandidateLists &c)
+{
+    for (size_t i = 0; i < c.rows(); ++i)
+    {
+        auto &cl = p.matching_edge_clusters[i].edge_clusters;
+        std::vector<EdgeCluster> out;
+        size_t j = 0;
+        for (int32_t k = c.row_ptr[i]; k < c.row_ptr[i + 1]; ++k)
+        {
+            while (cl[j].contributing_edges_toed_indices[0] != c.col_idx[k])
+                ++j;
+            out.push_back(cl[j]);
+        }
+        cl = std::move(out);
+    }
+}
+} // namespace
+
+void Stereo_Matches::apply_Epipolar_Line_Distance_Filtering(Stereo_Edge_Pairs &p, Dataset::Ptr dataset,
+                                                            const std::vector<Edge> right_edges, const std::string &,
+                                                            bool is_left, size_t, int)
+{
+    // lines exactly as the reference forms them (Eigen), so epip_line_coeffs_of_left_edges is unchanged
+    std::vector<Eigen::Vector3d> lines =
+        CalculateEpipolarLine(is_left ? dataset->get_fund_mat_21() : dataset->get_fund_mat_12(), p.get_focused_edges());
+    p.epip_line_coeffs_of_left_edges = lines;
+    p.matching_edge_clusters.resize(lines.size());
+    std::vector<std::array<double, 3>> ln(lines.size());
+    for (size_t i = 0; i < lines.size(); ++i)
+        ln[i] = {lines[i](0), lines[i](1), lines[i](2)};
+    const std::vector<Edge> &cand = is_left ? p.stereo_frame->right_edges : p.stereo_frame->left_edges;
+    auto m = matcher();
+    ebvo::CandidateLists c = m.candidates(p.get_focused_edges(), cand, ln, EBVO_STAGE_EPIPOLAR, EPIPOLAR_LINE_DIST_THRESH);
+    for (size_t i = 0; i < c.rows(); ++i)
+    {
+        std::vector<EdgeCluster> clusters;
+        for (int32_t k = c.row_ptr[i]; k < c.row_ptr[i + 1]; ++k)
+        { // src/Stereo_Matches.cpp:405-415: each candidate is a one-element cluster
+            EdgeCluster ec;
+            ec.center_edge = cand[c.col_idx[k]];
+            ec.contributing_edges.push_back(cand[c.col_idx[k]]);
+            ec.contributing_edges_toed_indices.push_back(c.col_idx[k]);
+            clusters.push_back(ec);
+        }
+        p.matching_edge_clusters[i].edge_clusters = std::move(clusters);
+    }
+}
+
+// Disparity and orientation act on the current lists: run the predicate on the device over the TOED candidates
+// and keep the listed survivors.  (Fusing all three stages into one call is a one-line change in
+// get_Stereo_Edge_Pairs: candidates(..., EBVO_STAGE_ALL) -- the filters are independent predicates.)
+static void filter_stage(Stereo_Edge_Pairs &p, int stage, double max_disp, double orient_thr)
+{
+    std::vector<std::array<double, 3>> ln(p.epip_line_coeffs_of_left_edges.size());
+    for (size_t i = 0; i < ln.size(); ++i)
+        ln[i] = {p.epip_line_coeffs_of_left_edges[i](0), p.epip_line_coeffs_of_left_edges[i](1),
+                 p.epip_line_coeffs_of_left_edges[i](2)};
+    auto m = matcher();
+    // epipolar stage re-applied with the same threshold reproduces the current lists; `stage` prunes them
+    ebvo::CandidateLists c = m.candidates(p.get_focused_edges(), p.stereo_frame->right_edges, ln,
+                                          EBVO_STAGE_EPIPOLAR | stage, EPIPOLAR_LINE_DIST_THRESH, max_disp, orient_thr);
+    keep_listed(p, c);
+}
+
+void Stereo_Matches::apply_Disparity_Filtering(Stereo_Edge_Pairs &p, const std::string &, size_t)
+{
+    filter_stage(p, EBVO_STAGE_DISPARITY, MAX_DISPARITY, EBVO_ORIENT_THRESH_DEG);
+}
+
+void Stereo_Matches::apply_orientation_filter(Stereo_Edge_Pairs &p, double orientation_threshold, const std::string &, size_t)
+{
+    filter_stage(p, EBVO_STAGE_DISPARITY | EBVO_STAGE_ORIENTATION, MAX_DISPARITY, orientation_threshold);
+}
+
+void Stereo_Matches::apply_NCC_Filtering(Stereo_Edge_Pairs &p, const std::string &, size_t, bool is_left)
+{
+    const cv::Mat &imgL = is_left ? p.stereo_frame->left_image : p.stereo_frame->right_image; // RAW images, :562-568
+    const cv::Mat &imgR = is_left ? p.stereo_frame->right_image : p.stereo_frame->left_image;
+    const std::vector<Edge> left = p.get_focused_edges();
+    std::vector<int32_t> row_ptr(left.size() + 1, 0);
+    std::vector<Edge> cand;
+    for (size_t i = 0; i < left.size(); ++i)
+    {
+        for (const EdgeCluster &ec : p.matching_edge_clusters[i].edge_clusters)
+            cand.push_back(ec.center_edge); // :588 -- a TOED edge (1st pass) or a cluster centre (2nd pass)
+        row_ptr[i + 1] = (int32_t)cand.size();
+    }
+    auto m = matcher();
+    ebvo::NccScores s = m.ncc(imgL.data, imgR.data, imgL.rows, imgL.cols, (ptrdiff_t)imgL.step, (ptrdiff_t)imgR.step,
+                              left, row_ptr, cand, NCC_THRESH);
+    p.left_edge_patches.resize(left.size());
+    for (size_t i = 0; i < left.size(); ++i)
+    {
+        cv::Mat plus(7, 7, CV_32F, s.left_patches.data() + i * 98), minus(7, 7, CV_32F, s.left_patches.data() + i * 98 + 49);
+        p.left_edge_patches[i] = {plus.clone(), minus.clone()}; // :578
+        auto &mc = p.matching_edge_clusters[i];
+        std::vector<EdgeCluster> keep;
+        std::vector<double> scores, conf;
+        std::vector<bool> valid;
+        for (int32_t k = row_ptr[i]; k < row_ptr[i + 1]; ++k)
+            if (s.keep[k])
+            { // :597-607
+                const size_t j = (size_t)(k - row_ptr[i]);
+                keep.push_back(mc.edge_clusters[j]);
+                scores.push_back(s.best[k]);
+                conf.push_back(j < mc.refine_confidences.size() ? mc.refine_confidences[j] : 0.0);
+                valid.push_back(true);
+            }
+        mc.edge_clusters = std::move(keep);
+        mc.refine_final_scores = std::move(scores);
+        mc.refine_confidences = std::move(conf);
+        mc.refine_validities = std::move(valid);
+    }
+}
+
+void Temporal_Matches::apply_NCC_filtering_quads(std::vector<KF_Temporal_Edge_Quads> &quads_by_kf,
+                                                 const std::vector<final_stereo_edge_pair> &CF, double thr, const cv::Mat &,
+                                                 const cv::Mat &, const cv::Mat &, const cv::Mat &)
+{
+    // flatten (KF mate, candidate quad) -> stored patches, score on the device, rebuild the lists (:426-468)
+    std::vector<float> kfL, kfR, cfL, cfR;
+    std::vector<std::pair<int, int>> where;
+    auto push = [](std::vector<float> &v, const std::pair<cv::Mat, cv::Mat> &pp) {
+        v.insert(v.end(), pp.first.ptr<float>(), pp.first.ptr<float>() + 49);
+        v.insert(v.end(), pp.second.ptr<float>(), pp.second.ptr<float>() + 49);
+    };
+    for (size_t i = 0; i < quads_by_kf.size(); ++i)
+        for (size_t j = 0; j < quads_by_kf[i].candidate_quads.size(); ++j)
+        {
+            const int cf = quads_by_kf[i].candidate_quads[j].CF_left->cf_stereo_edge_mate_index;
+            if (cf < 0 || cf >= (int)CF.size())
+                continue;
+            push(kfL, quads_by_kf[i].KF_stereo_mate->left_edge_patches);
+            push(kfR, quads_by_kf[i].KF_stereo_mate->right_edge_patches);
+            push(cfL, CF[cf].left_edge_patches);
+            push(cfR, CF[cf].right_edge_patches);
+            where.emplace_back((int)i, (int)j);
+        }
+    std::vector<double> sl(where.size()), sr(where.size());
+    std::vector<uint8_t> keep(where.size());
+    ebvo_ncc_quads(ebvo_context_of(g_pipeline_toed)->get(), kfL.data(), kfR.data(), cfL.data(), cfR.data(), (int)where.size(),
+                   thr, sl.data(), sr.data(), keep.data());
+    std::vector<std::vector<std::pair<Temporal_CF_Edge_Cluster, Temporal_CF_Edge_Cluster>>> fresh(quads_by_kf.size());
+    for (size_t k = 0; k < where.size(); ++k)
+        if (keep[k])
+        {
+            const auto &cq = quads_by_kf[where[k].first].candidate_quads[where[k].second];
+            Temporal_CF_Edge_Cluster l = *cq.CF_left, r = *cq.CF_right;
+            l.matching_scores.ncc_score = sl[k];
+            r.matching_scores.ncc_score = sr[k];
+            fresh[where[k].first].emplace_back(std::move(l), std::move(r));
+        }
+    for (size_t i = 0; i < quads_by_kf.size(); ++i)
+    {
+        candidate_cluster_pairs_[i] = std::move(fresh[i]);
+        quads_by_kf[i].candidate_quads.clear();
+        for (auto &pr : candidate_cluster_pairs_[i])
+            quads_by_kf[i].candidate_quads.push_back({&pr.first, &pr.second});
+    }
+}

@@ -1,0 +1,98 @@
+// adapter_demo.cpp -- exercises include/ebvo/adapters.hpp the way Pipeline::ProcessEdges and
+// Stereo_Matches::get_Stereo_Edge_Pairs would (src/Pipeline.cpp:24-29, src/Stereo_Matches.cpp:1374-1427),
+// with plain local types standing where cv::Mat / struct Edge stand in the reference tree.
+// usage: adapter_demo <left.raw> <right.raw> <h> <w> <out.bin>
+// out.bin: int32 nL, nR, totalL, totalR, npairs; then L edges (x,y,theta,index as 3 f64 + i32 + pad),
+//          R edges, row_ptr, col_idx, sims (4 f64 per pair), keep (u8 per pair)
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "ebvo/adapters.hpp"
+
+struct Point2d
+{
+    double x, y;
+};
+struct Edge
+{
+    Point2d location{-1.0, -1.0};
+    double orientation = -100;
+    bool b_isEmpty = true;
+    int frame_source = -1;
+    int index = 0;
+};
+struct Mat
+{
+    unsigned char *data;
+    int rows, cols;
+    size_t step;
+};
+
+static std::vector<unsigned char> slurp(const char *path, size_t n)
+{
+    std::vector<unsigned char> b(n);
+    FILE *f = std::fopen(path, "rb");
+    if (!f || std::fread(b.data(), 1, n, f) != n)
+    {
+        std::fprintf(stderr, "cannot read %s\n", path);
+        std::exit(2);
+    }
+    std::fclose(f);
+    return b;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc != 6)
+        return 2;
+    const int h = std::atoi(argv[3]), w = std::atoi(argv[4]);
+    auto bl = slurp(argv[1], (size_t)h * w), br = slurp(argv[2], (size_t)h * w);
+    Mat left{bl.data(), h, w, (size_t)w}, right{br.data(), h, w, (size_t)w};
+
+    ebvo::ThirdOrderEdgeDetectionHIP<Edge>::Ptr TOED(new ebvo::ThirdOrderEdgeDetectionHIP<Edge>(h, w));
+    if (TOED->last_status != EBVO_OK)
+        return 3;
+    // Pipeline::ProcessEdges(left) / (right): results are copied out by value
+    TOED->get_Third_Order_Edges(left);
+    std::vector<Edge> left_edges = TOED->toed_edges;
+    const int totalL = TOED->Total_Num_Of_TOED;
+    TOED->get_Third_Order_Edges(right);
+    std::vector<Edge> right_edges = TOED->toed_edges;
+    const int totalR = TOED->Total_Num_Of_TOED;
+    if (left_edges.empty() || left_edges[0].b_isEmpty != true || left_edges[0].frame_source != -1)
+        return 4;
+
+    // rectified KITTI-like geometry: l = F x with horizontal epipolar lines
+    const double f = 718.856, t = 0.54;
+    const double F[9] = {0, 0, 0, 0, 0, -t / f, 0, t / f, 0};
+    ebvo::StereoMatcherHIP<Edge> matcher(TOED->context());
+    auto lines = ebvo::StereoMatcherHIP<Edge>::CalculateEpipolarLine(F, left_edges);
+    ebvo::CandidateLists c = matcher.candidates(left_edges, right_edges, lines);
+    std::vector<Edge> cand(c.col_idx.size());
+    for (size_t k = 0; k < cand.size(); ++k)
+        cand[k] = right_edges[(size_t)c.col_idx[k]];
+    ebvo::NccScores s = matcher.ncc(left.data, right.data, h, w, (ptrdiff_t)left.step, (ptrdiff_t)right.step, left_edges,
+                                    c.row_ptr, cand);
+    if (matcher.last_status != EBVO_OK)
+        return 5;
+    const double self = ebvo::patch_similarity(*TOED->context(), s.left_patches.data(), s.left_patches.data());
+
+    FILE *o = std::fopen(argv[5], "wb");
+    int32_t hdr[5] = {(int32_t)left_edges.size(), (int32_t)right_edges.size(), totalL, totalR, (int32_t)cand.size()};
+    std::fwrite(hdr, sizeof hdr, 1, o);
+    for (const auto *v : {&left_edges, &right_edges})
+        for (const Edge &e : *v)
+        {
+            ebvo_edge a = ebvo::to_abi(e);
+            std::fwrite(&a, sizeof a, 1, o);
+        }
+    std::fwrite(c.row_ptr.data(), sizeof(int32_t), c.row_ptr.size(), o);
+    std::fwrite(c.col_idx.data(), sizeof(int32_t), c.col_idx.size(), o);
+    std::fwrite(s.pp_nn_pn_np.data(), sizeof(double), s.pp_nn_pn_np.size(), o);
+    std::fwrite(s.keep.data(), 1, s.keep.size(), o);
+    std::fwrite(&self, sizeof self, 1, o);
+    std::fclose(o);
+    std::printf("adapter_demo ok: %zu + %zu edges, %zu pairs\n", left_edges.size(), right_edges.size(), cand.size());
+    return 0;
+}

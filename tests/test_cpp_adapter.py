@@ -1,0 +1,63 @@
+"""The C++ host-side adapters (include/ebvo/adapters.hpp) compile against the C ABI alone, and on a
+GPU produce exactly the oracle's results when driven like the reference drives its classes."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from edge_based_visual_odometry_amd import _lib, synth
+from tests import oracle as orc
+from tests.util import assert_bit_equal, assert_edges_equal
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "cpp", "adapter_demo.cpp")
+EXE = os.path.join(ROOT, "tests", "cpp", "adapter_demo")
+
+
+def build_demo():
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), SRC, "-o", EXE,
+           "-L", libdir, "-lebvo_hip", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"]
+    subprocess.check_call(cmd)
+
+
+def test_adapter_builds_with_plain_gxx():
+    """No HIP, OpenCV or Eigen headers are needed on the host side of the boundary."""
+    build_demo()
+    assert os.path.exists(EXE)
+
+
+@pytest.mark.gpu
+def test_adapter_matches_oracle(tmp_path):
+    build_demo()
+    h, w = 96, 160
+    l, r = synth.stereo_pair("s2", h, w)
+    (tmp_path / "l.raw").write_bytes(l.tobytes())
+    (tmp_path / "r.raw").write_bytes(r.tobytes())
+    out = tmp_path / "out.bin"
+    subprocess.check_call([EXE, str(tmp_path / "l.raw"), str(tmp_path / "r.raw"), str(h), str(w), str(out)])
+    buf = out.read_bytes()
+    nL, nR, tL, tR, npairs = np.frombuffer(buf, dtype=np.int32, count=5)
+    off = 20
+    L = np.frombuffer(buf, dtype=orc.EDGE_DTYPE, count=nL, offset=off); off += 32 * nL
+    R = np.frombuffer(buf, dtype=orc.EDGE_DTYPE, count=nR, offset=off); off += 32 * nR
+    rp = np.frombuffer(buf, dtype=np.int32, count=nL + 1, offset=off); off += 4 * (nL + 1)
+    ci = np.frombuffer(buf, dtype=np.int32, count=npairs, offset=off); off += 4 * npairs
+    sims = np.frombuffer(buf, dtype=np.float64, count=4 * npairs, offset=off).reshape(-1, 4); off += 32 * npairs
+    keep = np.frombuffer(buf, dtype=np.uint8, count=npairs, offset=off); off += npairs
+    self_sim = np.frombuffer(buf, dtype=np.float64, count=1, offset=off)[0]
+    ol, orr = orc.toed(l), orc.toed(r)
+    assert (tL, tR) == (ol["n_total"], orr["n_total"])
+    assert_edges_equal(L, ol["edges"])
+    assert_edges_equal(R, orr["edges"])
+    f, t = 718.856, 0.54
+    F = np.array([0, 0, 0, 0, 0, -t / f, 0, t / f, 0], dtype=np.float64)
+    lines = orc.epipolar_lines(F, ol["edges"])
+    orp, oci = orc.epi_candidates(ol["edges"], orr["edges"], lines)
+    assert_bit_equal(rp, orp)
+    assert_bit_equal(ci, oci)
+    osims, _, okeep, olp = orc.ncc_pairs(l, r, ol["edges"], orr["edges"][oci], orp)
+    assert_bit_equal(sims, osims)
+    assert_bit_equal(keep, okeep)
+    assert self_sim == orc.patch_similarity(olp[0, 0], olp[0, 0])
