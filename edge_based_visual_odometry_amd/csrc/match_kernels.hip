@@ -10,12 +10,15 @@
 //   Temporal_Matches::apply_NCC_filtering_quads (scoring)      src/Temporal_Matches.cpp:426-468
 //
 // Candidate search.  The reference scans all N_R right edges for each of the N_L left edges
-// (O(N_L * N_R) fp64 predicates).  Here the right edges are summarised by two levels of bounding
-// boxes over consecutive index ranges (32 edges per chunk, 32 chunks per group); a left edge
-// visits only the boxes that can intersect {epipolar band} ∩ {disparity square}, in index order,
-// and evaluates the reference's exact predicates on the survivors.  The boxes are a conservative
-// pre-filter only: the result (set AND order, ascending right index) is identical to the brute
-// force for any input order; TOED's raster order just makes the boxes tight.
+// (O(N_L * N_R) fp64 predicates).  Here the right edges are summarised by bounding boxes over
+// consecutive index ranges (16 edges per chunk).  A block owns 256 consecutive left edges: it
+// selects, in index order, the chunks whose box can intersect the union of its lefts' search
+// regions ({epipolar band} ∩ {disparity square}), stages their edges in LDS, and then every lane
+// walks only the staged chunks that can intersect ITS region and evaluates the reference's exact
+// predicates on their edges -- all from LDS, in ascending right index.  The boxes are a conservative
+// pre-filter only: the result (set AND order) is identical to the brute force for any input order;
+// TOED's raster order just makes the boxes tight.  The exact predicates avoid the fp64 division and
+// square root except within 2^-50 of a threshold (see pair_passes).
 //
 // NCC.  16 lanes cooperate on one (left edge, candidate) pair: lanes 0-6 hold the rows of the
 // "plus" patch, lanes 8-14 the rows of the "minus" patch (lanes 7 and 15 carry +0.0).  A 49-term
@@ -30,8 +33,9 @@
 namespace
 {
 
-constexpr int CHUNK = 32;  // edges per chunk box
-constexpr int GROUP = 32;  // chunks per group box
+constexpr int CHUNK = 16;        // edges per chunk box
+constexpr int GROUP = 64;        // chunks per group box (1024 edges)
+constexpr int BATCH = 64;        // chunks staged in LDS at a time (1024 edges, 24 KB)
 constexpr double BOX_SLACK = 1e-6;
 
 struct Box
@@ -120,32 +124,101 @@ __device__ inline bool box_may_match(const Box &bx, double xl, double yl, double
     return true;
 }
 
-// The reference's predicates, in its arithmetic.
-__device__ inline bool pair_passes(double lx, double ly, double lth, double rx, double ry, double rth, double a,
-                                   double b, double c, double nrm, const CandParams &P)
+// Per-left-edge constants of the predicates.
+struct LeftCtx
+{
+    double lx, ly, lth;
+    double a, b, c, nrm;    // epipolar line and sqrt(a*a + b*b) (src/Stereo_Matches.cpp:99)
+    double ah, bh, ch;      // normalised line, for the conservative box tests only
+    double t_lo, t_hi;      // epi_thr * nrm * (1 -+ 2^-50)
+    double s_lo, s_hi;      // max_disp^2 * (1 -+ 2^-50)
+};
+
+// The reference's predicates, bit-exact.
+//   epipolar (:99-101):  fl(|a x + b y + c| / nrm) < thr.   With t = fl(thr*nrm): |num| < t(1-2^-50) implies the
+//     rounded quotient is < thr, |num| > t(1+2^-50) implies it is >= thr (division is monotone and correctly rounded,
+//     all roundings involved are <= 2^-53 relative); only inside that sliver is the division evaluated.
+//   disparity (:545-546): fl(sqrt(fl(dx*dx + dy*dy))) <= D, same argument on s = fl(dx*dx + dy*dy) against D^2.
+//   orientation (:887-901): as written.
+__device__ inline bool pair_passes(const LeftCtx &l, double rx, double ry, double rth, const CandParams &P)
 {
     if (P.mask & EBVO_STAGE_EPIPOLAR)
-    { // src/Stereo_Matches.cpp:99-101
-        const double d = fabs(a * rx + b * ry + c) / nrm;
-        if (!(d < P.epi_thr))
-            return false;
+    {
+        const double num = fabs(l.a * rx + l.b * ry + l.c);
+        if (!(num < l.t_lo))
+        {
+            if (!(num <= l.t_hi)) // also catches NaN
+                return false;
+            if (!(num / l.nrm < P.epi_thr))
+                return false;
+        }
     }
     if (P.mask & EBVO_STAGE_DISPARITY)
-    { // :545-546
-        const double dx = lx - rx, dy = ly - ry;
-        const double disp = sqrt(dx * dx + dy * dy);
-        if (!(disp <= P.max_disp))
-            return false;
+    {
+        const double dx = l.lx - rx, dy = l.ly - ry;
+        const double s = dx * dx + dy * dy;
+        if (!(s < l.s_lo))
+        {
+            if (!(s <= l.s_hi))
+                return false;
+            if (!(sqrt(s) <= P.max_disp))
+                return false;
+        }
     }
     if (P.mask & EBVO_STAGE_ORIENTATION)
-    { // :887-901
-        double od = fabs((lth - rth) * 0x1.ca5dc1a63c1f8p+5 /* 180.0 / M_PI */);
+    {
+        double od = fabs((l.lth - rth) * 0x1.ca5dc1a63c1f8p+5 /* 180.0 / M_PI */);
         if (od > 180.0)
             od = 360.0 - od;
         if (!(od < P.orient_thr || fabs(od - 180.0) < P.orient_thr))
             return false;
     }
     return true;
+}
+
+// Conservative bounding box of one left edge's search region {band} ∩ {disparity square}.
+__device__ inline Box region_box(const LeftCtx &l, double D, double band, int mask)
+{
+    const double inf = __builtin_inf();
+    Box r;
+    r.x0 = -inf; r.x1 = inf; r.y0 = -inf; r.y1 = inf;
+    if (mask & EBVO_STAGE_DISPARITY)
+    {
+        r.x0 = l.lx - D; r.x1 = l.lx + D; r.y0 = l.ly - D; r.y1 = l.ly + D;
+    }
+    if ((mask & EBVO_STAGE_EPIPOLAR) && (mask & EBVO_STAGE_DISPARITY) && l.ah == l.ah && l.bh == l.bh && l.ch == l.ch)
+    {
+        // |ah x + bh y + ch| <= band inside the square: bound y from the x-range, then x from the y-range
+        const double m = 1e-9; // below this slope the other coordinate is unconstrained
+        if (fabs(l.bh) > m)
+        {
+            const double ya = -(l.ah * r.x0 + l.ch) / l.bh, yb = -(l.ah * r.x1 + l.ch) / l.bh;
+            const double e = band / fabs(l.bh) + BOX_SLACK;
+            r.y0 = fmax(r.y0, fmin(ya, yb) - e);
+            r.y1 = fmin(r.y1, fmax(ya, yb) + e);
+        }
+        if (fabs(l.ah) > m)
+        {
+            const double xa = -(l.bh * r.y0 + l.ch) / l.ah, xb = -(l.bh * r.y1 + l.ch) / l.ah;
+            const double e = band / fabs(l.ah) + BOX_SLACK;
+            r.x0 = fmax(r.x0, fmin(xa, xb) - e);
+            r.x1 = fmin(r.x1, fmax(xa, xb) + e);
+        }
+    }
+    return r;
+}
+
+__device__ inline double wave_min(double v)
+{
+    for (int d = 32; d > 0; d >>= 1)
+        v = fmin(v, __shfl_xor(v, d));
+    return v;
+}
+__device__ inline double wave_max(double v)
+{
+    for (int d = 32; d > 0; d >>= 1)
+        v = fmax(v, __shfl_xor(v, d));
+    return v;
 }
 
 template <bool FILL>
@@ -158,39 +231,133 @@ __global__ __launch_bounds__(256) void candidates_kernel(const ebvo_edge *__rest
                                                          int32_t *__restrict__ col_idx,
                                                          unsigned long long *__restrict__ total)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ double s_x[BATCH * CHUNK], s_y[BATCH * CHUNK], s_th[BATCH * CHUNK];
+    __shared__ Box s_box[BATCH];
+    __shared__ int s_round[256];   // chunks selected in the current round, ascending
+    __shared__ int s_groups[256];  // groups selected in the current group round, ascending
+    __shared__ int s_wcnt[4];
+    __shared__ double s_red[4][4];
+    __shared__ unsigned long long s_tot[4];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int i = blockIdx.x * 256 + tid;
     const bool live = i < P.nL;
     const int il = live ? i : 0;
-    const double lx = L[il].x, ly = L[il].y, lth = L[il].theta;
-    const double a = lines[(size_t)il * 3], b = lines[(size_t)il * 3 + 1], c = lines[(size_t)il * 3 + 2];
-    const double nrm = sqrt((a * a) + (b * b)); // src/Stereo_Matches.cpp:99
-    const double ah = a / nrm, bh = b / nrm, ch = c / nrm;
+    LeftCtx l;
+    l.lx = L[il].x; l.ly = L[il].y; l.lth = L[il].theta;
+    l.a = lines[(size_t)il * 3]; l.b = lines[(size_t)il * 3 + 1]; l.c = lines[(size_t)il * 3 + 2];
+    l.nrm = sqrt((l.a * l.a) + (l.b * l.b));
+    l.ah = l.a / l.nrm; l.bh = l.b / l.nrm; l.ch = l.c / l.nrm;
+    const double t = P.epi_thr * l.nrm;
+    l.t_lo = t * (1.0 - 0x1p-50); l.t_hi = t * (1.0 + 0x1p-50);
+    const double d2 = P.max_disp * P.max_disp;
+    l.s_lo = d2 * (1.0 - 0x1p-50); l.s_hi = d2 * (1.0 + 0x1p-50);
     const double D = P.max_disp + BOX_SLACK, band = P.epi_thr + BOX_SLACK;
+
+    // union of the block's search regions
+    Box rb = region_box(l, D, band, P.mask);
+    const double inf = __builtin_inf();
+    if (!live) { rb.x0 = inf; rb.x1 = -inf; rb.y0 = inf; rb.y1 = -inf; }
+    {
+        const double a0 = wave_min(rb.x0), a1 = wave_max(rb.x1), b0 = wave_min(rb.y0), b1 = wave_max(rb.y1);
+        if (lane == 0) { s_red[wid][0] = a0; s_red[wid][1] = a1; s_red[wid][2] = b0; s_red[wid][3] = b1; }
+    }
+    __syncthreads();
+    Box U;
+    U.x0 = fmin(fmin(s_red[0][0], s_red[1][0]), fmin(s_red[2][0], s_red[3][0]));
+    U.x1 = fmax(fmax(s_red[0][1], s_red[1][1]), fmax(s_red[2][1], s_red[3][1]));
+    U.y0 = fmin(fmin(s_red[0][2], s_red[1][2]), fmin(s_red[2][2], s_red[3][2]));
+    U.y1 = fmax(fmax(s_red[0][3], s_red[1][3]), fmax(s_red[2][3], s_red[3][3]));
+
     int n = 0;
     int32_t o = FILL ? row_ptr[il] : 0;
-    for (int g = 0; live && g < P.ngroups; ++g)
-    {
-        if (!box_may_match(gb[g], lx, ly, ah, bh, ch, D, band, P.mask))
-            continue;
-        const int c1 = min(P.nchunks, (g + 1) * GROUP);
-        for (int cc = g * GROUP; cc < c1; ++cc)
+    // Two levels of index-range boxes: groups of 64 chunks first (one test per thread), then the chunks of the
+    // selected groups, four groups (256 chunks) at a time.  Every selection is an ordered compaction, so chunks
+    // are visited in ascending index.
+    auto compact = [&](bool sel, int value, int *list) -> int {
+        const unsigned long long m = __ballot(sel);
+        if (lane == 0)
+            s_wcnt[wid] = __popcll(m);
+        __syncthreads();
+        int pre = 0, tot = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
         {
-            if (!box_may_match(cb[cc], lx, ly, ah, bh, ch, D, band, P.mask))
-                continue;
-            const int k1 = min(P.nR, (cc + 1) * CHUNK);
-            for (int k = cc * CHUNK; k < k1; ++k)
+            if (k < wid) pre += s_wcnt[k];
+            tot += s_wcnt[k];
+        }
+        if (sel)
+            list[pre + __popcll(m & ((1ull << lane) - 1ull))] = value;
+        __syncthreads();
+        return tot;
+    };
+    auto meets_union = [&](const Box &bx) {
+        return !(bx.x0 > U.x1 || bx.x1 < U.x0 || bx.y0 > U.y1 || bx.y1 < U.y0);
+    };
+
+    for (int g0 = 0; g0 < P.ngroups; g0 += 256)
+    {
+        const int g = g0 + tid;
+        const int ngsel = compact(g < P.ngroups && meets_union(gb[g < P.ngroups ? g : 0]), g, s_groups);
+        for (int q = 0; q < ngsel; q += 4)
+        {
+            // ---- chunks of up to four selected groups: one chunk per thread
+            const int gq = q + (tid >> 6);
+            const int c = (gq < ngsel) ? s_groups[gq] * GROUP + (tid & 63) : P.nchunks;
+            const int nsel = compact(c < P.nchunks && meets_union(cb[c < P.nchunks ? c : 0]), c, s_round);
+            for (int b0 = 0; b0 < nsel; b0 += BATCH)
             {
-                const double rx = R[k].x, ry = R[k].y;
-                if (P.mask & EBVO_STAGE_DISPARITY)
-                    if (fabs(lx - rx) > D || fabs(ly - ry) > D)
-                        continue;
-                if (pair_passes(lx, ly, lth, rx, ry, R[k].theta, a, b, c, nrm, P))
+                const int mb = min(BATCH, nsel - b0);
+                // ---- stage the batch: edges and boxes of the selected chunks
+                for (int idx = tid; idx < mb * CHUNK; idx += 256)
                 {
-                    if (FILL)
-                        col_idx[o++] = k;
-                    else
-                        ++n;
+                    const int k = s_round[b0 + idx / CHUNK] * CHUNK + (idx % CHUNK);
+                    double x = __builtin_nan(""), y = x, th = x; // NaN fails every predicate
+                    if (k < P.nR)
+                    {
+                        x = R[k].x; y = R[k].y; th = R[k].theta;
+                    }
+                    s_x[idx] = x; s_y[idx] = y; s_th[idx] = th;
                 }
+                if (tid < mb)
+                    s_box[tid] = cb[s_round[b0 + tid]];
+                __syncthreads();
+                // ---- every lane walks the staged chunks that can meet ITS region
+                if (live)
+                {
+                    // which staged chunks can meet this lane's region (uniform loop, one bit per chunk) ...
+                    unsigned long long pm = 0;
+                    for (int j = 0; j < mb; ++j)
+                        if (box_may_match(s_box[j], l.lx, l.ly, l.ah, l.bh, l.ch, D, band, P.mask))
+                            pm |= 1ull << j;
+                    // ... then each lane visits ITS chunks, ascending; lanes advance by rank, not by chunk id
+                    while (pm)
+                    {
+                        const int j = __ffsll((long long)pm) - 1;
+                        pm &= pm - 1;
+                        const int kbase = s_round[b0 + j] * CHUNK;
+                        unsigned hits = 0;
+#pragma unroll
+                        for (int e = 0; e < CHUNK; ++e)
+                        {
+                            const int idx = j * CHUNK + e;
+                            const bool ok = pair_passes(l, s_x[idx], s_y[idx], s_th[idx], P);
+                            hits |= (ok ? 1u : 0u) << e;
+                        }
+                        if (FILL)
+                        {
+                            while (hits)
+                            {
+                                const int e = __ffs((int)hits) - 1;
+                                hits &= hits - 1;
+                                col_idx[o++] = kbase + e;
+                            }
+                        }
+                        else
+                            n += __popc(hits);
+                    }
+                }
+                __syncthreads();
             }
         }
     }
@@ -199,18 +366,17 @@ __global__ __launch_bounds__(256) void candidates_kernel(const ebvo_edge *__rest
         if (live)
             cnt[i] = n;
         // 64-bit total (one atomic per block) guards the int32 CSR offsets
-        __shared__ unsigned long long wsum[4];
         unsigned long long s = (unsigned long long)n;
         for (int d = 32; d > 0; d >>= 1)
             s += __shfl_down(s, d);
-        if ((threadIdx.x & 63) == 0)
-            wsum[threadIdx.x >> 6] = s;
+        if (lane == 0)
+            s_tot[wid] = s;
         __syncthreads();
-        if (threadIdx.x == 0)
+        if (tid == 0)
         {
-            const unsigned long long t = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-            if (t)
-                atomicAdd(total, t);
+            const unsigned long long tt = s_tot[0] + s_tot[1] + s_tot[2] + s_tot[3];
+            if (tt)
+                atomicAdd(total, tt);
         }
     }
 }
