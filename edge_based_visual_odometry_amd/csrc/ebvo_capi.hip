@@ -151,7 +151,7 @@ extern "C" void ebvo_ctx_destroy(ebvo_ctx *ctx)
     }
     GrowBuf *bufs[] = {&ctx->lines,      &ctx->boxes_chunk,  &ctx->boxes_group,  &ctx->cand_cnt,  &ctx->row_ptr,
                        &ctx->scan_tmp,   &ctx->col_idx,      &ctx->rc_edges,     &ctx->sims,      &ctx->best,
-                       &ctx->keep,       &ctx->patches_raw,  &ctx->patches_norm, &ctx->patches_flag,
+                       &ctx->keep,       &ctx->patches_raw,  &ctx->patches_norm, &ctx->patches_flag, &ctx->patches_norm_r, &ctx->patches_flag_r,
                        &ctx->match_cnt,  &ctx->scratch_a,    &ctx->scratch_b,    &ctx->scratch_c, &ctx->scratch_d};
     for (GrowBuf *b : bufs)
         free_buf(*b);
@@ -615,13 +615,36 @@ extern "C" int ebvo_stereo_run(ebvo_ctx *ctx, const ebvo_stereo_params *p, ebvo_
     if ((rc = match_candidates_device(ctx, ctx->im[0].edges, nL, ctx->im[1].edges, nR, (const double *)ctx->lines.p,
                                       p->epi_thr, p->max_disp, p->orient_thr_deg, p->stage_mask, &np)))
         return rc;
-    if ((rc = ebvo_grow(ctx, ctx->rc_edges, sizeof(ebvo_edge) * ((size_t)np + 1))))
+    // NCC from banks: left and right patches are sampled and normalised once per edge
+    if ((rc = ebvo_grow(ctx, ctx->patches_raw, sizeof(float) * 98 * ((size_t)nL + 1))))
         return rc;
-    if ((rc = match_gather_edges_device(ctx, ctx->im[1].edges, (const int32_t *)ctx->col_idx.p, np,
-                                        (ebvo_edge *)ctx->rc_edges.p)))
+    if ((rc = ebvo_grow(ctx, ctx->patches_norm, sizeof(float) * 98 * ((size_t)nL + 1))))
         return rc;
-    if ((rc = ncc_pairs_core(ctx, h, w, ctx->im[0].edges, nL, (const ebvo_edge *)ctx->rc_edges.p,
-                             (const int32_t *)ctx->row_ptr.p, np, p->ncc_thr, true)))
+    if ((rc = ebvo_grow(ctx, ctx->patches_flag, 2 * ((size_t)nL + 1))))
+        return rc;
+    if ((rc = ebvo_grow(ctx, ctx->patches_norm_r, sizeof(float) * 98 * ((size_t)nR + 1))))
+        return rc;
+    if ((rc = ebvo_grow(ctx, ctx->patches_flag_r, 2 * ((size_t)nR + 1))))
+        return rc;
+    if ((rc = ebvo_grow(ctx, ctx->match_cnt, 64)))
+        return rc;
+    if ((rc = ebvo_grow(ctx, ctx->sims, sizeof(double) * 4 * ((size_t)np + 1))))
+        return rc;
+    if ((rc = ebvo_grow(ctx, ctx->best, sizeof(double) * ((size_t)np + 1))))
+        return rc;
+    if ((rc = ebvo_grow(ctx, ctx->keep, (size_t)np + 1)))
+        return rc;
+    if ((rc = match_patches_device(ctx, ctx->im[0].img, h, w, w, ctx->im[0].edges, nL, (float *)ctx->patches_raw.p,
+                                   (float *)ctx->patches_norm.p, (uint8_t *)ctx->patches_flag.p)))
+        return rc;
+    if ((rc = match_patches_device(ctx, ctx->im[1].img, h, w, w, ctx->im[1].edges, nR, nullptr,
+                                   (float *)ctx->patches_norm_r.p, (uint8_t *)ctx->patches_flag_r.p)))
+        return rc;
+    if ((rc = match_ncc_banked_device(ctx, (const int32_t *)ctx->row_ptr.p, (const int32_t *)ctx->col_idx.p, nL, np,
+                                      (const float *)ctx->patches_norm.p, (const uint8_t *)ctx->patches_flag.p,
+                                      (const float *)ctx->patches_norm_r.p, (const uint8_t *)ctx->patches_flag_r.p,
+                                      p->ncc_thr, (double *)ctx->sims.p, (double *)ctx->best.p, (uint8_t *)ctx->keep.p,
+                                      (int32_t *)ctx->match_cnt.p)))
         return rc;
     EBVO_HIP(ctx, hipMemcpyAsync(ctx->h_small + 8, ctx->match_cnt.p, sizeof(int32_t), hipMemcpyDeviceToHost,
                                  ctx->stream));

@@ -85,7 +85,7 @@ struct ebvo_ctx
 
     // matching workspace (grown on demand)
     GrowBuf lines, boxes_chunk, boxes_group, cand_cnt, row_ptr, scan_tmp, col_idx, rc_edges, sims, best, keep,
-        patches_raw, patches_norm, patches_flag, match_cnt, scratch_a, scratch_b, scratch_c, scratch_d;
+        patches_raw, patches_norm, patches_flag, patches_norm_r, patches_flag_r, match_cnt, scratch_a, scratch_b, scratch_c, scratch_d;
     int64_t n_pairs = 0, n_matches = 0;
     int n_left = 0;
     double *d_params = nullptr; // F21 for the device line kernel (9 doubles)
@@ -146,6 +146,10 @@ int match_ncc_pairs_device(ebvo_ctx *ctx, const uint8_t *d_imgR, int h, int w, i
                            const int32_t *d_row_ptr, int nL, int64_t n_pairs, const float *d_left_norm,
                            const uint8_t *d_left_flag, double thr, double *d_sims, double *d_best,
                            uint8_t *d_keep, int32_t *d_match_cnt);
+int match_ncc_banked_device(ebvo_ctx *ctx, const int32_t *d_row_ptr, const int32_t *d_col_idx, int nL, int64_t n_pairs,
+                            const float *d_left_norm, const uint8_t *d_left_flag, const float *d_right_norm,
+                            const uint8_t *d_right_flag, double thr, double *d_sims, double *d_best, uint8_t *d_keep,
+                            int32_t *d_match_cnt);
 int match_ncc_stored_device(ebvo_ctx *ctx, const float *d_A, const float *d_B, int n, double *d_sim);
 int misc_fp64_peak(ebvo_ctx *ctx, int iters, double *tf_muladd, double *tf_fma);
 

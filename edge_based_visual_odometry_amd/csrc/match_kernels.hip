@@ -718,6 +718,71 @@ __global__ void expand_rows_kernel(const int32_t *__restrict__ row_ptr, int nL, 
         pair_left[k] = i;
 }
 
+// NCC of (left edge, right TOED edge) pairs from precomputed normalised-patch banks (device pipeline: every
+// right edge is a candidate of ~5 left edges, so its patches are sampled and normalised once, not per pair).
+// Same arithmetic as ncc_pairs_kernel: the normalised rows are identical, the four dots use the same order.
+__global__ __launch_bounds__(256) void ncc_banked_kernel(const float *__restrict__ left_norm,
+                                                         const uint8_t *__restrict__ left_flag,
+                                                         const float *__restrict__ right_norm,
+                                                         const uint8_t *__restrict__ right_flag,
+                                                         const int32_t *__restrict__ pair_left,
+                                                         const int32_t *__restrict__ col_idx, int64_t n_pairs,
+                                                         double thr, double *__restrict__ sims,
+                                                         double *__restrict__ best, uint8_t *__restrict__ keep)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t k = t >> 4;
+    const int g = (int)(t & 15), side = g >> 3, row = g & 7;
+    const bool valid = k < n_pairs;
+    const bool active = valid && row < 7;
+    float rn[7], lp[7], lm[7];
+#pragma unroll
+    for (int c = 0; c < 7; ++c)
+        rn[c] = lp[c] = lm[c] = 0.0f;
+    int li = 0, ri = 0;
+    if (valid)
+    {
+        li = pair_left[k];
+        ri = col_idx[k];
+    }
+    if (active)
+    {
+        const float *rr = right_norm + (size_t)ri * 98 + side * 49 + row * 7;
+        const float *ln = left_norm + (size_t)li * 98 + row * 7;
+#pragma unroll
+        for (int c = 0; c < 7; ++c)
+        {
+            rn[c] = rr[c];
+            lp[c] = ln[c];
+            lm[c] = ln[49 + c];
+        }
+    }
+    const double d_lp = dot_rows(active, lp, rn);
+    const double d_lm = dot_rows(active, lm, rn);
+    const double o_lp = __shfl_xor(d_lp, 8), o_lm = __shfl_xor(d_lm, 8);
+    if (valid && g == 0)
+    {
+        const bool lsent_p = left_flag[(size_t)li * 2] != 0, lsent_m = left_flag[(size_t)li * 2 + 1] != 0;
+        const bool rsent_p = right_flag[(size_t)ri * 2] != 0, rsent_m = right_flag[(size_t)ri * 2 + 1] != 0;
+        const double pp = (lsent_p || rsent_p) ? -1.0 : d_lp;
+        const double np = (lsent_m || rsent_p) ? -1.0 : d_lm;
+        const double pn = (lsent_p || rsent_m) ? -1.0 : o_lp;
+        const double nn = (lsent_m || rsent_m) ? -1.0 : o_lm;
+        const double b = max4(pp, nn, pn, np);
+        if (sims)
+        {
+            sims[k * 4 + 0] = pp;
+            sims[k * 4 + 1] = nn;
+            sims[k * 4 + 2] = pn;
+            sims[k * 4 + 3] = np;
+        }
+        if (best)
+            best[k] = b;
+        if (keep)
+            keep[k] = (b > thr) ? 1 : 0;
+    }
+}
+
 // NCC of stored patch pairs (src/utility.cpp:163-180); 16 lanes per pair: side 0 = A, side 1 = B.
 __global__ __launch_bounds__(256) void ncc_stored_kernel(const float *__restrict__ A, const float *__restrict__ B,
                                                          int n, double *__restrict__ sim)
@@ -962,6 +1027,38 @@ int match_ncc_pairs_device(ebvo_ctx *ctx, const uint8_t *d_imgR, int h, int w, i
         hipLaunchKernelGGL(ncc_pairs_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream,
                            d_imgR, h, w, pitchR, d_Rc, (const double2 *)sc, (const int32_t *)pair_left, n_pairs,
                            d_left_norm, d_left_flag, thr, d_sims, d_best, d_keep, d_match_cnt);
+        if (d_match_cnt && d_keep)
+            hipLaunchKernelGGL(count_keep_kernel, dim3(256), dim3(256), 0, ctx->stream, (const uint8_t *)d_keep,
+                               n_pairs, d_match_cnt);
+    }
+    EBVO_HIP(ctx, hipGetLastError());
+    return EBVO_OK;
+}
+
+int match_ncc_banked_device(ebvo_ctx *ctx, const int32_t *d_row_ptr, const int32_t *d_col_idx, int nL, int64_t n_pairs,
+                            const float *d_left_norm, const uint8_t *d_left_flag, const float *d_right_norm,
+                            const uint8_t *d_right_flag, double thr, double *d_sims, double *d_best, uint8_t *d_keep,
+                            int32_t *d_match_cnt)
+{
+    if (d_match_cnt)
+        EBVO_HIP(ctx, hipMemsetAsync(d_match_cnt, 0, sizeof(int32_t), ctx->stream));
+    if (n_pairs <= 0 || nL <= 0)
+        return EBVO_OK;
+    int rc;
+    if ((rc = ebvo_grow(ctx, ctx->scratch_a, sizeof(int32_t) * (size_t)n_pairs)))
+        return rc;
+    int32_t *pair_left = (int32_t *)ctx->scratch_a.p;
+    {
+        ProfScope ps(ctx, K_MISC);
+        hipLaunchKernelGGL(expand_rows_kernel, dim3((nL + 255) / 256), dim3(256), 0, ctx->stream, d_row_ptr, nL,
+                           pair_left);
+    }
+    {
+        ProfScope ps(ctx, K_NCC_PAIRS);
+        const int64_t threads = n_pairs * 16;
+        hipLaunchKernelGGL(ncc_banked_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream,
+                           d_left_norm, d_left_flag, d_right_norm, d_right_flag, (const int32_t *)pair_left, d_col_idx,
+                           n_pairs, thr, d_sims, d_best, d_keep);
         if (d_match_cnt && d_keep)
             hipLaunchKernelGGL(count_keep_kernel, dim3(256), dim3(256), 0, ctx->stream, (const uint8_t *)d_keep,
                                n_pairs, d_match_cnt);

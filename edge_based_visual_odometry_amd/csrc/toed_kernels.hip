@@ -13,9 +13,10 @@
 // LDS tile instead of being skipped: x + (+-0.0) == x for every running sum that started at +0.0.
 //
 // Kernels
-//   toed_conv_kernel     K1: LDS-staged fp64 tile (8 x 32 pixels + 9-pixel halo), one thread per
-//                            input pixel, all four sub-pixel phases (36 fp64 accumulators) in
-//                            registers, filter taps as scalar (SGPR) operands from constant memory
+//   toed_conv_kernel     K1: LDS-staged fp64 tile (8 x 32 pixels + 9-pixel halo); one thread per
+//                            (input pixel, x-phase): the two sub-pixel phases that share the column
+//                            taps (18 fp64 accumulators) in registers, filter taps as scalar (SGPR)
+//                            operands, software-pipelined tap fetch
 //   toed_nms_kernel      K2: NMS + parabola fit per interpolated pixel, flags + per-row counts
 //   toed_rowscan_kernel  K3a: exclusive scan of the per-row counts
 //   toed_compact_kernel  K3b: ordered (raster) stream compaction of the flagged pixels
@@ -135,21 +136,119 @@ __device__ inline void third_order_dir(const double *f, double &tx, double &ty)
     ty = TO_Iy / TO_mag;
 }
 
-__device__ inline void store_pair(double *plane, size_t o, double a, double b)
+// Interpolated pixel (I, J) of a 2H x 2W plane lives in the sub-plane of its phase (I&1, J&1) at
+// (I>>1, J>>1): [sy][sx][H][W].  Keeps every access of a fixed phase unit-stride.
+__device__ inline size_t midx(int I, int J, int h, int w)
 {
-    double2 v;
-    v.x = a;
-    v.y = b;
-    *reinterpret_cast<double2 *>(plane + o) = v;
+    return ((size_t)(((I & 1) << 1) | (J & 1)) * h + (I >> 1)) * w + (J >> 1);
 }
 
 // K1 ---------------------------------------------------------------------------------------
+// SX = 0: phases (0,0) [17x17, integer grid] and (1,0); SX = 1: phases (0,1) and (1,1).
+// Both phases of a thread use the same column taps, so v*Kcol[q] is formed once per tap.
+template <int SX>
+__device__ inline void conv_body(const double (*tile)[LDS_W], const ToedTables *__restrict__ T,
+                                 double *__restrict__ maps, int h, int w, int i, int j, int ty, int tx)
+{
+    const double(*colk)[19] = SX ? T->tap_half : T->tap_int;
+    double a0[9], a1[9]; // phase (0, SX) and (1, SX)
+#pragma unroll
+    for (int r = 0; r < 9; ++r)
+        a0[r] = a1[r] = 0.0;
+
+#pragma unroll 1
+    for (int p = -HALO; p <= HALO; ++p)
+    {
+        double ru[4], rs[4]; // row taps: integer grid / half-pixel grid (wave-uniform -> SGPRs)
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+        {
+            ru[d] = T->tap_int[d][p + 9];
+            rs[d] = T->tap_half[d][p + 9];
+        }
+        const bool row00 = (p >= -8) && (p <= 8);
+        const int pr = row00 ? p + 8 : 0;
+        const double *__restrict__ trow = &tile[ty + HALO - p][tx + HALO];
+        // software pipeline: the pixel and the column taps of tap q+1 are fetched while tap q is accumulated
+        double vn = trow[HALO];
+        double kn[4], pxn = 0, pyn = 0;
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+            kn[d] = colk[d][0];
+        if (SX == 0)
+        {
+            pxn = T->prod_fx[pr][0];
+            pyn = T->prod_fy[pr][0];
+        }
+#pragma unroll 1
+        for (int q = -HALO; q <= HALO; ++q)
+        {
+            const double v = vn, px = pxn, py = pyn;
+            double ck[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+                ck[d] = v * kn[d];
+            const int qn = min(q + 1, HALO);
+            vn = trow[-qn];
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+                kn[d] = colk[d][qn + 9];
+            if (SX == 0)
+            {
+                const int qp = min(max(qn + 8, 0), 16);
+                pxn = T->prod_fx[pr][qp];
+                pyn = T->prod_fy[pr][qp];
+                if (row00 && q >= -8 && q <= 8) // wave-uniform; integer phase, src/toed/cpu_toed.cpp:207-216
+                {
+                    a0[0] += v * px;
+                    a0[1] += v * py;
+                    a0[2] += ck[2] * ru[0];
+                    a0[3] += ck[1] * ru[1];
+                    a0[4] += ck[0] * ru[2];
+                    a0[5] += ck[2] * ru[1];
+                    a0[6] += ck[1] * ru[2];
+                    a0[7] += ck[3] * ru[0];
+                    a0[8] += ck[0] * ru[3];
+                }
+            }
+            else
+            {
+                EBVO_ACCUM9(a0, ck, ru) // shifted in x only, :251-260
+            }
+            EBVO_ACCUM9(a1, ck, rs) // shifted in y (SX = 0, :295-304) or in both (SX = 1, :339-348)
+        }
+    }
+
+    const size_t plane = (size_t)4 * h * w;
+    double tx0, ty0;
+    {
+        const size_t o = midx(2 * i, 2 * j + SX, h, w);
+        maps[PL_IX * plane + o] = a0[0];
+        maps[PL_IY * plane + o] = a0[1];
+        maps[PL_MAG * plane + o] = sqrt(a0[0] * a0[0] + a0[1] * a0[1]);
+        third_order_dir(a0, tx0, ty0);
+        maps[PL_TOX * plane + o] = tx0;
+        maps[PL_TOY * plane + o] = ty0;
+    }
+    {
+        const size_t o = midx(2 * i + 1, 2 * j + SX, h, w);
+        maps[PL_IX * plane + o] = a1[0];
+        maps[PL_IY * plane + o] = a1[1];
+        maps[PL_MAG * plane + o] = sqrt(a1[0] * a1[0] + a1[1] * a1[1]);
+        third_order_dir(a1, tx0, ty0);
+        maps[PL_TOX * plane + o] = tx0;
+        maps[PL_TOY * plane + o] = ty0;
+    }
+}
+
+// grid (tiles_x, tiles_y, 2 * n_img): z = 2 * image + x-phase
 __global__ __launch_bounds__(256) void toed_conv_kernel(ImgBatch B, const ToedTables *__restrict__ T, int h,
                                                         int w)
 {
     __shared__ double tile[LDS_H][LDS_W];
-    const uint8_t *__restrict__ img = B.img[blockIdx.z];
-    double *__restrict__ maps = B.maps[blockIdx.z];
+    const int im = blockIdx.z >> 1, sx = blockIdx.z & 1;
+    const uint8_t *__restrict__ img = B.img[im];
+    double *__restrict__ maps = B.maps[im];
     const int j0 = blockIdx.x * TILE_W, i0 = blockIdx.y * TILE_H;
 
     for (int t = threadIdx.x; t < LDS_H * LDS_W; t += 256)
@@ -167,110 +266,18 @@ __global__ __launch_bounds__(256) void toed_conv_kernel(ImgBatch B, const ToedTa
     const int i = i0 + ty, j = j0 + tx;
     if (i >= h || j >= w)
         return;
-
-    double a00[9], a01[9], a10[9], a11[9]; // phase (sy, sx)
-#pragma unroll
-    for (int r = 0; r < 9; ++r)
-        a00[r] = a01[r] = a10[r] = a11[r] = 0.0;
-
-#pragma unroll 1
-    for (int p = -HALO; p <= HALO; ++p)
-    {
-        double ru[4], rs[4]; // row taps: integer grid / half-pixel grid (wave-uniform -> SGPRs)
-#pragma unroll
-        for (int d = 0; d < 4; ++d)
-        {
-            ru[d] = T->tap_int[d][p + 9];
-            rs[d] = T->tap_half[d][p + 9];
-        }
-        const bool row00 = (p >= -8) && (p <= 8);
-        const int pr = row00 ? p + 8 : 0;
-        const double *__restrict__ trow = &tile[ty + HALO - p][tx + HALO];
-        // software pipeline: the pixel and the column taps of tap q+1 are fetched while tap q is
-        // being accumulated, so the LDS / scalar-cache latency hides behind ~80 fp64 VALU ops
-        double vn = trow[HALO];
-        double kun[4], ksn[4], pxn, pyn;
-#pragma unroll
-        for (int d = 0; d < 4; ++d)
-        {
-            kun[d] = T->tap_int[d][0];
-            ksn[d] = T->tap_half[d][0];
-        }
-        pxn = T->prod_fx[pr][0];
-        pyn = T->prod_fy[pr][0];
-#pragma unroll 1
-        for (int q = -HALO; q <= HALO; ++q)
-        {
-            const double v = vn, px = pxn, py = pyn;
-            double cu[4], cs[4];
-#pragma unroll
-            for (int d = 0; d < 4; ++d)
-            {
-                cu[d] = v * kun[d];
-                cs[d] = v * ksn[d];
-            }
-            const int qn = min(q + 1, HALO);
-            const int qp = min(max(qn + 8, 0), 16);
-            vn = trow[-qn];
-#pragma unroll
-            for (int d = 0; d < 4; ++d)
-            {
-                kun[d] = T->tap_int[d][qn + 9];
-                ksn[d] = T->tap_half[d][qn + 9];
-            }
-            pxn = T->prod_fx[pr][qp];
-            pyn = T->prod_fy[pr][qp];
-            if (row00 && q >= -8 && q <= 8) // wave-uniform
-            {
-                a00[0] += v * px;
-                a00[1] += v * py;
-                a00[2] += cu[2] * ru[0];
-                a00[3] += cu[1] * ru[1];
-                a00[4] += cu[0] * ru[2];
-                a00[5] += cu[2] * ru[1];
-                a00[6] += cu[1] * ru[2];
-                a00[7] += cu[3] * ru[0];
-                a00[8] += cu[0] * ru[3];
-            }
-            EBVO_ACCUM9(a01, cs, ru) // shifted in x only
-            EBVO_ACCUM9(a10, cu, rs) // shifted in y only
-            EBVO_ACCUM9(a11, cs, rs) // shifted in both
-        }
-    }
-
-    const int W2 = 2 * w;
-    const size_t plane = (size_t)(2 * h) * W2;
-    double tx0, ty0, tx1, ty1;
-    {
-        const size_t o = (size_t)(2 * i) * W2 + 2 * j;
-        store_pair(maps + PL_IX * plane, o, a00[0], a01[0]);
-        store_pair(maps + PL_IY * plane, o, a00[1], a01[1]);
-        store_pair(maps + PL_MAG * plane, o, sqrt(a00[0] * a00[0] + a00[1] * a00[1]),
-                   sqrt(a01[0] * a01[0] + a01[1] * a01[1]));
-        third_order_dir(a00, tx0, ty0);
-        third_order_dir(a01, tx1, ty1);
-        store_pair(maps + PL_TOX * plane, o, tx0, tx1);
-        store_pair(maps + PL_TOY * plane, o, ty0, ty1);
-    }
-    {
-        const size_t o = (size_t)(2 * i + 1) * W2 + 2 * j;
-        store_pair(maps + PL_IX * plane, o, a10[0], a11[0]);
-        store_pair(maps + PL_IY * plane, o, a10[1], a11[1]);
-        store_pair(maps + PL_MAG * plane, o, sqrt(a10[0] * a10[0] + a10[1] * a10[1]),
-                   sqrt(a11[0] * a11[0] + a11[1] * a11[1]));
-        third_order_dir(a10, tx0, ty0);
-        third_order_dir(a11, tx1, ty1);
-        store_pair(maps + PL_TOX * plane, o, tx0, tx1);
-        store_pair(maps + PL_TOY * plane, o, ty0, ty1);
-    }
+    if (sx)
+        conv_body<1>(tile, T, maps, h, w, i, j, ty, tx);
+    else
+        conv_body<0>(tile, T, maps, h, w, i, j, ty, tx);
 }
 
 // NMS + parabola fit at interpolated pixel (i, j): src/toed/cpu_toed.cpp:406-511.
 __device__ inline bool nms_eval(const double *__restrict__ Ix, const double *__restrict__ Iy,
-                                const double *__restrict__ M, int W2, int i, int j, double &pos_x,
+                                const double *__restrict__ M, int h, int w, int i, int j, double &pos_x,
                                 double &pos_y, double &smag)
 {
-    const size_t o = (size_t)i * W2 + j;
+    const size_t o = midx(i, j, h, w);
     const double m = M[o];
     if (m <= 2) // :406
         return false;
@@ -303,8 +310,8 @@ __device__ inline bool nms_eval(const double *__restrict__ Ix, const double *__r
     }
     else
         return false;
-    const double fp = M[(size_t)(i + a1) * W2 + (j + b1)] * (1 - slope) + M[(size_t)(i + a2) * W2 + (j + b2)] * slope;
-    const double fm = M[(size_t)(i - a1) * W2 + (j - b1)] * (1 - slope) + M[(size_t)(i - a2) * W2 + (j - b2)] * slope;
+    const double fp = M[midx(i + a1, j + b1, h, w)] * (1 - slope) + M[midx(i + a2, j + b2, h, w)] * slope;
+    const double fm = M[midx(i - a1, j - b1, h, w)] * (1 - slope) + M[midx(i - a2, j - b2, h, w)] * slope;
     const double s = sqrt(1 + slope * slope);
     if (!((m > fm && m > fp) || (m > fm && m >= fp) || (m >= fm && m > fp))) // :481-483
         return false;
@@ -337,7 +344,7 @@ __global__ __launch_bounds__(256) void toed_nms_kernel(ImgBatch B, int h, int w)
     if (j < W2 - 10)
     {
         double px, py, sm;
-        if (nms_eval(maps + PL_IX * plane, maps + PL_IY * plane, maps + PL_MAG * plane, W2, i, j, px, py, sm))
+        if (nms_eval(maps + PL_IX * plane, maps + PL_IY * plane, maps + PL_MAG * plane, h, w, i, j, px, py, sm))
         {
             const double x = (px - 1) / 2, y = (py - 1) / 2; // :538,542
             f = (x > 10 && x < w - 10 && y > 10 && y < h - 10) ? 3 : 1; // :553-554
@@ -459,10 +466,11 @@ __global__ __launch_bounds__(256) void toed_finalize_kernel(ImgBatch B, int h, i
         const int o = src[2 * t], kr = src[2 * t + 1];
         const int i = o / W2, j = o - i * W2;
         double px = 0, py = 0, sm = 0;
-        nms_eval(maps + PL_IX * plane, maps + PL_IY * plane, maps + PL_MAG * plane, W2, i, j, px, py, sm);
+        nms_eval(maps + PL_IX * plane, maps + PL_IY * plane, maps + PL_MAG * plane, h, w, i, j, px, py, sm);
         const double x = (px - 1) / 2, y = (py - 1) / 2;
         // src/toed/cpu_toed.cpp:229: atan2(TO_Ix, -TO_Iy)
-        const double th = ebvo_atan2(maps[PL_TOX * plane + o], -maps[PL_TOY * plane + o]);
+        const size_t mo = midx(i, j, h, w);
+        const double th = ebvo_atan2(maps[PL_TOX * plane + mo], -maps[PL_TOY * plane + mo]);
         all4[(size_t)t * 4 + 0] = x;
         all4[(size_t)t * 4 + 1] = y;
         all4[(size_t)t * 4 + 2] = th;
@@ -536,7 +544,7 @@ int toed_run_device(ebvo_ctx *ctx, int n_img, int h, int w, float *ms_conv, floa
     }
     {
         ProfScope ps(ctx, K_CONV);
-        dim3 grid((w + TILE_W - 1) / TILE_W, (h + TILE_H - 1) / TILE_H, n_img);
+        dim3 grid((w + TILE_W - 1) / TILE_W, (h + TILE_H - 1) / TILE_H, 2 * n_img);
         hipLaunchKernelGGL(toed_conv_kernel, grid, dim3(256), 0, ctx->stream, B,
                            (const ToedTables *)g_tables_dev[ctx->device], h, w);
     }
