@@ -76,7 +76,7 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--streams", type=int, default=1, help="concurrent contexts (host thread + HIP stream each) per GPU")
+    ap.add_argument("--streams", type=int, default=3, help="stereo pairs kept in flight per GPU (slots / HIP streams)")
     args = ap.parse_args()
 
     info = sharding.rank_info()
@@ -93,15 +93,17 @@ def main():
     cal = synth.CALIB["kitti"]
     F = synth.fundamental_21(cal["K"], cal["K"], cal["R21"], cal["T21"])
 
-    import threading
-    ctxs = [Context(H, W, device=local_rank) for _ in range(max(1, args.streams))]
-    ctx = ctxs[0]
-    for c in ctxs:
-        c.stereo_upload(left, right)
+    # one context per GPU; --streams S keeps S pairs in flight from this one host thread (S slots, one HIP stream
+    # each): submit enqueues a whole pair without host synchronisation, wait blocks on that pair only
+    nslots = max(1, args.streams)
+    ctx = Context(H, W, device=local_rank)
+    ctx.set_slots(nslots)
     params = ctx.default_params(F)
-    for c in ctxs:
+    for k in range(nslots):
+        ctx.stereo_upload(left, right, slot=k)
         for _ in range(args.warmup):
-            counts = c.stereo_run(params)
+            ctx.stereo_submit(params, slot=k)
+            counts = ctx.stereo_wait(slot=k)
 
     def barrier():
         torch.cuda.synchronize()
@@ -109,33 +111,25 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for c in ctxs:
-        c.profile_reset()
-        c.profile_enable(True)
+    ctx.profile_reset()
+    ctx.profile_enable(True)
     barrier()
     t0 = time.perf_counter()
-    if len(ctxs) == 1:
-        for _ in range(args.steps):
-            counts = ctx.stereo_run(params)      # synchronous: returns after the last kernel of the pair
-    else:
-        # EXACTLY args.steps pairs in total, dealt round-robin to the contexts; ctypes releases the GIL
-        def work(c, n):
-            for _ in range(n):
-                c.stereo_run(params)
-        share = [args.steps // len(ctxs) + (1 if k < args.steps % len(ctxs) else 0) for k in range(len(ctxs))]
-        th = [threading.Thread(target=work, args=(c, n)) for c, n in zip(ctxs, share)]
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
+    submitted = completed = 0
+    while submitted < min(nslots, args.steps):
+        ctx.stereo_submit(params, slot=submitted % nslots)
+        submitted += 1
+    while completed < args.steps:                 # EXACTLY args.steps pairs
+        k = completed % nslots
+        counts = ctx.stereo_wait(slot=k)
+        completed += 1
+        if submitted < args.steps:
+            ctx.stereo_submit(params, slot=k)
+            submitted += 1
     barrier()
     dt = time.perf_counter() - t0
-    prof = {}
-    for c in ctxs:
-        c.profile_enable(False)
-        for k, (ms, n) in c.profile_get().items():
-            a = prof.get(k, (0.0, 0))
-            prof[k] = (a[0] + ms, a[1] + n)
+    ctx.profile_enable(False)
+    prof = ctx.profile_get()
 
     dt = sharding.max_over_ranks(dt, dist, f"cuda:{local_rank}")
 
@@ -164,7 +158,7 @@ def main():
                                    "disparity/orientation candidate search + NCC, resident in HBM, replayed",
                        "edges_left": counts.n_left, "edges_right": counts.n_right,
                        "candidate_pairs": counts.n_pairs, "ncc_matches": counts.n_matches,
-                       "streams_per_gpu": len(ctxs),
+                       "pairs_in_flight_per_gpu": nslots,
                        "parallelism": f"{world} independent sequence(s), one per GPU, no collective"},
             "roofline": {"bound": "hbm", "kernel": "toed_conv_kernel", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,

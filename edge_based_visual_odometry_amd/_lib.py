@@ -35,7 +35,8 @@ ABI_SYMBOLS = (
     "ebvo_strerror", "ebvo_last_error", "ebvo_abi_version", "ebvo_ctx_create", "ebvo_ctx_destroy",
     "ebvo_toed", "ebvo_toed_pair", "ebvo_epipolar_lines", "ebvo_epi_candidates", "ebvo_ncc_pairs",
     "ebvo_edge_patches", "ebvo_ncc_patches", "ebvo_ncc_quads", "ebvo_stereo_default_params",
-    "ebvo_stereo_upload", "ebvo_stereo_run", "ebvo_stereo_fetch", "ebvo_profile_enable",
+    "ebvo_stereo_upload", "ebvo_stereo_run", "ebvo_stereo_fetch", "ebvo_stereo_set_slots",
+    "ebvo_stereo_upload_slot", "ebvo_stereo_submit", "ebvo_stereo_wait", "ebvo_stereo_fetch_slot", "ebvo_profile_enable",
     "ebvo_profile_reset", "ebvo_profile_get", "ebvo_fp64_peak",
 )
 
@@ -100,6 +101,11 @@ def load_library() -> C.CDLL:
     lib.ebvo_stereo_upload.argtypes = [vp, vp, vp, i32, i32, ssz, ssz]
     lib.ebvo_stereo_run.argtypes = [vp, C.POINTER(StereoParams), C.POINTER(StereoCounts)]
     lib.ebvo_stereo_fetch.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.ebvo_stereo_set_slots.argtypes = [vp, i32]
+    lib.ebvo_stereo_upload_slot.argtypes = [vp, i32, vp, vp, i32, i32, ssz, ssz]
+    lib.ebvo_stereo_submit.argtypes = [vp, i32, C.POINTER(StereoParams)]
+    lib.ebvo_stereo_wait.argtypes = [vp, i32, C.POINTER(StereoCounts)]
+    lib.ebvo_stereo_fetch_slot.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.ebvo_profile_enable.argtypes = [vp, i32]
     lib.ebvo_profile_reset.argtypes = [vp]
     lib.ebvo_profile_get.argtypes = [vp, C.POINTER(KernelTime), C.POINTER(i32)]

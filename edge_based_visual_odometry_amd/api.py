@@ -179,19 +179,30 @@ class Context:
                 p.F21[k] = float(F[k])
         return p
 
-    def stereo_upload(self, left, right):
+    def set_slots(self, n: int):
+        self._check(self.lib.ebvo_stereo_set_slots(self._ctx, n), "ebvo_stereo_set_slots")
+
+    def stereo_upload(self, left, right, slot: int = 0):
         left, right = _u8(left), _u8(right)
         h, w = left.shape
         assert right.shape == (h, w)
-        self._check(self.lib.ebvo_stereo_upload(self._ctx, ptr(left), ptr(right), h, w, left.strides[0],
-                                                right.strides[0]), "ebvo_stereo_upload")
+        self._check(self.lib.ebvo_stereo_upload_slot(self._ctx, slot, ptr(left), ptr(right), h, w, left.strides[0],
+                                                     right.strides[0]), "ebvo_stereo_upload_slot")
 
     def stereo_run(self, params: StereoParams) -> StereoCounts:
         c = StereoCounts()
         self._check(self.lib.ebvo_stereo_run(self._ctx, C.byref(params), C.byref(c)), "ebvo_stereo_run")
         return c
 
-    def stereo_fetch(self, counts: StereoCounts, patches: bool = False):
+    def stereo_submit(self, params: StereoParams, slot: int = 0):
+        self._check(self.lib.ebvo_stereo_submit(self._ctx, slot, C.byref(params)), "ebvo_stereo_submit")
+
+    def stereo_wait(self, slot: int = 0) -> StereoCounts:
+        c = StereoCounts()
+        self._check(self.lib.ebvo_stereo_wait(self._ctx, slot, C.byref(c)), "ebvo_stereo_wait")
+        return c
+
+    def stereo_fetch(self, counts: StereoCounts, patches: bool = False, slot: int = 0):
         nL, nR, npairs = counts.n_left, counts.n_right, counts.n_pairs
         left = np.zeros(nL, dtype=EDGE_DTYPE)
         right = np.zeros(nR, dtype=EDGE_DTYPE)
@@ -201,8 +212,8 @@ class Context:
         best = np.zeros(npairs)
         keep = np.zeros(npairs, dtype=np.uint8)
         lp = np.zeros((nL, 2, 49), dtype=np.float32) if patches else None
-        self._check(self.lib.ebvo_stereo_fetch(self._ctx, ptr(left), ptr(right), ptr(row_ptr), ptr(col), ptr(sims),
-                                               ptr(best), ptr(keep), ptr(lp)), "ebvo_stereo_fetch")
+        self._check(self.lib.ebvo_stereo_fetch_slot(self._ctx, slot, ptr(left), ptr(right), ptr(row_ptr), ptr(col),
+                                                    ptr(sims), ptr(best), ptr(keep), ptr(lp)), "ebvo_stereo_fetch_slot")
         return dict(left=left, right=right, row_ptr=row_ptr, col_idx=col, sims=sims, best=best, keep=keep,
                     left_patches=lp)
 

@@ -1,5 +1,5 @@
-// ebvo_capi.hip -- the C ABI of include/ebvo_hip.h: context, host-buffer entry points,
-// device-resident stereo pipeline, profiling.
+// ebvo_capi.hip -- the C ABI of include/ebvo_hip.h: context and slots, host-buffer entry points,
+// the sync-free device-resident stereo pipeline, profiling.
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -24,17 +24,17 @@ int ebvo_fail_hip(ebvo_ctx *ctx, hipError_t e, const char *what, const char *fil
     return EBVO_ERR_HIP;
 }
 
-int ebvo_grow(ebvo_ctx *ctx, GrowBuf &b, size_t bytes)
+int ebvo_grow(ebvo_ctx *ctx, Slot &s, GrowBuf &b, size_t bytes)
 {
     if (bytes <= b.bytes && b.p)
         return EBVO_OK;
     // the stream may still be using the old allocation
-    EBVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    EBVO_HIP(ctx, hipStreamSynchronize(s.stream));
     if (b.p)
-        hipFree(b.p);
+        (void)hipFree(b.p);
     b.p = nullptr;
     b.bytes = 0;
-    size_t want = bytes + bytes / 4 + 256;
+    const size_t want = bytes + bytes / 4 + 256;
     hipError_t e = hipMalloc(&b.p, want);
     if (e != hipSuccess)
     {
@@ -46,7 +46,7 @@ int ebvo_grow(ebvo_ctx *ctx, GrowBuf &b, size_t bytes)
     return EBVO_OK;
 }
 
-void ebvo_prof_begin(ebvo_ctx *ctx, int kid)
+void ebvo_prof_begin(ebvo_ctx *ctx, Slot &s, int kid)
 {
     if (!ctx->prof)
         return;
@@ -62,42 +62,131 @@ void ebvo_prof_begin(ebvo_ctx *ctx, int kid)
             return;
     }
     pe.kid = kid;
-    hipEventRecord(pe.a, ctx->stream);
-    ctx->prof_pending.push_back(pe);
+    (void)hipEventRecord(pe.a, s.stream);
+    s.prof_pending.push_back(pe);
 }
 
-void ebvo_prof_end(ebvo_ctx *ctx)
+void ebvo_prof_end(ebvo_ctx *ctx, Slot &s)
 {
-    if (!ctx->prof || ctx->prof_pending.empty())
+    if (!ctx->prof || s.prof_pending.empty())
         return;
-    hipEventRecord(ctx->prof_pending.back().b, ctx->stream);
+    (void)hipEventRecord(s.prof_pending.back().b, s.stream);
 }
 
 static int prof_drain(ebvo_ctx *ctx)
 {
-    if (ctx->prof_pending.empty())
-        return EBVO_OK;
-    EBVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    for (ProfEvent &pe : ctx->prof_pending)
+    for (Slot *sp : ctx->slots)
     {
-        float ms = 0;
-        if (hipEventElapsedTime(&ms, pe.a, pe.b) == hipSuccess)
+        Slot &s = *sp;
+        if (s.prof_pending.empty())
+            continue;
+        EBVO_HIP(ctx, hipStreamSynchronize(s.stream));
+        for (ProfEvent &pe : s.prof_pending)
         {
-            ctx->prof_ms[pe.kid] += ms;
-            ctx->prof_launches[pe.kid] += 1;
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, pe.a, pe.b) == hipSuccess)
+            {
+                ctx->prof_ms[pe.kid] += ms;
+                ctx->prof_launches[pe.kid] += 1;
+            }
+            ctx->prof_free.push_back(pe);
         }
-        ctx->prof_free.push_back(pe);
+        s.prof_pending.clear();
     }
-    ctx->prof_pending.clear();
     return EBVO_OK;
 }
 
 static void free_buf(GrowBuf &b)
 {
     if (b.p)
-        hipFree(b.p);
+        (void)hipFree(b.p);
     b.p = nullptr;
     b.bytes = 0;
+}
+
+static void slot_destroy(Slot *s)
+{
+    if (!s)
+        return;
+    if (s->stream)
+        (void)hipStreamSynchronize(s->stream);
+    for (ProfEvent &pe : s->prof_pending)
+    {
+        (void)hipEventDestroy(pe.a);
+        (void)hipEventDestroy(pe.b);
+    }
+    for (int k = 0; k < 2; ++k)
+    {
+        ImageWS &ws = s->im[k];
+        (void)hipFree(ws.img);
+        (void)hipFree(ws.maps);
+        (void)hipFree(ws.flag);
+        (void)hipFree(ws.row_cnt);
+        (void)hipFree(ws.row_off);
+        (void)hipFree(ws.counts);
+        (void)hipFree(ws.src);
+        (void)hipFree(ws.edges);
+        (void)hipFree(ws.all4);
+    }
+    GrowBuf *bufs[] = {&s->lines,        &s->boxes_chunk,  &s->boxes_group,    &s->cand_cnt,       &s->row_ptr,
+                       &s->scan_tmp,     &s->col_idx,      &s->rc_edges,       &s->sims,           &s->best,
+                       &s->keep,         &s->patches_raw,  &s->patches_norm,   &s->patches_flag,   &s->patches_norm_r,
+                       &s->patches_flag_r, &s->pair_left,  &s->sincos,         &s->scratch_b,      &s->scratch_c,
+                       &s->scratch_d};
+    for (GrowBuf *b : bufs)
+        free_buf(*b);
+    (void)hipFree(s->d_total);
+    (void)hipFree(s->d_matches);
+    (void)hipFree(s->d_sizes);
+    (void)hipFree(s->d_F);
+    (void)hipFree(s->d_result);
+    if (s->h_result)
+        (void)hipHostFree(s->h_result);
+    if (s->stream)
+        (void)hipStreamDestroy(s->stream);
+    delete s;
+}
+
+static int slot_create(ebvo_ctx *ctx, Slot **out)
+{
+    Slot *s = new (std::nothrow) Slot();
+    if (!s)
+        return EBVO_ERR_NOMEM;
+#define CK(call)                                                                   \
+    do                                                                             \
+    {                                                                              \
+        hipError_t e_ = (call);                                                    \
+        if (e_ != hipSuccess)                                                      \
+        {                                                                          \
+            ebvo_fail_hip(ctx, e_, #call, __FILE__, __LINE__);                     \
+            slot_destroy(s);                                                       \
+            return e_ == hipErrorOutOfMemory ? EBVO_ERR_NOMEM : EBVO_ERR_HIP;      \
+        }                                                                          \
+    } while (0)
+    CK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    const size_t H2 = 2 * (size_t)ctx->max_h, W2 = 2 * (size_t)ctx->max_w, np2 = H2 * W2;
+    for (int k = 0; k < 2; ++k)
+    {
+        ImageWS &ws = s->im[k];
+        CK(hipMalloc(&ws.img, (size_t)ctx->max_h * ctx->max_w));
+        CK(hipMalloc(&ws.maps, sizeof(double) * np2 * PL_NUM));
+        CK(hipMalloc(&ws.flag, np2));
+        CK(hipMalloc(&ws.row_cnt, sizeof(int32_t) * 2 * H2));
+        CK(hipMalloc(&ws.row_off, sizeof(int32_t) * 2 * (H2 + 1)));
+        CK(hipMalloc(&ws.counts, sizeof(int32_t) * 2));
+        CK(hipMalloc(&ws.src, sizeof(int32_t) * 2 * (size_t)ctx->cap_edges));
+        CK(hipMalloc(&ws.edges, sizeof(ebvo_edge) * (size_t)ctx->cap_edges));
+        CK(hipMalloc(&ws.all4, sizeof(double) * 4 * (size_t)ctx->cap_edges));
+    }
+    CK(hipMalloc(&s->d_total, sizeof(unsigned long long)));
+    CK(hipMalloc(&s->d_matches, sizeof(int32_t)));
+    CK(hipMalloc(&s->d_sizes, sizeof(int32_t) * 4));
+    CK(hipMalloc(&s->d_F, sizeof(double) * 9));
+    CK(hipMalloc(&s->d_result, sizeof(PairResult)));
+    CK(hipHostMalloc(&s->h_result, sizeof(PairResult)));
+#undef CK
+    *out = s;
+    return EBVO_OK;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -123,43 +212,14 @@ extern "C" void ebvo_ctx_destroy(ebvo_ctx *ctx)
 {
     if (!ctx)
         return;
-    hipSetDevice(ctx->device);
-    if (ctx->stream)
-        hipStreamSynchronize(ctx->stream);
-    for (ProfEvent &pe : ctx->prof_pending)
-    {
-        hipEventDestroy(pe.a);
-        hipEventDestroy(pe.b);
-    }
+    (void)hipSetDevice(ctx->device);
+    for (Slot *s : ctx->slots)
+        slot_destroy(s);
     for (ProfEvent &pe : ctx->prof_free)
     {
-        hipEventDestroy(pe.a);
-        hipEventDestroy(pe.b);
+        (void)hipEventDestroy(pe.a);
+        (void)hipEventDestroy(pe.b);
     }
-    for (int k = 0; k < 2; ++k)
-    {
-        ImageWS &ws = ctx->im[k];
-        hipFree(ws.img);
-        hipFree(ws.maps);
-        hipFree(ws.flag);
-        hipFree(ws.row_cnt);
-        hipFree(ws.row_off);
-        hipFree(ws.counts);
-        hipFree(ws.src);
-        hipFree(ws.edges);
-        hipFree(ws.all4);
-    }
-    GrowBuf *bufs[] = {&ctx->lines,      &ctx->boxes_chunk,  &ctx->boxes_group,  &ctx->cand_cnt,  &ctx->row_ptr,
-                       &ctx->scan_tmp,   &ctx->col_idx,      &ctx->rc_edges,     &ctx->sims,      &ctx->best,
-                       &ctx->keep,       &ctx->patches_raw,  &ctx->patches_norm, &ctx->patches_flag, &ctx->patches_norm_r, &ctx->patches_flag_r,
-                       &ctx->match_cnt,  &ctx->scratch_a,    &ctx->scratch_b,    &ctx->scratch_c, &ctx->scratch_d};
-    for (GrowBuf *b : bufs)
-        free_buf(*b);
-    hipFree(ctx->d_params);
-    if (ctx->h_small)
-        hipHostFree(ctx->h_small);
-    if (ctx->stream)
-        hipStreamDestroy(ctx->stream);
     delete ctx;
 }
 
@@ -182,41 +242,18 @@ extern "C" int ebvo_ctx_create(int device, int max_h, int max_w, ebvo_ctx **out)
     ctx->max_h = max_h;
     ctx->max_w = max_w;
     ctx->cap_edges = max_h * max_w;
-    int rc = EBVO_OK;
+    int rc;
     auto fail = [&](int code) {
         fprintf(stderr, "[ebvo] ebvo_ctx_create: %s (%s)\n", ebvo_strerror(code), ctx->last_error.c_str());
         ebvo_ctx_destroy(ctx);
         return code;
     };
-#define CK(call)                                                             \
-    do                                                                       \
-    {                                                                        \
-        hipError_t e_ = (call);                                              \
-        if (e_ != hipSuccess)                                                \
-        {                                                                    \
-            ebvo_fail_hip(ctx, e_, #call, __FILE__, __LINE__);               \
-            return fail(e_ == hipErrorOutOfMemory ? EBVO_ERR_NOMEM : EBVO_ERR_HIP); \
-        }                                                                    \
-    } while (0)
-    CK(hipSetDevice(device));
-    CK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-    const size_t H2 = 2 * (size_t)max_h, W2 = 2 * (size_t)max_w, np2 = H2 * W2;
-    for (int k = 0; k < 2; ++k)
-    {
-        ImageWS &ws = ctx->im[k];
-        CK(hipMalloc(&ws.img, (size_t)max_h * max_w));
-        CK(hipMalloc(&ws.maps, sizeof(double) * np2 * PL_NUM));
-        CK(hipMalloc(&ws.flag, np2));
-        CK(hipMalloc(&ws.row_cnt, sizeof(int32_t) * 2 * H2));
-        CK(hipMalloc(&ws.row_off, sizeof(int32_t) * 2 * (H2 + 1)));
-        CK(hipMalloc(&ws.counts, sizeof(int32_t) * 2));
-        CK(hipMalloc(&ws.src, sizeof(int32_t) * 2 * (size_t)ctx->cap_edges));
-        CK(hipMalloc(&ws.edges, sizeof(ebvo_edge) * (size_t)ctx->cap_edges));
-        CK(hipMalloc(&ws.all4, sizeof(double) * 4 * (size_t)ctx->cap_edges));
-    }
-    CK(hipMalloc(&ctx->d_params, sizeof(double) * 16));
-    CK(hipHostMalloc(&ctx->h_small, sizeof(int32_t) * 64));
-#undef CK
+    if (hipSetDevice(device) != hipSuccess)
+        return fail(EBVO_ERR_HIP);
+    Slot *s0 = nullptr;
+    if ((rc = slot_create(ctx, &s0)))
+        return fail(rc);
+    ctx->slots.push_back(s0);
     if ((rc = toed_init_constants(ctx)))
         return fail(rc);
     *out = ctx;
@@ -233,12 +270,63 @@ static int check_size(ebvo_ctx *ctx, int h, int w)
     return EBVO_OK;
 }
 
-static int upload_image(ebvo_ctx *ctx, int slot, const uint8_t *img, int h, int w, ptrdiff_t stride)
+static int upload_image(ebvo_ctx *ctx, Slot &s, int k, const uint8_t *img, int h, int w, ptrdiff_t stride)
 {
     if (stride < w)
         return EBVO_ERR_ARG;
-    EBVO_HIP(ctx, hipMemcpy2DAsync(ctx->im[slot].img, (size_t)w, img, (size_t)stride, (size_t)w, (size_t)h,
-                                   hipMemcpyHostToDevice, ctx->stream));
+    EBVO_HIP(ctx, hipMemcpy2DAsync(s.im[k].img, (size_t)w, img, (size_t)stride, (size_t)w, (size_t)h,
+                                   hipMemcpyHostToDevice, s.stream));
+    return EBVO_OK;
+}
+
+// host-buffer entry points use slot 0; they must not run while a submitted pair is in flight on it
+static int host_slot(ebvo_ctx *ctx, Slot **out)
+{
+    Slot &s = *ctx->slots[0];
+    if (s.in_flight)
+    {
+        ctx->last_error = "slot 0 has a submitted pair in flight; call ebvo_stereo_wait first";
+        return EBVO_ERR_STATE;
+    }
+    s.have_pair = s.have_run = false;
+    *out = &s;
+    return EBVO_OK;
+}
+
+// run TOED on n_img resident images of the slot and read the counts back (synchronises)
+static int toed_sync(ebvo_ctx *ctx, Slot &s, int n_img, int h, int w, float *ms_conv, float *ms_nms)
+{
+    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+    const bool timed = ms_conv || ms_nms;
+    if (timed)
+    {
+        EBVO_HIP(ctx, hipEventCreate(&e0));
+        EBVO_HIP(ctx, hipEventCreate(&e1));
+        EBVO_HIP(ctx, hipEventCreate(&e2));
+    }
+    int rc = toed_enqueue(ctx, s, n_img, h, w, e0, e1, e2);
+    if (rc)
+        return rc;
+    int32_t hc[4] = {0, 0, 0, 0};
+    for (int k = 0; k < n_img; ++k)
+        EBVO_HIP(ctx, hipMemcpyAsync(hc + 2 * k, s.im[k].counts, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s.stream));
+    EBVO_HIP(ctx, hipStreamSynchronize(s.stream));
+    for (int k = 0; k < n_img; ++k)
+    {
+        s.im[k].n_total = hc[2 * k];
+        s.im[k].n_kept = hc[2 * k + 1];
+    }
+    if (timed)
+    {
+        float a = 0, b = 0;
+        EBVO_HIP(ctx, hipEventElapsedTime(&a, e0, e1));
+        EBVO_HIP(ctx, hipEventElapsedTime(&b, e1, e2));
+        if (ms_conv) *ms_conv = a;
+        if (ms_nms) *ms_nms = b;
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        (void)hipEventDestroy(e2);
+    }
     return EBVO_OK;
 }
 
@@ -250,15 +338,17 @@ extern "C" int ebvo_toed(ebvo_ctx *ctx, const uint8_t *img, int h, int w, ptrdif
         return EBVO_ERR_ARG;
     EBVO_HIP(ctx, hipSetDevice(ctx->device));
     int rc;
-    if ((rc = check_size(ctx, h, w)))
+    Slot *sp;
+    if ((rc = check_size(ctx, h, w)) || (rc = host_slot(ctx, &sp)))
         return rc;
-    if ((rc = upload_image(ctx, 0, img, h, w, stride)))
+    Slot &s = *sp;
+    if ((rc = upload_image(ctx, s, 0, img, h, w, stride)))
         return rc;
-    ctx->have_pair = ctx->have_run = false;
     float ms_c = 0, ms_n = 0;
-    if ((rc = toed_run_device(ctx, 1, h, w, (t_conv || t_nms) ? &ms_c : nullptr, (t_conv || t_nms) ? &ms_n : nullptr)))
+    const bool timed = t_conv || t_nms;
+    if ((rc = toed_sync(ctx, s, 1, h, w, timed ? &ms_c : nullptr, timed ? &ms_n : nullptr)))
         return rc;
-    const ImageWS &ws = ctx->im[0];
+    const ImageWS &ws = s.im[0];
     *n_kept = ws.n_kept;
     *n_total = ws.n_total;
     if (t_conv) *t_conv = ms_c * 1e-3;
@@ -272,11 +362,11 @@ extern "C" int ebvo_toed(ebvo_ctx *ctx, const uint8_t *img, int h, int w, ptrdif
         return EBVO_ERR_CAPACITY;
     if (out && ws.n_kept)
         EBVO_HIP(ctx, hipMemcpyAsync(out, ws.edges, sizeof(ebvo_edge) * (size_t)ws.n_kept, hipMemcpyDeviceToHost,
-                                     ctx->stream));
+                                     s.stream));
     if (all4 && ws.n_total)
         EBVO_HIP(ctx, hipMemcpyAsync(all4, ws.all4, sizeof(double) * 4 * (size_t)ws.n_total, hipMemcpyDeviceToHost,
-                                     ctx->stream));
-    EBVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                                     s.stream));
+    EBVO_HIP(ctx, hipStreamSynchronize(s.stream));
     return EBVO_OK;
 }
 
@@ -288,33 +378,34 @@ extern "C" int ebvo_toed_pair(ebvo_ctx *ctx, const uint8_t *img_left, const uint
         return EBVO_ERR_ARG;
     EBVO_HIP(ctx, hipSetDevice(ctx->device));
     int rc;
-    if ((rc = check_size(ctx, h, w)))
+    Slot *sp;
+    if ((rc = check_size(ctx, h, w)) || (rc = host_slot(ctx, &sp)))
         return rc;
-    if ((rc = upload_image(ctx, 0, img_left, h, w, stride_left)))
+    Slot &s = *sp;
+    if ((rc = upload_image(ctx, s, 0, img_left, h, w, stride_left)))
         return rc;
-    if ((rc = upload_image(ctx, 1, img_right, h, w, stride_right)))
+    if ((rc = upload_image(ctx, s, 1, img_right, h, w, stride_right)))
         return rc;
-    ctx->have_pair = ctx->have_run = false;
-    if ((rc = toed_run_device(ctx, 2, h, w, nullptr, nullptr)))
+    if ((rc = toed_sync(ctx, s, 2, h, w, nullptr, nullptr)))
         return rc;
     ebvo_edge *outs[2] = {out_left, out_right};
     bool too_small = false;
     for (int k = 0; k < 2; ++k)
     {
-        n_kept[k] = ctx->im[k].n_kept;
-        n_total[k] = ctx->im[k].n_total;
-        if (ctx->im[k].n_total > ctx->cap_edges)
+        n_kept[k] = s.im[k].n_kept;
+        n_total[k] = s.im[k].n_total;
+        if (s.im[k].n_total > ctx->cap_edges)
             return EBVO_ERR_CAPACITY;
-        if (outs[k] && ctx->im[k].n_kept > cap)
+        if (outs[k] && s.im[k].n_kept > cap)
             too_small = true;
     }
     if (too_small)
         return EBVO_ERR_CAPACITY;
     for (int k = 0; k < 2; ++k)
-        if (outs[k] && ctx->im[k].n_kept)
-            EBVO_HIP(ctx, hipMemcpyAsync(outs[k], ctx->im[k].edges, sizeof(ebvo_edge) * (size_t)ctx->im[k].n_kept,
-                                         hipMemcpyDeviceToHost, ctx->stream));
-    EBVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (outs[k] && s.im[k].n_kept)
+            EBVO_HIP(ctx, hipMemcpyAsync(outs[k], s.im[k].edges, sizeof(ebvo_edge) * (size_t)s.im[k].n_kept,
+                                         hipMemcpyDeviceToHost, s.stream));
+    EBVO_HIP(ctx, hipStreamSynchronize(s.stream));
     return EBVO_OK;
 }
 
@@ -338,42 +429,55 @@ extern "C" int ebvo_epi_candidates(ebvo_ctx *ctx, const ebvo_edge *L, int nL, co
         return EBVO_ERR_ARG;
     EBVO_HIP(ctx, hipSetDevice(ctx->device));
     int rc;
-    if ((rc = ebvo_grow(ctx, ctx->scratch_b, sizeof(ebvo_edge) * ((size_t)nL + 1))))
+    Slot *sp;
+    if ((rc = host_slot(ctx, &sp)))
         return rc;
-    if ((rc = ebvo_grow(ctx, ctx->scratch_c, sizeof(ebvo_edge) * ((size_t)nR + 1))))
-        return rc;
-    if ((rc = ebvo_grow(ctx, ctx->lines, sizeof(double) * 3 * ((size_t)nL + 1))))
-        return rc;
-    if (nL)
+    Slot &s = *sp;
+    *n_pairs = 0;
+    if (nL == 0 || nR == 0)
     {
-        EBVO_HIP(ctx, hipMemcpyAsync(ctx->scratch_b.p, L, sizeof(ebvo_edge) * (size_t)nL, hipMemcpyHostToDevice,
-                                     ctx->stream));
-        EBVO_HIP(ctx, hipMemcpyAsync(ctx->lines.p, lines, sizeof(double) * 3 * (size_t)nL, hipMemcpyHostToDevice,
-                                     ctx->stream));
+        memset(row_ptr, 0, sizeof(int32_t) * ((size_t)nL + 1));
+        return EBVO_OK;
     }
-    if (nR)
-        EBVO_HIP(ctx, hipMemcpyAsync(ctx->scratch_c.p, R, sizeof(ebvo_edge) * (size_t)nR, hipMemcpyHostToDevice,
-                                     ctx->stream));
-    ctx->have_run = false;
-    int64_t np = 0;
-    if ((rc = match_candidates_device(ctx, (const ebvo_edge *)ctx->scratch_b.p, nL, (const ebvo_edge *)ctx->scratch_c.p,
-                                      nR, (const double *)ctx->lines.p, epi_thr, max_disp, orient_thr_deg, stage_mask,
-                                      &np)))
+    if ((rc = ebvo_grow(ctx, s, s.scratch_b, sizeof(ebvo_edge) * (size_t)nL)))
         return rc;
+    if ((rc = ebvo_grow(ctx, s, s.scratch_c, sizeof(ebvo_edge) * (size_t)nR)))
+        return rc;
+    if ((rc = ebvo_grow(ctx, s, s.lines, sizeof(double) * 3 * (size_t)nL)))
+        return rc;
+    EBVO_HIP(ctx, hipMemcpyAsync(s.scratch_b.p, L, sizeof(ebvo_edge) * (size_t)nL, hipMemcpyHostToDevice, s.stream));
+    EBVO_HIP(ctx, hipMemcpyAsync(s.lines.p, lines, sizeof(double) * 3 * (size_t)nL, hipMemcpyHostToDevice, s.stream));
+    EBVO_HIP(ctx, hipMemcpyAsync(s.scratch_c.p, R, sizeof(ebvo_edge) * (size_t)nR, hipMemcpyHostToDevice, s.stream));
+    const ebvo_edge *dL = (const ebvo_edge *)s.scratch_b.p, *dR = (const ebvo_edge *)s.scratch_c.p;
+    if ((rc = match_candidates_enqueue(ctx, s, dL, nL, nullptr, dR, nR, nullptr, 0, (const double *)s.lines.p, epi_thr,
+                                       max_disp, orient_thr_deg, stage_mask, false)))
+        return rc;
+    unsigned long long h_total = 0;
+    EBVO_HIP(ctx, hipMemcpyAsync(&h_total, s.d_total, sizeof(h_total), hipMemcpyDeviceToHost, s.stream));
+    EBVO_HIP(ctx, hipMemcpyAsync(row_ptr, s.row_ptr.p, sizeof(int32_t) * ((size_t)nL + 1), hipMemcpyDeviceToHost,
+                                 s.stream));
+    EBVO_HIP(ctx, hipStreamSynchronize(s.stream));
+    if (h_total > 0x7fffffffull)
+    {
+        ctx->last_error = "candidate list exceeds 2^31-1 pairs";
+        return EBVO_ERR_CAPACITY;
+    }
+    const int64_t np = (int64_t)h_total;
     *n_pairs = np;
-    EBVO_HIP(ctx, hipMemcpyAsync(row_ptr, ctx->row_ptr.p, sizeof(int32_t) * ((size_t)nL + 1), hipMemcpyDeviceToHost,
-                                 ctx->stream));
-    int ret = EBVO_OK;
-    if (col_idx && np <= cap)
-    {
-        if (np)
-            EBVO_HIP(ctx, hipMemcpyAsync(col_idx, ctx->col_idx.p, sizeof(int32_t) * (size_t)np, hipMemcpyDeviceToHost,
-                                         ctx->stream));
-    }
-    else if (np > cap && (col_idx || cap > 0))
-        ret = EBVO_ERR_CAPACITY;
-    EBVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return ret;
+    if (np > cap)
+        return (col_idx || cap > 0) ? EBVO_ERR_CAPACITY : EBVO_OK;
+    if (np == 0 || !col_idx)
+        return EBVO_OK;
+    if ((rc = ebvo_grow(ctx, s, s.col_idx, sizeof(int32_t) * (size_t)np)))
+        return rc;
+    s.cap_pairs = np;
+    if ((rc = match_candidates_fill_enqueue(ctx, s, dL, nL, nullptr, dR, nR, nullptr, 0, (const double *)s.lines.p,
+                                            epi_thr, max_disp, orient_thr_deg, stage_mask)))
+        return rc;
+    EBVO_HIP(ctx, hipMemcpyAsync(col_idx, s.col_idx.p, sizeof(int32_t) * (size_t)np, hipMemcpyDeviceToHost, s.stream));
+    EBVO_HIP(ctx, hipStreamSynchronize(s.stream));
+    s.cap_pairs = 0; // the pipeline re-establishes its own capacity
+    return EBVO_OK;
 }
 
 extern "C" int ebvo_edge_patches(ebvo_ctx *ctx, const uint8_t *img, int h, int w, ptrdiff_t stride,
@@ -383,54 +487,26 @@ extern "C" int ebvo_edge_patches(ebvo_ctx *ctx, const uint8_t *img, int h, int w
         return EBVO_ERR_ARG;
     EBVO_HIP(ctx, hipSetDevice(ctx->device));
     int rc;
-    if ((rc = check_size(ctx, h, w)))
+    Slot *sp;
+    if ((rc = check_size(ctx, h, w)) || (rc = host_slot(ctx, &sp)))
         return rc;
+    Slot &s = *sp;
     if (n == 0)
         return EBVO_OK;
-    ctx->have_pair = ctx->have_run = false;
-    if ((rc = upload_image(ctx, 0, img, h, w, stride)))
+    if ((rc = upload_image(ctx, s, 0, img, h, w, stride)))
         return rc;
-    if ((rc = ebvo_grow(ctx, ctx->scratch_b, sizeof(ebvo_edge) * (size_t)n)))
+    if ((rc = ebvo_grow(ctx, s, s.scratch_b, sizeof(ebvo_edge) * (size_t)n)))
         return rc;
-    if ((rc = ebvo_grow(ctx, ctx->patches_raw, sizeof(float) * 98 * (size_t)n)))
+    if ((rc = ebvo_grow(ctx, s, s.patches_raw, sizeof(float) * 98 * (size_t)n)))
         return rc;
-    EBVO_HIP(ctx, hipMemcpyAsync(ctx->scratch_b.p, edges, sizeof(ebvo_edge) * (size_t)n, hipMemcpyHostToDevice,
-                                 ctx->stream));
-    if ((rc = match_patches_device(ctx, ctx->im[0].img, h, w, w, (const ebvo_edge *)ctx->scratch_b.p, n,
-                                   (float *)ctx->patches_raw.p, nullptr, nullptr)))
+    EBVO_HIP(ctx, hipMemcpyAsync(s.scratch_b.p, edges, sizeof(ebvo_edge) * (size_t)n, hipMemcpyHostToDevice, s.stream));
+    if ((rc = match_patches_enqueue(ctx, s, s.im[0].img, h, w, w, (const ebvo_edge *)s.scratch_b.p, n, nullptr, 0,
+                                    (float *)s.patches_raw.p, nullptr, nullptr)))
         return rc;
-    EBVO_HIP(ctx, hipMemcpyAsync(patches, ctx->patches_raw.p, sizeof(float) * 98 * (size_t)n, hipMemcpyDeviceToHost,
-                                 ctx->stream));
-    EBVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    EBVO_HIP(ctx, hipMemcpyAsync(patches, s.patches_raw.p, sizeof(float) * 98 * (size_t)n, hipMemcpyDeviceToHost,
+                                 s.stream));
+    EBVO_HIP(ctx, hipStreamSynchronize(s.stream));
     return EBVO_OK;
-}
-
-// shared by the host entry point and the pipeline: left patches + NCC over the CSR pairs
-static int ncc_pairs_core(ebvo_ctx *ctx, int h, int w, const ebvo_edge *d_L, int nL, const ebvo_edge *d_Rc,
-                          const int32_t *d_row_ptr, int64_t n_pairs, double thr, bool want_sims)
-{
-    int rc;
-    if ((rc = ebvo_grow(ctx, ctx->patches_raw, sizeof(float) * 98 * ((size_t)nL + 1))))
-        return rc;
-    if ((rc = ebvo_grow(ctx, ctx->patches_norm, sizeof(float) * 98 * ((size_t)nL + 1))))
-        return rc;
-    if ((rc = ebvo_grow(ctx, ctx->patches_flag, 2 * ((size_t)nL + 1))))
-        return rc;
-    if ((rc = ebvo_grow(ctx, ctx->match_cnt, 64)))
-        return rc;
-    if (want_sims && (rc = ebvo_grow(ctx, ctx->sims, sizeof(double) * 4 * ((size_t)n_pairs + 1))))
-        return rc;
-    if ((rc = ebvo_grow(ctx, ctx->best, sizeof(double) * ((size_t)n_pairs + 1))))
-        return rc;
-    if ((rc = ebvo_grow(ctx, ctx->keep, (size_t)n_pairs + 1)))
-        return rc;
-    if ((rc = match_patches_device(ctx, ctx->im[0].img, h, w, w, d_L, nL, (float *)ctx->patches_raw.p,
-                                   (float *)ctx->patches_norm.p, (uint8_t *)ctx->patches_flag.p)))
-        return rc;
-    return match_ncc_pairs_device(ctx, ctx->im[1].img, h, w, w, d_Rc, d_row_ptr, nL, n_pairs,
-                                  (const float *)ctx->patches_norm.p, (const uint8_t *)ctx->patches_flag.p, thr,
-                                  want_sims ? (double *)ctx->sims.p : nullptr, (double *)ctx->best.p,
-                                  (uint8_t *)ctx->keep.p, (int32_t *)ctx->match_cnt.p);
 }
 
 extern "C" int ebvo_ncc_pairs(ebvo_ctx *ctx, const uint8_t *imgL, const uint8_t *imgR, int h, int w,
@@ -442,8 +518,10 @@ extern "C" int ebvo_ncc_pairs(ebvo_ctx *ctx, const uint8_t *imgL, const uint8_t 
         return EBVO_ERR_ARG;
     EBVO_HIP(ctx, hipSetDevice(ctx->device));
     int rc;
-    if ((rc = check_size(ctx, h, w)))
+    Slot *sp;
+    if ((rc = check_size(ctx, h, w)) || (rc = host_slot(ctx, &sp)))
         return rc;
+    Slot &s = *sp;
     if (row_ptr[0] != 0)
         return EBVO_ERR_ARG;
     for (int i = 0; i < nL; ++i)
@@ -454,42 +532,54 @@ extern "C" int ebvo_ncc_pairs(ebvo_ctx *ctx, const uint8_t *imgL, const uint8_t 
         return EBVO_ERR_ARG;
     if (nL == 0)
         return EBVO_OK;
-    ctx->have_pair = ctx->have_run = false;
-    if ((rc = upload_image(ctx, 0, imgL, h, w, strideL)))
+    if ((rc = upload_image(ctx, s, 0, imgL, h, w, strideL)))
         return rc;
-    if ((rc = upload_image(ctx, 1, imgR, h, w, strideR)))
+    if ((rc = upload_image(ctx, s, 1, imgR, h, w, strideR)))
         return rc;
-    if ((rc = ebvo_grow(ctx, ctx->scratch_b, sizeof(ebvo_edge) * (size_t)nL)))
+    if ((rc = ebvo_grow(ctx, s, s.scratch_b, sizeof(ebvo_edge) * (size_t)nL)))
         return rc;
-    if ((rc = ebvo_grow(ctx, ctx->rc_edges, sizeof(ebvo_edge) * ((size_t)np + 1))))
+    if ((rc = ebvo_grow(ctx, s, s.rc_edges, sizeof(ebvo_edge) * ((size_t)np + 1))))
         return rc;
-    if ((rc = ebvo_grow(ctx, ctx->row_ptr, sizeof(int32_t) * ((size_t)nL + 1))))
+    if ((rc = ebvo_grow(ctx, s, s.row_ptr, sizeof(int32_t) * ((size_t)nL + 1))))
         return rc;
-    EBVO_HIP(ctx, hipMemcpyAsync(ctx->scratch_b.p, L, sizeof(ebvo_edge) * (size_t)nL, hipMemcpyHostToDevice,
-                                 ctx->stream));
+    if ((rc = ebvo_grow(ctx, s, s.patches_raw, sizeof(float) * 98 * (size_t)nL)))
+        return rc;
+    if ((rc = ebvo_grow(ctx, s, s.patches_norm, sizeof(float) * 98 * (size_t)nL)))
+        return rc;
+    if ((rc = ebvo_grow(ctx, s, s.patches_flag, 2 * (size_t)nL)))
+        return rc;
+    if (sims && (rc = ebvo_grow(ctx, s, s.sims, sizeof(double) * 4 * ((size_t)np + 1))))
+        return rc;
+    if ((rc = ebvo_grow(ctx, s, s.best, sizeof(double) * ((size_t)np + 1))))
+        return rc;
+    if ((rc = ebvo_grow(ctx, s, s.keep, (size_t)np + 1)))
+        return rc;
+    EBVO_HIP(ctx, hipMemcpyAsync(s.scratch_b.p, L, sizeof(ebvo_edge) * (size_t)nL, hipMemcpyHostToDevice, s.stream));
     if (np)
-        EBVO_HIP(ctx, hipMemcpyAsync(ctx->rc_edges.p, Rc, sizeof(ebvo_edge) * (size_t)np, hipMemcpyHostToDevice,
-                                     ctx->stream));
-    EBVO_HIP(ctx, hipMemcpyAsync(ctx->row_ptr.p, row_ptr, sizeof(int32_t) * ((size_t)nL + 1), hipMemcpyHostToDevice,
-                                 ctx->stream));
-    if ((rc = ncc_pairs_core(ctx, h, w, (const ebvo_edge *)ctx->scratch_b.p, nL, (const ebvo_edge *)ctx->rc_edges.p,
-                             (const int32_t *)ctx->row_ptr.p, np, thr, sims != nullptr)))
+        EBVO_HIP(ctx, hipMemcpyAsync(s.rc_edges.p, Rc, sizeof(ebvo_edge) * (size_t)np, hipMemcpyHostToDevice, s.stream));
+    EBVO_HIP(ctx, hipMemcpyAsync(s.row_ptr.p, row_ptr, sizeof(int32_t) * ((size_t)nL + 1), hipMemcpyHostToDevice,
+                                 s.stream));
+    if ((rc = match_patches_enqueue(ctx, s, s.im[0].img, h, w, w, (const ebvo_edge *)s.scratch_b.p, nL, nullptr, 0,
+                                    (float *)s.patches_raw.p, (float *)s.patches_norm.p, (uint8_t *)s.patches_flag.p)))
+        return rc;
+    if ((rc = match_ncc_pairs_enqueue(ctx, s, s.im[1].img, h, w, w, (const ebvo_edge *)s.rc_edges.p,
+                                      (const int32_t *)s.row_ptr.p, nL, np, (const float *)s.patches_norm.p,
+                                      (const uint8_t *)s.patches_flag.p, thr, sims ? (double *)s.sims.p : nullptr,
+                                      (double *)s.best.p, (uint8_t *)s.keep.p)))
         return rc;
     if (left_patches)
-        EBVO_HIP(ctx, hipMemcpyAsync(left_patches, ctx->patches_raw.p, sizeof(float) * 98 * (size_t)nL,
-                                     hipMemcpyDeviceToHost, ctx->stream));
+        EBVO_HIP(ctx, hipMemcpyAsync(left_patches, s.patches_raw.p, sizeof(float) * 98 * (size_t)nL,
+                                     hipMemcpyDeviceToHost, s.stream));
     if (np)
     {
         if (sims)
-            EBVO_HIP(ctx, hipMemcpyAsync(sims, ctx->sims.p, sizeof(double) * 4 * (size_t)np, hipMemcpyDeviceToHost,
-                                         ctx->stream));
+            EBVO_HIP(ctx, hipMemcpyAsync(sims, s.sims.p, sizeof(double) * 4 * (size_t)np, hipMemcpyDeviceToHost, s.stream));
         if (best)
-            EBVO_HIP(ctx, hipMemcpyAsync(best, ctx->best.p, sizeof(double) * (size_t)np, hipMemcpyDeviceToHost,
-                                         ctx->stream));
+            EBVO_HIP(ctx, hipMemcpyAsync(best, s.best.p, sizeof(double) * (size_t)np, hipMemcpyDeviceToHost, s.stream));
         if (keep)
-            EBVO_HIP(ctx, hipMemcpyAsync(keep, ctx->keep.p, (size_t)np, hipMemcpyDeviceToHost, ctx->stream));
+            EBVO_HIP(ctx, hipMemcpyAsync(keep, s.keep.p, (size_t)np, hipMemcpyDeviceToHost, s.stream));
     }
-    EBVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    EBVO_HIP(ctx, hipStreamSynchronize(s.stream));
     return EBVO_OK;
 }
 
@@ -501,21 +591,24 @@ extern "C" int ebvo_ncc_patches(ebvo_ctx *ctx, const float *A, const float *B, i
     if (n == 0)
         return EBVO_OK;
     int rc;
+    Slot *sp;
+    if ((rc = host_slot(ctx, &sp)))
+        return rc;
+    Slot &s = *sp;
     const size_t pb = sizeof(float) * 49 * (size_t)n;
-    if ((rc = ebvo_grow(ctx, ctx->scratch_b, pb)))
+    if ((rc = ebvo_grow(ctx, s, s.scratch_b, pb)))
         return rc;
-    if ((rc = ebvo_grow(ctx, ctx->scratch_c, pb)))
+    if ((rc = ebvo_grow(ctx, s, s.scratch_c, pb)))
         return rc;
-    if ((rc = ebvo_grow(ctx, ctx->scratch_d, sizeof(double) * (size_t)n)))
+    if ((rc = ebvo_grow(ctx, s, s.scratch_d, sizeof(double) * (size_t)n)))
         return rc;
-    EBVO_HIP(ctx, hipMemcpyAsync(ctx->scratch_b.p, A, pb, hipMemcpyHostToDevice, ctx->stream));
-    EBVO_HIP(ctx, hipMemcpyAsync(ctx->scratch_c.p, B, pb, hipMemcpyHostToDevice, ctx->stream));
-    if ((rc = match_ncc_stored_device(ctx, (const float *)ctx->scratch_b.p, (const float *)ctx->scratch_c.p, n,
-                                      (double *)ctx->scratch_d.p)))
+    EBVO_HIP(ctx, hipMemcpyAsync(s.scratch_b.p, A, pb, hipMemcpyHostToDevice, s.stream));
+    EBVO_HIP(ctx, hipMemcpyAsync(s.scratch_c.p, B, pb, hipMemcpyHostToDevice, s.stream));
+    if ((rc = match_ncc_stored_enqueue(ctx, s, (const float *)s.scratch_b.p, (const float *)s.scratch_c.p, n,
+                                       (double *)s.scratch_d.p)))
         return rc;
-    EBVO_HIP(ctx, hipMemcpyAsync(sim, ctx->scratch_d.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost,
-                                 ctx->stream));
-    EBVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    EBVO_HIP(ctx, hipMemcpyAsync(sim, s.scratch_d.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, s.stream));
+    EBVO_HIP(ctx, hipStreamSynchronize(s.stream));
     return EBVO_OK;
 }
 
@@ -537,17 +630,17 @@ extern "C" int ebvo_ncc_quads(ebvo_ctx *ctx, const float *kfL, const float *kfR,
             memcpy(&A[((size_t)k * 8 + m) * 49], kf, sizeof(float) * 49);
             memcpy(&B[((size_t)k * 8 + m) * 49], cf, sizeof(float) * 49);
         }
-    std::vector<double> s((size_t)n * 8);
-    int rc = ebvo_ncc_patches(ctx, A.data(), B.data(), n * 8, s.data());
+    std::vector<double> sv((size_t)n * 8);
+    int rc = ebvo_ncc_patches(ctx, A.data(), B.data(), n * 8, sv.data());
     if (rc)
         return rc;
     for (int k = 0; k < n; ++k)
     {
-        double sl = s[(size_t)k * 8], sr = s[(size_t)k * 8 + 4];
+        double sl = sv[(size_t)k * 8], sr = sv[(size_t)k * 8 + 4];
         for (int m = 1; m < 4; ++m)
         {
-            if (sl < s[(size_t)k * 8 + m]) sl = s[(size_t)k * 8 + m];
-            if (sr < s[(size_t)k * 8 + 4 + m]) sr = s[(size_t)k * 8 + 4 + m];
+            if (sl < sv[(size_t)k * 8 + m]) sl = sv[(size_t)k * 8 + m];
+            if (sr < sv[(size_t)k * 8 + 4 + m]) sr = sv[(size_t)k * 8 + 4 + m];
         }
         sim_left[k] = sl;
         sim_right[k] = sr;
@@ -558,6 +651,10 @@ extern "C" int ebvo_ncc_quads(ebvo_ctx *ctx, const float *kfL, const float *kfR,
 }
 
 // ------------------------------------------------------------------------------------------
+// Device-resident pipeline.  A pair is ENQUEUED without any host synchronisation: every size lives in device
+// memory, every launch is sized by a capacity, the last kernel gathers the counts, one async copy brings them to
+// pinned host memory.  ebvo_stereo_wait synchronises the slot's stream, and only if the candidate list did not
+// fit the pair-indexed buffers does it grow them and re-enqueue the matching half.
 extern "C" void ebvo_stereo_default_params(ebvo_stereo_params *p)
 {
     if (!p)
@@ -570,127 +667,253 @@ extern "C" void ebvo_stereo_default_params(ebvo_stereo_params *p)
     p->stage_mask = EBVO_STAGE_ALL;
 }
 
+static int get_slot(ebvo_ctx *ctx, int slot, Slot **out)
+{
+    if (!ctx || slot < 0 || slot >= (int)ctx->slots.size())
+        return EBVO_ERR_ARG;
+    *out = ctx->slots[(size_t)slot];
+    return EBVO_OK;
+}
+
+extern "C" int ebvo_stereo_set_slots(ebvo_ctx *ctx, int n_slots)
+{
+    if (!ctx || n_slots < 1 || n_slots > 64)
+        return EBVO_ERR_ARG;
+    EBVO_HIP(ctx, hipSetDevice(ctx->device));
+    while ((int)ctx->slots.size() < n_slots)
+    {
+        Slot *s = nullptr;
+        int rc = slot_create(ctx, &s);
+        if (rc)
+            return rc;
+        ctx->slots.push_back(s);
+    }
+    return EBVO_OK;
+}
+
+extern "C" int ebvo_stereo_upload_slot(ebvo_ctx *ctx, int slot, const uint8_t *img_left, const uint8_t *img_right,
+                                       int h, int w, ptrdiff_t stride_left, ptrdiff_t stride_right)
+{
+    Slot *sp;
+    int rc;
+    if (!img_left || !img_right || (rc = get_slot(ctx, slot, &sp)))
+        return EBVO_ERR_ARG;
+    EBVO_HIP(ctx, hipSetDevice(ctx->device));
+    if ((rc = check_size(ctx, h, w)))
+        return rc;
+    Slot &s = *sp;
+    if (s.in_flight)
+        return EBVO_ERR_STATE;
+    s.have_pair = s.have_run = false;
+    if ((rc = upload_image(ctx, s, 0, img_left, h, w, stride_left)))
+        return rc;
+    if ((rc = upload_image(ctx, s, 1, img_right, h, w, stride_right)))
+        return rc;
+    EBVO_HIP(ctx, hipStreamSynchronize(s.stream));
+    s.cur_h = h;
+    s.cur_w = w;
+    s.have_pair = true;
+    return EBVO_OK;
+}
+
 extern "C" int ebvo_stereo_upload(ebvo_ctx *ctx, const uint8_t *img_left, const uint8_t *img_right, int h, int w,
                                   ptrdiff_t stride_left, ptrdiff_t stride_right)
 {
-    if (!ctx || !img_left || !img_right)
+    return ebvo_stereo_upload_slot(ctx, 0, img_left, img_right, h, w, stride_left, stride_right);
+}
+
+// capacity-sized buffers of the pipeline
+static int ensure_pipeline_buffers(ebvo_ctx *ctx, Slot &s, int64_t cap_pairs)
+{
+    const size_t ce = (size_t)ctx->cap_edges;
+    int rc;
+    if ((rc = ebvo_grow(ctx, s, s.lines, sizeof(double) * 3 * ce)))
+        return rc;
+    if ((rc = ebvo_grow(ctx, s, s.patches_raw, sizeof(float) * 98 * ce)))
+        return rc;
+    if ((rc = ebvo_grow(ctx, s, s.patches_norm, sizeof(float) * 98 * ce)))
+        return rc;
+    if ((rc = ebvo_grow(ctx, s, s.patches_flag, 2 * ce)))
+        return rc;
+    if ((rc = ebvo_grow(ctx, s, s.patches_norm_r, sizeof(float) * 98 * ce)))
+        return rc;
+    if ((rc = ebvo_grow(ctx, s, s.patches_flag_r, 2 * ce)))
+        return rc;
+    if ((rc = ebvo_grow(ctx, s, s.sincos, sizeof(double) * 2 * ce)))
+        return rc;
+    const size_t cp = (size_t)cap_pairs;
+    if ((rc = ebvo_grow(ctx, s, s.col_idx, sizeof(int32_t) * cp)))
+        return rc;
+    if ((rc = ebvo_grow(ctx, s, s.pair_left, sizeof(int32_t) * cp)))
+        return rc;
+    if ((rc = ebvo_grow(ctx, s, s.sims, sizeof(double) * 4 * cp)))
+        return rc;
+    if ((rc = ebvo_grow(ctx, s, s.best, sizeof(double) * cp)))
+        return rc;
+    if ((rc = ebvo_grow(ctx, s, s.keep, cp)))
+        return rc;
+    s.cap_pairs = cap_pairs;
+    s.pipe_cap = cap_pairs;
+    return EBVO_OK;
+}
+
+// lines -> candidates (count, scan, fill) -> patch banks -> NCC -> result record; no host synchronisation
+static int enqueue_matching(ebvo_ctx *ctx, Slot &s)
+{
+    const ebvo_stereo_params &p = s.params;
+    const int h = s.cur_h, w = s.cur_w, ce = ctx->cap_edges;
+    const int32_t *d_nL = s.im[0].counts + 1, *d_nR = s.im[1].counts + 1;
+    int rc;
+    if ((rc = match_lines_enqueue(ctx, s, s.d_F, s.im[0].edges, 0, d_nL, ce, (double *)s.lines.p)))
+        return rc;
+    if ((rc = match_candidates_enqueue(ctx, s, s.im[0].edges, 0, d_nL, s.im[1].edges, 0, d_nR, ce,
+                                       (const double *)s.lines.p, p.epi_thr, p.max_disp, p.orient_thr_deg, p.stage_mask,
+                                       true)))
+        return rc;
+    if ((rc = match_patches_enqueue(ctx, s, s.im[0].img, h, w, w, s.im[0].edges, 0, d_nL, ce, (float *)s.patches_raw.p,
+                                    (float *)s.patches_norm.p, (uint8_t *)s.patches_flag.p)))
+        return rc;
+    if ((rc = match_patches_enqueue(ctx, s, s.im[1].img, h, w, w, s.im[1].edges, 0, d_nR, ce, nullptr,
+                                    (float *)s.patches_norm_r.p, (uint8_t *)s.patches_flag_r.p)))
+        return rc;
+    if ((rc = match_ncc_banked_enqueue(ctx, s, 0, d_nL, ce, 0, p.ncc_thr)))
+        return rc;
+    return match_pair_result_enqueue(ctx, s);
+}
+
+extern "C" int ebvo_stereo_submit(ebvo_ctx *ctx, int slot, const ebvo_stereo_params *p)
+{
+    Slot *sp;
+    if (!p || (p->stage_mask & ~EBVO_STAGE_ALL) || p->stage_mask == 0 || get_slot(ctx, slot, &sp))
         return EBVO_ERR_ARG;
+    Slot &s = *sp;
+    if (!s.have_pair || s.in_flight)
+        return EBVO_ERR_STATE;
     EBVO_HIP(ctx, hipSetDevice(ctx->device));
     int rc;
-    if ((rc = check_size(ctx, h, w)))
+    s.have_run = false;
+    s.params = *p;
+    {
+        int64_t want = s.pipe_cap > 0 ? s.pipe_cap : 8 * (int64_t)ctx->cap_edges;
+        if (want < 4096)
+            want = 4096;
+        if ((rc = ensure_pipeline_buffers(ctx, s, want)))
+            return rc;
+    }
+    EBVO_HIP(ctx, hipMemcpyAsync(s.d_F, s.params.F21, sizeof(double) * 9, hipMemcpyHostToDevice, s.stream));
+    if ((rc = toed_enqueue(ctx, s, 2, s.cur_h, s.cur_w, nullptr, nullptr, nullptr)))
         return rc;
-    ctx->have_pair = ctx->have_run = false;
-    if ((rc = upload_image(ctx, 0, img_left, h, w, stride_left)))
+    if ((rc = enqueue_matching(ctx, s)))
         return rc;
-    if ((rc = upload_image(ctx, 1, img_right, h, w, stride_right)))
-        return rc;
-    EBVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->cur_h = h;
-    ctx->cur_w = w;
-    ctx->have_pair = true;
+    s.in_flight = true;
+    return EBVO_OK;
+}
+
+extern "C" int ebvo_stereo_wait(ebvo_ctx *ctx, int slot, ebvo_stereo_counts *counts)
+{
+    Slot *sp;
+    if (!counts || get_slot(ctx, slot, &sp))
+        return EBVO_ERR_ARG;
+    Slot &s = *sp;
+    if (!s.in_flight)
+        return EBVO_ERR_STATE;
+    EBVO_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = EBVO_OK;
+    for (int attempt = 0; attempt < 4; ++attempt)
+    {
+        hipError_t e = hipStreamSynchronize(s.stream);
+        if (e != hipSuccess)
+        {
+            s.in_flight = false;
+            return ebvo_fail_hip(ctx, e, "hipStreamSynchronize", __FILE__, __LINE__);
+        }
+        const PairResult r = *s.h_result;
+        if (r.n_total_left > ctx->cap_edges || r.n_total_right > ctx->cap_edges)
+        {
+            s.in_flight = false;
+            ctx->last_error = "internal edge capacity exceeded";
+            return EBVO_ERR_CAPACITY;
+        }
+        if (!r.overflow)
+        {
+            s.result = r;
+            break;
+        }
+        if (r.n_pairs > 0x7fffffffll)
+        {
+            s.in_flight = false;
+            ctx->last_error = "candidate list exceeds 2^31-1 pairs";
+            return EBVO_ERR_CAPACITY;
+        }
+        // more candidates than the buffers hold: grow them and redo the matching half (TOED results are intact)
+        int64_t want = r.n_pairs + r.n_pairs / 4 + 1024;
+        if ((rc = ensure_pipeline_buffers(ctx, s, want)) || (rc = enqueue_matching(ctx, s)))
+        {
+            s.in_flight = false;
+            return rc;
+        }
+    }
+    s.in_flight = false;
+    s.im[0].n_kept = s.result.n_left;
+    s.im[0].n_total = s.result.n_total_left;
+    s.im[1].n_kept = s.result.n_right;
+    s.im[1].n_total = s.result.n_total_right;
+    counts->n_left = s.result.n_left;
+    counts->n_right = s.result.n_right;
+    counts->n_total_left = s.result.n_total_left;
+    counts->n_total_right = s.result.n_total_right;
+    counts->n_pairs = s.result.n_pairs;
+    counts->n_matches = s.result.n_matches;
+    s.have_run = true;
     return EBVO_OK;
 }
 
 extern "C" int ebvo_stereo_run(ebvo_ctx *ctx, const ebvo_stereo_params *p, ebvo_stereo_counts *counts)
 {
-    if (!ctx || !p || !counts || (p->stage_mask & ~EBVO_STAGE_ALL) || p->stage_mask == 0)
+    if (!ctx || !p || !counts)
         return EBVO_ERR_ARG;
-    if (!ctx->have_pair)
+    int rc = ebvo_stereo_submit(ctx, 0, p);
+    if (rc)
+        return rc;
+    return ebvo_stereo_wait(ctx, 0, counts);
+}
+
+extern "C" int ebvo_stereo_fetch_slot(ebvo_ctx *ctx, int slot, ebvo_edge *left, ebvo_edge *right, int32_t *row_ptr,
+                                      int32_t *col_idx, double *sims, double *best, uint8_t *keep, float *left_patches)
+{
+    Slot *sp;
+    if (get_slot(ctx, slot, &sp))
+        return EBVO_ERR_ARG;
+    Slot &s = *sp;
+    if (!s.have_run || s.in_flight)
         return EBVO_ERR_STATE;
     EBVO_HIP(ctx, hipSetDevice(ctx->device));
-    const int h = ctx->cur_h, w = ctx->cur_w;
-    int rc;
-    ctx->have_run = false;
-    EBVO_HIP(ctx, hipMemcpyAsync(ctx->d_params, p->F21, sizeof(double) * 9, hipMemcpyHostToDevice, ctx->stream));
-    if ((rc = toed_run_device(ctx, 2, h, w, nullptr, nullptr)))
-        return rc;
-    const int nL = ctx->im[0].n_kept, nR = ctx->im[1].n_kept;
-    if (ctx->im[0].n_total > ctx->cap_edges || ctx->im[1].n_total > ctx->cap_edges)
-        return EBVO_ERR_CAPACITY;
-    if ((rc = ebvo_grow(ctx, ctx->lines, sizeof(double) * 3 * ((size_t)nL + 1))))
-        return rc;
-    if ((rc = match_lines_device(ctx, ctx->d_params, ctx->im[0].edges, nL, (double *)ctx->lines.p)))
-        return rc;
-    int64_t np = 0;
-    if ((rc = match_candidates_device(ctx, ctx->im[0].edges, nL, ctx->im[1].edges, nR, (const double *)ctx->lines.p,
-                                      p->epi_thr, p->max_disp, p->orient_thr_deg, p->stage_mask, &np)))
-        return rc;
-    // NCC from banks: left and right patches are sampled and normalised once per edge
-    if ((rc = ebvo_grow(ctx, ctx->patches_raw, sizeof(float) * 98 * ((size_t)nL + 1))))
-        return rc;
-    if ((rc = ebvo_grow(ctx, ctx->patches_norm, sizeof(float) * 98 * ((size_t)nL + 1))))
-        return rc;
-    if ((rc = ebvo_grow(ctx, ctx->patches_flag, 2 * ((size_t)nL + 1))))
-        return rc;
-    if ((rc = ebvo_grow(ctx, ctx->patches_norm_r, sizeof(float) * 98 * ((size_t)nR + 1))))
-        return rc;
-    if ((rc = ebvo_grow(ctx, ctx->patches_flag_r, 2 * ((size_t)nR + 1))))
-        return rc;
-    if ((rc = ebvo_grow(ctx, ctx->match_cnt, 64)))
-        return rc;
-    if ((rc = ebvo_grow(ctx, ctx->sims, sizeof(double) * 4 * ((size_t)np + 1))))
-        return rc;
-    if ((rc = ebvo_grow(ctx, ctx->best, sizeof(double) * ((size_t)np + 1))))
-        return rc;
-    if ((rc = ebvo_grow(ctx, ctx->keep, (size_t)np + 1)))
-        return rc;
-    if ((rc = match_patches_device(ctx, ctx->im[0].img, h, w, w, ctx->im[0].edges, nL, (float *)ctx->patches_raw.p,
-                                   (float *)ctx->patches_norm.p, (uint8_t *)ctx->patches_flag.p)))
-        return rc;
-    if ((rc = match_patches_device(ctx, ctx->im[1].img, h, w, w, ctx->im[1].edges, nR, nullptr,
-                                   (float *)ctx->patches_norm_r.p, (uint8_t *)ctx->patches_flag_r.p)))
-        return rc;
-    if ((rc = match_ncc_banked_device(ctx, (const int32_t *)ctx->row_ptr.p, (const int32_t *)ctx->col_idx.p, nL, np,
-                                      (const float *)ctx->patches_norm.p, (const uint8_t *)ctx->patches_flag.p,
-                                      (const float *)ctx->patches_norm_r.p, (const uint8_t *)ctx->patches_flag_r.p,
-                                      p->ncc_thr, (double *)ctx->sims.p, (double *)ctx->best.p, (uint8_t *)ctx->keep.p,
-                                      (int32_t *)ctx->match_cnt.p)))
-        return rc;
-    EBVO_HIP(ctx, hipMemcpyAsync(ctx->h_small + 8, ctx->match_cnt.p, sizeof(int32_t), hipMemcpyDeviceToHost,
-                                 ctx->stream));
-    EBVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    counts->n_left = nL;
-    counts->n_right = nR;
-    counts->n_total_left = ctx->im[0].n_total;
-    counts->n_total_right = ctx->im[1].n_total;
-    counts->n_pairs = np;
-    counts->n_matches = ctx->h_small[8];
-    ctx->n_pairs = np;
-    ctx->n_matches = counts->n_matches;
-    ctx->n_left = nL;
-    ctx->have_run = true;
+    const size_t nL = (size_t)s.result.n_left, nR = (size_t)s.result.n_right, np = (size_t)s.result.n_pairs;
+    hipStream_t st = s.stream;
+    if (left && nL)
+        EBVO_HIP(ctx, hipMemcpyAsync(left, s.im[0].edges, sizeof(ebvo_edge) * nL, hipMemcpyDeviceToHost, st));
+    if (right && nR)
+        EBVO_HIP(ctx, hipMemcpyAsync(right, s.im[1].edges, sizeof(ebvo_edge) * nR, hipMemcpyDeviceToHost, st));
+    if (row_ptr)
+        EBVO_HIP(ctx, hipMemcpyAsync(row_ptr, s.row_ptr.p, sizeof(int32_t) * (nL + 1), hipMemcpyDeviceToHost, st));
+    if (col_idx && np)
+        EBVO_HIP(ctx, hipMemcpyAsync(col_idx, s.col_idx.p, sizeof(int32_t) * np, hipMemcpyDeviceToHost, st));
+    if (sims && np)
+        EBVO_HIP(ctx, hipMemcpyAsync(sims, s.sims.p, sizeof(double) * 4 * np, hipMemcpyDeviceToHost, st));
+    if (best && np)
+        EBVO_HIP(ctx, hipMemcpyAsync(best, s.best.p, sizeof(double) * np, hipMemcpyDeviceToHost, st));
+    if (keep && np)
+        EBVO_HIP(ctx, hipMemcpyAsync(keep, s.keep.p, np, hipMemcpyDeviceToHost, st));
+    if (left_patches && nL)
+        EBVO_HIP(ctx, hipMemcpyAsync(left_patches, s.patches_raw.p, sizeof(float) * 98 * nL, hipMemcpyDeviceToHost, st));
+    EBVO_HIP(ctx, hipStreamSynchronize(st));
     return EBVO_OK;
 }
 
 extern "C" int ebvo_stereo_fetch(ebvo_ctx *ctx, ebvo_edge *left, ebvo_edge *right, int32_t *row_ptr,
                                  int32_t *col_idx, double *sims, double *best, uint8_t *keep, float *left_patches)
 {
-    if (!ctx)
-        return EBVO_ERR_ARG;
-    if (!ctx->have_run)
-        return EBVO_ERR_STATE;
-    EBVO_HIP(ctx, hipSetDevice(ctx->device));
-    const size_t nL = (size_t)ctx->im[0].n_kept, nR = (size_t)ctx->im[1].n_kept, np = (size_t)ctx->n_pairs;
-    hipStream_t s = ctx->stream;
-    if (left && nL)
-        EBVO_HIP(ctx, hipMemcpyAsync(left, ctx->im[0].edges, sizeof(ebvo_edge) * nL, hipMemcpyDeviceToHost, s));
-    if (right && nR)
-        EBVO_HIP(ctx, hipMemcpyAsync(right, ctx->im[1].edges, sizeof(ebvo_edge) * nR, hipMemcpyDeviceToHost, s));
-    if (row_ptr)
-        EBVO_HIP(ctx, hipMemcpyAsync(row_ptr, ctx->row_ptr.p, sizeof(int32_t) * (nL + 1), hipMemcpyDeviceToHost, s));
-    if (col_idx && np)
-        EBVO_HIP(ctx, hipMemcpyAsync(col_idx, ctx->col_idx.p, sizeof(int32_t) * np, hipMemcpyDeviceToHost, s));
-    if (sims && np)
-        EBVO_HIP(ctx, hipMemcpyAsync(sims, ctx->sims.p, sizeof(double) * 4 * np, hipMemcpyDeviceToHost, s));
-    if (best && np)
-        EBVO_HIP(ctx, hipMemcpyAsync(best, ctx->best.p, sizeof(double) * np, hipMemcpyDeviceToHost, s));
-    if (keep && np)
-        EBVO_HIP(ctx, hipMemcpyAsync(keep, ctx->keep.p, np, hipMemcpyDeviceToHost, s));
-    if (left_patches && nL)
-        EBVO_HIP(ctx, hipMemcpyAsync(left_patches, ctx->patches_raw.p, sizeof(float) * 98 * nL,
-                                     hipMemcpyDeviceToHost, s));
-    EBVO_HIP(ctx, hipStreamSynchronize(s));
-    return EBVO_OK;
+    return ebvo_stereo_fetch_slot(ctx, 0, left, right, row_ptr, col_idx, sims, best, keep, left_patches);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -736,5 +959,5 @@ extern "C" int ebvo_fp64_peak(ebvo_ctx *ctx, int iters, double *tflops_muladd, d
     if (!ctx || iters <= 0)
         return EBVO_ERR_ARG;
     EBVO_HIP(ctx, hipSetDevice(ctx->device));
-    return misc_fp64_peak(ctx, iters, tflops_muladd, tflops_fma);
+    return misc_fp64_peak(ctx, *ctx->slots[0], iters, tflops_muladd, tflops_fma);
 }

@@ -33,7 +33,8 @@ static_assert(K_NUM <= EBVO_MAX_KERNELS, "grow EBVO_MAX_KERNELS");
 
 extern const char *const g_kernel_names[K_NUM];
 
-// Interpolated-grid planes written by the convolution, per image.
+// Interpolated-grid planes written by the convolution, per image.  Each plane holds the four sub-pixel
+// phases as separate H x W sub-planes: [sy][sx][H][W] (toed_kernels.hip: midx).
 enum
 {
     PL_IX = 0,
@@ -50,19 +51,29 @@ struct GrowBuf
     size_t bytes = 0;
 };
 
-// Per-image device workspace (two of them: left / right).
+// Per-image device workspace.
 struct ImageWS
 {
     uint8_t *img = nullptr;     // h*w, tightly packed
-    double *maps = nullptr;     // PL_NUM planes of 2H x 2W
+    double *maps = nullptr;     // PL_NUM planes of 4 x H x W
     uint8_t *flag = nullptr;    // 2H x 2W: 0 none, 1 NMS maximum, 3 maximum inside the 10-px border
     int32_t *row_cnt = nullptr; // [2][H2]   per interpolated row: all maxima, kept maxima
     int32_t *row_off = nullptr; // [2][H2+1] exclusive prefix of row_cnt
-    int32_t *counts = nullptr;  // [2] n_total, n_kept
+    int32_t *counts = nullptr;  // [2] n_total, n_kept  (device-side sizes of everything downstream)
     int32_t *src = nullptr;     // [cap][2] (pixel offset, kept rank or -1) per maximum, raster order
     ebvo_edge *edges = nullptr; // [cap] kept edges
     double *all4 = nullptr;     // [cap][4] every maximum (x, y, theta, mag)
-    int n_total = 0, n_kept = 0;
+    int n_total = 0, n_kept = 0; // host copies, valid after a synchronising call
+};
+
+// What the last kernel of a device-resident pair reports (match_kernels.hip: pair_result_kernel).
+struct PairResult
+{
+    int32_t n_left, n_right, n_total_left, n_total_right;
+    int64_t n_pairs;
+    int64_t n_matches;
+    int32_t overflow;
+    int32_t pad;
 };
 
 struct ProfEvent
@@ -71,31 +82,41 @@ struct ProfEvent
     int kid;
 };
 
+// Everything that belongs to one HIP stream: a stereo pair in flight (or the workspace of a host-buffer call).
+struct Slot
+{
+    hipStream_t stream = nullptr;
+    ImageWS im[2];
+    int cur_h = 0, cur_w = 0;
+    bool have_pair = false, have_run = false, in_flight = false;
+
+    // matching workspace
+    GrowBuf lines, boxes_chunk, boxes_group, cand_cnt, row_ptr, scan_tmp, col_idx, rc_edges, sims, best, keep,
+        patches_raw, patches_norm, patches_flag, patches_norm_r, patches_flag_r, pair_left, sincos, scratch_b, scratch_c,
+        scratch_d;
+    int64_t cap_pairs = 0;               // capacity of col_idx & co. as the kernels of the current call see it
+    int64_t pipe_cap = 0;                // capacity the device pipeline keeps between pairs
+    unsigned long long *d_total = nullptr; // 64-bit candidate total
+    int32_t *d_matches = nullptr;
+    int32_t *d_sizes = nullptr;          // [4] host-provided sizes for the host-buffer entry points
+    double *d_F = nullptr;               // 9 doubles
+    PairResult *d_result = nullptr, *h_result = nullptr; // h_result is pinned
+    ebvo_stereo_params params{};
+    PairResult result{};                 // last completed result
+
+    std::vector<ProfEvent> prof_pending;
+};
+
 struct ebvo_ctx
 {
     int device = 0;
     int max_h = 0, max_w = 0;
     int cap_edges = 0; // per image
-    hipStream_t stream = nullptr;
     std::string last_error;
+    std::vector<Slot *> slots; // slot 0 always exists; it also serves the host-buffer entry points
 
-    ImageWS im[2];
-    int cur_h = 0, cur_w = 0; // size of the resident stereo pair
-    bool have_pair = false, have_run = false;
-
-    // matching workspace (grown on demand)
-    GrowBuf lines, boxes_chunk, boxes_group, cand_cnt, row_ptr, scan_tmp, col_idx, rc_edges, sims, best, keep,
-        patches_raw, patches_norm, patches_flag, patches_norm_r, patches_flag_r, match_cnt, scratch_a, scratch_b, scratch_c, scratch_d;
-    int64_t n_pairs = 0, n_matches = 0;
-    int n_left = 0;
-    double *d_params = nullptr; // F21 for the device line kernel (9 doubles)
-
-    // pinned host staging for small read-backs
-    int32_t *h_small = nullptr; // 64 ints
-
-    // profiling
+    // profiling (accumulated over all slots)
     bool prof = false;
-    std::vector<ProfEvent> prof_pending;
     std::vector<ProfEvent> prof_free;
     double prof_ms[K_NUM] = {0};
     int64_t prof_launches[K_NUM] = {0};
@@ -111,46 +132,54 @@ int ebvo_fail_hip(ebvo_ctx *ctx, hipError_t e, const char *what, const char *fil
             return ebvo_fail_hip((ctx), e_, #call, __FILE__, __LINE__);  \
     } while (0)
 
-int ebvo_grow(ebvo_ctx *ctx, GrowBuf &b, size_t bytes);
+// grow a slot buffer (synchronises the slot's stream before freeing the old allocation)
+int ebvo_grow(ebvo_ctx *ctx, Slot &s, GrowBuf &b, size_t bytes);
 
-// profiling brackets around a kernel launch
-void ebvo_prof_begin(ebvo_ctx *ctx, int kid);
-void ebvo_prof_end(ebvo_ctx *ctx);
+// profiling brackets around kernel launches on a slot's stream
+void ebvo_prof_begin(ebvo_ctx *ctx, Slot &s, int kid);
+void ebvo_prof_end(ebvo_ctx *ctx, Slot &s);
 
 struct ProfScope
 {
     ebvo_ctx *c;
-    ProfScope(ebvo_ctx *ctx, int kid) : c(ctx) { ebvo_prof_begin(c, kid); }
-    ~ProfScope() { ebvo_prof_end(c); }
+    Slot &s;
+    ProfScope(ebvo_ctx *ctx, Slot &slot, int kid) : c(ctx), s(slot) { ebvo_prof_begin(c, s, kid); }
+    ~ProfScope() { ebvo_prof_end(c, s); }
 };
 
-// ---- device-level stages (all pointers are device pointers; asynchronous on ctx->stream) ----
+// ---- device-level stages (device pointers; asynchronous on the slot's stream; NO host synchronisation) ----
+// A size argument is a host value plus an optional device pointer; when the pointer is non-null the kernels read
+// the size from device memory and `*_cap` bounds the launch.
 
 // toed_kernels.hip
 int toed_init_constants(ebvo_ctx *ctx);
-// runs conv + NMS + compaction for n_img (1 or 2) resident images ctx->im[0..n_img-1];
-// fills im[k].n_total / n_kept (synchronises once to read the counts).
-int toed_run_device(ebvo_ctx *ctx, int n_img, int h, int w, float *ms_conv, float *ms_nms);
+// conv + NMS + compaction of n_img (1 or 2) resident images of slot s; counts stay in s.im[k].counts
+int toed_enqueue(ebvo_ctx *ctx, Slot &s, int n_img, int h, int w, hipEvent_t ev_conv_begin, hipEvent_t ev_conv_end,
+                 hipEvent_t ev_end);
 
 // match_kernels.hip
-int match_lines_device(ebvo_ctx *ctx, const double *d_F, const ebvo_edge *d_edges, int n, double *d_lines);
-// candidate search: fills ctx->row_ptr / ctx->col_idx (device), returns n_pairs (synchronises)
-int match_candidates_device(ebvo_ctx *ctx, const ebvo_edge *d_L, int nL, const ebvo_edge *d_R, int nR,
-                            const double *d_lines, double epi_thr, double max_disp, double orient_thr_deg,
-                            int stage_mask, int64_t *n_pairs);
-int match_gather_edges_device(ebvo_ctx *ctx, const ebvo_edge *d_R, const int32_t *d_col_idx, int64_t n,
-                              ebvo_edge *d_out);
-int match_patches_device(ebvo_ctx *ctx, const uint8_t *d_img, int h, int w, int pitch, const ebvo_edge *d_edges,
-                         int n, float *d_raw, float *d_norm, uint8_t *d_flag);
-int match_ncc_pairs_device(ebvo_ctx *ctx, const uint8_t *d_imgR, int h, int w, int pitchR, const ebvo_edge *d_Rc,
-                           const int32_t *d_row_ptr, int nL, int64_t n_pairs, const float *d_left_norm,
-                           const uint8_t *d_left_flag, double thr, double *d_sims, double *d_best,
-                           uint8_t *d_keep, int32_t *d_match_cnt);
-int match_ncc_banked_device(ebvo_ctx *ctx, const int32_t *d_row_ptr, const int32_t *d_col_idx, int nL, int64_t n_pairs,
-                            const float *d_left_norm, const uint8_t *d_left_flag, const float *d_right_norm,
-                            const uint8_t *d_right_flag, double thr, double *d_sims, double *d_best, uint8_t *d_keep,
-                            int32_t *d_match_cnt);
-int match_ncc_stored_device(ebvo_ctx *ctx, const float *d_A, const float *d_B, int n, double *d_sim);
-int misc_fp64_peak(ebvo_ctx *ctx, int iters, double *tf_muladd, double *tf_fma);
+int match_lines_enqueue(ebvo_ctx *ctx, Slot &s, const double *d_F, const ebvo_edge *d_edges, int n,
+                        const int32_t *d_n, int cap_n, double *d_lines);
+// candidate search into s.row_ptr / s.col_idx (capacity s.cap_pairs must be set and the buffers allocated);
+// s.d_total receives the 64-bit number of pairs found
+int match_candidates_enqueue(ebvo_ctx *ctx, Slot &s, const ebvo_edge *d_L, int nL, const int32_t *d_nL,
+                             const ebvo_edge *d_R, int nR, const int32_t *d_nR, int cap_edges, const double *d_lines,
+                             double epi_thr, double max_disp, double orient_thr_deg, int stage_mask, bool fill);
+int match_candidates_fill_enqueue(ebvo_ctx *ctx, Slot &s, const ebvo_edge *d_L, int nL, const int32_t *d_nL,
+                                  const ebvo_edge *d_R, int nR, const int32_t *d_nR, int cap_edges,
+                                  const double *d_lines, double epi_thr, double max_disp, double orient_thr_deg,
+                                  int stage_mask);
+int match_patches_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_img, int h, int w, int pitch,
+                          const ebvo_edge *d_edges, int n, const int32_t *d_n, int cap_n, float *d_raw, float *d_norm,
+                          uint8_t *d_flag);
+int match_ncc_pairs_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_imgR, int h, int w, int pitchR,
+                            const ebvo_edge *d_Rc, const int32_t *d_row_ptr, int nL, int64_t n_pairs,
+                            const float *d_left_norm, const uint8_t *d_left_flag, double thr, double *d_sims,
+                            double *d_best, uint8_t *d_keep);
+int match_ncc_banked_enqueue(ebvo_ctx *ctx, Slot &s, int nL, const int32_t *d_nL, int cap_edges, int64_t n_pairs_host,
+                             double thr);
+int match_pair_result_enqueue(ebvo_ctx *ctx, Slot &s);
+int match_ncc_stored_enqueue(ebvo_ctx *ctx, Slot &s, const float *d_A, const float *d_B, int n, double *d_sim);
+int misc_fp64_peak(ebvo_ctx *ctx, Slot &s, int iters, double *tf_muladd, double *tf_fma);
 
 #endif

@@ -43,60 +43,90 @@ struct Box
     double x0, x1, y0, y1;
 };
 
+// A size that is either known on the host (dev == nullptr) or lives in device memory: the device-resident
+// pipeline never reads a count back before the last kernel of a pair, so every kernel takes its sizes this way
+// and runs grid-stride over whatever the count turns out to be.
+struct DevN
+{
+    int host;
+    const int32_t *dev;
+};
+__device__ inline int devn(const DevN &d) { return d.dev ? *d.dev : d.host; }
+
+// Number of candidate pairs: host value, or row_ptr[nL] with nL itself on the device; clamped to the capacity
+// of the pair-indexed buffers.
+struct DevPairs
+{
+    int64_t host;
+    const int32_t *row_ptr;
+    DevN nL;
+    int64_t cap;
+};
+__device__ inline int64_t devpairs(const DevPairs &d)
+{
+    const int64_t n = d.row_ptr ? (int64_t)d.row_ptr[devn(d.nL)] : d.host;
+    return n < d.cap ? n : d.cap;
+}
+
 struct CandParams
 {
     double epi_thr, max_disp, orient_thr;
-    int mask, nL, nR, nchunks, ngroups;
+    int mask;
+    DevN nL, nR;
+    int64_t cap; // capacity of col_idx (FILL)
 };
 
 // ------------------------------------------------------------------------------------------
-__global__ void lines_kernel(const double *__restrict__ F, const ebvo_edge *__restrict__ e, int n,
+__global__ void lines_kernel(const double *__restrict__ F, const ebvo_edge *__restrict__ e, DevN nd,
                              double *__restrict__ lines)
 {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n)
-        return;
-    const double x = e[k].x, y = e[k].y;
+    const int n = devn(nd);
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x)
+    {
+        const double x = e[k].x, y = e[k].y;
 #pragma unroll
-    for (int r = 0; r < 3; ++r)
-        lines[(size_t)k * 3 + r] = (F[r * 3 + 0] * x + F[r * 3 + 1] * y) + F[r * 3 + 2];
+        for (int r = 0; r < 3; ++r)
+            lines[(size_t)k * 3 + r] = (F[r * 3 + 0] * x + F[r * 3 + 1] * y) + F[r * 3 + 2];
+    }
 }
 
-__global__ void chunk_boxes_kernel(const ebvo_edge *__restrict__ R, int nR, int nchunks, Box *__restrict__ cb)
+__global__ void chunk_boxes_kernel(const ebvo_edge *__restrict__ R, DevN nRd, Box *__restrict__ cb)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= nchunks)
-        return;
-    const int k0 = c * CHUNK, k1 = min(nR, k0 + CHUNK);
-    Box b;
-    b.x0 = b.x1 = R[k0].x;
-    b.y0 = b.y1 = R[k0].y;
-    for (int k = k0 + 1; k < k1; ++k)
+    const int nR = devn(nRd), nchunks = (nR + CHUNK - 1) / CHUNK;
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < nchunks; c += gridDim.x * blockDim.x)
     {
-        const double x = R[k].x, y = R[k].y;
-        b.x0 = fmin(b.x0, x);
-        b.x1 = fmax(b.x1, x);
-        b.y0 = fmin(b.y0, y);
-        b.y1 = fmax(b.y1, y);
+        const int k0 = c * CHUNK, k1 = min(nR, k0 + CHUNK);
+        Box b;
+        b.x0 = b.x1 = R[k0].x;
+        b.y0 = b.y1 = R[k0].y;
+        for (int k = k0 + 1; k < k1; ++k)
+        {
+            const double x = R[k].x, y = R[k].y;
+            b.x0 = fmin(b.x0, x);
+            b.x1 = fmax(b.x1, x);
+            b.y0 = fmin(b.y0, y);
+            b.y1 = fmax(b.y1, y);
+        }
+        cb[c] = b;
     }
-    cb[c] = b;
 }
 
-__global__ void group_boxes_kernel(const Box *__restrict__ cb, int nchunks, int ngroups, Box *__restrict__ gb)
+__global__ void group_boxes_kernel(const Box *__restrict__ cb, DevN nRd, Box *__restrict__ gb)
 {
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= ngroups)
-        return;
-    const int c0 = g * GROUP, c1 = min(nchunks, c0 + GROUP);
-    Box b = cb[c0];
-    for (int c = c0 + 1; c < c1; ++c)
+    const int nR = devn(nRd), nchunks = (nR + CHUNK - 1) / CHUNK, ngroups = (nchunks + GROUP - 1) / GROUP;
+    for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < ngroups; g += gridDim.x * blockDim.x)
     {
-        b.x0 = fmin(b.x0, cb[c].x0);
-        b.x1 = fmax(b.x1, cb[c].x1);
-        b.y0 = fmin(b.y0, cb[c].y0);
-        b.y1 = fmax(b.y1, cb[c].y1);
+        const int c0 = g * GROUP, c1 = min(nchunks, c0 + GROUP);
+        Box b = cb[c0];
+        for (int c = c0 + 1; c < c1; ++c)
+        {
+            b.x0 = fmin(b.x0, cb[c].x0);
+            b.x1 = fmax(b.x1, cb[c].x1);
+            b.y0 = fmin(b.y0, cb[c].y0);
+            b.y1 = fmax(b.y1, cb[c].y1);
+        }
+        gb[g] = b;
     }
-    gb[g] = b;
 }
 
 // Can any point of the box satisfy the enabled epipolar / disparity predicates?  Conservative.
@@ -240,40 +270,13 @@ __global__ __launch_bounds__(256) void candidates_kernel(const ebvo_edge *__rest
     __shared__ unsigned long long s_tot[4];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int i = blockIdx.x * 256 + tid;
-    const bool live = i < P.nL;
-    const int il = live ? i : 0;
-    LeftCtx l;
-    l.lx = L[il].x; l.ly = L[il].y; l.lth = L[il].theta;
-    l.a = lines[(size_t)il * 3]; l.b = lines[(size_t)il * 3 + 1]; l.c = lines[(size_t)il * 3 + 2];
-    l.nrm = sqrt((l.a * l.a) + (l.b * l.b));
-    l.ah = l.a / l.nrm; l.bh = l.b / l.nrm; l.ch = l.c / l.nrm;
-    const double t = P.epi_thr * l.nrm;
-    l.t_lo = t * (1.0 - 0x1p-50); l.t_hi = t * (1.0 + 0x1p-50);
+    const int nL = devn(P.nL), nR = devn(P.nR);
+    const int nchunks = (nR + CHUNK - 1) / CHUNK, ngroups = (nchunks + GROUP - 1) / GROUP;
     const double d2 = P.max_disp * P.max_disp;
-    l.s_lo = d2 * (1.0 - 0x1p-50); l.s_hi = d2 * (1.0 + 0x1p-50);
     const double D = P.max_disp + BOX_SLACK, band = P.epi_thr + BOX_SLACK;
-
-    // union of the block's search regions
-    Box rb = region_box(l, D, band, P.mask);
     const double inf = __builtin_inf();
-    if (!live) { rb.x0 = inf; rb.x1 = -inf; rb.y0 = inf; rb.y1 = -inf; }
-    {
-        const double a0 = wave_min(rb.x0), a1 = wave_max(rb.x1), b0 = wave_min(rb.y0), b1 = wave_max(rb.y1);
-        if (lane == 0) { s_red[wid][0] = a0; s_red[wid][1] = a1; s_red[wid][2] = b0; s_red[wid][3] = b1; }
-    }
-    __syncthreads();
-    Box U;
-    U.x0 = fmin(fmin(s_red[0][0], s_red[1][0]), fmin(s_red[2][0], s_red[3][0]));
-    U.x1 = fmax(fmax(s_red[0][1], s_red[1][1]), fmax(s_red[2][1], s_red[3][1]));
-    U.y0 = fmin(fmin(s_red[0][2], s_red[1][2]), fmin(s_red[2][2], s_red[3][2]));
-    U.y1 = fmax(fmax(s_red[0][3], s_red[1][3]), fmax(s_red[2][3], s_red[3][3]));
 
-    int n = 0;
-    int32_t o = FILL ? row_ptr[il] : 0;
-    // Two levels of index-range boxes: groups of 64 chunks first (one test per thread), then the chunks of the
-    // selected groups, four groups (256 chunks) at a time.  Every selection is an ordered compaction, so chunks
-    // are visited in ascending index.
+    // ordered (index-preserving) compaction of one value per selected thread into an LDS list
     auto compact = [&](bool sel, int value, int *list) -> int {
         const unsigned long long m = __ballot(sel);
         if (lane == 0)
@@ -291,93 +294,129 @@ __global__ __launch_bounds__(256) void candidates_kernel(const ebvo_edge *__rest
         __syncthreads();
         return tot;
     };
-    auto meets_union = [&](const Box &bx) {
-        return !(bx.x0 > U.x1 || bx.x1 < U.x0 || bx.y0 > U.y1 || bx.y1 < U.y0);
-    };
 
-    for (int g0 = 0; g0 < P.ngroups; g0 += 256)
+    // one tile = 256 consecutive left edges; grid-stride so the launch does not depend on nL
+    for (int tile = blockIdx.x; tile * 256 < nL; tile += gridDim.x)
     {
-        const int g = g0 + tid;
-        const int ngsel = compact(g < P.ngroups && meets_union(gb[g < P.ngroups ? g : 0]), g, s_groups);
-        for (int q = 0; q < ngsel; q += 4)
+        const int i = tile * 256 + tid;
+        const bool live = i < nL;
+        const int il = live ? i : 0;
+        LeftCtx l;
+        l.lx = L[il].x; l.ly = L[il].y; l.lth = L[il].theta;
+        l.a = lines[(size_t)il * 3]; l.b = lines[(size_t)il * 3 + 1]; l.c = lines[(size_t)il * 3 + 2];
+        l.nrm = sqrt((l.a * l.a) + (l.b * l.b));
+        l.ah = l.a / l.nrm; l.bh = l.b / l.nrm; l.ch = l.c / l.nrm;
+        const double t = P.epi_thr * l.nrm;
+        l.t_lo = t * (1.0 - 0x1p-50); l.t_hi = t * (1.0 + 0x1p-50);
+        l.s_lo = d2 * (1.0 - 0x1p-50); l.s_hi = d2 * (1.0 + 0x1p-50);
+
+        // union of the tile's search regions
+        Box rb = region_box(l, D, band, P.mask);
+        if (!live) { rb.x0 = inf; rb.x1 = -inf; rb.y0 = inf; rb.y1 = -inf; }
         {
-            // ---- chunks of up to four selected groups: one chunk per thread
-            const int gq = q + (tid >> 6);
-            const int c = (gq < ngsel) ? s_groups[gq] * GROUP + (tid & 63) : P.nchunks;
-            const int nsel = compact(c < P.nchunks && meets_union(cb[c < P.nchunks ? c : 0]), c, s_round);
-            for (int b0 = 0; b0 < nsel; b0 += BATCH)
+            const double a0 = wave_min(rb.x0), a1 = wave_max(rb.x1), b0 = wave_min(rb.y0), b1 = wave_max(rb.y1);
+            if (lane == 0) { s_red[wid][0] = a0; s_red[wid][1] = a1; s_red[wid][2] = b0; s_red[wid][3] = b1; }
+        }
+        __syncthreads();
+        Box U;
+        U.x0 = fmin(fmin(s_red[0][0], s_red[1][0]), fmin(s_red[2][0], s_red[3][0]));
+        U.x1 = fmax(fmax(s_red[0][1], s_red[1][1]), fmax(s_red[2][1], s_red[3][1]));
+        U.y0 = fmin(fmin(s_red[0][2], s_red[1][2]), fmin(s_red[2][2], s_red[3][2]));
+        U.y1 = fmax(fmax(s_red[0][3], s_red[1][3]), fmax(s_red[2][3], s_red[3][3]));
+        auto meets_union = [&](const Box &bx) {
+            return !(bx.x0 > U.x1 || bx.x1 < U.x0 || bx.y0 > U.y1 || bx.y1 < U.y0);
+        };
+
+        int n = 0;
+        int64_t o = FILL ? (int64_t)row_ptr[il] : 0;
+        // Two levels of index-range boxes: groups of 64 chunks first (one test per thread), then the chunks of
+        // the selected groups, four groups (256 chunks) at a time; chunks are visited in ascending index.
+        for (int g0 = 0; g0 < ngroups; g0 += 256)
+        {
+            const int g = g0 + tid;
+            const int ngsel = compact(g < ngroups && meets_union(gb[g < ngroups ? g : 0]), g, s_groups);
+            for (int q = 0; q < ngsel; q += 4)
             {
-                const int mb = min(BATCH, nsel - b0);
-                // ---- stage the batch: edges and boxes of the selected chunks
-                for (int idx = tid; idx < mb * CHUNK; idx += 256)
+                // ---- chunks of up to four selected groups: one chunk per thread
+                const int gq = q + (tid >> 6);
+                const int c = (gq < ngsel) ? s_groups[gq] * GROUP + (tid & 63) : nchunks;
+                const int nsel = compact(c < nchunks && meets_union(cb[c < nchunks ? c : 0]), c, s_round);
+                for (int b0 = 0; b0 < nsel; b0 += BATCH)
                 {
-                    const int k = s_round[b0 + idx / CHUNK] * CHUNK + (idx % CHUNK);
-                    double x = __builtin_nan(""), y = x, th = x; // NaN fails every predicate
-                    if (k < P.nR)
+                    const int mb = min(BATCH, nsel - b0);
+                    // ---- stage the batch: edges and boxes of the selected chunks
+                    for (int idx = tid; idx < mb * CHUNK; idx += 256)
                     {
-                        x = R[k].x; y = R[k].y; th = R[k].theta;
+                        const int k = s_round[b0 + idx / CHUNK] * CHUNK + (idx % CHUNK);
+                        double x = __builtin_nan(""), y = x, th = x; // NaN fails every predicate
+                        if (k < nR)
+                        {
+                            x = R[k].x; y = R[k].y; th = R[k].theta;
+                        }
+                        s_x[idx] = x; s_y[idx] = y; s_th[idx] = th;
                     }
-                    s_x[idx] = x; s_y[idx] = y; s_th[idx] = th;
-                }
-                if (tid < mb)
-                    s_box[tid] = cb[s_round[b0 + tid]];
-                __syncthreads();
-                // ---- every lane walks the staged chunks that can meet ITS region
-                if (live)
-                {
-                    // which staged chunks can meet this lane's region (uniform loop, one bit per chunk) ...
-                    unsigned long long pm = 0;
-                    for (int j = 0; j < mb; ++j)
-                        if (box_may_match(s_box[j], l.lx, l.ly, l.ah, l.bh, l.ch, D, band, P.mask))
-                            pm |= 1ull << j;
-                    // ... then each lane visits ITS chunks, ascending; lanes advance by rank, not by chunk id
-                    while (pm)
+                    if (tid < mb)
+                        s_box[tid] = cb[s_round[b0 + tid]];
+                    __syncthreads();
+                    if (live)
                     {
-                        const int j = __ffsll((long long)pm) - 1;
-                        pm &= pm - 1;
-                        const int kbase = s_round[b0 + j] * CHUNK;
-                        unsigned hits = 0;
+                        // which staged chunks can meet this lane's region (uniform loop, one bit per chunk) ...
+                        unsigned long long pm = 0;
+                        for (int j = 0; j < mb; ++j)
+                            if (box_may_match(s_box[j], l.lx, l.ly, l.ah, l.bh, l.ch, D, band, P.mask))
+                                pm |= 1ull << j;
+                        // ... then each lane visits ITS chunks, ascending; lanes advance by rank, not by chunk id
+                        while (pm)
+                        {
+                            const int j = __ffsll((long long)pm) - 1;
+                            pm &= pm - 1;
+                            const int kbase = s_round[b0 + j] * CHUNK;
+                            unsigned hits = 0;
 #pragma unroll
-                        for (int e = 0; e < CHUNK; ++e)
-                        {
-                            const int idx = j * CHUNK + e;
-                            const bool ok = pair_passes(l, s_x[idx], s_y[idx], s_th[idx], P);
-                            hits |= (ok ? 1u : 0u) << e;
-                        }
-                        if (FILL)
-                        {
-                            while (hits)
+                            for (int e = 0; e < CHUNK; ++e)
                             {
-                                const int e = __ffs((int)hits) - 1;
-                                hits &= hits - 1;
-                                col_idx[o++] = kbase + e;
+                                const int idx = j * CHUNK + e;
+                                const bool ok = pair_passes(l, s_x[idx], s_y[idx], s_th[idx], P);
+                                hits |= (ok ? 1u : 0u) << e;
                             }
+                            if (FILL)
+                            {
+                                while (hits)
+                                {
+                                    const int e = __ffs((int)hits) - 1;
+                                    hits &= hits - 1;
+                                    if (o < P.cap)
+                                        col_idx[o] = kbase + e;
+                                    ++o;
+                                }
+                            }
+                            else
+                                n += __popc(hits);
                         }
-                        else
-                            n += __popc(hits);
                     }
+                    __syncthreads();
                 }
-                __syncthreads();
             }
         }
-    }
-    if (!FILL)
-    {
-        if (live)
-            cnt[i] = n;
-        // 64-bit total (one atomic per block) guards the int32 CSR offsets
-        unsigned long long s = (unsigned long long)n;
-        for (int d = 32; d > 0; d >>= 1)
-            s += __shfl_down(s, d);
-        if (lane == 0)
-            s_tot[wid] = s;
-        __syncthreads();
-        if (tid == 0)
+        if (!FILL)
         {
-            const unsigned long long tt = s_tot[0] + s_tot[1] + s_tot[2] + s_tot[3];
-            if (tt)
-                atomicAdd(total, tt);
+            if (live)
+                cnt[i] = n;
+            // 64-bit total (one atomic per tile) guards the int32 CSR offsets and the buffer capacity
+            unsigned long long s = (unsigned long long)n;
+            for (int d = 32; d > 0; d >>= 1)
+                s += __shfl_down(s, d);
+            if (lane == 0)
+                s_tot[wid] = s;
+            __syncthreads();
+            if (tid == 0)
+            {
+                const unsigned long long tt = s_tot[0] + s_tot[1] + s_tot[2] + s_tot[3];
+                if (tt)
+                    atomicAdd(total, tt);
+            }
         }
+        __syncthreads();
     }
 }
 
@@ -388,10 +427,11 @@ constexpr int SCAN_BLOCK = 256;
 constexpr int SCAN_TILE = SCAN_ITEMS * SCAN_BLOCK;
 
 __global__ __launch_bounds__(SCAN_BLOCK) void scan_tile_kernel(const int32_t *__restrict__ in,
-                                                               int32_t *__restrict__ out, int n,
+                                                               int32_t *__restrict__ out, DevN nd, int n_add,
                                                                int32_t *__restrict__ sums)
 {
     __shared__ int32_t wsum[SCAN_BLOCK / 64];
+    const int n = devn(nd) + n_add;
     const int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
     int32_t v[SCAN_ITEMS];
     int32_t s = 0;
@@ -432,8 +472,9 @@ __global__ __launch_bounds__(SCAN_BLOCK) void scan_tile_kernel(const int32_t *__
         sums[blockIdx.x] = tot;
 }
 
-__global__ void scan_add_kernel(int32_t *__restrict__ out, int n, const int32_t *__restrict__ offs)
+__global__ void scan_add_kernel(int32_t *__restrict__ out, DevN nd, int n_add, const int32_t *__restrict__ offs)
 {
+    const int n = devn(nd) + n_add;
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k < n)
         out[k] += offs[k / SCAN_TILE];
@@ -489,17 +530,18 @@ __device__ inline double butterfly8(double s)
 // sin / cos of every edge orientation, one thread per edge (dense: the double-double routine costs
 // ~700 instructions per wave, so it is evaluated once per edge here instead of once per 16-lane
 // group inside the sampling kernels).  src/utility.cpp:84-87,151 call std::sin / std::cos.
-__global__ void sincos_edges_kernel(const ebvo_edge *__restrict__ e, int64_t n, double2 *__restrict__ sc)
+__global__ void sincos_edges_kernel(const ebvo_edge *__restrict__ e, DevN nd, double2 *__restrict__ sc)
 {
-    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n)
-        return;
-    double sn, cs;
-    ebvo_sincos(e[k].theta, &sn, &cs);
-    double2 v;
-    v.x = sn;
-    v.y = cs;
-    sc[k] = v;
+    const int n = devn(nd);
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x)
+    {
+        double sn, cs;
+        ebvo_sincos(e[k].theta, &sn, &cs);
+        double2 v;
+        v.x = sn;
+        v.y = cs;
+        sc[k] = v;
+    }
 }
 
 // One lane's row (7 samples) of one side of an edge's patch pair.
@@ -577,35 +619,42 @@ __device__ inline double max4(double a, double b, double c, double d)
 }
 
 // Patches of n edges: raw floats (n x 2 x 49), optionally the normalised patches and sentinel flags.
-// 16 lanes per edge.
+// 16 lanes per edge; every 16-lane group strides over the edges with a wave-uniform trip count.
 __global__ __launch_bounds__(256) void patches_kernel(const uint8_t *__restrict__ img, int h, int w, int pitch,
                                                       const ebvo_edge *__restrict__ edges,
-                                                      const double2 *__restrict__ sc, int n,
+                                                      const double2 *__restrict__ sc, DevN nd,
                                                       float *__restrict__ raw, float *__restrict__ norm,
                                                       uint8_t *__restrict__ flag)
 {
+    const int n = devn(nd);
+    const int groups = (gridDim.x * blockDim.x) >> 4;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int e = t >> 4, g = t & 15, side = g >> 3, row = g & 7;
-    const bool valid = e < n; // uniform per 16-lane group
-    const bool active = valid && row < 7;
-    float p[7], nr[7];
-#pragma unroll
-    for (int c = 0; c < 7; ++c)
-        p[c] = 0.0f;
-    if (active)
-        sample_row(img, h, w, pitch, edges[e].x, edges[e].y, sc[e].x, sc[e].y, side, row, p);
-    const bool sent = normalise_rows(active, p, nr);
-    if (active)
+    const int g = t & 15, side = g >> 3, row = g & 7;
+    const int iters = (n + groups - 1) / groups;
+    for (int it = 0; it < iters; ++it)
     {
-        const size_t o = (size_t)e * 98 + side * 49 + row * 7;
+        const int e = it * groups + (t >> 4);
+        const bool valid = e < n; // uniform per 16-lane group
+        const bool active = valid && row < 7;
+        float p[7], nr[7];
 #pragma unroll
         for (int c = 0; c < 7; ++c)
+            p[c] = 0.0f;
+        if (active)
+            sample_row(img, h, w, pitch, edges[e].x, edges[e].y, sc[e].x, sc[e].y, side, row, p);
+        const bool sent = normalise_rows(active, p, nr);
+        if (active)
         {
-            if (raw) raw[o + c] = p[c];
-            if (norm) norm[o + c] = nr[c];
+            const size_t o = (size_t)e * 98 + side * 49 + row * 7;
+#pragma unroll
+            for (int c = 0; c < 7; ++c)
+            {
+                if (raw) raw[o + c] = p[c];
+                if (norm) norm[o + c] = nr[c];
+            }
+            if (flag && row == 0)
+                flag[(size_t)e * 2 + side] = sent ? 1 : 0;
         }
-        if (flag && row == 0)
-            flag[(size_t)e * 2 + side] = sent ? 1 : 0;
     }
 }
 
@@ -688,10 +737,11 @@ __global__ __launch_bounds__(256) void ncc_pairs_kernel(const uint8_t *__restric
 }
 
 // number of kept pairs: grid-stride byte sum, one atomic per block
-__global__ __launch_bounds__(256) void count_keep_kernel(const uint8_t *__restrict__ keep, int64_t n,
+__global__ __launch_bounds__(256) void count_keep_kernel(const uint8_t *__restrict__ keep, DevPairs np,
                                                          int32_t *__restrict__ out)
 {
     __shared__ int wsum[4];
+    const int64_t n = devpairs(np);
     int s = 0;
     for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x)
         s += keep[k];
@@ -709,13 +759,13 @@ __global__ __launch_bounds__(256) void count_keep_kernel(const uint8_t *__restri
 }
 
 // pair -> left row index (CSR expansion), one thread per left edge
-__global__ void expand_rows_kernel(const int32_t *__restrict__ row_ptr, int nL, int32_t *__restrict__ pair_left)
+__global__ void expand_rows_kernel(const int32_t *__restrict__ row_ptr, DevN nLd, int32_t *__restrict__ pair_left,
+                                   int64_t cap)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nL)
-        return;
-    for (int32_t k = row_ptr[i]; k < row_ptr[i + 1]; ++k)
-        pair_left[k] = i;
+    const int nL = devn(nLd);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nL; i += gridDim.x * blockDim.x)
+        for (int64_t k = row_ptr[i]; k < row_ptr[i + 1] && k < cap; ++k)
+            pair_left[k] = i;
 }
 
 // NCC of (left edge, right TOED edge) pairs from precomputed normalised-patch banks (device pipeline: every
@@ -726,61 +776,87 @@ __global__ __launch_bounds__(256) void ncc_banked_kernel(const float *__restrict
                                                          const float *__restrict__ right_norm,
                                                          const uint8_t *__restrict__ right_flag,
                                                          const int32_t *__restrict__ pair_left,
-                                                         const int32_t *__restrict__ col_idx, int64_t n_pairs,
-                                                         double thr, double *__restrict__ sims,
-                                                         double *__restrict__ best, uint8_t *__restrict__ keep)
+                                                         const int32_t *__restrict__ col_idx, DevPairs np, double thr,
+                                                         double *__restrict__ sims, double *__restrict__ best,
+                                                         uint8_t *__restrict__ keep)
 {
+    const int64_t n_pairs = devpairs(np);
+    const int64_t groups = ((int64_t)gridDim.x * blockDim.x) >> 4;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t k = t >> 4;
     const int g = (int)(t & 15), side = g >> 3, row = g & 7;
-    const bool valid = k < n_pairs;
-    const bool active = valid && row < 7;
-    float rn[7], lp[7], lm[7];
-#pragma unroll
-    for (int c = 0; c < 7; ++c)
-        rn[c] = lp[c] = lm[c] = 0.0f;
-    int li = 0, ri = 0;
-    if (valid)
+    const int64_t iters = (n_pairs + groups - 1) / groups;
+    for (int64_t it = 0; it < iters; ++it)
     {
-        li = pair_left[k];
-        ri = col_idx[k];
-    }
-    if (active)
-    {
-        const float *rr = right_norm + (size_t)ri * 98 + side * 49 + row * 7;
-        const float *ln = left_norm + (size_t)li * 98 + row * 7;
+        const int64_t k = it * groups + (t >> 4);
+        const bool valid = k < n_pairs;
+        const bool active = valid && row < 7;
+        float rn[7], lp[7], lm[7];
 #pragma unroll
         for (int c = 0; c < 7; ++c)
+            rn[c] = lp[c] = lm[c] = 0.0f;
+        int li = 0, ri = 0;
+        if (valid)
         {
-            rn[c] = rr[c];
-            lp[c] = ln[c];
-            lm[c] = ln[49 + c];
+            li = pair_left[k];
+            ri = col_idx[k];
+        }
+        if (active)
+        {
+            const float *rr = right_norm + (size_t)ri * 98 + side * 49 + row * 7;
+            const float *ln = left_norm + (size_t)li * 98 + row * 7;
+#pragma unroll
+            for (int c = 0; c < 7; ++c)
+            {
+                rn[c] = rr[c];
+                lp[c] = ln[c];
+                lm[c] = ln[49 + c];
+            }
+        }
+        const double d_lp = dot_rows(active, lp, rn);
+        const double d_lm = dot_rows(active, lm, rn);
+        const double o_lp = __shfl_xor(d_lp, 8), o_lm = __shfl_xor(d_lm, 8);
+        if (valid && g == 0)
+        {
+            const bool lsent_p = left_flag[(size_t)li * 2] != 0, lsent_m = left_flag[(size_t)li * 2 + 1] != 0;
+            const bool rsent_p = right_flag[(size_t)ri * 2] != 0, rsent_m = right_flag[(size_t)ri * 2 + 1] != 0;
+            const double pp = (lsent_p || rsent_p) ? -1.0 : d_lp;
+            const double npv = (lsent_m || rsent_p) ? -1.0 : d_lm;
+            const double pn = (lsent_p || rsent_m) ? -1.0 : o_lp;
+            const double nn = (lsent_m || rsent_m) ? -1.0 : o_lm;
+            const double b = max4(pp, nn, pn, npv);
+            if (sims)
+            {
+                sims[k * 4 + 0] = pp;
+                sims[k * 4 + 1] = nn;
+                sims[k * 4 + 2] = pn;
+                sims[k * 4 + 3] = npv;
+            }
+            if (best)
+                best[k] = b;
+            if (keep)
+                keep[k] = (b > thr) ? 1 : 0;
         }
     }
-    const double d_lp = dot_rows(active, lp, rn);
-    const double d_lm = dot_rows(active, lm, rn);
-    const double o_lp = __shfl_xor(d_lp, 8), o_lm = __shfl_xor(d_lm, 8);
-    if (valid && g == 0)
-    {
-        const bool lsent_p = left_flag[(size_t)li * 2] != 0, lsent_m = left_flag[(size_t)li * 2 + 1] != 0;
-        const bool rsent_p = right_flag[(size_t)ri * 2] != 0, rsent_m = right_flag[(size_t)ri * 2 + 1] != 0;
-        const double pp = (lsent_p || rsent_p) ? -1.0 : d_lp;
-        const double np = (lsent_m || rsent_p) ? -1.0 : d_lm;
-        const double pn = (lsent_p || rsent_m) ? -1.0 : o_lp;
-        const double nn = (lsent_m || rsent_m) ? -1.0 : o_lm;
-        const double b = max4(pp, nn, pn, np);
-        if (sims)
-        {
-            sims[k * 4 + 0] = pp;
-            sims[k * 4 + 1] = nn;
-            sims[k * 4 + 2] = pn;
-            sims[k * 4 + 3] = np;
-        }
-        if (best)
-            best[k] = b;
-        if (keep)
-            keep[k] = (b > thr) ? 1 : 0;
-    }
+}
+
+// Last kernel of a device-resident pair: gathers every count the host wants into one record (PairResult,
+// ebvo_internal.h).
+__global__ void pair_result_kernel(const int32_t *__restrict__ cntL, const int32_t *__restrict__ cntR,
+                                   const unsigned long long *__restrict__ total, const int32_t *__restrict__ matches,
+                                   int64_t cap, PairResult *__restrict__ out)
+{
+    if (threadIdx.x || blockIdx.x)
+        return;
+    PairResult r;
+    r.n_total_left = cntL[0];
+    r.n_left = cntL[1];
+    r.n_total_right = cntR[0];
+    r.n_right = cntR[1];
+    r.n_pairs = (int64_t)*total;
+    r.n_matches = *matches;
+    r.overflow = (r.n_pairs > cap || r.n_pairs > 0x7fffffffll) ? 1 : 0;
+    r.pad = 0;
+    *out = r;
 }
 
 // NCC of stored patch pairs (src/utility.cpp:163-180); 16 lanes per pair: side 0 = A, side 1 = B.
@@ -839,247 +915,243 @@ __global__ __launch_bounds__(256) void fp64_peak_kernel(double *out, int iters, 
     out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
-int device_exclusive_scan(ebvo_ctx *ctx, const int32_t *in, int32_t *out, int n, GrowBuf &tmp_a, GrowBuf &tmp_b)
+// exclusive scan of n (+ n_add) int32; n may live on the device, cap_n bounds it on the host
+int device_exclusive_scan(ebvo_ctx *ctx, Slot &s, const int32_t *in, int32_t *out, DevN n, int n_add, int cap_n)
 {
-    // level 0
-    const int nb0 = (n + SCAN_TILE - 1) / SCAN_TILE;
+    const int nb0 = (cap_n + SCAN_TILE - 1) / SCAN_TILE;
     if (nb0 <= 1)
     {
-        hipLaunchKernelGGL(scan_tile_kernel, dim3(1), dim3(SCAN_BLOCK), 0, ctx->stream, in, out, n,
+        hipLaunchKernelGGL(scan_tile_kernel, dim3(1), dim3(SCAN_BLOCK), 0, s.stream, in, out, n, n_add,
                            (int32_t *)nullptr);
         return EBVO_OK;
     }
     const int nb1 = (nb0 + SCAN_TILE - 1) / SCAN_TILE;
-    int rc = ebvo_grow(ctx, tmp_a, sizeof(int32_t) * (size_t)(2 * nb0 + 2 * nb1 + 16));
+    if (nb1 > SCAN_TILE)
+        return EBVO_ERR_ARG; // > 1e9 elements
+    int rc = ebvo_grow(ctx, s, s.scan_tmp, sizeof(int32_t) * (size_t)(2 * nb0 + 2 * nb1 + 16));
     if (rc)
         return rc;
-    int32_t *sums0 = (int32_t *)tmp_a.p, *offs0 = sums0 + nb0, *sums1 = offs0 + nb0, *offs1 = sums1 + nb1;
-    hipLaunchKernelGGL(scan_tile_kernel, dim3(nb0), dim3(SCAN_BLOCK), 0, ctx->stream, in, out, n, sums0);
+    int32_t *sums0 = (int32_t *)s.scan_tmp.p, *offs0 = sums0 + nb0, *sums1 = offs0 + nb0, *offs1 = sums1 + nb1;
+    const DevN n0{nb0, nullptr}, n1{nb1, nullptr};
+    hipLaunchKernelGGL(scan_tile_kernel, dim3(nb0), dim3(SCAN_BLOCK), 0, s.stream, in, out, n, n_add, sums0);
     if (nb1 <= 1)
     {
-        hipLaunchKernelGGL(scan_tile_kernel, dim3(1), dim3(SCAN_BLOCK), 0, ctx->stream, (const int32_t *)sums0,
-                           offs0, nb0, (int32_t *)nullptr);
+        hipLaunchKernelGGL(scan_tile_kernel, dim3(1), dim3(SCAN_BLOCK), 0, s.stream, (const int32_t *)sums0, offs0, n0,
+                           0, (int32_t *)nullptr);
     }
     else
     {
-        if (nb1 > SCAN_TILE)
-            return EBVO_ERR_ARG; // > 1e9 elements
-        hipLaunchKernelGGL(scan_tile_kernel, dim3(nb1), dim3(SCAN_BLOCK), 0, ctx->stream, (const int32_t *)sums0,
-                           offs0, nb0, sums1);
-        hipLaunchKernelGGL(scan_tile_kernel, dim3(1), dim3(SCAN_BLOCK), 0, ctx->stream, (const int32_t *)sums1,
-                           offs1, nb1, (int32_t *)nullptr);
-        hipLaunchKernelGGL(scan_add_kernel, dim3((nb0 + 255) / 256), dim3(256), 0, ctx->stream, offs0, nb0,
+        hipLaunchKernelGGL(scan_tile_kernel, dim3(nb1), dim3(SCAN_BLOCK), 0, s.stream, (const int32_t *)sums0, offs0,
+                           n0, 0, sums1);
+        hipLaunchKernelGGL(scan_tile_kernel, dim3(1), dim3(SCAN_BLOCK), 0, s.stream, (const int32_t *)sums1, offs1, n1,
+                           0, (int32_t *)nullptr);
+        hipLaunchKernelGGL(scan_add_kernel, dim3((nb0 + 255) / 256), dim3(256), 0, s.stream, offs0, n0, 0,
                            (const int32_t *)offs1);
     }
-    hipLaunchKernelGGL(scan_add_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, out, n,
+    hipLaunchKernelGGL(scan_add_kernel, dim3((cap_n + 255) / 256), dim3(256), 0, s.stream, out, n, n_add,
                        (const int32_t *)offs0);
-    (void)tmp_b;
     return EBVO_OK;
+}
+
+inline unsigned blocks_for(int64_t items, int per_block, int max_blocks)
+{
+    int64_t b = (items + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > max_blocks) b = max_blocks;
+    return (unsigned)b;
 }
 
 } // namespace
 
-int match_lines_device(ebvo_ctx *ctx, const double *d_F, const ebvo_edge *d_edges, int n, double *d_lines)
+int match_lines_enqueue(ebvo_ctx *ctx, Slot &s, const double *d_F, const ebvo_edge *d_edges, int n, const int32_t *d_n,
+                        int cap_n, double *d_lines)
 {
-    if (n <= 0)
+    if (!d_n && n <= 0)
         return EBVO_OK;
-    ProfScope ps(ctx, K_LINES);
-    hipLaunchKernelGGL(lines_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_F, d_edges, n, d_lines);
+    ProfScope ps(ctx, s, K_LINES);
+    hipLaunchKernelGGL(lines_kernel, dim3(blocks_for(d_n ? cap_n : n, 256, 1024)), dim3(256), 0, s.stream, d_F, d_edges,
+                       DevN{n, d_n}, d_lines);
     EBVO_HIP(ctx, hipGetLastError());
     return EBVO_OK;
 }
 
-int match_candidates_device(ebvo_ctx *ctx, const ebvo_edge *d_L, int nL, const ebvo_edge *d_R, int nR,
-                            const double *d_lines, double epi_thr, double max_disp, double orient_thr_deg,
-                            int stage_mask, int64_t *n_pairs)
+static CandParams cand_params(int nL, const int32_t *d_nL, int nR, const int32_t *d_nR, double epi_thr, double max_disp,
+                              double orient_thr_deg, int stage_mask, int64_t cap)
 {
-    *n_pairs = 0;
-    int rc;
-    if ((rc = ebvo_grow(ctx, ctx->row_ptr, sizeof(int32_t) * ((size_t)nL + 1))))
-        return rc;
-    if (nL <= 0 || nR <= 0)
-    {
-        EBVO_HIP(ctx, hipMemsetAsync(ctx->row_ptr.p, 0, sizeof(int32_t) * ((size_t)nL + 1), ctx->stream));
-        EBVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        return EBVO_OK;
-    }
     CandParams P;
     P.epi_thr = epi_thr;
     P.max_disp = max_disp;
     P.orient_thr = orient_thr_deg;
     P.mask = stage_mask;
-    P.nL = nL;
-    P.nR = nR;
-    P.nchunks = (nR + CHUNK - 1) / CHUNK;
-    P.ngroups = (P.nchunks + GROUP - 1) / GROUP;
-    if ((rc = ebvo_grow(ctx, ctx->boxes_chunk, sizeof(Box) * (size_t)P.nchunks)))
+    P.nL = DevN{nL, d_nL};
+    P.nR = DevN{nR, d_nR};
+    P.cap = cap;
+    return P;
+}
+
+int match_candidates_fill_enqueue(ebvo_ctx *ctx, Slot &s, const ebvo_edge *d_L, int nL, const int32_t *d_nL,
+                                  const ebvo_edge *d_R, int nR, const int32_t *d_nR, int cap_edges,
+                                  const double *d_lines, double epi_thr, double max_disp, double orient_thr_deg,
+                                  int stage_mask)
+{
+    const CandParams P = cand_params(nL, d_nL, nR, d_nR, epi_thr, max_disp, orient_thr_deg, stage_mask, s.cap_pairs);
+    ProfScope ps(ctx, s, K_CAND_FILL);
+    hipLaunchKernelGGL(candidates_kernel<true>, dim3(blocks_for(d_nL ? cap_edges : nL, 256, 4096)), dim3(256), 0,
+                       s.stream, d_L, d_R, d_lines, (const Box *)s.boxes_chunk.p, (const Box *)s.boxes_group.p, P,
+                       (int32_t *)nullptr, (const int32_t *)s.row_ptr.p, (int32_t *)s.col_idx.p,
+                       (unsigned long long *)nullptr);
+    EBVO_HIP(ctx, hipGetLastError());
+    return EBVO_OK;
+}
+
+int match_candidates_enqueue(ebvo_ctx *ctx, Slot &s, const ebvo_edge *d_L, int nL, const int32_t *d_nL,
+                             const ebvo_edge *d_R, int nR, const int32_t *d_nR, int cap_edges, const double *d_lines,
+                             double epi_thr, double max_disp, double orient_thr_deg, int stage_mask, bool fill)
+{
+    const int capL = d_nL ? cap_edges : nL, capR = d_nR ? cap_edges : nR;
+    int rc;
+    if ((rc = ebvo_grow(ctx, s, s.row_ptr, sizeof(int32_t) * ((size_t)capL + 1))))
         return rc;
-    if ((rc = ebvo_grow(ctx, ctx->boxes_group, sizeof(Box) * (size_t)P.ngroups)))
+    if ((rc = ebvo_grow(ctx, s, s.cand_cnt, sizeof(int32_t) * ((size_t)capL + 1))))
         return rc;
-    if ((rc = ebvo_grow(ctx, ctx->cand_cnt, sizeof(int32_t) * ((size_t)nL + 1) + 16)))
+    const int capchunks = (capR + CHUNK - 1) / CHUNK + 1, capgroups = (capchunks + GROUP - 1) / GROUP + 1;
+    if ((rc = ebvo_grow(ctx, s, s.boxes_chunk, sizeof(Box) * (size_t)capchunks)))
         return rc;
-    Box *cb = (Box *)ctx->boxes_chunk.p, *gb = (Box *)ctx->boxes_group.p;
-    int32_t *cnt = (int32_t *)ctx->cand_cnt.p;
-    // 64-bit total lives right after the counts (8-byte aligned)
-    unsigned long long *total =
-        (unsigned long long *)((char *)cnt + ((sizeof(int32_t) * ((size_t)nL + 1) + 7) & ~(size_t)7));
+    if ((rc = ebvo_grow(ctx, s, s.boxes_group, sizeof(Box) * (size_t)capgroups)))
+        return rc;
+    int32_t *cnt = (int32_t *)s.cand_cnt.p;
+    // cnt[i >= nL] must read as 0 in the scan: the scan masks by n, only element nL itself needs a zero
+    EBVO_HIP(ctx, hipMemsetAsync(cnt, 0, sizeof(int32_t) * ((size_t)capL + 1), s.stream));
+    EBVO_HIP(ctx, hipMemsetAsync(s.d_total, 0, sizeof(unsigned long long), s.stream));
     {
-        ProfScope ps(ctx, K_BOXES);
-        hipLaunchKernelGGL(chunk_boxes_kernel, dim3((P.nchunks + 255) / 256), dim3(256), 0, ctx->stream, d_R, nR,
-                           P.nchunks, cb);
-        hipLaunchKernelGGL(group_boxes_kernel, dim3((P.ngroups + 255) / 256), dim3(256), 0, ctx->stream,
-                           (const Box *)cb, P.nchunks, P.ngroups, gb);
+        ProfScope ps(ctx, s, K_BOXES);
+        hipLaunchKernelGGL(chunk_boxes_kernel, dim3(blocks_for(capchunks, 256, 256)), dim3(256), 0, s.stream, d_R,
+                           DevN{nR, d_nR}, (Box *)s.boxes_chunk.p);
+        hipLaunchKernelGGL(group_boxes_kernel, dim3(blocks_for(capgroups, 256, 16)), dim3(256), 0, s.stream,
+                           (const Box *)s.boxes_chunk.p, DevN{nR, d_nR}, (Box *)s.boxes_group.p);
     }
-    EBVO_HIP(ctx, hipMemsetAsync(cnt + nL, 0, sizeof(int32_t), ctx->stream));
-    EBVO_HIP(ctx, hipMemsetAsync(total, 0, sizeof(unsigned long long), ctx->stream));
+    const CandParams P = cand_params(nL, d_nL, nR, d_nR, epi_thr, max_disp, orient_thr_deg, stage_mask, s.cap_pairs);
     {
-        ProfScope ps(ctx, K_CAND_COUNT);
-        hipLaunchKernelGGL(candidates_kernel<false>, dim3((nL + 255) / 256), dim3(256), 0, ctx->stream, d_L, d_R,
-                           d_lines, (const Box *)cb, (const Box *)gb, P, cnt, (const int32_t *)nullptr,
-                           (int32_t *)nullptr, total);
+        ProfScope ps(ctx, s, K_CAND_COUNT);
+        hipLaunchKernelGGL(candidates_kernel<false>, dim3(blocks_for(capL, 256, 4096)), dim3(256), 0, s.stream, d_L, d_R,
+                           d_lines, (const Box *)s.boxes_chunk.p, (const Box *)s.boxes_group.p, P, cnt,
+                           (const int32_t *)nullptr, (int32_t *)nullptr, s.d_total);
     }
     {
-        ProfScope ps(ctx, K_SCAN);
-        if ((rc = device_exclusive_scan(ctx, cnt, (int32_t *)ctx->row_ptr.p, nL + 1, ctx->scan_tmp, ctx->scan_tmp)))
+        ProfScope ps(ctx, s, K_SCAN);
+        if ((rc = device_exclusive_scan(ctx, s, cnt, (int32_t *)s.row_ptr.p, DevN{nL, d_nL}, 1, capL + 1)))
             return rc;
     }
     EBVO_HIP(ctx, hipGetLastError());
-    unsigned long long h_total = 0;
-    EBVO_HIP(ctx, hipMemcpyAsync(&h_total, total, sizeof(h_total), hipMemcpyDeviceToHost, ctx->stream));
-    EBVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (h_total > 0x7fffffffull)
-    {
-        ctx->last_error = "candidate list exceeds 2^31-1 pairs";
-        return EBVO_ERR_CAPACITY;
-    }
-    *n_pairs = (int64_t)h_total;
-    if (h_total == 0)
-        return EBVO_OK;
-    if ((rc = ebvo_grow(ctx, ctx->col_idx, sizeof(int32_t) * (size_t)h_total)))
-        return rc;
-    {
-        ProfScope ps(ctx, K_CAND_FILL);
-        hipLaunchKernelGGL(candidates_kernel<true>, dim3((nL + 255) / 256), dim3(256), 0, ctx->stream, d_L, d_R,
-                           d_lines, (const Box *)cb, (const Box *)gb, P, (int32_t *)nullptr,
-                           (const int32_t *)ctx->row_ptr.p, (int32_t *)ctx->col_idx.p,
-                           (unsigned long long *)nullptr);
-    }
-    EBVO_HIP(ctx, hipGetLastError());
+    if (fill)
+        return match_candidates_fill_enqueue(ctx, s, d_L, nL, d_nL, d_R, nR, d_nR, cap_edges, d_lines, epi_thr, max_disp,
+                                             orient_thr_deg, stage_mask);
     return EBVO_OK;
 }
 
-int match_gather_edges_device(ebvo_ctx *ctx, const ebvo_edge *d_R, const int32_t *d_col_idx, int64_t n,
-                              ebvo_edge *d_out)
+int match_patches_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_img, int h, int w, int pitch,
+                          const ebvo_edge *d_edges, int n, const int32_t *d_n, int cap_n, float *d_raw, float *d_norm,
+                          uint8_t *d_flag)
 {
-    if (n <= 0)
+    if (!d_n && n <= 0)
         return EBVO_OK;
-    ProfScope ps(ctx, K_MISC);
-    hipLaunchKernelGGL(gather_edges_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_R,
-                       d_col_idx, n, d_out);
-    EBVO_HIP(ctx, hipGetLastError());
-    return EBVO_OK;
-}
-
-int match_patches_device(ebvo_ctx *ctx, const uint8_t *d_img, int h, int w, int pitch, const ebvo_edge *d_edges,
-                         int n, float *d_raw, float *d_norm, uint8_t *d_flag)
-{
-    if (n <= 0)
-        return EBVO_OK;
+    const int cap = d_n ? cap_n : n;
     int rc;
-    if ((rc = ebvo_grow(ctx, ctx->scratch_d, sizeof(double2) * (size_t)n)))
+    if ((rc = ebvo_grow(ctx, s, s.sincos, sizeof(double2) * (size_t)cap)))
         return rc;
-    ProfScope ps(ctx, K_PATCHES);
-    hipLaunchKernelGGL(sincos_edges_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_edges, (int64_t)n,
-                       (double2 *)ctx->scratch_d.p);
-    const int64_t threads = (int64_t)n * 16;
-    hipLaunchKernelGGL(patches_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, d_img, h,
-                       w, pitch, d_edges, (const double2 *)ctx->scratch_d.p, n, d_raw, d_norm, d_flag);
+    ProfScope ps(ctx, s, K_PATCHES);
+    hipLaunchKernelGGL(sincos_edges_kernel, dim3(blocks_for(cap, 256, 1024)), dim3(256), 0, s.stream, d_edges,
+                       DevN{n, d_n}, (double2 *)s.sincos.p);
+    hipLaunchKernelGGL(patches_kernel, dim3(blocks_for((int64_t)cap * 16, 256, 4096)), dim3(256), 0, s.stream, d_img, h,
+                       w, pitch, d_edges, (const double2 *)s.sincos.p, DevN{n, d_n}, d_raw, d_norm, d_flag);
     EBVO_HIP(ctx, hipGetLastError());
     return EBVO_OK;
 }
 
-int match_ncc_pairs_device(ebvo_ctx *ctx, const uint8_t *d_imgR, int h, int w, int pitchR, const ebvo_edge *d_Rc,
-                           const int32_t *d_row_ptr, int nL, int64_t n_pairs, const float *d_left_norm,
-                           const uint8_t *d_left_flag, double thr, double *d_sims, double *d_best,
-                           uint8_t *d_keep, int32_t *d_match_cnt)
+int match_ncc_pairs_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_imgR, int h, int w, int pitchR,
+                            const ebvo_edge *d_Rc, const int32_t *d_row_ptr, int nL, int64_t n_pairs,
+                            const float *d_left_norm, const uint8_t *d_left_flag, double thr, double *d_sims,
+                            double *d_best, uint8_t *d_keep)
 {
-    if (d_match_cnt)
-        EBVO_HIP(ctx, hipMemsetAsync(d_match_cnt, 0, sizeof(int32_t), ctx->stream));
     if (n_pairs <= 0 || nL <= 0)
         return EBVO_OK;
     int rc;
-    if ((rc = ebvo_grow(ctx, ctx->scratch_a, sizeof(int32_t) * (size_t)n_pairs)))
+    if ((rc = ebvo_grow(ctx, s, s.pair_left, sizeof(int32_t) * (size_t)n_pairs)))
         return rc;
-    if ((rc = ebvo_grow(ctx, ctx->scratch_d, sizeof(double2) * (size_t)n_pairs)))
+    if ((rc = ebvo_grow(ctx, s, s.sincos, sizeof(double2) * (size_t)n_pairs)))
         return rc;
-    int32_t *pair_left = (int32_t *)ctx->scratch_a.p;
-    double2 *sc = (double2 *)ctx->scratch_d.p;
+    int32_t *pair_left = (int32_t *)s.pair_left.p;
+    double2 *sc = (double2 *)s.sincos.p;
     {
-        ProfScope ps(ctx, K_MISC);
-        hipLaunchKernelGGL(expand_rows_kernel, dim3((nL + 255) / 256), dim3(256), 0, ctx->stream, d_row_ptr, nL,
-                           pair_left);
-        hipLaunchKernelGGL(sincos_edges_kernel, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, ctx->stream,
-                           d_Rc, n_pairs, sc);
+        ProfScope ps(ctx, s, K_MISC);
+        hipLaunchKernelGGL(expand_rows_kernel, dim3(blocks_for(nL, 256, 512)), dim3(256), 0, s.stream, d_row_ptr,
+                           DevN{nL, nullptr}, pair_left, n_pairs);
+        hipLaunchKernelGGL(sincos_edges_kernel, dim3(blocks_for(n_pairs, 256, 1024)), dim3(256), 0, s.stream, d_Rc,
+                           DevN{(int)n_pairs, nullptr}, sc);
     }
     {
-        ProfScope ps(ctx, K_NCC_PAIRS);
+        ProfScope ps(ctx, s, K_NCC_PAIRS);
         const int64_t threads = n_pairs * 16;
-        hipLaunchKernelGGL(ncc_pairs_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream,
-                           d_imgR, h, w, pitchR, d_Rc, (const double2 *)sc, (const int32_t *)pair_left, n_pairs,
-                           d_left_norm, d_left_flag, thr, d_sims, d_best, d_keep, d_match_cnt);
-        if (d_match_cnt && d_keep)
-            hipLaunchKernelGGL(count_keep_kernel, dim3(256), dim3(256), 0, ctx->stream, (const uint8_t *)d_keep,
-                               n_pairs, d_match_cnt);
+        hipLaunchKernelGGL(ncc_pairs_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s.stream, d_imgR, h,
+                           w, pitchR, d_Rc, (const double2 *)sc, (const int32_t *)pair_left, n_pairs, d_left_norm,
+                           d_left_flag, thr, d_sims, d_best, d_keep, (int32_t *)nullptr);
     }
     EBVO_HIP(ctx, hipGetLastError());
     return EBVO_OK;
 }
 
-int match_ncc_banked_device(ebvo_ctx *ctx, const int32_t *d_row_ptr, const int32_t *d_col_idx, int nL, int64_t n_pairs,
-                            const float *d_left_norm, const uint8_t *d_left_flag, const float *d_right_norm,
-                            const uint8_t *d_right_flag, double thr, double *d_sims, double *d_best, uint8_t *d_keep,
-                            int32_t *d_match_cnt)
+// NCC of the CSR pairs in s.row_ptr / s.col_idx from the banks s.patches_norm(_r) / s.patches_flag(_r)
+int match_ncc_banked_enqueue(ebvo_ctx *ctx, Slot &s, int nL, const int32_t *d_nL, int cap_edges, int64_t n_pairs_host,
+                             double thr)
 {
-    if (d_match_cnt)
-        EBVO_HIP(ctx, hipMemsetAsync(d_match_cnt, 0, sizeof(int32_t), ctx->stream));
-    if (n_pairs <= 0 || nL <= 0)
+    EBVO_HIP(ctx, hipMemsetAsync(s.d_matches, 0, sizeof(int32_t), s.stream));
+    if (!d_nL && (n_pairs_host <= 0 || nL <= 0))
         return EBVO_OK;
-    int rc;
-    if ((rc = ebvo_grow(ctx, ctx->scratch_a, sizeof(int32_t) * (size_t)n_pairs)))
-        return rc;
-    int32_t *pair_left = (int32_t *)ctx->scratch_a.p;
+    const DevN nLd{nL, d_nL};
+    const DevPairs np{n_pairs_host, d_nL ? (const int32_t *)s.row_ptr.p : nullptr, nLd, s.cap_pairs};
+    const int64_t cap_items = d_nL ? s.cap_pairs : n_pairs_host;
     {
-        ProfScope ps(ctx, K_MISC);
-        hipLaunchKernelGGL(expand_rows_kernel, dim3((nL + 255) / 256), dim3(256), 0, ctx->stream, d_row_ptr, nL,
-                           pair_left);
+        ProfScope ps(ctx, s, K_MISC);
+        hipLaunchKernelGGL(expand_rows_kernel, dim3(blocks_for(d_nL ? cap_edges : nL, 256, 512)), dim3(256), 0, s.stream,
+                           (const int32_t *)s.row_ptr.p, nLd, (int32_t *)s.pair_left.p, s.cap_pairs);
     }
     {
-        ProfScope ps(ctx, K_NCC_PAIRS);
-        const int64_t threads = n_pairs * 16;
-        hipLaunchKernelGGL(ncc_banked_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream,
-                           d_left_norm, d_left_flag, d_right_norm, d_right_flag, (const int32_t *)pair_left, d_col_idx,
-                           n_pairs, thr, d_sims, d_best, d_keep);
-        if (d_match_cnt && d_keep)
-            hipLaunchKernelGGL(count_keep_kernel, dim3(256), dim3(256), 0, ctx->stream, (const uint8_t *)d_keep,
-                               n_pairs, d_match_cnt);
+        ProfScope ps(ctx, s, K_NCC_PAIRS);
+        hipLaunchKernelGGL(ncc_banked_kernel, dim3(blocks_for(cap_items * 16, 256, 4096)), dim3(256), 0, s.stream,
+                           (const float *)s.patches_norm.p, (const uint8_t *)s.patches_flag.p,
+                           (const float *)s.patches_norm_r.p, (const uint8_t *)s.patches_flag_r.p,
+                           (const int32_t *)s.pair_left.p, (const int32_t *)s.col_idx.p, np, thr, (double *)s.sims.p,
+                           (double *)s.best.p, (uint8_t *)s.keep.p);
+        hipLaunchKernelGGL(count_keep_kernel, dim3(256), dim3(256), 0, s.stream, (const uint8_t *)s.keep.p, np,
+                           s.d_matches);
     }
     EBVO_HIP(ctx, hipGetLastError());
     return EBVO_OK;
 }
 
-int match_ncc_stored_device(ebvo_ctx *ctx, const float *d_A, const float *d_B, int n, double *d_sim)
+int match_pair_result_enqueue(ebvo_ctx *ctx, Slot &s)
+{
+    hipLaunchKernelGGL(pair_result_kernel, dim3(1), dim3(64), 0, s.stream, (const int32_t *)s.im[0].counts,
+                       (const int32_t *)s.im[1].counts, (const unsigned long long *)s.d_total,
+                       (const int32_t *)s.d_matches, s.cap_pairs, s.d_result);
+    EBVO_HIP(ctx, hipGetLastError());
+    EBVO_HIP(ctx, hipMemcpyAsync(s.h_result, s.d_result, sizeof(PairResult), hipMemcpyDeviceToHost, s.stream));
+    return EBVO_OK;
+}
+
+int match_ncc_stored_enqueue(ebvo_ctx *ctx, Slot &s, const float *d_A, const float *d_B, int n, double *d_sim)
 {
     if (n <= 0)
         return EBVO_OK;
-    ProfScope ps(ctx, K_NCC_STORED);
+    ProfScope ps(ctx, s, K_NCC_STORED);
     const int64_t threads = (int64_t)n * 16;
-    hipLaunchKernelGGL(ncc_stored_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, d_A,
-                       d_B, n, d_sim);
+    hipLaunchKernelGGL(ncc_stored_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s.stream, d_A, d_B, n,
+                       d_sim);
     EBVO_HIP(ctx, hipGetLastError());
     return EBVO_OK;
 }
 
-int misc_fp64_peak(ebvo_ctx *ctx, int iters, double *tf_muladd, double *tf_fma)
+int misc_fp64_peak(ebvo_ctx *ctx, Slot &s, int iters, double *tf_muladd, double *tf_fma)
 {
     const int blocks = 256 * 8, threads = 256, inner = 4096;
     double *d_out = nullptr;
@@ -1089,24 +1161,18 @@ int misc_fp64_peak(ebvo_ctx *ctx, int iters, double *tf_muladd, double *tf_fma)
     EBVO_HIP(ctx, hipEventCreate(&e1));
     for (int mode = 0; mode < 2; ++mode)
     {
-        // warm-up
-        if (mode == 0)
-            hipLaunchKernelGGL(fp64_peak_kernel<false>, dim3(blocks), dim3(threads), 0, ctx->stream, d_out, inner,
-                               1.0000001, 1e-9);
-        else
-            hipLaunchKernelGGL(fp64_peak_kernel<true>, dim3(blocks), dim3(threads), 0, ctx->stream, d_out, inner,
-                               1.0000001, 1e-9);
-        EBVO_HIP(ctx, hipEventRecord(e0, ctx->stream));
-        for (int it = 0; it < iters; ++it)
+        for (int it = -1; it < iters; ++it)
         {
+            if (it == 0)
+                EBVO_HIP(ctx, hipEventRecord(e0, s.stream));
             if (mode == 0)
-                hipLaunchKernelGGL(fp64_peak_kernel<false>, dim3(blocks), dim3(threads), 0, ctx->stream, d_out,
-                                   inner, 1.0000001, 1e-9);
+                hipLaunchKernelGGL(fp64_peak_kernel<false>, dim3(blocks), dim3(threads), 0, s.stream, d_out, inner,
+                                   1.0000001, 1e-9);
             else
-                hipLaunchKernelGGL(fp64_peak_kernel<true>, dim3(blocks), dim3(threads), 0, ctx->stream, d_out,
-                                   inner, 1.0000001, 1e-9);
+                hipLaunchKernelGGL(fp64_peak_kernel<true>, dim3(blocks), dim3(threads), 0, s.stream, d_out, inner,
+                                   1.0000001, 1e-9);
         }
-        EBVO_HIP(ctx, hipEventRecord(e1, ctx->stream));
+        EBVO_HIP(ctx, hipEventRecord(e1, s.stream));
         EBVO_HIP(ctx, hipEventSynchronize(e1));
         float ms = 0;
         EBVO_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));

@@ -513,7 +513,8 @@ int toed_init_constants(ebvo_ctx *ctx)
     return EBVO_OK;
 }
 
-int toed_run_device(ebvo_ctx *ctx, int n_img, int h, int w, float *ms_conv, float *ms_nms)
+int toed_enqueue(ebvo_ctx *ctx, Slot &s, int n_img, int h, int w, hipEvent_t ev_conv_begin, hipEvent_t ev_conv_end,
+                 hipEvent_t ev_end)
 {
     if (n_img < 1 || n_img > MAX_BATCH)
         return EBVO_ERR_ARG;
@@ -521,7 +522,7 @@ int toed_run_device(ebvo_ctx *ctx, int n_img, int h, int w, float *ms_conv, floa
     ImgBatch B{};
     for (int k = 0; k < n_img; ++k)
     {
-        ImageWS &ws = ctx->im[k];
+        ImageWS &ws = s.im[k];
         B.img[k] = ws.img;
         B.maps[k] = ws.maps;
         B.flag[k] = ws.flag;
@@ -531,66 +532,37 @@ int toed_run_device(ebvo_ctx *ctx, int n_img, int h, int w, float *ms_conv, floa
         B.src[k] = ws.src;
         B.edges[k] = ws.edges;
         B.all4[k] = ws.all4;
-        EBVO_HIP(ctx, hipMemsetAsync(ws.row_cnt, 0, sizeof(int32_t) * 2 * H2, ctx->stream));
+        EBVO_HIP(ctx, hipMemsetAsync(ws.row_cnt, 0, sizeof(int32_t) * 2 * H2, s.stream));
     }
-    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
-    const bool timed = ms_conv || ms_nms;
-    if (timed)
+    if (ev_conv_begin)
+        EBVO_HIP(ctx, hipEventRecord(ev_conv_begin, s.stream));
     {
-        EBVO_HIP(ctx, hipEventCreate(&e0));
-        EBVO_HIP(ctx, hipEventCreate(&e1));
-        EBVO_HIP(ctx, hipEventCreate(&e2));
-        EBVO_HIP(ctx, hipEventRecord(e0, ctx->stream));
-    }
-    {
-        ProfScope ps(ctx, K_CONV);
+        ProfScope ps(ctx, s, K_CONV);
         dim3 grid((w + TILE_W - 1) / TILE_W, (h + TILE_H - 1) / TILE_H, 2 * n_img);
-        hipLaunchKernelGGL(toed_conv_kernel, grid, dim3(256), 0, ctx->stream, B,
+        hipLaunchKernelGGL(toed_conv_kernel, grid, dim3(256), 0, s.stream, B,
                            (const ToedTables *)g_tables_dev[ctx->device], h, w);
     }
-    if (timed)
-        EBVO_HIP(ctx, hipEventRecord(e1, ctx->stream));
+    if (ev_conv_end)
+        EBVO_HIP(ctx, hipEventRecord(ev_conv_end, s.stream));
     {
-        ProfScope ps(ctx, K_NMS);
+        ProfScope ps(ctx, s, K_NMS);
         dim3 grid((W2 - 20 + 63) / 64, (H2 - 20 + 3) / 4, n_img);
-        hipLaunchKernelGGL(toed_nms_kernel, grid, dim3(64, 4), 0, ctx->stream, B, h, w);
+        hipLaunchKernelGGL(toed_nms_kernel, grid, dim3(64, 4), 0, s.stream, B, h, w);
     }
     {
-        ProfScope ps(ctx, K_ROWSCAN);
-        hipLaunchKernelGGL(toed_rowscan_kernel, dim3(n_img), dim3(64), 0, ctx->stream, B, H2);
+        ProfScope ps(ctx, s, K_ROWSCAN);
+        hipLaunchKernelGGL(toed_rowscan_kernel, dim3(n_img), dim3(64), 0, s.stream, B, H2);
     }
     {
-        ProfScope ps(ctx, K_COMPACT);
-        hipLaunchKernelGGL(toed_compact_kernel, dim3(H2 - 20, n_img), dim3(256), 0, ctx->stream, B, h, w,
-                           ctx->cap_edges);
+        ProfScope ps(ctx, s, K_COMPACT);
+        hipLaunchKernelGGL(toed_compact_kernel, dim3(H2 - 20, n_img), dim3(256), 0, s.stream, B, h, w, ctx->cap_edges);
     }
     {
-        ProfScope ps(ctx, K_FINALIZE);
-        hipLaunchKernelGGL(toed_finalize_kernel, dim3(512, n_img), dim3(256), 0, ctx->stream, B, h, w,
-                           ctx->cap_edges);
+        ProfScope ps(ctx, s, K_FINALIZE);
+        hipLaunchKernelGGL(toed_finalize_kernel, dim3(512, n_img), dim3(256), 0, s.stream, B, h, w, ctx->cap_edges);
     }
-    if (timed)
-        EBVO_HIP(ctx, hipEventRecord(e2, ctx->stream));
+    if (ev_end)
+        EBVO_HIP(ctx, hipEventRecord(ev_end, s.stream));
     EBVO_HIP(ctx, hipGetLastError());
-    for (int k = 0; k < n_img; ++k)
-        EBVO_HIP(ctx, hipMemcpyAsync(ctx->h_small + 2 * k, ctx->im[k].counts, 2 * sizeof(int32_t),
-                                     hipMemcpyDeviceToHost, ctx->stream));
-    EBVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    for (int k = 0; k < n_img; ++k)
-    {
-        ctx->im[k].n_total = ctx->h_small[2 * k];
-        ctx->im[k].n_kept = ctx->h_small[2 * k + 1];
-    }
-    if (timed)
-    {
-        float a = 0, b = 0;
-        EBVO_HIP(ctx, hipEventElapsedTime(&a, e0, e1));
-        EBVO_HIP(ctx, hipEventElapsedTime(&b, e1, e2));
-        if (ms_conv) *ms_conv = a;
-        if (ms_nms) *ms_nms = b;
-        hipEventDestroy(e0);
-        hipEventDestroy(e1);
-        hipEventDestroy(e2);
-    }
     return EBVO_OK;
 }

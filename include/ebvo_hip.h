@@ -180,13 +180,26 @@ void ebvo_stereo_default_params(ebvo_stereo_params *p);
 /* copy one stereo pair into HBM (not part of the timed region) */
 int ebvo_stereo_upload(ebvo_ctx *ctx, const uint8_t *img_left, const uint8_t *img_right, int h, int w,
                        ptrdiff_t stride_left, ptrdiff_t stride_right);
-/* run the whole hot path on the resident pair */
+/* run the whole hot path on the resident pair (= submit + wait on slot 0) */
 int ebvo_stereo_run(ebvo_ctx *ctx, const ebvo_stereo_params *p, ebvo_stereo_counts *counts);
 /* fetch the results of the last ebvo_stereo_run; any pointer may be NULL */
 int ebvo_stereo_fetch(ebvo_ctx *ctx, ebvo_edge *left, ebvo_edge *right, int32_t *row_ptr, int32_t *col_idx,
                       double *sims, double *best, uint8_t *keep, float *left_patches);
 
-/* Per-kernel device timing (HIP events on the ctx stream). */
+/* Several pairs in flight from one host thread: a slot is a stereo pair's workspace plus its own HIP stream.
+ * ebvo_stereo_submit enqueues the whole hot path of the slot's resident pair WITHOUT any host synchronisation
+ * (every size stays in device memory; launches are sized by capacities) and returns at once; ebvo_stereo_wait
+ * blocks until that pair is done and returns its counts.  Kernels of different slots overlap on the GPU.
+ * Slot 0 always exists and is the one the host-buffer entry points above use. */
+int ebvo_stereo_set_slots(ebvo_ctx *ctx, int n_slots);
+int ebvo_stereo_upload_slot(ebvo_ctx *ctx, int slot, const uint8_t *img_left, const uint8_t *img_right, int h, int w,
+                            ptrdiff_t stride_left, ptrdiff_t stride_right);
+int ebvo_stereo_submit(ebvo_ctx *ctx, int slot, const ebvo_stereo_params *p);
+int ebvo_stereo_wait(ebvo_ctx *ctx, int slot, ebvo_stereo_counts *counts);
+int ebvo_stereo_fetch_slot(ebvo_ctx *ctx, int slot, ebvo_edge *left, ebvo_edge *right, int32_t *row_ptr,
+                           int32_t *col_idx, double *sims, double *best, uint8_t *keep, float *left_patches);
+
+/* Per-kernel device timing (HIP events on the slots' streams, accumulated). */
 #define EBVO_MAX_KERNELS 16
 typedef struct ebvo_kernel_time
 {

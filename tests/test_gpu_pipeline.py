@@ -88,3 +88,69 @@ def test_pipeline_state_errors(ctx):
     with pytest.raises(EbvoError) as ei:
         ctx.stereo_run(ctx.default_params(F_KITTI))
     assert ei.value.status == EBVO_ERR_STATE
+
+
+def test_slots_overlap_and_agree(ctx):
+    """Several pairs in flight from one host thread: every slot returns exactly what a lone run returns."""
+    ctx.set_slots(3)
+    pairs = [synth.stereo_pair("s2", 120, 200, scene=7 + k, noise_base=10 * k) for k in range(3)]
+    p = ctx.default_params(F_KITTI)
+    for k, (l, r) in enumerate(pairs):
+        ctx.stereo_upload(l, r, slot=k)
+    for k in range(3):
+        ctx.stereo_submit(p, slot=k)
+    outs = []
+    for k in range(3):
+        c = ctx.stereo_wait(slot=k)
+        outs.append((c, ctx.stereo_fetch(c, slot=k)))
+    for k, (l, r) in enumerate(pairs):
+        ctx.stereo_upload(l, r, slot=0)
+        c = ctx.stereo_run(p)
+        ref = ctx.stereo_fetch(c)
+        ck, ok = outs[k]
+        assert (ck.n_left, ck.n_right, ck.n_pairs, ck.n_matches) == (c.n_left, c.n_right, c.n_pairs, c.n_matches)
+        for key in ("row_ptr", "col_idx", "sims", "keep"):
+            assert_bit_equal(ok[key], ref[key], f"slot {k} {key}")
+        assert_edges_equal(ok["left"], ref["left"])
+
+
+def test_pipeline_grows_pair_buffers_on_overflow():
+    """More candidates than the pair-indexed buffers hold: the library grows them and redoes the matching half."""
+    from edge_based_visual_odometry_amd.api import Context
+    l, r = synth.stereo_pair("s2", 120, 200)
+    with Context(120, 200) as small:              # capacity 8 * 120 * 200 = 192,000 pairs
+        small.stereo_upload(l, r)
+        p = small.default_params(F_KITTI)
+        p.stage_mask = 1                           # epipolar only: ~280,000 pairs
+        c = small.stereo_run(p)
+        out = small.stereo_fetch(c)
+        assert c.n_pairs > 8 * 120 * 200
+        L, R, _ = small.toed_pair(l, r)
+        lines = small.epipolar_lines(F_KITTI, L)
+        rp, ci = small.epi_candidates(L, R, lines, stage_mask=1)
+        assert_bit_equal(out["row_ptr"], rp)
+        assert_bit_equal(out["col_idx"], ci)
+        sims, best, keep, _ = small.ncc_pairs(l, r, L, R[ci], rp)
+        assert_bit_equal(out["sims"], sims)
+        assert c.n_matches == int(keep.sum())
+        small.stereo_upload(l, r)                  # the host-buffer calls above replaced the resident pair
+        c2 = small.stereo_run(p)                   # second run: buffers already large enough
+        assert (c2.n_pairs, c2.n_matches) == (c.n_pairs, c.n_matches)
+
+
+def test_submit_wait_state_machine(ctx):
+    from edge_based_visual_odometry_amd._lib import EbvoError, EBVO_ERR_STATE
+    l, r = synth.stereo_pair("s2", 64, 96)
+    ctx.stereo_upload(l, r)
+    p = ctx.default_params(F_KITTI)
+    with pytest.raises(EbvoError) as ei:
+        ctx.stereo_wait()                          # nothing submitted
+    assert ei.value.status == EBVO_ERR_STATE
+    ctx.stereo_submit(p)
+    with pytest.raises(EbvoError):
+        ctx.stereo_submit(p)                       # already in flight
+    with pytest.raises(EbvoError):
+        ctx.toed(l)                                # host-buffer calls share slot 0
+    c = ctx.stereo_wait()
+    assert c.n_pairs > 0
+    assert len(ctx.toed(l).edges) == c.n_left
