@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for the barrier / max (nccl = RCCL)")
     ap.add_argument("--streams", type=int, default=3, help="stereo pairs kept in flight per GPU (slots / HIP streams)")
     args = ap.parse_args()
 
@@ -83,10 +84,16 @@ def main():
     rank, local_rank, world = info.rank, info.local_rank, info.world
     dist = None
     import torch
+    ndev = torch.cuda.device_count()
+    device = local_rank % max(1, ndev)           # one rank per GPU on a full node; wraps only when rehearsing N > #GPUs
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(device)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(args.dist_backend)
+    reduce_device = f"cuda:{device}" if args.dist_backend == "nccl" else "cpu"
 
     # one sequence per GPU: its own scene and noise seeds
     left, right = synth.stereo_pair("s2", H, W, **sharding.rank_workload(rank))
@@ -96,7 +103,7 @@ def main():
     # one context per GPU; --streams S keeps S pairs in flight from this one host thread (S slots, one HIP stream
     # each): submit enqueues a whole pair without host synchronisation, wait blocks on that pair only
     nslots = max(1, args.streams)
-    ctx = Context(H, W, device=local_rank)
+    ctx = Context(H, W, device=device)
     ctx.set_slots(nslots)
     params = ctx.default_params(F)
     for k in range(nslots):
@@ -131,7 +138,7 @@ def main():
     ctx.profile_enable(False)
     prof = ctx.profile_get()
 
-    dt = sharding.max_over_ranks(dt, dist, f"cuda:{local_rank}")
+    dt = sharding.max_over_ranks(dt, dist, reduce_device)
 
     if rank == 0:
         conv_ms, conv_n = prof["toed_conv"]

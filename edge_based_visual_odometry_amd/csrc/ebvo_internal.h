@@ -40,7 +40,7 @@ enum
     PL_IX = 0,
     PL_IY,
     PL_MAG,
-    PL_TOX,
+    PL_TOX, // third-order orientation vector, unnormalised
     PL_TOY,
     PL_NUM
 };

@@ -495,27 +495,31 @@ __global__ void gather_edges_kernel(const ebvo_edge *__restrict__ R, const int32
 // those are exactly +1.0 and -1.0, and x / 1.0 == x, x / -1.0 == -x bit for bit; for an integer
 // coordinate they are 0 and the quotient 0/0 is NaN.  The four fp64 divisions are therefore
 // replaced by a select -- same bits, ~140 fewer instructions per sample.
+// Straight-line form (no early return): the four byte loads of every sample are issued unconditionally from a
+// clamped address, so the 28 loads of a patch row overlap; the NaN cases are applied by a final select.
 __device__ inline double bilinear_nan(const uint8_t *__restrict__ img, int rows, int cols, int pitch, double x,
                                       double y)
 {
     const double x1 = floor(x), x2 = ceil(x);
     const double yc = ceil(y), yf = floor(y);
-    if (x1 < 0 || yc < 0 || x2 >= cols || yc >= rows || yf < 0 || !(x == x) || !(y == y))
-        return __builtin_nan("");
-    const double qnan = __builtin_nan("");
-    const int r1 = (int)yc * pitch, r2 = (int)yf * pitch, c1 = (int)x1, c2 = (int)x2;
+    // include/utility.h:95-99 (a corner outside the image); NaN coordinates fail every comparison the same way
+    const bool inside = (x1 >= 0) && (yf >= 0) && (x2 < cols) && (yc < rows);
+    const int c1 = inside ? (int)x1 : 0, c2 = inside ? (int)x2 : 0;
+    const int r1 = inside ? (int)yc * pitch : 0, r2 = inside ? (int)yf * pitch : 0;
     const double I11 = (double)img[r1 + c1];
     const double I21 = (double)img[r1 + c2];
     const double I12 = (double)img[r2 + c1];
     const double I22 = (double)img[r2 + c2];
-    const bool xint = (x2 == x1), yint = (yf == yc);
-    const double wxa = xint ? qnan : (x2 - x); // (Q21.x - P.x) / (Q21.x - Q11.x)
-    const double wxb = xint ? qnan : (x - x1); // (P.x - Q11.x) / (Q21.x - Q11.x)
-    const double wya = yint ? qnan : -(yf - y); // (Q12.y - P.y) / (Q12.y - Q11.y),  Q12.y - Q11.y = -1
-    const double wyb = yint ? qnan : -(y - yc); // (P.y - Q11.y) / (Q12.y - Q11.y)
+    const double wxa = x2 - x;    // (Q21.x - P.x) / (Q21.x - Q11.x), denominator exactly 1
+    const double wxb = x - x1;    // (P.x - Q11.x) / (Q21.x - Q11.x)
+    const double wya = -(yf - y); // (Q12.y - P.y) / (Q12.y - Q11.y), denominator exactly -1
+    const double wyb = -(y - yc); // (P.y - Q11.y) / (Q12.y - Q11.y)
     const double f1 = wxa * I11 + wxb * I21;
     const double f2 = wxa * I12 + wxb * I22;
-    return wya * f1 + wyb * f2;
+    const double v = wya * f1 + wyb * f2;
+    // integer coordinate: the reference divides 0 by 0 (include/utility.h:101-103) -> NaN
+    const bool ok = inside && (x2 != x1) && (yf != yc);
+    return ok ? v : __builtin_nan("");
 }
 
 // 8-lane xor butterfly: ((s0+s1)+(s2+s3)) + ((s4+s5)+(s6+s7)) on every lane of the group
@@ -646,11 +650,17 @@ __global__ __launch_bounds__(256) void patches_kernel(const uint8_t *__restrict_
         if (active)
         {
             const size_t o = (size_t)e * 98 + side * 49 + row * 7;
-#pragma unroll
-            for (int c = 0; c < 7; ++c)
+            if (raw)
             {
-                if (raw) raw[o + c] = p[c];
-                if (norm) norm[o + c] = nr[c];
+#pragma unroll
+                for (int c = 0; c < 7; ++c)
+                    raw[o + c] = p[c];
+            }
+            if (norm)
+            {
+#pragma unroll
+                for (int c = 0; c < 7; ++c)
+                    norm[o + c] = nr[c];
             }
             if (flag && row == 0)
                 flag[(size_t)e * 2 + side] = sent ? 1 : 0;

@@ -122,7 +122,7 @@ struct ImgBatch
     acc[7] += cp[3] * rp[0];      \
     acc[8] += cp[0] * rp[3];
 
-// third-order orientation vector, src/toed/cpu_toed.cpp:224-228
+// third-order orientation vector (unnormalised), src/toed/cpu_toed.cpp:224-225
 __device__ inline void third_order_dir(const double *f, double &tx, double &ty)
 {
     const double fx = f[0], fy = f[1], fxx = f[2], fxy = f[3], fyy = f[4], fxxy = f[5], fxyy = f[6],
@@ -131,9 +131,9 @@ __device__ inline void third_order_dir(const double *f, double &tx, double &ty)
                    2 * fx * fy * fxxy + fy * fy * fxyy + fx * fx * fxxx;
     double TO_Iy = fx * (2 * fxx * fxy + 2 * fyy * fxy) + fy * (2 * fyy * fyy + 2 * fxy * fxy) +
                    2 * fx * fy * fxyy + fx * fx * fxxy + fy * fy * fyyy;
-    double TO_mag = sqrt(TO_Ix * TO_Ix + TO_Iy * TO_Iy);
-    tx = TO_Ix / TO_mag;
-    ty = TO_Iy / TO_mag;
+    // the normalisation (:226-228) is applied in toed_finalize_kernel, only where an edge survives NMS
+    tx = TO_Ix;
+    ty = TO_Iy;
 }
 
 // Interpolated pixel (I, J) of a 2H x 2W plane lives in the sub-plane of its phase (I&1, J&1) at
@@ -468,9 +468,13 @@ __global__ __launch_bounds__(256) void toed_finalize_kernel(ImgBatch B, int h, i
         double px = 0, py = 0, sm = 0;
         nms_eval(maps + PL_IX * plane, maps + PL_IY * plane, maps + PL_MAG * plane, h, w, i, j, px, py, sm);
         const double x = (px - 1) / 2, y = (py - 1) / 2;
-        // src/toed/cpu_toed.cpp:229: atan2(TO_Ix, -TO_Iy)
         const size_t mo = midx(i, j, h, w);
-        const double th = ebvo_atan2(maps[PL_TOX * plane + mo], -maps[PL_TOY * plane + mo]);
+        // src/toed/cpu_toed.cpp:226-229: normalise the third-order vector, then atan2(TO_Ix, -TO_Iy)
+        double TO_Ix = maps[PL_TOX * plane + mo], TO_Iy = maps[PL_TOY * plane + mo];
+        const double TO_mag = sqrt(TO_Ix * TO_Ix + TO_Iy * TO_Iy);
+        TO_Ix /= TO_mag;
+        TO_Iy /= TO_mag;
+        const double th = ebvo_atan2(TO_Ix, -TO_Iy);
         all4[(size_t)t * 4 + 0] = x;
         all4[(size_t)t * 4 + 1] = y;
         all4[(size_t)t * 4 + 2] = th;
