@@ -76,6 +76,9 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--toed-mode", default="hybrid", choices=["strict", "hybrid"],
+                    help="strict: direct-form convolution at every pixel; hybrid: separable screen + exact "
+                         "re-evaluation of the candidates (bit-identical edges, ~3x less work)")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for the barrier / max (nccl = RCCL)")
     ap.add_argument("--streams", type=int, default=3, help="stereo pairs kept in flight per GPU (slots / HIP streams)")
     args = ap.parse_args()
@@ -103,7 +106,7 @@ def main():
     # one context per GPU; --streams S keeps S pairs in flight from this one host thread (S slots, one HIP stream
     # each): submit enqueues a whole pair without host synchronisation, wait blocks on that pair only
     nslots = max(1, args.streams)
-    ctx = Context(H, W, device=device)
+    ctx = Context(H, W, device=device, toed_mode=args.toed_mode)
     ctx.set_slots(nslots)
     params = ctx.default_params(F)
     for k in range(nslots):

@@ -39,13 +39,24 @@ class ToedResult:
 class Context:
     """One HIP device workspace (``ebvo_ctx``).  Not thread-safe; one per process and GPU."""
 
-    def __init__(self, max_h: int, max_w: int, device: int = 0):
+    def __init__(self, max_h: int, max_w: int, device: int = 0, toed_mode: str | None = None):
         self.lib = _lib.load_library()
         self._ctx = C.c_void_p()
         rc = self.lib.ebvo_ctx_create(device, max_h, max_w, C.byref(self._ctx))
         if rc != 0:
             raise EbvoError(rc, "ebvo_ctx_create", self.lib.ebvo_strerror(rc).decode())
         self.max_h, self.max_w, self.device = max_h, max_w, device
+        if toed_mode is not None:
+            self.set_toed_mode(toed_mode)
+
+    def set_toed_mode(self, mode: str):
+        """'strict': direct-form convolution everywhere; 'hybrid': separable screen + exact re-evaluation."""
+        m = {"strict": _lib.TOED_STRICT, "hybrid": _lib.TOED_HYBRID}[mode]
+        self._check(self.lib.ebvo_set_toed_mode(self._ctx, m), "ebvo_set_toed_mode")
+
+    @property
+    def toed_mode(self) -> str:
+        return "hybrid" if self.lib.ebvo_get_toed_mode(self._ctx) == _lib.TOED_HYBRID else "strict"
 
     def close(self):
         if getattr(self, "_ctx", None):

@@ -2,13 +2,14 @@
 // the sync-free device-resident stereo pipeline, profiling.
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
 #include "ebvo_internal.h"
 
 const char *const g_kernel_names[K_NUM] = {
-    "toed_conv",   "toed_nms",   "toed_rowscan", "toed_compact", "toed_finalize", "cand_boxes", "epi_lines",
+    "toed_conv",   "toed_nms",   "toed_rowscan", "toed_compact", "toed_finalize", "toed_exact", "cand_boxes", "epi_lines",
     "cand_count",  "scan",       "cand_fill",    "edge_patches", "ncc_pairs",     "ncc_stored", "misc"};
 
 // ------------------------------------------------------------------------------------------
@@ -127,6 +128,9 @@ static void slot_destroy(Slot *s)
         (void)hipFree(ws.src);
         (void)hipFree(ws.edges);
         (void)hipFree(ws.all4);
+        (void)hipFree(ws.cand_rec);
+        (void)hipFree(ws.cand_flag);
+        (void)hipFree(ws.cand_off);
     }
     GrowBuf *bufs[] = {&s->lines,        &s->boxes_chunk,  &s->boxes_group,    &s->cand_cnt,       &s->row_ptr,
                        &s->scan_tmp,     &s->col_idx,      &s->rc_edges,       &s->sims,           &s->best,
@@ -173,7 +177,11 @@ static int slot_create(ebvo_ctx *ctx, Slot **out)
         CK(hipMalloc(&ws.flag, np2));
         CK(hipMalloc(&ws.row_cnt, sizeof(int32_t) * 2 * H2));
         CK(hipMalloc(&ws.row_off, sizeof(int32_t) * 2 * (H2 + 1)));
-        CK(hipMalloc(&ws.counts, sizeof(int32_t) * 2));
+        CK(hipMalloc(&ws.counts, sizeof(int32_t) * 4));
+        CK(hipMemset(ws.counts, 0, sizeof(int32_t) * 4));
+        CK(hipMalloc(&ws.cand_rec, 40 * (size_t)ctx->cap_edges));
+        CK(hipMalloc(&ws.cand_flag, sizeof(int32_t) * 2 * (size_t)ctx->cap_edges));
+        CK(hipMalloc(&ws.cand_off, sizeof(int32_t) * 2 * ((size_t)ctx->cap_edges + 1)));
         CK(hipMalloc(&ws.src, sizeof(int32_t) * 2 * (size_t)ctx->cap_edges));
         CK(hipMalloc(&ws.edges, sizeof(ebvo_edge) * (size_t)ctx->cap_edges));
         CK(hipMalloc(&ws.all4, sizeof(double) * 4 * (size_t)ctx->cap_edges));
@@ -207,6 +215,16 @@ extern "C" const char *ebvo_strerror(int status)
 extern "C" const char *ebvo_last_error(const ebvo_ctx *ctx) { return ctx ? ctx->last_error.c_str() : ""; }
 
 extern "C" int ebvo_abi_version(void) { return EBVO_ABI_VERSION; }
+
+extern "C" int ebvo_set_toed_mode(ebvo_ctx *ctx, int mode)
+{
+    if (!ctx || (mode != EBVO_TOED_STRICT && mode != EBVO_TOED_HYBRID))
+        return EBVO_ERR_ARG;
+    ctx->toed_mode = mode;
+    return EBVO_OK;
+}
+
+extern "C" int ebvo_get_toed_mode(const ebvo_ctx *ctx) { return ctx ? ctx->toed_mode : EBVO_ERR_ARG; }
 
 extern "C" void ebvo_ctx_destroy(ebvo_ctx *ctx)
 {
@@ -242,6 +260,10 @@ extern "C" int ebvo_ctx_create(int device, int max_h, int max_w, ebvo_ctx **out)
     ctx->max_h = max_h;
     ctx->max_w = max_w;
     ctx->cap_edges = max_h * max_w;
+    {
+        const char *m = getenv("EBVO_TOED_MODE");
+        ctx->toed_mode = (m && strcmp(m, "hybrid") == 0) ? EBVO_TOED_HYBRID : EBVO_TOED_STRICT;
+    }
     int rc;
     auto fail = [&](int code) {
         fprintf(stderr, "[ebvo] ebvo_ctx_create: %s (%s)\n", ebvo_strerror(code), ctx->last_error.c_str());

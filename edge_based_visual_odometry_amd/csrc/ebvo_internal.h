@@ -18,6 +18,7 @@ enum KernelId
     K_ROWSCAN,
     K_COMPACT,
     K_FINALIZE,
+    K_EXACT,
     K_BOXES,
     K_LINES,
     K_CAND_COUNT,
@@ -59,10 +60,13 @@ struct ImageWS
     uint8_t *flag = nullptr;    // 2H x 2W: 0 none, 1 NMS maximum, 3 maximum inside the 10-px border
     int32_t *row_cnt = nullptr; // [2][H2]   per interpolated row: all maxima, kept maxima
     int32_t *row_off = nullptr; // [2][H2+1] exclusive prefix of row_cnt
-    int32_t *counts = nullptr;  // [2] n_total, n_kept  (device-side sizes of everything downstream)
+    int32_t *counts = nullptr;  // [4] n_total, n_kept (device-side sizes of everything downstream), n_candidates, -
     int32_t *src = nullptr;     // [cap][2] (pixel offset, kept rank or -1) per maximum, raster order
     ebvo_edge *edges = nullptr; // [cap] kept edges
     double *all4 = nullptr;     // [cap][4] every maximum (x, y, theta, mag)
+    void *cand_rec = nullptr;       // hybrid TOED: [cap] exact records of the screened candidates
+    int32_t *cand_flag = nullptr;   // [2][cap]   is-maximum / is-kept flags per candidate
+    int32_t *cand_off = nullptr;    // [2][cap+1] exclusive scans of the flags
     int n_total = 0, n_kept = 0; // host copies, valid after a synchronising call
 };
 
@@ -112,6 +116,7 @@ struct ebvo_ctx
     int device = 0;
     int max_h = 0, max_w = 0;
     int cap_edges = 0; // per image
+    int toed_mode = EBVO_TOED_STRICT;
     std::string last_error;
     std::vector<Slot *> slots; // slot 0 always exists; it also serves the host-buffer entry points
 
@@ -179,6 +184,9 @@ int match_ncc_pairs_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_imgR, int h
 int match_ncc_banked_enqueue(ebvo_ctx *ctx, Slot &s, int nL, const int32_t *d_nL, int cap_edges, int64_t n_pairs_host,
                              double thr);
 int match_pair_result_enqueue(ebvo_ctx *ctx, Slot &s);
+// exclusive scan of n (+ n_add) int32 on the slot's stream; n_dev != nullptr: the count lives on the device, cap_n bounds it
+int ebvo_device_scan(ebvo_ctx *ctx, Slot &s, const int32_t *in, int32_t *out, int n_host, const int32_t *n_dev, int n_add,
+                     int cap_n);
 int match_ncc_stored_enqueue(ebvo_ctx *ctx, Slot &s, const float *d_A, const float *d_B, int n, double *d_sim);
 int misc_fp64_peak(ebvo_ctx *ctx, Slot &s, int iters, double *tf_muladd, double *tf_fma);
 

@@ -973,6 +973,17 @@ inline unsigned blocks_for(int64_t items, int per_block, int max_blocks)
 
 } // namespace
 
+int ebvo_device_scan(ebvo_ctx *ctx, Slot &s, const int32_t *in, int32_t *out, int n_host, const int32_t *n_dev, int n_add,
+                     int cap_n)
+{
+    ProfScope ps(ctx, s, K_SCAN);
+    int rc = device_exclusive_scan(ctx, s, in, out, DevN{n_host, n_dev}, n_add, cap_n);
+    if (rc)
+        return rc;
+    EBVO_HIP(ctx, hipGetLastError());
+    return EBVO_OK;
+}
+
 int match_lines_enqueue(ebvo_ctx *ctx, Slot &s, const double *d_F, const ebvo_edge *d_edges, int n, const int32_t *d_n,
                         int cap_n, double *d_lines)
 {

@@ -97,6 +97,11 @@ constexpr int LDS_W = TILE_W + 2 * HALO; // 50
 constexpr int LDS_H = TILE_H + 2 * HALO; // 26
 constexpr int MAX_BATCH = 2;
 
+struct CandRec
+{
+    double x, y, smag, tox, toy;
+};
+
 struct ImgBatch
 {
     const uint8_t *img[MAX_BATCH];
@@ -108,6 +113,10 @@ struct ImgBatch
     int32_t *src[MAX_BATCH];
     ebvo_edge *edges[MAX_BATCH];
     double *all4[MAX_BATCH];
+    // hybrid mode: per-candidate records and flags
+    CandRec *rec[MAX_BATCH];
+    int32_t *cand_flag[MAX_BATCH]; // [2][cap]: is a maximum, is a kept maximum
+    int32_t *cand_off[MAX_BATCH];  // [2][cap+1]: exclusive scans of the flags
 };
 
 // nine responses: fx fy fxx fxy fyy fxxy fxyy fxxx fyyy -> (x-derivative order, y-derivative order)
@@ -273,15 +282,13 @@ __global__ __launch_bounds__(256) void toed_conv_kernel(ImgBatch B, const ToedTa
 }
 
 // NMS + parabola fit at interpolated pixel (i, j): src/toed/cpu_toed.cpp:406-511.
-__device__ inline bool nms_eval(const double *__restrict__ Ix, const double *__restrict__ Iy,
-                                const double *__restrict__ M, int h, int w, int i, int j, double &pos_x,
+// m, gx, gy: magnitude and gradient at the pixel; mag_at(di, dj): magnitude of a neighbour.
+template <class MagAt>
+__device__ inline bool nms_core(double m, double gx, double gy, int i, int j, MagAt mag_at, double &pos_x,
                                 double &pos_y, double &smag)
 {
-    const size_t o = midx(i, j, h, w);
-    const double m = M[o];
     if (m <= 2) // :406
         return false;
-    const double gx = Ix[o], gy = Iy[o];
     if (fabs(gx) < 10e-6 && fabs(gy) < 10e-6) // :410
         return false;
     const double nx = gx / m, ny = gy / m;
@@ -310,8 +317,8 @@ __device__ inline bool nms_eval(const double *__restrict__ Ix, const double *__r
     }
     else
         return false;
-    const double fp = M[midx(i + a1, j + b1, h, w)] * (1 - slope) + M[midx(i + a2, j + b2, h, w)] * slope;
-    const double fm = M[midx(i - a1, j - b1, h, w)] * (1 - slope) + M[midx(i - a2, j - b2, h, w)] * slope;
+    const double fp = mag_at(a1, b1) * (1 - slope) + mag_at(a2, b2) * slope;
+    const double fm = mag_at(-a1, -b1) * (1 - slope) + mag_at(-a2, -b2) * slope;
     const double s = sqrt(1 + slope * slope);
     if (!((m > fm && m > fp) || (m > fm && m >= fp) || (m >= fm && m > fp))) // :481-483
         return false;
@@ -327,6 +334,15 @@ __device__ inline bool nms_eval(const double *__restrict__ Ix, const double *__r
     pos_x = j + s_star * nx;
     pos_y = i + s_star * ny;
     return true;
+}
+
+__device__ inline bool nms_eval(const double *__restrict__ Ix, const double *__restrict__ Iy,
+                                const double *__restrict__ M, int h, int w, int i, int j, double &pos_x,
+                                double &pos_y, double &smag)
+{
+    const size_t o = midx(i, j, h, w);
+    return nms_core(M[o], Ix[o], Iy[o], i, j, [&](int di, int dj) { return M[midx(i + di, j + dj, h, w)]; }, pos_x,
+                    pos_y, smag);
 }
 
 // K2 ---------------------------------------------------------------------------------------
@@ -361,7 +377,7 @@ __global__ __launch_bounds__(256) void toed_nms_kernel(ImgBatch B, int h, int w)
 
 // K3a --------------------------------------------------------------------------------------
 // one wave per image: exclusive scan of both per-row counters; totals to counts[0..1].
-__global__ __launch_bounds__(64) void toed_rowscan_kernel(ImgBatch B, int H2)
+__global__ __launch_bounds__(64) void toed_rowscan_kernel(ImgBatch B, int H2, int count_base)
 {
     const int32_t *cnt = B.row_cnt[blockIdx.x];
     int32_t *off = B.row_off[blockIdx.x];
@@ -391,7 +407,7 @@ __global__ __launch_bounds__(64) void toed_rowscan_kernel(ImgBatch B, int H2)
         if (lane == 63)
         {
             o[H2] = incl;
-            B.counts[blockIdx.x][which] = incl;
+            B.counts[blockIdx.x][count_base + which] = incl;
         }
     }
 }
@@ -492,6 +508,343 @@ __global__ __launch_bounds__(256) void toed_finalize_kernel(ImgBatch B, int h, i
     }
 }
 
+
+// ==========================================================================================
+// Hybrid TOED: separable screening + exact re-evaluation.  Bit-identical results, ~3x less work.
+//
+// The direct-form convolution above spends 27.6 k fp64 operations on every pixel, but only ~7 % of the
+// interpolated pixels become edges.  Here a cheap SEPARABLE fp64 convolution (FMA allowed: it is only a
+// screen) produces gx, gy, |g| with an absolute error below E = 1e-11 (bound: 2 * (361+2) * 2^-53 *
+// sum|v||Kq||Kp| <= 8e-12 for 8-bit pixels and these taps), a RELAXED non-maximum test with tolerance
+// 1e-6 >> E selects a superset of the pixels the reference accepts, and every selected pixel is then
+// evaluated in the reference's exact arithmetic (same taps, same order, no FMA): its nine responses and
+// the two-response magnitude of its four NMS neighbours.  The exact NMS decision, sub-pixel position,
+// magnitude and orientation are computed from those exact values only, so the edge list equals the
+// strict path's bit for bit; a pixel that the relaxed screen rejects is rejected by the exact test too.
+//   relaxed screen: |g| > 2 - 1e-6, and either the gradient sector is ambiguous within 1e-6
+//   (|gx|, |gy| or ||gx|-|gy|| below it) or |g| >= fm - 1e-6 and |g| >= fp - 1e-6 with the screen's
+//   own neighbours; the |s*| <= sqrt(2) test is left to the exact stage.
+// ==========================================================================================
+constexpr double SCREEN_TOL = 1e-6;
+
+// S1 ---------------------------------------------------------------------------------------
+// separable screening convolution: gx, gy, |g| at the four phases of every pixel (planes IX, IY, MAG)
+__global__ __launch_bounds__(256) void toed_sep_kernel(ImgBatch B, const ToedTables *__restrict__ T, int h, int w)
+{
+    __shared__ double tile[LDS_H][LDS_W];
+    __shared__ double R[2][LDS_H][TILE_W]; // row-filtered with G (0) and Gx (1)
+    const uint8_t *__restrict__ img = B.img[blockIdx.z];
+    double *__restrict__ maps = B.maps[blockIdx.z];
+    const int j0 = blockIdx.x * TILE_W, i0 = blockIdx.y * TILE_H;
+    for (int t = threadIdx.x; t < LDS_H * LDS_W; t += 256)
+    {
+        const int r = t / LDS_W, c = t - r * LDS_W;
+        const int ii = i0 + r - HALO, jj = j0 + c - HALO;
+        double v = 0.0;
+        if (ii >= 0 && ii < h && jj >= 0 && jj < w)
+            v = (double)img[(size_t)ii * w + jj];
+        tile[r][c] = v;
+    }
+    const int tx = threadIdx.x & (TILE_W - 1), ty = threadIdx.x >> 5;
+    const int i = i0 + ty, j = j0 + tx;
+    const bool inside = i < h && j < w;
+    const size_t plane = (size_t)4 * h * w;
+    // set 0: integer column taps, 17 wide -> phase (0,0); set 1: integer column taps, 19 wide -> phase (1,0);
+    // set 2: half-pixel column taps -> phases (0,1) and (1,1)
+    for (int set = 0; set < 3; ++set)
+    {
+        __syncthreads();
+        const double(*ck)[19] = (set == 2) ? T->tap_half : T->tap_int;
+        const int qmax = (set == 0) ? 8 : 9;
+        for (int item = threadIdx.x; item < LDS_H * TILE_W; item += 256)
+        {
+            const int r = item >> 5, c = item & 31;
+            double a0 = 0.0, a1 = 0.0;
+            for (int q = -qmax; q <= qmax; ++q)
+            {
+                const double v = tile[r][c + HALO - q];
+                a0 = __builtin_fma(v, ck[0][q + 9], a0);
+                a1 = __builtin_fma(v, ck[1][q + 9], a1);
+            }
+            R[0][r][c] = a0;
+            R[1][r][c] = a1;
+        }
+        __syncthreads();
+        const int nph = (set == 2) ? 2 : 1;
+        for (int ph = 0; ph < nph; ++ph)
+        {
+            const int sy = (set == 2) ? ph : set, sx = (set == 2) ? 1 : 0;
+            const double(*rk)[19] = sy ? T->tap_half : T->tap_int;
+            const int pmax = (set == 0) ? 8 : 9;
+            double fx = 0.0, fy = 0.0;
+            for (int p = -pmax; p <= pmax; ++p)
+            {
+                fx = __builtin_fma(R[1][ty + HALO - p][tx], rk[0][p + 9], fx); // Gx along x, G along y
+                fy = __builtin_fma(R[0][ty + HALO - p][tx], rk[1][p + 9], fy); // G along x, Gx along y
+            }
+            if (inside)
+            {
+                const size_t o = midx(2 * i + sy, 2 * j + sx, h, w);
+                maps[PL_IX * plane + o] = fx;
+                maps[PL_IY * plane + o] = fy;
+                maps[PL_MAG * plane + o] = sqrt(fx * fx + fy * fy);
+            }
+        }
+    }
+}
+
+// S2 ---------------------------------------------------------------------------------------
+// relaxed NMS on the screening planes: flag = 1 for every pixel the exact test could accept
+__global__ __launch_bounds__(256) void toed_screen_kernel(ImgBatch B, int h, int w)
+{
+    const int W2 = 2 * w, H2 = 2 * h;
+    const size_t plane = (size_t)H2 * W2;
+    const double *maps = B.maps[blockIdx.z];
+    const double *Ix = maps + PL_IX * plane, *Iy = maps + PL_IY * plane, *M = maps + PL_MAG * plane;
+    const int j = 10 + blockIdx.x * 64 + threadIdx.x;
+    const int i = 10 + blockIdx.y * 4 + threadIdx.y;
+    if (i >= H2 - 10) // wave-uniform
+        return;
+    int f = 0;
+    if (j < W2 - 10)
+    {
+        const size_t o = midx(i, j, h, w);
+        const double m = M[o];
+        if (m > 2.0 - SCREEN_TOL)
+        {
+            const double gx = Ix[o], gy = Iy[o], ax = fabs(gx), ay = fabs(gy);
+            if (ax < SCREEN_TOL || ay < SCREEN_TOL || fabs(ax - ay) < SCREEN_TOL)
+                f = 1; // the exact sector could differ from the screen's: let the exact stage decide
+            else
+            {
+                // same sector table as nms_core; slope in [0, 1]
+                int a1, b1, a2, b2;
+                double slope;
+                if (gx >= 0 && gy >= 0)
+                {
+                    if (gx >= gy) { slope = gy / gx; a1 = 0; b1 = 1; a2 = 1; b2 = 1; }
+                    else { slope = gx / gy; a1 = 1; b1 = 0; a2 = 1; b2 = 1; }
+                }
+                else if (gx < 0 && gy >= 0)
+                {
+                    if (ax < gy) { slope = -gx / gy; a1 = 1; b1 = 0; a2 = 1; b2 = -1; }
+                    else { slope = -gy / gx; a1 = 0; b1 = -1; a2 = 1; b2 = -1; }
+                }
+                else if (gx < 0 && gy < 0)
+                {
+                    if (ax >= ay) { slope = gy / gx; a1 = 0; b1 = -1; a2 = -1; b2 = -1; }
+                    else { slope = gx / gy; a1 = -1; b1 = 0; a2 = -1; b2 = -1; }
+                }
+                else
+                {
+                    if (gx < ay) { slope = -gx / gy; a1 = -1; b1 = 0; a2 = -1; b2 = 1; }
+                    else { slope = -gy / gx; a1 = 0; b1 = 1; a2 = -1; b2 = 1; }
+                }
+                const double fp = M[midx(i + a1, j + b1, h, w)] * (1 - slope) + M[midx(i + a2, j + b2, h, w)] * slope;
+                const double fm = M[midx(i - a1, j - b1, h, w)] * (1 - slope) + M[midx(i - a2, j - b2, h, w)] * slope;
+                if (m >= fm - SCREEN_TOL && m >= fp - SCREEN_TOL)
+                    f = 1;
+            }
+        }
+        B.flag[blockIdx.z][(size_t)i * W2 + j] = (uint8_t)f;
+    }
+    const unsigned long long any = __ballot(f != 0);
+    if (threadIdx.x == 0 && any)
+        atomicAdd(&B.row_cnt[blockIdx.z][i], __popcll(any));
+}
+
+// exact responses at input pixel (i, j), phase (sy, sx): the arithmetic of conv_body, tap tables in LDS
+// (the phase differs from lane to lane here).  Out-of-image samples enter as +0.0, like the zero-padded tile.
+__device__ inline void exact9(const uint8_t *__restrict__ img, int h, int w, const ToedTables &S, int i, int j, int sy,
+                              int sx, double f[9])
+{
+    const double(*ck)[19] = sx ? S.tap_half : S.tap_int;
+    const double(*rk)[19] = sy ? S.tap_half : S.tap_int;
+    const bool ip = !(sy | sx); // integer phase: 17 x 17, fx / fy from the pre-multiplied taps
+#pragma unroll
+    for (int r = 0; r < 9; ++r)
+        f[r] = 0.0;
+#pragma unroll 1
+    for (int p = -HALO; p <= HALO; ++p)
+    {
+        const int ii = i - p;
+        const bool rok = ii >= 0 && ii < h;
+        const uint8_t *__restrict__ rowp = img + (size_t)(rok ? ii : 0) * w;
+        const double r0 = rk[0][p + 9], r1 = rk[1][p + 9], r2 = rk[2][p + 9], r3 = rk[3][p + 9];
+        const bool pin = p >= -8 && p <= 8;
+#pragma unroll 1
+        for (int q = -HALO; q <= HALO; ++q)
+        {
+            const int jj = j - q;
+            const bool ok = rok && jj >= 0 && jj < w;
+            const double v = ok ? (double)rowp[jj] : 0.0;
+            const bool in17 = pin && q >= -8 && q <= 8;
+            if (ip && !in17)
+                continue;
+            const double c0 = v * ck[0][q + 9], c1 = v * ck[1][q + 9], c2 = v * ck[2][q + 9], c3 = v * ck[3][q + 9];
+            double t0, t1;
+            if (ip)
+            {
+                t0 = v * S.prod_fx[p + 8][q + 8];
+                t1 = v * S.prod_fy[p + 8][q + 8];
+            }
+            else
+            {
+                t0 = c1 * r0;
+                t1 = c0 * r1;
+            }
+            f[0] += t0;
+            f[1] += t1;
+            f[2] += c2 * r0;
+            f[3] += c1 * r1;
+            f[4] += c0 * r2;
+            f[5] += c2 * r1;
+            f[6] += c1 * r2;
+            f[7] += c3 * r0;
+            f[8] += c0 * r3;
+        }
+    }
+}
+
+// the gradient magnitude only (fx, fy) -- what NMS needs from a neighbour
+__device__ inline double exact_mag(const uint8_t *__restrict__ img, int h, int w, const ToedTables &S, int I, int J)
+{
+    const int i = I >> 1, j = J >> 1, sy = I & 1, sx = J & 1;
+    const double(*ck)[19] = sx ? S.tap_half : S.tap_int;
+    const double(*rk)[19] = sy ? S.tap_half : S.tap_int;
+    const bool ip = !(sy | sx);
+    double fx = 0.0, fy = 0.0;
+#pragma unroll 1
+    for (int p = -HALO; p <= HALO; ++p)
+    {
+        const int ii = i - p;
+        const bool rok = ii >= 0 && ii < h;
+        const uint8_t *__restrict__ rowp = img + (size_t)(rok ? ii : 0) * w;
+        const double r0 = rk[0][p + 9], r1 = rk[1][p + 9];
+        const bool pin = p >= -8 && p <= 8;
+#pragma unroll 1
+        for (int q = -HALO; q <= HALO; ++q)
+        {
+            const int jj = j - q;
+            const bool ok = rok && jj >= 0 && jj < w;
+            const double v = ok ? (double)rowp[jj] : 0.0;
+            const bool in17 = pin && q >= -8 && q <= 8;
+            if (ip && !in17)
+                continue;
+            double t0, t1;
+            if (ip)
+            {
+                t0 = v * S.prod_fx[p + 8][q + 8];
+                t1 = v * S.prod_fy[p + 8][q + 8];
+            }
+            else
+            {
+                t0 = (v * ck[1][q + 9]) * r0;
+                t1 = (v * ck[0][q + 9]) * r1;
+            }
+            fx += t0;
+            fy += t1;
+        }
+    }
+    return sqrt(fx * fx + fy * fy);
+}
+
+// S3 ---------------------------------------------------------------------------------------
+// exact evaluation + exact NMS decision of every screened candidate (grid-stride; count in device memory)
+__global__ __launch_bounds__(256) void toed_exact_kernel(ImgBatch B, const ToedTables *__restrict__ T, int h, int w,
+                                                         int cap)
+{
+    __shared__ ToedTables S;
+    {
+        const double *src = reinterpret_cast<const double *>(T);
+        double *dst = reinterpret_cast<double *>(&S);
+        for (int t = threadIdx.x; t < (int)(sizeof(ToedTables) / sizeof(double)); t += 256)
+            dst[t] = src[t];
+    }
+    __syncthreads();
+    const int W2 = 2 * w;
+    const uint8_t *__restrict__ img = B.img[blockIdx.y];
+    const int32_t *__restrict__ srcl = B.src[blockIdx.y];
+    CandRec *__restrict__ rec = B.rec[blockIdx.y];
+    int32_t *__restrict__ ft = B.cand_flag[blockIdx.y], *__restrict__ fk = ft + cap;
+    const int n = min(B.counts[blockIdx.y][2], cap);
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x)
+    {
+        const int o = srcl[2 * t];
+        const int I = o / W2, J = o - I * W2;
+        double f[9];
+        exact9(img, h, w, S, I >> 1, J >> 1, I & 1, J & 1, f);
+        const double gx = f[0], gy = f[1];
+        const double m = sqrt(gx * gx + gy * gy); // src/toed/cpu_toed.cpp:222
+        double px = 0, py = 0, sm = 0;
+        const bool is_max =
+            nms_core(m, gx, gy, I, J, [&](int di, int dj) { return exact_mag(img, h, w, S, I + di, J + dj); }, px, py, sm);
+        int kept = 0;
+        CandRec r;
+        r.x = r.y = r.smag = r.tox = r.toy = 0.0;
+        if (is_max)
+        {
+            r.x = (px - 1) / 2; // :538,542
+            r.y = (py - 1) / 2;
+            r.smag = sm;
+            third_order_dir(f, r.tox, r.toy);
+            kept = (r.x > 10 && r.x < w - 10 && r.y > 10 && r.y < h - 10) ? 1 : 0; // :553-554
+        }
+        rec[t] = r;
+        ft[t] = is_max ? 1 : 0;
+        fk[t] = kept;
+    }
+}
+
+// S4 ---------------------------------------------------------------------------------------
+// write the edge records at their scanned ranks (raster order is the candidate order)
+__global__ __launch_bounds__(256) void toed_cand_scatter_kernel(ImgBatch B, int cap)
+{
+    const CandRec *__restrict__ rec = B.rec[blockIdx.y];
+    const int32_t *__restrict__ ft = B.cand_flag[blockIdx.y], *__restrict__ fk = ft + cap;
+    const int32_t *__restrict__ ot = B.cand_off[blockIdx.y], *__restrict__ ok = ot + (cap + 1);
+    ebvo_edge *__restrict__ edges = B.edges[blockIdx.y];
+    double *__restrict__ all4 = B.all4[blockIdx.y];
+    int32_t *counts = B.counts[blockIdx.y];
+    const int n = min(counts[2], cap);
+    if (n == 0 && blockIdx.x == 0 && threadIdx.x == 0)
+    {
+        counts[0] = 0;
+        counts[1] = 0;
+    }
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x)
+    {
+        if (t == n - 1)
+        {
+            counts[0] = ot[t] + ft[t]; // Total_Num_Of_TOED
+            counts[1] = ok[t] + fk[t]; // toed_edges.size()
+        }
+        if (!ft[t])
+            continue;
+        const CandRec r = rec[t];
+        double TO_Ix = r.tox, TO_Iy = r.toy; // src/toed/cpu_toed.cpp:226-229
+        const double TO_mag = sqrt(TO_Ix * TO_Ix + TO_Iy * TO_Iy);
+        TO_Ix /= TO_mag;
+        TO_Iy /= TO_mag;
+        const double th = ebvo_atan2(TO_Ix, -TO_Iy);
+        const int ra = ot[t];
+        all4[(size_t)ra * 4 + 0] = r.x;
+        all4[(size_t)ra * 4 + 1] = r.y;
+        all4[(size_t)ra * 4 + 2] = th;
+        all4[(size_t)ra * 4 + 3] = r.smag;
+        if (fk[t])
+        {
+            ebvo_edge e;
+            e.x = r.x;
+            e.y = r.y;
+            e.theta = th;
+            e.index = ok[t];
+            e.pad = 0;
+            edges[e.index] = e;
+        }
+    }
+}
+
 } // namespace
 
 int toed_init_constants(ebvo_ctx *ctx)
@@ -536,7 +889,59 @@ int toed_enqueue(ebvo_ctx *ctx, Slot &s, int n_img, int h, int w, hipEvent_t ev_
         B.src[k] = ws.src;
         B.edges[k] = ws.edges;
         B.all4[k] = ws.all4;
+        B.rec[k] = (CandRec *)ws.cand_rec;
+        B.cand_flag[k] = ws.cand_flag;
+        B.cand_off[k] = ws.cand_off;
         EBVO_HIP(ctx, hipMemsetAsync(ws.row_cnt, 0, sizeof(int32_t) * 2 * H2, s.stream));
+    }
+    if (ctx->toed_mode == EBVO_TOED_HYBRID)
+    {
+        const int cap = ctx->cap_edges;
+        const dim3 tiles((w + TILE_W - 1) / TILE_W, (h + TILE_H - 1) / TILE_H, n_img);
+        const dim3 nmsgrid((W2 - 20 + 63) / 64, (H2 - 20 + 3) / 4, n_img);
+        if (ev_conv_begin)
+            EBVO_HIP(ctx, hipEventRecord(ev_conv_begin, s.stream));
+        {
+            ProfScope ps(ctx, s, K_CONV);
+            hipLaunchKernelGGL(toed_sep_kernel, tiles, dim3(256), 0, s.stream, B,
+                               (const ToedTables *)g_tables_dev[ctx->device], h, w);
+        }
+        {
+            ProfScope ps(ctx, s, K_NMS);
+            hipLaunchKernelGGL(toed_screen_kernel, nmsgrid, dim3(64, 4), 0, s.stream, B, h, w);
+        }
+        {
+            ProfScope ps(ctx, s, K_ROWSCAN);
+            hipLaunchKernelGGL(toed_rowscan_kernel, dim3(n_img), dim3(64), 0, s.stream, B, H2, 2);
+        }
+        {
+            ProfScope ps(ctx, s, K_COMPACT);
+            hipLaunchKernelGGL(toed_compact_kernel, dim3(H2 - 20, n_img), dim3(256), 0, s.stream, B, h, w, cap);
+        }
+        {
+            ProfScope ps(ctx, s, K_EXACT);
+            hipLaunchKernelGGL(toed_exact_kernel, dim3(1024, n_img), dim3(256), 0, s.stream, B,
+                               (const ToedTables *)g_tables_dev[ctx->device], h, w, cap);
+        }
+        if (ev_conv_end)
+            EBVO_HIP(ctx, hipEventRecord(ev_conv_end, s.stream));
+        for (int k = 0; k < n_img; ++k)
+        {
+            const int32_t *d_n = s.im[k].counts + 2;
+            int rc;
+            if ((rc = ebvo_device_scan(ctx, s, s.im[k].cand_flag, s.im[k].cand_off, 0, d_n, 0, cap)))
+                return rc;
+            if ((rc = ebvo_device_scan(ctx, s, s.im[k].cand_flag + cap, s.im[k].cand_off + (cap + 1), 0, d_n, 0, cap)))
+                return rc;
+        }
+        {
+            ProfScope ps(ctx, s, K_FINALIZE);
+            hipLaunchKernelGGL(toed_cand_scatter_kernel, dim3(512, n_img), dim3(256), 0, s.stream, B, cap);
+        }
+        if (ev_end)
+            EBVO_HIP(ctx, hipEventRecord(ev_end, s.stream));
+        EBVO_HIP(ctx, hipGetLastError());
+        return EBVO_OK;
     }
     if (ev_conv_begin)
         EBVO_HIP(ctx, hipEventRecord(ev_conv_begin, s.stream));
@@ -555,7 +960,7 @@ int toed_enqueue(ebvo_ctx *ctx, Slot &s, int n_img, int h, int w, hipEvent_t ev_
     }
     {
         ProfScope ps(ctx, s, K_ROWSCAN);
-        hipLaunchKernelGGL(toed_rowscan_kernel, dim3(n_img), dim3(64), 0, s.stream, B, H2);
+        hipLaunchKernelGGL(toed_rowscan_kernel, dim3(n_img), dim3(64), 0, s.stream, B, H2, 0);
     }
     {
         ProfScope ps(ctx, s, K_COMPACT);

@@ -82,6 +82,20 @@ int ebvo_abi_version(void);
 int ebvo_ctx_create(int device, int max_h, int max_w, ebvo_ctx **out);
 void ebvo_ctx_destroy(ebvo_ctx *ctx);
 
+/* How the third-order detector reaches its (identical) result:
+ *   EBVO_TOED_STRICT  the reference's direct-form convolution at every pixel (27.6 k fp64 operations per pixel);
+ *   EBVO_TOED_HYBRID  a separable fp64 screen selects a superset of the NMS maxima (tolerance 1e-6, five orders of
+ *                     magnitude above the screen's error), and only those pixels are evaluated in the reference's
+ *                     exact arithmetic.  Same bits out, ~3x less work; see toed_kernels.hip.
+ * The default is EBVO_TOED_STRICT unless the environment variable EBVO_TOED_MODE is "hybrid". */
+enum
+{
+    EBVO_TOED_STRICT = 0,
+    EBVO_TOED_HYBRID = 1
+};
+int ebvo_set_toed_mode(ebvo_ctx *ctx, int mode);
+int ebvo_get_toed_mode(const ebvo_ctx *ctx);
+
 /*
  * Replaces ThirdOrderEdgeDetectionCPU::get_Third_Order_Edges(cv::Mat)
  * (src/toed/cpu_toed.cpp:66-77: preprocessing + convolve_img + non_maximum_suppresion), called

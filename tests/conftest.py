@@ -18,10 +18,11 @@ def oracle():
     return orc
 
 
-@pytest.fixture(scope="session")
-def ctx():
-    """One HIP context for the whole GPU session, sized for the largest test image."""
+@pytest.fixture(scope="session", params=["strict", "hybrid"])
+def ctx(request):
+    """One HIP context per TOED mode for the whole GPU session, sized for the largest test image.
+    Every GPU parity test runs in both modes: the hybrid detector must be bit-identical too."""
     from edge_based_visual_odometry_amd.api import Context
-    c = Context(max_h=512, max_w=1280, device=0)
+    c = Context(max_h=512, max_w=1280, device=0, toed_mode=request.param)
     yield c
     c.close()
