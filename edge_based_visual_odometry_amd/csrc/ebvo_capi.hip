@@ -119,7 +119,7 @@ static void slot_destroy(Slot *s)
     for (int k = 0; k < 2; ++k)
     {
         ImageWS &ws = s->im[k];
-        (void)hipFree(ws.img);
+        (void)hipFree(ws.img_base);
         (void)hipFree(ws.maps);
         (void)hipFree(ws.flag);
         (void)hipFree(ws.row_cnt);
@@ -131,6 +131,10 @@ static void slot_destroy(Slot *s)
         (void)hipFree(ws.cand_rec);
         (void)hipFree(ws.cand_flag);
         (void)hipFree(ws.cand_off);
+        (void)hipFree(ws.cand_data);
+        (void)hipFree(ws.cand_sector);
+        (void)hipFree(ws.cand_lists);
+        (void)hipFree(ws.cand_lcount);
     }
     GrowBuf *bufs[] = {&s->lines,        &s->boxes_chunk,  &s->boxes_group,    &s->cand_cnt,       &s->row_ptr,
                        &s->scan_tmp,     &s->col_idx,      &s->rc_edges,       &s->sims,           &s->best,
@@ -172,7 +176,9 @@ static int slot_create(ebvo_ctx *ctx, Slot **out)
     for (int k = 0; k < 2; ++k)
     {
         ImageWS &ws = s->im[k];
-        CK(hipMalloc(&ws.img, (size_t)ctx->max_h * ctx->max_w));
+        CK(hipMalloc(&ws.img_base, (size_t)ctx->max_h * ctx->max_w + 128));
+        CK(hipMemset(ws.img_base, 0, (size_t)ctx->max_h * ctx->max_w + 128));
+        ws.img = ws.img_base + 64;
         CK(hipMalloc(&ws.maps, sizeof(double) * np2 * PL_NUM));
         CK(hipMalloc(&ws.flag, np2));
         CK(hipMalloc(&ws.row_cnt, sizeof(int32_t) * 2 * H2));
@@ -182,6 +188,10 @@ static int slot_create(ebvo_ctx *ctx, Slot **out)
         CK(hipMalloc(&ws.cand_rec, 40 * (size_t)ctx->cap_edges));
         CK(hipMalloc(&ws.cand_flag, sizeof(int32_t) * 2 * (size_t)ctx->cap_edges));
         CK(hipMalloc(&ws.cand_off, sizeof(int32_t) * 2 * ((size_t)ctx->cap_edges + 1)));
+        CK(hipMalloc(&ws.cand_data, sizeof(double) * 9 * (size_t)ctx->cap_edges));
+        CK(hipMalloc(&ws.cand_sector, sizeof(int32_t) * (size_t)ctx->cap_edges));
+        CK(hipMalloc(&ws.cand_lists, sizeof(int32_t) * 12 * (size_t)ctx->cap_edges));
+        CK(hipMalloc(&ws.cand_lcount, sizeof(int32_t) * 12));
         CK(hipMalloc(&ws.src, sizeof(int32_t) * 2 * (size_t)ctx->cap_edges));
         CK(hipMalloc(&ws.edges, sizeof(ebvo_edge) * (size_t)ctx->cap_edges));
         CK(hipMalloc(&ws.all4, sizeof(double) * 4 * (size_t)ctx->cap_edges));

@@ -55,7 +55,8 @@ struct GrowBuf
 // Per-image device workspace.
 struct ImageWS
 {
-    uint8_t *img = nullptr;     // h*w, tightly packed
+    uint8_t *img = nullptr;     // h*w, tightly packed; = img_base + 64: 64 readable bytes before and after (wide loads)
+    uint8_t *img_base = nullptr;
     double *maps = nullptr;     // PL_NUM planes of 4 x H x W
     uint8_t *flag = nullptr;    // 2H x 2W: 0 none, 1 NMS maximum, 3 maximum inside the 10-px border
     int32_t *row_cnt = nullptr; // [2][H2]   per interpolated row: all maxima, kept maxima
@@ -67,6 +68,10 @@ struct ImageWS
     void *cand_rec = nullptr;       // hybrid TOED: [cap] exact records of the screened candidates
     int32_t *cand_flag = nullptr;   // [2][cap]   is-maximum / is-kept flags per candidate
     int32_t *cand_off = nullptr;    // [2][cap+1] exclusive scans of the flags
+    double *cand_data = nullptr;    // [9][cap] exact gx, gy, |g|, TOx, TOy and the four neighbour magnitudes
+    int32_t *cand_sector = nullptr; // [cap] packed NMS sector, -1 if rejected early
+    int32_t *cand_lists = nullptr;  // [12][cap] candidate indices by phase (4) and by (phase, axis) (8)
+    int32_t *cand_lcount = nullptr; // [12]
     int n_total = 0, n_kept = 0; // host copies, valid after a synchronising call
 };
 

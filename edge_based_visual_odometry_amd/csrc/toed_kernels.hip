@@ -281,18 +281,22 @@ __global__ __launch_bounds__(256) void toed_conv_kernel(ImgBatch B, const ToedTa
         conv_body<0>(tile, T, maps, h, w, i, j, ty, tx);
 }
 
-// NMS + parabola fit at interpolated pixel (i, j): src/toed/cpu_toed.cpp:406-511.
-// m, gx, gy: magnitude and gradient at the pixel; mag_at(di, dj): magnitude of a neighbour.
-template <class MagAt>
-__device__ inline bool nms_core(double m, double gx, double gy, int i, int j, MagAt mag_at, double &pos_x,
-                                double &pos_y, double &smag)
+// NMS + parabola fit at interpolated pixel (i, j): src/toed/cpu_toed.cpp:406-511, in two steps.
+// Step 1 (:406-477): early rejects, unit gradient, the sector's neighbour offsets -- (a1, b1) the axis
+// neighbour and (a2, b2) the diagonal neighbour on the plus side, the minus side negates both -- and slope.
+struct NmsSector
+{
+    double nx, ny, slope;
+    int a1, b1, a2, b2;
+};
+
+__device__ inline bool nms_sector(double m, double gx, double gy, NmsSector &S)
 {
     if (m <= 2) // :406
         return false;
     if (fabs(gx) < 10e-6 && fabs(gy) < 10e-6) // :410
         return false;
     const double nx = gx / m, ny = gy / m;
-    // sector -> (di, dj) of the axis neighbour and of the diagonal neighbour on the plus side
     int a1, b1, a2, b2;
     double slope;
     if (gx >= 0 && gy >= 0)
@@ -317,8 +321,18 @@ __device__ inline bool nms_core(double m, double gx, double gy, int i, int j, Ma
     }
     else
         return false;
-    const double fp = mag_at(a1, b1) * (1 - slope) + mag_at(a2, b2) * slope;
-    const double fm = mag_at(-a1, -b1) * (1 - slope) + mag_at(-a2, -b2) * slope;
+    S.nx = nx; S.ny = ny; S.slope = slope;
+    S.a1 = a1; S.b1 = b1; S.a2 = a2; S.b2 = b2;
+    return true;
+}
+
+// Step 2 (:423-511): the four neighbour magnitudes in the order (a1,b1), (a2,b2), (-a1,-b1), (-a2,-b2).
+__device__ inline bool nms_finish(double m, const NmsSector &S, int i, int j, double m_p1, double m_p2, double m_m1,
+                                  double m_m2, double &pos_x, double &pos_y, double &smag)
+{
+    const double slope = S.slope, nx = S.nx, ny = S.ny;
+    const double fp = m_p1 * (1 - slope) + m_p2 * slope;
+    const double fm = m_m1 * (1 - slope) + m_m2 * slope;
     const double s = sqrt(1 + slope * slope);
     if (!((m > fm && m > fp) || (m > fm && m >= fp) || (m >= fm && m > fp))) // :481-483
         return false;
@@ -334,6 +348,18 @@ __device__ inline bool nms_core(double m, double gx, double gy, int i, int j, Ma
     pos_x = j + s_star * nx;
     pos_y = i + s_star * ny;
     return true;
+}
+
+template <class MagAt>
+__device__ inline bool nms_core(double m, double gx, double gy, int i, int j, MagAt mag_at, double &pos_x,
+                                double &pos_y, double &smag)
+{
+    NmsSector S;
+    if (!nms_sector(m, gx, gy, S))
+        return false;
+    const double m_p1 = mag_at(S.a1, S.b1), m_p2 = mag_at(S.a2, S.b2);
+    const double m_m1 = mag_at(-S.a1, -S.b1), m_m2 = mag_at(-S.a2, -S.b2);
+    return nms_finish(m, S, i, j, m_p1, m_p2, m_m1, m_m2, pos_x, pos_y, smag);
 }
 
 __device__ inline bool nms_eval(const double *__restrict__ Ix, const double *__restrict__ Iy,
@@ -653,141 +679,336 @@ __global__ __launch_bounds__(256) void toed_screen_kernel(ImgBatch B, int h, int
         atomicAdd(&B.row_cnt[blockIdx.z][i], __popcll(any));
 }
 
-// exact responses at input pixel (i, j), phase (sy, sx): the arithmetic of conv_body, tap tables in LDS
-// (the phase differs from lane to lane here).  Out-of-image samples enter as +0.0, like the zero-padded tile.
-__device__ inline void exact9(const uint8_t *__restrict__ img, int h, int w, const ToedTables &S, int i, int j, int sy,
-                              int sx, double f[9])
+// ---- exact stage -------------------------------------------------------------------------------------------
+// Candidates are bucketed by sub-pixel phase so that every wave works on ONE phase: the taps are scalar
+// operands again (no per-lane table look-ups, no divergence between the integer phase and the others), and
+// the 19 pixels of a tap row are fetched together (19 independent byte loads in flight per lane).
+struct CandData // structure of arrays, one entry per candidate, [cap] each
 {
-    const double(*ck)[19] = sx ? S.tap_half : S.tap_int;
-    const double(*rk)[19] = sy ? S.tap_half : S.tap_int;
-    const bool ip = !(sy | sx); // integer phase: 17 x 17, fx / fy from the pre-multiplied taps
+    double *gx, *gy, *m, *tox, *toy, *mag; // mag: [4][cap] neighbour magnitudes (p1, p2, m1, m2)
+    int32_t *sector;                       // packed (a1+1) | (b1+1)<<2 | (a2+1)<<4 | (b2+1)<<6, or -1 if rejected early
+};
+
+struct ExactBatch
+{
+    const uint8_t *img[MAX_BATCH];
+    const int32_t *src[MAX_BATCH];
+    const int32_t *counts[MAX_BATCH];
+    int32_t *lists[MAX_BATCH];   // [12][cap]: 0-3 candidates by phase; 4-11 candidates by (phase, axis)
+    int32_t *lcount[MAX_BATCH];  // [12]
+    CandData cd[MAX_BATCH];
+    CandRec *rec[MAX_BATCH];
+    int32_t *cand_flag[MAX_BATCH];
+};
+
+// append `value` to list `which` for the lanes with `put`, one atomic per block; returns nothing.
+// All 256 threads of the block must call it.
+__device__ inline void block_append(bool put, int value, int32_t *__restrict__ list, int32_t *__restrict__ counter,
+                                    int *s_cnt /* [5] shared */)
+{
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const unsigned long long m = __ballot(put);
+    if (lane == 0)
+        s_cnt[wid] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        const int tot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        s_cnt[4] = tot ? atomicAdd(counter, tot) : 0;
+    }
+    __syncthreads();
+    if (put)
+    {
+        int pre = 0;
+        for (int k = 0; k < wid; ++k)
+            pre += s_cnt[k];
+        list[s_cnt[4] + pre + __popcll(m & ((1ull << lane) - 1ull))] = value;
+    }
+    __syncthreads();
+}
+
+// S3a: candidates -> four lists by phase
+__global__ __launch_bounds__(256) void toed_split_phase_kernel(ExactBatch E, int w, int cap)
+{
+    __shared__ int s_cnt[5];
+    const int im = blockIdx.y, W2 = 2 * w;
+    const int n = min(E.counts[im][2], cap);
+    for (int base = blockIdx.x * 256; base < n; base += gridDim.x * 256)
+    {
+        const int t = base + threadIdx.x;
+        int ph = -1;
+        if (t < n)
+        {
+            const int o = E.src[im][2 * t];
+            const int I = o / W2, J = o - I * W2;
+            ph = ((I & 1) << 1) | (J & 1);
+        }
+        for (int k = 0; k < 4; ++k)
+            block_append(ph == k, t, E.lists[im] + (size_t)k * cap, E.lcount[im] + k, s_cnt);
+    }
+}
+
+// 19 pixels of image row ii around column j, v[q + 9] = img(ii, j - q), +0.0 outside the image.
+// The 19 bytes are fetched with three unaligned 8-byte loads (scattered single-byte loads cost one L1 look-up
+// per lane and made this stage texture-address bound).  The image buffer has 64 readable bytes on either side,
+// so the loads are always in bounds; bytes that fall outside the row are masked to zero.
+struct Row24
+{
+    unsigned long long w0, w1, w2;
+};
+
+__device__ inline Row24 fetch_row(const uint8_t *__restrict__ img, int h, int w, int ii, int j)
+{
+    const int ic = min(max(ii, 0), h - 1);
+    const uint8_t *p = img + (size_t)ic * w + (j - HALO);
+    Row24 r;
+    __builtin_memcpy(&r.w0, p, 8);
+    __builtin_memcpy(&r.w1, p + 8, 8);
+    __builtin_memcpy(&r.w2, p + 16, 8);
+    return r;
+}
+
+__device__ inline void unpack_row(const Row24 &r, int h, int w, int ii, int j, int v[19])
+{
+    const bool rok = ii >= 0 && ii < h;
+#pragma unroll
+    for (int k = 0; k < 19; ++k)
+    {
+        // byte k of the run is column j - 9 + k, i.e. tap q = 9 - k
+        const unsigned long long word = k < 8 ? r.w0 : (k < 16 ? r.w1 : r.w2);
+        const int b = (int)((word >> (8 * (k & 7))) & 0xffull);
+        const int col = j - HALO + k;
+        v[18 - k] = (rok && col >= 0 && col < w) ? b : 0;
+    }
+}
+
+// all nine responses at input pixel (i, j) for the compile-time phase (SY, SX): conv_body's arithmetic
+template <int SY, int SX>
+__device__ inline void exact9(const uint8_t *__restrict__ img, int h, int w, const ToedTables *__restrict__ T, int i,
+                              int j, double f[9])
+{
+    constexpr bool IP = (SY == 0 && SX == 0);
+    const double(*ck)[19] = SX ? T->tap_half : T->tap_int;
+    const double(*rk)[19] = SY ? T->tap_half : T->tap_int;
 #pragma unroll
     for (int r = 0; r < 9; ++r)
         f[r] = 0.0;
+    constexpr int PM = IP ? 8 : 9;
+    Row24 nxt = fetch_row(img, h, w, i + PM, j);
 #pragma unroll 1
-    for (int p = -HALO; p <= HALO; ++p)
+    for (int p = -PM; p <= PM; ++p)
     {
-        const int ii = i - p;
-        const bool rok = ii >= 0 && ii < h;
-        const uint8_t *__restrict__ rowp = img + (size_t)(rok ? ii : 0) * w;
-        const double r0 = rk[0][p + 9], r1 = rk[1][p + 9], r2 = rk[2][p + 9], r3 = rk[3][p + 9];
-        const bool pin = p >= -8 && p <= 8;
-#pragma unroll 1
-        for (int q = -HALO; q <= HALO; ++q)
+        const Row24 cur = nxt;
+        nxt = fetch_row(img, h, w, i - min(p + 1, PM), j); // next row in flight while this one is accumulated
+        int vb[19];
+        unpack_row(cur, h, w, i - p, j, vb);
+        double rr[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+            rr[d] = rk[d][p + 9];
+#pragma unroll
+        for (int q = -PM; q <= PM; ++q)
         {
-            const int jj = j - q;
-            const bool ok = rok && jj >= 0 && jj < w;
-            const double v = ok ? (double)rowp[jj] : 0.0;
-            const bool in17 = pin && q >= -8 && q <= 8;
-            if (ip && !in17)
-                continue;
-            const double c0 = v * ck[0][q + 9], c1 = v * ck[1][q + 9], c2 = v * ck[2][q + 9], c3 = v * ck[3][q + 9];
-            double t0, t1;
-            if (ip)
+            const double v = (double)vb[q + 9];
+            double cc[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+                cc[d] = v * ck[d][q + 9];
+            if (IP)
             {
-                t0 = v * S.prod_fx[p + 8][q + 8];
-                t1 = v * S.prod_fy[p + 8][q + 8];
+                f[0] += v * T->prod_fx[p + 8][q + 8];
+                f[1] += v * T->prod_fy[p + 8][q + 8];
+                f[2] += cc[2] * rr[0];
+                f[3] += cc[1] * rr[1];
+                f[4] += cc[0] * rr[2];
+                f[5] += cc[2] * rr[1];
+                f[6] += cc[1] * rr[2];
+                f[7] += cc[3] * rr[0];
+                f[8] += cc[0] * rr[3];
             }
             else
             {
-                t0 = c1 * r0;
-                t1 = c0 * r1;
+                EBVO_ACCUM9(f, cc, rr)
             }
-            f[0] += t0;
-            f[1] += t1;
-            f[2] += c2 * r0;
-            f[3] += c1 * r1;
-            f[4] += c0 * r2;
-            f[5] += c2 * r1;
-            f[6] += c1 * r2;
-            f[7] += c3 * r0;
-            f[8] += c0 * r3;
         }
     }
 }
 
-// the gradient magnitude only (fx, fy) -- what NMS needs from a neighbour
-__device__ inline double exact_mag(const uint8_t *__restrict__ img, int h, int w, const ToedTables &S, int I, int J)
+// gradient magnitude (fx, fy only) at interpolated pixel (I, J) of compile-time phase (SY, SX)
+template <int SY, int SX>
+__device__ inline double exact_mag(const uint8_t *__restrict__ img, int h, int w, const ToedTables *__restrict__ T,
+                                   int I, int J)
 {
-    const int i = I >> 1, j = J >> 1, sy = I & 1, sx = J & 1;
-    const double(*ck)[19] = sx ? S.tap_half : S.tap_int;
-    const double(*rk)[19] = sy ? S.tap_half : S.tap_int;
-    const bool ip = !(sy | sx);
+    constexpr bool IP = (SY == 0 && SX == 0);
+    const int i = I >> 1, j = J >> 1;
+    const double(*ck)[19] = SX ? T->tap_half : T->tap_int;
+    const double(*rk)[19] = SY ? T->tap_half : T->tap_int;
     double fx = 0.0, fy = 0.0;
+    constexpr int PM = IP ? 8 : 9;
+    Row24 nxt = fetch_row(img, h, w, i + PM, j);
 #pragma unroll 1
-    for (int p = -HALO; p <= HALO; ++p)
+    for (int p = -PM; p <= PM; ++p)
     {
-        const int ii = i - p;
-        const bool rok = ii >= 0 && ii < h;
-        const uint8_t *__restrict__ rowp = img + (size_t)(rok ? ii : 0) * w;
+        const Row24 cur = nxt;
+        nxt = fetch_row(img, h, w, i - min(p + 1, PM), j);
+        int vb[19];
+        unpack_row(cur, h, w, i - p, j, vb);
         const double r0 = rk[0][p + 9], r1 = rk[1][p + 9];
-        const bool pin = p >= -8 && p <= 8;
-#pragma unroll 1
-        for (int q = -HALO; q <= HALO; ++q)
+#pragma unroll
+        for (int q = -PM; q <= PM; ++q)
         {
-            const int jj = j - q;
-            const bool ok = rok && jj >= 0 && jj < w;
-            const double v = ok ? (double)rowp[jj] : 0.0;
-            const bool in17 = pin && q >= -8 && q <= 8;
-            if (ip && !in17)
-                continue;
-            double t0, t1;
-            if (ip)
+            const double v = (double)vb[q + 9];
+            if (IP)
             {
-                t0 = v * S.prod_fx[p + 8][q + 8];
-                t1 = v * S.prod_fy[p + 8][q + 8];
+                fx += v * T->prod_fx[p + 8][q + 8];
+                fy += v * T->prod_fy[p + 8][q + 8];
             }
             else
             {
-                t0 = (v * ck[1][q + 9]) * r0;
-                t1 = (v * ck[0][q + 9]) * r1;
+                fx += (v * ck[1][q + 9]) * r0;
+                fy += (v * ck[0][q + 9]) * r1;
             }
-            fx += t0;
-            fy += t1;
         }
     }
     return sqrt(fx * fx + fy * fy);
 }
 
-// S3 ---------------------------------------------------------------------------------------
-// exact evaluation + exact NMS decision of every screened candidate (grid-stride; count in device memory)
-__global__ __launch_bounds__(256) void toed_exact_kernel(ImgBatch B, const ToedTables *__restrict__ T, int h, int w,
-                                                         int cap)
+// S3b: exact centre of every candidate of one phase; early NMS rejects; bucket by (phase, axis)
+template <int SY, int SX>
+__device__ inline void centre_phase(const ExactBatch &E, const ToedTables *__restrict__ T, int h, int w, int cap,
+                                    int *s_cnt)
 {
-    __shared__ ToedTables S;
+    const int im = blockIdx.y, W2 = 2 * w;
+    constexpr int PH = (SY << 1) | SX;
+    const int32_t *__restrict__ list = E.lists[im] + (size_t)PH * cap;
+    const int n = min(E.lcount[im][PH], cap);
+    const CandData &cd = E.cd[im];
+    for (int base = blockIdx.x * 256; base < n; base += gridDim.x * 256)
     {
-        const double *src = reinterpret_cast<const double *>(T);
-        double *dst = reinterpret_cast<double *>(&S);
-        for (int t = threadIdx.x; t < (int)(sizeof(ToedTables) / sizeof(double)); t += 256)
-            dst[t] = src[t];
+        const int k = base + threadIdx.x;
+        int axis = -1, t = 0;
+        if (k < n)
+        {
+            t = list[k];
+            const int o = E.src[im][2 * t];
+            const int I = o / W2, J = o - I * W2;
+            double f[9];
+            exact9<SY, SX>(E.img[im], h, w, T, I >> 1, J >> 1, f);
+            const double gx = f[0], gy = f[1];
+            const double m = sqrt(gx * gx + gy * gy); // src/toed/cpu_toed.cpp:222
+            NmsSector S;
+            int packed = -1;
+            if (nms_sector(m, gx, gy, S))
+            {
+                packed = (S.a1 + 1) | ((S.b1 + 1) << 2) | ((S.a2 + 1) << 4) | ((S.b2 + 1) << 6);
+                axis = (S.a1 == 0) ? 0 : 1; // 0: axis neighbour along x (horizontal), 1: along y
+            }
+            cd.gx[t] = gx;
+            cd.gy[t] = gy;
+            cd.m[t] = m;
+            third_order_dir(f, cd.tox[t], cd.toy[t]);
+            cd.sector[t] = packed;
+        }
+        for (int a = 0; a < 2; ++a)
+        {
+            const int cls = 4 + PH * 2 + a;
+            block_append(axis == a, t, E.lists[im] + (size_t)cls * cap, E.lcount[im] + cls, s_cnt);
+        }
     }
-    __syncthreads();
-    const int W2 = 2 * w;
-    const uint8_t *__restrict__ img = B.img[blockIdx.y];
-    const int32_t *__restrict__ srcl = B.src[blockIdx.y];
-    CandRec *__restrict__ rec = B.rec[blockIdx.y];
-    int32_t *__restrict__ ft = B.cand_flag[blockIdx.y], *__restrict__ fk = ft + cap;
-    const int n = min(B.counts[blockIdx.y][2], cap);
+}
+
+__global__ __launch_bounds__(256) void toed_exact_centre_kernel(ExactBatch E, const ToedTables *__restrict__ T, int h,
+                                                                int w, int cap)
+{
+    __shared__ int s_cnt[5];
+    switch (blockIdx.z)
+    {
+    case 0: centre_phase<0, 0>(E, T, h, w, cap, s_cnt); break;
+    case 1: centre_phase<0, 1>(E, T, h, w, cap, s_cnt); break;
+    case 2: centre_phase<1, 0>(E, T, h, w, cap, s_cnt); break;
+    default: centre_phase<1, 1>(E, T, h, w, cap, s_cnt); break;
+    }
+}
+
+// S3c: the four neighbour magnitudes of every candidate of one (phase, axis) class.  The axis neighbours
+// (+-a1, +-b1) share one phase, the diagonal neighbours (+-a2, +-b2) the opposite phase (SY^1, SX^1);
+// PAIR selects which two a thread evaluates, so a launch slice has one phase throughout.
+template <int SY, int SX, int AXIS, int PAIR>
+__device__ inline void mags_class(const ExactBatch &E, const ToedTables *__restrict__ T, int h, int w, int cap)
+{
+    const int im = blockIdx.y, W2 = 2 * w;
+    constexpr int CLS = 4 + ((SY << 1) | SX) * 2 + AXIS;
+    constexpr int NSY = PAIR ? (SY ^ 1) : (AXIS ? (SY ^ 1) : SY);
+    constexpr int NSX = PAIR ? (SX ^ 1) : (AXIS ? SX : (SX ^ 1));
+    const int32_t *__restrict__ list = E.lists[im] + (size_t)CLS * cap;
+    const int n = min(E.lcount[im][CLS], cap);
+    const CandData &cd = E.cd[im];
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x)
+    {
+        const int t = list[k];
+        const int o = E.src[im][2 * t];
+        const int I = o / W2, J = o - I * W2;
+        const int pk = cd.sector[t];
+        const int da = PAIR ? ((pk >> 4) & 3) - 1 : (pk & 3) - 1;
+        const int db = PAIR ? ((pk >> 6) & 3) - 1 : ((pk >> 2) & 3) - 1;
+        cd.mag[(size_t)(0 + PAIR) * cap + t] = exact_mag<NSY, NSX>(E.img[im], h, w, T, I + da, J + db);
+        cd.mag[(size_t)(2 + PAIR) * cap + t] = exact_mag<NSY, NSX>(E.img[im], h, w, T, I - da, J - db);
+    }
+}
+
+__global__ __launch_bounds__(256) void toed_exact_mags_kernel(ExactBatch E, const ToedTables *__restrict__ T, int h,
+                                                              int w, int cap)
+{
+    switch (blockIdx.z)
+    {
+    case 0: mags_class<0, 0, 0, 0>(E, T, h, w, cap); break;
+    case 1: mags_class<0, 0, 0, 1>(E, T, h, w, cap); break;
+    case 2: mags_class<0, 0, 1, 0>(E, T, h, w, cap); break;
+    case 3: mags_class<0, 0, 1, 1>(E, T, h, w, cap); break;
+    case 4: mags_class<0, 1, 0, 0>(E, T, h, w, cap); break;
+    case 5: mags_class<0, 1, 0, 1>(E, T, h, w, cap); break;
+    case 6: mags_class<0, 1, 1, 0>(E, T, h, w, cap); break;
+    case 7: mags_class<0, 1, 1, 1>(E, T, h, w, cap); break;
+    case 8: mags_class<1, 0, 0, 0>(E, T, h, w, cap); break;
+    case 9: mags_class<1, 0, 0, 1>(E, T, h, w, cap); break;
+    case 10: mags_class<1, 0, 1, 0>(E, T, h, w, cap); break;
+    case 11: mags_class<1, 0, 1, 1>(E, T, h, w, cap); break;
+    case 12: mags_class<1, 1, 0, 0>(E, T, h, w, cap); break;
+    case 13: mags_class<1, 1, 0, 1>(E, T, h, w, cap); break;
+    case 14: mags_class<1, 1, 1, 0>(E, T, h, w, cap); break;
+    default: mags_class<1, 1, 1, 1>(E, T, h, w, cap); break;
+    }
+}
+
+// S3d: the exact NMS decision of every candidate, from exact values only
+__global__ __launch_bounds__(256) void toed_exact_decide_kernel(ExactBatch E, int h, int w, int cap)
+{
+    const int im = blockIdx.y, W2 = 2 * w;
+    const CandData &cd = E.cd[im];
+    CandRec *__restrict__ rec = E.rec[im];
+    int32_t *__restrict__ ft = E.cand_flag[im], *__restrict__ fk = ft + cap;
+    const int n = min(E.counts[im][2], cap);
     for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x)
     {
-        const int o = srcl[2 * t];
+        const int o = E.src[im][2 * t];
         const int I = o / W2, J = o - I * W2;
-        double f[9];
-        exact9(img, h, w, S, I >> 1, J >> 1, I & 1, J & 1, f);
-        const double gx = f[0], gy = f[1];
-        const double m = sqrt(gx * gx + gy * gy); // src/toed/cpu_toed.cpp:222
+        const double gx = cd.gx[t], gy = cd.gy[t], m = cd.m[t];
+        NmsSector S;
+        bool is_max = false;
         double px = 0, py = 0, sm = 0;
-        const bool is_max =
-            nms_core(m, gx, gy, I, J, [&](int di, int dj) { return exact_mag(img, h, w, S, I + di, J + dj); }, px, py, sm);
+        if (cd.sector[t] >= 0 && nms_sector(m, gx, gy, S))
+            is_max = nms_finish(m, S, I, J, cd.mag[(size_t)0 * cap + t], cd.mag[(size_t)1 * cap + t],
+                                cd.mag[(size_t)2 * cap + t], cd.mag[(size_t)3 * cap + t], px, py, sm);
         int kept = 0;
         CandRec r;
-        r.x = r.y = r.smag = r.tox = r.toy = 0.0;
+        r.x = r.y = r.smag = 0.0;
+        r.tox = cd.tox[t];
+        r.toy = cd.toy[t];
         if (is_max)
         {
             r.x = (px - 1) / 2; // :538,542
             r.y = (py - 1) / 2;
             r.smag = sm;
-            third_order_dir(f, r.tox, r.toy);
             kept = (r.x > 10 && r.x < w - 10 && r.y > 10 && r.y < h - 10) ? 1 : 0; // :553-554
         }
         rec[t] = r;
@@ -919,9 +1140,33 @@ int toed_enqueue(ebvo_ctx *ctx, Slot &s, int n_img, int h, int w, hipEvent_t ev_
             hipLaunchKernelGGL(toed_compact_kernel, dim3(H2 - 20, n_img), dim3(256), 0, s.stream, B, h, w, cap);
         }
         {
+            ExactBatch E{};
+            for (int k = 0; k < n_img; ++k)
+            {
+                ImageWS &ws = s.im[k];
+                E.img[k] = ws.img;
+                E.src[k] = ws.src;
+                E.counts[k] = ws.counts;
+                E.lists[k] = ws.cand_lists;
+                E.lcount[k] = ws.cand_lcount;
+                double *d = ws.cand_data;
+                E.cd[k].gx = d;
+                E.cd[k].gy = d + (size_t)cap;
+                E.cd[k].m = d + (size_t)2 * cap;
+                E.cd[k].tox = d + (size_t)3 * cap;
+                E.cd[k].toy = d + (size_t)4 * cap;
+                E.cd[k].mag = d + (size_t)5 * cap;
+                E.cd[k].sector = ws.cand_sector;
+                E.rec[k] = (CandRec *)ws.cand_rec;
+                E.cand_flag[k] = ws.cand_flag;
+                EBVO_HIP(ctx, hipMemsetAsync(ws.cand_lcount, 0, sizeof(int32_t) * 12, s.stream));
+            }
+            const ToedTables *T = (const ToedTables *)g_tables_dev[ctx->device];
             ProfScope ps(ctx, s, K_EXACT);
-            hipLaunchKernelGGL(toed_exact_kernel, dim3(1024, n_img), dim3(256), 0, s.stream, B,
-                               (const ToedTables *)g_tables_dev[ctx->device], h, w, cap);
+            hipLaunchKernelGGL(toed_split_phase_kernel, dim3(256, n_img), dim3(256), 0, s.stream, E, w, cap);
+            hipLaunchKernelGGL(toed_exact_centre_kernel, dim3(256, n_img, 4), dim3(256), 0, s.stream, E, T, h, w, cap);
+            hipLaunchKernelGGL(toed_exact_mags_kernel, dim3(128, n_img, 16), dim3(256), 0, s.stream, E, T, h, w, cap);
+            hipLaunchKernelGGL(toed_exact_decide_kernel, dim3(512, n_img), dim3(256), 0, s.stream, E, h, w, cap);
         }
         if (ev_conv_end)
             EBVO_HIP(ctx, hipEventRecord(ev_conv_end, s.stream));
