@@ -54,6 +54,12 @@ class Context:
         m = {"strict": _lib.TOED_STRICT, "hybrid": _lib.TOED_HYBRID}[mode]
         self._check(self.lib.ebvo_set_toed_mode(self._ctx, m), "ebvo_set_toed_mode")
 
+    def toed_stats(self, slot: int = 0) -> dict:
+        out = np.zeros(8, dtype=np.int32)
+        self._check(self.lib.ebvo_toed_stats(self._ctx, slot, ptr(out)), "ebvo_toed_stats")
+        return {"left": dict(n_total=int(out[0]), n_kept=int(out[1]), n_candidates=int(out[2])),
+                "right": dict(n_total=int(out[4]), n_kept=int(out[5]), n_candidates=int(out[6]))}
+
     @property
     def toed_mode(self) -> str:
         return "hybrid" if self.lib.ebvo_get_toed_mode(self._ctx) == _lib.TOED_HYBRID else "strict"

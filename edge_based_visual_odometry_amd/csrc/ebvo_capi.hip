@@ -9,7 +9,7 @@
 #include "ebvo_internal.h"
 
 const char *const g_kernel_names[K_NUM] = {
-    "toed_conv",   "toed_nms",   "toed_rowscan", "toed_compact", "toed_finalize", "toed_exact", "cand_boxes", "epi_lines",
+    "toed_conv",   "toed_nms",   "toed_rowscan", "toed_compact", "toed_finalize", "toed_exact_centre", "toed_exact_mags", "cand_boxes", "epi_lines",
     "cand_count",  "scan",       "cand_fill",    "edge_patches", "ncc_pairs",     "ncc_stored", "misc"};
 
 // ------------------------------------------------------------------------------------------
@@ -235,6 +235,20 @@ extern "C" int ebvo_set_toed_mode(ebvo_ctx *ctx, int mode)
 }
 
 extern "C" int ebvo_get_toed_mode(const ebvo_ctx *ctx) { return ctx ? ctx->toed_mode : EBVO_ERR_ARG; }
+
+extern "C" int ebvo_toed_stats(ebvo_ctx *ctx, int slot, int32_t out[8])
+{
+    if (!ctx || !out || slot < 0 || slot >= (int)ctx->slots.size())
+        return EBVO_ERR_ARG;
+    Slot &s = *ctx->slots[(size_t)slot];
+    if (s.in_flight)
+        return EBVO_ERR_STATE;
+    EBVO_HIP(ctx, hipSetDevice(ctx->device));
+    for (int k = 0; k < 2; ++k)
+        EBVO_HIP(ctx, hipMemcpyAsync(out + 4 * k, s.im[k].counts, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, s.stream));
+    EBVO_HIP(ctx, hipStreamSynchronize(s.stream));
+    return EBVO_OK;
+}
 
 extern "C" void ebvo_ctx_destroy(ebvo_ctx *ctx)
 {

@@ -18,7 +18,8 @@ enum KernelId
     K_ROWSCAN,
     K_COMPACT,
     K_FINALIZE,
-    K_EXACT,
+    K_EXACT_CENTRE,
+    K_EXACT_MAGS,
     K_BOXES,
     K_LINES,
     K_CAND_COUNT,

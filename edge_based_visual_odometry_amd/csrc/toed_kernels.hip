@@ -1162,11 +1162,18 @@ int toed_enqueue(ebvo_ctx *ctx, Slot &s, int n_img, int h, int w, hipEvent_t ev_
                 EBVO_HIP(ctx, hipMemsetAsync(ws.cand_lcount, 0, sizeof(int32_t) * 12, s.stream));
             }
             const ToedTables *T = (const ToedTables *)g_tables_dev[ctx->device];
-            ProfScope ps(ctx, s, K_EXACT);
-            hipLaunchKernelGGL(toed_split_phase_kernel, dim3(256, n_img), dim3(256), 0, s.stream, E, w, cap);
-            hipLaunchKernelGGL(toed_exact_centre_kernel, dim3(256, n_img, 4), dim3(256), 0, s.stream, E, T, h, w, cap);
-            hipLaunchKernelGGL(toed_exact_mags_kernel, dim3(128, n_img, 16), dim3(256), 0, s.stream, E, T, h, w, cap);
-            hipLaunchKernelGGL(toed_exact_decide_kernel, dim3(512, n_img), dim3(256), 0, s.stream, E, h, w, cap);
+            {
+                ProfScope ps(ctx, s, K_EXACT_CENTRE);
+                hipLaunchKernelGGL(toed_split_phase_kernel, dim3(256, n_img), dim3(256), 0, s.stream, E, w, cap);
+                hipLaunchKernelGGL(toed_exact_centre_kernel, dim3(256, n_img, 4), dim3(256), 0, s.stream, E, T, h, w,
+                                   cap);
+            }
+            {
+                ProfScope ps(ctx, s, K_EXACT_MAGS);
+                hipLaunchKernelGGL(toed_exact_mags_kernel, dim3(128, n_img, 16), dim3(256), 0, s.stream, E, T, h, w,
+                                   cap);
+                hipLaunchKernelGGL(toed_exact_decide_kernel, dim3(512, n_img), dim3(256), 0, s.stream, E, h, w, cap);
+            }
         }
         if (ev_conv_end)
             EBVO_HIP(ctx, hipEventRecord(ev_conv_end, s.stream));

@@ -95,6 +95,8 @@ enum
 };
 int ebvo_set_toed_mode(ebvo_ctx *ctx, int mode);
 int ebvo_get_toed_mode(const ebvo_ctx *ctx);
+/* diagnostics of the last TOED run on a slot: per image {all NMS maxima, kept edges, screened candidates (hybrid), 0} */
+int ebvo_toed_stats(ebvo_ctx *ctx, int slot, int32_t out[8]);
 
 /*
  * Replaces ThirdOrderEdgeDetectionCPU::get_Third_Order_Edges(cv::Mat)
@@ -214,7 +216,7 @@ int ebvo_stereo_fetch_slot(ebvo_ctx *ctx, int slot, ebvo_edge *left, ebvo_edge *
                            int32_t *col_idx, double *sims, double *best, uint8_t *keep, float *left_patches);
 
 /* Per-kernel device timing (HIP events on the slots' streams, accumulated). */
-#define EBVO_MAX_KERNELS 16
+#define EBVO_MAX_KERNELS 24
 typedef struct ebvo_kernel_time
 {
     const char *name;
