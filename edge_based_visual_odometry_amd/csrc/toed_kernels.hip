@@ -768,8 +768,19 @@ __device__ inline Row24 fetch_row(const uint8_t *__restrict__ img, int h, int w,
     return r;
 }
 
-__device__ inline void unpack_row(const Row24 &r, int h, int w, int ii, int j, int v[19])
+// `fast`: wave-uniform promise that the whole 19 x 19 window of every lane lies inside the image (no masking)
+__device__ inline void unpack_row(const Row24 &r, int h, int w, int ii, int j, bool fast, int v[19])
 {
+    if (fast)
+    {
+#pragma unroll
+        for (int k = 0; k < 19; ++k)
+        {
+            const unsigned long long word = k < 8 ? r.w0 : (k < 16 ? r.w1 : r.w2);
+            v[18 - k] = (int)((word >> (8 * (k & 7))) & 0xffull);
+        }
+        return;
+    }
     const bool rok = ii >= 0 && ii < h;
 #pragma unroll
     for (int k = 0; k < 19; ++k)
@@ -780,6 +791,11 @@ __device__ inline void unpack_row(const Row24 &r, int h, int w, int ii, int j, i
         const int col = j - HALO + k;
         v[18 - k] = (rok && col >= 0 && col < w) ? b : 0;
     }
+}
+
+__device__ inline bool window_inside(int h, int w, int i, int j)
+{
+    return i >= HALO && i + HALO < h && j >= HALO && j + HALO < w;
 }
 
 // all nine responses at input pixel (i, j) for the compile-time phase (SY, SX): conv_body's arithmetic
@@ -794,6 +810,7 @@ __device__ inline void exact9(const uint8_t *__restrict__ img, int h, int w, con
     for (int r = 0; r < 9; ++r)
         f[r] = 0.0;
     constexpr int PM = IP ? 8 : 9;
+    const bool fast = __all(window_inside(h, w, i, j));
     Row24 nxt = fetch_row(img, h, w, i + PM, j);
 #pragma unroll 1
     for (int p = -PM; p <= PM; ++p)
@@ -801,7 +818,7 @@ __device__ inline void exact9(const uint8_t *__restrict__ img, int h, int w, con
         const Row24 cur = nxt;
         nxt = fetch_row(img, h, w, i - min(p + 1, PM), j); // next row in flight while this one is accumulated
         int vb[19];
-        unpack_row(cur, h, w, i - p, j, vb);
+        unpack_row(cur, h, w, i - p, j, fast, vb);
         double rr[4];
 #pragma unroll
         for (int d = 0; d < 4; ++d)
@@ -810,10 +827,17 @@ __device__ inline void exact9(const uint8_t *__restrict__ img, int h, int w, con
         for (int q = -PM; q <= PM; ++q)
         {
             const double v = (double)vb[q + 9];
+            // the column taps are (re)loaded four taps at a time: a laundered zero offset keeps the scalar loads
+            // from being hoisted and clustered (all 76 doubles do not fit the SGPR file; they came back one
+            // v_readlane at a time, 292 extra instructions per row measured)
+            int lz = 0;
+            if (((q + PM) & 3) == 0)
+                asm volatile("" : "+s"(lz));
+            const double(*ckl)[19] = ck + lz;
             double cc[4];
 #pragma unroll
             for (int d = 0; d < 4; ++d)
-                cc[d] = v * ck[d][q + 9];
+                cc[d] = v * ckl[d][q + 9];
             if (IP)
             {
                 f[0] += v * T->prod_fx[p + 8][q + 8];
@@ -845,6 +869,7 @@ __device__ inline double exact_mag(const uint8_t *__restrict__ img, int h, int w
     const double(*rk)[19] = SY ? T->tap_half : T->tap_int;
     double fx = 0.0, fy = 0.0;
     constexpr int PM = IP ? 8 : 9;
+    const bool fast = __all(window_inside(h, w, i, j));
     Row24 nxt = fetch_row(img, h, w, i + PM, j);
 #pragma unroll 1
     for (int p = -PM; p <= PM; ++p)
@@ -852,7 +877,10 @@ __device__ inline double exact_mag(const uint8_t *__restrict__ img, int h, int w
         const Row24 cur = nxt;
         nxt = fetch_row(img, h, w, i - min(p + 1, PM), j);
         int vb[19];
-        unpack_row(cur, h, w, i - p, j, vb);
+        unpack_row(cur, h, w, i - p, j, fast, vb);
+        int lz = 0;
+        asm volatile("" : "+s"(lz)); // see exact9: keeps the tap loads in the loop
+        const double(*ckl)[19] = ck + lz;
         const double r0 = rk[0][p + 9], r1 = rk[1][p + 9];
 #pragma unroll
         for (int q = -PM; q <= PM; ++q)
@@ -865,8 +893,8 @@ __device__ inline double exact_mag(const uint8_t *__restrict__ img, int h, int w
             }
             else
             {
-                fx += (v * ck[1][q + 9]) * r0;
-                fy += (v * ck[0][q + 9]) * r1;
+                fx += (v * ckl[1][q + 9]) * r0;
+                fy += (v * ckl[0][q + 9]) * r1;
             }
         }
     }
