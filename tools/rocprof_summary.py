@@ -19,6 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 mode = sys.argv[2] if len(sys.argv) > 2 else "hybrid"          # toed mode of the profiled run
 dominant = sys.argv[3] if len(sys.argv) > 3 else "toed_exact_centre"   # bench.py's name of the dominant kernel
+symbol = sys.argv[4] if len(sys.argv) > 4 else dominant + "_kernel"   # its HIP symbol (substring)
 src = os.path.join(ROOT, "gpurun_out", "prof")
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
@@ -56,7 +57,7 @@ for name, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
                      "group by kernel_name order by avg(value) desc", (counter,)).fetchall()
     for k, n, v in rows:
         pm.append(f"{short(k):40s} {n:8d} {v:16.1f}")
-        if dominant + "_kernel" in k:
+        if symbol in k:
             res[counter] = v * 1024.0
 if pm:
     if "FETCH_SIZE" in res and "WRITE_SIZE" in res:
