@@ -90,9 +90,25 @@ def img_fnv(img: np.ndarray) -> str:
 
 # Calibrations of the reference configs (config/kitti.yaml:13-28 etc.): fx, fy, cx, cy, R21, T21.
 CALIB = {
-    "kitti": dict(K=(718.856, 718.856, 607.1928, 185.2157),
+    # config/kitti.yaml:13-28 (rectified)
+    "kitti": dict(K=(718.856, 718.856, 607.1928, 185.2157), K_right=(718.856, 718.856, 607.1928, 185.2157),
                   R21=((1.0, 0.0, 0.0), (0.0, 1.0, 0.0), (0.0, 0.0, 1.0)), T21=(0.54, 0.0, 0.0)),
+    # config/euroc.yaml:10-28 (NOT rectified: slanted epipolar lines)
+    "euroc": dict(K=(458.654, 457.296, 367.215, 248.375), K_right=(457.587, 456.134, 379.999, 255.238),
+                  R21=((0.999997256477450, 0.002312067192420, 0.000376008102351),
+                       (-0.002317135723285, 0.999898048506528, 0.014089835846697),
+                       (-0.000343393120589, -0.014090668452670, 0.999900662638179)),
+                  T21=(-0.110073808127139, 0.000399121547014534, -0.000853702503351098)),
+    # config/eth3d_delivery_area.yaml:10-28
+    "eth3d": dict(K=(541.764, 541.764, 553.869, 232.396), K_right=(541.764, 541.764, 553.869, 232.396),
+                  R21=((1.0, 0.0, 0.0), (0.0, 1.0, 0.0), (0.0, 0.0, 1.0)),
+                  T21=(-0.059891300000001, 0.000000000000001, 0.000000000000001)),
 }
+
+
+def fundamental_for(name: str) -> np.ndarray:
+    c = CALIB[name]
+    return fundamental_21(c["K"], c["K_right"], c["R21"], c["T21"])
 
 
 def fundamental_21(K_left, K_right, R21, T21) -> np.ndarray:

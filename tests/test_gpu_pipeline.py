@@ -154,3 +154,58 @@ def test_submit_wait_state_machine(ctx):
     c = ctx.stereo_wait()
     assert c.n_pairs > 0
     assert len(ctx.toed(l).edges) == c.n_left
+
+
+@pytest.mark.parametrize("cfg", ["euroc", "eth3d"])
+def test_pipeline_other_reference_configs(ctx, cfg):
+    """configs[2] / configs[3] of BASELINE.json as parity cases: EuRoC 752x480 with its non-rectified calibration
+    (slanted epipolar lines) and ETH3D delivery_area 942x489.  The device pipeline equals the stage-wise calls, and the
+    candidate lists equal the brute-force oracle on a strided subset of the left edges."""
+    h, w = synth.SHAPES[cfg]
+    F = synth.fundamental_for(cfg)
+    l, r = synth.stereo_pair("s2", h, w, scene=11, noise_base=4, disparity=9)
+    ctx.stereo_upload(l, r)
+    c = ctx.stereo_run(ctx.default_params(F))
+    out = ctx.stereo_fetch(c)
+    L, R, _ = ctx.toed_pair(l, r)
+    assert_edges_equal(out["left"], L)
+    lines = ctx.epipolar_lines(F, L)
+    rp, ci = ctx.epi_candidates(L, R, lines)
+    assert_bit_equal(out["row_ptr"], rp, "row_ptr")
+    assert_bit_equal(out["col_idx"], ci, "col_idx")
+    sims, best, keep, _ = ctx.ncc_pairs(l, r, L, R[ci], rp)
+    assert_bit_equal(out["sims"], sims, "sims")
+    assert_bit_equal(out["keep"], keep, "keep")
+    assert c.n_pairs > 1000
+    Ls = L[::211]
+    ls = orc.epipolar_lines(F, Ls)
+    orp, oci = orc.epi_candidates(Ls, R, ls)
+    grp, gci = ctx.epi_candidates(Ls, R, ls)
+    assert_bit_equal(grp, orp, "subset row_ptr")
+    assert_bit_equal(gci, oci, "subset col_idx")
+    osims, _, okeep, _ = orc.ncc_pairs(l, r, Ls, R[oci], orp)
+    gsims, _, gkeep, _ = ctx.ncc_pairs(l, r, Ls, R[gci], grp)
+    assert_bit_equal(gsims, osims, "subset sims")
+    assert_bit_equal(gkeep, okeep, "subset keep")
+
+
+def test_temporal_quads_at_sequence_scale(ctx):
+    """configs[2]: temporal NCC on stored patches, frame 0 (keyframe) vs a later frame, tens of thousands of quads."""
+    h, w = synth.SHAPES["euroc"]
+    F = synth.fundamental_for("euroc")
+    frames = []
+    for k in (0, 3):
+        l, r = synth.stereo_pair("s2", h, w, scene=7, noise_base=2 * k, disparity=9)
+        l, r = np.roll(l, k, axis=1), np.roll(r, k, axis=1)          # k px of global motion
+        L, R, _ = ctx.toed_pair(l, r)
+        frames.append((l, r, L[:20000], R[:20000]))
+    (l0, r0, L0, R0), (l1, r1, L1, R1) = frames
+    n = min(len(L0), len(L1), len(R0), len(R1))
+    kfL, kfR = ctx.edge_patches(l0, L0[:n]), ctx.edge_patches(r0, R0[:n])
+    cfL, cfR = ctx.edge_patches(l1, L1[:n]), ctx.edge_patches(r1, R1[:n])
+    sl, sr, keep = ctx.ncc_quads(kfL, kfR, cfL, cfR, 0.8)
+    osl, osr, okeep = orc.ncc_quads(kfL, kfR, cfL, cfR, 0.8)
+    assert_bit_equal(sl, osl, "sim_left")
+    assert_bit_equal(sr, osr, "sim_right")
+    assert_bit_equal(keep, okeep, "keep")
+    assert n > 10000
