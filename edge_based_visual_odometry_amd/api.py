@@ -235,8 +235,9 @@ class Context:
                     left_patches=lp)
 
     # -- profiling -----------------------------------------------------------------------------
-    def profile_enable(self, on: bool = True):
-        self._check(self.lib.ebvo_profile_enable(self._ctx, int(on)), "ebvo_profile_enable")
+    def profile_enable(self, on: bool = True, every: int = 1):
+        """every = N > 1: bracket only every N-th pair submitted to the device pipeline."""
+        self._check(self.lib.ebvo_profile_enable(self._ctx, (max(1, every) if on else 0)), "ebvo_profile_enable")
 
     def profile_reset(self):
         self._check(self.lib.ebvo_profile_reset(self._ctx), "ebvo_profile_reset")

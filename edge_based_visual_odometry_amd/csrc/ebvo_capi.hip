@@ -49,7 +49,7 @@ int ebvo_grow(ebvo_ctx *ctx, Slot &s, GrowBuf &b, size_t bytes)
 
 void ebvo_prof_begin(ebvo_ctx *ctx, Slot &s, int kid)
 {
-    if (!ctx->prof)
+    if (!ctx->prof || !s.prof_now)
         return;
     ProfEvent pe;
     if (!ctx->prof_free.empty())
@@ -69,7 +69,7 @@ void ebvo_prof_begin(ebvo_ctx *ctx, Slot &s, int kid)
 
 void ebvo_prof_end(ebvo_ctx *ctx, Slot &s)
 {
-    if (!ctx->prof || s.prof_pending.empty())
+    if (!ctx->prof || !s.prof_now || s.prof_pending.empty())
         return;
     (void)hipEventRecord(s.prof_pending.back().b, s.stream);
 }
@@ -839,6 +839,7 @@ extern "C" int ebvo_stereo_submit(ebvo_ctx *ctx, int slot, const ebvo_stereo_par
     int rc;
     s.have_run = false;
     s.params = *p;
+    s.prof_now = ctx->prof && (ctx->prof_submits++ % ctx->prof_every == 0);
     {
         int64_t want = s.pipe_cap > 0 ? s.pipe_cap : 8 * (int64_t)ctx->cap_edges;
         if (want < 4096)
@@ -865,6 +866,11 @@ extern "C" int ebvo_stereo_wait(ebvo_ctx *ctx, int slot, ebvo_stereo_counts *cou
         return EBVO_ERR_STATE;
     EBVO_HIP(ctx, hipSetDevice(ctx->device));
     int rc = EBVO_OK;
+    struct Restore
+    {
+        Slot &s;
+        ~Restore() { s.prof_now = true; } // host-buffer calls on this slot are always bracketed
+    } restore{s};
     for (int attempt = 0; attempt < 4; ++attempt)
     {
         hipError_t e = hipStreamSynchronize(s.stream);
@@ -969,6 +975,8 @@ extern "C" int ebvo_profile_enable(ebvo_ctx *ctx, int on)
         return EBVO_ERR_ARG;
     int rc = prof_drain(ctx);
     ctx->prof = on != 0;
+    ctx->prof_every = on > 1 ? on : 1; // on = N > 1: sample every N-th pair submitted to the device pipeline
+    ctx->prof_submits = 0;
     return rc;
 }
 

@@ -115,6 +115,7 @@ struct Slot
     PairResult result{};                 // last completed result
 
     std::vector<ProfEvent> prof_pending;
+    bool prof_now = true; // this submission is one of the sampled ones
 };
 
 struct ebvo_ctx
@@ -128,6 +129,8 @@ struct ebvo_ctx
 
     // profiling (accumulated over all slots)
     bool prof = false;
+    int prof_every = 1;          // device pipeline: bracket the kernels of every N-th submitted pair only
+    int64_t prof_submits = 0;
     std::vector<ProfEvent> prof_free;
     double prof_ms[K_NUM] = {0};
     int64_t prof_launches[K_NUM] = {0};

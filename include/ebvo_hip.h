@@ -223,6 +223,8 @@ typedef struct ebvo_kernel_time
     double ms;        /* accumulated */
     int64_t launches; /* accumulated */
 } ebvo_kernel_time;
+/* on = 0: off; 1: bracket every kernel launch with HIP events; N > 1: in the device pipeline bracket the kernels of every
+ * N-th submitted pair only (the event records themselves cost ~0.2 ms of device timeline per pair). */
 int ebvo_profile_enable(ebvo_ctx *ctx, int on);
 int ebvo_profile_reset(ebvo_ctx *ctx);
 int ebvo_profile_get(ebvo_ctx *ctx, ebvo_kernel_time *out /* EBVO_MAX_KERNELS */, int *n);
