@@ -136,7 +136,7 @@ static void slot_destroy(Slot *s)
         (void)hipFree(ws.cand_lists);
         (void)hipFree(ws.cand_lcount);
     }
-    GrowBuf *bufs[] = {&s->lines,        &s->boxes_chunk,  &s->boxes_group,    &s->cand_cnt,       &s->row_ptr,
+    GrowBuf *bufs[] = {&s->lines,        &s->boxes_chunk,  &s->boxes_group,    &s->cand_cnt,       &s->cand_stage, &s->cand_tileflag, &s->row_ptr,
                        &s->scan_tmp,     &s->col_idx,      &s->rc_edges,       &s->sims,           &s->best,
                        &s->keep,         &s->patches_raw,  &s->patches_norm,   &s->patches_flag,   &s->patches_norm_r,
                        &s->patches_flag_r, &s->pair_left,  &s->sincos,         &s->scratch_b,      &s->scratch_c,
@@ -197,7 +197,7 @@ static int slot_create(ebvo_ctx *ctx, Slot **out)
         CK(hipMalloc(&ws.all4, sizeof(double) * 4 * (size_t)ctx->cap_edges));
     }
     CK(hipMalloc(&s->d_total, sizeof(unsigned long long)));
-    CK(hipMalloc(&s->d_matches, sizeof(int32_t)));
+    CK(hipMalloc(&s->d_matches, sizeof(int32_t) * EBVO_MATCH_PARTS));
     CK(hipMalloc(&s->d_sizes, sizeof(int32_t) * 4));
     CK(hipMalloc(&s->d_F, sizeof(double) * 9));
     CK(hipMalloc(&s->d_result, sizeof(PairResult)));
@@ -816,11 +816,7 @@ static int enqueue_matching(ebvo_ctx *ctx, Slot &s)
                                        (const double *)s.lines.p, p.epi_thr, p.max_disp, p.orient_thr_deg, p.stage_mask,
                                        true)))
         return rc;
-    if ((rc = match_patches_enqueue(ctx, s, s.im[0].img, h, w, w, s.im[0].edges, 0, d_nL, ce, (float *)s.patches_raw.p,
-                                    (float *)s.patches_norm.p, (uint8_t *)s.patches_flag.p)))
-        return rc;
-    if ((rc = match_patches_enqueue(ctx, s, s.im[1].img, h, w, w, s.im[1].edges, 0, d_nR, ce, nullptr,
-                                    (float *)s.patches_norm_r.p, (uint8_t *)s.patches_flag_r.p)))
+    if ((rc = match_patch_banks_enqueue(ctx, s, h, w, ce)))
         return rc;
     if ((rc = match_ncc_banked_enqueue(ctx, s, 0, d_nL, ce, 0, p.ncc_thr)))
         return rc;
@@ -957,7 +953,15 @@ extern "C" int ebvo_stereo_fetch_slot(ebvo_ctx *ctx, int slot, ebvo_edge *left, 
     if (keep && np)
         EBVO_HIP(ctx, hipMemcpyAsync(keep, s.keep.p, np, hipMemcpyDeviceToHost, st));
     if (left_patches && nL)
+    {
+        // the pipeline keeps only the normalised banks; the raw left patches (what the reference stores per match,
+        // src/Stereo_Matches.cpp:1622) are sampled when they are asked for
+        int rc = match_patches_enqueue(ctx, s, s.im[0].img, s.cur_h, s.cur_w, s.cur_w, s.im[0].edges, (int)nL, nullptr, 0,
+                                       (float *)s.patches_raw.p, nullptr, nullptr);
+        if (rc)
+            return rc;
         EBVO_HIP(ctx, hipMemcpyAsync(left_patches, s.patches_raw.p, sizeof(float) * 98 * nL, hipMemcpyDeviceToHost, st));
+    }
     EBVO_HIP(ctx, hipStreamSynchronize(st));
     return EBVO_OK;
 }

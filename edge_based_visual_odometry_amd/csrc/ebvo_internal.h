@@ -92,6 +92,9 @@ struct ProfEvent
     int kid;
 };
 
+constexpr int EBVO_CLEAR_MAX = 8;      // arrays one clear launch zeroes
+constexpr int EBVO_MATCH_PARTS = 4096; // most blocks ncc_banked_kernel is launched with
+
 // Everything that belongs to one HIP stream: a stereo pair in flight (or the workspace of a host-buffer call).
 struct Slot
 {
@@ -101,13 +104,14 @@ struct Slot
     bool have_pair = false, have_run = false, in_flight = false;
 
     // matching workspace
-    GrowBuf lines, boxes_chunk, boxes_group, cand_cnt, row_ptr, scan_tmp, col_idx, rc_edges, sims, best, keep,
+    GrowBuf lines, boxes_chunk, boxes_group, cand_cnt, cand_stage, cand_tileflag, row_ptr, scan_tmp, col_idx, rc_edges, sims, best, keep,
         patches_raw, patches_norm, patches_flag, patches_norm_r, patches_flag_r, pair_left, sincos, scratch_b, scratch_c,
         scratch_d;
     int64_t cap_pairs = 0;               // capacity of col_idx & co. as the kernels of the current call see it
     int64_t pipe_cap = 0;                // capacity the device pipeline keeps between pairs
     unsigned long long *d_total = nullptr; // 64-bit candidate total
-    int32_t *d_matches = nullptr;
+    int32_t *d_matches = nullptr; // [EBVO_MATCH_PARTS] per-block kept-pair counts of ncc_banked_kernel
+    int n_match_part = 0;
     int32_t *d_sizes = nullptr;          // [4] host-provided sizes for the host-buffer entry points
     double *d_F = nullptr;               // 9 doubles
     PairResult *d_result = nullptr, *h_result = nullptr; // h_result is pinned
@@ -183,6 +187,7 @@ int match_candidates_fill_enqueue(ebvo_ctx *ctx, Slot &s, const ebvo_edge *d_L, 
                                   const ebvo_edge *d_R, int nR, const int32_t *d_nR, int cap_edges,
                                   const double *d_lines, double epi_thr, double max_disp, double orient_thr_deg,
                                   int stage_mask);
+int match_patch_banks_enqueue(ebvo_ctx *ctx, Slot &s, int h, int w, int cap_edges);
 int match_patches_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_img, int h, int w, int pitch,
                           const ebvo_edge *d_edges, int n, const int32_t *d_n, int cap_n, float *d_raw, float *d_norm,
                           uint8_t *d_flag);
@@ -194,6 +199,11 @@ int match_ncc_banked_enqueue(ebvo_ctx *ctx, Slot &s, int nL, const int32_t *d_nL
                              double thr);
 int match_pair_result_enqueue(ebvo_ctx *ctx, Slot &s);
 // exclusive scan of n (+ n_add) int32 on the slot's stream; n_dev != nullptr: the count lives on the device, cap_n bounds it
+// zero n (<= EBVO_CLEAR_MAX) int32 arrays with one launch
+int ebvo_clear_enqueue(ebvo_ctx *ctx, Slot &s, int32_t *const ptrs[], const int counts[], int n);
+// up to four scans (device-side lengths) in one pair of launches
+int ebvo_device_scan4(ebvo_ctx *ctx, Slot &s, const int32_t *const in[4], int32_t *const out[4],
+                      const int32_t *const n_dev[4], int nb, int cap_n);
 int ebvo_device_scan(ebvo_ctx *ctx, Slot &s, const int32_t *in, int32_t *out, int n_host, const int32_t *n_dev, int n_add,
                      int cap_n);
 int match_ncc_stored_enqueue(ebvo_ctx *ctx, Slot &s, const float *d_A, const float *d_B, int n, double *d_sim);

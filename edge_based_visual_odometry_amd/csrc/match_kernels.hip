@@ -36,6 +36,7 @@ namespace
 constexpr int CHUNK = 16;        // edges per chunk box
 constexpr int GROUP = 64;        // chunks per group box (1024 edges)
 constexpr int BATCH = 64;        // chunks staged in LDS at a time (1024 edges, 24 KB)
+constexpr int STAGE = 16;        // candidates per left edge kept by the counting pass (rows beyond it are refilled)
 constexpr double BOX_SLACK = 1e-6;
 
 struct Box
@@ -73,7 +74,9 @@ struct CandParams
     double epi_thr, max_disp, orient_thr;
     int mask;
     DevN nL, nR;
-    int64_t cap; // capacity of col_idx (FILL)
+    int64_t cap;        // capacity of col_idx (FILL)
+    int32_t *stage;     // [nL][STAGE] first STAGE candidates of every left edge, written by the counting pass
+    int32_t *tile_flag; // [tiles] 1: some row of the tile has more than STAGE candidates -> the fill pass redoes the tile
 };
 
 // ------------------------------------------------------------------------------------------
@@ -295,9 +298,13 @@ __global__ __launch_bounds__(256) void candidates_kernel(const ebvo_edge *__rest
         return tot;
     };
 
+    if (!FILL && blockIdx.x == 0 && tid == 0)
+        cnt[nL] = 0; // the scan covers nL + 1 counts: row_ptr[nL] = total
     // one tile = 256 consecutive left edges; grid-stride so the launch does not depend on nL
     for (int tile = blockIdx.x; tile * 256 < nL; tile += gridDim.x)
     {
+        if (FILL && !P.tile_flag[tile]) // every row of this tile was completed from the staging area
+            continue;
         const int i = tile * 256 + tid;
         const bool live = i < nL;
         const int il = live ? i : 0;
@@ -391,7 +398,16 @@ __global__ __launch_bounds__(256) void candidates_kernel(const ebvo_edge *__rest
                                 }
                             }
                             else
-                                n += __popc(hits);
+                            {
+                                while (hits)
+                                {
+                                    const int e = __ffs((int)hits) - 1;
+                                    hits &= hits - 1;
+                                    if (n < STAGE)
+                                        P.stage[(size_t)i * STAGE + n] = kbase + e;
+                                    ++n;
+                                }
+                            }
                         }
                     }
                     __syncthreads();
@@ -401,7 +417,11 @@ __global__ __launch_bounds__(256) void candidates_kernel(const ebvo_edge *__rest
         if (!FILL)
         {
             if (live)
+            {
                 cnt[i] = n;
+                if (n > STAGE)
+                    P.tile_flag[tile] = 1; // benign race: every writer stores 1
+            }
             // 64-bit total (one atomic per tile) guards the int32 CSR offsets and the buffer capacity
             unsigned long long s = (unsigned long long)n;
             for (int d = 32; d > 0; d >>= 1)
@@ -420,27 +440,126 @@ __global__ __launch_bounds__(256) void candidates_kernel(const ebvo_edge *__rest
     }
 }
 
+// rows with at most STAGE candidates are completed from the staging area (the fill pass only redoes the rest)
+__global__ void candidates_copy_kernel(const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ stage, DevN nLd,
+                                       int64_t cap, int32_t *__restrict__ col_idx)
+{
+    const int nL = devn(nLd);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nL; i += gridDim.x * blockDim.x)
+    {
+        const int64_t o = row_ptr[i];
+        const int n = row_ptr[i + 1] - row_ptr[i];
+        if (n > STAGE)
+            continue;
+        for (int k = 0; k < n; ++k)
+            if (o + k < cap)
+                col_idx[o + k] = stage[(size_t)i * STAGE + k];
+    }
+}
+
 // ------------------------------------------------------------------------------------------
-// exclusive scan of int32 (two-level, recursive on the block sums)
-constexpr int SCAN_ITEMS = 4;
+// one launch zeroes every small counter array a stage needs (instead of one memset node per array)
+struct ClearList
+{
+    int32_t *p[EBVO_CLEAR_MAX];
+    int n[EBVO_CLEAR_MAX];
+};
+__global__ void clear_kernel(ClearList C)
+{
+    int32_t *__restrict__ p = C.p[blockIdx.y];
+    const int n = C.n[blockIdx.y];
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x)
+        p[k] = 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// Exclusive scan of int32, up to four independent arrays per launch, two kernels whatever the length:
+//   scan_reduce_kernel  sum of every 4096-element tile
+//   scan_apply_kernel   each block adds up the sums of the tiles before it (a few hundred at most), then scans its
+//                       own tile from that offset
+// Lengths may live on the device (DevN); the grid is sized by the host-side bound and idle blocks leave at once.
+constexpr int SCAN_ITEMS = 16;
 constexpr int SCAN_BLOCK = 256;
 constexpr int SCAN_TILE = SCAN_ITEMS * SCAN_BLOCK;
+constexpr int SCAN_BATCH = 4;
 
-__global__ __launch_bounds__(SCAN_BLOCK) void scan_tile_kernel(const int32_t *__restrict__ in,
-                                                               int32_t *__restrict__ out, DevN nd, int n_add,
-                                                               int32_t *__restrict__ sums)
+struct ScanBatch
+{
+    const int32_t *in[SCAN_BATCH];
+    int32_t *out[SCAN_BATCH];
+    DevN n[SCAN_BATCH];
+    int n_add;      // scan n + n_add elements (the candidate counts carry one trailing zero: out[n] = total)
+    int32_t *sums;  // [SCAN_BATCH][tiles]
+    int tiles;
+};
+
+__device__ inline int32_t block_sum_256(int32_t v, int32_t *wsum)
+{
+    for (int d = 32; d > 0; d >>= 1)
+        v += __shfl_down(v, d);
+    if ((threadIdx.x & 63) == 0)
+        wsum[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+__global__ __launch_bounds__(SCAN_BLOCK) void scan_reduce_kernel(ScanBatch S)
 {
     __shared__ int32_t wsum[SCAN_BLOCK / 64];
-    const int n = devn(nd) + n_add;
-    const int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
-    int32_t v[SCAN_ITEMS];
-    int32_t s = 0;
+    const int a = blockIdx.y;
+    const int n = devn(S.n[a]) + S.n_add;
+    const int base = blockIdx.x * SCAN_TILE;
+    if (base >= n)
+        return;
+    const int32_t *__restrict__ in = S.in[a];
+    int32_t v = 0;
 #pragma unroll
     for (int t = 0; t < SCAN_ITEMS; ++t)
     {
-        v[t] = (base + t < n) ? in[base + t] : 0;
-        s += v[t];
+        const int k = base + t * SCAN_BLOCK + threadIdx.x; // coalesced; the order inside a tile does not matter here
+        v += (k < n) ? in[k] : 0;
     }
+    const int32_t tot = block_sum_256(v, wsum);
+    if (threadIdx.x == 0)
+        S.sums[(size_t)a * S.tiles + blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(SCAN_BLOCK) void scan_apply_kernel(ScanBatch S)
+{
+    __shared__ int32_t wsum[SCAN_BLOCK / 64], wpre[SCAN_BLOCK / 64];
+    const int a = blockIdx.y;
+    const int n = devn(S.n[a]) + S.n_add;
+    const int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    if (blockIdx.x * SCAN_TILE >= n)
+        return;
+    const int32_t *__restrict__ in = S.in[a];
+    int32_t *__restrict__ out = S.out[a];
+    // offset of this tile = sum of the tiles before it
+    int32_t o = 0;
+    for (int k = threadIdx.x; k < (int)blockIdx.x; k += SCAN_BLOCK)
+        o += S.sums[(size_t)a * S.tiles + k];
+    const int32_t tile_off = block_sum_256(o, wpre);
+    int32_t v[SCAN_ITEMS];
+    int32_t s = 0;
+    if (base + SCAN_ITEMS <= n && (reinterpret_cast<uintptr_t>(in + base) & 15) == 0)
+    {
+        const int4 *p = reinterpret_cast<const int4 *>(in + base);
+#pragma unroll
+        for (int t = 0; t < SCAN_ITEMS / 4; ++t)
+        {
+            const int4 q = p[t];
+            v[4 * t] = q.x; v[4 * t + 1] = q.y; v[4 * t + 2] = q.z; v[4 * t + 3] = q.w;
+        }
+    }
+    else
+    {
+#pragma unroll
+        for (int t = 0; t < SCAN_ITEMS; ++t)
+            v[t] = (base + t < n) ? in[base + t] : 0;
+    }
+#pragma unroll
+    for (int t = 0; t < SCAN_ITEMS; ++t)
+        s += v[t];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     int32_t incl = s;
     for (int d = 1; d < 64; d <<= 1)
@@ -452,15 +571,12 @@ __global__ __launch_bounds__(SCAN_BLOCK) void scan_tile_kernel(const int32_t *__
     if (lane == 63)
         wsum[wid] = incl;
     __syncthreads();
-    int32_t pre = 0, tot = 0;
+    int32_t pre = 0;
 #pragma unroll
     for (int k = 0; k < SCAN_BLOCK / 64; ++k)
-    {
         if (k < wid)
             pre += wsum[k];
-        tot += wsum[k];
-    }
-    int32_t run = pre + incl - s;
+    int32_t run = tile_off + pre + incl - s;
 #pragma unroll
     for (int t = 0; t < SCAN_ITEMS; ++t)
     {
@@ -468,16 +584,6 @@ __global__ __launch_bounds__(SCAN_BLOCK) void scan_tile_kernel(const int32_t *__
             out[base + t] = run;
         run += v[t];
     }
-    if (threadIdx.x == 0 && sums)
-        sums[blockIdx.x] = tot;
-}
-
-__global__ void scan_add_kernel(int32_t *__restrict__ out, DevN nd, int n_add, const int32_t *__restrict__ offs)
-{
-    const int n = devn(nd) + n_add;
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < n)
-        out[k] += offs[k / SCAN_TILE];
 }
 
 __global__ void gather_edges_kernel(const ebvo_edge *__restrict__ R, const int32_t *__restrict__ idx, int64_t n,
@@ -534,6 +640,33 @@ __device__ inline double butterfly8(double s)
 // sin / cos of every edge orientation, one thread per edge (dense: the double-double routine costs
 // ~700 instructions per wave, so it is evaluated once per edge here instead of once per 16-lane
 // group inside the sampling kernels).  src/utility.cpp:84-87,151 call std::sin / std::cos.
+// Up to two edge lists (left / right image of a pair) per launch: blockIdx.y selects the list.
+struct PatchBatch
+{
+    const uint8_t *img[2];
+    const ebvo_edge *edges[2];
+    DevN n[2];
+    double2 *sc[2];
+    float *raw[2], *norm[2];
+    uint8_t *flag[2];
+};
+
+__global__ void sincos_batch_kernel(PatchBatch B)
+{
+    const ebvo_edge *__restrict__ e = B.edges[blockIdx.y];
+    double2 *__restrict__ sc = B.sc[blockIdx.y];
+    const int n = devn(B.n[blockIdx.y]);
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x)
+    {
+        double sn, cs;
+        ebvo_sincos(e[k].theta, &sn, &cs);
+        double2 v;
+        v.x = sn;
+        v.y = cs;
+        sc[k] = v;
+    }
+}
+
 __global__ void sincos_edges_kernel(const ebvo_edge *__restrict__ e, DevN nd, double2 *__restrict__ sc)
 {
     const int n = devn(nd);
@@ -624,13 +757,14 @@ __device__ inline double max4(double a, double b, double c, double d)
 
 // Patches of n edges: raw floats (n x 2 x 49), optionally the normalised patches and sentinel flags.
 // 16 lanes per edge; every 16-lane group strides over the edges with a wave-uniform trip count.
-__global__ __launch_bounds__(256) void patches_kernel(const uint8_t *__restrict__ img, int h, int w, int pitch,
-                                                      const ebvo_edge *__restrict__ edges,
-                                                      const double2 *__restrict__ sc, DevN nd,
-                                                      float *__restrict__ raw, float *__restrict__ norm,
-                                                      uint8_t *__restrict__ flag)
+__global__ __launch_bounds__(256) void patches_kernel(PatchBatch B, int h, int w, int pitch)
 {
-    const int n = devn(nd);
+    const uint8_t *__restrict__ img = B.img[blockIdx.y];
+    const ebvo_edge *__restrict__ edges = B.edges[blockIdx.y];
+    const double2 *__restrict__ sc = B.sc[blockIdx.y];
+    float *__restrict__ raw = B.raw[blockIdx.y], *__restrict__ norm = B.norm[blockIdx.y];
+    uint8_t *__restrict__ flag = B.flag[blockIdx.y];
+    const int n = devn(B.n[blockIdx.y]);
     const int groups = (gridDim.x * blockDim.x) >> 4;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int g = t & 15, side = g >> 3, row = g & 7;
@@ -746,28 +880,6 @@ __global__ __launch_bounds__(256) void ncc_pairs_kernel(const uint8_t *__restric
     (void)is_match;
 }
 
-// number of kept pairs: grid-stride byte sum, one atomic per block
-__global__ __launch_bounds__(256) void count_keep_kernel(const uint8_t *__restrict__ keep, DevPairs np,
-                                                         int32_t *__restrict__ out)
-{
-    __shared__ int wsum[4];
-    const int64_t n = devpairs(np);
-    int s = 0;
-    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x)
-        s += keep[k];
-    for (int d = 32; d > 0; d >>= 1)
-        s += __shfl_down(s, d);
-    if ((threadIdx.x & 63) == 0)
-        wsum[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0)
-    {
-        const int t = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-        if (t)
-            atomicAdd(out, t);
-    }
-}
-
 // pair -> left row index (CSR expansion), one thread per left edge
 __global__ void expand_rows_kernel(const int32_t *__restrict__ row_ptr, DevN nLd, int32_t *__restrict__ pair_left,
                                    int64_t cap)
@@ -788,8 +900,10 @@ __global__ __launch_bounds__(256) void ncc_banked_kernel(const float *__restrict
                                                          const int32_t *__restrict__ pair_left,
                                                          const int32_t *__restrict__ col_idx, DevPairs np, double thr,
                                                          double *__restrict__ sims, double *__restrict__ best,
-                                                         uint8_t *__restrict__ keep)
+                                                         uint8_t *__restrict__ keep, int32_t *__restrict__ match_part)
 {
+    __shared__ int s_mc[4];
+    int mc = 0; // kept pairs seen by this thread; summed per block into match_part[blockIdx.x] (no atomics)
     const int64_t n_pairs = devpairs(np);
     const int64_t groups = ((int64_t)gridDim.x * blockDim.x) >> 4;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -845,16 +959,31 @@ __global__ __launch_bounds__(256) void ncc_banked_kernel(const float *__restrict
                 best[k] = b;
             if (keep)
                 keep[k] = (b > thr) ? 1 : 0;
+            mc += (b > thr) ? 1 : 0;
         }
     }
+    for (int d = 32; d > 0; d >>= 1)
+        mc += __shfl_down(mc, d);
+    if ((threadIdx.x & 63) == 0)
+        s_mc[threadIdx.x >> 6] = mc;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        match_part[blockIdx.x] = s_mc[0] + s_mc[1] + s_mc[2] + s_mc[3];
 }
 
 // Last kernel of a device-resident pair: gathers every count the host wants into one record (PairResult,
 // ebvo_internal.h).
 __global__ void pair_result_kernel(const int32_t *__restrict__ cntL, const int32_t *__restrict__ cntR,
-                                   const unsigned long long *__restrict__ total, const int32_t *__restrict__ matches,
-                                   int64_t cap, PairResult *__restrict__ out)
+                                   const unsigned long long *__restrict__ total,
+                                   const int32_t *__restrict__ match_part, int n_part, int64_t cap,
+                                   PairResult *__restrict__ out)
 {
+    // one wave: the per-block match counts of ncc_banked_kernel are summed here
+    int m = 0;
+    for (int k = threadIdx.x; k < n_part; k += 64)
+        m += match_part[k];
+    for (int d = 32; d > 0; d >>= 1)
+        m += __shfl_down(m, d);
     if (threadIdx.x || blockIdx.x)
         return;
     PairResult r;
@@ -863,7 +992,7 @@ __global__ void pair_result_kernel(const int32_t *__restrict__ cntL, const int32
     r.n_total_right = cntR[0];
     r.n_right = cntR[1];
     r.n_pairs = (int64_t)*total;
-    r.n_matches = *matches;
+    r.n_matches = m;
     r.overflow = (r.n_pairs > cap || r.n_pairs > 0x7fffffffll) ? 1 : 0;
     r.pad = 0;
     *out = r;
@@ -925,42 +1054,33 @@ __global__ __launch_bounds__(256) void fp64_peak_kernel(double *out, int iters, 
     out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
-// exclusive scan of n (+ n_add) int32; n may live on the device, cap_n bounds it on the host
-int device_exclusive_scan(ebvo_ctx *ctx, Slot &s, const int32_t *in, int32_t *out, DevN n, int n_add, int cap_n)
+// exclusive scans of n (+ n_add) int32 each, nb arrays (<= SCAN_BATCH) in one pair of launches; the lengths may live on
+// the device, cap_n bounds them on the host
+int device_exclusive_scan_batch(ebvo_ctx *ctx, Slot &s, ScanBatch S, int nb, int cap_n)
 {
-    const int nb0 = (cap_n + SCAN_TILE - 1) / SCAN_TILE;
-    if (nb0 <= 1)
-    {
-        hipLaunchKernelGGL(scan_tile_kernel, dim3(1), dim3(SCAN_BLOCK), 0, s.stream, in, out, n, n_add,
-                           (int32_t *)nullptr);
-        return EBVO_OK;
-    }
-    const int nb1 = (nb0 + SCAN_TILE - 1) / SCAN_TILE;
-    if (nb1 > SCAN_TILE)
-        return EBVO_ERR_ARG; // > 1e9 elements
-    int rc = ebvo_grow(ctx, s, s.scan_tmp, sizeof(int32_t) * (size_t)(2 * nb0 + 2 * nb1 + 16));
+    if (nb < 1 || nb > SCAN_BATCH || cap_n < 0)
+        return EBVO_ERR_ARG;
+    S.tiles = (cap_n + SCAN_TILE - 1) / SCAN_TILE;
+    if (S.tiles < 1)
+        S.tiles = 1;
+    int rc = ebvo_grow(ctx, s, s.scan_tmp, sizeof(int32_t) * (size_t)S.tiles * SCAN_BATCH);
     if (rc)
         return rc;
-    int32_t *sums0 = (int32_t *)s.scan_tmp.p, *offs0 = sums0 + nb0, *sums1 = offs0 + nb0, *offs1 = sums1 + nb1;
-    const DevN n0{nb0, nullptr}, n1{nb1, nullptr};
-    hipLaunchKernelGGL(scan_tile_kernel, dim3(nb0), dim3(SCAN_BLOCK), 0, s.stream, in, out, n, n_add, sums0);
-    if (nb1 <= 1)
-    {
-        hipLaunchKernelGGL(scan_tile_kernel, dim3(1), dim3(SCAN_BLOCK), 0, s.stream, (const int32_t *)sums0, offs0, n0,
-                           0, (int32_t *)nullptr);
-    }
-    else
-    {
-        hipLaunchKernelGGL(scan_tile_kernel, dim3(nb1), dim3(SCAN_BLOCK), 0, s.stream, (const int32_t *)sums0, offs0,
-                           n0, 0, sums1);
-        hipLaunchKernelGGL(scan_tile_kernel, dim3(1), dim3(SCAN_BLOCK), 0, s.stream, (const int32_t *)sums1, offs1, n1,
-                           0, (int32_t *)nullptr);
-        hipLaunchKernelGGL(scan_add_kernel, dim3((nb0 + 255) / 256), dim3(256), 0, s.stream, offs0, n0, 0,
-                           (const int32_t *)offs1);
-    }
-    hipLaunchKernelGGL(scan_add_kernel, dim3((cap_n + 255) / 256), dim3(256), 0, s.stream, out, n, n_add,
-                       (const int32_t *)offs0);
+    S.sums = (int32_t *)s.scan_tmp.p;
+    if (S.tiles > 1)
+        hipLaunchKernelGGL(scan_reduce_kernel, dim3(S.tiles - 1, nb), dim3(SCAN_BLOCK), 0, s.stream, S);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3(S.tiles, nb), dim3(SCAN_BLOCK), 0, s.stream, S);
     return EBVO_OK;
+}
+
+int device_exclusive_scan(ebvo_ctx *ctx, Slot &s, const int32_t *in, int32_t *out, DevN n, int n_add, int cap_n)
+{
+    ScanBatch S{};
+    S.in[0] = in;
+    S.out[0] = out;
+    S.n[0] = n;
+    S.n_add = n_add;
+    return device_exclusive_scan_batch(ctx, s, S, 1, cap_n);
 }
 
 inline unsigned blocks_for(int64_t items, int per_block, int max_blocks)
@@ -972,6 +1092,41 @@ inline unsigned blocks_for(int64_t items, int per_block, int max_blocks)
 }
 
 } // namespace
+
+int ebvo_clear_enqueue(ebvo_ctx *ctx, Slot &s, int32_t *const ptrs[], const int counts[], int n)
+{
+    if (n < 1 || n > EBVO_CLEAR_MAX)
+        return EBVO_ERR_ARG;
+    ClearList C{};
+    int most = 1;
+    for (int k = 0; k < n; ++k)
+    {
+        C.p[k] = ptrs[k];
+        C.n[k] = counts[k];
+        most = counts[k] > most ? counts[k] : most;
+    }
+    hipLaunchKernelGGL(clear_kernel, dim3(blocks_for(most, 256, 64), n), dim3(256), 0, s.stream, C);
+    EBVO_HIP(ctx, hipGetLastError());
+    return EBVO_OK;
+}
+
+int ebvo_device_scan4(ebvo_ctx *ctx, Slot &s, const int32_t *const in[4], int32_t *const out[4],
+                      const int32_t *const n_dev[4], int nb, int cap_n)
+{
+    ProfScope ps(ctx, s, K_SCAN);
+    ScanBatch S{};
+    for (int k = 0; k < nb && k < SCAN_BATCH; ++k)
+    {
+        S.in[k] = in[k];
+        S.out[k] = out[k];
+        S.n[k] = DevN{0, n_dev[k]};
+    }
+    int rc = device_exclusive_scan_batch(ctx, s, S, nb, cap_n);
+    if (rc)
+        return rc;
+    EBVO_HIP(ctx, hipGetLastError());
+    return EBVO_OK;
+}
 
 int ebvo_device_scan(ebvo_ctx *ctx, Slot &s, const int32_t *in, int32_t *out, int n_host, const int32_t *n_dev, int n_add,
                      int cap_n)
@@ -996,8 +1151,8 @@ int match_lines_enqueue(ebvo_ctx *ctx, Slot &s, const double *d_F, const ebvo_ed
     return EBVO_OK;
 }
 
-static CandParams cand_params(int nL, const int32_t *d_nL, int nR, const int32_t *d_nR, double epi_thr, double max_disp,
-                              double orient_thr_deg, int stage_mask, int64_t cap)
+static CandParams cand_params(Slot &s, int nL, const int32_t *d_nL, int nR, const int32_t *d_nR, double epi_thr,
+                              double max_disp, double orient_thr_deg, int stage_mask, int64_t cap)
 {
     CandParams P;
     P.epi_thr = epi_thr;
@@ -1007,6 +1162,8 @@ static CandParams cand_params(int nL, const int32_t *d_nL, int nR, const int32_t
     P.nL = DevN{nL, d_nL};
     P.nR = DevN{nR, d_nR};
     P.cap = cap;
+    P.stage = (int32_t *)s.cand_stage.p;
+    P.tile_flag = (int32_t *)s.cand_tileflag.p;
     return P;
 }
 
@@ -1015,8 +1172,11 @@ int match_candidates_fill_enqueue(ebvo_ctx *ctx, Slot &s, const ebvo_edge *d_L, 
                                   const double *d_lines, double epi_thr, double max_disp, double orient_thr_deg,
                                   int stage_mask)
 {
-    const CandParams P = cand_params(nL, d_nL, nR, d_nR, epi_thr, max_disp, orient_thr_deg, stage_mask, s.cap_pairs);
+    const CandParams P = cand_params(s, nL, d_nL, nR, d_nR, epi_thr, max_disp, orient_thr_deg, stage_mask, s.cap_pairs);
     ProfScope ps(ctx, s, K_CAND_FILL);
+    hipLaunchKernelGGL(candidates_copy_kernel, dim3(blocks_for(d_nL ? cap_edges : nL, 256, 1024)), dim3(256), 0, s.stream,
+                       (const int32_t *)s.row_ptr.p, (const int32_t *)s.cand_stage.p, DevN{nL, d_nL}, s.cap_pairs,
+                       (int32_t *)s.col_idx.p);
     hipLaunchKernelGGL(candidates_kernel<true>, dim3(blocks_for(d_nL ? cap_edges : nL, 256, 4096)), dim3(256), 0,
                        s.stream, d_L, d_R, d_lines, (const Box *)s.boxes_chunk.p, (const Box *)s.boxes_group.p, P,
                        (int32_t *)nullptr, (const int32_t *)s.row_ptr.p, (int32_t *)s.col_idx.p,
@@ -1040,10 +1200,19 @@ int match_candidates_enqueue(ebvo_ctx *ctx, Slot &s, const ebvo_edge *d_L, int n
         return rc;
     if ((rc = ebvo_grow(ctx, s, s.boxes_group, sizeof(Box) * (size_t)capgroups)))
         return rc;
+    const size_t ntiles = ((size_t)capL + 255) / 256 + 1;
+    if ((rc = ebvo_grow(ctx, s, s.cand_stage, sizeof(int32_t) * STAGE * ((size_t)capL + 1))))
+        return rc;
+    if ((rc = ebvo_grow(ctx, s, s.cand_tileflag, sizeof(int32_t) * ntiles)))
+        return rc;
     int32_t *cnt = (int32_t *)s.cand_cnt.p;
-    // cnt[i >= nL] must read as 0 in the scan: the scan masks by n, only element nL itself needs a zero
-    EBVO_HIP(ctx, hipMemsetAsync(cnt, 0, sizeof(int32_t) * ((size_t)capL + 1), s.stream));
-    EBVO_HIP(ctx, hipMemsetAsync(s.d_total, 0, sizeof(unsigned long long), s.stream));
+    {
+        // tile flags and the 64-bit total; cnt[nL] (the scan's trailing zero) is written by the counting kernel
+        int32_t *ptrs[2] = {(int32_t *)s.cand_tileflag.p, (int32_t *)s.d_total};
+        const int counts[2] = {(int)ntiles, 2};
+        if ((rc = ebvo_clear_enqueue(ctx, s, ptrs, counts, 2)))
+            return rc;
+    }
     {
         ProfScope ps(ctx, s, K_BOXES);
         hipLaunchKernelGGL(chunk_boxes_kernel, dim3(blocks_for(capchunks, 256, 256)), dim3(256), 0, s.stream, d_R,
@@ -1051,7 +1220,7 @@ int match_candidates_enqueue(ebvo_ctx *ctx, Slot &s, const ebvo_edge *d_L, int n
         hipLaunchKernelGGL(group_boxes_kernel, dim3(blocks_for(capgroups, 256, 16)), dim3(256), 0, s.stream,
                            (const Box *)s.boxes_chunk.p, DevN{nR, d_nR}, (Box *)s.boxes_group.p);
     }
-    const CandParams P = cand_params(nL, d_nL, nR, d_nR, epi_thr, max_disp, orient_thr_deg, stage_mask, s.cap_pairs);
+    const CandParams P = cand_params(s, nL, d_nL, nR, d_nR, epi_thr, max_disp, orient_thr_deg, stage_mask, s.cap_pairs);
     {
         ProfScope ps(ctx, s, K_CAND_COUNT);
         hipLaunchKernelGGL(candidates_kernel<false>, dim3(blocks_for(capL, 256, 4096)), dim3(256), 0, s.stream, d_L, d_R,
@@ -1080,11 +1249,45 @@ int match_patches_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_img, int h, i
     int rc;
     if ((rc = ebvo_grow(ctx, s, s.sincos, sizeof(double2) * (size_t)cap)))
         return rc;
+    PatchBatch B{};
+    B.img[0] = d_img;
+    B.edges[0] = d_edges;
+    B.n[0] = DevN{n, d_n};
+    B.sc[0] = (double2 *)s.sincos.p;
+    B.raw[0] = d_raw;
+    B.norm[0] = d_norm;
+    B.flag[0] = d_flag;
     ProfScope ps(ctx, s, K_PATCHES);
-    hipLaunchKernelGGL(sincos_edges_kernel, dim3(blocks_for(cap, 256, 1024)), dim3(256), 0, s.stream, d_edges,
-                       DevN{n, d_n}, (double2 *)s.sincos.p);
-    hipLaunchKernelGGL(patches_kernel, dim3(blocks_for((int64_t)cap * 16, 256, 4096)), dim3(256), 0, s.stream, d_img, h,
-                       w, pitch, d_edges, (const double2 *)s.sincos.p, DevN{n, d_n}, d_raw, d_norm, d_flag);
+    hipLaunchKernelGGL(sincos_batch_kernel, dim3(blocks_for(cap, 256, 1024), 1), dim3(256), 0, s.stream, B);
+    hipLaunchKernelGGL(patches_kernel, dim3(blocks_for((int64_t)cap * 16, 256, 4096), 1), dim3(256), 0, s.stream, B, h, w,
+                       pitch);
+    EBVO_HIP(ctx, hipGetLastError());
+    return EBVO_OK;
+}
+
+// Normalised-patch banks (and sentinel flags) of the left and the right TOED edges of the resident pair: one sin/cos
+// launch and one sampling launch for both images.  The raw left patches are only produced when the host fetches them.
+int match_patch_banks_enqueue(ebvo_ctx *ctx, Slot &s, int h, int w, int cap_edges)
+{
+    int rc;
+    if ((rc = ebvo_grow(ctx, s, s.sincos, sizeof(double2) * 2 * (size_t)cap_edges)))
+        return rc;
+    PatchBatch B{};
+    for (int k = 0; k < 2; ++k)
+    {
+        B.img[k] = s.im[k].img;
+        B.edges[k] = s.im[k].edges;
+        B.n[k] = DevN{0, s.im[k].counts + 1};
+        B.sc[k] = (double2 *)s.sincos.p + (size_t)k * cap_edges;
+    }
+    B.norm[0] = (float *)s.patches_norm.p;
+    B.flag[0] = (uint8_t *)s.patches_flag.p;
+    B.norm[1] = (float *)s.patches_norm_r.p;
+    B.flag[1] = (uint8_t *)s.patches_flag_r.p;
+    ProfScope ps(ctx, s, K_PATCHES);
+    hipLaunchKernelGGL(sincos_batch_kernel, dim3(blocks_for(cap_edges, 256, 512), 2), dim3(256), 0, s.stream, B);
+    hipLaunchKernelGGL(patches_kernel, dim3(blocks_for((int64_t)cap_edges * 16, 256, 2048), 2), dim3(256), 0, s.stream, B,
+                       h, w, w);
     EBVO_HIP(ctx, hipGetLastError());
     return EBVO_OK;
 }
@@ -1125,7 +1328,7 @@ int match_ncc_pairs_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_imgR, int h
 int match_ncc_banked_enqueue(ebvo_ctx *ctx, Slot &s, int nL, const int32_t *d_nL, int cap_edges, int64_t n_pairs_host,
                              double thr)
 {
-    EBVO_HIP(ctx, hipMemsetAsync(s.d_matches, 0, sizeof(int32_t), s.stream));
+    s.n_match_part = 0;
     if (!d_nL && (n_pairs_host <= 0 || nL <= 0))
         return EBVO_OK;
     const DevN nLd{nL, d_nL};
@@ -1138,13 +1341,13 @@ int match_ncc_banked_enqueue(ebvo_ctx *ctx, Slot &s, int nL, const int32_t *d_nL
     }
     {
         ProfScope ps(ctx, s, K_NCC_PAIRS);
-        hipLaunchKernelGGL(ncc_banked_kernel, dim3(blocks_for(cap_items * 16, 256, 4096)), dim3(256), 0, s.stream,
+        const int nblk = blocks_for(cap_items * 16, 256, EBVO_MATCH_PARTS);
+        s.n_match_part = nblk;
+        hipLaunchKernelGGL(ncc_banked_kernel, dim3(nblk), dim3(256), 0, s.stream,
                            (const float *)s.patches_norm.p, (const uint8_t *)s.patches_flag.p,
                            (const float *)s.patches_norm_r.p, (const uint8_t *)s.patches_flag_r.p,
                            (const int32_t *)s.pair_left.p, (const int32_t *)s.col_idx.p, np, thr, (double *)s.sims.p,
-                           (double *)s.best.p, (uint8_t *)s.keep.p);
-        hipLaunchKernelGGL(count_keep_kernel, dim3(256), dim3(256), 0, s.stream, (const uint8_t *)s.keep.p, np,
-                           s.d_matches);
+                           (double *)s.best.p, (uint8_t *)s.keep.p, s.d_matches);
     }
     EBVO_HIP(ctx, hipGetLastError());
     return EBVO_OK;
@@ -1154,7 +1357,7 @@ int match_pair_result_enqueue(ebvo_ctx *ctx, Slot &s)
 {
     hipLaunchKernelGGL(pair_result_kernel, dim3(1), dim3(64), 0, s.stream, (const int32_t *)s.im[0].counts,
                        (const int32_t *)s.im[1].counts, (const unsigned long long *)s.d_total,
-                       (const int32_t *)s.d_matches, s.cap_pairs, s.d_result);
+                       (const int32_t *)s.d_matches, s.n_match_part, s.cap_pairs, s.d_result);
     EBVO_HIP(ctx, hipGetLastError());
     EBVO_HIP(ctx, hipMemcpyAsync(s.h_result, s.d_result, sizeof(PairResult), hipMemcpyDeviceToHost, s.stream));
     return EBVO_OK;

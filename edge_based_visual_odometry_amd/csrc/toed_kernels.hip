@@ -1141,7 +1141,25 @@ int toed_enqueue(ebvo_ctx *ctx, Slot &s, int n_img, int h, int w, hipEvent_t ev_
         B.rec[k] = (CandRec *)ws.cand_rec;
         B.cand_flag[k] = ws.cand_flag;
         B.cand_off[k] = ws.cand_off;
-        EBVO_HIP(ctx, hipMemsetAsync(ws.row_cnt, 0, sizeof(int32_t) * 2 * H2, s.stream));
+    }
+    {
+        // per-row counters (and the hybrid path's list counters) of every image: one launch
+        int32_t *ptrs[2 * MAX_BATCH];
+        int counts[2 * MAX_BATCH];
+        int nc = 0;
+        for (int k = 0; k < n_img; ++k)
+        {
+            ptrs[nc] = s.im[k].row_cnt;
+            counts[nc++] = 2 * H2;
+            if (ctx->toed_mode == EBVO_TOED_HYBRID)
+            {
+                ptrs[nc] = s.im[k].cand_lcount;
+                counts[nc++] = 12;
+            }
+        }
+        int rc = ebvo_clear_enqueue(ctx, s, ptrs, counts, nc);
+        if (rc)
+            return rc;
     }
     if (ctx->toed_mode == EBVO_TOED_HYBRID)
     {
@@ -1187,7 +1205,6 @@ int toed_enqueue(ebvo_ctx *ctx, Slot &s, int n_img, int h, int w, hipEvent_t ev_
                 E.cd[k].sector = ws.cand_sector;
                 E.rec[k] = (CandRec *)ws.cand_rec;
                 E.cand_flag[k] = ws.cand_flag;
-                EBVO_HIP(ctx, hipMemsetAsync(ws.cand_lcount, 0, sizeof(int32_t) * 12, s.stream));
             }
             const ToedTables *T = (const ToedTables *)g_tables_dev[ctx->device];
             {
@@ -1205,13 +1222,24 @@ int toed_enqueue(ebvo_ctx *ctx, Slot &s, int n_img, int h, int w, hipEvent_t ev_
         }
         if (ev_conv_end)
             EBVO_HIP(ctx, hipEventRecord(ev_conv_end, s.stream));
-        for (int k = 0; k < n_img; ++k)
+        for (int k0 = 0; k0 < n_img; k0 += 2)
         {
-            const int32_t *d_n = s.im[k].counts + 2;
+            // "is a maximum" and "is a kept maximum" flags of up to two images: four scans, one pair of launches
+            const int32_t *in[4];
+            int32_t *out[4];
+            const int32_t *nd[4];
+            int nb = 0;
+            for (int k = k0; k < n_img && k < k0 + 2; ++k)
+            {
+                in[nb] = s.im[k].cand_flag;
+                out[nb] = s.im[k].cand_off;
+                nd[nb++] = s.im[k].counts + 2;
+                in[nb] = s.im[k].cand_flag + cap;
+                out[nb] = s.im[k].cand_off + (cap + 1);
+                nd[nb++] = s.im[k].counts + 2;
+            }
             int rc;
-            if ((rc = ebvo_device_scan(ctx, s, s.im[k].cand_flag, s.im[k].cand_off, 0, d_n, 0, cap)))
-                return rc;
-            if ((rc = ebvo_device_scan(ctx, s, s.im[k].cand_flag + cap, s.im[k].cand_off + (cap + 1), 0, d_n, 0, cap)))
+            if ((rc = ebvo_device_scan4(ctx, s, in, out, nd, nb, cap)))
                 return rc;
         }
         {
