@@ -196,7 +196,7 @@ static int slot_create(ebvo_ctx *ctx, Slot **out)
         CK(hipMalloc(&ws.edges, sizeof(ebvo_edge) * (size_t)ctx->cap_edges));
         CK(hipMalloc(&ws.all4, sizeof(double) * 4 * (size_t)ctx->cap_edges));
     }
-    CK(hipMalloc(&s->d_total, sizeof(unsigned long long)));
+    CK(hipMalloc(&s->d_total, sizeof(unsigned long long) * (1 + EBVO_TOTAL_PARTS)));
     CK(hipMalloc(&s->d_matches, sizeof(int32_t) * EBVO_MATCH_PARTS));
     CK(hipMalloc(&s->d_sizes, sizeof(int32_t) * 4));
     CK(hipMalloc(&s->d_F, sizeof(double) * 9));

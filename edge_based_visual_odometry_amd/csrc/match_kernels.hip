@@ -36,7 +36,8 @@ namespace
 constexpr int CHUNK = 16;        // edges per chunk box
 constexpr int GROUP = 64;        // chunks per group box (1024 edges)
 constexpr int BATCH = 64;        // chunks staged in LDS at a time (1024 edges, 24 KB)
-constexpr int STAGE = 16;        // candidates per left edge kept by the counting pass (rows beyond it are refilled)
+constexpr int TILE = 64;         // left edges per block of the candidate search
+constexpr int STAGE = 32;        // candidates per left edge kept by the counting pass (rows beyond it are refilled)
 constexpr double BOX_SLACK = 1e-6;
 
 struct Box
@@ -173,40 +174,44 @@ struct LeftCtx
 //     all roundings involved are <= 2^-53 relative); only inside that sliver is the division evaluated.
 //   disparity (:545-546): fl(sqrt(fl(dx*dx + dy*dy))) <= D, same argument on s = fl(dx*dx + dy*dy) against D^2.
 //   orientation (:887-901): as written.
+// Straight-line form: the three quantities are always evaluated and compared against both margins; only a lane inside
+// a 2^-50 sliver (practically never) takes the branch with the division / square root.  One lane = one pair in the
+// candidate walk, so an early exit saves nothing unless all 64 lanes take it, while every nested exit costs
+// exec-mask bookkeeping.
 __device__ inline bool pair_passes(const LeftCtx &l, double rx, double ry, double rth, const CandParams &P)
 {
+    bool e_fast = true, e_maybe = true, d_fast = true, d_maybe = true, o_ok = true;
+    double num = 0.0, s = 0.0;
     if (P.mask & EBVO_STAGE_EPIPOLAR)
     {
-        const double num = fabs(l.a * rx + l.b * ry + l.c);
-        if (!(num < l.t_lo))
-        {
-            if (!(num <= l.t_hi)) // also catches NaN
-                return false;
-            if (!(num / l.nrm < P.epi_thr))
-                return false;
-        }
+        num = fabs(l.a * rx + l.b * ry + l.c);
+        e_fast = num < l.t_lo;
+        e_maybe = num <= l.t_hi; // false for NaN
     }
     if (P.mask & EBVO_STAGE_DISPARITY)
     {
         const double dx = l.lx - rx, dy = l.ly - ry;
-        const double s = dx * dx + dy * dy;
-        if (!(s < l.s_lo))
-        {
-            if (!(s <= l.s_hi))
-                return false;
-            if (!(sqrt(s) <= P.max_disp))
-                return false;
-        }
+        s = dx * dx + dy * dy;
+        d_fast = s < l.s_lo;
+        d_maybe = s <= l.s_hi;
     }
     if (P.mask & EBVO_STAGE_ORIENTATION)
     {
         double od = fabs((l.lth - rth) * 0x1.ca5dc1a63c1f8p+5 /* 180.0 / M_PI */);
         if (od > 180.0)
             od = 360.0 - od;
-        if (!(od < P.orient_thr || fabs(od - 180.0) < P.orient_thr))
-            return false;
+        o_ok = od < P.orient_thr || fabs(od - 180.0) < P.orient_thr;
     }
-    return true;
+    bool ok = o_ok && e_maybe && d_maybe;
+    if (ok && !(e_fast && d_fast))
+    {
+        asm volatile("" : "+v"(num), "+v"(s)); // keeps the division and the square root inside the rare branch
+        if (!e_fast)
+            ok = num / l.nrm < P.epi_thr;
+        if (ok && !d_fast)
+            ok = sqrt(s) <= P.max_disp;
+    }
+    return ok;
 }
 
 // Conservative bounding box of one left edge's search region {band} ∩ {disparity square}.
@@ -254,6 +259,18 @@ __device__ inline double wave_max(double v)
     return v;
 }
 
+// Candidate search.  One block = one tile of TILE (64) consecutive left edges; the right edges are visited through
+// two levels of index-range bounding boxes (chunks of 16 edges, groups of 64 chunks):
+//   1. wave 0 builds the 64 left-edge contexts (LDS) and the union of their search regions;
+//   2. all 256 threads select the groups, then the chunks, whose boxes meet the union (ordered LDS compaction, so
+//      chunks stay in ascending index), and stage the selected chunks' edges in LDS, 64 chunks at a time;
+//   3. walk: sixteen lanes per left edge (four rounds of sixteen left edges).  The sixteen lanes test the staged
+//      chunk boxes against their edge's own region (four ballots -> a 64-bit chunk mask), then take the marked
+//      chunks in ascending order, ONE pair test per lane per chunk; a ballot gives the 16-bit hit mask, hence every
+//      hit's rank in the row.  ~2 M threads instead of one per left edge: the walk used to be a serial chain of
+//      ~120 dependent LDS reads + tests per lane with two waves per SIMD to hide it behind.
+// The counting pass also keeps the first STAGE candidates of every row; after the scan of the counts a copy kernel
+// completes every row that fits, and the FILL pass only redoes tiles that hold a longer row.
 template <bool FILL>
 __global__ __launch_bounds__(256) void candidates_kernel(const ebvo_edge *__restrict__ L,
                                                          const ebvo_edge *__restrict__ R,
@@ -262,22 +279,25 @@ __global__ __launch_bounds__(256) void candidates_kernel(const ebvo_edge *__rest
                                                          CandParams P, int32_t *__restrict__ cnt,
                                                          const int32_t *__restrict__ row_ptr,
                                                          int32_t *__restrict__ col_idx,
-                                                         unsigned long long *__restrict__ total)
+                                                         unsigned long long *__restrict__ total_part)
 {
     __shared__ double s_x[BATCH * CHUNK], s_y[BATCH * CHUNK], s_th[BATCH * CHUNK];
     __shared__ Box s_box[BATCH];
+    __shared__ LeftCtx s_left[TILE];
     __shared__ int s_round[256];   // chunks selected in the current round, ascending
     __shared__ int s_groups[256];  // groups selected in the current group round, ascending
     __shared__ int s_wcnt[4];
-    __shared__ double s_red[4][4];
+    __shared__ double s_red[4];
     __shared__ unsigned long long s_tot[4];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int gid = tid >> 4, e = tid & 15, gshift = lane & 48; // 16-lane group, lane in group, group's bit offset
     const int nL = devn(P.nL), nR = devn(P.nR);
     const int nchunks = (nR + CHUNK - 1) / CHUNK, ngroups = (nchunks + GROUP - 1) / GROUP;
     const double d2 = P.max_disp * P.max_disp;
     const double D = P.max_disp + BOX_SLACK, band = P.epi_thr + BOX_SLACK;
     const double inf = __builtin_inf();
+    unsigned long long blk_total = 0; // thread 0: candidates counted by this block
 
     // ordered (index-preserving) compaction of one value per selected thread into an LDS list
     auto compact = [&](bool sel, int value, int *list) -> int {
@@ -300,58 +320,63 @@ __global__ __launch_bounds__(256) void candidates_kernel(const ebvo_edge *__rest
 
     if (!FILL && blockIdx.x == 0 && tid == 0)
         cnt[nL] = 0; // the scan covers nL + 1 counts: row_ptr[nL] = total
-    // one tile = 256 consecutive left edges; grid-stride so the launch does not depend on nL
-    for (int tile = blockIdx.x; tile * 256 < nL; tile += gridDim.x)
+    // grid-stride over the tiles so the launch does not depend on nL
+    for (int tile = blockIdx.x; tile * TILE < nL; tile += gridDim.x)
     {
         if (FILL && !P.tile_flag[tile]) // every row of this tile was completed from the staging area
             continue;
-        const int i = tile * 256 + tid;
-        const bool live = i < nL;
-        const int il = live ? i : 0;
-        LeftCtx l;
-        l.lx = L[il].x; l.ly = L[il].y; l.lth = L[il].theta;
-        l.a = lines[(size_t)il * 3]; l.b = lines[(size_t)il * 3 + 1]; l.c = lines[(size_t)il * 3 + 2];
-        l.nrm = sqrt((l.a * l.a) + (l.b * l.b));
-        l.ah = l.a / l.nrm; l.bh = l.b / l.nrm; l.ch = l.c / l.nrm;
-        const double t = P.epi_thr * l.nrm;
-        l.t_lo = t * (1.0 - 0x1p-50); l.t_hi = t * (1.0 + 0x1p-50);
-        l.s_lo = d2 * (1.0 - 0x1p-50); l.s_hi = d2 * (1.0 + 0x1p-50);
-
-        // union of the tile's search regions
-        Box rb = region_box(l, D, band, P.mask);
-        if (!live) { rb.x0 = inf; rb.x1 = -inf; rb.y0 = inf; rb.y1 = -inf; }
+        // ---- 1. left contexts and the union of the tile's search regions (wave 0)
+        if (wid == 0)
         {
+            const int i = tile * TILE + lane;
+            const bool live = i < nL;
+            const int il = live ? i : 0;
+            LeftCtx l;
+            l.lx = L[il].x; l.ly = L[il].y; l.lth = L[il].theta;
+            l.a = lines[(size_t)il * 3]; l.b = lines[(size_t)il * 3 + 1]; l.c = lines[(size_t)il * 3 + 2];
+            l.nrm = sqrt((l.a * l.a) + (l.b * l.b));
+            l.ah = l.a / l.nrm; l.bh = l.b / l.nrm; l.ch = l.c / l.nrm;
+            const double t = P.epi_thr * l.nrm;
+            l.t_lo = t * (1.0 - 0x1p-50); l.t_hi = t * (1.0 + 0x1p-50);
+            l.s_lo = d2 * (1.0 - 0x1p-50); l.s_hi = d2 * (1.0 + 0x1p-50);
+            Box rb = region_box(l, D, band, P.mask);
+            if (!live) { rb.x0 = inf; rb.x1 = -inf; rb.y0 = inf; rb.y1 = -inf; }
+            s_left[lane] = l;
             const double a0 = wave_min(rb.x0), a1 = wave_max(rb.x1), b0 = wave_min(rb.y0), b1 = wave_max(rb.y1);
-            if (lane == 0) { s_red[wid][0] = a0; s_red[wid][1] = a1; s_red[wid][2] = b0; s_red[wid][3] = b1; }
+            if (lane == 0) { s_red[0] = a0; s_red[1] = a1; s_red[2] = b0; s_red[3] = b1; }
         }
         __syncthreads();
         Box U;
-        U.x0 = fmin(fmin(s_red[0][0], s_red[1][0]), fmin(s_red[2][0], s_red[3][0]));
-        U.x1 = fmax(fmax(s_red[0][1], s_red[1][1]), fmax(s_red[2][1], s_red[3][1]));
-        U.y0 = fmin(fmin(s_red[0][2], s_red[1][2]), fmin(s_red[2][2], s_red[3][2]));
-        U.y1 = fmax(fmax(s_red[0][3], s_red[1][3]), fmax(s_red[2][3], s_red[3][3]));
+        U.x0 = s_red[0]; U.x1 = s_red[1]; U.y0 = s_red[2]; U.y1 = s_red[3];
         auto meets_union = [&](const Box &bx) {
             return !(bx.x0 > U.x1 || bx.x1 < U.x0 || bx.y0 > U.y1 || bx.y1 < U.y0);
         };
 
-        int n = 0;
-        int64_t o = FILL ? (int64_t)row_ptr[il] : 0;
-        // Two levels of index-range boxes: groups of 64 chunks first (one test per thread), then the chunks of
-        // the selected groups, four groups (256 chunks) at a time; chunks are visited in ascending index.
+        // the four left edges of this 16-lane group (one per walk round): hit counts and output cursors
+        int n[4] = {0, 0, 0, 0};
+        int64_t o[4] = {0, 0, 0, 0};
+        if (FILL)
+        {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+            {
+                const int i = tile * TILE + r * 16 + gid;
+                o[r] = (int64_t)row_ptr[i < nL ? i : 0];
+            }
+        }
         for (int g0 = 0; g0 < ngroups; g0 += 256)
         {
             const int g = g0 + tid;
             const int ngsel = compact(g < ngroups && meets_union(gb[g < ngroups ? g : 0]), g, s_groups);
             for (int q = 0; q < ngsel; q += 4)
             {
-                // ---- chunks of up to four selected groups: one chunk per thread
+                // ---- 2. chunks of up to four selected groups: one chunk per thread
                 const int gq = q + (tid >> 6);
                 const int c = (gq < ngsel) ? s_groups[gq] * GROUP + (tid & 63) : nchunks;
                 const int nsel = compact(c < nchunks && meets_union(cb[c < nchunks ? c : 0]), c, s_round);
                 for (int b0 = 0; b0 < nsel; b0 += BATCH)
                 {
                     const int mb = min(BATCH, nsel - b0);
-                    // ---- stage the batch: edges and boxes of the selected chunks
                     for (int idx = tid; idx < mb * CHUNK; idx += 256)
                     {
                         const int k = s_round[b0 + idx / CHUNK] * CHUNK + (idx % CHUNK);
@@ -365,49 +390,50 @@ __global__ __launch_bounds__(256) void candidates_kernel(const ebvo_edge *__rest
                     if (tid < mb)
                         s_box[tid] = cb[s_round[b0 + tid]];
                     __syncthreads();
-                    if (live)
-                    {
-                        // which staged chunks can meet this lane's region (uniform loop, one bit per chunk) ...
-                        unsigned long long pm = 0;
-                        for (int j = 0; j < mb; ++j)
-                            if (box_may_match(s_box[j], l.lx, l.ly, l.ah, l.bh, l.ch, D, band, P.mask))
-                                pm |= 1ull << j;
-                        // ... then each lane visits ITS chunks, ascending; lanes advance by rank, not by chunk id
-                        while (pm)
-                        {
-                            const int j = __ffsll((long long)pm) - 1;
-                            pm &= pm - 1;
-                            const int kbase = s_round[b0 + j] * CHUNK;
-                            unsigned hits = 0;
+                    // ---- 3. walk
 #pragma unroll
-                            for (int e = 0; e < CHUNK; ++e)
+                    for (int r = 0; r < 4; ++r)
+                    {
+                        const int li = r * 16 + gid;
+                        const int i = tile * TILE + li;
+                        const bool live = i < nL; // uniform in the group
+                        const LeftCtx l = s_left[li];
+                        // which staged chunks can meet this edge's region: lane e looks at boxes e, e+16, e+32, e+48
+                        unsigned long long pm = 0;
+#pragma unroll
+                        for (int k = 0; k < BATCH / 16; ++k)
+                        {
+                            const int j = k * 16 + e;
+                            const bool may = live && j < mb &&
+                                             box_may_match(s_box[j < mb ? j : 0], l.lx, l.ly, l.ah, l.bh, l.ch, D, band,
+                                                           P.mask);
+                            const unsigned long long bal = __ballot(may);
+                            pm |= ((bal >> gshift) & 0xffffull) << (16 * k);
+                        }
+                        // marked chunks in ascending order, one pair test per lane
+                        while (__any(pm != 0))
+                        {
+                            const bool act = pm != 0;
+                            const int j = act ? __ffsll((long long)pm) - 1 : 0;
+                            pm &= pm - 1; // 0 stays 0
+                            const int idx = j * CHUNK + e;
+                            const bool ok = act && pair_passes(l, s_x[idx], s_y[idx], s_th[idx], P);
+                            const unsigned hits = (unsigned)((__ballot(ok) >> gshift) & 0xffffull);
+                            if (ok)
                             {
-                                const int idx = j * CHUNK + e;
-                                const bool ok = pair_passes(l, s_x[idx], s_y[idx], s_th[idx], P);
-                                hits |= (ok ? 1u : 0u) << e;
-                            }
-                            if (FILL)
-                            {
-                                while (hits)
+                                const int rank = __popc(hits & ((1u << e) - 1u));
+                                const int k = s_round[b0 + j] * CHUNK + e;
+                                if (FILL)
                                 {
-                                    const int e = __ffs((int)hits) - 1;
-                                    hits &= hits - 1;
-                                    if (o < P.cap)
-                                        col_idx[o] = kbase + e;
-                                    ++o;
+                                    if (o[r] + rank < P.cap)
+                                        col_idx[o[r] + rank] = k;
                                 }
+                                else if (n[r] + rank < STAGE)
+                                    P.stage[(size_t)i * STAGE + n[r] + rank] = k;
                             }
-                            else
-                            {
-                                while (hits)
-                                {
-                                    const int e = __ffs((int)hits) - 1;
-                                    hits &= hits - 1;
-                                    if (n < STAGE)
-                                        P.stage[(size_t)i * STAGE + n] = kbase + e;
-                                    ++n;
-                                }
-                            }
+                            const int nh = __popc(hits);
+                            n[r] += nh;
+                            o[r] += nh;
                         }
                     }
                     __syncthreads();
@@ -416,28 +442,44 @@ __global__ __launch_bounds__(256) void candidates_kernel(const ebvo_edge *__rest
         }
         if (!FILL)
         {
-            if (live)
+            unsigned long long tsum = 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
             {
-                cnt[i] = n;
-                if (n > STAGE)
-                    P.tile_flag[tile] = 1; // benign race: every writer stores 1
+                const int i = tile * TILE + r * 16 + gid;
+                if (e == 0 && i < nL)
+                {
+                    cnt[i] = n[r];
+                    if (n[r] > STAGE)
+                        P.tile_flag[tile] = 1; // benign race: every writer stores 1
+                    tsum += (unsigned long long)n[r];
+                }
             }
-            // 64-bit total (one atomic per tile) guards the int32 CSR offsets and the buffer capacity
-            unsigned long long s = (unsigned long long)n;
+            // 64-bit total (guards the int32 CSR offsets and the buffer capacity): per-block partial, no atomics
             for (int d = 32; d > 0; d >>= 1)
-                s += __shfl_down(s, d);
+                tsum += __shfl_down(tsum, d);
             if (lane == 0)
-                s_tot[wid] = s;
+                s_tot[wid] = tsum;
             __syncthreads();
             if (tid == 0)
-            {
-                const unsigned long long tt = s_tot[0] + s_tot[1] + s_tot[2] + s_tot[3];
-                if (tt)
-                    atomicAdd(total, tt);
-            }
+                blk_total += s_tot[0] + s_tot[1] + s_tot[2] + s_tot[3];
         }
         __syncthreads();
     }
+    if (!FILL && tid == 0)
+        total_part[blockIdx.x] = blk_total;
+}
+
+// sum of the per-block candidate totals (host-buffer path; the pipeline sums them in pair_result_kernel)
+__global__ void total_sum_kernel(const unsigned long long *__restrict__ part, int n, unsigned long long *__restrict__ total)
+{
+    unsigned long long v = 0;
+    for (int k = threadIdx.x; k < n; k += 64)
+        v += part[k];
+    for (int d = 32; d > 0; d >>= 1)
+        v += __shfl_down(v, d);
+    if (threadIdx.x == 0)
+        *total = v;
 }
 
 // rows with at most STAGE candidates are completed from the staging area (the fill pass only redoes the rest)
@@ -974,10 +1016,15 @@ __global__ __launch_bounds__(256) void ncc_banked_kernel(const float *__restrict
 // Last kernel of a device-resident pair: gathers every count the host wants into one record (PairResult,
 // ebvo_internal.h).
 __global__ void pair_result_kernel(const int32_t *__restrict__ cntL, const int32_t *__restrict__ cntR,
-                                   const unsigned long long *__restrict__ total,
+                                   const unsigned long long *__restrict__ total_part, int n_total_part,
                                    const int32_t *__restrict__ match_part, int n_part, int64_t cap,
                                    PairResult *__restrict__ out)
 {
+    unsigned long long tot = 0;
+    for (int k = threadIdx.x; k < n_total_part; k += 64)
+        tot += total_part[k];
+    for (int d = 32; d > 0; d >>= 1)
+        tot += __shfl_down(tot, d);
     // one wave: the per-block match counts of ncc_banked_kernel are summed here
     int m = 0;
     for (int k = threadIdx.x; k < n_part; k += 64)
@@ -991,7 +1038,7 @@ __global__ void pair_result_kernel(const int32_t *__restrict__ cntL, const int32
     r.n_left = cntL[1];
     r.n_total_right = cntR[0];
     r.n_right = cntR[1];
-    r.n_pairs = (int64_t)*total;
+    r.n_pairs = (int64_t)tot;
     r.n_matches = m;
     r.overflow = (r.n_pairs > cap || r.n_pairs > 0x7fffffffll) ? 1 : 0;
     r.pad = 0;
@@ -1177,7 +1224,7 @@ int match_candidates_fill_enqueue(ebvo_ctx *ctx, Slot &s, const ebvo_edge *d_L, 
     hipLaunchKernelGGL(candidates_copy_kernel, dim3(blocks_for(d_nL ? cap_edges : nL, 256, 1024)), dim3(256), 0, s.stream,
                        (const int32_t *)s.row_ptr.p, (const int32_t *)s.cand_stage.p, DevN{nL, d_nL}, s.cap_pairs,
                        (int32_t *)s.col_idx.p);
-    hipLaunchKernelGGL(candidates_kernel<true>, dim3(blocks_for(d_nL ? cap_edges : nL, 256, 4096)), dim3(256), 0,
+    hipLaunchKernelGGL(candidates_kernel<true>, dim3(blocks_for(d_nL ? cap_edges : nL, TILE, 4096)), dim3(256), 0,
                        s.stream, d_L, d_R, d_lines, (const Box *)s.boxes_chunk.p, (const Box *)s.boxes_group.p, P,
                        (int32_t *)nullptr, (const int32_t *)s.row_ptr.p, (int32_t *)s.col_idx.p,
                        (unsigned long long *)nullptr);
@@ -1200,17 +1247,17 @@ int match_candidates_enqueue(ebvo_ctx *ctx, Slot &s, const ebvo_edge *d_L, int n
         return rc;
     if ((rc = ebvo_grow(ctx, s, s.boxes_group, sizeof(Box) * (size_t)capgroups)))
         return rc;
-    const size_t ntiles = ((size_t)capL + 255) / 256 + 1;
+    const size_t ntiles = ((size_t)capL + TILE - 1) / TILE + 1;
     if ((rc = ebvo_grow(ctx, s, s.cand_stage, sizeof(int32_t) * STAGE * ((size_t)capL + 1))))
         return rc;
     if ((rc = ebvo_grow(ctx, s, s.cand_tileflag, sizeof(int32_t) * ntiles)))
         return rc;
     int32_t *cnt = (int32_t *)s.cand_cnt.p;
     {
-        // tile flags and the 64-bit total; cnt[nL] (the scan's trailing zero) is written by the counting kernel
-        int32_t *ptrs[2] = {(int32_t *)s.cand_tileflag.p, (int32_t *)s.d_total};
-        const int counts[2] = {(int)ntiles, 2};
-        if ((rc = ebvo_clear_enqueue(ctx, s, ptrs, counts, 2)))
+        // tile flags; cnt[nL] (the scan's trailing zero) and the per-block totals are written by the counting kernel
+        int32_t *ptrs[1] = {(int32_t *)s.cand_tileflag.p};
+        const int counts[1] = {(int)ntiles};
+        if ((rc = ebvo_clear_enqueue(ctx, s, ptrs, counts, 1)))
             return rc;
     }
     {
@@ -1223,9 +1270,14 @@ int match_candidates_enqueue(ebvo_ctx *ctx, Slot &s, const ebvo_edge *d_L, int n
     const CandParams P = cand_params(s, nL, d_nL, nR, d_nR, epi_thr, max_disp, orient_thr_deg, stage_mask, s.cap_pairs);
     {
         ProfScope ps(ctx, s, K_CAND_COUNT);
-        hipLaunchKernelGGL(candidates_kernel<false>, dim3(blocks_for(capL, 256, 4096)), dim3(256), 0, s.stream, d_L, d_R,
-                           d_lines, (const Box *)s.boxes_chunk.p, (const Box *)s.boxes_group.p, P, cnt,
-                           (const int32_t *)nullptr, (int32_t *)nullptr, s.d_total);
+        const int nblk = blocks_for(capL, TILE, EBVO_TOTAL_PARTS);
+        s.n_total_part = nblk;
+        hipLaunchKernelGGL(candidates_kernel<false>, dim3(nblk), dim3(256), 0, s.stream, d_L, d_R, d_lines,
+                           (const Box *)s.boxes_chunk.p, (const Box *)s.boxes_group.p, P, cnt, (const int32_t *)nullptr,
+                           (int32_t *)nullptr, s.d_total + 1);
+        if (!fill) // host-buffer path reads the total back; the pipeline sums the parts in pair_result_kernel
+            hipLaunchKernelGGL(total_sum_kernel, dim3(1), dim3(64), 0, s.stream,
+                               (const unsigned long long *)(s.d_total + 1), nblk, s.d_total);
     }
     {
         ProfScope ps(ctx, s, K_SCAN);
@@ -1356,7 +1408,7 @@ int match_ncc_banked_enqueue(ebvo_ctx *ctx, Slot &s, int nL, const int32_t *d_nL
 int match_pair_result_enqueue(ebvo_ctx *ctx, Slot &s)
 {
     hipLaunchKernelGGL(pair_result_kernel, dim3(1), dim3(64), 0, s.stream, (const int32_t *)s.im[0].counts,
-                       (const int32_t *)s.im[1].counts, (const unsigned long long *)s.d_total,
+                       (const int32_t *)s.im[1].counts, (const unsigned long long *)(s.d_total + 1), s.n_total_part,
                        (const int32_t *)s.d_matches, s.n_match_part, s.cap_pairs, s.d_result);
     EBVO_HIP(ctx, hipGetLastError());
     EBVO_HIP(ctx, hipMemcpyAsync(s.h_result, s.d_result, sizeof(PairResult), hipMemcpyDeviceToHost, s.stream));
