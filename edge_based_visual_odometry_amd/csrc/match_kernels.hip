@@ -37,7 +37,7 @@ constexpr int CHUNK = 16;        // edges per chunk box
 constexpr int GROUP = 64;        // chunks per group box (1024 edges)
 constexpr int BATCH = 64;        // chunks staged in LDS at a time (1024 edges, 24 KB)
 constexpr int TILE = 64;         // left edges per block of the candidate search
-constexpr int STAGE = 32;        // candidates per left edge kept by the counting pass (rows beyond it are refilled)
+constexpr int STAGE = 64;        // candidates per left edge kept by the counting pass (rows beyond it are refilled)
 constexpr double BOX_SLACK = 1e-6;
 
 struct Box
@@ -487,13 +487,15 @@ __global__ void candidates_copy_kernel(const int32_t *__restrict__ row_ptr, cons
                                        int64_t cap, int32_t *__restrict__ col_idx)
 {
     const int nL = devn(nLd);
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nL; i += gridDim.x * blockDim.x)
+    const int e = threadIdx.x & 15; // sixteen lanes per row: coalesced within the row
+    const int rows = (gridDim.x * blockDim.x) >> 4;
+    for (int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 4; i < nL; i += rows)
     {
         const int64_t o = row_ptr[i];
         const int n = row_ptr[i + 1] - row_ptr[i];
         if (n > STAGE)
             continue;
-        for (int k = 0; k < n; ++k)
+        for (int k = e; k < n; k += 16)
             if (o + k < cap)
                 col_idx[o + k] = stage[(size_t)i * STAGE + k];
     }
@@ -1020,17 +1022,36 @@ __global__ void pair_result_kernel(const int32_t *__restrict__ cntL, const int32
                                    const int32_t *__restrict__ match_part, int n_part, int64_t cap,
                                    PairResult *__restrict__ out)
 {
+    // one block of 1024 threads: the per-block candidate totals and match counts are summed here
+    __shared__ unsigned long long s_t[16];
+    __shared__ int s_m[16];
     unsigned long long tot = 0;
-    for (int k = threadIdx.x; k < n_total_part; k += 64)
-        tot += total_part[k];
-    for (int d = 32; d > 0; d >>= 1)
-        tot += __shfl_down(tot, d);
-    // one wave: the per-block match counts of ncc_banked_kernel are summed here
     int m = 0;
-    for (int k = threadIdx.x; k < n_part; k += 64)
+    for (int k = threadIdx.x; k < n_total_part; k += blockDim.x)
+        tot += total_part[k];
+    for (int k = threadIdx.x; k < n_part; k += blockDim.x)
         m += match_part[k];
     for (int d = 32; d > 0; d >>= 1)
+    {
+        tot += __shfl_down(tot, d);
         m += __shfl_down(m, d);
+    }
+    if ((threadIdx.x & 63) == 0)
+    {
+        s_t[threadIdx.x >> 6] = tot;
+        s_m[threadIdx.x >> 6] = m;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        tot = 0;
+        m = 0;
+        for (int k = 0; k < (int)(blockDim.x >> 6); ++k)
+        {
+            tot += s_t[k];
+            m += s_m[k];
+        }
+    }
     if (threadIdx.x || blockIdx.x)
         return;
     PairResult r;
@@ -1221,7 +1242,7 @@ int match_candidates_fill_enqueue(ebvo_ctx *ctx, Slot &s, const ebvo_edge *d_L, 
 {
     const CandParams P = cand_params(s, nL, d_nL, nR, d_nR, epi_thr, max_disp, orient_thr_deg, stage_mask, s.cap_pairs);
     ProfScope ps(ctx, s, K_CAND_FILL);
-    hipLaunchKernelGGL(candidates_copy_kernel, dim3(blocks_for(d_nL ? cap_edges : nL, 256, 1024)), dim3(256), 0, s.stream,
+    hipLaunchKernelGGL(candidates_copy_kernel, dim3(blocks_for((int64_t)(d_nL ? cap_edges : nL) * 16, 256, 2048)), dim3(256), 0, s.stream,
                        (const int32_t *)s.row_ptr.p, (const int32_t *)s.cand_stage.p, DevN{nL, d_nL}, s.cap_pairs,
                        (int32_t *)s.col_idx.p);
     hipLaunchKernelGGL(candidates_kernel<true>, dim3(blocks_for(d_nL ? cap_edges : nL, TILE, 4096)), dim3(256), 0,
@@ -1407,7 +1428,7 @@ int match_ncc_banked_enqueue(ebvo_ctx *ctx, Slot &s, int nL, const int32_t *d_nL
 
 int match_pair_result_enqueue(ebvo_ctx *ctx, Slot &s)
 {
-    hipLaunchKernelGGL(pair_result_kernel, dim3(1), dim3(64), 0, s.stream, (const int32_t *)s.im[0].counts,
+    hipLaunchKernelGGL(pair_result_kernel, dim3(1), dim3(1024), 0, s.stream, (const int32_t *)s.im[0].counts,
                        (const int32_t *)s.im[1].counts, (const unsigned long long *)(s.d_total + 1), s.n_total_part,
                        (const int32_t *)s.d_matches, s.n_match_part, s.cap_pairs, s.d_result);
     EBVO_HIP(ctx, hipGetLastError());

@@ -209,3 +209,28 @@ def test_temporal_quads_at_sequence_scale(ctx):
     assert_bit_equal(sr, osr, "sim_right")
     assert_bit_equal(keep, okeep, "keep")
     assert n > 10000
+
+
+@pytest.mark.parametrize("mode", ["strict", "hybrid"])
+def test_fresh_contexts_are_deterministic(mode):
+    """Twelve fresh contexts (fresh, uninitialised device allocations each time) on the same pair, the first run of each
+    overflowing the pair buffers: every output must be byte-identical to the first context's.  Guards against any
+    read of memory the pipeline has not written itself."""
+    import hashlib
+    from edge_based_visual_odometry_amd.api import Context
+    l, r = synth.stereo_pair("s2", 120, 200)
+    ref = None
+    for it in range(12):
+        with Context(120, 200, toed_mode=mode) as c:
+            c.stereo_upload(l, r)
+            p = c.default_params(F_KITTI)
+            p.stage_mask = 1 if it % 2 == 0 else 7
+            cnt = c.stereo_run(p)
+            out = c.stereo_fetch(cnt, patches=True)
+            sig = {k: hashlib.sha1(np.ascontiguousarray(v).view(np.uint8).tobytes()).hexdigest() for k, v in out.items()}
+            sig["counts"] = (cnt.n_left, cnt.n_right, cnt.n_pairs, cnt.n_matches)
+        if it < 2:
+            ref = ref or {}
+            ref[it % 2] = sig
+        else:
+            assert sig == ref[it % 2], f"context #{it} differs: " + ", ".join(k for k in sig if sig[k] != ref[it % 2][k])
