@@ -182,7 +182,7 @@ static int slot_create(ebvo_ctx *ctx, Slot **out)
         CK(hipMalloc(&ws.maps, sizeof(double) * np2 * PL_NUM));
         CK(hipMalloc(&ws.flag, np2));
         CK(hipMalloc(&ws.row_cnt, sizeof(int32_t) * 2 * H2));
-        CK(hipMalloc(&ws.row_off, sizeof(int32_t) * 2 * (H2 + 1)));
+        CK(hipMalloc(&ws.row_off, sizeof(int32_t) * 3 * (H2 + 1)));
         CK(hipMalloc(&ws.counts, sizeof(int32_t) * 4));
         CK(hipMemset(ws.counts, 0, sizeof(int32_t) * 4));
         CK(hipMalloc(&ws.cand_rec, 40 * (size_t)ctx->cap_edges));

@@ -60,8 +60,8 @@ struct ImageWS
     uint8_t *img_base = nullptr;
     double *maps = nullptr;     // PL_NUM planes of 4 x H x W
     uint8_t *flag = nullptr;    // 2H x 2W: 0 none, 1 NMS maximum, 3 maximum inside the 10-px border
-    int32_t *row_cnt = nullptr; // [2][H2]   per interpolated row: all maxima, kept maxima
-    int32_t *row_off = nullptr; // [2][H2+1] exclusive prefix of row_cnt
+    int32_t *row_cnt = nullptr; // [2][H2]   per interpolated row: all maxima, kept maxima (hybrid: even / odd column candidates)
+    int32_t *row_off = nullptr; // [3][H2+1] exclusive prefix of row_cnt (hybrid: all, even-column, odd-column per row parity)
     int32_t *counts = nullptr;  // [4] n_total, n_kept (device-side sizes of everything downstream), n_candidates, -
     int32_t *src = nullptr;     // [cap][2] (pixel offset, kept rank or -1) per maximum, raster order
     ebvo_edge *edges = nullptr; // [cap] kept edges

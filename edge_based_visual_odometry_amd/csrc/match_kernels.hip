@@ -94,42 +94,52 @@ __global__ void lines_kernel(const double *__restrict__ F, const ebvo_edge *__re
     }
 }
 
-__global__ void chunk_boxes_kernel(const ebvo_edge *__restrict__ R, DevN nRd, Box *__restrict__ cb)
+__device__ inline double wave_min(double v)
 {
-    const int nR = devn(nRd), nchunks = (nR + CHUNK - 1) / CHUNK;
-    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < nchunks; c += gridDim.x * blockDim.x)
-    {
-        const int k0 = c * CHUNK, k1 = min(nR, k0 + CHUNK);
-        Box b;
-        b.x0 = b.x1 = R[k0].x;
-        b.y0 = b.y1 = R[k0].y;
-        for (int k = k0 + 1; k < k1; ++k)
-        {
-            const double x = R[k].x, y = R[k].y;
-            b.x0 = fmin(b.x0, x);
-            b.x1 = fmax(b.x1, x);
-            b.y0 = fmin(b.y0, y);
-            b.y1 = fmax(b.y1, y);
-        }
-        cb[c] = b;
-    }
+    for (int d = 32; d > 0; d >>= 1)
+        v = fmin(v, __shfl_xor(v, d));
+    return v;
+}
+__device__ inline double wave_max(double v)
+{
+    for (int d = 32; d > 0; d >>= 1)
+        v = fmax(v, __shfl_xor(v, d));
+    return v;
 }
 
-__global__ void group_boxes_kernel(const Box *__restrict__ cb, DevN nRd, Box *__restrict__ gb)
+// Bounding boxes of the index ranges: one thread per chunk (16 edges), one wave per group (64 chunks), so the group
+// box is a wave reduction of the chunk boxes it has just produced.
+__global__ __launch_bounds__(256) void boxes_kernel(const ebvo_edge *__restrict__ R, DevN nRd, Box *__restrict__ cb,
+                                                    Box *__restrict__ gb)
 {
+    static_assert(GROUP == 64, "one wave per group");
     const int nR = devn(nRd), nchunks = (nR + CHUNK - 1) / CHUNK, ngroups = (nchunks + GROUP - 1) / GROUP;
-    for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < ngroups; g += gridDim.x * blockDim.x)
+    const int lane = threadIdx.x & 63;
+    const double inf = __builtin_inf();
+    for (int g = blockIdx.x * 4 + (threadIdx.x >> 6); g < ngroups; g += gridDim.x * 4)
     {
-        const int c0 = g * GROUP, c1 = min(nchunks, c0 + GROUP);
-        Box b = cb[c0];
-        for (int c = c0 + 1; c < c1; ++c)
+        const int c = g * GROUP + lane;
+        Box b;
+        b.x0 = inf; b.x1 = -inf; b.y0 = inf; b.y1 = -inf;
+        if (c < nchunks)
         {
-            b.x0 = fmin(b.x0, cb[c].x0);
-            b.x1 = fmax(b.x1, cb[c].x1);
-            b.y0 = fmin(b.y0, cb[c].y0);
-            b.y1 = fmax(b.y1, cb[c].y1);
+            const int k0 = c * CHUNK, k1 = min(nR, k0 + CHUNK);
+            b.x0 = b.x1 = R[k0].x;
+            b.y0 = b.y1 = R[k0].y;
+            for (int k = k0 + 1; k < k1; ++k)
+            {
+                const double x = R[k].x, y = R[k].y;
+                b.x0 = fmin(b.x0, x);
+                b.x1 = fmax(b.x1, x);
+                b.y0 = fmin(b.y0, y);
+                b.y1 = fmax(b.y1, y);
+            }
+            cb[c] = b;
         }
-        gb[g] = b;
+        Box u;
+        u.x0 = wave_min(b.x0); u.x1 = wave_max(b.x1); u.y0 = wave_min(b.y0); u.y1 = wave_max(b.y1);
+        if (lane == 0)
+            gb[g] = u;
     }
 }
 
@@ -244,19 +254,6 @@ __device__ inline Box region_box(const LeftCtx &l, double D, double band, int ma
         }
     }
     return r;
-}
-
-__device__ inline double wave_min(double v)
-{
-    for (int d = 32; d > 0; d >>= 1)
-        v = fmin(v, __shfl_xor(v, d));
-    return v;
-}
-__device__ inline double wave_max(double v)
-{
-    for (int d = 32; d > 0; d >>= 1)
-        v = fmax(v, __shfl_xor(v, d));
-    return v;
 }
 
 // Candidate search.  One block = one tile of TILE (64) consecutive left edges; the right edges are visited through
@@ -1283,10 +1280,8 @@ int match_candidates_enqueue(ebvo_ctx *ctx, Slot &s, const ebvo_edge *d_L, int n
     }
     {
         ProfScope ps(ctx, s, K_BOXES);
-        hipLaunchKernelGGL(chunk_boxes_kernel, dim3(blocks_for(capchunks, 256, 256)), dim3(256), 0, s.stream, d_R,
-                           DevN{nR, d_nR}, (Box *)s.boxes_chunk.p);
-        hipLaunchKernelGGL(group_boxes_kernel, dim3(blocks_for(capgroups, 256, 16)), dim3(256), 0, s.stream,
-                           (const Box *)s.boxes_chunk.p, DevN{nR, d_nR}, (Box *)s.boxes_group.p);
+        hipLaunchKernelGGL(boxes_kernel, dim3(blocks_for(capgroups, 4, 1024)), dim3(256), 0, s.stream, d_R, DevN{nR, d_nR},
+                           (Box *)s.boxes_chunk.p, (Box *)s.boxes_group.p);
     }
     const CandParams P = cand_params(s, nL, d_nL, nR, d_nR, epi_thr, max_disp, orient_thr_deg, stage_mask, s.cap_pairs);
     {

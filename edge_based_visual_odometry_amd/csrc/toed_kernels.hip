@@ -117,6 +117,8 @@ struct ImgBatch
     CandRec *rec[MAX_BATCH];
     int32_t *cand_flag[MAX_BATCH]; // [2][cap]: is a maximum, is a kept maximum
     int32_t *cand_off[MAX_BATCH];  // [2][cap+1]: exclusive scans of the flags
+    int32_t *lists[MAX_BATCH];     // hybrid: [12][cap] candidate lists (0-3 by phase)
+    int32_t *lcount[MAX_BATCH];    // hybrid: [12] their lengths
 };
 
 // nine responses: fx fy fxx fxy fyy fxxy fxyy fxxx fyyy -> (x-derivative order, y-derivative order)
@@ -674,9 +676,148 @@ __global__ __launch_bounds__(256) void toed_screen_kernel(ImgBatch B, int h, int
         }
         B.flag[blockIdx.z][(size_t)i * W2 + j] = (uint8_t)f;
     }
+    // candidates of this row segment by column parity (the phase of a candidate is (row parity, column parity)); lane
+    // parity == column parity because every segment starts at an even column
     const unsigned long long any = __ballot(f != 0);
     if (threadIdx.x == 0 && any)
-        atomicAdd(&B.row_cnt[blockIdx.z][i], __popcll(any));
+    {
+        const int ne = __popcll(any & 0x5555555555555555ull), no = __popcll(any & 0xaaaaaaaaaaaaaaaaull);
+        if (ne)
+            atomicAdd(&B.row_cnt[blockIdx.z][i], ne);
+        if (no)
+            atomicAdd(&B.row_cnt[blockIdx.z][H2 + i], no);
+    }
+}
+
+// S2b: one block of three waves per image.  Wave 0: exclusive scan over the rows of all candidates (a candidate's rank
+// t); waves 1, 2: candidates in even / odd columns, scanned separately over the even and the odd rows, which gives
+// every row its offset in the list of its phase.  Totals -> counts[2] and lcount[0..3]; lcount[4..11] are zeroed for
+// the (phase, axis) lists appended by the centre kernel.
+__global__ __launch_bounds__(192) void toed_rowscan_phase_kernel(ImgBatch B, int H2)
+{
+    const int32_t *cnt = B.row_cnt[blockIdx.x];
+    int32_t *off = B.row_off[blockIdx.x];
+    int32_t *lcount = B.lcount[blockIdx.x];
+    const int lane = threadIdx.x & 63, which = threadIdx.x >> 6;
+    const int per = (H2 + 63) / 64;
+    const int beg = lane * per, end = min(H2, beg + per);
+    if (which == 0)
+    {
+        int s = 0;
+        for (int r = beg; r < end; ++r)
+            s += cnt[r] + cnt[H2 + r];
+        int incl = s;
+        for (int d = 1; d < 64; d <<= 1)
+        {
+            const int t = __shfl_up(incl, d);
+            if (lane >= d)
+                incl += t;
+        }
+        int run = incl - s;
+        for (int r = beg; r < end; ++r)
+        {
+            off[r] = run;
+            run += cnt[r] + cnt[H2 + r];
+        }
+        if (lane == 63)
+        {
+            off[H2] = incl;
+            B.counts[blockIdx.x][2] = incl;
+            B.counts[blockIdx.x][3] = 0;
+        }
+        if (lane >= 4 && lane < 12)
+            lcount[lane] = 0;
+        return;
+    }
+    const int sx = which - 1;
+    const int32_t *c = cnt + sx * H2;
+    int32_t *o = off + (1 + sx) * (H2 + 1);
+    int s[2] = {0, 0};
+    for (int r = beg; r < end; ++r)
+        s[r & 1] += c[r];
+    int incl[2] = {s[0], s[1]};
+    for (int d = 1; d < 64; d <<= 1)
+    {
+        const int t0 = __shfl_up(incl[0], d), t1 = __shfl_up(incl[1], d);
+        if (lane >= d)
+        {
+            incl[0] += t0;
+            incl[1] += t1;
+        }
+    }
+    int run[2] = {incl[0] - s[0], incl[1] - s[1]};
+    for (int r = beg; r < end; ++r)
+    {
+        o[r] = run[r & 1];
+        run[r & 1] += c[r];
+    }
+    if (lane == 63)
+    {
+        lcount[sx] = incl[0];     // phase (SY 0, SX sx)
+        lcount[2 + sx] = incl[1]; // phase (SY 1, SX sx)
+    }
+}
+
+// S2c: one block per interpolated row: ordered compaction of the candidates (rank t -> pixel) and, in the same pass,
+// the four phase lists in raster order (no atomics: every row knows its offset in its phase's list).
+__global__ __launch_bounds__(256) void toed_compact_phase_kernel(ImgBatch B, int h, int w, int cap)
+{
+    const int W2 = 2 * w, H2 = 2 * h;
+    const int i = 10 + blockIdx.x;
+    if (i >= H2 - 10)
+        return;
+    const uint8_t *flag = B.flag[blockIdx.y] + (size_t)i * W2;
+    const int32_t *off = B.row_off[blockIdx.y];
+    int32_t *src = B.src[blockIdx.y];
+    int32_t *lists = B.lists[blockIdx.y];
+    int base_all = off[i];
+    int base_ph[2] = {off[(H2 + 1) + i], off[2 * (H2 + 1) + i]};
+    __shared__ int w_all[4], w_par[2][4];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int par = threadIdx.x & 1; // column parity (j0 is even)
+    const unsigned long long pmask = par ? 0xaaaaaaaaaaaaaaaaull : 0x5555555555555555ull;
+    for (int j0 = 10; j0 < W2 - 10; j0 += 256)
+    {
+        const int j = j0 + threadIdx.x;
+        const int f = (j < W2 - 10) ? flag[j] : 0;
+        const unsigned long long m_all = __ballot(f != 0);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if (lane == 0)
+        {
+            w_all[wid] = __popcll(m_all);
+            w_par[0][wid] = __popcll(m_all & 0x5555555555555555ull);
+            w_par[1][wid] = __popcll(m_all & 0xaaaaaaaaaaaaaaaaull);
+        }
+        __syncthreads();
+        int pre_all = 0, tot_all = 0, pre_ph = 0, tot_ph[2] = {0, 0};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+        {
+            if (k < wid)
+            {
+                pre_all += w_all[k];
+                pre_ph += w_par[par][k];
+            }
+            tot_all += w_all[k];
+            tot_ph[0] += w_par[0][k];
+            tot_ph[1] += w_par[1][k];
+        }
+        if (f)
+        {
+            const int r_all = base_all + pre_all + __popcll(m_all & below);
+            if (r_all < cap)
+            {
+                src[2 * r_all] = i * W2 + j;
+                src[2 * r_all + 1] = -1;
+                const int ph = ((i & 1) << 1) | par;
+                lists[(size_t)ph * cap + base_ph[par] + pre_ph + __popcll(m_all & pmask & below)] = r_all;
+            }
+        }
+        base_all += tot_all;
+        base_ph[0] += tot_ph[0];
+        base_ph[1] += tot_ph[1];
+        __syncthreads();
+    }
 }
 
 // ---- exact stage -------------------------------------------------------------------------------------------
@@ -725,27 +866,6 @@ __device__ inline void block_append(bool put, int value, int32_t *__restrict__ l
         list[s_cnt[4] + pre + __popcll(m & ((1ull << lane) - 1ull))] = value;
     }
     __syncthreads();
-}
-
-// S3a: candidates -> four lists by phase
-__global__ __launch_bounds__(256) void toed_split_phase_kernel(ExactBatch E, int w, int cap)
-{
-    __shared__ int s_cnt[5];
-    const int im = blockIdx.y, W2 = 2 * w;
-    const int n = min(E.counts[im][2], cap);
-    for (int base = blockIdx.x * 256; base < n; base += gridDim.x * 256)
-    {
-        const int t = base + threadIdx.x;
-        int ph = -1;
-        if (t < n)
-        {
-            const int o = E.src[im][2 * t];
-            const int I = o / W2, J = o - I * W2;
-            ph = ((I & 1) << 1) | (J & 1);
-        }
-        for (int k = 0; k < 4; ++k)
-            block_append(ph == k, t, E.lists[im] + (size_t)k * cap, E.lcount[im] + k, s_cnt);
-    }
 }
 
 // 19 pixels of image row ii around column j, v[q + 9] = img(ii, j - q), +0.0 outside the image.
@@ -1141,9 +1261,11 @@ int toed_enqueue(ebvo_ctx *ctx, Slot &s, int n_img, int h, int w, hipEvent_t ev_
         B.rec[k] = (CandRec *)ws.cand_rec;
         B.cand_flag[k] = ws.cand_flag;
         B.cand_off[k] = ws.cand_off;
+        B.lists[k] = ws.cand_lists;
+        B.lcount[k] = ws.cand_lcount;
     }
     {
-        // per-row counters (and the hybrid path's list counters) of every image: one launch
+        // per-row counters of every image: one launch
         int32_t *ptrs[2 * MAX_BATCH];
         int counts[2 * MAX_BATCH];
         int nc = 0;
@@ -1151,11 +1273,6 @@ int toed_enqueue(ebvo_ctx *ctx, Slot &s, int n_img, int h, int w, hipEvent_t ev_
         {
             ptrs[nc] = s.im[k].row_cnt;
             counts[nc++] = 2 * H2;
-            if (ctx->toed_mode == EBVO_TOED_HYBRID)
-            {
-                ptrs[nc] = s.im[k].cand_lcount;
-                counts[nc++] = 12;
-            }
         }
         int rc = ebvo_clear_enqueue(ctx, s, ptrs, counts, nc);
         if (rc)
@@ -1179,11 +1296,11 @@ int toed_enqueue(ebvo_ctx *ctx, Slot &s, int n_img, int h, int w, hipEvent_t ev_
         }
         {
             ProfScope ps(ctx, s, K_ROWSCAN);
-            hipLaunchKernelGGL(toed_rowscan_kernel, dim3(n_img), dim3(64), 0, s.stream, B, H2, 2);
+            hipLaunchKernelGGL(toed_rowscan_phase_kernel, dim3(n_img), dim3(192), 0, s.stream, B, H2);
         }
         {
             ProfScope ps(ctx, s, K_COMPACT);
-            hipLaunchKernelGGL(toed_compact_kernel, dim3(H2 - 20, n_img), dim3(256), 0, s.stream, B, h, w, cap);
+            hipLaunchKernelGGL(toed_compact_phase_kernel, dim3(H2 - 20, n_img), dim3(256), 0, s.stream, B, h, w, cap);
         }
         {
             ExactBatch E{};
@@ -1209,7 +1326,6 @@ int toed_enqueue(ebvo_ctx *ctx, Slot &s, int n_img, int h, int w, hipEvent_t ev_
             const ToedTables *T = (const ToedTables *)g_tables_dev[ctx->device];
             {
                 ProfScope ps(ctx, s, K_EXACT_CENTRE);
-                hipLaunchKernelGGL(toed_split_phase_kernel, dim3(256, n_img), dim3(256), 0, s.stream, E, w, cap);
                 hipLaunchKernelGGL(toed_exact_centre_kernel, dim3(256, n_img, 4), dim3(256), 0, s.stream, E, T, h, w,
                                    cap);
             }
