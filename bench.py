@@ -40,6 +40,36 @@ def algorithmic_bytes_per_pair(n_left, n_right, n_pairs):
     return 2 * H * W + 64 * (n_left + n_right) + 48 * n_pairs
 
 
+# kernel id reported by the library's event profiler -> (HIP kernel symbol, launches) bracketed by one event pair
+KERNEL_SYMBOLS = {
+    "toed_conv": {"strict": [("toed_conv_kernel", 1)], "hybrid": [("toed_sep_kernel", 1)]},
+    "toed_nms": {"strict": [("toed_nms_kernel", 1)], "hybrid": [("toed_screen_kernel", 1)]},
+    "toed_exact_centre": {"hybrid": [("toed_exact_centre_kernel", 1)]},
+    "toed_exact_mags": {"hybrid": [("toed_exact_mags_kernel", 1), ("toed_exact_decide_kernel", 1)]},
+    "cand_count": {"*": [("candidates_kernel<false>", 1)]},
+    "cand_fill": {"*": [("candidates_copy_kernel", 1), ("candidates_kernel<true>", 1)]},
+    "edge_patches": {"*": [("sincos_batch_kernel", 1), ("patches_kernel", 1)]},
+    "ncc_pairs": {"*": [("ncc_banked_kernel", 1)]},
+}
+
+
+def pmc_traffic(kernel_id, toed_mode):
+    """HBM bytes per launch of the dominant kernel id from the committed rocprofv3 PMC passes (FETCH_SIZE x 2 +
+    WRITE_SIZE, profiles/kernel_pmc_<mode>.json, written by tools/rocprof_summary.py); None if not collected."""
+    path = os.path.join(ROOT, "profiles", f"kernel_pmc_{toed_mode}.json")
+    syms = KERNEL_SYMBOLS.get(kernel_id, {})
+    syms = syms.get(toed_mode) or syms.get("*")
+    if not syms or not os.path.exists(path):
+        return None
+    table = json.load(open(path)).get("kernels", {})
+    total = 0.0
+    for sym, n in syms:
+        if sym not in table:
+            return None
+        total += n * table[sym]["hbm_bytes_per_launch"]
+    return total
+
+
 def cpu_baseline(left, right, F):
     """The CPU oracle (a port of the reference's path) on this box's host cores; bounded sample (~10-30 s)."""
     from tests import oracle as orc
@@ -170,12 +200,7 @@ def main():
             ops_note = "fp64 operations executed: 4 neighbours x candidates x taps x (2 column products + 2 x (mul, add))"
         else:
             ops, executed, ops_note = None, None, "not an fp64-ALU kernel"
-        traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "dominant_pmc.json")
-        if os.path.exists(pmc_path):
-            pmc = json.load(open(pmc_path))
-            if pmc.get("kernel") == dom and pmc.get("toed_mode") == args.toed_mode:
-                traffic = pmc.get("hbm_bytes_per_launch")
+        traffic = pmc_traffic(dom, args.toed_mode)
         out = {
             "metric": "stereo pairs/sec (TOED+NCC match) on KITTI 1241x376; achieved HBM GB/s",
             "value": sharding.job_throughput(world, args.steps, dt),

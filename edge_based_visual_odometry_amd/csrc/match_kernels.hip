@@ -947,7 +947,13 @@ __global__ __launch_bounds__(256) void ncc_banked_kernel(const float *__restrict
     int mc = 0; // kept pairs seen by this thread; summed per block into match_part[blockIdx.x] (no atomics)
     const int64_t n_pairs = devpairs(np);
     const int64_t groups = ((int64_t)gridDim.x * blockDim.x) >> 4;
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // XCD-aware block order: workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  Consecutive pairs
+    // share their left edge and neighbouring right edges, so every XCD gets a CONTIGUOUS eighth of each sweep of pairs:
+    // its slice of the patch banks then stays in its L2 instead of all eight L2s streaming the whole bank from HBM.
+    int vb = blockIdx.x;
+    if ((gridDim.x & 7) == 0)
+        vb = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int64_t t = (int64_t)vb * blockDim.x + threadIdx.x;
     const int g = (int)(t & 15), side = g >> 3, row = g & 7;
     const int64_t iters = (n_pairs + groups - 1) / groups;
     for (int64_t it = 0; it < iters; ++it)
@@ -1354,7 +1360,7 @@ int match_patch_banks_enqueue(ebvo_ctx *ctx, Slot &s, int h, int w, int cap_edge
     B.flag[1] = (uint8_t *)s.patches_flag_r.p;
     ProfScope ps(ctx, s, K_PATCHES);
     hipLaunchKernelGGL(sincos_batch_kernel, dim3(blocks_for(cap_edges, 256, 512), 2), dim3(256), 0, s.stream, B);
-    hipLaunchKernelGGL(patches_kernel, dim3(blocks_for((int64_t)cap_edges * 16, 256, 2048), 2), dim3(256), 0, s.stream, B,
+    hipLaunchKernelGGL(patches_kernel, dim3(blocks_for((int64_t)cap_edges * 16, 256, 896), 2), dim3(256), 0, s.stream, B,
                        h, w, w);
     EBVO_HIP(ctx, hipGetLastError());
     return EBVO_OK;

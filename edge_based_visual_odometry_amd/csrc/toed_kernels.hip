@@ -919,13 +919,41 @@ __device__ inline bool window_inside(int h, int w, int i, int j)
 }
 
 // all nine responses at input pixel (i, j) for the compile-time phase (SY, SX): conv_body's arithmetic
+// Tap tables of the exact stage in LDS, laid out for one 16-byte broadcast read per (tap, kernel pair):
+//   tap[half][k][d]   = (half ? tap_half : tap_int)[d][k]   (d = derivative order 0..3, k = tap index 0..18)
+//   prod[p][q][0 / 1] = prod_fx / prod_fy                    (integer phase, src/toed/cpu_toed.cpp:207-208)
+// Every lane of a wave reads the same address, so the reads are conflict-free broadcasts and the taps arrive as
+// vector operands: no SGPR file pressure (76 tap doubles do not fit it; they used to come back through
+// v_readlane), no scalar-load waits in the tap loop.
+struct ExactTaps
+{
+    double tap[2][19][4];
+    double prod[17][17][2];
+};
+
+__device__ inline void load_exact_taps(ExactTaps &L, const ToedTables *__restrict__ T)
+{
+    for (int t = threadIdx.x; t < 2 * 19 * 4; t += blockDim.x)
+    {
+        const int half = t / 76, k = (t % 76) / 4, d = t & 3;
+        L.tap[half][k][d] = half ? T->tap_half[d][k] : T->tap_int[d][k];
+    }
+    for (int t = threadIdx.x; t < 17 * 17; t += blockDim.x)
+    {
+        const int p = t / 17, q = t % 17;
+        L.prod[p][q][0] = T->prod_fx[p][q];
+        L.prod[p][q][1] = T->prod_fy[p][q];
+    }
+    __syncthreads();
+}
+
 template <int SY, int SX>
-__device__ inline void exact9(const uint8_t *__restrict__ img, int h, int w, const ToedTables *__restrict__ T, int i,
-                              int j, double f[9])
+__device__ inline void exact9(const uint8_t *__restrict__ img, int h, int w, const ExactTaps &L, int i, int j,
+                              double f[9])
 {
     constexpr bool IP = (SY == 0 && SX == 0);
-    const double(*ck)[19] = SX ? T->tap_half : T->tap_int;
-    const double(*rk)[19] = SY ? T->tap_half : T->tap_int;
+    const double(*ck)[4] = L.tap[SX];
+    const double(*rk)[4] = L.tap[SY];
 #pragma unroll
     for (int r = 0; r < 9; ++r)
         f[r] = 0.0;
@@ -942,26 +970,25 @@ __device__ inline void exact9(const uint8_t *__restrict__ img, int h, int w, con
         double rr[4];
 #pragma unroll
         for (int d = 0; d < 4; ++d)
-            rr[d] = rk[d][p + 9];
+            rr[d] = rk[p + 9][d];
 #pragma unroll
         for (int q = -PM; q <= PM; ++q)
         {
             const double v = (double)vb[q + 9];
-            // the column taps are (re)loaded four taps at a time: a laundered zero offset keeps the scalar loads
-            // from being hoisted and clustered (all 76 doubles do not fit the SGPR file; they came back one
-            // v_readlane at a time, 292 extra instructions per row measured)
+            // the column taps are re-read from LDS a few taps at a time: a laundered zero offset keeps the reads in the
+            // row loop (hoisted, the 76 doubles would occupy 152 VGPRs and halve the occupancy)
             int lz = 0;
             if (((q + PM) & 3) == 0)
-                asm volatile("" : "+s"(lz));
-            const double(*ckl)[19] = ck + lz;
+                asm volatile("" : "+v"(lz));
+            const double(*ckl)[4] = ck + lz;
             double cc[4];
 #pragma unroll
             for (int d = 0; d < 4; ++d)
-                cc[d] = v * ckl[d][q + 9];
+                cc[d] = v * ckl[q + 9][d];
             if (IP)
             {
-                f[0] += v * T->prod_fx[p + 8][q + 8];
-                f[1] += v * T->prod_fy[p + 8][q + 8];
+                f[0] += v * L.prod[p + 8][q + 8][0];
+                f[1] += v * L.prod[p + 8][q + 8][1];
                 f[2] += cc[2] * rr[0];
                 f[3] += cc[1] * rr[1];
                 f[4] += cc[0] * rr[2];
@@ -980,13 +1007,12 @@ __device__ inline void exact9(const uint8_t *__restrict__ img, int h, int w, con
 
 // gradient magnitude (fx, fy only) at interpolated pixel (I, J) of compile-time phase (SY, SX)
 template <int SY, int SX>
-__device__ inline double exact_mag(const uint8_t *__restrict__ img, int h, int w, const ToedTables *__restrict__ T,
-                                   int I, int J)
+__device__ inline double exact_mag(const uint8_t *__restrict__ img, int h, int w, const ExactTaps &L, int I, int J)
 {
     constexpr bool IP = (SY == 0 && SX == 0);
     const int i = I >> 1, j = J >> 1;
-    const double(*ck)[19] = SX ? T->tap_half : T->tap_int;
-    const double(*rk)[19] = SY ? T->tap_half : T->tap_int;
+    const double(*ck)[4] = L.tap[SX];
+    const double(*rk)[4] = L.tap[SY];
     double fx = 0.0, fy = 0.0;
     constexpr int PM = IP ? 8 : 9;
     const bool fast = __all(window_inside(h, w, i, j));
@@ -998,23 +1024,23 @@ __device__ inline double exact_mag(const uint8_t *__restrict__ img, int h, int w
         nxt = fetch_row(img, h, w, i - min(p + 1, PM), j);
         int vb[19];
         unpack_row(cur, h, w, i - p, j, fast, vb);
+        const double r0 = rk[p + 9][0], r1 = rk[p + 9][1];
         int lz = 0;
-        asm volatile("" : "+s"(lz)); // see exact9: keeps the tap loads in the loop
-        const double(*ckl)[19] = ck + lz;
-        const double r0 = rk[0][p + 9], r1 = rk[1][p + 9];
+        asm volatile("" : "+v"(lz)); // keeps the column-tap reads in the row loop (see exact9)
+        const double(*ckl)[4] = ck + lz;
 #pragma unroll
         for (int q = -PM; q <= PM; ++q)
         {
             const double v = (double)vb[q + 9];
             if (IP)
             {
-                fx += v * T->prod_fx[p + 8][q + 8];
-                fy += v * T->prod_fy[p + 8][q + 8];
+                fx += v * L.prod[p + 8][q + 8][0];
+                fy += v * L.prod[p + 8][q + 8][1];
             }
             else
             {
-                fx += (v * ckl[1][q + 9]) * r0;
-                fy += (v * ckl[0][q + 9]) * r1;
+                fx += (v * ckl[q + 9][1]) * r0;
+                fy += (v * ckl[q + 9][0]) * r1;
             }
         }
     }
@@ -1023,8 +1049,7 @@ __device__ inline double exact_mag(const uint8_t *__restrict__ img, int h, int w
 
 // S3b: exact centre of every candidate of one phase; early NMS rejects; bucket by (phase, axis)
 template <int SY, int SX>
-__device__ inline void centre_phase(const ExactBatch &E, const ToedTables *__restrict__ T, int h, int w, int cap,
-                                    int *s_cnt)
+__device__ inline void centre_phase(const ExactBatch &E, const ExactTaps &L, int h, int w, int cap, int *s_cnt)
 {
     const int im = blockIdx.y, W2 = 2 * w;
     constexpr int PH = (SY << 1) | SX;
@@ -1041,7 +1066,7 @@ __device__ inline void centre_phase(const ExactBatch &E, const ToedTables *__res
             const int o = E.src[im][2 * t];
             const int I = o / W2, J = o - I * W2;
             double f[9];
-            exact9<SY, SX>(E.img[im], h, w, T, I >> 1, J >> 1, f);
+            exact9<SY, SX>(E.img[im], h, w, L, I >> 1, J >> 1, f);
             const double gx = f[0], gy = f[1];
             const double m = sqrt(gx * gx + gy * gy); // src/toed/cpu_toed.cpp:222
             NmsSector S;
@@ -1069,27 +1094,29 @@ __global__ __launch_bounds__(256) void toed_exact_centre_kernel(ExactBatch E, co
                                                                 int w, int cap)
 {
     __shared__ int s_cnt[5];
+    __shared__ ExactTaps L;
+    load_exact_taps(L, T);
     switch (blockIdx.z)
     {
-    case 0: centre_phase<0, 0>(E, T, h, w, cap, s_cnt); break;
-    case 1: centre_phase<0, 1>(E, T, h, w, cap, s_cnt); break;
-    case 2: centre_phase<1, 0>(E, T, h, w, cap, s_cnt); break;
-    default: centre_phase<1, 1>(E, T, h, w, cap, s_cnt); break;
+    case 0: centre_phase<0, 0>(E, L, h, w, cap, s_cnt); break;
+    case 1: centre_phase<0, 1>(E, L, h, w, cap, s_cnt); break;
+    case 2: centre_phase<1, 0>(E, L, h, w, cap, s_cnt); break;
+    default: centre_phase<1, 1>(E, L, h, w, cap, s_cnt); break;
     }
 }
 
 // S3c: the four neighbour magnitudes of every candidate of one (phase, axis) class.  The axis neighbours
 // (+-a1, +-b1) share one phase, the diagonal neighbours (+-a2, +-b2) the opposite phase (SY^1, SX^1);
 // PAIR selects which two a thread evaluates, so a launch slice has one phase throughout.
-template <int SY, int SX, int AXIS, int PAIR>
-__device__ inline void mags_class(const ExactBatch &E, const ToedTables *__restrict__ T, int h, int w, int cap)
+// The kernel is compiled for the four NEIGHBOUR phases only; which (phase, axis) list a slice reads and which
+// neighbour pair it evaluates are run-time values, and the + / - neighbours share one copy of the tap loop.  Sixteen
+// specialised slices were ~8x the code and the instruction cache felt it (a larger, "faster" variant ran slower).
+template <int NSY, int NSX>
+__device__ inline void mags_phase(const ExactBatch &E, const ExactTaps &L, int h, int w, int cap, int cls, int pair)
 {
     const int im = blockIdx.y, W2 = 2 * w;
-    constexpr int CLS = 4 + ((SY << 1) | SX) * 2 + AXIS;
-    constexpr int NSY = PAIR ? (SY ^ 1) : (AXIS ? (SY ^ 1) : SY);
-    constexpr int NSX = PAIR ? (SX ^ 1) : (AXIS ? SX : (SX ^ 1));
-    const int32_t *__restrict__ list = E.lists[im] + (size_t)CLS * cap;
-    const int n = min(E.lcount[im][CLS], cap);
+    const int32_t *__restrict__ list = E.lists[im] + (size_t)cls * cap;
+    const int n = min(E.lcount[im][cls], cap);
     const CandData &cd = E.cd[im];
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x)
     {
@@ -1097,34 +1124,33 @@ __device__ inline void mags_class(const ExactBatch &E, const ToedTables *__restr
         const int o = E.src[im][2 * t];
         const int I = o / W2, J = o - I * W2;
         const int pk = cd.sector[t];
-        const int da = PAIR ? ((pk >> 4) & 3) - 1 : (pk & 3) - 1;
-        const int db = PAIR ? ((pk >> 6) & 3) - 1 : ((pk >> 2) & 3) - 1;
-        cd.mag[(size_t)(0 + PAIR) * cap + t] = exact_mag<NSY, NSX>(E.img[im], h, w, T, I + da, J + db);
-        cd.mag[(size_t)(2 + PAIR) * cap + t] = exact_mag<NSY, NSX>(E.img[im], h, w, T, I - da, J - db);
+        const int da = pair ? ((pk >> 4) & 3) - 1 : (pk & 3) - 1;
+        const int db = pair ? ((pk >> 6) & 3) - 1 : ((pk >> 2) & 3) - 1;
+#pragma unroll 1
+        for (int sgn = 0; sgn < 2; ++sgn)
+        {
+            const int sa = sgn ? -da : da, sb = sgn ? -db : db;
+            cd.mag[(size_t)(2 * sgn + pair) * cap + t] = exact_mag<NSY, NSX>(E.img[im], h, w, L, I + sa, J + sb);
+        }
     }
 }
 
 __global__ __launch_bounds__(256) void toed_exact_mags_kernel(ExactBatch E, const ToedTables *__restrict__ T, int h,
                                                               int w, int cap)
 {
-    switch (blockIdx.z)
+    __shared__ ExactTaps L;
+    load_exact_taps(L, T);
+    // slice z = SY*8 + SX*4 + AXIS*2 + PAIR of the candidates' own phase (SY, SX)
+    const int z = blockIdx.z, sy = z >> 3, sx = (z >> 2) & 1, axis = (z >> 1) & 1, pair = z & 1;
+    const int cls = 4 + (z >> 1);
+    const int nsy = pair ? (sy ^ 1) : (axis ? (sy ^ 1) : sy);
+    const int nsx = pair ? (sx ^ 1) : (axis ? sx : (sx ^ 1));
+    switch ((nsy << 1) | nsx)
     {
-    case 0: mags_class<0, 0, 0, 0>(E, T, h, w, cap); break;
-    case 1: mags_class<0, 0, 0, 1>(E, T, h, w, cap); break;
-    case 2: mags_class<0, 0, 1, 0>(E, T, h, w, cap); break;
-    case 3: mags_class<0, 0, 1, 1>(E, T, h, w, cap); break;
-    case 4: mags_class<0, 1, 0, 0>(E, T, h, w, cap); break;
-    case 5: mags_class<0, 1, 0, 1>(E, T, h, w, cap); break;
-    case 6: mags_class<0, 1, 1, 0>(E, T, h, w, cap); break;
-    case 7: mags_class<0, 1, 1, 1>(E, T, h, w, cap); break;
-    case 8: mags_class<1, 0, 0, 0>(E, T, h, w, cap); break;
-    case 9: mags_class<1, 0, 0, 1>(E, T, h, w, cap); break;
-    case 10: mags_class<1, 0, 1, 0>(E, T, h, w, cap); break;
-    case 11: mags_class<1, 0, 1, 1>(E, T, h, w, cap); break;
-    case 12: mags_class<1, 1, 0, 0>(E, T, h, w, cap); break;
-    case 13: mags_class<1, 1, 0, 1>(E, T, h, w, cap); break;
-    case 14: mags_class<1, 1, 1, 0>(E, T, h, w, cap); break;
-    default: mags_class<1, 1, 1, 1>(E, T, h, w, cap); break;
+    case 0: mags_phase<0, 0>(E, L, h, w, cap, cls, pair); break;
+    case 1: mags_phase<0, 1>(E, L, h, w, cap, cls, pair); break;
+    case 2: mags_phase<1, 0>(E, L, h, w, cap, cls, pair); break;
+    default: mags_phase<1, 1>(E, L, h, w, cap, cls, pair); break;
     }
 }
 
