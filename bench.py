@@ -173,6 +173,19 @@ def main():
     ctx.profile_enable(False)
     prof = ctx.profile_get()
 
+    # Outside the timed region: a few pairs one at a time with events on every pair.  In the timed region several pairs
+    # overlap on the GPU, so an event-bracketed "launch duration" there includes time shared with other pairs' kernels;
+    # the one-at-a-time durations are the ones a rocprofv3 trace of `--streams 1` reproduces (profiles/).
+    serial = None
+    if rank == 0 and nslots > 1:
+        ctx.profile_reset()
+        ctx.profile_enable(True, every=1)
+        for _ in range(min(8, args.steps)):
+            ctx.stereo_submit(params, slot=0)
+            ctx.stereo_wait(slot=0)
+        ctx.profile_enable(False)
+        serial = ctx.profile_get()
+
     dt = sharding.max_over_ranks(dt, dist, reduce_device)
 
     if rank == 0:
@@ -225,6 +238,12 @@ def main():
                                  "avg_launch_ms is measured with pairs overlapping on the GPU when pairs_in_flight > 1"},
             "kernels": kernels,
         }
+        if serial is not None and serial[dom][1]:
+            one = serial[dom][0] * 1e-3 / serial[dom][1]
+            out["roofline"]["avg_launch_ms_one_in_flight"] = one * 1e3
+            out["roofline"]["achieved_one_in_flight"] = alg_bytes / one / 1e9
+            out["kernels_one_in_flight"] = {k: {"ms_per_step": v[0] / max(1, serial["epi_lines"][1])}
+                                            for k, v in serial.items() if v[1]}
         if ops is not None:
             tf = ops / dom_avg_s / 1e12
             out["roofline_fp64"] = {"bound": "valu_fp64_no_fma", "kernel": dom, "achieved": tf,
@@ -232,6 +251,9 @@ def main():
                                     "ops_per_launch": ops, "executed_ops_per_launch": executed,
                                     "executed_frac": executed / dom_avg_s / 1e12 / FP64_VALU_PEAK_NOFMA_TF,
                                     "note": ops_note + "; peak = 78.6 / 2 (mul and add are separate ops)"}
+            if serial is not None and serial[dom][1]:
+                one = serial[dom][0] * 1e-3 / serial[dom][1]
+                out["roofline_fp64"]["frac_one_in_flight"] = ops / one / 1e12 / FP64_VALU_PEAK_NOFMA_TF
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(left, right, F)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]

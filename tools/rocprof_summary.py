@@ -44,6 +44,15 @@ if t:
     open(os.path.join(dst, f"{tag}_kernel_stats_{mode}.txt"), "w").write("\n".join(out) + "\n")
     print("\n".join(out))
 
+t = db("trace_default") if mode == "hybrid" else None
+if t:
+    out = ["# rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline   (the default run: hybrid TOED, 3 pairs "
+           f"in flight; kernels of different pairs overlap, and the tracer itself slows the overlap)   [{tag}]",
+           f"{'kernel':40s} {'calls':>6s} {'total_us':>12s} {'avg_us':>10s} {'pct':>7s}"]
+    for name, calls, total, avg, pct in t.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
+        out.append(f"{short(name):40s} {calls:6d} {total:12.1f} {avg:10.2f} {pct:7.2f}")
+    open(os.path.join(dst, f"{tag}_kernel_stats_default.txt"), "w").write("\n".join(out) + "\n")
+
 pm, res = [], {}
 for name, counter in ((f"pmc_fetch_{mode}", "FETCH_SIZE"), (f"pmc_write_{mode}", "WRITE_SIZE")):
     d = db(name)
