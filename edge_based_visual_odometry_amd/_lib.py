@@ -40,6 +40,7 @@ ABI_SYMBOLS = (
     "ebvo_stereo_upload", "ebvo_stereo_run", "ebvo_stereo_fetch", "ebvo_stereo_set_slots",
     "ebvo_stereo_upload_slot", "ebvo_stereo_submit", "ebvo_stereo_wait", "ebvo_stereo_fetch_slot", "ebvo_profile_enable",
     "ebvo_profile_reset", "ebvo_profile_get", "ebvo_fp64_peak",
+    "ebvo_gn_default_params", "ebvo_sobel_gradients", "ebvo_gn_refine_stereo",
 )
 
 
@@ -47,6 +48,10 @@ class StereoParams(C.Structure):
     _fields_ = [("F21", C.c_double * 9), ("epi_thr", C.c_double), ("max_disp", C.c_double),
                 ("orient_thr_deg", C.c_double), ("ncc_thr", C.c_double), ("stage_mask", C.c_int),
                 ("reserved", C.c_int)]
+
+
+class GnParams(C.Structure):
+    _fields_ = [("max_iter", C.c_int), ("tol", C.c_double), ("huber_delta", C.c_double)]
 
 
 class StereoCounts(C.Structure):
@@ -115,6 +120,11 @@ def load_library() -> C.CDLL:
     lib.ebvo_profile_reset.argtypes = [vp]
     lib.ebvo_profile_get.argtypes = [vp, C.POINTER(KernelTime), C.POINTER(i32)]
     lib.ebvo_fp64_peak.argtypes = [vp, i32, C.POINTER(dbl), C.POINTER(dbl)]
+    lib.ebvo_gn_default_params.restype = None
+    lib.ebvo_gn_default_params.argtypes = [C.POINTER(GnParams)]
+    lib.ebvo_sobel_gradients.argtypes = [vp, vp, i32, i32, ssz, vp, vp]
+    lib.ebvo_gn_refine_stereo.argtypes = [vp, vp, vp, i32, i32, ssz, ssz, vp, i32, vp, vp, vp, C.POINTER(GnParams),
+                                          vp, vp, vp, vp, vp, vp]
     _lib = lib
     return lib
 

@@ -157,6 +157,46 @@ class Context:
         self._check(rc, "ebvo_ncc_pairs")
         return sims, best, keep, lp
 
+    # -- util_compute_Img_Gradients (include/utility.h:131-141) -----------------------------------
+    def sobel_gradients(self, img):
+        img = _u8(img)
+        h, w = img.shape
+        gx = np.zeros((h, w), dtype=np.float32)
+        gy = np.zeros((h, w), dtype=np.float32)
+        self._check(self.lib.ebvo_sobel_gradients(self._ctx, ptr(img), h, w, img.strides[0], ptr(gx), ptr(gy)),
+                    "ebvo_sobel_gradients")
+        return gx, gy
+
+    # -- Stereo_Matches::refine_edge_disparity (src/Stereo_Matches.cpp:1290-1358) ----------------
+    def gn_refine_stereo(self, imgL, imgR, L, lines, row_ptr, cand_xy, max_iter=None, tol=None, huber_delta=None):
+        """Photometric Gauss-Newton refinement of every (left edge, candidate) pair along the epipolar line.
+        Returns dict(alpha, score, confidence, validity, iters, refined_xy)."""
+        from ._lib import GnParams
+        imgL, imgR = _u8(imgL), _u8(imgR)
+        h, w = imgL.shape
+        L = _edges(L)
+        lines = np.ascontiguousarray(lines, dtype=np.float64).reshape(-1, 3)
+        row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int32)
+        cand_xy = np.ascontiguousarray(cand_xy, dtype=np.float64).reshape(-1, 2)
+        n = int(row_ptr[-1]) if len(row_ptr) else 0
+        assert len(cand_xy) == n and len(lines) == len(L) and len(row_ptr) == len(L) + 1
+        p = GnParams()
+        self.lib.ebvo_gn_default_params(p)
+        if max_iter is not None:
+            p.max_iter = int(max_iter)
+        if tol is not None:
+            p.tol = float(tol)
+        if huber_delta is not None:
+            p.huber_delta = float(huber_delta)
+        out = dict(alpha=np.zeros(n), score=np.zeros(n), confidence=np.zeros(n), validity=np.zeros(n, dtype=np.uint8),
+                   iters=np.zeros(n, dtype=np.int32), refined_xy=np.zeros((n, 2)))
+        rc = self.lib.ebvo_gn_refine_stereo(self._ctx, ptr(imgL), ptr(imgR), h, w, imgL.strides[0], imgR.strides[0],
+                                            ptr(L), len(L), ptr(lines), ptr(row_ptr), ptr(cand_xy), C.byref(p),
+                                            ptr(out["alpha"]), ptr(out["score"]), ptr(out["confidence"]),
+                                            ptr(out["validity"]), ptr(out["iters"]), ptr(out["refined_xy"]))
+        self._check(rc, "ebvo_gn_refine_stereo")
+        return out
+
     # -- Utility::get_edge_patches ------------------------------------------------------------
     def edge_patches(self, img, edges) -> np.ndarray:
         img = _u8(img)

@@ -10,7 +10,7 @@
 
 const char *const g_kernel_names[K_NUM] = {
     "toed_conv",   "toed_nms",   "toed_rowscan", "toed_compact", "toed_finalize", "toed_exact_centre", "toed_exact_mags", "cand_boxes", "epi_lines",
-    "cand_count",  "scan",       "cand_fill",    "edge_patches", "ncc_pairs",     "ncc_stored", "misc"};
+    "cand_count",  "scan",       "cand_fill",    "edge_patches", "ncc_pairs",     "ncc_stored", "misc", "sobel", "gn_refine"};
 
 // ------------------------------------------------------------------------------------------
 int ebvo_fail_hip(ebvo_ctx *ctx, hipError_t e, const char *what, const char *file, int line)
@@ -136,7 +136,7 @@ static void slot_destroy(Slot *s)
         (void)hipFree(ws.cand_lists);
         (void)hipFree(ws.cand_lcount);
     }
-    GrowBuf *bufs[] = {&s->lines,        &s->boxes_chunk,  &s->boxes_group,    &s->cand_cnt,       &s->cand_stage, &s->cand_tileflag, &s->row_ptr,
+    GrowBuf *bufs[] = {&s->lines,        &s->boxes_chunk,  &s->boxes_group,    &s->cand_cnt,       &s->cand_stage, &s->cand_tileflag, &s->row_ptr, &s->grad_x, &s->grad_y, &s->gn_xy, &s->gn_out, &s->gn_valid, &s->gn_iters, &s->gn_state, &s->gn_lists,
                        &s->scan_tmp,     &s->col_idx,      &s->rc_edges,       &s->sims,           &s->best,
                        &s->keep,         &s->patches_raw,  &s->patches_norm,   &s->patches_flag,   &s->patches_norm_r,
                        &s->patches_flag_r, &s->pair_left,  &s->sincos,         &s->scratch_b,      &s->scratch_c,
@@ -177,14 +177,16 @@ static int slot_create(ebvo_ctx *ctx, Slot **out)
     {
         ImageWS &ws = s->im[k];
         CK(hipMalloc(&ws.img_base, (size_t)ctx->max_h * ctx->max_w + 128));
-        CK(hipMemset(ws.img_base, 0, (size_t)ctx->max_h * ctx->max_w + 128));
+        // on the slot's own stream: hipMemset runs asynchronously on the NULL stream, which a non-blocking stream does
+        // not wait for -- the zero fill could land after the first upload of a fresh context
+        CK(hipMemsetAsync(ws.img_base, 0, (size_t)ctx->max_h * ctx->max_w + 128, s->stream));
         ws.img = ws.img_base + 64;
         CK(hipMalloc(&ws.maps, sizeof(double) * np2 * PL_NUM));
         CK(hipMalloc(&ws.flag, np2));
         CK(hipMalloc(&ws.row_cnt, sizeof(int32_t) * 2 * H2));
         CK(hipMalloc(&ws.row_off, sizeof(int32_t) * 3 * (H2 + 1)));
         CK(hipMalloc(&ws.counts, sizeof(int32_t) * 4));
-        CK(hipMemset(ws.counts, 0, sizeof(int32_t) * 4));
+        CK(hipMemsetAsync(ws.counts, 0, sizeof(int32_t) * 4, s->stream));
         CK(hipMalloc(&ws.cand_rec, 40 * (size_t)ctx->cap_edges));
         CK(hipMalloc(&ws.cand_flag, sizeof(int32_t) * 2 * (size_t)ctx->cap_edges));
         CK(hipMalloc(&ws.cand_off, sizeof(int32_t) * 2 * ((size_t)ctx->cap_edges + 1)));
@@ -202,6 +204,7 @@ static int slot_create(ebvo_ctx *ctx, Slot **out)
     CK(hipMalloc(&s->d_F, sizeof(double) * 9));
     CK(hipMalloc(&s->d_result, sizeof(PairResult)));
     CK(hipHostMalloc(&s->h_result, sizeof(PairResult)));
+    CK(hipStreamSynchronize(s->stream));
 #undef CK
     *out = s;
     return EBVO_OK;
@@ -523,6 +526,97 @@ extern "C" int ebvo_epi_candidates(ebvo_ctx *ctx, const ebvo_edge *L, int nL, co
     EBVO_HIP(ctx, hipMemcpyAsync(col_idx, s.col_idx.p, sizeof(int32_t) * (size_t)np, hipMemcpyDeviceToHost, s.stream));
     EBVO_HIP(ctx, hipStreamSynchronize(s.stream));
     s.cap_pairs = 0; // the pipeline re-establishes its own capacity
+    return EBVO_OK;
+}
+
+extern "C" void ebvo_gn_default_params(ebvo_gn_params *p)
+{
+    if (!p)
+        return;
+    p->max_iter = EBVO_GN_MAX_ITER;
+    p->tol = EBVO_GN_TOL;
+    p->huber_delta = EBVO_GN_HUBER_DELTA;
+}
+
+extern "C" int ebvo_sobel_gradients(ebvo_ctx *ctx, const uint8_t *img, int h, int w, ptrdiff_t stride, float *gx,
+                                    float *gy)
+{
+    if (!ctx || !img || !gx || !gy)
+        return EBVO_ERR_ARG;
+    EBVO_HIP(ctx, hipSetDevice(ctx->device));
+    int rc;
+    Slot *sp;
+    if ((rc = check_size(ctx, h, w)) || (rc = host_slot(ctx, &sp)))
+        return rc;
+    Slot &s = *sp;
+    const size_t bytes = sizeof(float) * (size_t)h * w;
+    if ((rc = upload_image(ctx, s, 0, img, h, w, stride)) || (rc = ebvo_grow(ctx, s, s.grad_x, bytes)) ||
+        (rc = ebvo_grow(ctx, s, s.grad_y, bytes)))
+        return rc;
+    if ((rc = refine_sobel_enqueue(ctx, s, s.im[0].img, h, w, w, (float *)s.grad_x.p, (float *)s.grad_y.p, nullptr)))
+        return rc;
+    EBVO_HIP(ctx, hipMemcpyAsync(gx, s.grad_x.p, bytes, hipMemcpyDeviceToHost, s.stream));
+    EBVO_HIP(ctx, hipMemcpyAsync(gy, s.grad_y.p, bytes, hipMemcpyDeviceToHost, s.stream));
+    EBVO_HIP(ctx, hipStreamSynchronize(s.stream));
+    return EBVO_OK;
+}
+
+extern "C" int ebvo_gn_refine_stereo(ebvo_ctx *ctx, const uint8_t *imgL, const uint8_t *imgR, int h, int w,
+                                     ptrdiff_t strideL, ptrdiff_t strideR, const ebvo_edge *L, int nL,
+                                     const double *lines, const int32_t *row_ptr, const double *cand_xy,
+                                     const ebvo_gn_params *params, double *alpha, double *score, double *confidence,
+                                     uint8_t *validity, int32_t *iters, double *refined_xy)
+{
+    if (!ctx || !imgL || !imgR || nL < 0 || !row_ptr || !params || (nL > 0 && (!L || !lines)) || params->max_iter < 1 ||
+        !(params->tol >= 0) || !(params->huber_delta > 0))
+        return EBVO_ERR_ARG;
+    EBVO_HIP(ctx, hipSetDevice(ctx->device));
+    int rc;
+    Slot *sp;
+    if ((rc = check_size(ctx, h, w)) || (rc = host_slot(ctx, &sp)))
+        return rc;
+    Slot &s = *sp;
+    if (row_ptr[0] != 0)
+        return EBVO_ERR_ARG;
+    for (int i = 0; i < nL; ++i)
+        if (row_ptr[i + 1] < row_ptr[i])
+            return EBVO_ERR_ARG;
+    const int64_t np = row_ptr[nL];
+    if (np == 0)
+        return EBVO_OK;
+    if (!cand_xy || !alpha || !score || !confidence || !validity || !iters || !refined_xy)
+        return EBVO_ERR_ARG;
+    const size_t img_bytes = sizeof(float) * (size_t)h * w, npz = (size_t)np;
+    if ((rc = upload_image(ctx, s, 0, imgL, h, w, strideL)) || (rc = upload_image(ctx, s, 1, imgR, h, w, strideR)) ||
+        (rc = ebvo_grow(ctx, s, s.grad_x, 2 * img_bytes + 64)) || /* interleaved (gx, gy) plane + slack for the 16-byte corner loads */
+        (rc = ebvo_grow(ctx, s, s.scratch_b, sizeof(ebvo_edge) * (size_t)nL)) ||
+        (rc = ebvo_grow(ctx, s, s.lines, sizeof(double) * 3 * (size_t)nL)) ||
+        (rc = ebvo_grow(ctx, s, s.row_ptr, sizeof(int32_t) * ((size_t)nL + 1))) ||
+        (rc = ebvo_grow(ctx, s, s.pair_left, sizeof(int32_t) * npz)) || (rc = ebvo_grow(ctx, s, s.gn_xy, sizeof(double) * 2 * npz)) ||
+        (rc = ebvo_grow(ctx, s, s.gn_out, sizeof(double) * 5 * npz)) || (rc = ebvo_grow(ctx, s, s.gn_valid, npz)) ||
+        (rc = ebvo_grow(ctx, s, s.gn_iters, sizeof(int32_t) * npz)))
+        return rc;
+    hipStream_t st = s.stream;
+    EBVO_HIP(ctx, hipMemcpyAsync(s.scratch_b.p, L, sizeof(ebvo_edge) * (size_t)nL, hipMemcpyHostToDevice, st));
+    EBVO_HIP(ctx, hipMemcpyAsync(s.lines.p, lines, sizeof(double) * 3 * (size_t)nL, hipMemcpyHostToDevice, st));
+    EBVO_HIP(ctx, hipMemcpyAsync(s.row_ptr.p, row_ptr, sizeof(int32_t) * ((size_t)nL + 1), hipMemcpyHostToDevice, st));
+    EBVO_HIP(ctx, hipMemcpyAsync(s.gn_xy.p, cand_xy, sizeof(double) * 2 * npz, hipMemcpyHostToDevice, st));
+    double *out = (double *)s.gn_out.p;
+    if ((rc = refine_sobel_enqueue(ctx, s, s.im[1].img, h, w, w, nullptr, nullptr, s.grad_x.p)) ||
+        (rc = match_expand_rows_enqueue(ctx, s, (const int32_t *)s.row_ptr.p, nL, np, (int32_t *)s.pair_left.p)) ||
+        (rc = refine_gn_stereo_enqueue(ctx, s, s.im[0].img, s.im[1].img, s.grad_x.p, h, w, (const ebvo_edge *)s.scratch_b.p,
+                                       (const double *)s.lines.p, (const int32_t *)s.pair_left.p,
+                                       (const double *)s.gn_xy.p, np, params->max_iter, params->tol, params->huber_delta,
+                                       out, out + npz, out + 2 * npz, (uint8_t *)s.gn_valid.p, (int32_t *)s.gn_iters.p,
+                                       out + 3 * npz)))
+        return rc;
+    EBVO_HIP(ctx, hipMemcpyAsync(alpha, out, sizeof(double) * npz, hipMemcpyDeviceToHost, st));
+    EBVO_HIP(ctx, hipMemcpyAsync(score, out + npz, sizeof(double) * npz, hipMemcpyDeviceToHost, st));
+    EBVO_HIP(ctx, hipMemcpyAsync(confidence, out + 2 * npz, sizeof(double) * npz, hipMemcpyDeviceToHost, st));
+    EBVO_HIP(ctx, hipMemcpyAsync(refined_xy, out + 3 * npz, sizeof(double) * 2 * npz, hipMemcpyDeviceToHost, st));
+    EBVO_HIP(ctx, hipMemcpyAsync(validity, s.gn_valid.p, npz, hipMemcpyDeviceToHost, st));
+    EBVO_HIP(ctx, hipMemcpyAsync(iters, s.gn_iters.p, sizeof(int32_t) * npz, hipMemcpyDeviceToHost, st));
+    EBVO_HIP(ctx, hipStreamSynchronize(st));
     return EBVO_OK;
 }
 

@@ -29,6 +29,8 @@ enum KernelId
     K_NCC_PAIRS,
     K_NCC_STORED,
     K_MISC,
+    K_SOBEL,
+    K_GN_REFINE,
     K_NUM
 };
 static_assert(K_NUM <= EBVO_MAX_KERNELS, "grow EBVO_MAX_KERNELS");
@@ -105,6 +107,7 @@ struct Slot
     bool have_pair = false, have_run = false, in_flight = false;
 
     // matching workspace
+    GrowBuf grad_x, grad_y, gn_xy, gn_out, gn_valid, gn_iters, gn_state, gn_lists; // photometric refinement (refine_kernels.hip)
     GrowBuf lines, boxes_chunk, boxes_group, cand_cnt, cand_stage, cand_tileflag, row_ptr, scan_tmp, col_idx, rc_edges, sims, best, keep,
         patches_raw, patches_norm, patches_flag, patches_norm_r, patches_flag_r, pair_left, sincos, scratch_b, scratch_c,
         scratch_d;
@@ -208,6 +211,15 @@ int ebvo_device_scan4(ebvo_ctx *ctx, Slot &s, const int32_t *const in[4], int32_
                       const int32_t *const n_dev[4], int nb, int cap_n);
 int ebvo_device_scan(ebvo_ctx *ctx, Slot &s, const int32_t *in, int32_t *out, int n_host, const int32_t *n_dev, int n_add,
                      int cap_n);
+// refine_kernels.hip
+int refine_sobel_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_img, int h, int w, int pitch, float *d_gx, float *d_gy,
+                         void *d_gxy /* optional interleaved float2 plane */);
+int refine_gn_stereo_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_imgL, const uint8_t *d_imgR, const void *d_gxy,
+                             int h, int w, const ebvo_edge *d_L, const double *d_lines,
+                             const int32_t *d_pair_left, const double *d_cand_xy, int64_t n_pairs, int max_iter,
+                             double tol, double huber, double *d_alpha, double *d_score, double *d_conf,
+                             uint8_t *d_valid, int32_t *d_iters, double *d_refined_xy);
+int match_expand_rows_enqueue(ebvo_ctx *ctx, Slot &s, const int32_t *d_row_ptr, int nL, int64_t n_pairs, int32_t *d_pair_left);
 int match_ncc_stored_enqueue(ebvo_ctx *ctx, Slot &s, const float *d_A, const float *d_B, int n, double *d_sim);
 int misc_fp64_peak(ebvo_ctx *ctx, Slot &s, int iters, double *tf_muladd, double *tf_fma);
 

@@ -1437,6 +1437,17 @@ int match_pair_result_enqueue(ebvo_ctx *ctx, Slot &s)
     return EBVO_OK;
 }
 
+int match_expand_rows_enqueue(ebvo_ctx *ctx, Slot &s, const int32_t *d_row_ptr, int nL, int64_t n_pairs, int32_t *d_pair_left)
+{
+    if (nL <= 0 || n_pairs <= 0)
+        return EBVO_OK;
+    ProfScope ps(ctx, s, K_MISC);
+    hipLaunchKernelGGL(expand_rows_kernel, dim3(blocks_for(nL, 256, 512)), dim3(256), 0, s.stream, d_row_ptr,
+                       DevN{nL, nullptr}, d_pair_left, n_pairs);
+    EBVO_HIP(ctx, hipGetLastError());
+    return EBVO_OK;
+}
+
 int match_ncc_stored_enqueue(ebvo_ctx *ctx, Slot &s, const float *d_A, const float *d_B, int n, double *d_sim)
 {
     if (n <= 0)

@@ -1,0 +1,359 @@
+// refine_kernels.hip -- photometric Gauss-Newton refinement of stereo candidates along the epipolar line
+// (SURVEY.md 8(f) rank 1), gfx950.
+//
+//   sobel_kernel      util_compute_Img_Gradients, include/utility.h:131-141 (cv::Sobel 3x3, scale 1/8, reflect-101)
+//   gn_init_kernel + gn_iter_kernel
+//                     Stereo_Matches::min_Edge_Photometric_Residual_by_Gauss_Newton_along_EpipolarLine,
+//                     src/Stereo_Matches.cpp:1159-1288, driven as refine_edge_disparity does (:1290-1358)
+//
+// Arithmetic contract: every quantity is computed by the same scalar IEEE operations in the same order as the
+// reference (doubles, no FMA contraction; the 49-term sums are sequential), so one thread owns one (left edge,
+// candidate) pair within an iteration.  Nothing is staged: a thread re-samples instead of storing (the 98 centred left
+// samples and the 3 x 98 right samples of an iteration would need ~2 KB per thread); re-evaluating a bilinear sample
+// returns the same bits, so the result is unchanged.  Only exp() (confidence) comes
+// from the device math library (<= 1 ulp from glibc's); cos/sin are csrc/ebvo_math.h's correctly rounded pair.
+#include <hip/hip_runtime.h>
+
+#include "ebvo_internal.h"
+#include "ebvo_math.h"
+
+namespace
+{
+
+__device__ inline int reflect101(int p, int n)
+{
+    if (n == 1)
+        return 0;
+    while (p < 0 || p >= n)
+        p = p < 0 ? -p : 2 * (n - 1) - p;
+    return p;
+}
+
+// On an image of 8-bit integers the 3x3 sums are integers below 2^11 and the scale is 2^-3: the float result is exact
+// whatever order OpenCV's separable filter adds in.
+__global__ void sobel_kernel(const uint8_t *__restrict__ img, int h, int w, int pitch, float *__restrict__ gx,
+                             float *__restrict__ gy, float2 *__restrict__ gxy)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= w || y >= h)
+        return;
+    const uint8_t *r0 = img + (size_t)reflect101(y - 1, h) * pitch, *r1 = img + (size_t)y * pitch,
+                  *r2 = img + (size_t)reflect101(y + 1, h) * pitch;
+    const int xm = reflect101(x - 1, w), xp = reflect101(x + 1, w);
+    const int sx = (r0[xp] - r0[xm]) + 2 * (r1[xp] - r1[xm]) + (r2[xp] - r2[xm]);
+    const int sy = (r2[xm] - r0[xm]) + 2 * (r2[x] - r0[x]) + (r2[xp] - r0[xp]);
+    const float fx = (float)sx * 0.125f, fy = (float)sy * 0.125f;
+    if (gx)
+        gx[(size_t)y * w + x] = fx;
+    if (gy)
+        gy[(size_t)y * w + x] = fy;
+    if (gxy) // interleaved plane for the refinement: both gradients of a corner pair arrive in one 16-byte load
+        gxy[(size_t)y * w + x] = make_float2(fx, fy);
+}
+
+// util_bilinear_Sample_F (include/utility.h:160-173): corner indices and weights, shared by every image sampled at
+// one point
+__device__ inline void tap_at(double x, double y, int w, int h, int &x0, int &x1, int &y0, int &y1, double &a, double &b)
+{
+    x = x < 0.0 ? 0.0 : (((double)w - 1.0) < x ? ((double)w - 1.0) : x); // std::clamp
+    y = y < 0.0 ? 0.0 : (((double)h - 1.0) < y ? ((double)h - 1.0) : y);
+    const double fx = floor(x), fy = floor(y);
+    x0 = (int)fx;
+    y0 = (int)fy;
+    x1 = min(x0 + 1, w - 1);
+    y1 = min(y0 + 1, h - 1);
+    a = x - x0;
+    b = y - y0;
+}
+
+__device__ inline float blend(double a, double b, float v00, float v10, float v01, float v11)
+{
+    return (float)((1 - a) * (1 - b) * v00 + a * (1 - b) * v10 + (1 - a) * b * v01 + a * b * v11);
+}
+
+// The two corners of a row are adjacent pixels: one 2-byte load (u8 image) or one 16-byte load (interleaved gradient
+// plane) fetches both.  The sampling is address-divergent (every lane its own patch), so the number of load
+// INSTRUCTIONS is what the texture path charges for; pairing halves it (and the interleaved plane halves it again).
+// At the right border x1 == x0 == w - 1: the pair is fetched one pixel to the left and its second element used twice.
+struct Corners
+{
+    float v00, v10, v01, v11;
+};
+
+__device__ inline Corners corners_u8(const uint8_t *__restrict__ img, int pitch, int w, int x0, int x1, int y0, int y1)
+{
+    const int xa = min(x0, max(w - 2, 0));
+    unsigned short p0, p1;
+    __builtin_memcpy(&p0, img + (size_t)y0 * pitch + xa, 2);
+    __builtin_memcpy(&p1, img + (size_t)y1 * pitch + xa, 2);
+    const bool shifted = xa != x0; // x0 == x1 == w - 1
+    Corners c;
+    c.v10 = (float)(p0 >> 8);
+    c.v11 = (float)(p1 >> 8);
+    c.v00 = shifted ? c.v10 : (float)(p0 & 0xff);
+    c.v01 = shifted ? c.v11 : (float)(p1 & 0xff);
+    (void)x1;
+    return c;
+}
+
+__device__ inline float sample_u8(const uint8_t *__restrict__ img, int pitch, int w, int h, double x, double y)
+{
+    int x0, x1, y0, y1;
+    double a, b;
+    tap_at(x, y, w, h, x0, x1, y0, y1, a, b);
+    if (w < 2)
+    {
+        const uint8_t *r0 = img + (size_t)y0 * pitch, *r1 = img + (size_t)y1 * pitch;
+        return blend(a, b, (float)r0[x0], (float)r0[x1], (float)r1[x0], (float)r1[x1]);
+    }
+    const Corners c = corners_u8(img, pitch, w, x0, x1, y0, y1);
+    return blend(a, b, c.v00, c.v10, c.v01, c.v11);
+}
+
+struct GnArgs
+{
+    const uint8_t *imgL, *imgR;
+    const float2 *gxy;    // interleaved Sobel planes (gx, gy) of the right image, pitch w
+    int h, w;
+    const ebvo_edge *L;       // left edges
+    const double *lines;      // nL x 3
+    const int32_t *pair_left; // pair -> left edge
+    const double *cand_xy;    // n_pairs x 2
+    int64_t n_pairs;
+    int max_iter;
+    double tol, huber;
+    double *alpha, *score, *conf, *refined_xy; // outputs; alpha doubles as the iteration state
+    uint8_t *valid;
+    int32_t *iters;
+    // iteration state
+    double *mean_l;   // [2][n_pairs] means of the left plus / minus patches
+    double *sc;       // [2][n_pairs] sin, cos of the left orientation
+    int32_t *list[2]; // active pairs, ping-pong
+    int32_t *counts;  // [max_iter + 1] active pairs entering iteration it
+};
+
+// The pairs need 1 .. max_iter iterations each (mean ~8, an eighth run all 20): one thread looping to its own
+// convergence keeps a wave busy until its slowest lane is done (2.6x the work at 64 lanes).  So the iteration is a
+// launch: gn_iter_kernel<it> runs iteration `it` of every pair still active and appends the survivors to the next
+// list (wave-aggregated append; the order of a list does not influence any result).  State per pair: alpha, the two
+// left-patch means and sin/cos of the left orientation (40 bytes).
+__device__ inline void gn_geometry(const GnArgs &A, int64_t k, ebvo_edge &le, double &ex, double &ey)
+{
+    const int li = A.pair_left[k];
+    le = A.L[li];
+    ex = -A.lines[(size_t)li * 3 + 1]; // :1331
+    ey = A.lines[(size_t)li * 3];
+    const double en = sqrt(ex * ex + ey * ey);
+    ex /= en;
+    ey /= en;
+}
+
+__global__ __launch_bounds__(256) void gn_init_kernel(GnArgs A)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        A.counts[0] = (int32_t)A.n_pairs;
+    const int h = A.h, w = A.w;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < A.n_pairs; k += (int64_t)gridDim.x * blockDim.x)
+    {
+        ebvo_edge le;
+        double ex, ey, st, ct;
+        gn_geometry(A, k, le, ex, ey);
+        ebvo_sincos(le.theta, &st, &ct);
+        const double nx = -st, ny = ct;      // n(-t.y, t.x), :1172
+        const double side = (7 / 2.0) + 1.0; // :1173
+        // means of the two left patches (:1183-1190); the centred samples are re-derived where they are used
+#pragma unroll 1
+        for (int sd = 0; sd < 2; ++sd)
+        {
+            const double cx = sd ? le.x - nx * side : le.x + nx * side, cy = sd ? le.y - ny * side : le.y + ny * side;
+            double sum = 0;
+#pragma unroll 1
+            for (int i = -3; i <= 3; ++i)
+#pragma unroll
+                for (int j = -3; j <= 3; ++j)
+                    sum += (double)sample_u8(A.imgL, w, w, h, cx + ct * i - st * j, cy + st * i + ct * j);
+            A.mean_l[(size_t)sd * A.n_pairs + k] = sum / 49;
+        }
+        A.sc[k] = st;
+        A.sc[A.n_pairs + k] = ct;
+        A.alpha[k] = 0.0;
+        A.score[k] = __builtin_nan("");
+        A.conf[k] = __builtin_nan("");
+        A.valid[k] = 2; // the reference leaves its outputs unset when it stops on H < 1e-8 (:1255)
+        A.iters[k] = 0;
+        A.list[0][k] = (int32_t)k;
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_iter_kernel(GnArgs A, int it)
+{
+    const int h = A.h, w = A.w;
+    const int n_in = A.counts[it];
+    const int32_t *__restrict__ lin = A.list[it & 1];
+    int32_t *__restrict__ lout = A.list[(it + 1) & 1];
+    const int lane = threadIdx.x & 63;
+    for (int base = blockIdx.x * blockDim.x; base < n_in; base += gridDim.x * blockDim.x)
+    {
+        const int idx = base + threadIdx.x;
+        bool survives = false;
+        int64_t k = 0;
+        if (idx < n_in)
+        {
+            k = lin[idx];
+            ebvo_edge le;
+            double ex, ey;
+            gn_geometry(A, k, le, ex, ey);
+            const double st = A.sc[k], ct = A.sc[A.n_pairs + k];
+            const double nx = -st, ny = ct, side = (7 / 2.0) + 1.0;
+            const double rx = A.cand_xy[2 * k], ry = A.cand_xy[2 * k + 1];
+            const double meanL[2] = {A.mean_l[k], A.mean_l[A.n_pairs + k]};
+            double alpha = A.alpha[k];
+            const double shx = ex * alpha, shy = ey * alpha;
+            double meanR[2];
+#pragma unroll 1
+            for (int sd = 0; sd < 2; ++sd)
+            {
+                const double cx = (sd ? rx - nx * side : rx + nx * side) + shx; // :1204-1205
+                const double cy = (sd ? ry - ny * side : ry + ny * side) + shy;
+                double sum = 0;
+#pragma unroll 1
+                for (int i = -3; i <= 3; ++i)
+#pragma unroll
+                    for (int j = -3; j <= 3; ++j)
+                        sum += (double)sample_u8(A.imgR, w, w, h, cx + ct * i - st * j, cy + st * i + ct * j);
+                meanR[sd] = sum / 49;
+            }
+            double H = 0.0, b = 0.0, cost = 0.0;
+#pragma unroll 1
+            for (int sd = 0; sd < 2; ++sd)
+            {
+                const double lcx = sd ? le.x - nx * side : le.x + nx * side, lcy = sd ? le.y - ny * side : le.y + ny * side;
+                const double cx = (sd ? rx - nx * side : rx + nx * side) + shx;
+                const double cy = (sd ? ry - ny * side : ry + ny * side) + shy;
+#pragma unroll 1
+                for (int i = -3; i <= 3; ++i)
+#pragma unroll 1
+                    for (int j = -3; j <= 3; ++j)
+                    {
+                        const double Lf = (double)sample_u8(A.imgL, w, w, h, lcx + ct * i - st * j, lcy + st * i + ct * j);
+                        int x0, x1, y0, y1;
+                        double wa, wb;
+                        tap_at(cx + ct * i - st * j, cy + st * i + ct * j, w, h, x0, x1, y0, y1, wa, wb);
+                        const int xa = min(x0, w - 2);
+                        const bool shifted = xa != x0; // right border: x1 == x0 == w - 1
+                        const Corners ci = corners_u8(A.imgR, w, w, x0, x1, y0, y1);
+                        const float4 g0 = *reinterpret_cast<const float4 *>(A.gxy + (size_t)y0 * w + xa);
+                        const float4 g1 = *reinterpret_cast<const float4 *>(A.gxy + (size_t)y1 * w + xa);
+                        const double Rf = (double)blend(wa, wb, ci.v00, ci.v10, ci.v01, ci.v11);
+                        const double gxv = (double)blend(wa, wb, shifted ? g0.z : g0.x, g0.z, shifted ? g1.z : g1.x, g1.z);
+                        const double gyv = (double)blend(wa, wb, shifted ? g0.w : g0.y, g0.w, shifted ? g1.w : g1.y, g1.w);
+                        const double r = (Lf - meanL[sd]) - (Rf - meanR[sd]);
+                        const double g = -gxv * ex + gyv * ey; // :1237
+                        const double absr = fabs(r);
+                        const double wgt = (absr <= A.huber) ? 1.0 : A.huber / absr;
+                        H += wgt * g * g;
+                        b += wgt * g * r;
+                        cost += wgt * r * r;
+                    }
+            }
+            int done_iters = it; // stop on H < 1e-8: outputs stay unset (:1255)
+            bool finished = true;
+            if (!(H < 1e-8))
+            {
+                const double delta = -b / H;
+                alpha += delta;
+                const double rms = sqrt(cost / 98);
+                const bool is_outlier = (rms > A.huber * 2.0) || (it + 1 < 2); // residual_log.size() == it + 1
+                if (fabs(delta) < A.tol || it == A.max_iter - 1)
+                {
+                    A.valid[k] = is_outlier ? 0 : 1;
+                    A.score[k] = rms;
+                    A.conf[k] = exp(-rms / A.huber);
+                    done_iters = it + 1;
+                }
+                else
+                    finished = false;
+            }
+            A.alpha[k] = alpha;
+            if (finished)
+            {
+                A.iters[k] = done_iters;
+                A.refined_xy[2 * k] = rx + ex * alpha; // :1349-1351
+                A.refined_xy[2 * k + 1] = ry + ey * alpha;
+            }
+            survives = !finished;
+        }
+        // append the survivors: one atomic per wave
+        const unsigned long long m = __ballot(survives);
+        int wbase = 0;
+        if (lane == 0 && m)
+            wbase = atomicAdd(&A.counts[it + 1], __popcll(m));
+        wbase = __shfl(wbase, 0);
+        if (survives)
+            lout[wbase + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)k;
+    }
+}
+
+} // namespace
+
+int refine_sobel_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_img, int h, int w, int pitch, float *d_gx, float *d_gy,
+                         void *d_gxy)
+{
+    ProfScope ps(ctx, s, K_SOBEL);
+    hipLaunchKernelGGL(sobel_kernel, dim3((w + 63) / 64, (h + 3) / 4), dim3(64, 4), 0, s.stream, d_img, h, w, pitch, d_gx,
+                       d_gy, (float2 *)d_gxy);
+    EBVO_HIP(ctx, hipGetLastError());
+    return EBVO_OK;
+}
+
+int refine_gn_stereo_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_imgL, const uint8_t *d_imgR, const void *d_gxy,
+                             int h, int w, const ebvo_edge *d_L, const double *d_lines,
+                             const int32_t *d_pair_left, const double *d_cand_xy, int64_t n_pairs, int max_iter,
+                             double tol, double huber, double *d_alpha, double *d_score, double *d_conf,
+                             uint8_t *d_valid, int32_t *d_iters, double *d_refined_xy)
+{
+    if (n_pairs <= 0)
+        return EBVO_OK;
+    if (n_pairs > 0x7fffffffll)
+        return EBVO_ERR_CAPACITY;
+    if (w < 2 || h < 1)
+        return EBVO_ERR_ARG;
+    int rc;
+    const size_t np = (size_t)n_pairs;
+    if ((rc = ebvo_grow(ctx, s, s.gn_state, sizeof(double) * 4 * np)) ||
+        (rc = ebvo_grow(ctx, s, s.gn_lists, sizeof(int32_t) * (2 * np + (size_t)max_iter + 2))))
+        return rc;
+    GnArgs A{};
+    A.imgL = d_imgL;
+    A.imgR = d_imgR;
+    A.gxy = (const float2 *)d_gxy;
+    A.h = h;
+    A.w = w;
+    A.L = d_L;
+    A.lines = d_lines;
+    A.pair_left = d_pair_left;
+    A.cand_xy = d_cand_xy;
+    A.n_pairs = n_pairs;
+    A.max_iter = max_iter;
+    A.tol = tol;
+    A.huber = huber;
+    A.alpha = d_alpha;
+    A.score = d_score;
+    A.conf = d_conf;
+    A.refined_xy = d_refined_xy;
+    A.valid = d_valid;
+    A.iters = d_iters;
+    A.mean_l = (double *)s.gn_state.p;
+    A.sc = A.mean_l + 2 * np;
+    A.list[0] = (int32_t *)s.gn_lists.p;
+    A.list[1] = A.list[0] + np;
+    A.counts = A.list[1] + np;
+    ProfScope ps(ctx, s, K_GN_REFINE);
+    EBVO_HIP(ctx, hipMemsetAsync(A.counts, 0, sizeof(int32_t) * ((size_t)max_iter + 2), s.stream));
+    const unsigned blocks = (unsigned)((n_pairs + 255) / 256 < 4096 ? (n_pairs + 255) / 256 : 4096);
+    hipLaunchKernelGGL(gn_init_kernel, dim3(blocks), dim3(256), 0, s.stream, A);
+    for (int it = 0; it < max_iter; ++it)
+        hipLaunchKernelGGL(gn_iter_kernel, dim3(blocks), dim3(256), 0, s.stream, A, it);
+    EBVO_HIP(ctx, hipGetLastError());
+    return EBVO_OK;
+}

@@ -154,6 +154,48 @@ int ebvo_ncc_pairs(ebvo_ctx *ctx, const uint8_t *imgL, const uint8_t *imgR, int 
                    const int32_t *row_ptr, double thr, float *left_patches, double *sims, double *best,
                    uint8_t *keep);
 
+/* ---- photometric refinement (no fixture of the reference pins it) -------------------- */
+
+/* Defaults of Stereo_Matches::min_Edge_Photometric_Residual_by_Gauss_Newton_along_EpipolarLine
+ * (include/Stereo_Matches.h:79-84). */
+#define EBVO_GN_MAX_ITER 20
+#define EBVO_GN_TOL 1e-3
+#define EBVO_GN_HUBER_DELTA 3.0
+
+typedef struct
+{
+    int max_iter;       /* >= 1 */
+    double tol;         /* |delta| below which the iteration stops */
+    double huber_delta; /* Huber threshold; outlier if rms > 2 * huber_delta */
+} ebvo_gn_params;
+
+void ebvo_gn_default_params(ebvo_gn_params *p);
+
+/* util_compute_Img_Gradients (include/utility.h:131-141; called from src/Pipeline.cpp:83-84): cv::Sobel 3x3 with
+ * scale 1/8 and OpenCV's default border (reflect-101) of the CV_8UC1 image converted to CV_32F.
+ * gx, gy: h x w floats, tightly packed. */
+int ebvo_sobel_gradients(ebvo_ctx *ctx, const uint8_t *img, int h, int w, ptrdiff_t stride, float *gx, float *gy);
+
+/*
+ * Replaces the per-candidate body of Stereo_Matches::refine_edge_disparity (src/Stereo_Matches.cpp:1290-1358) and
+ * under it min_Edge_Photometric_Residual_by_Gauss_Newton_along_EpipolarLine (:1159-1288): 1-D Gauss-Newton on the
+ * photometric residual of the two 7x7 side patches, the right patch pair sliding along the epipolar direction
+ * (-b, a)/|(-b, a)| of the left edge's line (:1331-1336), Huber weights, init_alpha 0.
+ *   imgL/imgR   : the undistorted left / right CV_8UC1 images (the reference converts them to CV_32F, :1292-1294;
+ *                 pass them swapped for is_left = false).  The gradients of imgR are formed internally.
+ *   L/nL, lines : left edges and their nL x 3 line coefficients (epip_line_coeffs_of_left_edges)
+ *   row_ptr     : nL + 1 CSR offsets into the pair arrays;  cand_xy : n_pairs x 2 candidate locations
+ *                 (EdgeCluster::center_edge.location)
+ * Outputs, one per pair: alpha (refined_alpha), score (refine_final_scores: final RMS), confidence
+ * (refine_confidences: exp(-rms / huber_delta)), validity (refine_validities: 0 / 1), iters (iterations
+ * executed) and refined_xy (the updated centre location, :1349-1351).  validity = 2 marks the case the reference
+ * leaves undefined: it stops on H < 1e-8 without assigning its outputs (:1255); score and confidence are NaN there.
+ */
+int ebvo_gn_refine_stereo(ebvo_ctx *ctx, const uint8_t *imgL, const uint8_t *imgR, int h, int w, ptrdiff_t strideL,
+                          ptrdiff_t strideR, const ebvo_edge *L, int nL, const double *lines, const int32_t *row_ptr,
+                          const double *cand_xy, const ebvo_gn_params *params, double *alpha, double *score,
+                          double *confidence, uint8_t *validity, int32_t *iters, double *refined_xy);
+
 /* Utility::get_edge_patches for n edges on one image: patches = n x 2 x 49 floats
  * (src/utility.cpp:182-212; used again by finalize_stereo_edge_mates, src/Stereo_Matches.cpp:1622). */
 int ebvo_edge_patches(ebvo_ctx *ctx, const uint8_t *img, int h, int w, ptrdiff_t stride,

@@ -556,6 +556,191 @@ void orc_ncc_quads(const float *kfL, const float *kfR, const float *cfL, const f
     }
 }
 
+/* ------------------------------------------------------------------------------------------
+ * Photometric Gauss-Newton refinement along the epipolar line.
+ * No fixture of the reference pins this function: PARITY UNPINNED (the restatement follows the source line by line;
+ * every operation is a scalar IEEE operation in a fixed order, so the only open points are std::cos/sin/exp).
+ * ------------------------------------------------------------------------------------------ */
+
+/* util_compute_Img_Gradients, include/utility.h:131-141: cv::Sobel(I_32F, ., CV_32F, 1|0, 0|1, 3, 1/8) with OpenCV's
+ * default border (BORDER_REFLECT_101).  OpenCV 4.x is not part of the reference tree; its published Sobel is the
+ * separable pair [-1 0 1] x [1 2 1].  On an image of 8-bit integers every partial sum is an integer below 2^24 and the
+ * scale is a power of two, so the float result is exact whatever the summation order. */
+static inline int reflect101(int p, int n)
+{
+    if (n == 1)
+        return 0;
+    while (p < 0 || p >= n)
+        p = p < 0 ? -p : 2 * (n - 1) - p;
+    return p;
+}
+
+void orc_sobel_gradients(const uint8_t *img, int h, int w, ptrdiff_t stride, float *gx, float *gy)
+{
+    for (int y = 0; y < h; y++)
+    {
+        const uint8_t *r0 = img + (ptrdiff_t)reflect101(y - 1, h) * stride, *r1 = img + (ptrdiff_t)y * stride,
+                      *r2 = img + (ptrdiff_t)reflect101(y + 1, h) * stride;
+        for (int x = 0; x < w; x++)
+        {
+            const int xm = reflect101(x - 1, w), xp = reflect101(x + 1, w);
+            const int sx = (r0[xp] - r0[xm]) + 2 * (r1[xp] - r1[xm]) + (r2[xp] - r2[xm]);
+            const int sy = (r2[xm] - r0[xm]) + 2 * (r2[x] - r0[x]) + (r2[xp] - r0[xp]);
+            gx[(size_t)y * w + x] = (float)sx * 0.125f;
+            gy[(size_t)y * w + x] = (float)sy * 0.125f;
+        }
+    }
+}
+
+/* util_bilinear_Sample_F, include/utility.h:160-173: clamp-to-edge bilinear on a CV_32F image; weights in double,
+ * result returned as float.  `pix` abstracts I.at<float>(y, x). */
+#define ORC_GN_SAMPLE(PIX, W_, H_, X_, Y_, OUT)                                                                  \
+    do                                                                                                              \
+    {                                                                                                               \
+        double xx_ = (X_), yy_ = (Y_);                                                                              \
+        xx_ = xx_ < 0.0 ? 0.0 : (((double)(W_) - 1.0) < xx_ ? ((double)(W_) - 1.0) : xx_); /* std::clamp */      \
+        yy_ = yy_ < 0.0 ? 0.0 : (((double)(H_) - 1.0) < yy_ ? ((double)(H_) - 1.0) : yy_);                        \
+        const int x0_ = (int)floor(xx_), y0_ = (int)floor(yy_);                                                    \
+        const int x1_ = x0_ + 1 < (W_) - 1 ? x0_ + 1 : (W_) - 1, y1_ = y0_ + 1 < (H_) - 1 ? y0_ + 1 : (H_) - 1;   \
+        const double a_ = xx_ - x0_, b_ = yy_ - y0_;                                                                \
+        const float v00_ = PIX(y0_, x0_), v10_ = PIX(y0_, x1_), v01_ = PIX(y1_, x0_), v11_ = PIX(y1_, x1_);        \
+        (OUT) = (float)((1 - a_) * (1 - b_) * v00_ + a_ * (1 - b_) * v10_ + (1 - a_) * b_ * v01_ +                \
+                        a_ * b_ * v11_);                                                                            \
+    } while (0)
+
+/* Stereo_Matches::min_Edge_Photometric_Residual_by_Gauss_Newton_along_EpipolarLine, src/Stereo_Matches.cpp:1159-1288,
+ * driven as refine_edge_disparity does (:1290-1358): epipolar direction (-b, a)/|(-b, a)| (:1331-1336), init_alpha 0. */
+static void gn_stereo_one(const uint8_t *imgL, const uint8_t *imgR, const float *gxR, const float *gyR, int h, int w,
+                          ptrdiff_t sL, ptrdiff_t sR, const orc_edge *le, const double *line, double rx, double ry,
+                          int max_iter, double tol, double huber, int math_mode, double *alpha_out, double *score,
+                          double *conf, uint8_t *valid, int32_t *iters, double *rxy)
+{
+#define PIXL(y, x) ((float)imgL[(ptrdiff_t)(y) * sL + (x)])
+#define PIXR(y, x) ((float)imgR[(ptrdiff_t)(y) * sR + (x)])
+#define PIXGX(y, x) (gxR[(size_t)(y) * w + (x)])
+#define PIXGY(y, x) (gyR[(size_t)(y) * w + (x)])
+    double ex = -line[1], ey = line[0]; /* :1331 */
+    const double en = sqrt(ex * ex + ey * ey);
+    ex /= en;
+    ey /= en;
+    double st, ct;
+    if (math_mode == ORC_MATH_LIBM)
+    {
+        ct = cos(le->theta);
+        st = sin(le->theta);
+    }
+    else
+        ebvo_sincos(le->theta, &st, &ct);
+    const double nx = -st, ny = ct;           /* n(-t.y, t.x), :1172 */
+    const double side = (7 / 2.0) + 1.0;      /* :1173, PATCH_SIZE 7 */
+    const double cpx = le->x + nx * side, cpy = le->y + ny * side; /* :1176 */
+    const double cmx = le->x - nx * side, cmy = le->y - ny * side;
+    double Lc[2][49];
+    for (int sd = 0; sd < 2; sd++)
+    {
+        const double cx = sd ? cmx : cpx, cy = sd ? cmy : cpy;
+        double pf[49], sum = 0;
+        int k = 0;
+        for (int i = -3; i <= 3; i++)
+            for (int j = -3; j <= 3; j++, k++)
+            {
+                float v;
+                ORC_GN_SAMPLE(PIXL, w, h, cx + ct * i - st * j, cy + st * i + ct * j, v); /* include/utility.h:153 */
+                pf[k] = (double)v;
+            }
+        for (k = 0; k < 49; k++)
+            sum += pf[k];
+        const double mean = sum / 49; /* util_vector_mean */
+        for (k = 0; k < 49; k++)
+            Lc[sd][k] = pf[k] - mean;
+    }
+    double alpha = 0.0;
+    int n_log = 0;
+    *valid = 2; /* the reference leaves its outputs uninitialised when it stops on H < 1e-8 (:1255) */
+    *score = NAN;
+    *conf = NAN;
+    int iter = 0;
+    for (; iter < max_iter; ++iter)
+    {
+        const double shx = ex * alpha, shy = ey * alpha; /* alpha * epipolar_direction */
+        double H = 0.0, b = 0.0, cost = 0.0;
+        double Rf[2][49], Gx[2][49], Gy[2][49], meanR[2];
+        for (int sd = 0; sd < 2; sd++)
+        {
+            const double cx = (sd ? rx - nx * side : rx + nx * side) + shx; /* :1204-1205 */
+            const double cy = (sd ? ry - ny * side : ry + ny * side) + shy;
+            int k = 0;
+            double sum = 0;
+            for (int i = -3; i <= 3; i++)
+                for (int j = -3; j <= 3; j++, k++)
+                {
+                    const double X = cx + ct * i - st * j, Y = cy + st * i + ct * j;
+                    float v, g1, g2;
+                    ORC_GN_SAMPLE(PIXR, w, h, X, Y, v);
+                    ORC_GN_SAMPLE(PIXGX, w, h, X, Y, g1);
+                    ORC_GN_SAMPLE(PIXGY, w, h, X, Y, g2);
+                    Rf[sd][k] = (double)v;
+                    Gx[sd][k] = (double)g1;
+                    Gy[sd][k] = (double)g2;
+                }
+            for (k = 0; k < 49; k++)
+                sum += Rf[sd][k];
+            meanR[sd] = sum / 49;
+        }
+        for (int sd = 0; sd < 2; sd++)
+            for (int k = 0; k < 49; k++)
+            {
+                const double r = Lc[sd][k] - (Rf[sd][k] - meanR[sd]);
+                const double g = -Gx[sd][k] * ex + Gy[sd][k] * ey; /* :1237 */
+                const double absr = fabs(r);
+                const double wgt = (absr <= huber) ? 1.0 : huber / absr;
+                H += wgt * g * g;
+                b += wgt * g * r;
+                cost += wgt * r * r;
+            }
+        if (H < 1e-8)
+            break;
+        const double delta = -b / H;
+        alpha += delta;
+        const double rms = sqrt(cost / 98);
+        n_log++;
+        const int is_outlier = (rms > huber * 2.0) || (n_log < 2);
+        if (fabs(delta) < tol || iter == max_iter - 1)
+        {
+            *valid = is_outlier ? 0 : 1;
+            *score = rms;
+            *conf = exp(-rms / huber);
+            ++iter;
+            break;
+        }
+    }
+    *alpha_out = alpha;
+    *iters = iter;
+    rxy[0] = rx + ex * alpha; /* :1349-1351 */
+    rxy[1] = ry + ey * alpha;
+#undef PIXL
+#undef PIXR
+#undef PIXGX
+#undef PIXGY
+}
+
+void orc_gn_refine_stereo(const uint8_t *imgL, const uint8_t *imgR, int h, int w, ptrdiff_t strideL, ptrdiff_t strideR,
+                          const orc_edge *L, const double *lines, const int32_t *row_ptr, int nL, const double *cand_xy,
+                          int max_iter, double tol, double huber_delta, int math_mode, int nthreads, double *alpha,
+                          double *score, double *confidence, uint8_t *validity, int32_t *iters, double *refined_xy)
+{
+    float *gx = (float *)malloc(sizeof(float) * (size_t)h * w), *gy = (float *)malloc(sizeof(float) * (size_t)h * w);
+    orc_sobel_gradients(imgR, h, w, strideR, gx, gy);
+#pragma omp parallel for schedule(dynamic, 16) num_threads(nthreads > 0 ? nthreads : omp_get_max_threads())
+    for (int i = 0; i < nL; i++)
+        for (int k = row_ptr[i]; k < row_ptr[i + 1]; k++)
+            gn_stereo_one(imgL, imgR, gx, gy, h, w, strideL, strideR, &L[i], lines + (size_t)i * 3, cand_xy[2 * (size_t)k],
+                          cand_xy[2 * (size_t)k + 1], max_iter, tol, huber_delta, math_mode, &alpha[k], &score[k],
+                          &confidence[k], &validity[k], &iters[k], &refined_xy[2 * (size_t)k]);
+    free(gx);
+    free(gy);
+}
+
 void orc_atan2_v(const double *y, const double *x, int n, int math_mode, double *out)
 {
     for (int k = 0; k < n; k++)

@@ -99,6 +99,20 @@ uint64_t orc_fnv1a64(const uint8_t *bytes, size_t n);
 /* with_theta != 0: "xy-theta-i" hash (24 raw bytes + index); else "xyi" (16 raw bytes + index). */
 uint64_t orc_edge_hash(const orc_edge *e, int n, int with_theta);
 
+/* util_compute_Img_Gradients (include/utility.h:131-141): Sobel 3x3 / 8 with BORDER_REFLECT_101, float planes h x w. */
+void orc_sobel_gradients(const uint8_t *img, int h, int w, ptrdiff_t stride, float *gx, float *gy);
+
+/*
+ * Photometric Gauss-Newton refinement of each (left edge i, candidate k) pair along the epipolar line of edge i
+ * (src/Stereo_Matches.cpp:1159-1358).  cand_xy = n_pairs x 2 right-image locations; outputs per pair: alpha, final
+ * RMS score, confidence exp(-rms/huber), validity (0 / 1; 2 = the reference stops on H < 1e-8 without setting its
+ * outputs -- score and confidence are NaN here), iterations executed, refined right location.  PARITY UNPINNED.
+ */
+void orc_gn_refine_stereo(const uint8_t *imgL, const uint8_t *imgR, int h, int w, ptrdiff_t strideL, ptrdiff_t strideR,
+                          const orc_edge *L, const double *lines, const int32_t *row_ptr, int nL, const double *cand_xy,
+                          int max_iter, double tol, double huber_delta, int math_mode, int nthreads, double *alpha,
+                          double *score, double *confidence, uint8_t *validity, int32_t *iters, double *refined_xy);
+
 #ifdef __cplusplus
 }
 #endif

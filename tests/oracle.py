@@ -121,6 +121,34 @@ def ncc_pairs(imgL, imgR, L, Rc, row_ptr, thr=0.6, math_mode=PORTABLE, nthreads=
     return sims, best, keep, lp
 
 
+def sobel_gradients(img):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w = img.shape
+    gx = np.zeros((h, w), dtype=np.float32)
+    gy = np.zeros((h, w), dtype=np.float32)
+    lib().orc_sobel_gradients(_p(img), h, w, C.c_ssize_t(img.strides[0]), _p(gx), _p(gy))
+    return gx, gy
+
+
+def gn_refine_stereo(imgL, imgR, L, lines, row_ptr, cand_xy, max_iter=20, tol=1e-3, huber_delta=3.0, math_mode=PORTABLE,
+                     nthreads=0):
+    imgL = np.ascontiguousarray(imgL, dtype=np.uint8)
+    imgR = np.ascontiguousarray(imgR, dtype=np.uint8)
+    h, w = imgL.shape
+    L = np.ascontiguousarray(L, dtype=EDGE_DTYPE)
+    lines = np.ascontiguousarray(lines, dtype=np.float64).reshape(-1, 3)
+    row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int32)
+    cand_xy = np.ascontiguousarray(cand_xy, dtype=np.float64).reshape(-1, 2)
+    n = int(row_ptr[-1])
+    out = dict(alpha=np.zeros(n), score=np.zeros(n), confidence=np.zeros(n), validity=np.zeros(n, dtype=np.uint8),
+               iters=np.zeros(n, dtype=np.int32), refined_xy=np.zeros((n, 2)))
+    lib().orc_gn_refine_stereo(_p(imgL), _p(imgR), h, w, C.c_ssize_t(imgL.strides[0]), C.c_ssize_t(imgR.strides[0]),
+                               _p(L), _p(lines), _p(row_ptr), len(L), _p(cand_xy), int(max_iter), C.c_double(tol),
+                               C.c_double(huber_delta), math_mode, nthreads, _p(out["alpha"]), _p(out["score"]),
+                               _p(out["confidence"]), _p(out["validity"]), _p(out["iters"]), _p(out["refined_xy"]))
+    return out
+
+
 def ncc_quads(kfL, kfR, cfL, cfR, thr=0.8, nthreads=0):
     arrs = [np.ascontiguousarray(a, dtype=np.float32).reshape(-1, 98) for a in (kfL, kfR, cfL, cfR)]
     n = len(arrs[0])

@@ -1,0 +1,32 @@
+"""Kernel time of the photometric refinement on every kept match of the KITTI-shaped S2 pair."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from edge_based_visual_odometry_amd import synth
+from edge_based_visual_odometry_amd.api import Context
+
+h, w = synth.SHAPES["kitti"]
+F = synth.fundamental_for("kitti")
+l, r = synth.stereo_pair("s2", h, w)
+with Context(h, w, toed_mode="hybrid") as c:
+    c.stereo_upload(l, r)
+    cnt = c.stereo_run(c.default_params(F))
+    o = c.stereo_fetch(cnt)
+    keep = o["keep"].astype(bool)
+    rows = np.repeat(np.arange(cnt.n_left), np.diff(o["row_ptr"]))[keep]
+    rp = np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=cnt.n_left))]).astype(np.int32)
+    cand = np.stack([o["right"]["x"][o["col_idx"][keep]], o["right"]["y"][o["col_idx"][keep]]], 1)
+    lines = c.epipolar_lines(F, o["left"])
+    c.gn_refine_stereo(l, r, o["left"], lines, rp, cand)
+    c.profile_reset()
+    c.profile_enable(True)
+    t0 = time.perf_counter()
+    out = c.gn_refine_stereo(l, r, o["left"], lines, rp, cand)
+    dt = time.perf_counter() - t0
+    c.profile_enable(False)
+    prof = c.profile_get()
+    print("pairs", len(cand), "valid", float((out["validity"] == 1).mean()), "mean iters", float(out["iters"].mean()),
+          "max iters", int(out["iters"].max()))
+    print("host call %.2f ms" % (dt * 1e3), {k: round(v[0], 3) for k, v in prof.items() if v[1]})
+    hist = np.bincount(out["iters"], minlength=21)
+    print("iteration histogram", hist.tolist())
