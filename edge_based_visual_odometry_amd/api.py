@@ -197,6 +197,31 @@ class Context:
         self._check(rc, "ebvo_gn_refine_stereo")
         return out
 
+    def _gn_params(self, max_iter=None, tol=None, huber_delta=None):
+        from ._lib import GnParams
+        p = GnParams()
+        self.lib.ebvo_gn_default_params(p)
+        if max_iter is not None:
+            p.max_iter = int(max_iter)
+        if tol is not None:
+            p.tol = float(tol)
+        if huber_delta is not None:
+            p.huber_delta = float(huber_delta)
+        return p
+
+    def stereo_refine(self, counts, slot=0, **kw):
+        """Refine every kept match of the resident pair on the device; returns the per-pair outputs (n_pairs entries,
+        validity 255 where the pair was not a kept match)."""
+        p = self._gn_params(**kw)
+        self._check(self.lib.ebvo_stereo_refine(self._ctx, slot, C.byref(p)), "ebvo_stereo_refine")
+        n = int(counts.n_pairs)
+        out = dict(alpha=np.zeros(n), score=np.zeros(n), confidence=np.zeros(n), validity=np.zeros(n, dtype=np.uint8),
+                   iters=np.zeros(n, dtype=np.int32), refined_xy=np.zeros((n, 2)))
+        self._check(self.lib.ebvo_stereo_fetch_refined(self._ctx, slot, ptr(out["alpha"]), ptr(out["score"]),
+                                                       ptr(out["confidence"]), ptr(out["validity"]), ptr(out["iters"]),
+                                                       ptr(out["refined_xy"])), "ebvo_stereo_fetch_refined")
+        return out
+
     # -- Utility::get_edge_patches ------------------------------------------------------------
     def edge_patches(self, img, edges) -> np.ndarray:
         img = _u8(img)

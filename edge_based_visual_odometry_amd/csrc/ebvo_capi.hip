@@ -337,7 +337,7 @@ static int host_slot(ebvo_ctx *ctx, Slot **out)
         ctx->last_error = "slot 0 has a submitted pair in flight; call ebvo_stereo_wait first";
         return EBVO_ERR_STATE;
     }
-    s.have_pair = s.have_run = false;
+    s.have_pair = s.have_run = s.have_refined = false;
     *out = &s;
     return EBVO_OK;
 }
@@ -606,7 +606,8 @@ extern "C" int ebvo_gn_refine_stereo(ebvo_ctx *ctx, const uint8_t *imgL, const u
         (rc = match_expand_rows_enqueue(ctx, s, (const int32_t *)s.row_ptr.p, nL, np, (int32_t *)s.pair_left.p)) ||
         (rc = refine_gn_stereo_enqueue(ctx, s, s.im[0].img, s.im[1].img, s.grad_x.p, h, w, (const ebvo_edge *)s.scratch_b.p,
                                        (const double *)s.lines.p, (const int32_t *)s.pair_left.p,
-                                       (const double *)s.gn_xy.p, np, params->max_iter, params->tol, params->huber_delta,
+                                       (const double *)s.gn_xy.p, nullptr, nullptr, nullptr, np, params->max_iter,
+                                       params->tol, params->huber_delta,
                                        out, out + npz, out + 2 * npz, (uint8_t *)s.gn_valid.p, (int32_t *)s.gn_iters.p,
                                        out + 3 * npz)))
         return rc;
@@ -927,7 +928,7 @@ extern "C" int ebvo_stereo_submit(ebvo_ctx *ctx, int slot, const ebvo_stereo_par
         return EBVO_ERR_STATE;
     EBVO_HIP(ctx, hipSetDevice(ctx->device));
     int rc;
-    s.have_run = false;
+    s.have_run = s.have_refined = false;
     s.params = *p;
     s.prof_now = ctx->prof && (ctx->prof_submits++ % ctx->prof_every == 0);
     {
@@ -1018,6 +1019,75 @@ extern "C" int ebvo_stereo_run(ebvo_ctx *ctx, const ebvo_stereo_params *p, ebvo_
     if (rc)
         return rc;
     return ebvo_stereo_wait(ctx, 0, counts);
+}
+
+// ---- photometric refinement of the kept matches of a resident pair ---------------------------------------------
+extern "C" int ebvo_stereo_refine(ebvo_ctx *ctx, int slot, const ebvo_gn_params *params)
+{
+    Slot *sp;
+    if (!params || params->max_iter < 1 || !(params->tol >= 0) || !(params->huber_delta > 0) || get_slot(ctx, slot, &sp))
+        return EBVO_ERR_ARG;
+    Slot &s = *sp;
+    if (!s.have_run || s.in_flight)
+        return EBVO_ERR_STATE;
+    EBVO_HIP(ctx, hipSetDevice(ctx->device));
+    const int64_t np = s.result.n_pairs;
+    s.have_refined = false;
+    if (np == 0)
+    {
+        s.have_refined = true;
+        return EBVO_OK;
+    }
+    const int h = s.cur_h, w = s.cur_w;
+    const size_t npz = (size_t)np;
+    int rc;
+    if ((rc = ebvo_grow(ctx, s, s.grad_x, 2 * sizeof(float) * (size_t)h * w + 64)) ||
+        (rc = ebvo_grow(ctx, s, s.gn_out, sizeof(double) * 5 * npz)) || (rc = ebvo_grow(ctx, s, s.gn_valid, npz)) ||
+        (rc = ebvo_grow(ctx, s, s.gn_iters, sizeof(int32_t) * npz)))
+        return rc;
+    double *out = (double *)s.gn_out.p;
+    // the pipeline's own device arrays: left / right TOED edges, epipolar lines, CSR expansion, NCC keep flags
+    if ((rc = refine_sobel_enqueue(ctx, s, s.im[1].img, h, w, w, nullptr, nullptr, s.grad_x.p)) ||
+        (rc = refine_gn_stereo_enqueue(ctx, s, s.im[0].img, s.im[1].img, s.grad_x.p, h, w, s.im[0].edges,
+                                       (const double *)s.lines.p, (const int32_t *)s.pair_left.p, nullptr, s.im[1].edges,
+                                       (const int32_t *)s.col_idx.p, (const uint8_t *)s.keep.p, np, params->max_iter,
+                                       params->tol, params->huber_delta, out, out + npz, out + 2 * npz,
+                                       (uint8_t *)s.gn_valid.p, (int32_t *)s.gn_iters.p, out + 3 * npz)))
+        return rc;
+    EBVO_HIP(ctx, hipStreamSynchronize(s.stream));
+    s.have_refined = true;
+    return EBVO_OK;
+}
+
+extern "C" int ebvo_stereo_fetch_refined(ebvo_ctx *ctx, int slot, double *alpha, double *score, double *confidence,
+                                         uint8_t *validity, int32_t *iters, double *refined_xy)
+{
+    Slot *sp;
+    if (get_slot(ctx, slot, &sp))
+        return EBVO_ERR_ARG;
+    Slot &s = *sp;
+    if (!s.have_refined || s.in_flight)
+        return EBVO_ERR_STATE;
+    EBVO_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t npz = (size_t)s.result.n_pairs;
+    if (!npz)
+        return EBVO_OK;
+    const double *out = (const double *)s.gn_out.p;
+    hipStream_t st = s.stream;
+    if (alpha)
+        EBVO_HIP(ctx, hipMemcpyAsync(alpha, out, sizeof(double) * npz, hipMemcpyDeviceToHost, st));
+    if (score)
+        EBVO_HIP(ctx, hipMemcpyAsync(score, out + npz, sizeof(double) * npz, hipMemcpyDeviceToHost, st));
+    if (confidence)
+        EBVO_HIP(ctx, hipMemcpyAsync(confidence, out + 2 * npz, sizeof(double) * npz, hipMemcpyDeviceToHost, st));
+    if (refined_xy)
+        EBVO_HIP(ctx, hipMemcpyAsync(refined_xy, out + 3 * npz, sizeof(double) * 2 * npz, hipMemcpyDeviceToHost, st));
+    if (validity)
+        EBVO_HIP(ctx, hipMemcpyAsync(validity, s.gn_valid.p, npz, hipMemcpyDeviceToHost, st));
+    if (iters)
+        EBVO_HIP(ctx, hipMemcpyAsync(iters, s.gn_iters.p, sizeof(int32_t) * npz, hipMemcpyDeviceToHost, st));
+    EBVO_HIP(ctx, hipStreamSynchronize(st));
+    return EBVO_OK;
 }
 
 extern "C" int ebvo_stereo_fetch_slot(ebvo_ctx *ctx, int slot, ebvo_edge *left, ebvo_edge *right, int32_t *row_ptr,

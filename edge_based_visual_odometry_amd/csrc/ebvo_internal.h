@@ -104,7 +104,7 @@ struct Slot
     hipStream_t stream = nullptr;
     ImageWS im[2];
     int cur_h = 0, cur_w = 0;
-    bool have_pair = false, have_run = false, in_flight = false;
+    bool have_pair = false, have_run = false, in_flight = false, have_refined = false;
 
     // matching workspace
     GrowBuf grad_x, grad_y, gn_xy, gn_out, gn_valid, gn_iters, gn_state, gn_lists; // photometric refinement (refine_kernels.hip)
@@ -216,9 +216,10 @@ int refine_sobel_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_img, int h, in
                          void *d_gxy /* optional interleaved float2 plane */);
 int refine_gn_stereo_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_imgL, const uint8_t *d_imgR, const void *d_gxy,
                              int h, int w, const ebvo_edge *d_L, const double *d_lines,
-                             const int32_t *d_pair_left, const double *d_cand_xy, int64_t n_pairs, int max_iter,
-                             double tol, double huber, double *d_alpha, double *d_score, double *d_conf,
-                             uint8_t *d_valid, int32_t *d_iters, double *d_refined_xy);
+                             const int32_t *d_pair_left, const double *d_cand_xy /* or NULL with R + col_idx */,
+                             const ebvo_edge *d_R, const int32_t *d_col_idx, const uint8_t *d_keep /* optional */,
+                             int64_t n_pairs, int max_iter, double tol, double huber, double *d_alpha, double *d_score,
+                             double *d_conf, uint8_t *d_valid, int32_t *d_iters, double *d_refined_xy);
 int match_expand_rows_enqueue(ebvo_ctx *ctx, Slot &s, const int32_t *d_row_ptr, int nL, int64_t n_pairs, int32_t *d_pair_left);
 int match_ncc_stored_enqueue(ebvo_ctx *ctx, Slot &s, const float *d_A, const float *d_B, int n, double *d_sim);
 int misc_fp64_peak(ebvo_ctx *ctx, Slot &s, int iters, double *tf_muladd, double *tf_fma);

@@ -118,7 +118,10 @@ struct GnArgs
     const ebvo_edge *L;       // left edges
     const double *lines;      // nL x 3
     const int32_t *pair_left; // pair -> left edge
-    const double *cand_xy;    // n_pairs x 2
+    const double *cand_xy;    // n_pairs x 2, or NULL: candidate k is the right edge R[col_idx[k]] (device pipeline)
+    const ebvo_edge *R;
+    const int32_t *col_idx;
+    const uint8_t *keep;      // optional: only pairs with keep[k] != 0 are refined, the others get validity 255
     int64_t n_pairs;
     int max_iter;
     double tol, huber;
@@ -148,13 +151,53 @@ __device__ inline void gn_geometry(const GnArgs &A, int64_t k, ebvo_edge &le, do
     ey /= en;
 }
 
+__device__ inline void gn_candidate(const GnArgs &A, int64_t k, double &rx, double &ry)
+{
+    if (A.cand_xy)
+    {
+        rx = A.cand_xy[2 * k];
+        ry = A.cand_xy[2 * k + 1];
+    }
+    else
+    {
+        const int c = A.col_idx[k];
+        rx = A.R[c].x;
+        ry = A.R[c].y;
+    }
+}
+
 __global__ __launch_bounds__(256) void gn_init_kernel(GnArgs A)
 {
-    if (blockIdx.x == 0 && threadIdx.x == 0)
-        A.counts[0] = (int32_t)A.n_pairs;
     const int h = A.h, w = A.w;
-    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < A.n_pairs; k += (int64_t)gridDim.x * blockDim.x)
+    const int lane = threadIdx.x & 63;
+    const int64_t span = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t k0 = (int64_t)blockIdx.x * blockDim.x; k0 < A.n_pairs; k0 += span)
     {
+        const int64_t k = k0 + threadIdx.x;
+        const bool inside = k < A.n_pairs;
+        const bool active = inside && (!A.keep || A.keep[k]);
+        // the first active list, one atomic per wave (its order does not influence any result)
+        const unsigned long long m = __ballot(active);
+        int wbase = 0;
+        if (lane == 0 && m)
+            wbase = atomicAdd(&A.counts[0], __popcll(m));
+        wbase = __shfl(wbase, 0);
+        if (active)
+            A.list[0][wbase + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)k;
+        if (inside && !active)
+        {
+            double rx, ry;
+            gn_candidate(A, k, rx, ry);
+            A.alpha[k] = 0.0;
+            A.score[k] = __builtin_nan("");
+            A.conf[k] = __builtin_nan("");
+            A.valid[k] = 255; // not a kept match: not refined
+            A.iters[k] = 0;
+            A.refined_xy[2 * k] = rx;
+            A.refined_xy[2 * k + 1] = ry;
+        }
+        if (!active)
+            continue;
         ebvo_edge le;
         double ex, ey, st, ct;
         gn_geometry(A, k, le, ex, ey);
@@ -181,7 +224,6 @@ __global__ __launch_bounds__(256) void gn_init_kernel(GnArgs A)
         A.conf[k] = __builtin_nan("");
         A.valid[k] = 2; // the reference leaves its outputs unset when it stops on H < 1e-8 (:1255)
         A.iters[k] = 0;
-        A.list[0][k] = (int32_t)k;
     }
 }
 
@@ -205,7 +247,8 @@ __global__ __launch_bounds__(256) void gn_iter_kernel(GnArgs A, int it)
             gn_geometry(A, k, le, ex, ey);
             const double st = A.sc[k], ct = A.sc[A.n_pairs + k];
             const double nx = -st, ny = ct, side = (7 / 2.0) + 1.0;
-            const double rx = A.cand_xy[2 * k], ry = A.cand_xy[2 * k + 1];
+            double rx, ry;
+            gn_candidate(A, k, rx, ry);
             const double meanL[2] = {A.mean_l[k], A.mean_l[A.n_pairs + k]};
             double alpha = A.alpha[k];
             const double shx = ex * alpha, shy = ey * alpha;
@@ -308,7 +351,8 @@ int refine_sobel_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_img, int h, in
 
 int refine_gn_stereo_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_imgL, const uint8_t *d_imgR, const void *d_gxy,
                              int h, int w, const ebvo_edge *d_L, const double *d_lines,
-                             const int32_t *d_pair_left, const double *d_cand_xy, int64_t n_pairs, int max_iter,
+                             const int32_t *d_pair_left, const double *d_cand_xy, const ebvo_edge *d_R,
+                             const int32_t *d_col_idx, const uint8_t *d_keep, int64_t n_pairs, int max_iter,
                              double tol, double huber, double *d_alpha, double *d_score, double *d_conf,
                              uint8_t *d_valid, int32_t *d_iters, double *d_refined_xy)
 {
@@ -333,6 +377,9 @@ int refine_gn_stereo_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_imgL, cons
     A.lines = d_lines;
     A.pair_left = d_pair_left;
     A.cand_xy = d_cand_xy;
+    A.R = d_R;
+    A.col_idx = d_col_idx;
+    A.keep = d_keep;
     A.n_pairs = n_pairs;
     A.max_iter = max_iter;
     A.tol = tol;

@@ -196,6 +196,16 @@ int ebvo_gn_refine_stereo(ebvo_ctx *ctx, const uint8_t *imgL, const uint8_t *img
                           const double *cand_xy, const ebvo_gn_params *params, double *alpha, double *score,
                           double *confidence, uint8_t *validity, int32_t *iters, double *refined_xy);
 
+/*
+ * The same refinement on the pair resident in `slot` after ebvo_stereo_run / ebvo_stereo_wait, without leaving the
+ * device: every candidate pair the NCC filter kept (keep[k] = 1) is refined against its right TOED edge, using the
+ * pipeline's own edge lists, lines and images.  Outputs are indexed like sims / keep (n_pairs entries); pairs that
+ * were not kept get validity 255, alpha 0 and their unrefined location.  Any output pointer may be NULL.
+ */
+int ebvo_stereo_refine(ebvo_ctx *ctx, int slot, const ebvo_gn_params *params);
+int ebvo_stereo_fetch_refined(ebvo_ctx *ctx, int slot, double *alpha, double *score, double *confidence,
+                              uint8_t *validity, int32_t *iters, double *refined_xy);
+
 /* Utility::get_edge_patches for n edges on one image: patches = n x 2 x 49 floats
  * (src/utility.cpp:182-212; used again by finalize_stereo_edge_mates, src/Stereo_Matches.cpp:1622). */
 int ebvo_edge_patches(ebvo_ctx *ctx, const uint8_t *img, int h, int w, ptrdiff_t stride,

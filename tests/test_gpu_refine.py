@@ -114,3 +114,27 @@ def test_refine_full_size_property(ctx):
     assert true.mean() > 0.5
     assert np.median(np.abs(disp[true] - 12.0)) < 0.1
     assert np.all(out["refined_xy"][:, 1] == cand[:, 1])                        # rectified: rows do not move
+
+
+@pytest.mark.parametrize("shape", [(96, 160), (376, 1241)])
+def test_device_resident_refine_equals_host_buffer_call(ctx, shape):
+    """ebvo_stereo_refine on the resident pair == ebvo_gn_refine_stereo fed with the fetched kept matches."""
+    from edge_based_visual_odometry_amd._lib import EbvoError, EBVO_ERR_STATE
+    l, r = synth.stereo_pair("s2", *shape)
+    ctx.stereo_upload(l, r)
+    with pytest.raises(EbvoError) as ei:
+        ctx.stereo_refine(type("C", (), {"n_pairs": 0})())          # nothing has run on the pair yet
+    assert ei.value.status == EBVO_ERR_STATE
+    c = ctx.stereo_run(ctx.default_params(F_KITTI))
+    dev = ctx.stereo_refine(c)
+    o = ctx.stereo_fetch(c)
+    keep = o["keep"].astype(bool)
+    assert np.all(dev["validity"][~keep] == 255) and np.all(dev["validity"][keep] != 255)
+    rows = np.repeat(np.arange(c.n_left), np.diff(o["row_ptr"]))[keep]
+    rp = np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=c.n_left))]).astype(np.int32)
+    cand = np.stack([o["right"]["x"][o["col_idx"][keep]], o["right"]["y"][o["col_idx"][keep]]], 1)
+    host = ctx.gn_refine_stereo(l, r, o["left"], ctx.epipolar_lines(F_KITTI, o["left"]), rp, cand)
+    for k in host:
+        assert_bit_equal(dev[k][keep], host[k], k)
+    xy_all = np.stack([o["right"]["x"][o["col_idx"]], o["right"]["y"][o["col_idx"]]], 1)
+    assert_bit_equal(dev["refined_xy"][~keep], xy_all[~keep], "unrefined locations")

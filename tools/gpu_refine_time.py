@@ -30,3 +30,17 @@ with Context(h, w, toed_mode="hybrid") as c:
     print("host call %.2f ms" % (dt * 1e3), {k: round(v[0], 3) for k, v in prof.items() if v[1]})
     hist = np.bincount(out["iters"], minlength=21)
     print("iteration histogram", hist.tolist())
+
+    # CPU oracle on the host cores of this box, a 1/16 sample of the left edges (bounded run), scaled
+    from tests import oracle as orc
+    nthr = min(16, len(os.sched_getaffinity(0)))
+    sel = np.arange(0, cnt.n_left, 16)
+    counts = np.diff(rp)[sel]
+    rp_s = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    idx = np.concatenate([np.arange(rp[i], rp[i + 1]) for i in sel]) if len(sel) else np.zeros(0, dtype=np.int64)
+    t0 = time.perf_counter()
+    ref = orc.gn_refine_stereo(l, r, o["left"][sel], lines[sel], rp_s, cand[idx], nthreads=nthr)
+    dt = time.perf_counter() - t0
+    print("oracle (%d threads): %.3f s for %d pairs -> %.2f s for all %d pairs" % (nthr, dt, len(idx), dt * len(cand) / len(idx), len(cand)))
+    same = all(np.array_equal(ref[k], out[k][idx], equal_nan=True) for k in ("alpha", "score", "validity", "iters", "refined_xy"))
+    print("sample equals the GPU result bit for bit:", same)
