@@ -244,6 +244,39 @@ class StereoMatcherHIP
         return s;
     }
 
+    // refine_edge_disparity (:1290-1358): photometric Gauss-Newton of every (left edge, candidate centre) pair along
+    // the epipolar line.  Images are the undistorted left / right images; pass them swapped for is_left = false.
+    struct Refined
+    {
+        std::vector<double> alpha, score, confidence, xy; // xy: n_pairs x 2 updated centre locations (:1349-1351)
+        std::vector<uint8_t> validity;                    // refine_validities; 2 = left undefined by the reference
+        std::vector<int32_t> iters;
+    };
+    Refined refine(const uint8_t *imgL, const uint8_t *imgR, int rows, int cols, ptrdiff_t stepL, ptrdiff_t stepR,
+                   const std::vector<EdgeT> &left, const std::vector<std::array<double, 3>> &lines,
+                   const std::vector<int32_t> &row_ptr, const std::vector<double> &candidate_xy)
+    {
+        Refined r;
+        const size_t n = candidate_xy.size() / 2;
+        std::vector<ebvo_edge> L(left.size());
+        for (size_t k = 0; k < left.size(); ++k)
+            L[k] = to_abi(left[k]);
+        r.alpha.resize(n);
+        r.score.resize(n);
+        r.confidence.resize(n);
+        r.xy.resize(2 * n);
+        r.validity.resize(n);
+        r.iters.resize(n);
+        ebvo_gn_params p;
+        ebvo_gn_default_params(&p);
+        last_status = ebvo_gn_refine_stereo(ctx_->get(), imgL, imgR, rows, cols, stepL, stepR, L.data(), (int)L.size(),
+                                            lines.empty() ? nullptr : lines[0].data(), row_ptr.data(), candidate_xy.data(),
+                                            &p, r.alpha.data(), r.score.data(), r.confidence.data(), r.validity.data(),
+                                            r.iters.data(), r.xy.data());
+        report(*ctx_, last_status, "ebvo_gn_refine_stereo");
+        return r;
+    }
+
   private:
     Context::Ptr ctx_;
 };

@@ -133,6 +133,48 @@ void Stereo_Matches::apply_NCC_Filtering(Stereo_Edge_Pairs &p, const std::string
     }
 }
 
+// refine_edge_disparity (src/Stereo_Matches.cpp:1290-1358): every (focused edge, cluster centre) pair is refined on the
+// device; the loop below only scatters the results back into the reference's containers.
+void Stereo_Matches::refine_edge_disparity(Stereo_Edge_Pairs &p, size_t, bool is_left)
+{
+    const cv::Mat &imgL = is_left ? p.stereo_frame->left_image_undistorted : p.stereo_frame->right_image_undistorted;
+    const cv::Mat &imgR = is_left ? p.stereo_frame->right_image_undistorted : p.stereo_frame->left_image_undistorted;
+    const std::vector<Edge> left = p.get_focused_edges();
+    std::vector<int32_t> row_ptr(left.size() + 1, 0);
+    std::vector<double> cand_xy;
+    std::vector<std::array<double, 3>> lines(left.size());
+    for (size_t i = 0; i < left.size(); ++i)
+    {
+        const Eigen::Vector3d &l = p.epip_line_coeffs_of_left_edges[i]; // :1331
+        lines[i] = {l(0), l(1), l(2)};
+        for (const EdgeCluster &ec : p.matching_edge_clusters[i].edge_clusters)
+        {
+            cand_xy.push_back(ec.center_edge.location.x);
+            cand_xy.push_back(ec.center_edge.location.y);
+        }
+        row_ptr[i + 1] = (int32_t)(cand_xy.size() / 2);
+    }
+    auto m = matcher();
+    auto r = m.refine(imgL.data, imgR.data, imgL.rows, imgL.cols, (ptrdiff_t)imgL.step, (ptrdiff_t)imgR.step, left, lines,
+                      row_ptr, cand_xy);
+    for (size_t i = 0; i < left.size(); ++i)
+    {
+        auto &mc = p.matching_edge_clusters[i];
+        mc.refine_final_scores.clear();
+        mc.refine_confidences.clear();
+        mc.refine_validities.clear();
+        for (int32_t k = row_ptr[i]; k < row_ptr[i + 1]; ++k)
+        {
+            EdgeCluster &ec = mc.edge_clusters[(size_t)(k - row_ptr[i])];
+            mc.refine_final_scores.push_back(r.score[k]); // NaN where the reference leaves the value undefined (:1255)
+            mc.refine_confidences.push_back(r.confidence[k]);
+            mc.refine_validities.push_back(r.validity[k] == 1);
+            ec.center_edge.location.x = r.xy[2 * k]; // :1349-1351
+            ec.center_edge.location.y = r.xy[2 * k + 1];
+        }
+    }
+}
+
 void Temporal_Matches::apply_NCC_filtering_quads(std::vector<KF_Temporal_Edge_Quads> &quads_by_kf,
                                                  const std::vector<final_stereo_edge_pair> &CF, double thr, const cv::Mat &,
                                                  const cv::Mat &, const cv::Mat &, const cv::Mat &)

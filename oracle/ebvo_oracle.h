@@ -9,6 +9,8 @@
  * known-answer hash recorded from the unmodified reference source in SURVEY.md section 8(c)
  * (tests/test_oracle_kat.py); the NCC restatement reproduces the reference fixture
  * test/ncc_debug_frame1_edge8 (tests/test_oracle_ncc_fixture.py) to its 8-bit precision.
+ * PARITY UNPINNED for orc_gn_refine_stereo / orc_sobel_gradients (the reference holds no fixture for its photometric
+ * refinement): see tests/test_oracle_gn.py for what anchors them instead.
  */
 #ifndef EBVO_ORACLE_H
 #define EBVO_ORACLE_H

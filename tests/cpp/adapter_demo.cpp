@@ -77,6 +77,17 @@ int main(int argc, char **argv)
     if (matcher.last_status != EBVO_OK)
         return 5;
     const double self = ebvo::patch_similarity(*TOED->context(), s.left_patches.data(), s.left_patches.data());
+    // refine_edge_disparity: every candidate pair, candidate centre = the right TOED edge
+    std::vector<double> cand_xy(2 * cand.size());
+    for (size_t k = 0; k < cand.size(); ++k)
+    {
+        cand_xy[2 * k] = cand[k].location.x;
+        cand_xy[2 * k + 1] = cand[k].location.y;
+    }
+    auto refined = matcher.refine(left.data, right.data, h, w, (ptrdiff_t)left.step, (ptrdiff_t)right.step, left_edges, lines,
+                                  c.row_ptr, cand_xy);
+    if (matcher.last_status != EBVO_OK)
+        return 6;
 
     FILE *o = std::fopen(argv[5], "wb");
     int32_t hdr[5] = {(int32_t)left_edges.size(), (int32_t)right_edges.size(), totalL, totalR, (int32_t)cand.size()};
@@ -92,6 +103,10 @@ int main(int argc, char **argv)
     std::fwrite(s.pp_nn_pn_np.data(), sizeof(double), s.pp_nn_pn_np.size(), o);
     std::fwrite(s.keep.data(), 1, s.keep.size(), o);
     std::fwrite(&self, sizeof self, 1, o);
+    std::fwrite(refined.alpha.data(), sizeof(double), refined.alpha.size(), o);
+    std::fwrite(refined.score.data(), sizeof(double), refined.score.size(), o);
+    std::fwrite(refined.xy.data(), sizeof(double), refined.xy.size(), o);
+    std::fwrite(refined.validity.data(), 1, refined.validity.size(), o);
     std::fclose(o);
     std::printf("adapter_demo ok: %zu + %zu edges, %zu pairs\n", left_edges.size(), right_edges.size(), cand.size());
     return 0;

@@ -46,7 +46,11 @@ def test_adapter_matches_oracle(tmp_path):
     ci = np.frombuffer(buf, dtype=np.int32, count=npairs, offset=off); off += 4 * npairs
     sims = np.frombuffer(buf, dtype=np.float64, count=4 * npairs, offset=off).reshape(-1, 4); off += 32 * npairs
     keep = np.frombuffer(buf, dtype=np.uint8, count=npairs, offset=off); off += npairs
-    self_sim = np.frombuffer(buf, dtype=np.float64, count=1, offset=off)[0]
+    self_sim = np.frombuffer(buf, dtype=np.float64, count=1, offset=off)[0]; off += 8
+    alpha = np.frombuffer(buf, dtype=np.float64, count=npairs, offset=off); off += 8 * npairs
+    score = np.frombuffer(buf, dtype=np.float64, count=npairs, offset=off); off += 8 * npairs
+    xy = np.frombuffer(buf, dtype=np.float64, count=2 * npairs, offset=off).reshape(-1, 2); off += 16 * npairs
+    valid = np.frombuffer(buf, dtype=np.uint8, count=npairs, offset=off)
     ol, orr = orc.toed(l), orc.toed(r)
     assert (tL, tR) == (ol["n_total"], orr["n_total"])
     assert_edges_equal(L, ol["edges"])
@@ -61,3 +65,9 @@ def test_adapter_matches_oracle(tmp_path):
     assert_bit_equal(sims, osims)
     assert_bit_equal(keep, okeep)
     assert self_sim == orc.patch_similarity(olp[0, 0], olp[0, 0])
+    cand_xy = np.stack([orr["edges"]["x"][oci], orr["edges"]["y"][oci]], 1)
+    ref = orc.gn_refine_stereo(l, r, ol["edges"], lines, orp, cand_xy)
+    assert_bit_equal(alpha, ref["alpha"])
+    assert_bit_equal(score, ref["score"])
+    assert_bit_equal(xy, ref["refined_xy"])
+    assert_bit_equal(valid, ref["validity"])
