@@ -209,6 +209,23 @@ class Context:
             p.huber_delta = float(huber_delta)
         return p
 
+    # -- Temporal_Matches::min_Edge_Photometric_Residual_by_Gauss_Newton (src/Temporal_Matches.cpp:735-851) ------
+    def gn_refine_temporal(self, imgKF, imgCF, kf, cf, init_disp, **kw):
+        imgKF, imgCF = _u8(imgKF), _u8(imgCF)
+        h, w = imgKF.shape
+        kf, cf = _edges(kf), _edges(cf)
+        init_disp = np.ascontiguousarray(init_disp, dtype=np.float64).reshape(-1, 2)
+        n = len(kf)
+        assert len(cf) == n and len(init_disp) == n
+        p = self._gn_params(**kw)
+        out = dict(disp=np.zeros((n, 2)), score=np.zeros(n), validity=np.zeros(n, dtype=np.uint8),
+                   iters=np.zeros(n, dtype=np.int32))
+        rc = self.lib.ebvo_gn_refine_temporal(self._ctx, ptr(imgKF), ptr(imgCF), h, w, imgKF.strides[0], imgCF.strides[0],
+                                              ptr(kf), ptr(cf), ptr(init_disp), n, C.byref(p), ptr(out["disp"]),
+                                              ptr(out["score"]), ptr(out["validity"]), ptr(out["iters"]))
+        self._check(rc, "ebvo_gn_refine_temporal")
+        return out
+
     def stereo_refine(self, counts, slot=0, **kw):
         """Refine every kept match of the resident pair on the device; returns the per-pair outputs (n_pairs entries,
         validity 255 where the pair was not a kept match)."""

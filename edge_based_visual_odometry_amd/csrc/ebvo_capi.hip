@@ -1021,6 +1021,50 @@ extern "C" int ebvo_stereo_run(ebvo_ctx *ctx, const ebvo_stereo_params *p, ebvo_
     return ebvo_stereo_wait(ctx, 0, counts);
 }
 
+extern "C" int ebvo_gn_refine_temporal(ebvo_ctx *ctx, const uint8_t *imgKF, const uint8_t *imgCF, int h, int w,
+                                       ptrdiff_t strideKF, ptrdiff_t strideCF, const ebvo_edge *kf, const ebvo_edge *cf,
+                                       const double *init_disp, int n, const ebvo_gn_params *params, double *disp,
+                                       double *score, uint8_t *validity, int32_t *iters)
+{
+    if (!ctx || !imgKF || !imgCF || n < 0 || !params || params->max_iter < 1 || !(params->tol >= 0) ||
+        !(params->huber_delta > 0))
+        return EBVO_ERR_ARG;
+    EBVO_HIP(ctx, hipSetDevice(ctx->device));
+    int rc;
+    Slot *sp;
+    if ((rc = check_size(ctx, h, w)) || (rc = host_slot(ctx, &sp)))
+        return rc;
+    Slot &s = *sp;
+    if (n == 0)
+        return EBVO_OK;
+    if (!kf || !cf || !init_disp || !disp || !score || !validity || !iters)
+        return EBVO_ERR_ARG;
+    const size_t nz = (size_t)n, img_bytes = sizeof(float) * (size_t)h * w;
+    if ((rc = upload_image(ctx, s, 0, imgKF, h, w, strideKF)) || (rc = upload_image(ctx, s, 1, imgCF, h, w, strideCF)) ||
+        (rc = ebvo_grow(ctx, s, s.grad_x, 2 * img_bytes + 64)) || (rc = ebvo_grow(ctx, s, s.scratch_b, sizeof(ebvo_edge) * nz)) ||
+        (rc = ebvo_grow(ctx, s, s.scratch_c, sizeof(ebvo_edge) * nz)) || (rc = ebvo_grow(ctx, s, s.gn_xy, sizeof(double) * 2 * nz)) ||
+        (rc = ebvo_grow(ctx, s, s.gn_out, sizeof(double) * 3 * nz)) || (rc = ebvo_grow(ctx, s, s.gn_valid, nz)) ||
+        (rc = ebvo_grow(ctx, s, s.gn_iters, sizeof(int32_t) * nz)))
+        return rc;
+    hipStream_t st = s.stream;
+    EBVO_HIP(ctx, hipMemcpyAsync(s.scratch_b.p, kf, sizeof(ebvo_edge) * nz, hipMemcpyHostToDevice, st));
+    EBVO_HIP(ctx, hipMemcpyAsync(s.scratch_c.p, cf, sizeof(ebvo_edge) * nz, hipMemcpyHostToDevice, st));
+    EBVO_HIP(ctx, hipMemcpyAsync(s.gn_xy.p, init_disp, sizeof(double) * 2 * nz, hipMemcpyHostToDevice, st));
+    double *out = (double *)s.gn_out.p;
+    if ((rc = refine_sobel_enqueue(ctx, s, s.im[1].img, h, w, w, nullptr, nullptr, s.grad_x.p)) ||
+        (rc = refine_gn_temporal_enqueue(ctx, s, s.im[0].img, s.im[1].img, s.grad_x.p, h, w,
+                                         (const ebvo_edge *)s.scratch_b.p, (const ebvo_edge *)s.scratch_c.p,
+                                         (const double *)s.gn_xy.p, n, params->max_iter, params->tol, params->huber_delta,
+                                         out, out + 2 * nz, (uint8_t *)s.gn_valid.p, (int32_t *)s.gn_iters.p)))
+        return rc;
+    EBVO_HIP(ctx, hipMemcpyAsync(disp, out, sizeof(double) * 2 * nz, hipMemcpyDeviceToHost, st));
+    EBVO_HIP(ctx, hipMemcpyAsync(score, out + 2 * nz, sizeof(double) * nz, hipMemcpyDeviceToHost, st));
+    EBVO_HIP(ctx, hipMemcpyAsync(validity, s.gn_valid.p, nz, hipMemcpyDeviceToHost, st));
+    EBVO_HIP(ctx, hipMemcpyAsync(iters, s.gn_iters.p, sizeof(int32_t) * nz, hipMemcpyDeviceToHost, st));
+    EBVO_HIP(ctx, hipStreamSynchronize(st));
+    return EBVO_OK;
+}
+
 // ---- photometric refinement of the kept matches of a resident pair ---------------------------------------------
 extern "C" int ebvo_stereo_refine(ebvo_ctx *ctx, int slot, const ebvo_gn_params *params)
 {

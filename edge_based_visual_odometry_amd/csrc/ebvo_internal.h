@@ -220,6 +220,10 @@ int refine_gn_stereo_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_imgL, cons
                              const ebvo_edge *d_R, const int32_t *d_col_idx, const uint8_t *d_keep /* optional */,
                              int64_t n_pairs, int max_iter, double tol, double huber, double *d_alpha, double *d_score,
                              double *d_conf, uint8_t *d_valid, int32_t *d_iters, double *d_refined_xy);
+int refine_gn_temporal_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_imgK, const uint8_t *d_imgC, const void *d_gxy,
+                               int h, int w, const ebvo_edge *d_kf, const ebvo_edge *d_cf, const double *d_init, int64_t n,
+                               int max_iter, double tol, double huber, double *d_disp, double *d_score, uint8_t *d_valid,
+                               int32_t *d_iters);
 int match_expand_rows_enqueue(ebvo_ctx *ctx, Slot &s, const int32_t *d_row_ptr, int nL, int64_t n_pairs, int32_t *d_pair_left);
 int match_ncc_stored_enqueue(ebvo_ctx *ctx, Slot &s, const float *d_A, const float *d_B, int n, double *d_sim);
 int misc_fp64_peak(ebvo_ctx *ctx, Slot &s, int iters, double *tf_muladd, double *tf_fma);

@@ -337,6 +337,196 @@ __global__ __launch_bounds__(256) void gn_iter_kernel(GnArgs A, int it)
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Temporal 2-D refinement: Temporal_Matches::min_Edge_Photometric_Residual_by_Gauss_Newton,
+// src/Temporal_Matches.cpp:735-851.  Same launch-per-iteration scheme; differences from the stereo variant: the
+// current-frame patches use the current-frame edge's own orientation, the Huber test is strict, H is 2x2 with the 1e-6
+// regulariser added once per sample (:809), and the update solves H x = b with Eigen's pivoted LDL^T.
+struct Gn2Args
+{
+    const uint8_t *imgK, *imgC;
+    const float2 *gxy; // interleaved Sobel planes of the current-frame image
+    int h, w;
+    const ebvo_edge *kf, *cf;
+    const double *init; // n x 2
+    int64_t n;
+    int max_iter;
+    double tol, huber;
+    double *disp, *score; // disp (n x 2) doubles as the iteration state
+    uint8_t *valid;
+    int32_t *iters;
+    double *mean_l; // [2][n]
+    double *sc;     // [4][n]: sin, cos of the keyframe edge, sin, cos of the current-frame edge
+    int32_t *list[2];
+    int32_t *counts;
+};
+
+// Eigen 3.4.0 H.ldlt().solve(b) for a 2x2 double H (Eigen/src/Cholesky/LDLT.h, restated; see oracle/ebvo_oracle.c)
+__device__ inline void ldlt2_solve(double h00, double h10, double h11, double b0, double b1, double &x0, double &x1)
+{
+    bool swap = fabs(h11) > fabs(h00);
+    if (swap)
+    {
+        const double t = h00;
+        h00 = h11;
+        h11 = t;
+    }
+    double l10 = h10;
+    if (!(fabs(h00) > 0.0))
+        swap = false;
+    else
+    {
+        l10 = h10 / h00;
+        const double temp = h00 * l10;
+        h11 -= l10 * temp;
+    }
+    double y0 = swap ? b1 : b0, y1 = swap ? b0 : b1;
+    y1 -= l10 * y0;
+    const double tiny = 2.2250738585072014e-308;
+    y0 = (fabs(h00) > tiny) ? y0 / h00 : 0.0;
+    y1 = (fabs(h11) > tiny) ? y1 / h11 : 0.0;
+    y0 -= l10 * y1;
+    x0 = swap ? y1 : y0;
+    x1 = swap ? y0 : y1;
+}
+
+__global__ __launch_bounds__(256) void gn2_init_kernel(Gn2Args A)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        A.counts[0] = (int32_t)A.n;
+    const int h = A.h, w = A.w;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < A.n; k += (int64_t)gridDim.x * blockDim.x)
+    {
+        const ebvo_edge ke = A.kf[k];
+        double st, ct, stc, ctc;
+        ebvo_sincos(ke.theta, &st, &ct);
+        ebvo_sincos(A.cf[k].theta, &stc, &ctc);
+        const double nx = -st, ny = ct, side = (7 / 2.0) + 1.0;
+#pragma unroll 1
+        for (int sd = 0; sd < 2; ++sd)
+        {
+            const double cx = sd ? ke.x - nx * side : ke.x + nx * side, cy = sd ? ke.y - ny * side : ke.y + ny * side;
+            double sum = 0;
+#pragma unroll 1
+            for (int i = -3; i <= 3; ++i)
+#pragma unroll
+                for (int j = -3; j <= 3; ++j)
+                    sum += (double)sample_u8(A.imgK, w, w, h, cx + ct * i - st * j, cy + st * i + ct * j);
+            A.mean_l[(size_t)sd * A.n + k] = sum / 49;
+        }
+        A.sc[k] = st;
+        A.sc[A.n + k] = ct;
+        A.sc[2 * A.n + k] = stc;
+        A.sc[3 * A.n + k] = ctc;
+        A.disp[2 * k] = A.init[2 * k];
+        A.disp[2 * k + 1] = A.init[2 * k + 1];
+        A.score[k] = __builtin_nan("");
+        A.valid[k] = 2;
+        A.iters[k] = 0;
+        A.list[0][k] = (int32_t)k;
+    }
+}
+
+__global__ __launch_bounds__(256) void gn2_iter_kernel(Gn2Args A, int it)
+{
+    const int h = A.h, w = A.w;
+    const int n_in = A.counts[it];
+    const int32_t *__restrict__ lin = A.list[it & 1];
+    int32_t *__restrict__ lout = A.list[(it + 1) & 1];
+    const int lane = threadIdx.x & 63;
+    for (int base = blockIdx.x * blockDim.x; base < n_in; base += gridDim.x * blockDim.x)
+    {
+        const int idx = base + threadIdx.x;
+        bool survives = false;
+        int64_t k = 0;
+        if (idx < n_in)
+        {
+            k = lin[idx];
+            const ebvo_edge ke = A.kf[k];
+            const double st = A.sc[k], ct = A.sc[A.n + k], stc = A.sc[2 * A.n + k], ctc = A.sc[3 * A.n + k];
+            const double nx = -st, ny = ct, ncx = -stc, ncy = ctc, side = (7 / 2.0) + 1.0;
+            const double meanL[2] = {A.mean_l[k], A.mean_l[A.n + k]};
+            double d0 = A.disp[2 * k], d1 = A.disp[2 * k + 1];
+            const double lx = ke.x - d0, ly = ke.y - d1; // :786
+            double meanR[2];
+#pragma unroll 1
+            for (int sd = 0; sd < 2; ++sd)
+            {
+                const double cx = sd ? lx - ncx * side : lx + ncx * side, cy = sd ? ly - ncy * side : ly + ncy * side;
+                double sum = 0;
+#pragma unroll 1
+                for (int i = -3; i <= 3; ++i)
+#pragma unroll
+                    for (int j = -3; j <= 3; ++j)
+                        sum += (double)sample_u8(A.imgC, w, w, h, cx + ctc * i - stc * j, cy + stc * i + ctc * j);
+                meanR[sd] = sum / 49;
+            }
+            double H00 = 0, H10 = 0, H11 = 0, b0 = 0, b1 = 0, cost = 0;
+#pragma unroll 1
+            for (int sd = 0; sd < 2; ++sd)
+            {
+                const double lcx = sd ? ke.x - nx * side : ke.x + nx * side, lcy = sd ? ke.y - ny * side : ke.y + ny * side;
+                const double cx = sd ? lx - ncx * side : lx + ncx * side, cy = sd ? ly - ncy * side : ly + ncy * side;
+#pragma unroll 1
+                for (int i = -3; i <= 3; ++i)
+#pragma unroll 1
+                    for (int j = -3; j <= 3; ++j)
+                    {
+                        const double Lf = (double)sample_u8(A.imgK, w, w, h, lcx + ct * i - st * j, lcy + st * i + ct * j);
+                        int x0, x1, y0, y1;
+                        double wa, wb;
+                        tap_at(cx + ctc * i - stc * j, cy + stc * i + ctc * j, w, h, x0, x1, y0, y1, wa, wb);
+                        const int xa = min(x0, w - 2);
+                        const bool shifted = xa != x0;
+                        const Corners ci = corners_u8(A.imgC, w, w, x0, x1, y0, y1);
+                        const float4 g0 = *reinterpret_cast<const float4 *>(A.gxy + (size_t)y0 * w + xa);
+                        const float4 g1 = *reinterpret_cast<const float4 *>(A.gxy + (size_t)y1 * w + xa);
+                        const double Rf = (double)blend(wa, wb, ci.v00, ci.v10, ci.v01, ci.v11);
+                        const double J0 = (double)blend(wa, wb, shifted ? g0.z : g0.x, g0.z, shifted ? g1.z : g1.x, g1.z);
+                        const double J1 = (double)blend(wa, wb, shifted ? g0.w : g0.y, g0.w, shifted ? g1.w : g1.y, g1.w);
+                        const double r = (Lf - meanL[sd]) - (Rf - meanR[sd]);
+                        const double absr = fabs(r);
+                        const double wgt = (absr < A.huber) ? 1.0 : A.huber / absr; // strict, :806
+                        const double wJ0 = wgt * J0, wJ1 = wgt * J1;
+                        H00 += wJ0 * J0; // H += w * J * J^T, coefficient (i, j) = (w J(i)) J(j)
+                        H10 += wJ1 * J0;
+                        H11 += wJ1 * J1;
+                        H00 += 1e-6;     // H += 1e-6 * I (:809)
+                        H10 += 0.0;
+                        H11 += 1e-6;
+                        b0 += wJ0 * r;
+                        b1 += wJ1 * r;
+                        cost += wgt * r * r;
+                    }
+            }
+            double s0, s1;
+            ldlt2_solve(H00, H10, H11, b0, b1, s0, s1);
+            const double delta0 = -s0, delta1 = -s1;
+            d0 += delta0;
+            d1 += delta1;
+            const double rms = sqrt(cost / 98);
+            const bool is_outlier = (rms > A.huber * 2.0) || (it + 1 < 2);
+            const bool finished = sqrt(delta0 * delta0 + delta1 * delta1) < A.tol || it == A.max_iter - 1;
+            A.disp[2 * k] = d0;
+            A.disp[2 * k + 1] = d1;
+            if (finished)
+            {
+                A.valid[k] = is_outlier ? 0 : 1;
+                A.score[k] = rms;
+                A.iters[k] = it + 1;
+            }
+            survives = !finished;
+        }
+        const unsigned long long m = __ballot(survives);
+        int wbase = 0;
+        if (lane == 0 && m)
+            wbase = atomicAdd(&A.counts[it + 1], __popcll(m));
+        wbase = __shfl(wbase, 0);
+        if (survives)
+            lout[wbase + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)k;
+    }
+}
+
 } // namespace
 
 int refine_sobel_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_img, int h, int w, int pitch, float *d_gx, float *d_gy,
@@ -401,6 +591,54 @@ int refine_gn_stereo_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_imgL, cons
     hipLaunchKernelGGL(gn_init_kernel, dim3(blocks), dim3(256), 0, s.stream, A);
     for (int it = 0; it < max_iter; ++it)
         hipLaunchKernelGGL(gn_iter_kernel, dim3(blocks), dim3(256), 0, s.stream, A, it);
+    EBVO_HIP(ctx, hipGetLastError());
+    return EBVO_OK;
+}
+
+int refine_gn_temporal_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_imgK, const uint8_t *d_imgC, const void *d_gxy,
+                               int h, int w, const ebvo_edge *d_kf, const ebvo_edge *d_cf, const double *d_init, int64_t n,
+                               int max_iter, double tol, double huber, double *d_disp, double *d_score, uint8_t *d_valid,
+                               int32_t *d_iters)
+{
+    if (n <= 0)
+        return EBVO_OK;
+    if (n > 0x7fffffffll)
+        return EBVO_ERR_CAPACITY;
+    if (w < 2 || h < 1)
+        return EBVO_ERR_ARG;
+    int rc;
+    const size_t np = (size_t)n;
+    if ((rc = ebvo_grow(ctx, s, s.gn_state, sizeof(double) * 6 * np)) ||
+        (rc = ebvo_grow(ctx, s, s.gn_lists, sizeof(int32_t) * (2 * np + (size_t)max_iter + 2))))
+        return rc;
+    Gn2Args A{};
+    A.imgK = d_imgK;
+    A.imgC = d_imgC;
+    A.gxy = (const float2 *)d_gxy;
+    A.h = h;
+    A.w = w;
+    A.kf = d_kf;
+    A.cf = d_cf;
+    A.init = d_init;
+    A.n = n;
+    A.max_iter = max_iter;
+    A.tol = tol;
+    A.huber = huber;
+    A.disp = d_disp;
+    A.score = d_score;
+    A.valid = d_valid;
+    A.iters = d_iters;
+    A.mean_l = (double *)s.gn_state.p;
+    A.sc = A.mean_l + 2 * np;
+    A.list[0] = (int32_t *)s.gn_lists.p;
+    A.list[1] = A.list[0] + np;
+    A.counts = A.list[1] + np;
+    ProfScope ps(ctx, s, K_GN_REFINE);
+    EBVO_HIP(ctx, hipMemsetAsync(A.counts, 0, sizeof(int32_t) * ((size_t)max_iter + 2), s.stream));
+    const unsigned blocks = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(gn2_init_kernel, dim3(blocks), dim3(256), 0, s.stream, A);
+    for (int it = 0; it < max_iter; ++it)
+        hipLaunchKernelGGL(gn2_iter_kernel, dim3(blocks), dim3(256), 0, s.stream, A, it);
     EBVO_HIP(ctx, hipGetLastError());
     return EBVO_OK;
 }

@@ -277,6 +277,40 @@ class StereoMatcherHIP
         return r;
     }
 
+    // Temporal_Matches::min_Edge_Photometric_Residual_by_Gauss_Newton (src/Temporal_Matches.cpp:735-851) over n
+    // (keyframe edge, current-frame edge, initial disparity) items of ONE camera, as apply_photometric_refinement_quads
+    // issues them for the left and for the right image of every candidate quad (:605-610).
+    struct RefinedTemporal
+    {
+        std::vector<double> disp, score; // disp: n x 2 refined_disparity; the new location is kf.location - disp
+        std::vector<uint8_t> validity;
+        std::vector<int32_t> iters;
+    };
+    RefinedTemporal refine_temporal(const uint8_t *imgKF, const uint8_t *imgCF, int rows, int cols, ptrdiff_t stepKF,
+                                    ptrdiff_t stepCF, const std::vector<EdgeT> &kf, const std::vector<EdgeT> &cf,
+                                    const std::vector<double> &init_disp)
+    {
+        RefinedTemporal r;
+        const size_t n = kf.size();
+        std::vector<ebvo_edge> K(n), C(n);
+        for (size_t k = 0; k < n; ++k)
+        {
+            K[k] = to_abi(kf[k]);
+            C[k] = to_abi(cf[k]);
+        }
+        r.disp.resize(2 * n);
+        r.score.resize(n);
+        r.validity.resize(n);
+        r.iters.resize(n);
+        ebvo_gn_params p;
+        ebvo_gn_default_params(&p);
+        last_status = ebvo_gn_refine_temporal(ctx_->get(), imgKF, imgCF, rows, cols, stepKF, stepCF, K.data(), C.data(),
+                                              init_disp.data(), (int)n, &p, r.disp.data(), r.score.data(),
+                                              r.validity.data(), r.iters.data());
+        report(*ctx_, last_status, "ebvo_gn_refine_temporal");
+        return r;
+    }
+
   private:
     Context::Ptr ctx_;
 };

@@ -197,6 +197,21 @@ int ebvo_gn_refine_stereo(ebvo_ctx *ctx, const uint8_t *imgL, const uint8_t *img
                           double *confidence, uint8_t *validity, int32_t *iters, double *refined_xy);
 
 /*
+ * Replaces Temporal_Matches::min_Edge_Photometric_Residual_by_Gauss_Newton (src/Temporal_Matches.cpp:735-851) as
+ * apply_photometric_refinement_quads calls it (:572-634, once for the left and once for the right image of a quad):
+ * 2-D Gauss-Newton on the photometric residual between the keyframe edge's side patches and the current-frame edge's,
+ * the current-frame patch pair (oriented by the CURRENT-frame edge) placed at kf.location - d.
+ *   imgKF / imgCF : undistorted keyframe / current-frame CV_8UC1 images of one camera; gradients of imgCF are formed
+ *                   internally (current_frame.*_image_gradients_*)
+ *   kf, cf, init_disp : n keyframe edges, n current-frame edges, n x 2 initial disparities (kf.location - cf.location)
+ * Outputs per item: disp (refined_disparity, n x 2), score (final RMS), validity (0 / 1), iters.  The update solves the
+ * 2x2 system with Eigen 3.4's pivoted LDL^T as published (H.ldlt().solve(b), :818).
+ */
+int ebvo_gn_refine_temporal(ebvo_ctx *ctx, const uint8_t *imgKF, const uint8_t *imgCF, int h, int w, ptrdiff_t strideKF,
+                            ptrdiff_t strideCF, const ebvo_edge *kf, const ebvo_edge *cf, const double *init_disp, int n,
+                            const ebvo_gn_params *params, double *disp, double *score, uint8_t *validity, int32_t *iters);
+
+/*
  * The same refinement on the pair resident in `slot` after ebvo_stereo_run / ebvo_stereo_wait, without leaving the
  * device: every candidate pair the NCC filter kept (keep[k] = 1) is refined against its right TOED edge, using the
  * pipeline's own edge lists, lines and images.  Outputs are indexed like sims / keep (n_pairs entries); pairs that

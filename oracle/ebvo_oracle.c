@@ -741,6 +741,176 @@ void orc_gn_refine_stereo(const uint8_t *imgL, const uint8_t *imgR, int h, int w
     free(gy);
 }
 
+/* Eigen 3.4.0 (pinned by load_modules.sh:9, not in the reference tree): x = H.ldlt().solve(b) for a 2x2 double H.
+ * Restated from the published algorithm (Eigen/src/Cholesky/LDLT.h): in-place unblocked LDL^T of the LOWER triangle
+ * with diagonal pivoting (largest |diagonal| first, the first on ties), scaling of the sub-column by the pivot when it
+ * is non-zero; solve = P, unit-lower forward substitution, division by D where |D| > DBL_MIN (zero otherwise),
+ * unit-upper back substitution, P^T.  Only H(0,0), H(1,0), H(1,1) are read. */
+static void ldlt2_solve(double h00, double h10, double h11, const double b[2], double x[2])
+{
+    int swap = fabs(h11) > fabs(h00); /* maxCoeff of |diag|: index 1 only if strictly larger */
+    if (swap)
+    {
+        const double t = h00;
+        h00 = h11;
+        h11 = t;
+    }
+    double l10 = h10;
+    if (!(fabs(h00) > 0.0))
+    {
+        /* "the entire diagonal is zero": transpositions reset to identity, nothing factorised (LDLT.h) */
+        swap = 0;
+    }
+    else
+    {
+        l10 = h10 / h00;                 /* A21 /= realAkk */
+        const double temp = h00 * l10;   /* temp.head(k) = D.head(k).asDiagonal() * A10.adjoint() */
+        h11 -= l10 * temp;               /* mat(k,k) -= (A10 * temp.head(k)).value() */
+    }
+    double y0 = swap ? b[1] : b[0], y1 = swap ? b[0] : b[1]; /* dst = P b */
+    y1 -= l10 * y0;                                            /* L^-1 */
+    const double tiny = 2.2250738585072014e-308;               /* (std::numeric_limits<double>::min)() */
+    y0 = (fabs(h00) > tiny) ? y0 / h00 : 0.0;                  /* pseudo-inverse of D */
+    y1 = (fabs(h11) > tiny) ? y1 / h11 : 0.0;
+    y0 -= l10 * y1;                                            /* L^-T */
+    x[0] = swap ? y1 : y0;                                     /* P^T */
+    x[1] = swap ? y0 : y1;
+}
+
+/* Temporal_Matches::min_Edge_Photometric_Residual_by_Gauss_Newton, src/Temporal_Matches.cpp:735-851 (2-D update; the
+ * current-frame patches use the CURRENT-frame edge's own orientation; Huber test is strict; H carries the 1e-6
+ * regulariser once per sample, :809).  PARITY UNPINNED (no fixture in the reference; Eigen restated as above). */
+static void gn_temporal_one(const uint8_t *imgK, const uint8_t *imgC, const float *gxC, const float *gyC, int h, int w,
+                            ptrdiff_t sK, ptrdiff_t sC, const orc_edge *kf, const orc_edge *cf, const double *init,
+                            int max_iter, double tol, double huber, int math_mode, double *disp, double *score,
+                            uint8_t *valid, int32_t *iters)
+{
+#define PIXK(y, x) ((float)imgK[(ptrdiff_t)(y) * sK + (x)])
+#define PIXC(y, x) ((float)imgC[(ptrdiff_t)(y) * sC + (x)])
+#define PIXGX(y, x) (gxC[(size_t)(y) * w + (x)])
+#define PIXGY(y, x) (gyC[(size_t)(y) * w + (x)])
+    double st, ct, stc, ctc;
+    if (math_mode == ORC_MATH_LIBM)
+    {
+        ct = cos(kf->theta);
+        st = sin(kf->theta);
+        ctc = cos(cf->theta);
+        stc = sin(cf->theta);
+    }
+    else
+    {
+        ebvo_sincos(kf->theta, &st, &ct);
+        ebvo_sincos(cf->theta, &stc, &ctc);
+    }
+    const double nx = -st, ny = ct, ncx = -stc, ncy = ctc; /* :751-752, :776-777 */
+    const double side = (7 / 2.0) + 1.0;
+    double Lc[2][49];
+    for (int sd = 0; sd < 2; sd++)
+    {
+        const double cx = sd ? kf->x - nx * side : kf->x + nx * side, cy = sd ? kf->y - ny * side : kf->y + ny * side;
+        double pf[49], sum = 0;
+        int k = 0;
+        for (int i = -3; i <= 3; i++)
+            for (int j = -3; j <= 3; j++, k++)
+            {
+                float v;
+                ORC_GN_SAMPLE(PIXK, w, h, cx + ct * i - st * j, cy + st * i + ct * j, v);
+                pf[k] = (double)v;
+            }
+        for (k = 0; k < 49; k++)
+            sum += pf[k];
+        const double mean = sum / 49;
+        for (k = 0; k < 49; k++)
+            Lc[sd][k] = pf[k] - mean;
+    }
+    double d[2] = {init[0], init[1]};
+    *valid = 2;
+    *score = NAN;
+    int iter = 0;
+    for (; iter < max_iter; ++iter)
+    {
+        const double lx = kf->x - d[0], ly = kf->y - d[1]; /* :786 */
+        double H00 = 0, H10 = 0, H11 = 0, b0 = 0, b1 = 0, cost = 0.0;
+        double Rf[2][49], Gx[2][49], Gy[2][49], meanR[2];
+        for (int sd = 0; sd < 2; sd++)
+        {
+            const double cx = sd ? lx - ncx * side : lx + ncx * side, cy = sd ? ly - ncy * side : ly + ncy * side;
+            int k = 0;
+            double sum = 0;
+            for (int i = -3; i <= 3; i++)
+                for (int j = -3; j <= 3; j++, k++)
+                {
+                    const double X = cx + ctc * i - stc * j, Y = cy + stc * i + ctc * j;
+                    float v, g1, g2;
+                    ORC_GN_SAMPLE(PIXC, w, h, X, Y, v);
+                    ORC_GN_SAMPLE(PIXGX, w, h, X, Y, g1);
+                    ORC_GN_SAMPLE(PIXGY, w, h, X, Y, g2);
+                    Rf[sd][k] = (double)v;
+                    Gx[sd][k] = (double)g1;
+                    Gy[sd][k] = (double)g2;
+                }
+            for (k = 0; k < 49; k++)
+                sum += Rf[sd][k];
+            meanR[sd] = sum / 49;
+        }
+        for (int sd = 0; sd < 2; sd++)
+            for (int k = 0; k < 49; k++)
+            {
+                const double r = Lc[sd][k] - (Rf[sd][k] - meanR[sd]);
+                const double J0 = Gx[sd][k], J1 = Gy[sd][k];
+                const double absr = fabs(r);
+                const double wgt = (absr < huber) ? 1.0 : huber / absr; /* strict, :806 */
+                const double wJ0 = wgt * J0, wJ1 = wgt * J1;
+                H00 += wJ0 * J0; /* H += w * J * J^T: coefficient (i, j) = (w * J(i)) * J(j) */
+                H10 += wJ1 * J0;
+                H11 += wJ1 * J1;
+                H00 += 1e-6;     /* H += 1e-6 * I (the off-diagonal receives + 0.0) */
+                H10 += 0.0;
+                H11 += 1e-6;
+                b0 += wJ0 * r;
+                b1 += wJ1 * r;
+                cost += wgt * r * r;
+            }
+        const double rhs[2] = {b0, b1};
+        double sol[2];
+        ldlt2_solve(H00, H10, H11, rhs, sol);
+        const double delta0 = -sol[0], delta1 = -sol[1];
+        d[0] += delta0;
+        d[1] += delta1;
+        const double rms = sqrt(cost / 98);
+        const int is_outlier = (rms > huber * 2.0) || (iter + 1 < 2);
+        if (sqrt(delta0 * delta0 + delta1 * delta1) < tol || iter == max_iter - 1)
+        {
+            *valid = is_outlier ? 0 : 1;
+            *score = rms;
+            ++iter;
+            break;
+        }
+    }
+    disp[0] = d[0];
+    disp[1] = d[1];
+    *iters = iter;
+#undef PIXK
+#undef PIXC
+#undef PIXGX
+#undef PIXGY
+}
+
+void orc_gn_refine_temporal(const uint8_t *imgKF, const uint8_t *imgCF, int h, int w, ptrdiff_t strideKF,
+                            ptrdiff_t strideCF, const orc_edge *kf, const orc_edge *cf, const double *init_disp, int n,
+                            int max_iter, double tol, double huber_delta, int math_mode, int nthreads, double *disp,
+                            double *score, uint8_t *validity, int32_t *iters)
+{
+    float *gx = (float *)malloc(sizeof(float) * (size_t)h * w), *gy = (float *)malloc(sizeof(float) * (size_t)h * w);
+    orc_sobel_gradients(imgCF, h, w, strideCF, gx, gy);
+#pragma omp parallel for schedule(dynamic, 64) num_threads(nthreads > 0 ? nthreads : omp_get_max_threads())
+    for (int k = 0; k < n; k++)
+        gn_temporal_one(imgKF, imgCF, gx, gy, h, w, strideKF, strideCF, &kf[k], &cf[k], init_disp + 2 * (size_t)k, max_iter,
+                        tol, huber_delta, math_mode, disp + 2 * (size_t)k, &score[k], &validity[k], &iters[k]);
+    free(gx);
+    free(gy);
+}
+
 void orc_atan2_v(const double *y, const double *x, int n, int math_mode, double *out)
 {
     for (int k = 0; k < n; k++)

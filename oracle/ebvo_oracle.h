@@ -115,6 +115,16 @@ void orc_gn_refine_stereo(const uint8_t *imgL, const uint8_t *imgR, int h, int w
                           int max_iter, double tol, double huber_delta, int math_mode, int nthreads, double *alpha,
                           double *score, double *confidence, uint8_t *validity, int32_t *iters, double *refined_xy);
 
+/*
+ * Temporal 2-D photometric refinement (src/Temporal_Matches.cpp:735-851, driven by apply_photometric_refinement_quads
+ * :572-634): n independent (keyframe edge, current-frame edge, initial disparity) triples; outputs the refined
+ * disparity d (the current-frame location is kf - d), final RMS score, validity, iterations.  PARITY UNPINNED.
+ */
+void orc_gn_refine_temporal(const uint8_t *imgKF, const uint8_t *imgCF, int h, int w, ptrdiff_t strideKF,
+                            ptrdiff_t strideCF, const orc_edge *kf, const orc_edge *cf, const double *init_disp, int n,
+                            int max_iter, double tol, double huber_delta, int math_mode, int nthreads, double *disp,
+                            double *score, uint8_t *validity, int32_t *iters);
+
 #ifdef __cplusplus
 }
 #endif

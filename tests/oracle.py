@@ -9,7 +9,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
-LIB = os.path.join(ORACLE_DIR, "libebvo_oracle.so")
+LIB = os.environ.get("EBVO_ORACLE_LIB", os.path.join(ORACLE_DIR, "libebvo_oracle.so"))  # override: sanitizer build
 
 EDGE_DTYPE = np.dtype([("x", "<f8"), ("y", "<f8"), ("theta", "<f8"), ("index", "<i4"), ("pad", "<i4")])
 PORTABLE, LIBM = 0, 1
@@ -146,6 +146,24 @@ def gn_refine_stereo(imgL, imgR, L, lines, row_ptr, cand_xy, max_iter=20, tol=1e
                                _p(L), _p(lines), _p(row_ptr), len(L), _p(cand_xy), int(max_iter), C.c_double(tol),
                                C.c_double(huber_delta), math_mode, nthreads, _p(out["alpha"]), _p(out["score"]),
                                _p(out["confidence"]), _p(out["validity"]), _p(out["iters"]), _p(out["refined_xy"]))
+    return out
+
+
+def gn_refine_temporal(imgKF, imgCF, kf, cf, init_disp, max_iter=20, tol=1e-3, huber_delta=3.0, math_mode=PORTABLE,
+                       nthreads=0):
+    imgKF = np.ascontiguousarray(imgKF, dtype=np.uint8)
+    imgCF = np.ascontiguousarray(imgCF, dtype=np.uint8)
+    h, w = imgKF.shape
+    kf = np.ascontiguousarray(kf, dtype=EDGE_DTYPE)
+    cf = np.ascontiguousarray(cf, dtype=EDGE_DTYPE)
+    init_disp = np.ascontiguousarray(init_disp, dtype=np.float64).reshape(-1, 2)
+    n = len(kf)
+    out = dict(disp=np.zeros((n, 2)), score=np.zeros(n), validity=np.zeros(n, dtype=np.uint8),
+               iters=np.zeros(n, dtype=np.int32))
+    lib().orc_gn_refine_temporal(_p(imgKF), _p(imgCF), h, w, C.c_ssize_t(imgKF.strides[0]),
+                                 C.c_ssize_t(imgCF.strides[0]), _p(kf), _p(cf), _p(init_disp), n, int(max_iter),
+                                 C.c_double(tol), C.c_double(huber_delta), math_mode, nthreads, _p(out["disp"]),
+                                 _p(out["score"]), _p(out["validity"]), _p(out["iters"]))
     return out
 
 

@@ -138,3 +138,51 @@ def test_device_resident_refine_equals_host_buffer_call(ctx, shape):
         assert_bit_equal(dev[k][keep], host[k], k)
     xy_all = np.stack([o["right"]["x"][o["col_idx"]], o["right"]["y"][o["col_idx"]]], 1)
     assert_bit_equal(dev["refined_xy"][~keep], xy_all[~keep], "unrefined locations")
+
+
+def _temporal_scene(h, w, sx=3, sy=2):
+    kf_img = synth.s2_image(h + 16, w + 16, scene=7, noise_seed=1)
+    cf_img = np.ascontiguousarray(kf_img[8 - sy:8 - sy + h, 8 - sx:8 - sx + w])
+    kf_img = np.ascontiguousarray(kf_img[8:8 + h, 8:8 + w])
+    return kf_img, cf_img
+
+
+def _compare_temporal(out, ref):
+    for k in ("validity", "iters", "disp", "score"):
+        assert_bit_equal(out[k], ref[k], k)
+
+
+@pytest.mark.parametrize("shape", [(96, 160), (120, 200)])
+def test_temporal_refine_equals_oracle(ctx, shape):
+    """ebvo_gn_refine_temporal vs the restatement of src/Temporal_Matches.cpp:735-851: bit-exact disparity, score,
+    validity and iteration count, incl. items starting on / beyond the border and non-default parameters."""
+    h, w = shape
+    kf_img, cf_img = _temporal_scene(h, w)
+    kf = ctx.toed(kf_img).edges
+    cfe = ctx.toed(cf_img).edges
+    rng = np.random.default_rng(9)
+    n = 1500
+    kf = kf[rng.choice(len(kf), n, replace=True)]
+    cf = cfe[rng.choice(len(cfe), n, replace=True)].copy()
+    good = rng.random(n) < 0.7                                            # 70 %: the true mate, the rest: unrelated edges
+    cf["x"][good], cf["y"][good], cf["theta"][good] = kf["x"][good] + 3, kf["y"][good] + 2, kf["theta"][good]
+    init = np.stack([kf["x"] - cf["x"], kf["y"] - cf["y"]], 1) + rng.uniform(-1.5, 1.5, (n, 2))
+    init[::31] += rng.uniform(-40, 40, (len(init[::31]), 2))             # patches clamped at the border
+    for kw in ({}, dict(max_iter=4, tol=5e-2, huber_delta=1.5), dict(max_iter=1)):
+        out = ctx.gn_refine_temporal(kf_img, cf_img, kf, cf, init, **kw)
+        ref = orc.gn_refine_temporal(kf_img, cf_img, kf, cf, init, **{**dict(max_iter=20, tol=1e-3, huber_delta=3.0), **kw})
+        _compare_temporal(out, ref)
+    assert (out["validity"] != 1).all()                                   # one iteration: always "outlier"
+    empty = ctx.gn_refine_temporal(kf_img, cf_img, kf[:0], cf[:0], init[:0])
+    assert len(empty["score"]) == 0
+
+
+def test_temporal_refine_flat_image(ctx):
+    """Zero gradients: H is only the accumulated 1e-6 regulariser, the update is exactly zero, one iteration."""
+    flat = np.full((64, 96), 90, dtype=np.uint8)
+    kf = np.zeros(3, dtype=orc.EDGE_DTYPE)
+    kf["x"], kf["y"], kf["theta"] = [30.0, 40.0, 50.0], [30.0, 20.0, 40.0], [0.1, 1.0, -2.0]
+    init = np.array([[1.0, -2.0], [0.0, 0.0], [5.5, 3.25]])
+    out = ctx.gn_refine_temporal(flat, flat, kf, kf, init)
+    _compare_temporal(out, orc.gn_refine_temporal(flat, flat, kf, kf, init))
+    assert np.array_equal(out["disp"], init) and np.all(out["iters"] == 1) and np.all(out["score"] == 0.0)
