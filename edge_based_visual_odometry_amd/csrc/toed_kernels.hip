@@ -555,137 +555,200 @@ __global__ __launch_bounds__(256) void toed_finalize_kernel(ImgBatch B, int h, i
 // ==========================================================================================
 constexpr double SCREEN_TOL = 1e-6;
 
-// S1 ---------------------------------------------------------------------------------------
-// separable screening convolution: gx, gy, |g| at the four phases of every pixel (planes IX, IY, MAG)
-__global__ __launch_bounds__(256) void toed_sep_kernel(ImgBatch B, const ToedTables *__restrict__ T, int h, int w)
-{
-    __shared__ double tile[LDS_H][LDS_W];
-    __shared__ double R[2][LDS_H][TILE_W]; // row-filtered with G (0) and Gx (1)
-    const uint8_t *__restrict__ img = B.img[blockIdx.z];
-    double *__restrict__ maps = B.maps[blockIdx.z];
-    const int j0 = blockIdx.x * TILE_W, i0 = blockIdx.y * TILE_H;
-    for (int t = threadIdx.x; t < LDS_H * LDS_W; t += 256)
-    {
-        const int r = t / LDS_W, c = t - r * LDS_W;
-        const int ii = i0 + r - HALO, jj = j0 + c - HALO;
-        double v = 0.0;
-        if (ii >= 0 && ii < h && jj >= 0 && jj < w)
-            v = (double)img[(size_t)ii * w + jj];
-        tile[r][c] = v;
-    }
-    const int tx = threadIdx.x & (TILE_W - 1), ty = threadIdx.x >> 5;
-    const int i = i0 + ty, j = j0 + tx;
-    const bool inside = i < h && j < w;
-    const size_t plane = (size_t)4 * h * w;
-    // set 0: integer column taps, 17 wide -> phase (0,0); set 1: integer column taps, 19 wide -> phase (1,0);
-    // set 2: half-pixel column taps -> phases (0,1) and (1,1)
-    for (int set = 0; set < 3; ++set)
-    {
-        __syncthreads();
-        const double(*ck)[19] = (set == 2) ? T->tap_half : T->tap_int;
-        const int qmax = (set == 0) ? 8 : 9;
-        for (int item = threadIdx.x; item < LDS_H * TILE_W; item += 256)
-        {
-            const int r = item >> 5, c = item & 31;
-            double a0 = 0.0, a1 = 0.0;
-            for (int q = -qmax; q <= qmax; ++q)
-            {
-                const double v = tile[r][c + HALO - q];
-                a0 = __builtin_fma(v, ck[0][q + 9], a0);
-                a1 = __builtin_fma(v, ck[1][q + 9], a1);
-            }
-            R[0][r][c] = a0;
-            R[1][r][c] = a1;
-        }
-        __syncthreads();
-        const int nph = (set == 2) ? 2 : 1;
-        for (int ph = 0; ph < nph; ++ph)
-        {
-            const int sy = (set == 2) ? ph : set, sx = (set == 2) ? 1 : 0;
-            const double(*rk)[19] = sy ? T->tap_half : T->tap_int;
-            const int pmax = (set == 0) ? 8 : 9;
-            double fx = 0.0, fy = 0.0;
-            for (int p = -pmax; p <= pmax; ++p)
-            {
-                fx = __builtin_fma(R[1][ty + HALO - p][tx], rk[0][p + 9], fx); // Gx along x, G along y
-                fy = __builtin_fma(R[0][ty + HALO - p][tx], rk[1][p + 9], fy); // G along x, Gx along y
-            }
-            if (inside)
-            {
-                const size_t o = midx(2 * i + sy, 2 * j + sx, h, w);
-                maps[PL_IX * plane + o] = fx;
-                maps[PL_IY * plane + o] = fy;
-                maps[PL_MAG * plane + o] = sqrt(fx * fx + fy * fy);
-            }
-        }
-    }
-}
+// S1+S2 fused -------------------------------------------------------------------------------
+// The screen in one kernel: the separable planes never leave LDS (the two-kernel form wrote 98 MB of fp64 planes per
+// pair and read 138 MB back, and its passes issued one ds_read_b64 per FMA).  One block screens the four phases of a
+// 12 x 30-pixel tile; it needs |g| one grid step around it, i.e. a 14 x 32 "ext" tile, i.e. a 32 x 50 image tile.
+//   row pass     thread = (image-tile row, 4 adjacent ext columns): 22 pixels in registers feed 24 accumulators
+//                (G and Gx taps; integer positions with 17 and 19 taps, half-pixel positions) -> six R planes in LDS
+//   column pass  thread = (ext column, phase, 7 adjacent ext rows): 25 + 25 R values feed 14 accumulators; gx, gy stay
+//                in registers, |g| goes to LDS (aliasing the R planes once every thread is past them)
+//   relaxed NMS  every thread decides its own <= 7 grid points; flags and per-row candidate counts as before
+// The screen only has to be within SCREEN_TOL of the exact values, so sums may be re-associated: the 19-tap integer
+// row sum is the 17-tap one plus its two end taps.
+constexpr int FT_H = 12, FT_W = 30;           // pixels screened per block
+constexpr int FE_H = FT_H + 2, FE_W = FT_W + 2; // ext tile
+constexpr int FI_H = FE_H + 2 * HALO, FI_W = FE_W + 2 * HALO; // image tile 32 x 50
+static_assert(FI_H * (FE_W / 4) == 256 && FE_W * 4 * (FE_H / 7) == 256, "one work item per thread in both passes");
 
-// S2 ---------------------------------------------------------------------------------------
-// relaxed NMS on the screening planes: flag = 1 for every pixel the exact test could accept
-__global__ __launch_bounds__(256) void toed_screen_kernel(ImgBatch B, int h, int w)
+struct FusedLds
 {
-    const int W2 = 2 * w, H2 = 2 * h;
-    const size_t plane = (size_t)H2 * W2;
-    const double *maps = B.maps[blockIdx.z];
-    const double *Ix = maps + PL_IX * plane, *Iy = maps + PL_IY * plane, *M = maps + PL_MAG * plane;
-    const int j = 10 + blockIdx.x * 64 + threadIdx.x;
-    const int i = 10 + blockIdx.y * 4 + threadIdx.y;
-    if (i >= H2 - 10) // wave-uniform
-        return;
-    int f = 0;
-    if (j < W2 - 10)
+    double img[FI_H][FI_W];
+    union
     {
-        const size_t o = midx(i, j, h, w);
-        const double m = M[o];
-        if (m > 2.0 - SCREEN_TOL)
+        double R[6][FI_H][FE_W]; // [0,1] 17-tap integer (G, Gx); [2,3] 19-tap integer; [4,5] half-pixel
+        double M[4][FE_H][FE_W]; // |g| of the ext tile per phase ((sy << 1) | sx)
+    };
+    double tap[2][19][4];        // [half][tap][derivative order], as ExactTaps
+};
+
+__global__ __launch_bounds__(256) void toed_screen_fused_kernel(ImgBatch B, const ToedTables *__restrict__ T, int h, int w)
+{
+    __shared__ FusedLds L;
+    const uint8_t *__restrict__ img = B.img[blockIdx.z];
+    const int W2 = 2 * w, H2 = 2 * h;
+    const int j0 = blockIdx.x * FT_W - 1, i0 = blockIdx.y * FT_H - 1; // pixel of ext (0, 0)
+    const int tid = threadIdx.x;
+    for (int t = tid; t < 2 * 19 * 4; t += 256)
+    {
+        const int half = t / 76, k = (t % 76) / 4, d = t & 3;
+        L.tap[half][k][d] = half ? T->tap_half[d][k] : T->tap_int[d][k];
+    }
+    // image tile: ONE 8-byte load per thread (32 rows x 7 chunks cover the 50 columns; a per-pixel loop was seven
+    // dependent byte loads per thread and, at two waves per SIMD, most of the kernel's time).  The image buffer has 64
+    // readable bytes either side, rows are clamped and masked, columns masked per byte.
+    if (tid < FI_H * 7)
+    {
+        const int r = tid / 7, k = tid - r * 7;
+        const int ii = i0 + r - HALO, jc = j0 - HALO + 8 * k;
+        const int ic = min(max(ii, 0), h - 1);
+        unsigned long long bits;
+        __builtin_memcpy(&bits, img + (size_t)ic * w + jc, 8);
+        const bool rok = ii >= 0 && ii < h;
+#pragma unroll
+        for (int b = 0; b < 8; ++b)
         {
-            const double gx = Ix[o], gy = Iy[o], ax = fabs(gx), ay = fabs(gy);
-            if (ax < SCREEN_TOL || ay < SCREEN_TOL || fabs(ax - ay) < SCREEN_TOL)
-                f = 1; // the exact sector could differ from the screen's: let the exact stage decide
-            else
+            const int c = 8 * k + b, jj = jc + b;
+            if (c < FI_W)
+                L.img[r][c] = (rok && jj >= 0 && jj < w) ? (double)((bits >> (8 * b)) & 0xffull) : 0.0;
+        }
+    }
+    __syncthreads();
+    // ---- row pass: R[.][r][c] = sum_q img[r][c + HALO - q] * tap[q]
+    {
+        const int r = tid >> 3, c0 = (tid & 7) * 4;
+        double v[22];
+#pragma unroll
+        for (int k = 0; k < 22; ++k)
+            v[k] = L.img[r][c0 + k];
+        double a17[4][2], ah[4][2];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            a17[c][0] = a17[c][1] = ah[c][0] = ah[c][1] = 0.0;
+#pragma unroll
+        for (int q = -8; q <= 8; ++q)
+        {
+            const double g = L.tap[0][q + 9][0], gx = L.tap[0][q + 9][1];
+            const double hg = L.tap[1][q + 9][0], hgx = L.tap[1][q + 9][1];
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
             {
-                // same sector table as nms_core; slope in [0, 1]
-                int a1, b1, a2, b2;
-                double slope;
-                if (gx >= 0 && gy >= 0)
-                {
-                    if (gx >= gy) { slope = gy / gx; a1 = 0; b1 = 1; a2 = 1; b2 = 1; }
-                    else { slope = gx / gy; a1 = 1; b1 = 0; a2 = 1; b2 = 1; }
-                }
-                else if (gx < 0 && gy >= 0)
-                {
-                    if (ax < gy) { slope = -gx / gy; a1 = 1; b1 = 0; a2 = 1; b2 = -1; }
-                    else { slope = -gy / gx; a1 = 0; b1 = -1; a2 = 1; b2 = -1; }
-                }
-                else if (gx < 0 && gy < 0)
-                {
-                    if (ax >= ay) { slope = gy / gx; a1 = 0; b1 = -1; a2 = -1; b2 = -1; }
-                    else { slope = gx / gy; a1 = -1; b1 = 0; a2 = -1; b2 = -1; }
-                }
+                const double x = v[c + HALO - q];
+                a17[c][0] = __builtin_fma(x, g, a17[c][0]);
+                a17[c][1] = __builtin_fma(x, gx, a17[c][1]);
+                ah[c][0] = __builtin_fma(x, hg, ah[c][0]);
+                ah[c][1] = __builtin_fma(x, hgx, ah[c][1]);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+        {
+            const double xl = v[c + HALO + 9], xr = v[c + HALO - 9]; // taps q = -9 and q = +9
+            L.R[0][r][c0 + c] = a17[c][0];
+            L.R[1][r][c0 + c] = a17[c][1];
+            L.R[2][r][c0 + c] = __builtin_fma(xr, L.tap[0][18][0], __builtin_fma(xl, L.tap[0][0][0], a17[c][0]));
+            L.R[3][r][c0 + c] = __builtin_fma(xr, L.tap[0][18][1], __builtin_fma(xl, L.tap[0][0][1], a17[c][1]));
+            L.R[4][r][c0 + c] = __builtin_fma(xr, L.tap[1][18][0], __builtin_fma(xl, L.tap[1][0][0], ah[c][0]));
+            L.R[5][r][c0 + c] = __builtin_fma(xr, L.tap[1][18][1], __builtin_fma(xl, L.tap[1][0][1], ah[c][1]));
+        }
+    }
+    __syncthreads();
+    // ---- column pass: thread = (ext column, phase, 7 ext rows)
+    const int c = tid & 31, ph = (tid >> 5) & 3, sy = ph >> 1, sx = ph & 1, e0 = (tid >> 7) * 7;
+    double fx[7], fy[7], mg[7];
+    {
+        // x kernel: sx ? half : integer (17 taps for phase (0,0), 19 otherwise); y kernel: sy ? half : integer
+        const int base = sx ? 4 : (sy ? 2 : 0);
+        const int pm = (ph == 0) ? 8 : 9;
+        double rg[25], rgx[25]; // R filtered with G / Gx along x, image-tile rows e0 .. e0 + 24
+#pragma unroll
+        for (int k = 0; k < 25; ++k)
+        {
+            rg[k] = L.R[base][e0 + k][c];
+            rgx[k] = L.R[base + 1][e0 + k][c];
+        }
+#pragma unroll
+        for (int e = 0; e < 7; ++e)
+            fx[e] = fy[e] = 0.0;
+#pragma unroll
+        for (int p = -9; p <= 9; ++p)
+        {
+            if (p < -pm || p > pm) // uniform per wave half: phase (0,0) has no +-9 taps
+                continue;
+            const double kg = L.tap[sy][p + 9][0], kgx = L.tap[sy][p + 9][1];
+#pragma unroll
+            for (int e = 0; e < 7; ++e)
+            {
+                fx[e] = __builtin_fma(rgx[e + HALO - p], kg, fx[e]);  // Gx along x, G along y
+                fy[e] = __builtin_fma(rg[e + HALO - p], kgx, fy[e]);  // G along x, Gx along y
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 7; ++e)
+            mg[e] = sqrt(fx[e] * fx[e] + fy[e] * fy[e]);
+    }
+    __syncthreads(); // every thread is done with R: M may overwrite it
+#pragma unroll
+    for (int e = 0; e < 7; ++e)
+        L.M[ph][e0 + e][c] = mg[e];
+    __syncthreads();
+    // ---- relaxed NMS of this thread's grid points
+    auto mag_at = [&](int I, int J) -> double {
+        // grid point (I, J) -> (pixel, phase) -> ext coordinates
+        const int pi = (I >> 1) - i0, pj = (J >> 1) - j0;
+        return L.M[((I & 1) << 1) | (J & 1)][pi][pj];
+    };
+    const int lane = tid & 63;
+#pragma unroll
+    for (int e = 0; e < 7; ++e)
+    {
+        const int er = e0 + e;                     // ext row, column c
+        const int i = i0 + er, j = j0 + c;         // pixel
+        const int I = 2 * i + sy, J = 2 * j + sx;  // grid point
+        int f = 0;
+        const bool mine = er >= 1 && er <= FT_H && c >= 1 && c <= FT_W && I >= 10 && I < H2 - 10 && J >= 10 && J < W2 - 10;
+        if (mine)
+        {
+            const double m = mg[e];
+            if (m > 2.0 - SCREEN_TOL)
+            {
+                const double gx = fx[e], gy = fy[e], ax = fabs(gx), ay = fabs(gy);
+                if (ax < SCREEN_TOL || ay < SCREEN_TOL || fabs(ax - ay) < SCREEN_TOL)
+                    f = 1; // the exact sector could differ from the screen's: let the exact stage decide
                 else
                 {
-                    if (gx < ay) { slope = -gx / gy; a1 = -1; b1 = 0; a2 = -1; b2 = 1; }
-                    else { slope = -gy / gx; a1 = 0; b1 = 1; a2 = -1; b2 = 1; }
+                    // the sector table of nms_core, by selects: eight divergent branches each carried their own fp64
+                    // division (a wave executed most of them); here one division per grid point.
+                    //   quadrant (sign of gx, gy) x (which of |gx|, |gy| dominates) -> axis step (a1, b1), diagonal
+                    //   step (a2, b2), slope = minor / major with the quadrant's sign convention
+                    const bool px = gx >= 0, py = gy >= 0;
+                    // "x dominates" exactly as the reference compares in each quadrant
+                    const bool xdom = px ? (py ? gx >= gy : !(gx < ay)) : (py ? !(ax < gy) : ax >= ay);
+                    const double num = xdom ? ((px == py) ? gy : -gy) : ((px == py) ? gx : -gx);
+                    const double den = xdom ? gx : gy;
+                    const double slope = num / den;
+                    // diagonal step: sign of gy along rows, sign of gx along columns; axis step: the dominant axis only
+                    const int a2 = py ? 1 : -1, b2 = px ? 1 : -1;
+                    const int a1 = xdom ? 0 : a2, b1 = xdom ? b2 : 0;
+                    const double fp = mag_at(I + a1, J + b1) * (1 - slope) + mag_at(I + a2, J + b2) * slope;
+                    const double fm = mag_at(I - a1, J - b1) * (1 - slope) + mag_at(I - a2, J - b2) * slope;
+                    if (m >= fm - SCREEN_TOL && m >= fp - SCREEN_TOL)
+                        f = 1;
                 }
-                const double fp = M[midx(i + a1, j + b1, h, w)] * (1 - slope) + M[midx(i + a2, j + b2, h, w)] * slope;
-                const double fm = M[midx(i - a1, j - b1, h, w)] * (1 - slope) + M[midx(i - a2, j - b2, h, w)] * slope;
-                if (m >= fm - SCREEN_TOL && m >= fp - SCREEN_TOL)
-                    f = 1;
             }
+            B.flag[blockIdx.z][(size_t)I * W2 + J] = (uint8_t)f;
         }
-        B.flag[blockIdx.z][(size_t)i * W2 + j] = (uint8_t)f;
-    }
-    // candidates of this row segment by column parity (the phase of a candidate is (row parity, column parity)); lane
-    // parity == column parity because every segment starts at an even column
-    const unsigned long long any = __ballot(f != 0);
-    if (threadIdx.x == 0 && any)
-    {
-        const int ne = __popcll(any & 0x5555555555555555ull), no = __popcll(any & 0xaaaaaaaaaaaaaaaaull);
-        if (ne)
-            atomicAdd(&B.row_cnt[blockIdx.z][i], ne);
-        if (no)
-            atomicAdd(&B.row_cnt[blockIdx.z][H2 + i], no);
+        // candidates of grid row I by column parity: a wave holds 32 columns x (sx = 0, 1) of ONE sy and one row group,
+        // so all its lanes share I; lanes 0-31 are even columns (sx = 0), lanes 32-63 odd
+        const unsigned long long any = __ballot(f != 0);
+        if (lane == 0 && any)
+        {
+            const int ne = __popcll(any & 0xffffffffull), no = __popcll(any >> 32);
+            if (ne)
+                atomicAdd(&B.row_cnt[blockIdx.z][I], ne);
+            if (no)
+                atomicAdd(&B.row_cnt[blockIdx.z][H2 + I], no);
+        }
     }
 }
 
@@ -1307,18 +1370,13 @@ int toed_enqueue(ebvo_ctx *ctx, Slot &s, int n_img, int h, int w, hipEvent_t ev_
     if (ctx->toed_mode == EBVO_TOED_HYBRID)
     {
         const int cap = ctx->cap_edges;
-        const dim3 tiles((w + TILE_W - 1) / TILE_W, (h + TILE_H - 1) / TILE_H, n_img);
-        const dim3 nmsgrid((W2 - 20 + 63) / 64, (H2 - 20 + 3) / 4, n_img);
         if (ev_conv_begin)
             EBVO_HIP(ctx, hipEventRecord(ev_conv_begin, s.stream));
         {
-            ProfScope ps(ctx, s, K_CONV);
-            hipLaunchKernelGGL(toed_sep_kernel, tiles, dim3(256), 0, s.stream, B,
-                               (const ToedTables *)g_tables_dev[ctx->device], h, w);
-        }
-        {
             ProfScope ps(ctx, s, K_NMS);
-            hipLaunchKernelGGL(toed_screen_kernel, nmsgrid, dim3(64, 4), 0, s.stream, B, h, w);
+            const dim3 ftiles((w + FT_W - 1) / FT_W, (h + FT_H - 1) / FT_H, n_img);
+            hipLaunchKernelGGL(toed_screen_fused_kernel, ftiles, dim3(256), 0, s.stream, B,
+                               (const ToedTables *)g_tables_dev[ctx->device], h, w);
         }
         {
             ProfScope ps(ctx, s, K_ROWSCAN);
