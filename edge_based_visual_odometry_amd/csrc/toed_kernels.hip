@@ -903,6 +903,12 @@ struct ExactBatch
     CandData cd[MAX_BATCH];
     CandRec *rec[MAX_BATCH];
     int32_t *cand_flag[MAX_BATCH];
+    // neighbour magnitudes, every distinct grid point once
+    const uint8_t *flag[MAX_BATCH]; // screen flags: 1 = candidate (its own exact |g| goes to magmap)
+    uint32_t *needbits[MAX_BATCH];  // [2H][ceil(2W / 32)] bit J of row I: the exact |g| of grid point (I, J) is needed
+    int32_t *need_cnt[MAX_BATCH];   // [2][2H] marked points per grid row, even / odd columns
+    int32_t *need_off[MAX_BATCH];   // [2][2H] their offsets in the phase lists (lists 4..7, lengths lcount[4..7])
+    double *magmap[MAX_BATCH];      // [2H x 2W] exact |g| at candidates and at marked points
 };
 
 // append `value` to list `which` for the lanes with `put`, one atomic per block; returns nothing.
@@ -1110,91 +1116,197 @@ __device__ inline double exact_mag(const uint8_t *__restrict__ img, int h, int w
     return sqrt(fx * fx + fy * fy);
 }
 
-// S3b: exact centre of every candidate of one phase; early NMS rejects; bucket by (phase, axis)
+// S3b: exact centre of every candidate of one phase; early NMS rejects; marks the grid points whose exact |g| the NMS of
+// this candidate needs.  Adjacent candidates along a contour share two of their four neighbours and 14 % of the
+// neighbours are candidates themselves (whose |g| is computed right here): marking every distinct point once in a
+// bitmap (no-return atomicOr; one row of the bitmap per grid row) leaves 54 % of the neighbour evaluations.
 template <int SY, int SX>
-__device__ inline void centre_phase(const ExactBatch &E, const ExactTaps &L, int h, int w, int cap, int *s_cnt)
+__device__ inline void centre_phase(const ExactBatch &E, const ExactTaps &L, int h, int w, int cap)
 {
-    const int im = blockIdx.y, W2 = 2 * w;
+    const int im = blockIdx.y, W2 = 2 * w, H2 = 2 * h, wpr = (W2 + 31) >> 5;
     constexpr int PH = (SY << 1) | SX;
     const int32_t *__restrict__ list = E.lists[im] + (size_t)PH * cap;
     const int n = min(E.lcount[im][PH], cap);
     const CandData &cd = E.cd[im];
-    for (int base = blockIdx.x * 256; base < n; base += gridDim.x * 256)
+    const uint8_t *__restrict__ flag = E.flag[im];
+    for (int k = blockIdx.x * 256 + threadIdx.x; k < n; k += gridDim.x * 256)
     {
-        const int k = base + threadIdx.x;
-        int axis = -1, t = 0;
-        if (k < n)
+        const int t = list[k];
+        const int o = E.src[im][2 * t];
+        const int I = o / W2, J = o - I * W2;
+        double f[9];
+        exact9<SY, SX>(E.img[im], h, w, L, I >> 1, J >> 1, f);
+        const double gx = f[0], gy = f[1];
+        const double m = sqrt(gx * gx + gy * gy); // src/toed/cpu_toed.cpp:222
+        NmsSector S;
+        int packed = -1;
+        if (nms_sector(m, gx, gy, S))
         {
-            t = list[k];
-            const int o = E.src[im][2 * t];
-            const int I = o / W2, J = o - I * W2;
-            double f[9];
-            exact9<SY, SX>(E.img[im], h, w, L, I >> 1, J >> 1, f);
-            const double gx = f[0], gy = f[1];
-            const double m = sqrt(gx * gx + gy * gy); // src/toed/cpu_toed.cpp:222
-            NmsSector S;
-            int packed = -1;
-            if (nms_sector(m, gx, gy, S))
+            packed = (S.a1 + 1) | ((S.b1 + 1) << 2) | ((S.a2 + 1) << 4) | ((S.b2 + 1) << 6);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
             {
-                packed = (S.a1 + 1) | ((S.b1 + 1) << 2) | ((S.a2 + 1) << 4) | ((S.b2 + 1) << 6);
-                axis = (S.a1 == 0) ? 0 : 1; // 0: axis neighbour along x (horizontal), 1: along y
+                const int da = (q & 2) ? S.a2 : S.a1, db = (q & 2) ? S.b2 : S.b1;
+                const int nI = (q & 1) ? I - da : I + da, nJ = (q & 1) ? J - db : J + db;
+                const int no = nI * W2 + nJ;
+                // a neighbour that is a candidate itself gets its |g| from its own thread (flags exist only inside
+                // the screened interior)
+                const bool is_cand = nI >= 10 && nI < H2 - 10 && nJ >= 10 && nJ < W2 - 10 && flag[no] == 1;
+                if (!is_cand) // fire-and-forget: rows are counted from the bitmap afterwards (toed_need_count_kernel)
+                    atomicOr(&E.needbits[im][(size_t)nI * wpr + (nJ >> 5)], 1u << (nJ & 31));
             }
-            cd.gx[t] = gx;
-            cd.gy[t] = gy;
-            cd.m[t] = m;
-            third_order_dir(f, cd.tox[t], cd.toy[t]);
-            cd.sector[t] = packed;
         }
-        for (int a = 0; a < 2; ++a)
-        {
-            const int cls = 4 + PH * 2 + a;
-            block_append(axis == a, t, E.lists[im] + (size_t)cls * cap, E.lcount[im] + cls, s_cnt);
-        }
+        cd.gx[t] = gx;
+        cd.gy[t] = gy;
+        cd.m[t] = m;
+        third_order_dir(f, cd.tox[t], cd.toy[t]);
+        cd.sector[t] = packed;
+        E.magmap[im][o] = m;
     }
 }
 
 __global__ __launch_bounds__(256) void toed_exact_centre_kernel(ExactBatch E, const ToedTables *__restrict__ T, int h,
                                                                 int w, int cap)
 {
-    __shared__ int s_cnt[5];
     __shared__ ExactTaps L;
     load_exact_taps(L, T);
     switch (blockIdx.z)
     {
-    case 0: centre_phase<0, 0>(E, L, h, w, cap, s_cnt); break;
-    case 1: centre_phase<0, 1>(E, L, h, w, cap, s_cnt); break;
-    case 2: centre_phase<1, 0>(E, L, h, w, cap, s_cnt); break;
-    default: centre_phase<1, 1>(E, L, h, w, cap, s_cnt); break;
+    case 0: centre_phase<0, 0>(E, L, h, w, cap); break;
+    case 1: centre_phase<0, 1>(E, L, h, w, cap); break;
+    case 2: centre_phase<1, 0>(E, L, h, w, cap); break;
+    default: centre_phase<1, 1>(E, L, h, w, cap); break;
     }
 }
 
 // S3c: the four neighbour magnitudes of every candidate of one (phase, axis) class.  The axis neighbours
 // (+-a1, +-b1) share one phase, the diagonal neighbours (+-a2, +-b2) the opposite phase (SY^1, SX^1);
 // PAIR selects which two a thread evaluates, so a launch slice has one phase throughout.
-// The kernel is compiled for the four NEIGHBOUR phases only; which (phase, axis) list a slice reads and which
-// neighbour pair it evaluates are run-time values, and the + / - neighbours share one copy of the tap loop.  Sixteen
-// specialised slices were ~8x the code and the instruction cache felt it (a larger, "faster" variant ran slower).
-template <int NSY, int NSX>
-__device__ inline void mags_phase(const ExactBatch &E, const ExactTaps &L, int h, int w, int cap, int cls, int pair)
+// S3c-0: marked points per grid row, even / odd columns (one wave per row)
+__global__ __launch_bounds__(256) void toed_need_count_kernel(ExactBatch E, int h, int w)
+{
+    const int W2 = 2 * w, H2 = 2 * h, wpr = (W2 + 31) >> 5;
+    const int im = blockIdx.y, I = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (I >= H2)
+        return;
+    const uint32_t *__restrict__ row = E.needbits[im] + (size_t)I * wpr;
+    int ne = 0, no = 0;
+    for (int k = lane; k < wpr; k += 64)
+    {
+        const uint32_t v = row[k];
+        ne += __popc(v & 0x55555555u);
+        no += __popc(v & 0xaaaaaaaau);
+    }
+    for (int d = 32; d > 0; d >>= 1)
+    {
+        ne += __shfl_down(ne, d);
+        no += __shfl_down(no, d);
+    }
+    if (lane == 0)
+    {
+        E.need_cnt[im][I] = ne;
+        E.need_cnt[im][H2 + I] = no;
+    }
+}
+
+// S3c-1: offsets of the marked points of every grid row in the list of their phase (two waves: even / odd columns,
+// each scanned separately over the even and the odd rows); list lengths -> lcount[4..7]
+__global__ __launch_bounds__(128) void toed_need_rowscan_kernel(ExactBatch E, int H2)
+{
+    const int im = blockIdx.x;
+    const int lane = threadIdx.x & 63, sx = threadIdx.x >> 6;
+    const int32_t *c = E.need_cnt[im] + sx * H2;
+    int32_t *o = E.need_off[im] + sx * H2;
+    const int per = (H2 + 63) / 64;
+    const int beg = lane * per, end = min(H2, beg + per);
+    int s[2] = {0, 0};
+    for (int r = beg; r < end; ++r)
+        s[r & 1] += c[r];
+    int incl[2] = {s[0], s[1]};
+    for (int d = 1; d < 64; d <<= 1)
+    {
+        const int t0 = __shfl_up(incl[0], d), t1 = __shfl_up(incl[1], d);
+        if (lane >= d)
+        {
+            incl[0] += t0;
+            incl[1] += t1;
+        }
+    }
+    int run[2] = {incl[0] - s[0], incl[1] - s[1]};
+    for (int r = beg; r < end; ++r)
+    {
+        o[r] = run[r & 1];
+        run[r & 1] += c[r];
+    }
+    if (lane == 63)
+    {
+        E.lcount[im][4 + sx] = incl[0];     // phase (row parity 0, column parity sx)
+        E.lcount[im][4 + 2 + sx] = incl[1]; // phase (row parity 1, column parity sx)
+    }
+}
+
+// S3c-2: one block per grid row: the marked points of the row, in column order, into the list of their phase
+__global__ __launch_bounds__(256) void toed_need_compact_kernel(ExactBatch E, int h, int w, int cap)
+{
+    const int W2 = 2 * w, H2 = 2 * h, wpr = (W2 + 31) >> 5;
+    const int I = blockIdx.x, im = blockIdx.y;
+    if (E.need_cnt[im][I] + E.need_cnt[im][H2 + I] == 0)
+        return;
+    const uint32_t *__restrict__ bits = E.needbits[im];
+    int32_t *__restrict__ lists = E.lists[im];
+    int base_ph[2] = {E.need_off[im][I], E.need_off[im][H2 + I]};
+    __shared__ int w_par[2][4];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int par = threadIdx.x & 1; // column parity (J0 is a multiple of 256)
+    const unsigned long long pmask = par ? 0xaaaaaaaaaaaaaaaaull : 0x5555555555555555ull;
+    for (int J0 = 0; J0 < W2; J0 += 256)
+    {
+        const int J = J0 + threadIdx.x;
+        const int o = I * W2 + J;
+        const bool f = J < W2 && ((bits[(size_t)I * wpr + (J >> 5)] >> (J & 31)) & 1u);
+        const unsigned long long m_all = __ballot(f);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if (lane == 0)
+        {
+            w_par[0][wid] = __popcll(m_all & 0x5555555555555555ull);
+            w_par[1][wid] = __popcll(m_all & 0xaaaaaaaaaaaaaaaaull);
+        }
+        __syncthreads();
+        int pre_ph = 0, tot_ph[2] = {0, 0};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+        {
+            if (k < wid)
+                pre_ph += w_par[par][k];
+            tot_ph[0] += w_par[0][k];
+            tot_ph[1] += w_par[1][k];
+        }
+        if (f)
+        {
+            const int ph = ((I & 1) << 1) | par;
+            const int pos = base_ph[par] + pre_ph + __popcll(m_all & pmask & below);
+            if (pos < cap)
+                lists[(size_t)(4 + ph) * cap + pos] = o;
+        }
+        base_ph[0] += tot_ph[0];
+        base_ph[1] += tot_ph[1];
+        __syncthreads();
+    }
+}
+
+// S3c-3: exact |g| at every marked grid point, one thread per point, one phase per launch slice
+template <int SY, int SX>
+__device__ inline void mags_phase(const ExactBatch &E, const ExactTaps &L, int h, int w, int cap)
 {
     const int im = blockIdx.y, W2 = 2 * w;
-    const int32_t *__restrict__ list = E.lists[im] + (size_t)cls * cap;
-    const int n = min(E.lcount[im][cls], cap);
-    const CandData &cd = E.cd[im];
+    constexpr int PH = (SY << 1) | SX;
+    const int32_t *__restrict__ list = E.lists[im] + (size_t)(4 + PH) * cap;
+    const int n = min(E.lcount[im][4 + PH], cap);
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x)
     {
-        const int t = list[k];
-        const int o = E.src[im][2 * t];
+        const int o = list[k];
         const int I = o / W2, J = o - I * W2;
-        const int pk = cd.sector[t];
-        const int da = pair ? ((pk >> 4) & 3) - 1 : (pk & 3) - 1;
-        const int db = pair ? ((pk >> 6) & 3) - 1 : ((pk >> 2) & 3) - 1;
-#pragma unroll 1
-        for (int sgn = 0; sgn < 2; ++sgn)
-        {
-            const int sa = sgn ? -da : da, sb = sgn ? -db : db;
-            cd.mag[(size_t)(2 * sgn + pair) * cap + t] = exact_mag<NSY, NSX>(E.img[im], h, w, L, I + sa, J + sb);
-        }
+        E.magmap[im][o] = exact_mag<SY, SX>(E.img[im], h, w, L, I, J);
     }
 }
 
@@ -1203,17 +1315,12 @@ __global__ __launch_bounds__(256) void toed_exact_mags_kernel(ExactBatch E, cons
 {
     __shared__ ExactTaps L;
     load_exact_taps(L, T);
-    // slice z = SY*8 + SX*4 + AXIS*2 + PAIR of the candidates' own phase (SY, SX)
-    const int z = blockIdx.z, sy = z >> 3, sx = (z >> 2) & 1, axis = (z >> 1) & 1, pair = z & 1;
-    const int cls = 4 + (z >> 1);
-    const int nsy = pair ? (sy ^ 1) : (axis ? (sy ^ 1) : sy);
-    const int nsx = pair ? (sx ^ 1) : (axis ? sx : (sx ^ 1));
-    switch ((nsy << 1) | nsx)
+    switch (blockIdx.z)
     {
-    case 0: mags_phase<0, 0>(E, L, h, w, cap, cls, pair); break;
-    case 1: mags_phase<0, 1>(E, L, h, w, cap, cls, pair); break;
-    case 2: mags_phase<1, 0>(E, L, h, w, cap, cls, pair); break;
-    default: mags_phase<1, 1>(E, L, h, w, cap, cls, pair); break;
+    case 0: mags_phase<0, 0>(E, L, h, w, cap); break;
+    case 1: mags_phase<0, 1>(E, L, h, w, cap); break;
+    case 2: mags_phase<1, 0>(E, L, h, w, cap); break;
+    default: mags_phase<1, 1>(E, L, h, w, cap); break;
     }
 }
 
@@ -1234,8 +1341,11 @@ __global__ __launch_bounds__(256) void toed_exact_decide_kernel(ExactBatch E, in
         bool is_max = false;
         double px = 0, py = 0, sm = 0;
         if (cd.sector[t] >= 0 && nms_sector(m, gx, gy, S))
-            is_max = nms_finish(m, S, I, J, cd.mag[(size_t)0 * cap + t], cd.mag[(size_t)1 * cap + t],
-                                cd.mag[(size_t)2 * cap + t], cd.mag[(size_t)3 * cap + t], px, py, sm);
+        {
+            const double *__restrict__ mm = E.magmap[im];
+            is_max = nms_finish(m, S, I, J, mm[(I + S.a1) * W2 + (J + S.b1)], mm[(I + S.a2) * W2 + (J + S.b2)],
+                                mm[(I - S.a1) * W2 + (J - S.b1)], mm[(I - S.a2) * W2 + (J - S.b2)], px, py, sm);
+        }
         int kept = 0;
         CandRec r;
         r.x = r.y = r.smag = 0.0;
@@ -1334,6 +1444,7 @@ int toed_enqueue(ebvo_ctx *ctx, Slot &s, int n_img, int h, int w, hipEvent_t ev_
     if (n_img < 1 || n_img > MAX_BATCH)
         return EBVO_ERR_ARG;
     const int H2 = 2 * h, W2 = 2 * w;
+    const int need_words = H2 * ((W2 + 31) / 32); // one bitmap row per grid row
     ImgBatch B{};
     for (int k = 0; k < n_img; ++k)
     {
@@ -1362,6 +1473,12 @@ int toed_enqueue(ebvo_ctx *ctx, Slot &s, int n_img, int h, int w, hipEvent_t ev_
         {
             ptrs[nc] = s.im[k].row_cnt;
             counts[nc++] = 2 * H2;
+            if (ctx->toed_mode == EBVO_TOED_HYBRID)
+            {
+                // need bitmap + its per-row counters live behind the |g| map in the (otherwise unused) plane buffer
+                ptrs[nc] = (int32_t *)(s.im[k].maps + (size_t)H2 * W2);
+                counts[nc++] = need_words; // the per-row counters behind it are written by toed_need_count_kernel
+            }
         }
         int rc = ebvo_clear_enqueue(ctx, s, ptrs, counts, nc);
         if (rc)
@@ -1402,10 +1519,15 @@ int toed_enqueue(ebvo_ctx *ctx, Slot &s, int n_img, int h, int w, hipEvent_t ev_
                 E.cd[k].m = d + (size_t)2 * cap;
                 E.cd[k].tox = d + (size_t)3 * cap;
                 E.cd[k].toy = d + (size_t)4 * cap;
-                E.cd[k].mag = d + (size_t)5 * cap;
                 E.cd[k].sector = ws.cand_sector;
                 E.rec[k] = (CandRec *)ws.cand_rec;
                 E.cand_flag[k] = ws.cand_flag;
+                // the planes of the strict path are free in hybrid mode: |g| map, need bitmap, per-row counters
+                E.flag[k] = ws.flag;
+                E.magmap[k] = ws.maps;
+                E.needbits[k] = (uint32_t *)(ws.maps + (size_t)H2 * W2);
+                E.need_cnt[k] = (int32_t *)(E.needbits[k] + need_words);
+                E.need_off[k] = E.need_cnt[k] + 2 * H2;
             }
             const ToedTables *T = (const ToedTables *)g_tables_dev[ctx->device];
             {
@@ -1415,8 +1537,10 @@ int toed_enqueue(ebvo_ctx *ctx, Slot &s, int n_img, int h, int w, hipEvent_t ev_
             }
             {
                 ProfScope ps(ctx, s, K_EXACT_MAGS);
-                hipLaunchKernelGGL(toed_exact_mags_kernel, dim3(128, n_img, 16), dim3(256), 0, s.stream, E, T, h, w,
-                                   cap);
+                hipLaunchKernelGGL(toed_need_count_kernel, dim3((H2 + 3) / 4, n_img), dim3(256), 0, s.stream, E, h, w);
+                hipLaunchKernelGGL(toed_need_rowscan_kernel, dim3(n_img), dim3(128), 0, s.stream, E, H2);
+                hipLaunchKernelGGL(toed_need_compact_kernel, dim3(H2, n_img), dim3(256), 0, s.stream, E, h, w, cap);
+                hipLaunchKernelGGL(toed_exact_mags_kernel, dim3(256, n_img, 4), dim3(256), 0, s.stream, E, T, h, w, cap);
                 hipLaunchKernelGGL(toed_exact_decide_kernel, dim3(512, n_img), dim3(256), 0, s.stream, E, h, w, cap);
             }
         }
