@@ -651,12 +651,18 @@ __device__ inline double bilinear_nan(const uint8_t *__restrict__ img, int rows,
     const double yc = ceil(y), yf = floor(y);
     // include/utility.h:95-99 (a corner outside the image); NaN coordinates fail every comparison the same way
     const bool inside = (x1 >= 0) && (yf >= 0) && (x2 < cols) && (yc < rows);
-    const int c1 = inside ? (int)x1 : 0, c2 = inside ? (int)x2 : 0;
+    const int c1 = inside ? (int)x1 : 0;
     const int r1 = inside ? (int)yc * pitch : 0, r2 = inside ? (int)yf * pitch : 0;
-    const double I11 = (double)img[r1 + c1];
-    const double I21 = (double)img[r1 + c2];
-    const double I12 = (double)img[r2 + c1];
-    const double I22 = (double)img[r2 + c2];
+    // the two corners of a row are adjacent bytes (x2 = x1 + 1 unless x is an integer, and then the result is NaN
+    // whatever is loaded): one 2-byte load per row instead of two byte loads -- the sampling is address-divergent, so
+    // the texture path charges per load instruction.  The image buffer has readable bytes past its last pixel.
+    unsigned short p1, p2;
+    __builtin_memcpy(&p1, img + r1 + c1, 2);
+    __builtin_memcpy(&p2, img + r2 + c1, 2);
+    const double I11 = (double)(p1 & 0xff);
+    const double I21 = (double)(p1 >> 8);
+    const double I12 = (double)(p2 & 0xff);
+    const double I22 = (double)(p2 >> 8);
     const double wxa = x2 - x;    // (Q21.x - P.x) / (Q21.x - Q11.x), denominator exactly 1
     const double wxb = x - x1;    // (P.x - Q11.x) / (Q21.x - Q11.x)
     const double wya = -(yf - y); // (Q12.y - P.y) / (Q12.y - Q11.y), denominator exactly -1
