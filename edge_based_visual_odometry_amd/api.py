@@ -57,8 +57,9 @@ class Context:
     def toed_stats(self, slot: int = 0) -> dict:
         out = np.zeros(8, dtype=np.int32)
         self._check(self.lib.ebvo_toed_stats(self._ctx, slot, ptr(out)), "ebvo_toed_stats")
-        return {"left": dict(n_total=int(out[0]), n_kept=int(out[1]), n_candidates=int(out[2])),
-                "right": dict(n_total=int(out[4]), n_kept=int(out[5]), n_candidates=int(out[6]))}
+        return {"left": dict(n_total=int(out[0]), n_kept=int(out[1]), n_candidates=int(out[2]), n_neighbour_points=int(out[3])),
+                "right": dict(n_total=int(out[4]), n_kept=int(out[5]), n_candidates=int(out[6]),
+                              n_neighbour_points=int(out[7]))}
 
     @property
     def toed_mode(self) -> str:

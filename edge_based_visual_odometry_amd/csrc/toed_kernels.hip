@@ -569,11 +569,12 @@ constexpr double SCREEN_TOL = 1e-6;
 constexpr int FT_H = 12, FT_W = 30;           // pixels screened per block
 constexpr int FE_H = FT_H + 2, FE_W = FT_W + 2; // ext tile
 constexpr int FI_H = FE_H + 2 * HALO, FI_W = FE_W + 2 * HALO; // image tile 32 x 50
-static_assert(FI_H * (FE_W / 4) == 256 && FE_W * 4 * (FE_H / 7) == 256, "one work item per thread in both passes");
+static_assert(FI_W + 6 == 56 && FI_H * (FE_W / 4) == 256 && FE_W * 4 * (FE_H / 7) == 256, "one work item per thread in both passes");
 
+constexpr int FI_P = 56; // image-tile row pitch in bytes (>= FI_W + 2, multiple of 4)
 struct FusedLds
 {
-    double img[FI_H][FI_W];
+    uint32_t img[FI_H][FI_P / 4]; // the image tile as bytes: 1.8 KB instead of 12.8 KB as doubles -> three blocks per CU
     union
     {
         double R[6][FI_H][FE_W]; // [0,1] 17-tap integer (G, Gx); [2,3] 19-tap integer; [4,5] half-pixel
@@ -594,7 +595,7 @@ __global__ __launch_bounds__(256) void toed_screen_fused_kernel(ImgBatch B, cons
         const int half = t / 76, k = (t % 76) / 4, d = t & 3;
         L.tap[half][k][d] = half ? T->tap_half[d][k] : T->tap_int[d][k];
     }
-    // image tile: ONE 8-byte load per thread (32 rows x 7 chunks cover the 50 columns; a per-pixel loop was seven
+    // image tile: ONE 8-byte load per thread (32 rows x 7 chunks = 56 bytes cover the 50 columns; a per-pixel loop was seven
     // dependent byte loads per thread and, at two waves per SIMD, most of the kernel's time).  The image buffer has 64
     // readable bytes either side, rows are clamped and masked, columns masked per byte.
     if (tid < FI_H * 7)
@@ -605,13 +606,16 @@ __global__ __launch_bounds__(256) void toed_screen_fused_kernel(ImgBatch B, cons
         unsigned long long bits;
         __builtin_memcpy(&bits, img + (size_t)ic * w + jc, 8);
         const bool rok = ii >= 0 && ii < h;
+        unsigned long long masked = 0; // bytes outside the image read as 0, as the reference skips those taps
 #pragma unroll
         for (int b = 0; b < 8; ++b)
         {
-            const int c = 8 * k + b, jj = jc + b;
-            if (c < FI_W)
-                L.img[r][c] = (rok && jj >= 0 && jj < w) ? (double)((bits >> (8 * b)) & 0xffull) : 0.0;
+            const int jj = jc + b;
+            if (rok && jj >= 0 && jj < w)
+                masked |= bits & (0xffull << (8 * b));
         }
+        L.img[r][2 * k] = (uint32_t)masked;
+        L.img[r][2 * k + 1] = (uint32_t)(masked >> 32);
     }
     __syncthreads();
     // ---- row pass: R[.][r][c] = sum_q img[r][c + HALO - q] * tap[q]
@@ -619,8 +623,14 @@ __global__ __launch_bounds__(256) void toed_screen_fused_kernel(ImgBatch B, cons
         const int r = tid >> 3, c0 = (tid & 7) * 4;
         double v[22];
 #pragma unroll
-        for (int k = 0; k < 22; ++k)
-            v[k] = L.img[r][c0 + k];
+        for (int q = 0; q < 6; ++q) // c0 is a multiple of 4: six aligned words hold the 22 pixels
+        {
+            const uint32_t wq = L.img[r][(c0 >> 2) + q];
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                if (4 * q + b < 22)
+                    v[4 * q + b] = (double)((wq >> (8 * b)) & 0xffu);
+        }
         double a17[4][2], ah[4][2];
 #pragma unroll
         for (int c = 0; c < 4; ++c)
@@ -693,11 +703,12 @@ __global__ __launch_bounds__(256) void toed_screen_fused_kernel(ImgBatch B, cons
         L.M[ph][e0 + e][c] = mg[e];
     __syncthreads();
     // ---- relaxed NMS of this thread's grid points
-    auto mag_at = [&](int I, int J) -> double {
-        // grid point (I, J) -> (pixel, phase) -> ext coordinates
-        const int pi = (I >> 1) - i0, pj = (J >> 1) - j0;
-        return L.M[((I & 1) << 1) | (J & 1)][pi][pj];
-    };
+    // |g| of the grid neighbours one step along the rows / columns: the thread's phase is fixed, so the LDS offsets
+    // (plane, ext row, ext column) of "one grid step up / down / left / right" are three constants per axis
+    const double *Mflat = &L.M[0][0][0];
+    auto row_step = [&](int da) { return ((((sy + da) & 1) - sy) * 2 * FE_H + ((sy + da) >> 1)) * FE_W; };
+    auto col_step = [&](int db) { return (((sx + db) & 1) - sx) * FE_H * FE_W + ((sx + db) >> 1); };
+    const int rdn = row_step(-1), rup = row_step(1), cdn = col_step(-1), cup = col_step(1);
     const int lane = tid & 63;
 #pragma unroll
     for (int e = 0; e < 7; ++e)
@@ -728,10 +739,13 @@ __global__ __launch_bounds__(256) void toed_screen_fused_kernel(ImgBatch B, cons
                     const double den = xdom ? gx : gy;
                     const double slope = num / den;
                     // diagonal step: sign of gy along rows, sign of gx along columns; axis step: the dominant axis only
-                    const int a2 = py ? 1 : -1, b2 = px ? 1 : -1;
-                    const int a1 = xdom ? 0 : a2, b1 = xdom ? b2 : 0;
-                    const double fp = mag_at(I + a1, J + b1) * (1 - slope) + mag_at(I + a2, J + b2) * slope;
-                    const double fm = mag_at(I - a1, J - b1) * (1 - slope) + mag_at(I - a2, J - b2) * slope;
+                    // (a2, b2) = (sign gy, sign gx); (a1, b1) = (0, b2) if x dominates, (a2, 0) otherwise
+                    const int ctr = (ph * FE_H + er) * FE_W + c;
+                    const int rP = py ? rup : rdn, rM = py ? rdn : rup, cP = px ? cup : cdn, cM = px ? cdn : cup;
+                    const double p1 = Mflat[ctr + (xdom ? cP : rP)], p2 = Mflat[ctr + rP + cP];
+                    const double m1 = Mflat[ctr + (xdom ? cM : rM)], m2 = Mflat[ctr + rM + cM];
+                    const double fp = p1 * (1 - slope) + p2 * slope;
+                    const double fm = m1 * (1 - slope) + m2 * slope;
                     if (m >= fm - SCREEN_TOL && m >= fp - SCREEN_TOL)
                         f = 1;
                 }
@@ -1242,6 +1256,8 @@ __global__ __launch_bounds__(128) void toed_need_rowscan_kernel(ExactBatch E, in
     {
         E.lcount[im][4 + sx] = incl[0];     // phase (row parity 0, column parity sx)
         E.lcount[im][4 + 2 + sx] = incl[1]; // phase (row parity 1, column parity sx)
+        // diagnostics: counts[3] = distinct neighbour grid points evaluated (zeroed by toed_rowscan_phase_kernel)
+        atomicAdd(const_cast<int32_t *>(E.counts[im]) + 3, incl[0] + incl[1]);
     }
 }
 
@@ -1536,10 +1552,13 @@ int toed_enqueue(ebvo_ctx *ctx, Slot &s, int n_img, int h, int w, hipEvent_t ev_
                                    cap);
             }
             {
-                ProfScope ps(ctx, s, K_EXACT_MAGS);
+                ProfScope ps(ctx, s, K_COMPACT); // the lists of the distinct neighbour points
                 hipLaunchKernelGGL(toed_need_count_kernel, dim3((H2 + 3) / 4, n_img), dim3(256), 0, s.stream, E, h, w);
                 hipLaunchKernelGGL(toed_need_rowscan_kernel, dim3(n_img), dim3(128), 0, s.stream, E, H2);
                 hipLaunchKernelGGL(toed_need_compact_kernel, dim3(H2, n_img), dim3(256), 0, s.stream, E, h, w, cap);
+            }
+            {
+                ProfScope ps(ctx, s, K_EXACT_MAGS);
                 hipLaunchKernelGGL(toed_exact_mags_kernel, dim3(256, n_img, 4), dim3(256), 0, s.stream, E, T, h, w, cap);
                 hipLaunchKernelGGL(toed_exact_decide_kernel, dim3(512, n_img), dim3(256), 0, s.stream, E, h, w, cap);
             }

@@ -95,7 +95,8 @@ enum
 };
 int ebvo_set_toed_mode(ebvo_ctx *ctx, int mode);
 int ebvo_get_toed_mode(const ebvo_ctx *ctx);
-/* diagnostics of the last TOED run on a slot: per image {all NMS maxima, kept edges, screened candidates (hybrid), 0} */
+/* diagnostics of the last TOED run on a slot: per image {all NMS maxima, kept edges, screened candidates (hybrid),
+ * distinct neighbour grid points whose exact magnitude was evaluated (hybrid)} */
 int ebvo_toed_stats(ebvo_ctx *ctx, int slot, int32_t out[8]);
 
 /*
