@@ -21,6 +21,15 @@
 //   toed_rowscan_kernel  K3a: exclusive scan of the per-row counts
 //   toed_compact_kernel  K3b: ordered (raster) stream compaction of the flagged pixels
 //   toed_finalize_kernel K3c: dense per-edge epilogue (sub-pixel position, atan2, records)
+// Hybrid mode (second half of the file; same bits out):
+//   toed_screen_fused_kernel   S1+S2: separable fp64 screen and relaxed NMS of a 12 x 30-pixel tile, all in LDS
+//   toed_rowscan_phase_kernel / toed_compact_phase_kernel
+//                              S2b/c: candidate ranks and the four phase lists, ordered, no atomics
+//   toed_exact_centre_kernel   S3b: the nine exact responses of every candidate; marks its NMS neighbours
+//   toed_need_{count,rowscan,compact}_kernel
+//                              S3c-0..2: the distinct neighbour grid points, by phase
+//   toed_exact_mags_kernel     S3c-3: exact gradient magnitude of every distinct neighbour point
+//   toed_exact_decide_kernel   S3d: exact NMS + sub-pixel fit;  toed_cand_scatter_kernel S4: edge records
 #include <cstring>
 
 #include "ebvo_internal.h"
@@ -546,7 +555,7 @@ __global__ __launch_bounds__(256) void toed_finalize_kernel(ImgBatch B, int h, i
 // sum|v||Kq||Kp| <= 8e-12 for 8-bit pixels and these taps), a RELAXED non-maximum test with tolerance
 // 1e-6 >> E selects a superset of the pixels the reference accepts, and every selected pixel is then
 // evaluated in the reference's exact arithmetic (same taps, same order, no FMA): its nine responses and
-// the two-response magnitude of its four NMS neighbours.  The exact NMS decision, sub-pixel position,
+// the two-response magnitude of its four NMS neighbours (each distinct neighbour grid point once).  The exact NMS decision, sub-pixel position,
 // magnitude and orientation are computed from those exact values only, so the edge list equals the
 // strict path's bit for bit; a pixel that the relaxed screen rejects is rejected by the exact test too.
 //   relaxed screen: |g| > 2 - 1e-6, and either the gradient sector is ambiguous within 1e-6
