@@ -41,7 +41,7 @@ ABI_SYMBOLS = (
     "ebvo_stereo_upload_slot", "ebvo_stereo_submit", "ebvo_stereo_wait", "ebvo_stereo_fetch_slot", "ebvo_profile_enable",
     "ebvo_profile_reset", "ebvo_profile_get", "ebvo_fp64_peak",
     "ebvo_gn_default_params", "ebvo_sobel_gradients", "ebvo_gn_refine_stereo", "ebvo_stereo_refine",
-    "ebvo_stereo_fetch_refined", "ebvo_gn_refine_temporal",
+    "ebvo_stereo_fetch_refined", "ebvo_gn_refine_temporal", "ebvo_finalize_pairs",
 )
 
 
@@ -49,6 +49,10 @@ class StereoParams(C.Structure):
     _fields_ = [("F21", C.c_double * 9), ("epi_thr", C.c_double), ("max_disp", C.c_double),
                 ("orient_thr_deg", C.c_double), ("ncc_thr", C.c_double), ("stage_mask", C.c_int),
                 ("reserved", C.c_int)]
+
+
+class StereoCalib(C.Structure):
+    _fields_ = [("K_left", C.c_double * 9), ("K_right", C.c_double * 9), ("R21", C.c_double * 9), ("T21", C.c_double * 3)]
 
 
 class GnParams(C.Structure):
@@ -126,6 +130,7 @@ def load_library() -> C.CDLL:
     lib.ebvo_sobel_gradients.argtypes = [vp, vp, i32, i32, ssz, vp, vp]
     lib.ebvo_gn_refine_temporal.argtypes = [vp, vp, vp, i32, i32, ssz, ssz, vp, vp, vp, i32, C.POINTER(GnParams), vp, vp, vp,
                                             vp]
+    lib.ebvo_finalize_pairs.argtypes = [vp, C.POINTER(StereoCalib), vp, vp, i32, vp]
     lib.ebvo_stereo_refine.argtypes = [vp, i32, C.POINTER(GnParams)]
     lib.ebvo_stereo_fetch_refined.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp]
     lib.ebvo_gn_refine_stereo.argtypes = [vp, vp, vp, i32, i32, ssz, ssz, vp, i32, vp, vp, vp, C.POINTER(GnParams),

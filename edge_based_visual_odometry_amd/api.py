@@ -227,6 +227,20 @@ class Context:
         self._check(rc, "ebvo_gn_refine_temporal")
         return out
 
+    # -- write_finalized_stereo_edge_pairs_to_file, numeric body (src/Stereo_Matches.cpp:1656-1699) -----------------
+    def finalize_pairs(self, K_left, K_right, R21, T21, left, right) -> np.ndarray:
+        from ._lib import StereoCalib
+        cal = StereoCalib()
+        for name, v, n in (("K_left", K_left, 9), ("K_right", K_right, 9), ("R21", R21, 9), ("T21", T21, 3)):
+            a = np.ascontiguousarray(v, dtype=np.float64).reshape(n)
+            getattr(cal, name)[:] = a.tolist()
+        left, right = _edges(left), _edges(right)
+        assert len(left) == len(right)
+        out = np.zeros((len(left), 16))
+        self._check(self.lib.ebvo_finalize_pairs(self._ctx, C.byref(cal), ptr(left), ptr(right), len(left), ptr(out)),
+                    "ebvo_finalize_pairs")
+        return out
+
     def stereo_refine(self, counts, slot=0, **kw):
         """Refine every kept match of the resident pair on the device; returns the per-pair outputs (n_pairs entries,
         validity 255 where the pair was not a kept match)."""

@@ -1065,6 +1065,35 @@ extern "C" int ebvo_gn_refine_temporal(ebvo_ctx *ctx, const uint8_t *imgKF, cons
     return EBVO_OK;
 }
 
+extern "C" int ebvo_finalize_pairs(ebvo_ctx *ctx, const ebvo_stereo_calib *calib, const ebvo_edge *left,
+                                   const ebvo_edge *right, int n, double *out16)
+{
+    if (!ctx || !calib || n < 0 || (n > 0 && (!left || !right || !out16)))
+        return EBVO_ERR_ARG;
+    EBVO_HIP(ctx, hipSetDevice(ctx->device));
+    int rc;
+    Slot *sp;
+    if ((rc = host_slot(ctx, &sp)))
+        return rc;
+    Slot &s = *sp;
+    if (n == 0)
+        return EBVO_OK;
+    const size_t nz = (size_t)n;
+    if ((rc = ebvo_grow(ctx, s, s.scratch_b, sizeof(ebvo_edge) * nz)) || (rc = ebvo_grow(ctx, s, s.scratch_c, sizeof(ebvo_edge) * nz)) ||
+        (rc = ebvo_grow(ctx, s, s.gn_out, sizeof(double) * 16 * nz)))
+        return rc;
+    hipStream_t st = s.stream;
+    EBVO_HIP(ctx, hipMemcpyAsync(s.scratch_b.p, left, sizeof(ebvo_edge) * nz, hipMemcpyHostToDevice, st));
+    EBVO_HIP(ctx, hipMemcpyAsync(s.scratch_c.p, right, sizeof(ebvo_edge) * nz, hipMemcpyHostToDevice, st));
+    if ((rc = refine_finalize_pairs_enqueue(ctx, s, calib->K_left, calib->K_right, calib->R21, calib->T21,
+                                            (const ebvo_edge *)s.scratch_b.p, (const ebvo_edge *)s.scratch_c.p, n,
+                                            (double *)s.gn_out.p)))
+        return rc;
+    EBVO_HIP(ctx, hipMemcpyAsync(out16, s.gn_out.p, sizeof(double) * 16 * nz, hipMemcpyDeviceToHost, st));
+    EBVO_HIP(ctx, hipStreamSynchronize(st));
+    return EBVO_OK;
+}
+
 // ---- photometric refinement of the kept matches of a resident pair ---------------------------------------------
 extern "C" int ebvo_stereo_refine(ebvo_ctx *ctx, int slot, const ebvo_gn_params *params)
 {

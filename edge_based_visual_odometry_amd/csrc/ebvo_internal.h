@@ -220,6 +220,8 @@ int refine_gn_stereo_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_imgL, cons
                              const ebvo_edge *d_R, const int32_t *d_col_idx, const uint8_t *d_keep /* optional */,
                              int64_t n_pairs, int max_iter, double tol, double huber, double *d_alpha, double *d_score,
                              double *d_conf, uint8_t *d_valid, int32_t *d_iters, double *d_refined_xy);
+int refine_finalize_pairs_enqueue(ebvo_ctx *ctx, Slot &s, const double *K_left, const double *K_right, const double *R21,
+                                  const double *T21, const ebvo_edge *d_L, const ebvo_edge *d_R, int n, double *d_out);
 int refine_gn_temporal_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_imgK, const uint8_t *d_imgC, const void *d_gxy,
                                int h, int w, const ebvo_edge *d_kf, const ebvo_edge *d_cf, const double *d_init, int64_t n,
                                int max_iter, double tol, double huber, double *d_disp, double *d_score, uint8_t *d_valid,

@@ -527,6 +527,90 @@ __global__ __launch_bounds__(256) void gn2_iter_kernel(Gn2Args A, int it)
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Finalisation geometry: the 16 numbers write_finalized_stereo_edge_pairs_to_file prints per final pair
+// (src/Stereo_Matches.cpp:1656-1699; src/utility.cpp:95-119).  One thread per pair; the calibration inverses are
+// formed once on the host (Eigen's cofactor inverse, restated), every product / cross / normalize in Eigen's
+// fixed-size order.
+struct FinalCalib
+{
+    double Kli[9], Kri[9], R21[9], T21[3];
+};
+
+__device__ inline void mv3(const double *m, const double *v, double *o)
+{
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        o[i] = (m[i * 3] * v[0] + m[i * 3 + 1] * v[1]) + m[i * 3 + 2] * v[2];
+}
+__device__ inline void mtv3(const double *m, const double *v, double *o)
+{
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        o[i] = (m[i] * v[0] + m[3 + i] * v[1]) + m[6 + i] * v[2];
+}
+__device__ inline void cross3(const double *a, const double *b, double *o)
+{
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+__device__ inline void normalize3(double *v)
+{
+    const double z = (v[0] * v[0] + v[1] * v[1]) + v[2] * v[2];
+    if (z > 0)
+    {
+        const double n = sqrt(z);
+        v[0] /= n;
+        v[1] /= n;
+        v[2] /= n;
+    }
+}
+
+__global__ void finalize_pairs_kernel(FinalCalib C, const ebvo_edge *__restrict__ L, const ebvo_edge *__restrict__ R, int n,
+                                      double *__restrict__ out)
+{
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x)
+    {
+        const ebvo_edge l = L[k], r = R[k];
+        const double el[3] = {l.x, l.y, 1.0}, er[3] = {r.x, r.y, 1.0};
+        double g1[3], g2[3], Rg1[3];
+        mv3(C.Kli, el, g1);
+        mv3(C.Kri, er, g2);
+        mv3(C.R21, g1, Rg1);
+        const double numerator = C.T21[0] - C.T21[2] * g2[0]; // e1.dot(T) - e3.dot(T) * e1.dot(ray2)
+        const double denominator = Rg1[2] * g2[0] - Rg1[0];
+        const double rho1 = numerator / denominator;
+        double sl, cl, sr, cr;
+        ebvo_sincos(l.theta, &sl, &cl);
+        ebvo_sincos(r.theta, &sr, &cr);
+        const double t1r[3] = {cl, sl, 0.0}, t2r[3] = {cr, sr, 0.0};
+        double t1[3], t2[3], n1[3], c2[3], n2[3], T[3], p1[3], p2[3];
+        mv3(C.Kli, t1r, t1);
+        mv3(C.Kri, t2r, t2);
+        cross3(t1, g1, n1);
+        cross3(t2, g2, c2);
+        mtv3(C.R21, c2, n2);
+        cross3(n1, n2, T);
+        normalize3(T);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+        {
+            p1[i] = T[i] - T[2] * g1[i];
+            p2[i] = T[i] - T[2] * g2[i];
+        }
+        normalize3(p1);
+        normalize3(p2);
+        double *o = out + (size_t)k * 16;
+        o[0] = l.x; o[1] = l.y; o[2] = l.theta;
+        o[3] = r.x; o[4] = r.y; o[5] = r.theta;
+        o[6] = rho1 * g1[0]; o[7] = rho1 * g1[1]; o[8] = rho1 * g1[2];
+        o[9] = T[0]; o[10] = T[1]; o[11] = T[2];
+        o[12] = p1[0]; o[13] = p1[1];
+        o[14] = p2[0]; o[15] = p2[1];
+    }
+}
+
 } // namespace
 
 int refine_sobel_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_img, int h, int w, int pitch, float *d_gx, float *d_gy,
@@ -639,6 +723,45 @@ int refine_gn_temporal_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_imgK, co
     hipLaunchKernelGGL(gn2_init_kernel, dim3(blocks), dim3(256), 0, s.stream, A);
     for (int it = 0; it < max_iter; ++it)
         hipLaunchKernelGGL(gn2_iter_kernel, dim3(blocks), dim3(256), 0, s.stream, A, it);
+    EBVO_HIP(ctx, hipGetLastError());
+    return EBVO_OK;
+}
+
+static double cof3_host(const double *m, int i, int j)
+{
+    const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+    return m[i1 * 3 + j1] * m[i2 * 3 + j2] - m[i1 * 3 + j2] * m[i2 * 3 + j1];
+}
+
+// Matrix3d::inverse() (Eigen/src/LU/InverseImpl.h, cofactor form), row-major
+static void inverse3_host(const double *m, double *inv)
+{
+    const double c0 = cof3_host(m, 0, 0), c1 = cof3_host(m, 1, 0), c2 = cof3_host(m, 2, 0);
+    const double det = (c0 * m[0] + c1 * m[3]) + c2 * m[6];
+    const double invdet = 1.0 / det;
+    inv[0] = c0 * invdet;
+    inv[1] = c1 * invdet;
+    inv[2] = c2 * invdet;
+    for (int i = 1; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            inv[i * 3 + j] = cof3_host(m, j, i) * invdet;
+}
+
+int refine_finalize_pairs_enqueue(ebvo_ctx *ctx, Slot &s, const double *K_left, const double *K_right, const double *R21,
+                                  const double *T21, const ebvo_edge *d_L, const ebvo_edge *d_R, int n, double *d_out)
+{
+    if (n <= 0)
+        return EBVO_OK;
+    FinalCalib C;
+    inverse3_host(K_left, C.Kli);
+    inverse3_host(K_right, C.Kri);
+    for (int i = 0; i < 9; ++i)
+        C.R21[i] = R21[i];
+    for (int i = 0; i < 3; ++i)
+        C.T21[i] = T21[i];
+    ProfScope ps(ctx, s, K_MISC);
+    const unsigned blocks = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(finalize_pairs_kernel, dim3(blocks), dim3(256), 0, s.stream, C, d_L, d_R, n, d_out);
     EBVO_HIP(ctx, hipGetLastError());
     return EBVO_OK;
 }

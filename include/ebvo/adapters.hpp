@@ -25,7 +25,9 @@
 #include <array>
 #include <cstdint>
 #include <cstdio>
+#include <fstream>
 #include <memory>
+#include <string>
 #include <utility>
 #include <vector>
 
@@ -325,6 +327,44 @@ inline double patch_similarity(const Context &c, const float *patch_one, const f
     if (!report(c, rc, "ebvo_ncc_patches"))
         return __builtin_nan("");
     return s;
+}
+
+// The numeric body of Stereo_Matches::write_finalized_stereo_edge_pairs_to_file (src/Stereo_Matches.cpp:1656-1699):
+// 16 numbers per final (left edge, right edge) pair, computed on the device.
+template <class EdgeT>
+inline std::vector<double> finalize_pairs(const Context &c, const ebvo_stereo_calib &calib, const std::vector<EdgeT> &left,
+                                          const std::vector<EdgeT> &right)
+{
+    std::vector<ebvo_edge> L(left.size()), R(right.size());
+    for (size_t k = 0; k < left.size(); ++k)
+        L[k] = to_abi(left[k]);
+    for (size_t k = 0; k < right.size(); ++k)
+        R[k] = to_abi(right[k]);
+    std::vector<double> out(16 * left.size());
+    const int rc = ebvo_finalize_pairs(c.get(), &calib, L.data(), R.data(), (int)L.size(), out.data());
+    if (!report(c, rc, "ebvo_finalize_pairs"))
+        out.clear();
+    return out;
+}
+
+// ... and its text: the header line and one row of 16 space-separated numbers per pair, through the same iostream
+// insertions as the reference (:1660, :1690-1695), hence the same default formatting (6 significant digits).
+inline bool write_finalized_stereo_edge_pairs(const std::string &filename, const std::vector<double> &out16)
+{
+    std::ofstream outfile(filename);
+    if (!outfile)
+        return false;
+    outfile << "left_edge_location, left_edge_orientation, right_edge_location, right_edge_orientation, "
+               "left_edge_3D_point, left_edge_tangent"
+            << std::endl;
+    for (size_t k = 0; k + 16 <= out16.size(); k += 16)
+    {
+        const double *o = &out16[k];
+        outfile << o[0] << " " << o[1] << " " << o[2] << " " << o[3] << " " << o[4] << " " << o[5] << " " << o[6] << " "
+                << o[7] << " " << o[8] << " " << o[9] << " " << o[10] << " " << o[11] << " " << o[12] << " " << o[13] << " "
+                << o[14] << " " << o[15] << std::endl;
+    }
+    return (bool)outfile;
 }
 
 } // namespace ebvo

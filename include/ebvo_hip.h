@@ -212,6 +212,26 @@ int ebvo_gn_refine_temporal(ebvo_ctx *ctx, const uint8_t *imgKF, const uint8_t *
                             ptrdiff_t strideCF, const ebvo_edge *kf, const ebvo_edge *cf, const double *init_disp, int n,
                             const ebvo_gn_params *params, double *disp, double *score, uint8_t *validity, int32_t *iters);
 
+/* ---- finalisation geometry (what the output file holds) ----------------- */
+
+typedef struct
+{
+    double K_left[9], K_right[9]; /* row-major 3x3 calibration matrices (Dataset::get_left/right_calib_matrix) */
+    double R21[9], T21[3];        /* get_relative_rot_left_to_right / get_relative_transl_left_to_right */
+} ebvo_stereo_calib;
+
+/*
+ * The numeric body of Stereo_Matches::write_finalized_stereo_edge_pairs_to_file (src/Stereo_Matches.cpp:1656-1699)
+ * with Utility::backproject_2D_point_to_3D_point_using_rays, reconstruct_3D_Tangent_through_intersection_of_planes
+ * and project_3D_Tangent_to_2D_Tangent (src/utility.cpp:95-119): per final (left edge, right edge) pair the 16
+ * numbers of one output row, out16[k] = {lx, ly, ltheta, rx, ry, rtheta, Gamma.x, .y, .z, T.x, .y, .z,
+ * projected_T_1.x, .y, projected_T_2.x, .y}.  The text itself (header line, 6 significant digits, spaces) is written
+ * by the caller (ebvo::write_finalized_stereo_edge_pairs in include/ebvo/adapters.hpp uses the reference's iostream
+ * calls).
+ */
+int ebvo_finalize_pairs(ebvo_ctx *ctx, const ebvo_stereo_calib *calib, const ebvo_edge *left, const ebvo_edge *right,
+                        int n, double *out16);
+
 /*
  * The same refinement on the pair resident in `slot` after ebvo_stereo_run / ebvo_stereo_wait, without leaving the
  * device: every candidate pair the NCC filter kept (keep[k] = 1) is refined against its right TOED edge, using the

@@ -911,6 +911,125 @@ void orc_gn_refine_temporal(const uint8_t *imgKF, const uint8_t *imgCF, int h, i
     free(gy);
 }
 
+/* ------------------------------------------------------------------------------------------
+ * Finalisation geometry of write_finalized_stereo_edge_pairs_to_file, src/Stereo_Matches.cpp:1656-1699: the 16
+ * numbers written per final pair.  Eigen (3.4.0, not in the reference tree) is restated from its published fixed-size
+ * code paths: 3x3 inverse by cofactors, 3x3 * 3 products and dot products summed left to right, cross product,
+ * normalize() = divide by sqrt(squaredNorm).  PARITY UNPINNED (outputs_kitti/finalized_stereo_edge_pairs_frame_*.txt
+ * are listed in .MISSING_LARGE_BLOBS); the file itself holds 6 significant digits per number.
+ * ------------------------------------------------------------------------------------------ */
+static double cof3(const double *m, int i, int j) /* Eigen::internal::cofactor_3x3<i, j> on a row-major 3x3 */
+{
+    const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+    return m[i1 * 3 + j1] * m[i2 * 3 + j2] - m[i1 * 3 + j2] * m[i2 * 3 + j1];
+}
+
+void orc_inverse3(const double *m, double *inv) /* Matrix3d::inverse(), Eigen/src/LU/InverseImpl.h */
+{
+    const double c0 = cof3(m, 0, 0), c1 = cof3(m, 1, 0), c2 = cof3(m, 2, 0);
+    const double det = (c0 * m[0] + c1 * m[3]) + c2 * m[6];
+    const double invdet = 1.0 / det;
+    inv[0] = c0 * invdet;
+    inv[1] = c1 * invdet;
+    inv[2] = c2 * invdet;
+    inv[3] = cof3(m, 0, 1) * invdet;
+    inv[4] = cof3(m, 1, 1) * invdet;
+    inv[5] = cof3(m, 2, 1) * invdet;
+    inv[6] = cof3(m, 0, 2) * invdet;
+    inv[7] = cof3(m, 1, 2) * invdet;
+    inv[8] = cof3(m, 2, 2) * invdet;
+}
+
+static void mv3(const double *m, const double *v, double *o) /* row-major m * v */
+{
+    for (int i = 0; i < 3; i++)
+        o[i] = (m[i * 3] * v[0] + m[i * 3 + 1] * v[1]) + m[i * 3 + 2] * v[2];
+}
+static void mtv3(const double *m, const double *v, double *o) /* m^T * v */
+{
+    for (int i = 0; i < 3; i++)
+        o[i] = (m[i] * v[0] + m[3 + i] * v[1]) + m[6 + i] * v[2];
+}
+static void cross3(const double *a, const double *b, double *o)
+{
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+static void normalize3(double *v) /* DenseBase::normalize(): z = squaredNorm(); if (z > 0) v /= sqrt(z) */
+{
+    const double z = (v[0] * v[0] + v[1] * v[1]) + v[2] * v[2];
+    if (z > 0)
+    {
+        const double n = sqrt(z);
+        v[0] /= n;
+        v[1] /= n;
+        v[2] /= n;
+    }
+}
+
+void orc_finalize_pairs(const double *Kl, const double *Kr, const double *R21, const double *T21, const orc_edge *L,
+                        const orc_edge *R, int n, int math_mode, double *out)
+{
+    double Kli[9], Kri[9];
+    orc_inverse3(Kl, Kli);
+    orc_inverse3(Kr, Kri);
+    for (int k = 0; k < n; k++)
+    {
+        const double el[3] = {L[k].x, L[k].y, 1.0}, er[3] = {R[k].x, R[k].y, 1.0};
+        double g1[3], g2[3];
+        mv3(Kli, el, g1); /* gamma_1, :1671 */
+        mv3(Kri, er, g2);
+        /* backproject_2D_point_to_3D_point_using_rays, src/utility.cpp:95-102: e1.dot(x) = x(0), e3.dot(x) = x(2) */
+        double Rg1[3];
+        mv3(R21, g1, Rg1);
+        const double numerator = T21[0] - T21[2] * g2[0];
+        const double denominator = Rg1[2] * g2[0] - Rg1[0];
+        const double rho1 = numerator / denominator;
+        const double G[3] = {rho1 * g1[0], rho1 * g1[1], rho1 * g1[2]};
+        double sl, cl, sr, cr;
+        if (math_mode == ORC_MATH_LIBM)
+        {
+            cl = cos(L[k].theta);
+            sl = sin(L[k].theta);
+            cr = cos(R[k].theta);
+            sr = sin(R[k].theta);
+        }
+        else
+        {
+            ebvo_sincos(L[k].theta, &sl, &cl);
+            ebvo_sincos(R[k].theta, &sr, &cr);
+        }
+        const double t1r[3] = {cl, sl, 0.0}, t2r[3] = {cr, sr, 0.0};
+        double t1[3], t2[3];
+        mv3(Kli, t1r, t1); /* :1684-1685 */
+        mv3(Kri, t2r, t2);
+        /* reconstruct_3D_Tangent_through_intersection_of_planes(rel_R, gamma1, gamma2, tangent1, tangent2), :104-112 */
+        double n1[3], c2[3], n2[3], T[3];
+        cross3(t1, g1, n1);
+        cross3(t2, g2, c2);
+        mtv3(R21, c2, n2);
+        cross3(n1, n2, T);
+        normalize3(T);
+        /* project_3D_Tangent_to_2D_Tangent, :114-119 */
+        double p1[3], p2[3];
+        for (int i = 0; i < 3; i++)
+        {
+            p1[i] = T[i] - T[2] * g1[i];
+            p2[i] = T[i] - T[2] * g2[i];
+        }
+        normalize3(p1);
+        normalize3(p2);
+        double *o = out + (size_t)k * 16;
+        o[0] = L[k].x; o[1] = L[k].y; o[2] = L[k].theta;
+        o[3] = R[k].x; o[4] = R[k].y; o[5] = R[k].theta;
+        o[6] = G[0]; o[7] = G[1]; o[8] = G[2];
+        o[9] = T[0]; o[10] = T[1]; o[11] = T[2];
+        o[12] = p1[0]; o[13] = p1[1];
+        o[14] = p2[0]; o[15] = p2[1];
+    }
+}
+
 void orc_atan2_v(const double *y, const double *x, int n, int math_mode, double *out)
 {
     for (int k = 0; k < n; k++)

@@ -125,6 +125,15 @@ void orc_gn_refine_temporal(const uint8_t *imgKF, const uint8_t *imgCF, int h, i
                             int max_iter, double tol, double huber_delta, int math_mode, int nthreads, double *disp,
                             double *score, uint8_t *validity, int32_t *iters);
 
+/*
+ * The 16 numbers write_finalized_stereo_edge_pairs_to_file (src/Stereo_Matches.cpp:1656-1699) prints per final pair:
+ * lx ly ltheta rx ry rtheta Gamma(3) T(3) projected_T_1(2) projected_T_2(2).  K, R21 row-major 3x3, T21 3-vector.
+ * PARITY UNPINNED (the reference's sample outputs are missing blobs).
+ */
+void orc_inverse3(const double *m, double *inv);
+void orc_finalize_pairs(const double *K_left, const double *K_right, const double *R21, const double *T21,
+                        const orc_edge *L, const orc_edge *R, int n, int math_mode, double *out16);
+
 #ifdef __cplusplus
 }
 #endif

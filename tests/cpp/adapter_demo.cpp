@@ -89,6 +89,21 @@ int main(int argc, char **argv)
     if (matcher.last_status != EBVO_OK)
         return 6;
 
+    // finalisation: every kept NCC match as a final pair -> the reference's output file
+    std::vector<Edge> fl, fr;
+    for (size_t i = 0; i + 1 < c.row_ptr.size(); ++i)
+        for (int32_t k = c.row_ptr[i]; k < c.row_ptr[i + 1]; ++k)
+            if (s.keep[(size_t)k])
+            {
+                fl.push_back(left_edges[i]);
+                fr.push_back(cand[(size_t)k]);
+            }
+    ebvo_stereo_calib calib = {{f, 0, 607.1928, 0, f, 185.2157, 0, 0, 1}, {f, 0, 607.1928, 0, f, 185.2157, 0, 0, 1},
+                               {1, 0, 0, 0, 1, 0, 0, 0, 1}, {t, 0, 0}};
+    std::vector<double> fin = ebvo::finalize_pairs(*TOED->context(), calib, fl, fr);
+    if (fin.size() != 16 * fl.size() || !ebvo::write_finalized_stereo_edge_pairs(std::string(argv[5]) + ".txt", fin))
+        return 7;
+
     FILE *o = std::fopen(argv[5], "wb");
     int32_t hdr[5] = {(int32_t)left_edges.size(), (int32_t)right_edges.size(), totalL, totalR, (int32_t)cand.size()};
     std::fwrite(hdr, sizeof hdr, 1, o);

@@ -167,6 +167,15 @@ def gn_refine_temporal(imgKF, imgCF, kf, cf, init_disp, max_iter=20, tol=1e-3, h
     return out
 
 
+def finalize_pairs(K_left, K_right, R21, T21, left, right, math_mode=PORTABLE):
+    arrs = [np.ascontiguousarray(a, dtype=np.float64).reshape(-1) for a in (K_left, K_right, R21, T21)]
+    left = np.ascontiguousarray(left, dtype=EDGE_DTYPE)
+    right = np.ascontiguousarray(right, dtype=EDGE_DTYPE)
+    out = np.zeros((len(left), 16))
+    lib().orc_finalize_pairs(*[_p(a) for a in arrs], _p(left), _p(right), len(left), math_mode, _p(out))
+    return out
+
+
 def ncc_quads(kfL, kfR, cfL, cfR, thr=0.8, nthreads=0):
     arrs = [np.ascontiguousarray(a, dtype=np.float32).reshape(-1, 98) for a in (kfL, kfR, cfL, cfR)]
     n = len(arrs[0])

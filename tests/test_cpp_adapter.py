@@ -71,3 +71,14 @@ def test_adapter_matches_oracle(tmp_path):
     assert_bit_equal(score, ref["score"])
     assert_bit_equal(xy, ref["refined_xy"])
     assert_bit_equal(valid, ref["validity"])
+    # the output file of the reference's writer: header + 16 numbers per kept match at 6 significant digits
+    kept = okeep.astype(bool)
+    rows = np.repeat(np.arange(len(ol["edges"])), np.diff(orp))[kept]
+    K = [f, 0, 607.1928, 0, f, 185.2157, 0, 0, 1]
+    fin = orc.finalize_pairs(K, K, np.eye(3), [t, 0, 0], ol["edges"][rows], orr["edges"][oci[kept]])
+    text = (tmp_path / "out.bin.txt").read_text().splitlines()
+    assert text[0] == ("left_edge_location, left_edge_orientation, right_edge_location, right_edge_orientation, "
+                       "left_edge_3D_point, left_edge_tangent")
+    assert len(text) == 1 + len(fin)
+    for line, row in zip(text[1:], fin):
+        assert line == " ".join("%g" % v for v in row)          # std::ostream default == printf %g

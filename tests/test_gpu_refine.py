@@ -186,3 +186,37 @@ def test_temporal_refine_flat_image(ctx):
     out = ctx.gn_refine_temporal(flat, flat, kf, kf, init)
     _compare_temporal(out, orc.gn_refine_temporal(flat, flat, kf, kf, init))
     assert np.array_equal(out["disp"], init) and np.all(out["iters"] == 1) and np.all(out["score"] == 0.0)
+
+
+def test_finalize_pairs_equals_oracle_and_geometry(ctx):
+    """ebvo_finalize_pairs vs the restatement of src/Stereo_Matches.cpp:1656-1699 (bit-exact), plus the geometry it
+    must satisfy on the synthetic rectified pair: depth f B / d, unit tangents, projected tangent along the edge."""
+    l, r = synth.stereo_pair("s2", 120, 200)
+    ctx.stereo_upload(l, r)
+    c = ctx.stereo_run(ctx.default_params(F_KITTI))
+    o = ctx.stereo_fetch(c)
+    keep = o["keep"].astype(bool)
+    rows = np.repeat(np.arange(c.n_left), np.diff(o["row_ptr"]))[keep]
+    L, R = o["left"][rows], o["right"][o["col_idx"][keep]]
+    cal = synth.CALIB["kitti"]
+    fx, fy, cx, cy = cal["K"]
+    K = [fx, 0, cx, 0, fy, cy, 0, 0, 1]
+    out = ctx.finalize_pairs(K, K, cal["R21"], cal["T21"], L, R)
+    ref = orc.finalize_pairs(K, K, cal["R21"], cal["T21"], L, R)
+    assert_bit_equal(out, ref, "finalize_pairs")
+    assert_bit_equal(out[:, 0], L["x"]) and assert_bit_equal(out[:, 5], R["theta"])
+    d = L["x"] - R["x"]
+    ok = np.abs(d - 12.0) < 0.5
+    assert ok.mean() > 0.5
+    # |Gamma.z| = f B / disparity; with the reference's T21 = (+0.54, 0, 0) (config/kitti.yaml) and x_R = x_L - d its
+    # formula (src/utility.cpp:95-102) returns the depth with a minus sign -- reproduced, not corrected
+    assert np.allclose(-out[ok, 8], fx * 0.54 / d[ok], rtol=1e-9)
+    assert np.allclose(np.linalg.norm(out[:, 9:12], axis=1), 1.0, atol=1e-12)
+    assert np.allclose(np.linalg.norm(out[:, 12:14], axis=1)[ok], 1.0, atol=1e-6)
+    # other calibration (non-identity rotation) and an empty list
+    ce = synth.CALIB["euroc"]
+    Kl = [ce["K"][0], 0, ce["K"][2], 0, ce["K"][1], ce["K"][3], 0, 0, 1]
+    Kr = [ce["K_right"][0], 0, ce["K_right"][2], 0, ce["K_right"][1], ce["K_right"][3], 0, 0, 1]
+    assert_bit_equal(ctx.finalize_pairs(Kl, Kr, ce["R21"], ce["T21"], L[:500], R[:500]),
+                     orc.finalize_pairs(Kl, Kr, ce["R21"], ce["T21"], L[:500], R[:500]), "euroc calib")
+    assert ctx.finalize_pairs(K, K, cal["R21"], cal["T21"], L[:0], R[:0]).shape == (0, 16)
