@@ -227,6 +227,36 @@ class Context:
         self._check(rc, "ebvo_gn_refine_temporal")
         return out
 
+    # -- stage glue: apply_Best_Nearly_Best_Test / apply_Lowe_Ratio_Test / shift_Edge_to_Epipolar_Line ---------------
+    def bnb_test(self, row_ptr, scores, ratio_thr, higher_is_better=True):
+        row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int32)
+        scores = np.ascontiguousarray(scores, dtype=np.float64)
+        nL = len(row_ptr) - 1
+        cnt = np.zeros(nL, dtype=np.int32)
+        order = np.full(len(scores), -1, dtype=np.int32)
+        self._check(self.lib.ebvo_bnb_test(self._ctx, ptr(row_ptr), nL, ptr(scores), ratio_thr, int(higher_is_better),
+                                           ptr(cnt), ptr(order)), "ebvo_bnb_test")
+        return cnt, order
+
+    def keep_best(self, row_ptr, scores):
+        row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int32)
+        scores = np.ascontiguousarray(scores, dtype=np.float64)
+        nL = len(row_ptr) - 1
+        cnt = np.zeros(nL, dtype=np.int32)
+        order = np.full(len(scores), -1, dtype=np.int32)
+        self._check(self.lib.ebvo_keep_best(self._ctx, ptr(row_ptr), nL, ptr(scores), ptr(cnt), ptr(order)),
+                    "ebvo_keep_best")
+        return cnt, order
+
+    def epipolar_shift(self, cand, lines, row_ptr):
+        cand = _edges(cand)
+        lines = np.ascontiguousarray(lines, dtype=np.float64).reshape(-1, 3)
+        row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int32)
+        out = np.zeros(len(cand), dtype=EDGE_DTYPE)
+        self._check(self.lib.ebvo_epipolar_shift(self._ctx, ptr(cand), ptr(lines), ptr(row_ptr), len(row_ptr) - 1,
+                                                 ptr(out)), "ebvo_epipolar_shift")
+        return out
+
     # -- write_finalized_stereo_edge_pairs_to_file, numeric body (src/Stereo_Matches.cpp:1656-1699) -----------------
     def finalize_pairs(self, K_left, K_right, R21, T21, left, right) -> np.ndarray:
         from ._lib import StereoCalib

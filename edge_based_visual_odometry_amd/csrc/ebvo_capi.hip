@@ -1065,6 +1065,102 @@ extern "C" int ebvo_gn_refine_temporal(ebvo_ctx *ctx, const uint8_t *imgKF, cons
     return EBVO_OK;
 }
 
+// ---- stage glue on CSR candidate lists -------------------------------------------------------------------------
+static int check_csr(const int32_t *row_ptr, int nL, int64_t *np)
+{
+    if (nL < 0 || !row_ptr || row_ptr[0] != 0)
+        return EBVO_ERR_ARG;
+    for (int i = 0; i < nL; ++i)
+        if (row_ptr[i + 1] < row_ptr[i])
+            return EBVO_ERR_ARG;
+    *np = row_ptr[nL];
+    return EBVO_OK;
+}
+
+static int row_select(ebvo_ctx *ctx, const int32_t *row_ptr, int nL, const double *scores, double thr, int mode,
+                      int32_t *new_count, int32_t *order)
+{
+    int64_t np = 0;
+    if (!ctx || check_csr(row_ptr, nL, &np) || (nL > 0 && !new_count) || (np > 0 && (!scores || !order)))
+        return EBVO_ERR_ARG;
+    EBVO_HIP(ctx, hipSetDevice(ctx->device));
+    int rc;
+    Slot *sp;
+    if ((rc = host_slot(ctx, &sp)))
+        return rc;
+    Slot &s = *sp;
+    if (nL == 0)
+        return EBVO_OK;
+    const size_t npz = (size_t)np;
+    if ((rc = ebvo_grow(ctx, s, s.row_ptr, sizeof(int32_t) * ((size_t)nL + 1))) ||
+        (rc = ebvo_grow(ctx, s, s.best, sizeof(double) * (npz + 1))) ||
+        (rc = ebvo_grow(ctx, s, s.cand_cnt, sizeof(int32_t) * ((size_t)nL + 1))) ||
+        (rc = ebvo_grow(ctx, s, s.pair_left, sizeof(int32_t) * (npz + 1))))
+        return rc;
+    hipStream_t st = s.stream;
+    EBVO_HIP(ctx, hipMemcpyAsync(s.row_ptr.p, row_ptr, sizeof(int32_t) * ((size_t)nL + 1), hipMemcpyHostToDevice, st));
+    if (npz)
+        EBVO_HIP(ctx, hipMemcpyAsync(s.best.p, scores, sizeof(double) * npz, hipMemcpyHostToDevice, st));
+    if (mode == 2)
+        rc = glue_keep_best_enqueue(ctx, s, (const int32_t *)s.row_ptr.p, nL, (const double *)s.best.p,
+                                    (int32_t *)s.cand_cnt.p, (int32_t *)s.pair_left.p);
+    else
+        rc = glue_bnb_enqueue(ctx, s, (const int32_t *)s.row_ptr.p, nL, (const double *)s.best.p, thr, mode,
+                              (int32_t *)s.cand_cnt.p, (int32_t *)s.pair_left.p);
+    if (rc)
+        return rc;
+    EBVO_HIP(ctx, hipMemcpyAsync(new_count, s.cand_cnt.p, sizeof(int32_t) * (size_t)nL, hipMemcpyDeviceToHost, st));
+    if (npz)
+        EBVO_HIP(ctx, hipMemcpyAsync(order, s.pair_left.p, sizeof(int32_t) * npz, hipMemcpyDeviceToHost, st));
+    EBVO_HIP(ctx, hipStreamSynchronize(st));
+    return EBVO_OK;
+}
+
+extern "C" int ebvo_bnb_test(ebvo_ctx *ctx, const int32_t *row_ptr, int nL, const double *scores, double ratio_thr,
+                             int higher_is_better, int32_t *new_count, int32_t *order)
+{
+    return row_select(ctx, row_ptr, nL, scores, ratio_thr, higher_is_better ? 1 : 0, new_count, order);
+}
+
+extern "C" int ebvo_keep_best(ebvo_ctx *ctx, const int32_t *row_ptr, int nL, const double *scores, int32_t *new_count,
+                              int32_t *order)
+{
+    return row_select(ctx, row_ptr, nL, scores, 0.0, 2, new_count, order);
+}
+
+extern "C" int ebvo_epipolar_shift(ebvo_ctx *ctx, const ebvo_edge *cand, const double *lines, const int32_t *row_ptr, int nL,
+                                   ebvo_edge *shifted)
+{
+    int64_t np = 0;
+    if (!ctx || check_csr(row_ptr, nL, &np) || (np > 0 && (!cand || !lines || !shifted)))
+        return EBVO_ERR_ARG;
+    EBVO_HIP(ctx, hipSetDevice(ctx->device));
+    int rc;
+    Slot *sp;
+    if ((rc = host_slot(ctx, &sp)))
+        return rc;
+    Slot &s = *sp;
+    if (np == 0)
+        return EBVO_OK;
+    const size_t npz = (size_t)np;
+    if ((rc = ebvo_grow(ctx, s, s.row_ptr, sizeof(int32_t) * ((size_t)nL + 1))) ||
+        (rc = ebvo_grow(ctx, s, s.lines, sizeof(double) * 3 * (size_t)nL)) ||
+        (rc = ebvo_grow(ctx, s, s.rc_edges, sizeof(ebvo_edge) * npz)) || (rc = ebvo_grow(ctx, s, s.scratch_c, sizeof(ebvo_edge) * npz)) ||
+        (rc = ebvo_grow(ctx, s, s.pair_left, sizeof(int32_t) * npz)))
+        return rc;
+    hipStream_t st = s.stream;
+    EBVO_HIP(ctx, hipMemcpyAsync(s.row_ptr.p, row_ptr, sizeof(int32_t) * ((size_t)nL + 1), hipMemcpyHostToDevice, st));
+    EBVO_HIP(ctx, hipMemcpyAsync(s.lines.p, lines, sizeof(double) * 3 * (size_t)nL, hipMemcpyHostToDevice, st));
+    EBVO_HIP(ctx, hipMemcpyAsync(s.rc_edges.p, cand, sizeof(ebvo_edge) * npz, hipMemcpyHostToDevice, st));
+    if ((rc = match_expand_rows_enqueue(ctx, s, (const int32_t *)s.row_ptr.p, nL, np, (int32_t *)s.pair_left.p)) ||
+        (rc = glue_shift_enqueue(ctx, s, (const ebvo_edge *)s.rc_edges.p, (const double *)s.lines.p,
+                                 (const int32_t *)s.pair_left.p, np, (ebvo_edge *)s.scratch_c.p)))
+        return rc;
+    EBVO_HIP(ctx, hipMemcpyAsync(shifted, s.scratch_c.p, sizeof(ebvo_edge) * npz, hipMemcpyDeviceToHost, st));
+    EBVO_HIP(ctx, hipStreamSynchronize(st));
+    return EBVO_OK;
+}
+
 extern "C" int ebvo_finalize_pairs(ebvo_ctx *ctx, const ebvo_stereo_calib *calib, const ebvo_edge *left,
                                    const ebvo_edge *right, int n, double *out16)
 {

@@ -211,6 +211,13 @@ int ebvo_device_scan4(ebvo_ctx *ctx, Slot &s, const int32_t *const in[4], int32_
                       const int32_t *const n_dev[4], int nb, int cap_n);
 int ebvo_device_scan(ebvo_ctx *ctx, Slot &s, const int32_t *in, int32_t *out, int n_host, const int32_t *n_dev, int n_add,
                      int cap_n);
+// glue_kernels.hip
+int glue_bnb_enqueue(ebvo_ctx *ctx, Slot &s, const int32_t *d_row_ptr, int nL, const double *d_scores, double thr,
+                     int higher_is_better, int32_t *d_new_count, int32_t *d_order);
+int glue_keep_best_enqueue(ebvo_ctx *ctx, Slot &s, const int32_t *d_row_ptr, int nL, const double *d_scores,
+                           int32_t *d_new_count, int32_t *d_order);
+int glue_shift_enqueue(ebvo_ctx *ctx, Slot &s, const ebvo_edge *d_cand, const double *d_lines, const int32_t *d_pair_left,
+                       int64_t n, ebvo_edge *d_out);
 // refine_kernels.hip
 int refine_sobel_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_img, int h, int w, int pitch, float *d_gx, float *d_gy,
                          void *d_gxy /* optional interleaved float2 plane */);

@@ -1,0 +1,189 @@
+// glue_kernels.hip -- row-wise stage glue of Stereo_Matches::get_Stereo_Edge_Pairs on CSR candidate lists
+// (SURVEY.md 8(f) rank 3), gfx950.  These are small closed-form row operations; they exist on the device so that a
+// candidate list does not have to visit the host between the NCC pass, the refinement and the second NCC pass.
+//
+//   bnb_kernel        apply_Best_Nearly_Best_Test        src/Stereo_Matches.cpp:789-862
+//   keep_best_kernel  apply_Lowe_Ratio_Test (as written: keeps only the best)   :916-964
+//   shift_kernel      shift_Edge_to_Epipolar_Line for every candidate (consolidate_redundant_edge_hypothesis with
+//                     b_do_epipolar_shift, :976-996; Utility::getNormal/TangentialDistance2EpipolarLine,
+//                     src/utility.cpp:46-74)
+// A selection is returned as new_count[nL] + order[n_pairs]: order[row_ptr[i] + k] is the pair index of the k-th
+// survivor of row i.  One thread per row (rows hold a handful of candidates).
+#include <hip/hip_runtime.h>
+
+#include "ebvo_internal.h"
+#include "ebvo_math.h"
+
+namespace
+{
+
+__global__ void bnb_kernel(const int32_t *__restrict__ row_ptr, int nL, const double *__restrict__ scores, double thr,
+                           int higher, int32_t *__restrict__ new_count, int32_t *__restrict__ order)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nL; i += gridDim.x * blockDim.x)
+    {
+        const int b = row_ptr[i], n = row_ptr[i + 1] - b;
+        int32_t *ord = order + b;
+        for (int k = 0; k < n; ++k)
+            ord[k] = b + k;
+        new_count[i] = n;
+        if (n < 2)
+            continue;
+        // stable insertion sort by score: std::sort's result for rows of <= 16 entries; ties keep their position
+        for (int k = 1; k < n; ++k)
+        {
+            const int32_t v = ord[k];
+            const double sv = scores[v];
+            int j = k;
+            while (j > 0 && (higher ? sv > scores[ord[j - 1]] : sv < scores[ord[j - 1]]))
+            {
+                ord[j] = ord[j - 1];
+                --j;
+            }
+            ord[j] = v;
+        }
+        int keep = 1;
+        const double best = scores[ord[0]];
+        for (int j = 0; j < n - 1; ++j)
+        {
+            const double next = scores[ord[j + 1]];
+            if (best == 0)
+                break;
+            const double ratio = higher ? next / best : best / next; // against the BEST, not the previous one (:829)
+            if (ratio >= thr)
+                ++keep;
+            else
+                break;
+        }
+        if (keep < n)
+            new_count[i] = keep;
+        else
+            for (int k = 0; k < n; ++k) // nothing dropped: the reference leaves the row untouched (:840)
+                ord[k] = b + k;
+    }
+}
+
+__global__ void keep_best_kernel(const int32_t *__restrict__ row_ptr, int nL, const double *__restrict__ scores,
+                                 int32_t *__restrict__ new_count, int32_t *__restrict__ order)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nL; i += gridDim.x * blockDim.x)
+    {
+        const int b = row_ptr[i], n = row_ptr[i + 1] - b;
+        new_count[i] = n ? 1 : 0;
+        if (!n)
+            continue;
+        int best = 0;
+        double mx = -1.0;
+        for (int j = 0; j < n; ++j)
+            if (scores[b + j] > mx)
+            {
+                mx = scores[b + j];
+                best = j;
+            }
+        order[b] = b + best;
+    }
+}
+
+// Utility::getTangentialDistance2EpipolarLine, src/utility.cpp:63-74; tan(theta) as sin / cos of the shared correctly
+// rounded pair (the oracle's portable mode does the same)
+__device__ inline double tangential_dist(double a1, double b1, double c1, double x, double y, double theta, double &xi,
+                                         double &yi)
+{
+    double sn, cs;
+    ebvo_sincos(theta, &sn, &cs);
+    const double a_e = sn / cs, b_e = -1;
+    const double c_e = -(a_e * x - y);
+    xi = (b1 * c_e - b_e * c1) / (a1 * b_e - a_e * b1);
+    yi = (c1 * a_e - c_e * a1) / (a1 * b_e - a_e * b1);
+    return sqrt((xi - x) * (xi - x) + (yi - y) * (yi - y));
+}
+
+__global__ void shift_kernel(const ebvo_edge *__restrict__ cand, const double *__restrict__ lines,
+                             const int32_t *__restrict__ pair_left, int64_t n, ebvo_edge *__restrict__ out)
+{
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x)
+    {
+        const int i = pair_left[k];
+        const double a1 = lines[(size_t)i * 3], b1 = lines[(size_t)i * 3 + 1], c1 = lines[(size_t)i * 3 + 2];
+        ebvo_edge e = cand[k];
+        const double x = e.x, y = e.y, th = e.theta;
+        e.index = 0;
+        e.pad = 0;
+        const double ex = x - a1 * (a1 * x + b1 * y + c1) / (a1 * a1 + b1 * b1); // src/utility.cpp:51-52, pow(., 2) = x * x
+        const double ey = y - b1 * (a1 * x + b1 * y + c1) / (a1 * a1 + b1 * b1);
+        if (sqrt((x - ex) * (x - ex) + (y - ey) * (y - ey)) < 0.4) // LOCATION_PERTURBATION
+        {
+            e.x = ex;
+            e.y = ey;
+        }
+        else
+        {
+            double xi, yi;
+            if (tangential_dist(a1, b1, c1, x, y, th, xi, yi) < 3) // EPIP_TANGENCY_DISPL_THRESH
+            {
+                e.x = xi;
+                e.y = yi;
+            }
+            else
+            {
+                double sn, cs, theta = th;
+                ebvo_sincos(theta, &sn, &cs);
+                const double p = a1 * cs + b1 * sn, dp = -a1 * sn + b1 * cs; // :60-61
+                if (p > 0 && dp < 0)
+                    theta -= 0.174533; // ORIENT_PERTURBATION
+                else if (p < 0 && dp < 0)
+                    theta -= 0.174533;
+                else if (p > 0 && dp > 0)
+                    theta += 0.174533;
+                else if (p < 0 && dp > 0)
+                    theta += 0.174533;
+                if (tangential_dist(a1, b1, c1, x, y, theta, xi, yi) < 3)
+                {
+                    e.x = xi;
+                    e.y = yi;
+                    e.theta = theta;
+                }
+            }
+        }
+        out[k] = e;
+    }
+}
+
+inline unsigned grid_for(int64_t n) { return (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048); }
+
+} // namespace
+
+int glue_bnb_enqueue(ebvo_ctx *ctx, Slot &s, const int32_t *d_row_ptr, int nL, const double *d_scores, double thr,
+                     int higher_is_better, int32_t *d_new_count, int32_t *d_order)
+{
+    if (nL <= 0)
+        return EBVO_OK;
+    ProfScope ps(ctx, s, K_MISC);
+    hipLaunchKernelGGL(bnb_kernel, dim3(grid_for(nL)), dim3(256), 0, s.stream, d_row_ptr, nL, d_scores, thr, higher_is_better,
+                       d_new_count, d_order);
+    EBVO_HIP(ctx, hipGetLastError());
+    return EBVO_OK;
+}
+
+int glue_keep_best_enqueue(ebvo_ctx *ctx, Slot &s, const int32_t *d_row_ptr, int nL, const double *d_scores,
+                           int32_t *d_new_count, int32_t *d_order)
+{
+    if (nL <= 0)
+        return EBVO_OK;
+    ProfScope ps(ctx, s, K_MISC);
+    hipLaunchKernelGGL(keep_best_kernel, dim3(grid_for(nL)), dim3(256), 0, s.stream, d_row_ptr, nL, d_scores, d_new_count,
+                       d_order);
+    EBVO_HIP(ctx, hipGetLastError());
+    return EBVO_OK;
+}
+
+int glue_shift_enqueue(ebvo_ctx *ctx, Slot &s, const ebvo_edge *d_cand, const double *d_lines, const int32_t *d_pair_left,
+                       int64_t n, ebvo_edge *d_out)
+{
+    if (n <= 0)
+        return EBVO_OK;
+    ProfScope ps(ctx, s, K_MISC);
+    hipLaunchKernelGGL(shift_kernel, dim3(grid_for(n)), dim3(256), 0, s.stream, d_cand, d_lines, d_pair_left, n, d_out);
+    EBVO_HIP(ctx, hipGetLastError());
+    return EBVO_OK;
+}

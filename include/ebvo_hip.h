@@ -212,6 +212,37 @@ int ebvo_gn_refine_temporal(ebvo_ctx *ctx, const uint8_t *imgKF, const uint8_t *
                             ptrdiff_t strideCF, const ebvo_edge *kf, const ebvo_edge *cf, const double *init_disp, int n,
                             const ebvo_gn_params *params, double *disp, double *score, uint8_t *validity, int32_t *iters);
 
+/* ---- stage glue on CSR candidate lists (no fixture of the reference pins it) ----------- */
+
+#define EBVO_BNB_NCC 0.9  /* include/definitions.h:34 */
+#define EBVO_BNB_SIFT 0.4 /* :33 */
+
+/*
+ * Stereo_Matches::apply_Best_Nearly_Best_Test (src/Stereo_Matches.cpp:789-862) on every row of a CSR list.
+ *   scores           : one per pair -- refine_final_scores with higher_is_better = 1 (is_NCC), refine_confidences
+ *                      (SIFT distances) with higher_is_better = 0
+ *   new_count[nL]    : survivors per row;  order[n_pairs] : order[row_ptr[i] + k] = pair index of the k-th survivor of
+ *                      row i (k < new_count[i]), in the order the reference leaves them: by score when something was
+ *                      dropped, untouched otherwise (:840).  Equal scores keep their relative position (std::sort is
+ *                      not stable; this is what libstdc++ does for rows of at most 16 candidates).
+ */
+int ebvo_bnb_test(ebvo_ctx *ctx, const int32_t *row_ptr, int nL, const double *scores, double ratio_thr,
+                  int higher_is_better, int32_t *new_count, int32_t *order);
+
+/* Stereo_Matches::apply_Lowe_Ratio_Test as written (:916-964): only the best-scoring candidate of each row survives
+ * (the first one on ties; candidate 0 if no score exceeds -1).  Same outputs as ebvo_bnb_test. */
+int ebvo_keep_best(ebvo_ctx *ctx, const int32_t *row_ptr, int nL, const double *scores, int32_t *new_count,
+                   int32_t *order);
+
+/*
+ * Stereo_Matches::shift_Edge_to_Epipolar_Line (:26-89) for every candidate of every row, i.e. the shift-only pass of
+ * consolidate_redundant_edge_hypothesis (:976-996): cand / shifted hold n_pairs edges (x, y, theta; index is returned
+ * 0 like the reference's Edge{loc, theta, false, 0}), lines the nL x 3 epipolar coefficients of the left edges.
+ * tan(theta) is formed as sin / cos of the library's correctly rounded pair, pow(x, 2) as x * x.
+ */
+int ebvo_epipolar_shift(ebvo_ctx *ctx, const ebvo_edge *cand, const double *lines, const int32_t *row_ptr, int nL,
+                        ebvo_edge *shifted);
+
 /* ---- finalisation geometry (what the output file holds) ----------------- */
 
 typedef struct

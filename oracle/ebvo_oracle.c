@@ -1030,6 +1030,162 @@ void orc_finalize_pairs(const double *Kl, const double *Kr, const double *R21, c
     }
 }
 
+/* ------------------------------------------------------------------------------------------
+ * Stage glue of get_Stereo_Edge_Pairs on CSR candidate lists.  PARITY UNPINNED.
+ * ------------------------------------------------------------------------------------------ */
+
+/* apply_Best_Nearly_Best_Test, src/Stereo_Matches.cpp:789-862.  Per row: candidates ordered by score (descending if
+ * higher_is_better -- refine_final_scores / NCC; ascending otherwise -- refine_confidences / SIFT distance), the best is
+ * kept and every following one while its ratio to the BEST stays >= thr.  When nothing is dropped the row keeps its
+ * original order (the reference only rebuilds the vectors if keep_count < num_clusters, :840).  std::sort is not
+ * stable; ties are resolved here by the original position (what libstdc++ does for rows of <= 16 entries).
+ * order[row_ptr[i] + k] = index (into the pair arrays) of the k-th survivor of row i, k < new_count[i]. */
+void orc_bnb_test(const int32_t *row_ptr, int nL, const double *scores, double thr, int higher_is_better,
+                  int32_t *new_count, int32_t *order)
+{
+    for (int i = 0; i < nL; i++)
+    {
+        const int b = row_ptr[i], n = row_ptr[i + 1] - b;
+        int32_t *ord = order + b;
+        for (int k = 0; k < n; k++)
+            ord[k] = b + k;
+        new_count[i] = n;
+        if (n < 2)
+            continue;
+        for (int k = 1; k < n; k++) /* stable insertion sort */
+        {
+            const int32_t v = ord[k];
+            int j = k;
+            while (j > 0 && (higher_is_better ? scores[v] > scores[ord[j - 1]] : scores[v] < scores[ord[j - 1]]))
+            {
+                ord[j] = ord[j - 1];
+                j--;
+            }
+            ord[j] = v;
+        }
+        int keep = 1;
+        const double best = scores[ord[0]];
+        for (int j = 0; j < n - 1; j++)
+        {
+            const double next = scores[ord[j + 1]];
+            if (best == 0)
+                break;
+            const double ratio = higher_is_better ? next / best : best / next;
+            if (ratio >= thr)
+                keep++;
+            else
+                break;
+        }
+        if (keep < n)
+            new_count[i] = keep;
+        else
+            for (int k = 0; k < n; k++)
+                ord[k] = b + k; /* untouched row */
+    }
+}
+
+/* apply_Lowe_Ratio_Test as written (:916-964): keeps ONLY the candidate with the highest score (first one on ties,
+ * index 0 if no score exceeds -1.0). */
+void orc_keep_best(const int32_t *row_ptr, int nL, const double *scores, int32_t *new_count, int32_t *order)
+{
+    for (int i = 0; i < nL; i++)
+    {
+        const int b = row_ptr[i], n = row_ptr[i + 1] - b;
+        new_count[i] = n ? 1 : 0;
+        if (!n)
+            continue;
+        int best = 0;
+        double mx = -1.0;
+        for (int j = 0; j < n; j++)
+            if (scores[b + j] > mx)
+            {
+                mx = scores[b + j];
+                best = j;
+            }
+        order[b] = b + best;
+    }
+}
+
+/* Utility::getTangentialDistance2EpipolarLine, src/utility.cpp:63-74 (tan from the shared sin/cos in portable mode) */
+static double tangential_dist(const double *ln, double x, double y, double theta, int math_mode, double *xi, double *yi)
+{
+    double a_e;
+    if (math_mode == ORC_MATH_LIBM)
+        a_e = tan(theta);
+    else
+    {
+        double sn, cs;
+        ebvo_sincos(theta, &sn, &cs);
+        a_e = sn / cs;
+    }
+    const double b_e = -1;
+    const double c_e = -(a_e * x - y);
+    const double a1 = ln[0], b1 = ln[1], c1 = ln[2];
+    *xi = (b1 * c_e - b_e * c1) / (a1 * b_e - a_e * b1);
+    *yi = (c1 * a_e - c_e * a1) / (a1 * b_e - a_e * b1);
+    return sqrt((*xi - x) * (*xi - x) + (*yi - y) * (*yi - y));
+}
+
+/* Stereo_Matches::shift_Edge_to_Epipolar_Line, src/Stereo_Matches.cpp:26-89, for every candidate of every row (the
+ * shift-only pass of consolidate_redundant_edge_hypothesis, :976-996).  pow(x, 2) is evaluated as x * x. */
+void orc_epipolar_shift(const orc_edge *cand, const double *lines, const int32_t *row_ptr, int nL, int math_mode,
+                        orc_edge *out)
+{
+    for (int i = 0; i < nL; i++)
+        for (int k = row_ptr[i]; k < row_ptr[i + 1]; k++)
+        {
+            const double *ln = lines + (size_t)i * 3;
+            const double x = cand[k].x, y = cand[k].y, th = cand[k].theta;
+            orc_edge e = cand[k];
+            e.index = 0;
+            e.pad = 0;
+            const double a1 = ln[0], b1 = ln[1], c1 = ln[2];
+            const double ex = x - a1 * (a1 * x + b1 * y + c1) / (a1 * a1 + b1 * b1); /* src/utility.cpp:51-52 */
+            const double ey = y - b1 * (a1 * x + b1 * y + c1) / (a1 * a1 + b1 * b1);
+            if (sqrt((x - ex) * (x - ex) + (y - ey) * (y - ey)) < 0.4) /* LOCATION_PERTURBATION */
+            {
+                e.x = ex;
+                e.y = ey;
+            }
+            else
+            {
+                double xi, yi;
+                if (tangential_dist(ln, x, y, th, math_mode, &xi, &yi) < 3) /* EPIP_TANGENCY_DISPL_THRESH */
+                {
+                    e.x = xi;
+                    e.y = yi;
+                }
+                else
+                {
+                    double sn, cs, theta = th;
+                    if (math_mode == ORC_MATH_LIBM)
+                    {
+                        cs = cos(theta);
+                        sn = sin(theta);
+                    }
+                    else
+                        ebvo_sincos(theta, &sn, &cs);
+                    const double p = a1 * cs + b1 * sn, dp = -a1 * sn + b1 * cs; /* :60-61 */
+                    if (p > 0 && dp < 0)
+                        theta -= 0.174533;
+                    else if (p < 0 && dp < 0)
+                        theta -= 0.174533;
+                    else if (p > 0 && dp > 0)
+                        theta += 0.174533;
+                    else if (p < 0 && dp > 0)
+                        theta += 0.174533;
+                    if (tangential_dist(ln, x, y, theta, math_mode, &xi, &yi) < 3)
+                    {
+                        e.x = xi;
+                        e.y = yi;
+                        e.theta = theta;
+                    }
+                }
+            }
+            out[k] = e;
+        }
+}
+
 void orc_atan2_v(const double *y, const double *x, int n, int math_mode, double *out)
 {
     for (int k = 0; k < n; k++)

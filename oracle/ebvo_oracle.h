@@ -134,6 +134,14 @@ void orc_inverse3(const double *m, double *inv);
 void orc_finalize_pairs(const double *K_left, const double *K_right, const double *R21, const double *T21,
                         const orc_edge *L, const orc_edge *R, int n, int math_mode, double *out16);
 
+/* Stage glue on CSR candidate lists (src/Stereo_Matches.cpp:789-862, :916-964, :26-89 + :976-996).  PARITY UNPINNED.
+ * Selections are returned as new_count[nL] + order[n_pairs] (order[row_ptr[i] + k] = pair index of the k-th survivor). */
+void orc_bnb_test(const int32_t *row_ptr, int nL, const double *scores, double thr, int higher_is_better,
+                  int32_t *new_count, int32_t *order);
+void orc_keep_best(const int32_t *row_ptr, int nL, const double *scores, int32_t *new_count, int32_t *order);
+void orc_epipolar_shift(const orc_edge *cand, const double *lines, const int32_t *row_ptr, int nL, int math_mode,
+                        orc_edge *out);
+
 #ifdef __cplusplus
 }
 #endif

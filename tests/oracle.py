@@ -167,6 +167,34 @@ def gn_refine_temporal(imgKF, imgCF, kf, cf, init_disp, max_iter=20, tol=1e-3, h
     return out
 
 
+def bnb_test(row_ptr, scores, ratio_thr, higher_is_better=True):
+    row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int32)
+    scores = np.ascontiguousarray(scores, dtype=np.float64)
+    cnt = np.zeros(len(row_ptr) - 1, dtype=np.int32)
+    order = np.full(len(scores), -1, dtype=np.int32)
+    lib().orc_bnb_test(_p(row_ptr), len(row_ptr) - 1, _p(scores), C.c_double(ratio_thr), int(higher_is_better), _p(cnt),
+                       _p(order))
+    return cnt, order
+
+
+def keep_best(row_ptr, scores):
+    row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int32)
+    scores = np.ascontiguousarray(scores, dtype=np.float64)
+    cnt = np.zeros(len(row_ptr) - 1, dtype=np.int32)
+    order = np.full(len(scores), -1, dtype=np.int32)
+    lib().orc_keep_best(_p(row_ptr), len(row_ptr) - 1, _p(scores), _p(cnt), _p(order))
+    return cnt, order
+
+
+def epipolar_shift(cand, lines, row_ptr, math_mode=PORTABLE):
+    cand = np.ascontiguousarray(cand, dtype=EDGE_DTYPE)
+    lines = np.ascontiguousarray(lines, dtype=np.float64).reshape(-1, 3)
+    row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int32)
+    out = np.zeros(len(cand), dtype=EDGE_DTYPE)
+    lib().orc_epipolar_shift(_p(cand), _p(lines), _p(row_ptr), len(row_ptr) - 1, math_mode, _p(out))
+    return out
+
+
 def finalize_pairs(K_left, K_right, R21, T21, left, right, math_mode=PORTABLE):
     arrs = [np.ascontiguousarray(a, dtype=np.float64).reshape(-1) for a in (K_left, K_right, R21, T21)]
     left = np.ascontiguousarray(left, dtype=EDGE_DTYPE)

@@ -1,0 +1,86 @@
+"""Stage glue through the C ABI (ebvo_bnb_test, ebvo_keep_best, ebvo_epipolar_shift) vs the oracle: integer outputs and
+the shifted edges are bit-exact (shared sin/cos, tan formed as their quotient on both sides)."""
+import numpy as np
+import pytest
+
+from edge_based_visual_odometry_amd import synth
+from tests import oracle as orc
+from tests.util import assert_bit_equal, assert_edges_equal
+
+pytestmark = pytest.mark.gpu
+
+F_KITTI = synth.fundamental_for("kitti")
+
+
+def _rows(rng, n_rows, max_len):
+    lens = rng.integers(0, max_len, n_rows)
+    lens[::7] = 1
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    return rp, int(rp[-1])
+
+
+@pytest.mark.parametrize("higher,thr", [(True, 0.9), (False, 0.4), (True, 0.0), (True, 2.0)])
+def test_bnb_equals_oracle(ctx, higher, thr):
+    rng = np.random.default_rng(7)
+    rp, n = _rows(rng, 5000, 30)
+    sc = rng.uniform(0.3, 1.0, n) if higher else rng.uniform(50, 400, n)
+    sc[3::13] = sc[2::13][: len(sc[3::13])]                      # exact ties
+    sc[10] = 0.0
+    sc[100:110] = np.nan                                         # NaN scores (unset refinements) must not hang or reorder
+    cnt, order = ctx.bnb_test(rp, sc, thr, higher)
+    oc, oo = orc.bnb_test(rp, sc, thr, higher)
+    assert_bit_equal(cnt, oc, "new_count")
+    assert_bit_equal(order, oo, "order")
+
+
+def test_keep_best_equals_oracle_and_edge_cases(ctx):
+    rng = np.random.default_rng(8)
+    rp, n = _rows(rng, 3000, 12)
+    sc = rng.uniform(-1.5, 1.0, n)
+    cnt, order = ctx.keep_best(rp, sc)
+    oc, oo = orc.keep_best(rp, sc)
+    assert_bit_equal(cnt, oc)
+    kept = np.repeat(cnt > 0, 1)
+    assert_bit_equal(order[rp[:-1][kept]], oo[rp[:-1][kept]])
+    # empty list / all-empty rows
+    cnt, order = ctx.bnb_test(np.zeros(5, dtype=np.int32), np.zeros(0), 0.9)
+    assert np.all(cnt == 0) and len(order) == 0
+
+
+def test_on_pipeline_scores(ctx):
+    """The reference's use: BNB on the NCC scores of the kept matches of a pair."""
+    l, r = synth.stereo_pair("s2", 120, 200)
+    ctx.stereo_upload(l, r)
+    c = ctx.stereo_run(ctx.default_params(F_KITTI))
+    o = ctx.stereo_fetch(c)
+    keep = o["keep"].astype(bool)
+    rows = np.repeat(np.arange(c.n_left), np.diff(o["row_ptr"]))[keep]
+    rp = np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=c.n_left))]).astype(np.int32)
+    scores = o["best"][keep]
+    cnt, order = ctx.bnb_test(rp, scores, 0.9, True)
+    oc, oo = orc.bnb_test(rp, scores, 0.9, True)
+    assert_bit_equal(cnt, oc) and assert_bit_equal(order, oo)
+    assert 0 < cnt.sum() < len(scores)
+    # every survivor's score is within the ratio of its row's best
+    for i in np.nonzero(cnt > 0)[0][:500]:
+        s = scores[order[rp[i]:rp[i] + cnt[i]]]
+        assert np.all(s >= 0.9 * scores[rp[i]:rp[i + 1]].max() - 1e-15)
+
+
+@pytest.mark.parametrize("cfg", ["kitti", "euroc"])
+def test_epipolar_shift_equals_oracle(ctx, cfg):
+    F = synth.fundamental_for(cfg)
+    l, r = synth.stereo_pair("s2", 120, 200)
+    L = ctx.toed(l).edges
+    R = ctx.toed(r).edges
+    lines = ctx.epipolar_lines(F, L)
+    rp, ci = ctx.epi_candidates(L, R, lines, stage_mask=3)        # epipolar + disparity candidates: all three branches
+    cand = R[ci].copy()
+    rng = np.random.default_rng(5)
+    cand["y"] += rng.uniform(-2.5, 2.5, len(cand))                # spread the normal distances over the thresholds
+    out = ctx.epipolar_shift(cand, lines, rp)
+    ref = orc.epipolar_shift(cand, lines, rp)
+    assert_edges_equal(out, ref, "shifted")
+    assert np.all(out["index"] == 0)
+    moved = (out["x"] != cand["x"]) | (out["y"] != cand["y"])
+    assert 0.2 < moved.mean() <= 1.0 and (out["theta"] != cand["theta"]).any()
