@@ -41,7 +41,7 @@ ABI_SYMBOLS = (
     "ebvo_stereo_upload_slot", "ebvo_stereo_submit", "ebvo_stereo_wait", "ebvo_stereo_fetch_slot", "ebvo_profile_enable",
     "ebvo_profile_reset", "ebvo_profile_get", "ebvo_fp64_peak",
     "ebvo_gn_default_params", "ebvo_sobel_gradients", "ebvo_gn_refine_stereo", "ebvo_stereo_refine",
-    "ebvo_stereo_fetch_refined", "ebvo_gn_refine_temporal", "ebvo_finalize_pairs", "ebvo_bnb_test", "ebvo_keep_best", "ebvo_epipolar_shift",
+    "ebvo_stereo_fetch_refined", "ebvo_gn_refine_temporal", "ebvo_finalize_pairs", "ebvo_bnb_test", "ebvo_keep_best", "ebvo_epipolar_shift", "ebvo_cluster_rows",
 )
 
 
@@ -133,6 +133,7 @@ def load_library() -> C.CDLL:
     lib.ebvo_bnb_test.argtypes = [vp, vp, i32, vp, dbl, i32, vp, vp]
     lib.ebvo_keep_best.argtypes = [vp, vp, i32, vp, vp, vp]
     lib.ebvo_epipolar_shift.argtypes = [vp, vp, vp, vp, i32, vp]
+    lib.ebvo_cluster_rows.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, vp]
     lib.ebvo_finalize_pairs.argtypes = [vp, C.POINTER(StereoCalib), vp, vp, i32, vp]
     lib.ebvo_stereo_refine.argtypes = [vp, i32, C.POINTER(GnParams)]
     lib.ebvo_stereo_fetch_refined.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp]

@@ -257,6 +257,18 @@ class Context:
                                                  ptr(out)), "ebvo_epipolar_shift")
         return out
 
+    def cluster_rows(self, cand, row_ptr, by_orientation=False, skip_single=True):
+        """EdgeClusterer per row: (new_count, centres, cluster_of)."""
+        cand = _edges(cand)
+        row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int32)
+        nL = len(row_ptr) - 1
+        cnt = np.zeros(nL, dtype=np.int32)
+        centres = np.zeros(len(cand), dtype=EDGE_DTYPE)
+        cluster_of = np.full(len(cand), -1, dtype=np.int32)
+        self._check(self.lib.ebvo_cluster_rows(self._ctx, ptr(cand), ptr(row_ptr), nL, int(by_orientation), int(skip_single),
+                                               ptr(cnt), ptr(centres), ptr(cluster_of)), "ebvo_cluster_rows")
+        return cnt, centres, cluster_of
+
     # -- write_finalized_stereo_edge_pairs_to_file, numeric body (src/Stereo_Matches.cpp:1656-1699) -----------------
     def finalize_pairs(self, K_left, K_right, R21, T21, left, right) -> np.ndarray:
         from ._lib import StereoCalib

@@ -1161,6 +1161,44 @@ extern "C" int ebvo_epipolar_shift(ebvo_ctx *ctx, const ebvo_edge *cand, const d
     return EBVO_OK;
 }
 
+extern "C" int ebvo_cluster_rows(ebvo_ctx *ctx, const ebvo_edge *cand, const int32_t *row_ptr, int nL, int by_orientation,
+                                 int skip_single, int32_t *new_count, ebvo_edge *centres, int32_t *cluster_of)
+{
+    int64_t np = 0;
+    if (!ctx || check_csr(row_ptr, nL, &np) || (nL > 0 && !new_count) || (np > 0 && (!cand || !centres || !cluster_of)))
+        return EBVO_ERR_ARG;
+    EBVO_HIP(ctx, hipSetDevice(ctx->device));
+    int rc;
+    Slot *sp;
+    if ((rc = host_slot(ctx, &sp)))
+        return rc;
+    Slot &s = *sp;
+    if (nL == 0)
+        return EBVO_OK;
+    const size_t npz = (size_t)np;
+    if ((rc = ebvo_grow(ctx, s, s.row_ptr, sizeof(int32_t) * ((size_t)nL + 1))) ||
+        (rc = ebvo_grow(ctx, s, s.cand_cnt, sizeof(int32_t) * ((size_t)nL + 1))) ||
+        (rc = ebvo_grow(ctx, s, s.rc_edges, sizeof(ebvo_edge) * (npz + 1))) ||
+        (rc = ebvo_grow(ctx, s, s.scratch_c, sizeof(ebvo_edge) * (npz + 1))) ||
+        (rc = ebvo_grow(ctx, s, s.pair_left, sizeof(int32_t) * (npz + 1))))
+        return rc;
+    hipStream_t st = s.stream;
+    EBVO_HIP(ctx, hipMemcpyAsync(s.row_ptr.p, row_ptr, sizeof(int32_t) * ((size_t)nL + 1), hipMemcpyHostToDevice, st));
+    if (npz)
+        EBVO_HIP(ctx, hipMemcpyAsync(s.rc_edges.p, cand, sizeof(ebvo_edge) * npz, hipMemcpyHostToDevice, st));
+    if ((rc = glue_cluster_enqueue(ctx, s, (const ebvo_edge *)s.rc_edges.p, (const int32_t *)s.row_ptr.p, nL, by_orientation,
+                                   skip_single, (int32_t *)s.cand_cnt.p, (ebvo_edge *)s.scratch_c.p, (int32_t *)s.pair_left.p)))
+        return rc;
+    EBVO_HIP(ctx, hipMemcpyAsync(new_count, s.cand_cnt.p, sizeof(int32_t) * (size_t)nL, hipMemcpyDeviceToHost, st));
+    if (npz)
+    {
+        EBVO_HIP(ctx, hipMemcpyAsync(centres, s.scratch_c.p, sizeof(ebvo_edge) * npz, hipMemcpyDeviceToHost, st));
+        EBVO_HIP(ctx, hipMemcpyAsync(cluster_of, s.pair_left.p, sizeof(int32_t) * npz, hipMemcpyDeviceToHost, st));
+    }
+    EBVO_HIP(ctx, hipStreamSynchronize(st));
+    return EBVO_OK;
+}
+
 extern "C" int ebvo_finalize_pairs(ebvo_ctx *ctx, const ebvo_stereo_calib *calib, const ebvo_edge *left,
                                    const ebvo_edge *right, int n, double *out16)
 {

@@ -218,6 +218,9 @@ int glue_keep_best_enqueue(ebvo_ctx *ctx, Slot &s, const int32_t *d_row_ptr, int
                            int32_t *d_new_count, int32_t *d_order);
 int glue_shift_enqueue(ebvo_ctx *ctx, Slot &s, const ebvo_edge *d_cand, const double *d_lines, const int32_t *d_pair_left,
                        int64_t n, ebvo_edge *d_out);
+int glue_cluster_enqueue(ebvo_ctx *ctx, Slot &s, const ebvo_edge *d_cand, const int32_t *d_row_ptr, int nL,
+                         int by_orientation, int skip_single, int32_t *d_new_count, ebvo_edge *d_centres,
+                         int32_t *d_cluster_of);
 // refine_kernels.hip
 int refine_sobel_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_img, int h, int w, int pitch, float *d_gx, float *d_gy,
                          void *d_gxy /* optional interleaved float2 plane */);

@@ -4,6 +4,7 @@
 //
 //   bnb_kernel        apply_Best_Nearly_Best_Test        src/Stereo_Matches.cpp:789-862
 //   keep_best_kernel  apply_Lowe_Ratio_Test (as written: keeps only the best)   :916-964
+//   cluster_kernel    EdgeClusterer::performClustering per row           src/EdgeClusterer.cpp:119-302
 //   shift_kernel      shift_Edge_to_Epipolar_Line for every candidate (consolidate_redundant_edge_hypothesis with
 //                     b_do_epipolar_shift, :976-996; Utility::getNormal/TangentialDistance2EpipolarLine,
 //                     src/utility.cpp:46-74)
@@ -149,6 +150,139 @@ __global__ void shift_kernel(const ebvo_edge *__restrict__ cand, const double *_
     }
 }
 
+// EdgeClusterer::performClustering for one row per thread (src/EdgeClusterer.cpp:119-302, driven by
+// consolidate_redundant_edge_hypothesis :1006-1034).  Merging decisions use sqrt / compare only and equal the
+// restatement exactly; the Gaussian weights use the device exp (<= 1 ulp from glibc's), so the centres agree to rounding.
+__device__ inline void gaussian_average(const ebvo_edge *__restrict__ E, const int32_t *lab, int n, int label, double &gx,
+                                        double &gy, double &gt)
+{
+    double sx = 0, sy = 0;
+    int count = 0;
+    for (int i = 0; i < n; ++i)
+        if (lab[i] == label)
+        {
+            sx += E[i].x;
+            sy += E[i].y;
+            ++count;
+        }
+    if (!count)
+    {
+        gx = gy = gt = 0.0;
+        return;
+    }
+    const double cx = sx / count, cy = sy / count;
+    double tot = 0.0;
+    for (int i = 0; i < n; ++i)
+        if (lab[i] == label)
+        {
+            const double dx = E[i].x - cx, dy = E[i].y - cy;
+            tot += sqrt(dx * dx + dy * dy);
+        }
+    const double mean = tot / count;
+    double wx = 0, wy = 0, wt = 0, w = 0;
+    for (int i = 0; i < n; ++i)
+        if (lab[i] == label)
+        {
+            const double dx = E[i].x - cx, dy = E[i].y - cy;
+            const double d = sqrt(dx * dx + dy * dy);
+            const double q = (d - mean) / 2.0; // CLUSTER_ORIENT_GAUSS_SIGMA
+            const double g = exp(-0.5 * (q * q));
+            wx += g * E[i].x;
+            wy += g * E[i].y;
+            wt += g * E[i].theta;
+            w += g;
+        }
+    gx = wx / w;
+    gy = wy / w;
+    gt = wt / w;
+}
+
+__global__ void cluster_kernel(const ebvo_edge *__restrict__ cand, const int32_t *__restrict__ row_ptr, int nL,
+                               int by_orientation, int skip_single, int32_t *__restrict__ new_count,
+                               ebvo_edge *__restrict__ centres, int32_t *__restrict__ cluster_of)
+{
+    const double orient_thr = 20.0 * 0x1.921fb54442d18p+1 / 180.0; // deg_to_rad(CLUSTER_ORIENT_THRESH): 20 * M_PI / 180
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < nL; r += gridDim.x * blockDim.x)
+    {
+        const int b = row_ptr[r], n = row_ptr[r + 1] - b;
+        const ebvo_edge *E = cand + b;
+        int32_t *lab = cluster_of + b;
+        new_count[r] = n;
+        for (int i = 0; i < n; ++i)
+            lab[i] = i;
+        if (n == 0)
+            continue;
+        if (n == 1 && skip_single)
+        {
+            centres[b] = E[0];
+            continue;
+        }
+        bool merged = true;
+        while (merged)
+        {
+            merged = false;
+            for (int i = 0; i < n && !merged; ++i)
+            {
+                double min_dist = 1.7976931348623157e308;
+                int nearest = -1;
+                for (int j = 0; j < n; ++j)
+                    if (lab[i] != lab[j])
+                    {
+                        const double dx = E[i].x - E[j].x, dy = E[i].y - E[j].y;
+                        const double dist = sqrt(dx * dx + dy * dy);
+                        if (dist < min_dist && dist < 1 && (!by_orientation || fabs(E[i].theta - E[j].theta) < orient_thr))
+                        {
+                            min_dist = dist;
+                            nearest = j;
+                        }
+                    }
+                if (nearest != -1)
+                {
+                    const int old_label = lab[nearest], new_label = lab[i];
+                    int so = 0, sn = 0;
+                    for (int k = 0; k < n; ++k)
+                    {
+                        so += lab[k] == old_label;
+                        sn += lab[k] == new_label;
+                    }
+                    if (so + sn <= 10) // MAX_CLUSTER_SIZE
+                    {
+                        for (int k = 0; k < n; ++k)
+                            if (lab[k] == old_label)
+                                lab[k] = new_label;
+                        merged = true;
+                    }
+                }
+            }
+        }
+        int C = 0;
+        for (int l = 0; l < n; ++l)
+        {
+            bool present = false;
+            for (int i = 0; i < n && !present; ++i)
+                present = lab[i] == l;
+            if (!present)
+                continue;
+            double gx, gy, gt;
+            gaussian_average(E, lab, n, l, gx, gy, gt);
+            ebvo_edge c;
+            c.x = gx;
+            c.y = gy;
+            c.theta = gt;
+            c.index = 0;
+            c.pad = 0;
+            centres[b + C] = c;
+            for (int i = 0; i < n; ++i) // renumber in ascending label order; negative marks cannot collide with labels
+                if (lab[i] == l)
+                    lab[i] = -1 - C;
+            ++C;
+        }
+        for (int i = 0; i < n; ++i)
+            lab[i] = -1 - lab[i];
+        new_count[r] = C;
+    }
+}
+
 inline unsigned grid_for(int64_t n) { return (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048); }
 
 } // namespace
@@ -184,6 +318,19 @@ int glue_shift_enqueue(ebvo_ctx *ctx, Slot &s, const ebvo_edge *d_cand, const do
         return EBVO_OK;
     ProfScope ps(ctx, s, K_MISC);
     hipLaunchKernelGGL(shift_kernel, dim3(grid_for(n)), dim3(256), 0, s.stream, d_cand, d_lines, d_pair_left, n, d_out);
+    EBVO_HIP(ctx, hipGetLastError());
+    return EBVO_OK;
+}
+
+int glue_cluster_enqueue(ebvo_ctx *ctx, Slot &s, const ebvo_edge *d_cand, const int32_t *d_row_ptr, int nL,
+                         int by_orientation, int skip_single, int32_t *d_new_count, ebvo_edge *d_centres,
+                         int32_t *d_cluster_of)
+{
+    if (nL <= 0)
+        return EBVO_OK;
+    ProfScope ps(ctx, s, K_MISC);
+    hipLaunchKernelGGL(cluster_kernel, dim3(grid_for(nL)), dim3(256), 0, s.stream, d_cand, d_row_ptr, nL, by_orientation,
+                       skip_single, d_new_count, d_centres, d_cluster_of);
     EBVO_HIP(ctx, hipGetLastError());
     return EBVO_OK;
 }

@@ -243,6 +243,21 @@ int ebvo_keep_best(ebvo_ctx *ctx, const int32_t *row_ptr, int nL, const double *
 int ebvo_epipolar_shift(ebvo_ctx *ctx, const ebvo_edge *cand, const double *lines, const int32_t *row_ptr, int nL,
                         ebvo_edge *shifted);
 
+/*
+ * EdgeClusterer::performClustering (src/EdgeClusterer.cpp:119-302) on every row of a CSR list, as the clustering pass of
+ * consolidate_redundant_edge_hypothesis runs it (src/Stereo_Matches.cpp:1006-1034): single-linkage merging of the
+ * candidates' locations below CLUSTER_DIST_THRESH = 1 px (and |dtheta| < 20 deg if by_orientation), clusters capped at
+ * MAX_CLUSTER_SIZE = 10, one Gaussian-weighted average edge per cluster.  skip_single = 1 leaves rows with one
+ * candidate untouched (the cluster-only call, :998-999).
+ *   new_count[nL]      : clusters per row
+ *   centres[n_pairs]   : centres[row_ptr[i] + c] = centre edge of cluster c of row i (c < new_count[i]); the rest of a
+ *                        row's slots is unspecified
+ *   cluster_of[n_pairs]: cluster index (0 .. new_count[i] - 1) of every input candidate: its contributing_edges
+ * Merging decisions are exact; the centres carry the device exp() in their weights (within 1e-12 px of glibc's).
+ */
+int ebvo_cluster_rows(ebvo_ctx *ctx, const ebvo_edge *cand, const int32_t *row_ptr, int nL, int by_orientation,
+                      int skip_single, int32_t *new_count, ebvo_edge *centres, int32_t *cluster_of);
+
 /* ---- finalisation geometry (what the output file holds) ----------------- */
 
 typedef struct

@@ -1186,6 +1186,156 @@ void orc_epipolar_shift(const orc_edge *cand, const double *lines, const int32_t
         }
 }
 
+/* EdgeClusterer (src/EdgeClusterer.cpp:7-302) as consolidate_redundant_edge_hypothesis drives it (:1006-1034):
+ * single-linkage merging of the candidates of one row on their ORIGINAL locations (distance < CLUSTER_DIST_THRESH = 1 px,
+ * and |dtheta| < 20 deg if by_orientation), every point in turn absorbing the cluster of its nearest foreign point as
+ * long as the merged size stays <= MAX_CLUSTER_SIZE = 10, restarting after every merge; then one Gaussian-weighted
+ * average edge per cluster (weights exp(-0.5 ((d - mean d) / 2)^2) of the distance to the centroid), clusters ordered
+ * by label.  Rows with a single candidate are left alone when skip_single is set (the cluster-only call, :998-999).
+ * Outputs: new_count[nL]; centres[row_ptr[i] + c] for c < new_count[i]; cluster_of[k] = cluster index of candidate k. */
+static void gaussian_average(const orc_edge *E, const int32_t *lab, int n, int label, double *gx, double *gy, double *gt)
+{
+    double sx = 0, sy = 0;
+    int count = 0;
+    for (int i = 0; i < n; i++)
+        if (lab[i] == label)
+        {
+            sx += E[i].x;
+            sy += E[i].y;
+            count++;
+        }
+    if (!count)
+    {
+        *gx = *gy = *gt = 0.0;
+        return;
+    }
+    const double cx = sx / count, cy = sy / count;
+    double tot = 0.0;
+    for (int i = 0; i < n; i++)
+        if (lab[i] == label)
+        {
+            const double dx = E[i].x - cx, dy = E[i].y - cy;
+            tot += sqrt(dx * dx + dy * dy);
+        }
+    const double mean = tot / count;
+    double wx = 0, wy = 0, wt = 0, w = 0;
+    for (int i = 0; i < n; i++)
+        if (lab[i] == label)
+        {
+            const double dx = E[i].x - cx, dy = E[i].y - cy;
+            const double d = sqrt(dx * dx + dy * dy);
+            const double q = (d - mean) / 2.0; /* CLUSTER_ORIENT_GAUSS_SIGMA */
+            const double g = exp(-0.5 * (q * q)); /* std::pow(q, 2) */
+            wx += g * E[i].x;
+            wy += g * E[i].y;
+            wt += g * E[i].theta;
+            w += g;
+        }
+    *gx = wx / w;
+    *gy = wy / w;
+    *gt = wt / w;
+}
+
+void orc_cluster_rows(const orc_edge *cand, const int32_t *row_ptr, int nL, int by_orientation, int skip_single,
+                      int32_t *new_count, orc_edge *centres, int32_t *cluster_of)
+{
+    const double orient_thr = 20.0 * M_PI / 180.0; /* deg_to_rad(CLUSTER_ORIENT_THRESH) */
+    for (int r = 0; r < nL; r++)
+    {
+        const int b = row_ptr[r], n = row_ptr[r + 1] - b;
+        const orc_edge *E = cand + b;
+        int32_t *lab = cluster_of + b;
+        new_count[r] = n;
+        for (int i = 0; i < n; i++)
+            lab[i] = i;
+        if (n == 0)
+            continue;
+        if (n == 1 && skip_single)
+        {
+            centres[b] = E[0];
+            lab[0] = 0;
+            continue;
+        }
+        int merged = 1;
+        while (merged)
+        {
+            merged = 0;
+            for (int i = 0; i < n; i++)
+            {
+                double min_dist = 1.7976931348623157e308;
+                int nearest = -1;
+                for (int j = 0; j < n; j++)
+                    if (lab[i] != lab[j])
+                    {
+                        const double dx = E[i].x - E[j].x, dy = E[i].y - E[j].y;
+                        const double dist = sqrt(dx * dx + dy * dy); /* cv::norm */
+                        if (dist < min_dist && dist < 1 && (!by_orientation || fabs(E[i].theta - E[j].theta) < orient_thr))
+                        {
+                            min_dist = dist;
+                            nearest = j;
+                        }
+                    }
+                if (nearest != -1)
+                {
+                    const int old_label = lab[nearest], new_label = lab[i];
+                    int so = 0, sn = 0;
+                    for (int k = 0; k < n; k++)
+                    {
+                        so += lab[k] == old_label;
+                        sn += lab[k] == new_label;
+                    }
+                    if (so + sn <= 10) /* MAX_CLUSTER_SIZE */
+                    {
+                        for (int k = 0; k < n; k++)
+                            if (lab[k] == old_label)
+                                lab[k] = new_label;
+                        merged = 1;
+                        break;
+                    }
+                }
+            }
+        }
+        /* clusters in ascending label order (std::map), one Gaussian-weighted average edge each */
+        int C = 0;
+        for (int l = 0; l < n; l++)
+        {
+            int present = 0;
+            for (int i = 0; i < n && !present; i++)
+                present = lab[i] == l;
+            if (!present)
+                continue;
+            double gx, gy, gt;
+            gaussian_average(E, lab, n, l, &gx, &gy, &gt);
+            orc_edge c;
+            c.x = gx;
+            c.y = gy;
+            c.theta = gt;
+            c.index = 0;
+            c.pad = 0;
+            centres[b + C] = c;
+            C++;
+        }
+        /* renumber the labels 0 .. C-1 in ascending label order (:258-269) */
+        int next = 0;
+        for (int l = 0; l < n; l++)
+        {
+            int present = 0;
+            for (int i = 0; i < n; i++)
+                if (lab[i] == l)
+                    present = 1;
+            if (!present)
+                continue;
+            for (int i = 0; i < n; i++)
+                if (lab[i] == l)
+                    lab[i] = -1 - next; /* mark, so that renumbered values do not collide with pending labels */
+            next++;
+        }
+        for (int i = 0; i < n; i++)
+            lab[i] = -1 - lab[i];
+        new_count[r] = C;
+    }
+}
+
 void orc_atan2_v(const double *y, const double *x, int n, int math_mode, double *out)
 {
     for (int k = 0; k < n; k++)

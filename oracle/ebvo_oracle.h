@@ -142,6 +142,11 @@ void orc_keep_best(const int32_t *row_ptr, int nL, const double *scores, int32_t
 void orc_epipolar_shift(const orc_edge *cand, const double *lines, const int32_t *row_ptr, int nL, int math_mode,
                         orc_edge *out);
 
+/* EdgeClusterer::performClustering per CSR row (src/EdgeClusterer.cpp:119-302; consolidate_redundant_edge_hypothesis
+ * :1006-1034).  PARITY UNPINNED. */
+void orc_cluster_rows(const orc_edge *cand, const int32_t *row_ptr, int nL, int by_orientation, int skip_single,
+                      int32_t *new_count, orc_edge *centres, int32_t *cluster_of);
+
 #ifdef __cplusplus
 }
 #endif

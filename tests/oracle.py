@@ -195,6 +195,17 @@ def epipolar_shift(cand, lines, row_ptr, math_mode=PORTABLE):
     return out
 
 
+def cluster_rows(cand, row_ptr, by_orientation=False, skip_single=True):
+    cand = np.ascontiguousarray(cand, dtype=EDGE_DTYPE)
+    row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int32)
+    cnt = np.zeros(len(row_ptr) - 1, dtype=np.int32)
+    centres = np.zeros(len(cand), dtype=EDGE_DTYPE)
+    cluster_of = np.full(len(cand), -1, dtype=np.int32)
+    lib().orc_cluster_rows(_p(cand), _p(row_ptr), len(row_ptr) - 1, int(by_orientation), int(skip_single), _p(cnt),
+                           _p(centres), _p(cluster_of))
+    return cnt, centres, cluster_of
+
+
 def finalize_pairs(K_left, K_right, R21, T21, left, right, math_mode=PORTABLE):
     arrs = [np.ascontiguousarray(a, dtype=np.float64).reshape(-1) for a in (K_left, K_right, R21, T21)]
     left = np.ascontiguousarray(left, dtype=EDGE_DTYPE)

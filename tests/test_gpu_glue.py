@@ -84,3 +84,45 @@ def test_epipolar_shift_equals_oracle(ctx, cfg):
     assert np.all(out["index"] == 0)
     moved = (out["x"] != cand["x"]) | (out["y"] != cand["y"])
     assert 0.2 < moved.mean() <= 1.0 and (out["theta"] != cand["theta"]).any()
+
+
+@pytest.mark.parametrize("by_orient,skip", [(False, True), (True, False)])
+def test_cluster_rows_equals_oracle(ctx, by_orient, skip):
+    rng = np.random.default_rng(16)
+    lens = rng.integers(0, 40, 4000)
+    lens[::9] = 1
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    cand = np.zeros(rp[-1], dtype=orc.EDGE_DTYPE)
+    for i in range(len(lens)):
+        b, n = rp[i], lens[i]
+        x = np.cumsum(rng.choice([0.2, 0.6, 0.95, 1.05, 2.5], n)) + 50
+        cand["x"][b:b + n] = x[rng.permutation(n)]
+        cand["y"][b:b + n] = 30 + rng.uniform(-0.2, 0.2, n)
+        cand["theta"][b:b + n] = rng.choice([0.3, 0.5, 1.2], n) + rng.uniform(-0.05, 0.05, n)
+    cnt, centres, cof = ctx.cluster_rows(cand, rp, by_orient, skip)
+    oc, ocen, ocof = orc.cluster_rows(cand, rp, by_orient, skip)
+    assert_bit_equal(cnt, oc, "new_count")
+    assert_bit_equal(cof, ocof, "cluster_of")
+    valid = np.concatenate([np.arange(rp[i], rp[i] + cnt[i]) for i in range(len(lens))]) if cnt.sum() else np.zeros(0, int)
+    for f in ("x", "y", "theta"):                                  # weights carry exp(): device vs glibc, 1 ulp
+        assert np.allclose(centres[f][valid], ocen[f][valid], rtol=0, atol=1e-12), f
+    assert 0 < cnt.sum() < lens.sum()
+
+
+def test_cluster_on_refined_matches(ctx):
+    """The reference's use: cluster the refined candidate centres of every left edge (cluster-only call)."""
+    l, r = synth.stereo_pair("s2", 120, 200)
+    ctx.stereo_upload(l, r)
+    c = ctx.stereo_run(ctx.default_params(F_KITTI))
+    ref = ctx.stereo_refine(c)
+    o = ctx.stereo_fetch(c)
+    keep = o["keep"].astype(bool)
+    rows = np.repeat(np.arange(c.n_left), np.diff(o["row_ptr"]))[keep]
+    rp = np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=c.n_left))]).astype(np.int32)
+    cand = np.zeros(keep.sum(), dtype=orc.EDGE_DTYPE)
+    cand["x"], cand["y"] = ref["refined_xy"][keep].T
+    cand["theta"] = o["right"]["theta"][o["col_idx"][keep]]
+    cnt, centres, cof = ctx.cluster_rows(cand, rp)
+    oc, ocen, ocof = orc.cluster_rows(cand, rp)
+    assert_bit_equal(cnt, oc) and assert_bit_equal(cof, ocof)
+    assert cnt.sum() < len(cand)                                   # refinement pulls neighbouring candidates together

@@ -109,3 +109,86 @@ def test_epipolar_shift_geometry():
     same_branch = (out2["theta"] == out["theta"]) & ((out2["x"] != cand["x"]) == moved)
     assert same_branch.mean() > 0.99
     assert np.allclose(out2["x"][same_branch], out["x"][same_branch], rtol=0, atol=1e-9)
+
+
+def _cluster_python(E, by_orientation):
+    """EdgeClusterer::performClustering, src/EdgeClusterer.cpp:119-302, read directly."""
+    n = len(E)
+    lab = list(range(n))
+    thr = math.radians(20.0)
+
+    def gauss(label):
+        idx = [i for i in range(n) if lab[i] == label]
+        sx = sy = 0.0
+        for i in idx:
+            sx += E["x"][i]
+            sy += E["y"][i]
+        cx, cy = sx / len(idx), sy / len(idx)
+        tot = 0.0
+        for i in idx:
+            tot += math.sqrt((E["x"][i] - cx) ** 2 + (E["y"][i] - cy) ** 2)
+        mean = tot / len(idx)
+        wx = wy = wt = w = 0.0
+        for i in idx:
+            d = math.sqrt((E["x"][i] - cx) ** 2 + (E["y"][i] - cy) ** 2)
+            g = math.exp(-0.5 * ((d - mean) / 2.0) ** 2)
+            wx += g * E["x"][i]
+            wy += g * E["y"][i]
+            wt += g * E["theta"][i]
+            w += g
+        return wx / w, wy / w, wt / w
+
+    merged = True
+    while merged:
+        merged = False
+        for i in range(n):
+            md, nearest = float("inf"), -1
+            for j in range(n):
+                if lab[i] != lab[j]:
+                    dist = math.sqrt((E["x"][i] - E["x"][j]) ** 2 + (E["y"][i] - E["y"][j]) ** 2)
+                    ok = dist < md and dist < 1
+                    if by_orientation:
+                        ok = ok and abs(E["theta"][i] - E["theta"][j]) < thr
+                    if ok:
+                        md, nearest = dist, j
+            if nearest != -1:
+                old, new = lab[nearest], lab[i]
+                if lab.count(old) + lab.count(new) <= 10:
+                    lab = [new if v == old else v for v in lab]
+                    merged = True
+                    break
+    uniq = sorted(set(lab))
+    return [uniq.index(v) for v in lab], [gauss(u) for u in uniq]
+
+
+def test_cluster_rows_matches_python_reading():
+    rng = np.random.default_rng(6)
+    lens = rng.integers(0, 18, 300)
+    lens[::9] = 1
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    cand = np.zeros(rp[-1], dtype=orc.EDGE_DTYPE)
+    # candidates along a line with gaps around the 1-px threshold, a few dense groups that hit the size cap
+    for i in range(len(lens)):
+        b, n = rp[i], lens[i]
+        x = np.cumsum(rng.choice([0.2, 0.6, 0.95, 1.05, 2.5], n)) + 50
+        cand["x"][b:b + n] = x[rng.permutation(n)]
+        cand["y"][b:b + n] = 30 + rng.uniform(-0.2, 0.2, n)
+        cand["theta"][b:b + n] = rng.choice([0.3, 0.5, 1.2], n) + rng.uniform(-0.05, 0.05, n)
+    for by_orient in (False, True):
+        for skip in (True, False):
+            cnt, centres, cof = orc.cluster_rows(cand, rp, by_orient, skip)
+            for i in range(len(lens)):
+                b, n = rp[i], lens[i]
+                if n == 0:
+                    assert cnt[i] == 0
+                    continue
+                if n == 1 and skip:
+                    assert cnt[i] == 1 and centres[b] == cand[b]
+                    continue
+                lab, cen = _cluster_python(cand[b:b + n], by_orient)
+                assert cnt[i] == len(cen)
+                assert list(cof[b:b + n]) == lab
+                for c, (gx, gy, gt) in enumerate(cen):
+                    assert centres["x"][b + c] == gx and centres["y"][b + c] == gy and centres["theta"][b + c] == gt
+            sizes = np.bincount(np.repeat(np.arange(len(lens)), lens) * 64 + cof)
+            assert sizes.max() <= 10                                   # MAX_CLUSTER_SIZE
