@@ -41,7 +41,7 @@ ABI_SYMBOLS = (
     "ebvo_stereo_upload_slot", "ebvo_stereo_submit", "ebvo_stereo_wait", "ebvo_stereo_fetch_slot", "ebvo_profile_enable",
     "ebvo_profile_reset", "ebvo_profile_get", "ebvo_fp64_peak",
     "ebvo_gn_default_params", "ebvo_sobel_gradients", "ebvo_gn_refine_stereo", "ebvo_stereo_refine",
-    "ebvo_stereo_fetch_refined", "ebvo_gn_refine_temporal", "ebvo_finalize_pairs", "ebvo_bnb_test", "ebvo_keep_best", "ebvo_epipolar_shift", "ebvo_cluster_rows",
+    "ebvo_stereo_fetch_refined", "ebvo_gn_refine_temporal", "ebvo_finalize_pairs", "ebvo_bnb_test", "ebvo_keep_best", "ebvo_epipolar_shift", "ebvo_cluster_rows", "ebvo_stereo_finalize", "ebvo_stereo_fetch_final",
 )
 
 
@@ -57,6 +57,15 @@ class StereoCalib(C.Structure):
 
 class GnParams(C.Structure):
     _fields_ = [("max_iter", C.c_int), ("tol", C.c_double), ("huber_delta", C.c_double)]
+
+
+class FinalizeParams(C.Structure):
+    _fields_ = [("bnb_ratio", C.c_double), ("ncc_thr", C.c_double), ("gn", GnParams)]
+
+
+class FinalizeCounts(C.Structure):
+    _fields_ = [("n_ncc", C.c_int32), ("n_bnb", C.c_int32), ("n_clusters", C.c_int32), ("n_ncc2", C.c_int32),
+                ("n_final", C.c_int32)]
 
 
 class StereoCounts(C.Structure):
@@ -134,6 +143,8 @@ def load_library() -> C.CDLL:
     lib.ebvo_keep_best.argtypes = [vp, vp, i32, vp, vp, vp]
     lib.ebvo_epipolar_shift.argtypes = [vp, vp, vp, vp, i32, vp]
     lib.ebvo_cluster_rows.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, vp]
+    lib.ebvo_stereo_finalize.argtypes = [vp, i32, C.POINTER(FinalizeParams), C.POINTER(StereoCalib), C.POINTER(FinalizeCounts)]
+    lib.ebvo_stereo_fetch_final.argtypes = [vp, i32, vp, vp, vp, vp]
     lib.ebvo_finalize_pairs.argtypes = [vp, C.POINTER(StereoCalib), vp, vp, i32, vp]
     lib.ebvo_stereo_refine.argtypes = [vp, i32, C.POINTER(GnParams)]
     lib.ebvo_stereo_fetch_refined.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp]

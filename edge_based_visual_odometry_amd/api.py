@@ -283,6 +283,29 @@ class Context:
                     "ebvo_finalize_pairs")
         return out
 
+    def stereo_finalize(self, calib=None, slot=0, bnb_ratio=0.9, ncc_thr=0.6, **gn):
+        """BNB -> shift -> refine -> cluster -> NCC -> best on the resident pair.  calib = (K_left, K_right, R21, T21) adds the
+        output-file rows.  Returns (counts dict, dict(left_index, right, score[, rows]))."""
+        from ._lib import FinalizeCounts, FinalizeParams, StereoCalib
+        p = FinalizeParams()
+        p.bnb_ratio, p.ncc_thr, p.gn = bnb_ratio, ncc_thr, self._gn_params(**gn)
+        cal = None
+        if calib is not None:
+            cal = StereoCalib()
+            for name, v, n in zip(("K_left", "K_right", "R21", "T21"), calib, (9, 9, 9, 3)):
+                getattr(cal, name)[:] = np.ascontiguousarray(v, dtype=np.float64).reshape(n).tolist()
+        cnt = FinalizeCounts()
+        self._check(self.lib.ebvo_stereo_finalize(self._ctx, slot, C.byref(p), C.byref(cal) if cal is not None else None,
+                                                  C.byref(cnt)), "ebvo_stereo_finalize")
+        n = cnt.n_final
+        out = dict(left_index=np.zeros(n, dtype=np.int32), right=np.zeros(n, dtype=EDGE_DTYPE), score=np.zeros(n))
+        rows = np.zeros((n, 16)) if calib is not None else None
+        self._check(self.lib.ebvo_stereo_fetch_final(self._ctx, slot, ptr(out["left_index"]), ptr(out["right"]),
+                                                     ptr(out["score"]), ptr(rows)), "ebvo_stereo_fetch_final")
+        if rows is not None:
+            out["rows"] = rows
+        return {k: getattr(cnt, k) for k in ("n_ncc", "n_bnb", "n_clusters", "n_ncc2", "n_final")}, out
+
     def stereo_refine(self, counts, slot=0, **kw):
         """Refine every kept match of the resident pair on the device; returns the per-pair outputs (n_pairs entries,
         validity 255 where the pair was not a kept match)."""

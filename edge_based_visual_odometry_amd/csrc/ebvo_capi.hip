@@ -136,7 +136,7 @@ static void slot_destroy(Slot *s)
         (void)hipFree(ws.cand_lists);
         (void)hipFree(ws.cand_lcount);
     }
-    GrowBuf *bufs[] = {&s->lines,        &s->boxes_chunk,  &s->boxes_group,    &s->cand_cnt,       &s->cand_stage, &s->cand_tileflag, &s->row_ptr, &s->grad_x, &s->grad_y, &s->gn_xy, &s->gn_out, &s->gn_valid, &s->gn_iters, &s->gn_state, &s->gn_lists,
+    GrowBuf *bufs[] = {&s->lines,        &s->boxes_chunk,  &s->boxes_group,    &s->cand_cnt,       &s->cand_stage, &s->cand_tileflag, &s->row_ptr, &s->grad_x, &s->grad_y, &s->gn_xy, &s->gn_out, &s->gn_valid, &s->gn_iters, &s->gn_state, &s->gn_lists, &s->fin_i32, &s->fin_edges, &s->fin_f64, &s->fin_u8, &s->fin_out,
                        &s->scan_tmp,     &s->col_idx,      &s->rc_edges,       &s->sims,           &s->best,
                        &s->keep,         &s->patches_raw,  &s->patches_norm,   &s->patches_flag,   &s->patches_norm_r,
                        &s->patches_flag_r, &s->pair_left,  &s->sincos,         &s->scratch_b,      &s->scratch_c,
@@ -337,7 +337,7 @@ static int host_slot(ebvo_ctx *ctx, Slot **out)
         ctx->last_error = "slot 0 has a submitted pair in flight; call ebvo_stereo_wait first";
         return EBVO_ERR_STATE;
     }
-    s.have_pair = s.have_run = s.have_refined = false;
+    s.have_pair = s.have_run = s.have_refined = s.have_final = false;
     *out = &s;
     return EBVO_OK;
 }
@@ -928,7 +928,7 @@ extern "C" int ebvo_stereo_submit(ebvo_ctx *ctx, int slot, const ebvo_stereo_par
         return EBVO_ERR_STATE;
     EBVO_HIP(ctx, hipSetDevice(ctx->device));
     int rc;
-    s.have_run = s.have_refined = false;
+    s.have_run = s.have_refined = s.have_final = false;
     s.params = *p;
     s.prof_now = ctx->prof && (ctx->prof_submits++ % ctx->prof_every == 0);
     {
@@ -1293,6 +1293,157 @@ extern "C" int ebvo_stereo_fetch_refined(ebvo_ctx *ctx, int slot, double *alpha,
         EBVO_HIP(ctx, hipMemcpyAsync(validity, s.gn_valid.p, npz, hipMemcpyDeviceToHost, st));
     if (iters)
         EBVO_HIP(ctx, hipMemcpyAsync(iters, s.gn_iters.p, sizeof(int32_t) * npz, hipMemcpyDeviceToHost, st));
+    EBVO_HIP(ctx, hipStreamSynchronize(st));
+    return EBVO_OK;
+}
+
+// ---- the stages after the NCC pass, on the resident pair (no SIFT): BNB -> shift -> refine -> cluster -> NCC -> best
+// Every stage is the kernel behind the corresponding host-buffer entry point; only the CSR bookkeeping between them is
+// new (glue_kernels.hip).  The host reads one count per stage to size the next launches; no candidate data leaves HBM.
+static int read_i32(ebvo_ctx *ctx, Slot &s, const int32_t *d, int32_t *h)
+{
+    EBVO_HIP(ctx, hipMemcpyAsync(h, d, sizeof(int32_t), hipMemcpyDeviceToHost, s.stream));
+    EBVO_HIP(ctx, hipStreamSynchronize(s.stream));
+    return EBVO_OK;
+}
+
+extern "C" int ebvo_stereo_finalize(ebvo_ctx *ctx, int slot, const ebvo_finalize_params *p, const ebvo_stereo_calib *calib,
+                                    ebvo_finalize_counts *counts)
+{
+    Slot *sp;
+    if (!p || !counts || !(p->bnb_ratio >= 0) || !(p->ncc_thr == p->ncc_thr) || p->gn.max_iter < 1 || !(p->gn.tol >= 0) ||
+        !(p->gn.huber_delta > 0) || get_slot(ctx, slot, &sp))
+        return EBVO_ERR_ARG;
+    Slot &s = *sp;
+    if (!s.have_run || s.in_flight)
+        return EBVO_ERR_STATE;
+    EBVO_HIP(ctx, hipSetDevice(ctx->device));
+    memset(counts, 0, sizeof *counts);
+    s.have_final = s.have_refined = false; // the refinement buffers are reused
+
+    s.n_final = 0;
+    const int nL = s.result.n_left, h = s.cur_h, w = s.cur_w;
+    const int64_t n0 = s.result.n_pairs;
+    if (nL == 0 || n0 == 0)
+    {
+        s.have_final = true;
+        return EBVO_OK;
+    }
+    const size_t nz = (size_t)n0, nLz = (size_t)nL + 1;
+    int rc;
+    // carve the work buffers: everything is bounded by the pair count of the run (each stage only shrinks the lists)
+    if ((rc = ebvo_grow(ctx, s, s.fin_i32, sizeof(int32_t) * (4 * nLz + 4 * nz))) ||
+        (rc = ebvo_grow(ctx, s, s.fin_edges, sizeof(ebvo_edge) * (3 * nz + 2 * nLz))) ||
+        (rc = ebvo_grow(ctx, s, s.fin_f64, sizeof(double) * (3 * nz + nLz) + 16 * nz)) ||
+        (rc = ebvo_grow(ctx, s, s.fin_u8, nz)) || (rc = ebvo_grow(ctx, s, s.fin_out, sizeof(double) * 16 * nLz)) ||
+        (rc = ebvo_grow(ctx, s, s.grad_x, 2 * sizeof(float) * (size_t)h * w + 64)) ||
+        (rc = ebvo_grow(ctx, s, s.gn_xy, sizeof(double) * 2 * nz)) || (rc = ebvo_grow(ctx, s, s.gn_out, sizeof(double) * 5 * nz)) ||
+        (rc = ebvo_grow(ctx, s, s.gn_valid, nz)) || (rc = ebvo_grow(ctx, s, s.gn_iters, sizeof(int32_t) * nz)))
+        return rc;
+    int32_t *cnt = (int32_t *)s.fin_i32.p, *rpA = cnt + nLz, *rpB = rpA + nLz, *final_left = rpB + nLz;
+    int32_t *order = final_left + nLz, *left_of = order + nz, *cluster_of = left_of + nz, *ncc_left = cluster_of + nz;
+    ebvo_edge *candA = (ebvo_edge *)s.fin_edges.p, *candB = candA + nz, *candC = candB + nz, *fin_l = candC + nz,
+              *fin_r = fin_l + nLz;
+    double *scoreA = (double *)s.fin_f64.p, *scoreB = scoreA + nz, *best2 = scoreB + nz, *fin_score = best2 + nz;
+    void *sincos2 = fin_score + nLz; // n0 double2
+    uint8_t *keep2 = (uint8_t *)s.fin_u8.p;
+    const int32_t *rp0 = (const int32_t *)s.row_ptr.p;
+    hipStream_t st = s.stream;
+    auto scan_counts = [&](int32_t *rp_out, int32_t *total) -> int {
+        // exclusive scan of cnt[0 .. nL) with the total at rp_out[nL]
+        EBVO_HIP(ctx, hipMemsetAsync(cnt + nL, 0, sizeof(int32_t), st));
+        int r = ebvo_device_scan(ctx, s, cnt, rp_out, nL, nullptr, 1, nL + 1);
+        return r ? r : read_i32(ctx, s, rp_out + nL, total);
+    };
+    int32_t nA = 0, nB = 0, nE = 0, nF = 0, nG = 0;
+    // 1. the kept NCC matches as a CSR list of right TOED edges with their scores (apply_NCC_Filtering's output, :597-607)
+    if ((rc = glue_rows_from_flags_enqueue(ctx, s, rp0, nL, (const uint8_t *)s.keep.p, cnt, order)) ||
+        (rc = scan_counts(rpA, &nA)) ||
+        (rc = glue_gather_rows_enqueue(ctx, s, rp0, cnt, order, rpA, nL, s.im[1].edges, (const int32_t *)s.col_idx.p, candA,
+                                       (const double *)s.best.p, scoreA)))
+        return rc;
+    counts->n_ncc = nA;
+    // 2. Best-Nearly-Best test on the NCC scores (:1418)
+    if (nA && ((rc = glue_bnb_enqueue(ctx, s, rpA, nL, scoreA, p->bnb_ratio, 1, cnt, order)) || (rc = scan_counts(rpB, &nB)) ||
+               (rc = glue_gather_rows_enqueue(ctx, s, rpA, cnt, order, rpB, nL, candA, nullptr, candB, scoreA, scoreB))))
+        return rc;
+    counts->n_bnb = nB;
+    if (nB)
+    {
+        // 3. epipolar shift (:1436) and 4. photometric refinement along the epipolar line (:1438)
+        double *out = (double *)s.gn_out.p;
+        if ((rc = match_expand_rows_enqueue(ctx, s, rpB, nL, nB, left_of)) ||
+            (rc = glue_shift_enqueue(ctx, s, candB, (const double *)s.lines.p, left_of, nB, candC)) ||
+            (rc = glue_xy_enqueue(ctx, s, candC, (double *)s.gn_xy.p, nB, false)) ||
+            (rc = refine_sobel_enqueue(ctx, s, s.im[1].img, h, w, w, nullptr, nullptr, s.grad_x.p)) ||
+            (rc = refine_gn_stereo_enqueue(ctx, s, s.im[0].img, s.im[1].img, s.grad_x.p, h, w, s.im[0].edges,
+                                           (const double *)s.lines.p, left_of, (const double *)s.gn_xy.p, nullptr, nullptr,
+                                           nullptr, nB, p->gn.max_iter, p->gn.tol, p->gn.huber_delta, out, out + nz,
+                                           out + 2 * nz, (uint8_t *)s.gn_valid.p, (int32_t *)s.gn_iters.p, out + 3 * nz)) ||
+            (rc = glue_xy_enqueue(ctx, s, candC, out + 3 * nz, nB, true)))
+            return rc;
+        // 5. clustering of the refined centres (:1450: cluster-only call) -> candA in the rows of rpA
+        if ((rc = glue_cluster_enqueue(ctx, s, candC, rpB, nL, 0, 1, cnt, candB, cluster_of)) || (rc = scan_counts(rpA, &nE)) ||
+            (rc = glue_gather_rows_enqueue(ctx, s, rpB, cnt, nullptr, rpA, nL, candB, nullptr, candA, nullptr, nullptr)))
+            return rc;
+    }
+    counts->n_clusters = nE;
+    if (nE)
+    {
+        // 6. second NCC pass on the cluster centres (:1463) -> keep2 / best2, 7. the best survivor of every row (:1472)
+        if ((rc = match_ncc_pairs_enqueue(ctx, s, s.im[1].img, h, w, w, candA, rpA, nL, nE, (const float *)s.patches_norm.p,
+                                          (const uint8_t *)s.patches_flag.p, p->ncc_thr, nullptr, best2, keep2, ncc_left,
+                                          sincos2)) ||
+            (rc = glue_rows_from_flags_enqueue(ctx, s, rpA, nL, keep2, cnt, order)) || (rc = scan_counts(rpB, &nF)) ||
+            (rc = glue_gather_rows_enqueue(ctx, s, rpA, cnt, order, rpB, nL, candA, nullptr, candC, best2, scoreB)))
+            return rc;
+        counts->n_ncc2 = nF;
+        if (nF && ((rc = glue_keep_best_enqueue(ctx, s, rpB, nL, scoreB, cnt, order)) || (rc = scan_counts(rpA, &nG)) ||
+                   (rc = glue_final_pairs_enqueue(ctx, s, rpB, cnt, order, rpA, nL, s.im[0].edges, candC, scoreB, final_left,
+                                                  fin_l, fin_r, fin_score))))
+            return rc;
+    }
+    counts->n_final = nG;
+    // 8. the rows of the output file
+    if (nG && calib &&
+        (rc = refine_finalize_pairs_enqueue(ctx, s, calib->K_left, calib->K_right, calib->R21, calib->T21, fin_l, fin_r, nG,
+                                            (double *)s.fin_out.p)))
+        return rc;
+    EBVO_HIP(ctx, hipStreamSynchronize(st));
+    s.n_final = nG;
+    s.have_final = true;
+    s.final_has_rows = calib != nullptr;
+    return EBVO_OK;
+}
+
+extern "C" int ebvo_stereo_fetch_final(ebvo_ctx *ctx, int slot, int32_t *left_index, ebvo_edge *right_edge, double *ncc_score,
+                                       double *out16)
+{
+    Slot *sp;
+    if (get_slot(ctx, slot, &sp))
+        return EBVO_ERR_ARG;
+    Slot &s = *sp;
+    if (!s.have_final || s.in_flight)
+        return EBVO_ERR_STATE;
+    if (out16 && !s.final_has_rows)
+        return EBVO_ERR_STATE;
+    EBVO_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t n = (size_t)s.n_final;
+    if (!n)
+        return EBVO_OK;
+    const size_t nz = (size_t)s.result.n_pairs, nLz = (size_t)s.result.n_left + 1;
+    const int32_t *final_left = (const int32_t *)s.fin_i32.p + 3 * nLz;
+    const ebvo_edge *fin_r = (const ebvo_edge *)s.fin_edges.p + 3 * nz + nLz;
+    const double *fin_score = (const double *)s.fin_f64.p + 3 * nz;
+    hipStream_t st = s.stream;
+    if (left_index)
+        EBVO_HIP(ctx, hipMemcpyAsync(left_index, final_left, sizeof(int32_t) * n, hipMemcpyDeviceToHost, st));
+    if (right_edge)
+        EBVO_HIP(ctx, hipMemcpyAsync(right_edge, fin_r, sizeof(ebvo_edge) * n, hipMemcpyDeviceToHost, st));
+    if (ncc_score)
+        EBVO_HIP(ctx, hipMemcpyAsync(ncc_score, fin_score, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+    if (out16)
+        EBVO_HIP(ctx, hipMemcpyAsync(out16, s.fin_out.p, sizeof(double) * 16 * n, hipMemcpyDeviceToHost, st));
     EBVO_HIP(ctx, hipStreamSynchronize(st));
     return EBVO_OK;
 }

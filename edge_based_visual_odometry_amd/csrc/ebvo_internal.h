@@ -108,6 +108,9 @@ struct Slot
 
     // matching workspace
     GrowBuf grad_x, grad_y, gn_xy, gn_out, gn_valid, gn_iters, gn_state, gn_lists; // photometric refinement (refine_kernels.hip)
+    GrowBuf fin_i32, fin_edges, fin_f64, fin_u8, fin_out; // ebvo_stereo_finalize: CSRs, candidate lists, scores, final rows
+    int n_final = 0;
+    bool have_final = false, final_has_rows = false;
     GrowBuf lines, boxes_chunk, boxes_group, cand_cnt, cand_stage, cand_tileflag, row_ptr, scan_tmp, col_idx, rc_edges, sims, best, keep,
         patches_raw, patches_norm, patches_flag, patches_norm_r, patches_flag_r, pair_left, sincos, scratch_b, scratch_c,
         scratch_d;
@@ -199,7 +202,8 @@ int match_patches_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_img, int h, i
 int match_ncc_pairs_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_imgR, int h, int w, int pitchR,
                             const ebvo_edge *d_Rc, const int32_t *d_row_ptr, int nL, int64_t n_pairs,
                             const float *d_left_norm, const uint8_t *d_left_flag, double thr, double *d_sims,
-                            double *d_best, uint8_t *d_keep);
+                            double *d_best, uint8_t *d_keep, int32_t *d_pair_left_scratch = nullptr,
+                            void *d_sincos_scratch = nullptr /* n_pairs double2; NULL: the slot's own buffers */);
 int match_ncc_banked_enqueue(ebvo_ctx *ctx, Slot &s, int nL, const int32_t *d_nL, int cap_edges, int64_t n_pairs_host,
                              double thr);
 int match_pair_result_enqueue(ebvo_ctx *ctx, Slot &s);
@@ -221,6 +225,16 @@ int glue_shift_enqueue(ebvo_ctx *ctx, Slot &s, const ebvo_edge *d_cand, const do
 int glue_cluster_enqueue(ebvo_ctx *ctx, Slot &s, const ebvo_edge *d_cand, const int32_t *d_row_ptr, int nL,
                          int by_orientation, int skip_single, int32_t *d_new_count, ebvo_edge *d_centres,
                          int32_t *d_cluster_of);
+int glue_rows_from_flags_enqueue(ebvo_ctx *ctx, Slot &s, const int32_t *d_row_ptr, int nL, const uint8_t *d_flags,
+                                 int32_t *d_new_count, int32_t *d_order);
+int glue_gather_rows_enqueue(ebvo_ctx *ctx, Slot &s, const int32_t *d_rp_in, const int32_t *d_cnt, const int32_t *d_order,
+                             const int32_t *d_rp_out, int nL, const ebvo_edge *d_E_src, const int32_t *d_emap,
+                             ebvo_edge *d_E_dst, const double *d_D_src, double *d_D_dst);
+int glue_xy_enqueue(ebvo_ctx *ctx, Slot &s, ebvo_edge *d_edges, double *d_xy, int64_t n, bool to_edges);
+int glue_final_pairs_enqueue(ebvo_ctx *ctx, Slot &s, const int32_t *d_rp_in, const int32_t *d_cnt, const int32_t *d_order,
+                             const int32_t *d_rp_out, int nL, const ebvo_edge *d_L, const ebvo_edge *d_cand,
+                             const double *d_score, int32_t *d_left_index, ebvo_edge *d_left_edge, ebvo_edge *d_right_edge,
+                             double *d_final_score);
 // refine_kernels.hip
 int refine_sobel_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_img, int h, int w, int pitch, float *d_gx, float *d_gy,
                          void *d_gxy /* optional interleaved float2 plane */);

@@ -283,6 +283,82 @@ __global__ void cluster_kernel(const ebvo_edge *__restrict__ cand, const int32_t
     }
 }
 
+// ---- CSR plumbing of the device-resident chain (ebvo_stereo_finalize) ------------------------------------------------
+// rows from per-pair flags: new_count[i] = flagged pairs of row i, order[row_ptr[i] + k] = pair index of the k-th one
+__global__ void rows_from_flags_kernel(const int32_t *__restrict__ row_ptr, int nL, const uint8_t *__restrict__ flags,
+                                       int32_t *__restrict__ new_count, int32_t *__restrict__ order)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nL; i += gridDim.x * blockDim.x)
+    {
+        int c = 0;
+        for (int k = row_ptr[i]; k < row_ptr[i + 1]; ++k)
+            if (flags[k])
+                order[row_ptr[i] + c++] = k;
+        new_count[i] = c;
+    }
+}
+
+// per-pair data of a selection (new_count, order over the rows of rp_in) packed into the rows of rp_out.
+// order == NULL: the first new_count[i] slots of row i (cluster centres).  emap != NULL: edges are E_src[emap[p]].
+__global__ void gather_rows_kernel(const int32_t *__restrict__ rp_in, const int32_t *__restrict__ cnt,
+                                   const int32_t *__restrict__ order, const int32_t *__restrict__ rp_out, int nL,
+                                   const ebvo_edge *__restrict__ E_src, const int32_t *__restrict__ emap,
+                                   ebvo_edge *__restrict__ E_dst, const double *__restrict__ D_src,
+                                   double *__restrict__ D_dst)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nL; i += gridDim.x * blockDim.x)
+        for (int k = 0; k < cnt[i]; ++k)
+        {
+            const int p = order ? order[rp_in[i] + k] : rp_in[i] + k, q = rp_out[i] + k;
+            if (E_dst)
+            {
+                ebvo_edge e = E_src[emap ? emap[p] : p];
+                e.index = 0;
+                e.pad = 0;
+                E_dst[q] = e;
+            }
+            if (D_dst)
+                D_dst[q] = D_src[p];
+        }
+}
+
+__global__ void edges_to_xy_kernel(const ebvo_edge *__restrict__ e, int64_t n, double *__restrict__ xy)
+{
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x)
+    {
+        xy[2 * k] = e[k].x;
+        xy[2 * k + 1] = e[k].y;
+    }
+}
+
+__global__ void xy_to_edges_kernel(const double *__restrict__ xy, int64_t n, ebvo_edge *__restrict__ e)
+{
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x)
+    {
+        e[k].x = xy[2 * k];
+        e[k].y = xy[2 * k + 1];
+    }
+}
+
+// the rows that kept one candidate become the final pairs: left index, left edge, right centre, score
+__global__ void final_pairs_kernel(const int32_t *__restrict__ rp_in, const int32_t *__restrict__ cnt,
+                                   const int32_t *__restrict__ order, const int32_t *__restrict__ rp_out, int nL,
+                                   const ebvo_edge *__restrict__ L, const ebvo_edge *__restrict__ cand,
+                                   const double *__restrict__ score, int32_t *__restrict__ left_index,
+                                   ebvo_edge *__restrict__ left_edge, ebvo_edge *__restrict__ right_edge,
+                                   double *__restrict__ final_score)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nL; i += gridDim.x * blockDim.x)
+        if (cnt[i] > 0)
+        {
+            const int p = order[rp_in[i]], q = rp_out[i];
+            left_index[q] = i;
+            left_edge[q] = L[i];
+            right_edge[q] = cand[p];
+            final_score[q] = score[p];
+        }
+}
+
 inline unsigned grid_for(int64_t n) { return (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048); }
 
 } // namespace
@@ -331,6 +407,54 @@ int glue_cluster_enqueue(ebvo_ctx *ctx, Slot &s, const ebvo_edge *d_cand, const 
     ProfScope ps(ctx, s, K_MISC);
     hipLaunchKernelGGL(cluster_kernel, dim3(grid_for(nL)), dim3(256), 0, s.stream, d_cand, d_row_ptr, nL, by_orientation,
                        skip_single, d_new_count, d_centres, d_cluster_of);
+    EBVO_HIP(ctx, hipGetLastError());
+    return EBVO_OK;
+}
+
+int glue_rows_from_flags_enqueue(ebvo_ctx *ctx, Slot &s, const int32_t *d_row_ptr, int nL, const uint8_t *d_flags,
+                                 int32_t *d_new_count, int32_t *d_order)
+{
+    if (nL <= 0)
+        return EBVO_OK;
+    hipLaunchKernelGGL(rows_from_flags_kernel, dim3(grid_for(nL)), dim3(256), 0, s.stream, d_row_ptr, nL, d_flags,
+                       d_new_count, d_order);
+    EBVO_HIP(ctx, hipGetLastError());
+    return EBVO_OK;
+}
+
+int glue_gather_rows_enqueue(ebvo_ctx *ctx, Slot &s, const int32_t *d_rp_in, const int32_t *d_cnt, const int32_t *d_order,
+                             const int32_t *d_rp_out, int nL, const ebvo_edge *d_E_src, const int32_t *d_emap,
+                             ebvo_edge *d_E_dst, const double *d_D_src, double *d_D_dst)
+{
+    if (nL <= 0)
+        return EBVO_OK;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(nL)), dim3(256), 0, s.stream, d_rp_in, d_cnt, d_order, d_rp_out, nL,
+                       d_E_src, d_emap, d_E_dst, d_D_src, d_D_dst);
+    EBVO_HIP(ctx, hipGetLastError());
+    return EBVO_OK;
+}
+
+int glue_xy_enqueue(ebvo_ctx *ctx, Slot &s, ebvo_edge *d_edges, double *d_xy, int64_t n, bool to_edges)
+{
+    if (n <= 0)
+        return EBVO_OK;
+    if (to_edges)
+        hipLaunchKernelGGL(xy_to_edges_kernel, dim3(grid_for(n)), dim3(256), 0, s.stream, (const double *)d_xy, n, d_edges);
+    else
+        hipLaunchKernelGGL(edges_to_xy_kernel, dim3(grid_for(n)), dim3(256), 0, s.stream, (const ebvo_edge *)d_edges, n, d_xy);
+    EBVO_HIP(ctx, hipGetLastError());
+    return EBVO_OK;
+}
+
+int glue_final_pairs_enqueue(ebvo_ctx *ctx, Slot &s, const int32_t *d_rp_in, const int32_t *d_cnt, const int32_t *d_order,
+                             const int32_t *d_rp_out, int nL, const ebvo_edge *d_L, const ebvo_edge *d_cand,
+                             const double *d_score, int32_t *d_left_index, ebvo_edge *d_left_edge, ebvo_edge *d_right_edge,
+                             double *d_final_score)
+{
+    if (nL <= 0)
+        return EBVO_OK;
+    hipLaunchKernelGGL(final_pairs_kernel, dim3(grid_for(nL)), dim3(256), 0, s.stream, d_rp_in, d_cnt, d_order, d_rp_out, nL,
+                       d_L, d_cand, d_score, d_left_index, d_left_edge, d_right_edge, d_final_score);
     EBVO_HIP(ctx, hipGetLastError());
     return EBVO_OK;
 }

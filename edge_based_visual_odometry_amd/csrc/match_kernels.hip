@@ -1375,17 +1375,17 @@ int match_patch_banks_enqueue(ebvo_ctx *ctx, Slot &s, int h, int w, int cap_edge
 int match_ncc_pairs_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_imgR, int h, int w, int pitchR,
                             const ebvo_edge *d_Rc, const int32_t *d_row_ptr, int nL, int64_t n_pairs,
                             const float *d_left_norm, const uint8_t *d_left_flag, double thr, double *d_sims,
-                            double *d_best, uint8_t *d_keep)
+                            double *d_best, uint8_t *d_keep, int32_t *d_pair_left_scratch, void *d_sincos_scratch)
 {
     if (n_pairs <= 0 || nL <= 0)
         return EBVO_OK;
     int rc;
-    if ((rc = ebvo_grow(ctx, s, s.pair_left, sizeof(int32_t) * (size_t)n_pairs)))
+    if (!d_pair_left_scratch && (rc = ebvo_grow(ctx, s, s.pair_left, sizeof(int32_t) * (size_t)n_pairs)))
         return rc;
-    if ((rc = ebvo_grow(ctx, s, s.sincos, sizeof(double2) * (size_t)n_pairs)))
+    if (!d_sincos_scratch && (rc = ebvo_grow(ctx, s, s.sincos, sizeof(double2) * (size_t)n_pairs)))
         return rc;
-    int32_t *pair_left = (int32_t *)s.pair_left.p;
-    double2 *sc = (double2 *)s.sincos.p;
+    int32_t *pair_left = d_pair_left_scratch ? d_pair_left_scratch : (int32_t *)s.pair_left.p;
+    double2 *sc = d_sincos_scratch ? (double2 *)d_sincos_scratch : (double2 *)s.sincos.p;
     {
         ProfScope ps(ctx, s, K_MISC);
         hipLaunchKernelGGL(expand_rows_kernel, dim3(blocks_for(nL, 256, 512)), dim3(256), 0, s.stream, d_row_ptr,

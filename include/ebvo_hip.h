@@ -288,6 +288,36 @@ int ebvo_stereo_refine(ebvo_ctx *ctx, int slot, const ebvo_gn_params *params);
 int ebvo_stereo_fetch_refined(ebvo_ctx *ctx, int slot, double *alpha, double *score, double *confidence,
                               uint8_t *validity, int32_t *iters, double *refined_xy);
 
+/*
+ * The stages of get_Stereo_Edge_Pairs after the NCC pass (src/Stereo_Matches.cpp:1418-1481), without SIFT, on the pair
+ * resident in `slot` and without the candidate lists leaving the device:
+ *   kept NCC matches -> apply_Best_Nearly_Best_Test(BNB_NCC) -> epipolar shift -> refine_edge_disparity ->
+ *   clustering -> apply_NCC_Filtering on the cluster centres -> best candidate per row -> rows with a match
+ * and, if calib is given, the 16 numbers of the output file per final pair.  Each stage is the kernel behind the
+ * corresponding host-buffer entry point (ebvo_bnb_test, ebvo_epipolar_shift, ebvo_gn_refine_stereo,
+ * ebvo_cluster_rows, ebvo_ncc_pairs, ebvo_keep_best, ebvo_finalize_pairs), so the result equals chaining those calls
+ * on the fetched data.  The SIFT filter and the BNB test on SIFT distances of the reference (:1400, :1427) need OpenCV
+ * and stay on the host; a caller that wants them runs the entry points one by one instead.
+ */
+typedef struct
+{
+    double bnb_ratio; /* EBVO_BNB_NCC */
+    double ncc_thr;   /* EBVO_NCC_THRESH, second pass */
+    ebvo_gn_params gn;
+} ebvo_finalize_params;
+
+typedef struct
+{
+    int32_t n_ncc, n_bnb, n_clusters, n_ncc2, n_final; /* candidates surviving each stage */
+} ebvo_finalize_counts;
+
+int ebvo_stereo_finalize(ebvo_ctx *ctx, int slot, const ebvo_finalize_params *params, const ebvo_stereo_calib *calib,
+                         ebvo_finalize_counts *counts);
+/* n_final entries each: index of the left TOED edge, the matched right centre edge, its NCC score, and (if calib was
+ * given) the 16 numbers of the output row.  Any pointer may be NULL. */
+int ebvo_stereo_fetch_final(ebvo_ctx *ctx, int slot, int32_t *left_index, ebvo_edge *right_edge, double *ncc_score,
+                            double *out16);
+
 /* Utility::get_edge_patches for n edges on one image: patches = n x 2 x 49 floats
  * (src/utility.cpp:182-212; used again by finalize_stereo_edge_mates, src/Stereo_Matches.cpp:1622). */
 int ebvo_edge_patches(ebvo_ctx *ctx, const uint8_t *img, int h, int w, ptrdiff_t stride,
