@@ -197,89 +197,220 @@ __device__ inline void gaussian_average(const ebvo_edge *__restrict__ E, const i
     gt = wt / w;
 }
 
-__global__ void cluster_kernel(const ebvo_edge *__restrict__ cand, const int32_t *__restrict__ row_ptr, int nL,
-                               int by_orientation, int skip_single, int32_t *__restrict__ new_count,
-                               ebvo_edge *__restrict__ centres, int32_t *__restrict__ cluster_of)
+// Sixteen lanes per row.  The merging schedule itself is sequential (every point in turn, restart after a merge), but
+// the search for the nearest foreign point, the cluster sizes and the relabelling are loops over the row, and the
+// Gaussian averages are independent per cluster: lanes split the candidates (j = lane, lane + 16, ...) and the cluster
+// labels.  Every floating-point sum is still accumulated in index order by ONE lane, so the results equal the serial
+// form; with one thread per row the few rows with 20-40 candidates (O(n^3) work) set the kernel's duration.
+// Rows of more than 64 candidates take the serial path on lane 0 (labels as a 64-bit presence mask otherwise).
+__device__ inline void cluster_row_serial(const ebvo_edge *E, int32_t *lab, int n, int by_orientation, double orient_thr,
+                                          ebvo_edge *centres, int32_t *new_count)
 {
-    const double orient_thr = 20.0 * 0x1.921fb54442d18p+1 / 180.0; // deg_to_rad(CLUSTER_ORIENT_THRESH): 20 * M_PI / 180
-    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < nL; r += gridDim.x * blockDim.x)
+    bool merged = true;
+    while (merged)
     {
-        const int b = row_ptr[r], n = row_ptr[r + 1] - b;
-        const ebvo_edge *E = cand + b;
-        int32_t *lab = cluster_of + b;
-        new_count[r] = n;
-        for (int i = 0; i < n; ++i)
-            lab[i] = i;
-        if (n == 0)
-            continue;
-        if (n == 1 && skip_single)
+        merged = false;
+        for (int i = 0; i < n && !merged; ++i)
         {
-            centres[b] = E[0];
-            continue;
-        }
-        bool merged = true;
-        while (merged)
-        {
-            merged = false;
-            for (int i = 0; i < n && !merged; ++i)
-            {
-                double min_dist = 1.7976931348623157e308;
-                int nearest = -1;
-                for (int j = 0; j < n; ++j)
-                    if (lab[i] != lab[j])
-                    {
-                        const double dx = E[i].x - E[j].x, dy = E[i].y - E[j].y;
-                        const double dist = sqrt(dx * dx + dy * dy);
-                        if (dist < min_dist && dist < 1 && (!by_orientation || fabs(E[i].theta - E[j].theta) < orient_thr))
-                        {
-                            min_dist = dist;
-                            nearest = j;
-                        }
-                    }
-                if (nearest != -1)
+            double min_dist = 1.7976931348623157e308;
+            int nearest = -1;
+            for (int j = 0; j < n; ++j)
+                if (lab[i] != lab[j])
                 {
-                    const int old_label = lab[nearest], new_label = lab[i];
-                    int so = 0, sn = 0;
+                    const double dx = E[i].x - E[j].x, dy = E[i].y - E[j].y;
+                    const double dist = sqrt(dx * dx + dy * dy);
+                    if (dist < min_dist && dist < 1 && (!by_orientation || fabs(E[i].theta - E[j].theta) < orient_thr))
+                    {
+                        min_dist = dist;
+                        nearest = j;
+                    }
+                }
+            if (nearest != -1)
+            {
+                const int old_label = lab[nearest], new_label = lab[i];
+                int so = 0, sn = 0;
+                for (int k = 0; k < n; ++k)
+                {
+                    so += lab[k] == old_label;
+                    sn += lab[k] == new_label;
+                }
+                if (so + sn <= 10) // MAX_CLUSTER_SIZE
+                {
                     for (int k = 0; k < n; ++k)
-                    {
-                        so += lab[k] == old_label;
-                        sn += lab[k] == new_label;
-                    }
-                    if (so + sn <= 10) // MAX_CLUSTER_SIZE
-                    {
-                        for (int k = 0; k < n; ++k)
-                            if (lab[k] == old_label)
-                                lab[k] = new_label;
-                        merged = true;
-                    }
+                        if (lab[k] == old_label)
+                            lab[k] = new_label;
+                    merged = true;
                 }
             }
         }
-        int C = 0;
-        for (int l = 0; l < n; ++l)
-        {
-            bool present = false;
-            for (int i = 0; i < n && !present; ++i)
-                present = lab[i] == l;
-            if (!present)
-                continue;
-            double gx, gy, gt;
-            gaussian_average(E, lab, n, l, gx, gy, gt);
-            ebvo_edge c;
-            c.x = gx;
-            c.y = gy;
-            c.theta = gt;
-            c.index = 0;
-            c.pad = 0;
-            centres[b + C] = c;
-            for (int i = 0; i < n; ++i) // renumber in ascending label order; negative marks cannot collide with labels
-                if (lab[i] == l)
-                    lab[i] = -1 - C;
-            ++C;
-        }
+    }
+    int C = 0;
+    for (int l = 0; l < n; ++l)
+    {
+        bool present = false;
+        for (int i = 0; i < n && !present; ++i)
+            present = lab[i] == l;
+        if (!present)
+            continue;
+        double gx, gy, gt;
+        gaussian_average(E, lab, n, l, gx, gy, gt);
+        ebvo_edge c;
+        c.x = gx;
+        c.y = gy;
+        c.theta = gt;
+        c.index = 0;
+        c.pad = 0;
+        centres[C] = c;
         for (int i = 0; i < n; ++i)
-            lab[i] = -1 - lab[i];
-        new_count[r] = C;
+            if (lab[i] == l)
+                lab[i] = -1 - C;
+        ++C;
+    }
+    for (int i = 0; i < n; ++i)
+        lab[i] = -1 - lab[i];
+    *new_count = C;
+}
+
+__global__ __launch_bounds__(256) void cluster_kernel(const ebvo_edge *__restrict__ cand, const int32_t *__restrict__ row_ptr,
+                                                      int nL, int by_orientation, int skip_single,
+                                                      int32_t *__restrict__ new_count, ebvo_edge *__restrict__ centres,
+                                                      int32_t *__restrict__ cluster_of)
+{
+    // labels of the parallel path live in LDS (64 per group): lanes of a group read what other lanes wrote in the step
+    // before, which LDS orders within a wave
+    __shared__ int32_t s_lab[16][64];
+    const double orient_thr = 20.0 * 0x1.921fb54442d18p+1 / 180.0; // deg_to_rad(CLUSTER_ORIENT_THRESH): 20 * M_PI / 180
+    const int e = threadIdx.x & 15;                                 // lane in the 16-lane group
+    const int groups = (gridDim.x * blockDim.x) >> 4;
+    // every lane of a wave runs the same number of row iterations (shuffles below need the whole wave converged)
+    const int iters = (nL + groups - 1) / groups;
+    for (int it = 0; it < iters; ++it)
+    {
+        const int r = it * groups + ((blockIdx.x * blockDim.x + threadIdx.x) >> 4);
+        const bool row_ok = r < nL;
+        const int b = row_ok ? row_ptr[r] : 0, n = row_ok ? row_ptr[r + 1] - b : 0;
+        const ebvo_edge *E = cand + b;
+        int32_t *glab = cluster_of + b;
+        int32_t *lab = s_lab[threadIdx.x >> 4];
+        if (row_ok && e == 0)
+            new_count[r] = n;
+        const bool simple = n == 0 || (n == 1 && skip_single);
+        if (row_ok && simple && n == 1 && e == 0)
+        {
+            centres[b] = E[0];
+            glab[0] = 0;
+        }
+        const bool serial = !simple && n > 64;
+        if (serial && e == 0)
+        {
+            for (int i = 0; i < n; ++i)
+                glab[i] = i;
+            cluster_row_serial(E, glab, n, by_orientation, orient_thr, centres + b, &new_count[r]);
+        }
+        const bool par = !simple && !serial; // uniform within the group
+        if (par)
+            for (int i = e; i < n; i += 16)
+                lab[i] = i;
+        __builtin_amdgcn_wave_barrier();
+        // ---- merging: wave-uniform loop, each group on its own row
+        bool merged = par;
+        while (__any(merged))
+        {
+            const bool active = merged;
+            merged = false;
+            // the first i (ascending) whose nearest foreign point can be merged: groups scan i in lock step
+            int i = 0;
+            bool searching = active;
+            while (__any(searching))
+            {
+                double best = 1.7976931348623157e308;
+                int nearest = -1, li = 0;
+                if (searching)
+                {
+                    li = lab[i];
+                    const double xi = E[i].x, yi = E[i].y, ti = E[i].theta;
+                    for (int j = e; j < n; j += 16)
+                        if (lab[j] != li)
+                        {
+                            const double dx = xi - E[j].x, dy = yi - E[j].y;
+                            const double dist = sqrt(dx * dx + dy * dy);
+                            if (dist < best && dist < 1 && (!by_orientation || fabs(ti - E[j].theta) < orient_thr))
+                            {
+                                best = dist;
+                                nearest = j;
+                            }
+                        }
+                }
+                // minimum over the group; ties -> the lowest j, as the serial scan finds it
+#pragma unroll
+                for (int d = 8; d > 0; d >>= 1)
+                {
+                    const double ob = __shfl_xor(best, d);
+                    const int on = __shfl_xor(nearest, d);
+                    const bool take = on >= 0 && (nearest < 0 || ob < best || (ob == best && on < nearest));
+                    best = take ? ob : best;
+                    nearest = take ? on : nearest;
+                }
+                int so = 0, sn = 0, old_label = -1;
+                if (searching && nearest >= 0)
+                {
+                    old_label = lab[nearest];
+                    for (int k = e; k < n; k += 16)
+                    {
+                        so += lab[k] == old_label;
+                        sn += lab[k] == li;
+                    }
+                }
+#pragma unroll
+                for (int d = 8; d > 0; d >>= 1)
+                {
+                    so += __shfl_xor(so, d);
+                    sn += __shfl_xor(sn, d);
+                }
+                if (searching && nearest >= 0 && so + sn <= 10) // MAX_CLUSTER_SIZE
+                {
+                    for (int k = e; k < n; k += 16)
+                        if (lab[k] == old_label)
+                            lab[k] = li;
+                    merged = true;
+                    searching = false;
+                }
+                else if (searching)
+                {
+                    ++i;
+                    searching = i < n;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        // ---- one Gaussian-weighted average per cluster, clusters in ascending label order; labels renumbered
+        unsigned long long present = 0;
+        if (par)
+            for (int i = 0; i < n; ++i) // n <= 64, uniform in the group
+                present |= 1ull << lab[i];
+        if (par)
+        {
+            for (int l = e; l < n; l += 16)
+                if ((present >> l) & 1ull)
+                {
+                    double gx, gy, gt;
+                    gaussian_average(E, lab, n, l, gx, gy, gt);
+                    ebvo_edge c;
+                    c.x = gx;
+                    c.y = gy;
+                    c.theta = gt;
+                    c.index = 0;
+                    c.pad = 0;
+                    centres[b + __popcll(present & ((1ull << l) - 1ull))] = c;
+                }
+            if (e == 0)
+                new_count[r] = __popcll(present);
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (par) // renumbered labels 0 .. C-1 in ascending label order
+            for (int i = e; i < n; i += 16)
+                glab[i] = __popcll(present & ((1ull << lab[i]) - 1ull));
+        __builtin_amdgcn_wave_barrier(); // the LDS labels are reused by the next row of this group
     }
 }
 
@@ -405,7 +536,7 @@ int glue_cluster_enqueue(ebvo_ctx *ctx, Slot &s, const ebvo_edge *d_cand, const 
     if (nL <= 0)
         return EBVO_OK;
     ProfScope ps(ctx, s, K_MISC);
-    hipLaunchKernelGGL(cluster_kernel, dim3(grid_for(nL)), dim3(256), 0, s.stream, d_cand, d_row_ptr, nL, by_orientation,
+    hipLaunchKernelGGL(cluster_kernel, dim3(grid_for((int64_t)nL * 16)), dim3(256), 0, s.stream, d_cand, d_row_ptr, nL, by_orientation,
                        skip_single, d_new_count, d_centres, d_cluster_of);
     EBVO_HIP(ctx, hipGetLastError());
     return EBVO_OK;

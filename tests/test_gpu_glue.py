@@ -91,6 +91,7 @@ def test_cluster_rows_equals_oracle(ctx, by_orient, skip):
     rng = np.random.default_rng(16)
     lens = rng.integers(0, 40, 4000)
     lens[::9] = 1
+    lens[[5, 777, 3999]] = [64, 65, 130]                          # the 64-candidate limit of the 16-lane path and beyond
     rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
     cand = np.zeros(rp[-1], dtype=orc.EDGE_DTYPE)
     for i in range(len(lens)):
