@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define EBVO_ABI_VERSION 1
+#define EBVO_ABI_VERSION 2 /* 2: photometric refinement, stage glue, finalisation, resident chain */
 
 typedef struct ebvo_ctx ebvo_ctx;
 
