@@ -279,6 +279,66 @@ class StereoMatcherHIP
         return r;
     }
 
+    // ---- stage glue on flattened candidate lists (row_ptr + one entry per candidate) ------------------------------
+    struct Selection
+    {
+        std::vector<int32_t> new_count; // survivors per row
+        std::vector<int32_t> order;     // order[row_ptr[i] + k] = index of the k-th survivor of row i
+    };
+    // apply_Best_Nearly_Best_Test (:789-862): is_NCC -> scores = refine_final_scores, else refine_confidences
+    Selection bnb_test(const std::vector<int32_t> &row_ptr, const std::vector<double> &scores, double ratio, bool is_NCC)
+    {
+        Selection sel;
+        sel.new_count.assign(row_ptr.size() - 1, 0);
+        sel.order.assign(scores.size(), -1);
+        last_status = ebvo_bnb_test(ctx_->get(), row_ptr.data(), (int)row_ptr.size() - 1, scores.data(), ratio, is_NCC ? 1 : 0,
+                                    sel.new_count.data(), sel.order.data());
+        report(*ctx_, last_status, "ebvo_bnb_test");
+        return sel;
+    }
+    // apply_Lowe_Ratio_Test as written (:916-964): the best candidate of every row
+    Selection keep_best(const std::vector<int32_t> &row_ptr, const std::vector<double> &scores)
+    {
+        Selection sel;
+        sel.new_count.assign(row_ptr.size() - 1, 0);
+        sel.order.assign(scores.size(), -1);
+        last_status = ebvo_keep_best(ctx_->get(), row_ptr.data(), (int)row_ptr.size() - 1, scores.data(), sel.new_count.data(),
+                                     sel.order.data());
+        report(*ctx_, last_status, "ebvo_keep_best");
+        return sel;
+    }
+    // consolidate_redundant_edge_hypothesis, shift pass (:976-996): shift_Edge_to_Epipolar_Line of every candidate
+    std::vector<ebvo_edge> epipolar_shift(const std::vector<EdgeT> &candidates, const std::vector<std::array<double, 3>> &lines,
+                                          const std::vector<int32_t> &row_ptr)
+    {
+        std::vector<ebvo_edge> in(candidates.size()), out(candidates.size());
+        for (size_t k = 0; k < in.size(); ++k)
+            in[k] = to_abi(candidates[k]);
+        last_status = ebvo_epipolar_shift(ctx_->get(), in.data(), lines.empty() ? nullptr : lines[0].data(), row_ptr.data(),
+                                          (int)row_ptr.size() - 1, out.data());
+        report(*ctx_, last_status, "ebvo_epipolar_shift");
+        return out;
+    }
+    // consolidate_redundant_edge_hypothesis, clustering pass (:1006-1034): EdgeClusterer per row
+    struct Clusters
+    {
+        std::vector<int32_t> new_count, cluster_of; // clusters per row; cluster index of every input candidate
+        std::vector<ebvo_edge> centres;             // centres[row_ptr[i] + c], c < new_count[i]
+    };
+    Clusters cluster_rows(const std::vector<ebvo_edge> &candidates, const std::vector<int32_t> &row_ptr, bool by_orientation,
+                          bool skip_single)
+    {
+        Clusters c;
+        c.new_count.assign(row_ptr.size() - 1, 0);
+        c.cluster_of.assign(candidates.size(), -1);
+        c.centres.resize(candidates.size());
+        last_status = ebvo_cluster_rows(ctx_->get(), candidates.data(), row_ptr.data(), (int)row_ptr.size() - 1,
+                                        by_orientation ? 1 : 0, skip_single ? 1 : 0, c.new_count.data(), c.centres.data(),
+                                        c.cluster_of.data());
+        report(*ctx_, last_status, "ebvo_cluster_rows");
+        return c;
+    }
+
     // Temporal_Matches::min_Edge_Photometric_Residual_by_Gauss_Newton (src/Temporal_Matches.cpp:735-851) over n
     // (keyframe edge, current-frame edge, initial disparity) items of ONE camera, as apply_photometric_refinement_quads
     // issues them for the left and for the right image of every candidate quad (:605-610).

@@ -175,6 +175,122 @@ void Stereo_Matches::refine_edge_disparity(Stereo_Edge_Pairs &p, size_t, bool is
     }
 }
 
+// ---- stage glue: the containers are flattened to (row_ptr, per-candidate arrays), processed on the device, rebuilt ----
+namespace
+{
+struct Flat
+{
+    std::vector<int32_t> row_ptr;
+    std::vector<Edge> cand;
+    std::vector<double> scores, conf;
+};
+Flat flatten(const Stereo_Edge_Pairs &p)
+{
+    Flat f;
+    f.row_ptr.assign(p.matching_edge_clusters.size() + 1, 0);
+    for (size_t i = 0; i < p.matching_edge_clusters.size(); ++i)
+    {
+        const auto &mc = p.matching_edge_clusters[i];
+        for (size_t j = 0; j < mc.edge_clusters.size(); ++j)
+        {
+            f.cand.push_back(mc.edge_clusters[j].center_edge);
+            f.scores.push_back(j < mc.refine_final_scores.size() ? mc.refine_final_scores[j] : 0.0);
+            f.conf.push_back(j < mc.refine_confidences.size() ? mc.refine_confidences[j] : 0.0);
+        }
+        f.row_ptr[i + 1] = (int32_t)f.cand.size();
+    }
+    return f;
+}
+// keep, per row, the candidates order[row_ptr[i] + k], k < new_count[i], in that order
+template <class Sel> void apply_selection(Stereo_Edge_Pairs &p, const Flat &f, const Sel &sel)
+{
+    for (size_t i = 0; i < p.matching_edge_clusters.size(); ++i)
+    {
+        auto &mc = p.matching_edge_clusters[i];
+        const int32_t b = f.row_ptr[i];
+        if (sel.new_count[i] == f.row_ptr[i + 1] - b)
+            continue; // untouched row (:840)
+        std::vector<EdgeCluster> ec;
+        std::vector<double> sc, cf;
+        std::vector<bool> va;
+        for (int32_t k = 0; k < sel.new_count[i]; ++k)
+        {
+            const size_t j = (size_t)(sel.order[(size_t)b + k] - b);
+            ec.push_back(mc.edge_clusters[j]);
+            sc.push_back(mc.refine_final_scores[j]);
+            cf.push_back(mc.refine_confidences[j]);
+            va.push_back(mc.refine_validities[j]);
+        }
+        mc.edge_clusters = std::move(ec);
+        mc.refine_final_scores = std::move(sc);
+        mc.refine_confidences = std::move(cf);
+        mc.refine_validities = std::move(va);
+    }
+}
+} // namespace
+
+void Stereo_Matches::apply_Best_Nearly_Best_Test(Stereo_Edge_Pairs &p, double lowe_ratio_threshold, const std::string &, size_t,
+                                                 bool is_NCC)
+{
+    const Flat f = flatten(p);
+    auto m = matcher();
+    apply_selection(p, f, m.bnb_test(f.row_ptr, is_NCC ? f.scores : f.conf, lowe_ratio_threshold, is_NCC));
+}
+
+void Stereo_Matches::apply_Lowe_Ratio_Test(Stereo_Edge_Pairs &p, double, const std::string &, size_t)
+{
+    const Flat f = flatten(p);
+    auto m = matcher();
+    apply_selection(p, f, m.keep_best(f.row_ptr, f.scores));
+}
+
+void Stereo_Matches::consolidate_redundant_edge_hypothesis(Stereo_Edge_Pairs &p, size_t, bool b_do_epipolar_shift,
+                                                           bool b_do_clustering)
+{
+    Flat f = flatten(p);
+    auto m = matcher();
+    std::vector<ebvo_edge> cur(f.cand.size());
+    for (size_t k = 0; k < cur.size(); ++k)
+        cur[k] = ebvo::to_abi(f.cand[k]);
+    if (b_do_epipolar_shift)
+    {
+        std::vector<std::array<double, 3>> lines(p.epip_line_coeffs_of_left_edges.size());
+        for (size_t i = 0; i < lines.size(); ++i)
+            lines[i] = {p.epip_line_coeffs_of_left_edges[i](0), p.epip_line_coeffs_of_left_edges[i](1),
+                        p.epip_line_coeffs_of_left_edges[i](2)};
+        cur = m.epipolar_shift(f.cand, lines, f.row_ptr);
+        for (size_t i = 0; i + 1 < f.row_ptr.size(); ++i)
+        { // :989-995: fresh clusters that hold only the shifted centre
+            std::vector<EdgeCluster> shifted;
+            for (int32_t k = f.row_ptr[i]; k < f.row_ptr[i + 1]; ++k)
+            {
+                EdgeCluster c;
+                c.center_edge = Edge{cv::Point2d(cur[k].x, cur[k].y), cur[k].theta, false, 0};
+                shifted.push_back(c);
+            }
+            p.matching_edge_clusters[i].edge_clusters = std::move(shifted);
+        }
+    }
+    if (b_do_clustering)
+    {
+        auto cl = m.cluster_rows(cur, f.row_ptr, /*by_orientation=*/b_do_epipolar_shift, /*skip_single=*/!b_do_epipolar_shift);
+        for (size_t i = 0; i + 1 < f.row_ptr.size(); ++i)
+        {
+            const int32_t b = f.row_ptr[i], n = f.row_ptr[i + 1] - b;
+            if (n == 0 || (n == 1 && !b_do_epipolar_shift))
+                continue;
+            std::vector<EdgeCluster> out((size_t)cl.new_count[i]);
+            for (int32_t c = 0; c < cl.new_count[i]; ++c)
+                out[(size_t)c].center_edge = Edge{cv::Point2d(cl.centres[(size_t)b + c].x, cl.centres[(size_t)b + c].y),
+                                                  cl.centres[(size_t)b + c].theta, false, 0};
+            for (int32_t k = 0; k < n; ++k) // contributing_edges: the members, in input order (src/EdgeClusterer.cpp:283-295)
+                out[(size_t)cl.cluster_of[(size_t)b + k]].contributing_edges.push_back(
+                    Edge{cv::Point2d(cur[(size_t)b + k].x, cur[(size_t)b + k].y), cur[(size_t)b + k].theta, false, 0});
+            p.matching_edge_clusters[i].edge_clusters = std::move(out);
+        }
+    }
+}
+
 void Temporal_Matches::apply_NCC_filtering_quads(std::vector<KF_Temporal_Edge_Quads> &quads_by_kf,
                                                  const std::vector<final_stereo_edge_pair> &CF, double thr, const cv::Mat &,
                                                  const cv::Mat &, const cv::Mat &, const cv::Mat &)

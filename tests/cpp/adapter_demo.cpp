@@ -89,6 +89,13 @@ int main(int argc, char **argv)
     if (matcher.last_status != EBVO_OK)
         return 6;
 
+    // stage glue on the candidate lists: BNB on the NCC scores, epipolar shift, clustering, best per row
+    auto bnb = matcher.bnb_test(c.row_ptr, s.best, EBVO_BNB_NCC, true);
+    auto shifted = matcher.epipolar_shift(cand, lines, c.row_ptr);
+    auto clusters = matcher.cluster_rows(shifted, c.row_ptr, false, true);
+    auto bestsel = matcher.keep_best(c.row_ptr, s.best);
+    if (matcher.last_status != EBVO_OK)
+        return 8;
     // finalisation: every kept NCC match as a final pair -> the reference's output file
     std::vector<Edge> fl, fr;
     for (size_t i = 0; i + 1 < c.row_ptr.size(); ++i)
@@ -122,6 +129,12 @@ int main(int argc, char **argv)
     std::fwrite(refined.score.data(), sizeof(double), refined.score.size(), o);
     std::fwrite(refined.xy.data(), sizeof(double), refined.xy.size(), o);
     std::fwrite(refined.validity.data(), 1, refined.validity.size(), o);
+    std::fwrite(bnb.new_count.data(), sizeof(int32_t), bnb.new_count.size(), o);
+    std::fwrite(bnb.order.data(), sizeof(int32_t), bnb.order.size(), o);
+    std::fwrite(shifted.data(), sizeof(ebvo_edge), shifted.size(), o);
+    std::fwrite(clusters.new_count.data(), sizeof(int32_t), clusters.new_count.size(), o);
+    std::fwrite(clusters.cluster_of.data(), sizeof(int32_t), clusters.cluster_of.size(), o);
+    std::fwrite(bestsel.new_count.data(), sizeof(int32_t), bestsel.new_count.size(), o);
     std::fclose(o);
     std::printf("adapter_demo ok: %zu + %zu edges, %zu pairs\n", left_edges.size(), right_edges.size(), cand.size());
     return 0;

@@ -50,7 +50,13 @@ def test_adapter_matches_oracle(tmp_path):
     alpha = np.frombuffer(buf, dtype=np.float64, count=npairs, offset=off); off += 8 * npairs
     score = np.frombuffer(buf, dtype=np.float64, count=npairs, offset=off); off += 8 * npairs
     xy = np.frombuffer(buf, dtype=np.float64, count=2 * npairs, offset=off).reshape(-1, 2); off += 16 * npairs
-    valid = np.frombuffer(buf, dtype=np.uint8, count=npairs, offset=off)
+    valid = np.frombuffer(buf, dtype=np.uint8, count=npairs, offset=off); off += npairs
+    bnb_cnt = np.frombuffer(buf, dtype=np.int32, count=nL, offset=off); off += 4 * nL
+    bnb_order = np.frombuffer(buf, dtype=np.int32, count=npairs, offset=off); off += 4 * npairs
+    shifted = np.frombuffer(buf, dtype=orc.EDGE_DTYPE, count=npairs, offset=off); off += 32 * npairs
+    cl_cnt = np.frombuffer(buf, dtype=np.int32, count=nL, offset=off); off += 4 * nL
+    cl_of = np.frombuffer(buf, dtype=np.int32, count=npairs, offset=off); off += 4 * npairs
+    best_cnt = np.frombuffer(buf, dtype=np.int32, count=nL, offset=off)
     ol, orr = orc.toed(l), orc.toed(r)
     assert (tL, tR) == (ol["n_total"], orr["n_total"])
     assert_edges_equal(L, ol["edges"])
@@ -71,6 +77,15 @@ def test_adapter_matches_oracle(tmp_path):
     assert_bit_equal(score, ref["score"])
     assert_bit_equal(xy, ref["refined_xy"])
     assert_bit_equal(valid, ref["validity"])
+    # stage glue through the adapters
+    obest = orc.ncc_pairs(l, r, ol["edges"], orr["edges"][oci], orp)[1]
+    oc, oo = orc.bnb_test(orp, obest, 0.9, True)
+    assert_bit_equal(bnb_cnt, oc) and assert_bit_equal(bnb_order, oo)
+    osh = orc.epipolar_shift(orr["edges"][oci], lines, orp)
+    assert_edges_equal(shifted, osh)
+    occ, _, ocof = orc.cluster_rows(osh, orp, False, True)
+    assert_bit_equal(cl_cnt, occ) and assert_bit_equal(cl_of, ocof)
+    assert_bit_equal(best_cnt, (np.diff(orp) > 0).astype(np.int32))
     # the output file of the reference's writer: header + 16 numbers per kept match at 6 significant digits
     kept = okeep.astype(bool)
     rows = np.repeat(np.arange(len(ol["edges"])), np.diff(orp))[kept]
