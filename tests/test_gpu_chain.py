@@ -19,10 +19,10 @@ def _select(rp, cnt, order, *arrays):
     return new_rp, [a[idx] for a in arrays]
 
 
-def _host_chain(ctx, l, r, o, calib):
+def _host_chain(ctx, l, r, o, calib, F=F_KITTI):
     L, R = o["left"], o["right"]
     nL = len(L)
-    lines = ctx.epipolar_lines(F_KITTI, L)
+    lines = ctx.epipolar_lines(F, L)
     keep = o["keep"].astype(bool)
     rows = np.repeat(np.arange(nL), np.diff(o["row_ptr"]))[keep]
     rp = np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=nL))]).astype(np.int32)
@@ -87,3 +87,23 @@ def test_device_chain_equals_chained_entry_points(ctx, shape):
     counts2, fin2 = ctx.stereo_finalize(None)
     assert counts2 == counts and "rows" not in fin2
     assert_edges_equal(fin2["right"], right)
+
+
+def test_device_chain_slanted_epipolar_lines(ctx):
+    """EuRoC calibration (non-rectified): the shift, refinement and output rows run along slanted epipolar lines."""
+    F = synth.fundamental_for("euroc")
+    ce = synth.CALIB["euroc"]
+    Kl = [ce["K"][0], 0, ce["K"][2], 0, ce["K"][1], ce["K"][3], 0, 0, 1]
+    Kr = [ce["K_right"][0], 0, ce["K_right"][2], 0, ce["K_right"][1], ce["K_right"][3], 0, 0, 1]
+    calib = (Kl, Kr, ce["R21"], ce["T21"])
+    l, r = synth.stereo_pair("s2", 160, 240)
+    ctx.stereo_upload(l, r)
+    c = ctx.stereo_run(ctx.default_params(F))
+    counts, fin = ctx.stereo_finalize(calib)
+    o = ctx.stereo_fetch(c)
+    hc, left_index, right, score, rows16 = _host_chain(ctx, l, r, o, calib, F)
+    assert counts == hc and counts["n_final"] > 0
+    assert_bit_equal(fin["left_index"], left_index)
+    assert_edges_equal(fin["right"], right)
+    assert_bit_equal(fin["score"], score)
+    assert_bit_equal(fin["rows"], rows16)
