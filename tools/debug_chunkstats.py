@@ -1,4 +1,6 @@
 """How many 16-edge chunks of the right image meet one left edge's search region (sizing of the candidate walk)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from edge_based_visual_odometry_amd import synth
 from edge_based_visual_odometry_amd.api import Context

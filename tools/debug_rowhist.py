@@ -1,4 +1,6 @@
 """Histogram of candidates per left edge on the bench workload (sizing of the candidate staging area)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from edge_based_visual_odometry_amd import synth
 from edge_based_visual_odometry_amd.api import Context
