@@ -323,8 +323,13 @@ static int upload_image(ebvo_ctx *ctx, Slot &s, int k, const uint8_t *img, int h
 {
     if (stride < w)
         return EBVO_ERR_ARG;
-    EBVO_HIP(ctx, hipMemcpy2DAsync(s.im[k].img, (size_t)w, img, (size_t)stride, (size_t)w, (size_t)h,
-                                   hipMemcpyHostToDevice, s.stream));
+    // a tightly packed image is ONE linear copy: the 2-D copy of pageable memory is staged row by row (measured 3 ms
+    // per KITTI image against 0.1 ms)
+    if (stride == (ptrdiff_t)w)
+        EBVO_HIP(ctx, hipMemcpyAsync(s.im[k].img, img, (size_t)w * h, hipMemcpyHostToDevice, s.stream));
+    else
+        EBVO_HIP(ctx, hipMemcpy2DAsync(s.im[k].img, (size_t)w, img, (size_t)stride, (size_t)w, (size_t)h,
+                                       hipMemcpyHostToDevice, s.stream));
     return EBVO_OK;
 }
 
