@@ -609,7 +609,7 @@ extern "C" int ebvo_gn_refine_stereo(ebvo_ctx *ctx, const uint8_t *imgL, const u
     double *out = (double *)s.gn_out.p;
     if ((rc = refine_sobel_enqueue(ctx, s, s.im[1].img, h, w, w, nullptr, nullptr, s.grad_x.p)) ||
         (rc = match_expand_rows_enqueue(ctx, s, (const int32_t *)s.row_ptr.p, nL, np, (int32_t *)s.pair_left.p)) ||
-        (rc = refine_gn_stereo_enqueue(ctx, s, s.im[0].img, s.im[1].img, s.grad_x.p, h, w, (const ebvo_edge *)s.scratch_b.p,
+        (rc = refine_gn_stereo_enqueue(ctx, s, s.im[0].img, s.im[1].img, s.grad_x.p, h, w, (const ebvo_edge *)s.scratch_b.p, nL,
                                        (const double *)s.lines.p, (const int32_t *)s.pair_left.p,
                                        (const double *)s.gn_xy.p, nullptr, nullptr, nullptr, np, params->max_iter,
                                        params->tol, params->huber_delta,
@@ -1260,7 +1260,7 @@ extern "C" int ebvo_stereo_refine(ebvo_ctx *ctx, int slot, const ebvo_gn_params 
     double *out = (double *)s.gn_out.p;
     // the pipeline's own device arrays: left / right TOED edges, epipolar lines, CSR expansion, NCC keep flags
     if ((rc = refine_sobel_enqueue(ctx, s, s.im[1].img, h, w, w, nullptr, nullptr, s.grad_x.p)) ||
-        (rc = refine_gn_stereo_enqueue(ctx, s, s.im[0].img, s.im[1].img, s.grad_x.p, h, w, s.im[0].edges,
+        (rc = refine_gn_stereo_enqueue(ctx, s, s.im[0].img, s.im[1].img, s.grad_x.p, h, w, s.im[0].edges, s.result.n_left,
                                        (const double *)s.lines.p, (const int32_t *)s.pair_left.p, nullptr, s.im[1].edges,
                                        (const int32_t *)s.col_idx.p, (const uint8_t *)s.keep.p, np, params->max_iter,
                                        params->tol, params->huber_delta, out, out + npz, out + 2 * npz,
@@ -1381,7 +1381,7 @@ extern "C" int ebvo_stereo_finalize(ebvo_ctx *ctx, int slot, const ebvo_finalize
             (rc = glue_shift_enqueue(ctx, s, candB, (const double *)s.lines.p, left_of, nB, candC)) ||
             (rc = glue_xy_enqueue(ctx, s, candC, (double *)s.gn_xy.p, nB, false)) ||
             (rc = refine_sobel_enqueue(ctx, s, s.im[1].img, h, w, w, nullptr, nullptr, s.grad_x.p)) ||
-            (rc = refine_gn_stereo_enqueue(ctx, s, s.im[0].img, s.im[1].img, s.grad_x.p, h, w, s.im[0].edges,
+            (rc = refine_gn_stereo_enqueue(ctx, s, s.im[0].img, s.im[1].img, s.grad_x.p, h, w, s.im[0].edges, nL,
                                            (const double *)s.lines.p, left_of, (const double *)s.gn_xy.p, nullptr, nullptr,
                                            nullptr, nB, p->gn.max_iter, p->gn.tol, p->gn.huber_delta, out, out + nz,
                                            out + 2 * nz, (uint8_t *)s.gn_valid.p, (int32_t *)s.gn_iters.p, out + 3 * nz)) ||

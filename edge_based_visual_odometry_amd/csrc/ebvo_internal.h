@@ -239,7 +239,7 @@ int glue_final_pairs_enqueue(ebvo_ctx *ctx, Slot &s, const int32_t *d_rp_in, con
 int refine_sobel_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_img, int h, int w, int pitch, float *d_gx, float *d_gy,
                          void *d_gxy /* optional interleaved float2 plane */);
 int refine_gn_stereo_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_imgL, const uint8_t *d_imgR, const void *d_gxy,
-                             int h, int w, const ebvo_edge *d_L, const double *d_lines,
+                             int h, int w, const ebvo_edge *d_L, int nL, const double *d_lines,
                              const int32_t *d_pair_left, const double *d_cand_xy /* or NULL with R + col_idx */,
                              const ebvo_edge *d_R, const int32_t *d_col_idx, const uint8_t *d_keep /* optional */,
                              int64_t n_pairs, int max_iter, double tol, double huber, double *d_alpha, double *d_score,

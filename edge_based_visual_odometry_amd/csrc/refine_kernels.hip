@@ -129,8 +129,11 @@ struct GnArgs
     uint8_t *valid;
     int32_t *iters;
     // iteration state
-    double *mean_l;   // [2][n_pairs] means of the left plus / minus patches
-    double *sc;       // [2][n_pairs] sin, cos of the left orientation
+    int nL;
+    double *mean_l;   // [2][nL] means of the left plus / minus patches, per LEFT EDGE
+    float *left_rec;  // [nL][98] the left samples (the floats util_bilinear_Sample_F returns), sampled once per left edge:
+                      // the candidates of one left edge sit in neighbouring lanes and read the same record
+    double *sc;       // [2][nL] sin, cos of the left orientation
     int32_t *list[2]; // active pairs, ping-pong
     int32_t *counts;  // [max_iter + 1] active pairs entering iteration it
 };
@@ -166,9 +169,40 @@ __device__ inline void gn_candidate(const GnArgs &A, int64_t k, double &rx, doub
     }
 }
 
-__global__ __launch_bounds__(256) void gn_init_kernel(GnArgs A)
+// the left side of every pair depends on the left edge only: sin / cos, the 2 x 49 samples and their means, once per edge
+__global__ __launch_bounds__(256) void gn_left_kernel(GnArgs A)
 {
     const int h = A.h, w = A.w;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < A.nL; i += gridDim.x * blockDim.x)
+    {
+        const ebvo_edge le = A.L[i];
+        double st, ct;
+        ebvo_sincos(le.theta, &st, &ct);
+        const double nx = -st, ny = ct;      // n(-t.y, t.x), :1172
+        const double side = (7 / 2.0) + 1.0; // :1173
+#pragma unroll 1
+        for (int sd = 0; sd < 2; ++sd)
+        {
+            const double cx = sd ? le.x - nx * side : le.x + nx * side, cy = sd ? le.y - ny * side : le.y + ny * side;
+            double sum = 0;
+#pragma unroll 1
+            for (int a = -3; a <= 3; ++a)
+#pragma unroll
+                for (int b = -3; b <= 3; ++b)
+                {
+                    const float v = sample_u8(A.imgL, w, w, h, cx + ct * a - st * b, cy + st * a + ct * b);
+                    A.left_rec[(size_t)i * 98 + sd * 49 + (a + 3) * 7 + (b + 3)] = v;
+                    sum += (double)v;
+                }
+            A.mean_l[(size_t)sd * A.nL + i] = sum / 49; // :1183-1190
+        }
+        A.sc[i] = st;
+        A.sc[A.nL + i] = ct;
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_init_kernel(GnArgs A)
+{
     const int lane = threadIdx.x & 63;
     const int64_t span = (int64_t)gridDim.x * blockDim.x;
     for (int64_t k0 = (int64_t)blockIdx.x * blockDim.x; k0 < A.n_pairs; k0 += span)
@@ -198,27 +232,6 @@ __global__ __launch_bounds__(256) void gn_init_kernel(GnArgs A)
         }
         if (!active)
             continue;
-        ebvo_edge le;
-        double ex, ey, st, ct;
-        gn_geometry(A, k, le, ex, ey);
-        ebvo_sincos(le.theta, &st, &ct);
-        const double nx = -st, ny = ct;      // n(-t.y, t.x), :1172
-        const double side = (7 / 2.0) + 1.0; // :1173
-        // means of the two left patches (:1183-1190); the centred samples are re-derived where they are used
-#pragma unroll 1
-        for (int sd = 0; sd < 2; ++sd)
-        {
-            const double cx = sd ? le.x - nx * side : le.x + nx * side, cy = sd ? le.y - ny * side : le.y + ny * side;
-            double sum = 0;
-#pragma unroll 1
-            for (int i = -3; i <= 3; ++i)
-#pragma unroll
-                for (int j = -3; j <= 3; ++j)
-                    sum += (double)sample_u8(A.imgL, w, w, h, cx + ct * i - st * j, cy + st * i + ct * j);
-            A.mean_l[(size_t)sd * A.n_pairs + k] = sum / 49;
-        }
-        A.sc[k] = st;
-        A.sc[A.n_pairs + k] = ct;
         A.alpha[k] = 0.0;
         A.score[k] = __builtin_nan("");
         A.conf[k] = __builtin_nan("");
@@ -245,11 +258,12 @@ __global__ __launch_bounds__(256) void gn_iter_kernel(GnArgs A, int it)
             ebvo_edge le;
             double ex, ey;
             gn_geometry(A, k, le, ex, ey);
-            const double st = A.sc[k], ct = A.sc[A.n_pairs + k];
+            const int li = A.pair_left[k];
+            const double st = A.sc[li], ct = A.sc[A.nL + li];
             const double nx = -st, ny = ct, side = (7 / 2.0) + 1.0;
             double rx, ry;
             gn_candidate(A, k, rx, ry);
-            const double meanL[2] = {A.mean_l[k], A.mean_l[A.n_pairs + k]};
+            const double meanL[2] = {A.mean_l[li], A.mean_l[A.nL + li]};
             double alpha = A.alpha[k];
             const double shx = ex * alpha, shy = ey * alpha;
             double meanR[2];
@@ -270,7 +284,7 @@ __global__ __launch_bounds__(256) void gn_iter_kernel(GnArgs A, int it)
 #pragma unroll 1
             for (int sd = 0; sd < 2; ++sd)
             {
-                const double lcx = sd ? le.x - nx * side : le.x + nx * side, lcy = sd ? le.y - ny * side : le.y + ny * side;
+                const float *__restrict__ lrec = A.left_rec + (size_t)li * 98 + sd * 49;
                 const double cx = (sd ? rx - nx * side : rx + nx * side) + shx;
                 const double cy = (sd ? ry - ny * side : ry + ny * side) + shy;
 #pragma unroll 1
@@ -278,7 +292,7 @@ __global__ __launch_bounds__(256) void gn_iter_kernel(GnArgs A, int it)
 #pragma unroll 1
                     for (int j = -3; j <= 3; ++j)
                     {
-                        const double Lf = (double)sample_u8(A.imgL, w, w, h, lcx + ct * i - st * j, lcy + st * i + ct * j);
+                        const double Lf = (double)lrec[(i + 3) * 7 + (j + 3)]; // sampled once by gn_left_kernel
                         int x0, x1, y0, y1;
                         double wa, wb;
                         tap_at(cx + ct * i - st * j, cy + st * i + ct * j, w, h, x0, x1, y0, y1, wa, wb);
@@ -624,7 +638,7 @@ int refine_sobel_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_img, int h, in
 }
 
 int refine_gn_stereo_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_imgL, const uint8_t *d_imgR, const void *d_gxy,
-                             int h, int w, const ebvo_edge *d_L, const double *d_lines,
+                             int h, int w, const ebvo_edge *d_L, int nL, const double *d_lines,
                              const int32_t *d_pair_left, const double *d_cand_xy, const ebvo_edge *d_R,
                              const int32_t *d_col_idx, const uint8_t *d_keep, int64_t n_pairs, int max_iter,
                              double tol, double huber, double *d_alpha, double *d_score, double *d_conf,
@@ -638,10 +652,14 @@ int refine_gn_stereo_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_imgL, cons
         return EBVO_ERR_ARG;
     int rc;
     const size_t np = (size_t)n_pairs;
-    if ((rc = ebvo_grow(ctx, s, s.gn_state, sizeof(double) * 4 * np)) ||
+    const size_t nl = (size_t)nL;
+    if (nL <= 0)
+        return EBVO_ERR_ARG;
+    if ((rc = ebvo_grow(ctx, s, s.gn_state, sizeof(double) * 4 * nl + sizeof(float) * 98 * nl)) ||
         (rc = ebvo_grow(ctx, s, s.gn_lists, sizeof(int32_t) * (2 * np + (size_t)max_iter + 2))))
         return rc;
     GnArgs A{};
+    A.nL = nL;
     A.imgL = d_imgL;
     A.imgR = d_imgR;
     A.gxy = (const float2 *)d_gxy;
@@ -665,13 +683,16 @@ int refine_gn_stereo_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_imgL, cons
     A.valid = d_valid;
     A.iters = d_iters;
     A.mean_l = (double *)s.gn_state.p;
-    A.sc = A.mean_l + 2 * np;
+    A.sc = A.mean_l + 2 * nl;
+    A.left_rec = (float *)(A.sc + 2 * nl);
     A.list[0] = (int32_t *)s.gn_lists.p;
     A.list[1] = A.list[0] + np;
     A.counts = A.list[1] + np;
     ProfScope ps(ctx, s, K_GN_REFINE);
     EBVO_HIP(ctx, hipMemsetAsync(A.counts, 0, sizeof(int32_t) * ((size_t)max_iter + 2), s.stream));
     const unsigned blocks = (unsigned)((n_pairs + 255) / 256 < 4096 ? (n_pairs + 255) / 256 : 4096);
+    hipLaunchKernelGGL(gn_left_kernel, dim3((unsigned)((nL + 255) / 256 < 2048 ? (nL + 255) / 256 : 2048)), dim3(256), 0,
+                       s.stream, A);
     hipLaunchKernelGGL(gn_init_kernel, dim3(blocks), dim3(256), 0, s.stream, A);
     for (int it = 0; it < max_iter; ++it)
         hipLaunchKernelGGL(gn_iter_kernel, dim3(blocks), dim3(256), 0, s.stream, A, it);
