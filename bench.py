@@ -90,7 +90,20 @@ def cpu_baseline(left, right, F):
     orc.ncc_pairs(left, right, Ls, R[ci], rp, math_mode=orc.LIBM, nthreads=cores)
     t_ncc = (time.perf_counter() - t0) * stride
     total = t_toed + t_cand + t_ncc
+    # one thread, as SURVEY 8(d) also asks: TOED of one image timed, the matching scaled from a 1/128 sample of the left edges
+    t0 = time.perf_counter()
+    orc.toed(left, math_mode=orc.LIBM, nthreads=1)
+    t_toed1 = 2.0 * (time.perf_counter() - t0)
+    s1 = 128
+    L1 = L[::s1]
+    lines1 = orc.epipolar_lines(F, L1)
+    t0 = time.perf_counter()
+    rp1, ci1 = orc.epi_candidates(L1, R, lines1, nthreads=1)
+    orc.ncc_pairs(left, right, L1, R[ci1], rp1, math_mode=orc.LIBM, nthreads=1)
+    t_match1 = (time.perf_counter() - t0) * s1
     return {
+        "value_1_thread": 1.0 / (t_toed1 + t_match1),
+        "seconds_per_pair_1_thread": t_toed1 + t_match1,
         "value": 1.0 / total, "unit": "stereo pairs/s", "cores": cores, "kind": "port",
         "sample": (f"oracle/ (C + OpenMP restatement of the reference path, gcc -O2, no FMA, {cores} threads) on the same "
                    f"1241x376 S2 pair: TOED of both images {t_toed:.2f}s; candidate search (brute force as the reference) "
