@@ -97,3 +97,24 @@ def test_candidates_empty_and_degenerate(ctx):
     orp, oci = orc.epi_candidates(L, R, zero)
     assert_bit_equal(rp, orp)
     assert len(ci) == len(oci) == 0
+
+
+def test_candidates_rows_longer_than_the_staging_area(ctx):
+    """Rows with more than 64 candidates (the counting pass stages 64 per row; longer rows are redone by the fill pass),
+    mixed with short rows in the same 64-edge tiles, plus NaN and duplicated right edges."""
+    L, R = _edges_pair(ctx, 120, 200)
+    R = R.copy()
+    R["x"][5::97] = np.nan                                   # NaN fails every predicate
+    R = np.concatenate([R, R[100:140]])                      # exact duplicates (same location, later index)
+    R["index"] = np.arange(len(R))
+    lines = orc.epipolar_lines(F_KITTI, L)
+    for thr, disp, mask in ((3.0, 25.0, 1), (0.5, 60.0, 3), (0.5, 25.0, 7)):
+        rp, ci = orc.epi_candidates(L, R, lines, thr, disp, 10.0, stage_mask=mask)
+        grp, gci = ctx.epi_candidates(L, R, lines, thr, disp, 10.0, stage_mask=mask)
+        assert_bit_equal(grp, rp, "row_ptr")
+        assert_bit_equal(gci, ci, "col_idx")
+        n = np.diff(rp)
+        if mask == 1:
+            assert n.min() > 64                              # every row is refilled
+        if mask == 3:
+            assert n.max() > 64 and n.min() <= 64            # staged and refilled rows side by side
