@@ -1,15 +1,23 @@
 #!/usr/bin/env python3
 """bench.py -- stereo pairs/s of the edge-extraction-and-matching hot path on MI355X.
 
-A "step" is one pass of the whole hot path over one synthetic KITTI-shaped stereo pair that is
-already resident in HBM: TOED(left) + TOED(right) + epipolar/disparity/orientation candidate
-search + NCC scoring (ebvo_stereo_run).  One process per GPU, one sequence per GPU, no
-collective on the data path (torch.distributed is used only for the barrier and the max over
-ranks of the timed region).
+A "step" is one pass of the whole hot path over one synthetic stereo pair that is already resident in HBM:
+TOED(left) + TOED(right) + epipolar/disparity/orientation candidate search + NCC scoring (ebvo_stereo_submit /
+ebvo_stereo_wait).  One process per GPU, one sequence per GPU, no collective on the data path (torch.distributed is
+used only for the barrier and the max over ranks of the timed region).
 
-Prints ONE JSON line on rank 0 (see the contract in the task description): metric/value/unit,
-ms_per_step, `roofline` for the dominant kernel (toed_conv) measured live with HIP events on the
-library's own stream, and `cpu_baseline` (the CPU oracle timed on this box's host cores, N=1).
+Prints ONE JSON line on rank 0:
+  value / ms_per_step   EXACTLY --steps pairs between two barriers, nothing but submit / wait in the timed region;
+  kernels               per-kernel device time, HIP events on the library's own stream, measured AFTER the timed region
+                        on pairs run one at a time (what a rocprofv3 trace of `--streams 1` reproduces, profiles/);
+  roofline(_fp64)       the dominant kernel of that pass against HBM (the metric asks for it) and against the FP64
+                        vector peak (the bound that applies to this path);
+  verified              the last pair of the timed region fetched and checked: the reference's known-answer hashes of
+                        (x, y, index) of both edge lists and the pair / match counts of the workload; with the CPU
+                        baseline also every edge, the sampled CSR rows and their NCC scores against the oracle's;
+  with_h2d / with_h2d_d2h   the same loop with a NEW pair uploaded from host memory per step, and with the results
+                        fetched back as well (PCIe-inclusive; never `value`);
+  cpu_baseline          the CPU oracle (a port of the reference path) timed on this box's host cores, N = 1 only.
 """
 from __future__ import annotations
 
@@ -28,34 +36,50 @@ if ROOT not in sys.path:
 from edge_based_visual_odometry_amd import sharding, synth  # noqa: E402
 from edge_based_visual_odometry_amd.api import Context  # noqa: E402
 
-H, W = synth.SHAPES["kitti"]
 TOED_FLOPS_PER_PX = 37044            # 1,372 taps x 9 responses x 3 flops, as written in the reference
 HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: HBM3E spec
 FP64_VALU_PEAK_NOFMA_TF = 39.3       # 78.6 TFLOP/s vendor FP64 vector peak (FMA) / 2: mul and add are separate ops
 
+WORKLOADS = {
+    # BASELINE.json configs[1] (the headline), configs[2] shape / calibration, configs[3] shape / calibration
+    "kitti": dict(cfg="kitti", disparity=12,
+                  label="configs[1]: single KITTI-shaped stereo pair 1241x376 (generator S2, scene 7+rank, 12 px "
+                        "disparity), TOED both images (fp64, no FMA, bit-exact) + epipolar/disparity/orientation "
+                        "candidate search + NCC, resident in HBM, replayed"),
+    "euroc": dict(cfg="euroc", disparity=9,
+                  label="configs[2] shape: EuRoC 752x480 stereo pair, non-rectified calibration (slanted epipolar lines), "
+                        "same hot path"),
+    "eth3d": dict(cfg="eth3d", disparity=9,
+                  label="configs[3]: ETH3D delivery_area 942x489 stereo pair, same hot path (the rocprofv3 roofline run)"),
+}
+# known answers of the headline pair (S2 1241x376 scene 7, noise 1 / 2, shift 0 / 12)
+KITTI_KAT = dict(xyi_left="85fcd7aa12a47c8b", xyi_right="2b8a4c7b2e5454ca", n_left=126184, n_right=126340,
+                 n_pairs=581657, n_matches=472947)
 
-def algorithmic_bytes_per_pair(n_left, n_right, n_pairs):
-    """SURVEY.md 8(d) 'Algorithmic bytes': 2P (u8 images in) + 32(NL+NR) edges out + 32(NL+NR)
-    edges into matching + 8 Npairs (CSR) + 40 Npairs (4 sims + best)."""
-    return 2 * H * W + 64 * (n_left + n_right) + 48 * n_pairs
+
+def algorithmic_bytes_per_pair(h, w, n_left, n_right, n_pairs):
+    """SURVEY.md 8(d) 'Algorithmic bytes': 2P (u8 images in) + 32(NL+NR) edges out + 32(NL+NR) edges into matching
+    + 8 Npairs (CSR) + 40 Npairs (4 sims + best)."""
+    return 2 * h * w + 64 * (n_left + n_right) + 48 * n_pairs
 
 
-# kernel id reported by the library's event profiler -> (HIP kernel symbol, launches) bracketed by one event pair
+# kernel id reported by the library's event profiler -> HIP kernel symbols bracketed by one event pair
 KERNEL_SYMBOLS = {
-    "toed_conv": {"strict": [("toed_conv_kernel", 1)]},
-    "toed_nms": {"strict": [("toed_nms_kernel", 1)], "hybrid": [("toed_screen_fused_kernel", 1)]},
-    "toed_exact_centre": {"hybrid": [("toed_exact_centre_kernel", 1)]},
-    "toed_exact_mags": {"hybrid": [("toed_exact_mags_kernel", 1), ("toed_exact_decide_kernel", 1)]},
-    "cand_count": {"*": [("candidates_kernel<false>", 1)]},
-    "cand_fill": {"*": [("candidates_copy_kernel", 1), ("candidates_kernel<true>", 1)]},
-    "edge_patches": {"*": [("sincos_batch_kernel", 1), ("patches_kernel", 1)]},
-    "ncc_pairs": {"*": [("ncc_banked_kernel", 1)]},
+    "toed_conv": {"strict": ["toed_conv_kernel"]},
+    "toed_nms": {"strict": ["toed_nms_kernel"], "hybrid": ["toed_screen_fused_kernel"]},
+    "toed_exact_centre": {"hybrid": ["toed_exact_centre_kernel"]},
+    "toed_exact_mags": {"hybrid": ["toed_exact_mags_kernel", "toed_exact_decide_kernel"]},
+    "cand_count": {"*": ["candidates_kernel<false>"]},
+    "cand_fill": {"*": ["candidates_copy_kernel", "candidates_kernel<true>"]},
+    "edge_patches": {"*": ["sincos_batch_kernel", "right_bank_kernel"]},
+    "ncc_pairs": {"*": ["ncc_tile_kernel"]},
 }
 
 
 def pmc_traffic(kernel_id, toed_mode):
-    """HBM bytes per launch of the dominant kernel id from the committed rocprofv3 PMC passes (FETCH_SIZE x 2 +
-    WRITE_SIZE, profiles/kernel_pmc_<mode>.json, written by tools/rocprof_summary.py); None if not collected."""
+    """HBM bytes per launch of a kernel id from the COMMITTED rocprofv3 PMC passes (FETCH_SIZE x 2 + WRITE_SIZE,
+    profiles/kernel_pmc_<mode>.json, written by tools/rocprof_summary.py) -- not measured in this run; None if that
+    profile does not hold the kernel."""
     path = os.path.join(ROOT, "profiles", f"kernel_pmc_{toed_mode}.json")
     syms = KERNEL_SYMBOLS.get(kernel_id, {})
     syms = syms.get(toed_mode) or syms.get("*")
@@ -63,15 +87,29 @@ def pmc_traffic(kernel_id, toed_mode):
         return None
     table = json.load(open(path)).get("kernels", {})
     total = 0.0
-    for sym, n in syms:
-        if sym not in table:
+    for sym in syms:
+        hit = [v for k, v in table.items() if k == sym or k.startswith(sym + "<")]
+        if not hit:
             return None
-        total += n * table[sym]["hbm_bytes_per_launch"]
+        total += hit[0]["hbm_bytes_per_launch"]
     return total
 
 
+def xyi_hash(edges) -> str:
+    """FNV-1a-64 over the 16 raw bytes of (x, y) of every edge, then h ^= index; h *= prime (SURVEY.md 8(c) "xyi")."""
+    h, prime, mask = 1469598103934665603, 1099511628211, (1 << 64) - 1
+    xy = np.stack([edges["x"], edges["y"]], 1).astype("<f8").tobytes()
+    idx = edges["index"].tolist()
+    for k in range(len(idx)):
+        for b in xy[16 * k:16 * k + 16]:
+            h = ((h ^ b) * prime) & mask
+        h = ((h ^ (idx[k] & mask)) * prime) & mask
+    return f"{h:016x}"
+
+
 def cpu_baseline(left, right, F):
-    """The CPU oracle (a port of the reference's path) on this box's host cores; bounded sample (~10-30 s)."""
+    """The CPU oracle (a port of the reference's path) on this box's host cores; bounded sample (~10-30 s).  Returns the
+    timing record and what it computed (edges, the sampled rows) so that the GPU's results can be checked against it."""
     from tests import oracle as orc
     # a one-GPU box's CPU share is 16 cores; EBVO_CPU_THREADS overrides
     cores = int(os.environ.get("EBVO_CPU_THREADS", min(16, len(os.sched_getaffinity(0)))))
@@ -101,16 +139,72 @@ def cpu_baseline(left, right, F):
     rp1, ci1 = orc.epi_candidates(L1, R, lines1, nthreads=1)
     orc.ncc_pairs(left, right, L1, R[ci1], rp1, math_mode=orc.LIBM, nthreads=1)
     t_match1 = (time.perf_counter() - t0) * s1
-    return {
+    # checker leg (not timed): the scores of the sampled rows in the arithmetic the GPU path uses (shared sin / cos)
+    Lp, Rp = orc.toed(left, nthreads=cores)["edges"], orc.toed(right, nthreads=cores)["edges"]
+    rp, ci = orc.epi_candidates(Lp[::stride], Rp, orc.epipolar_lines(F, Lp[::stride]), nthreads=cores)
+    sims, _, keep, _ = orc.ncc_pairs(left, right, Lp[::stride], Rp[ci], rp, nthreads=cores)
+    record = {
         "value_1_thread": 1.0 / (t_toed1 + t_match1),
         "seconds_per_pair_1_thread": t_toed1 + t_match1,
         "value": 1.0 / total, "unit": "stereo pairs/s", "cores": cores, "kind": "port",
         "sample": (f"oracle/ (C + OpenMP restatement of the reference path, gcc -O2, no FMA, {cores} threads) on the same "
-                   f"1241x376 S2 pair: TOED of both images {t_toed:.2f}s; candidate search (brute force as the reference) "
+                   f"S2 pair: TOED of both images {t_toed:.2f}s; candidate search (brute force as the reference) "
                    f"+ NCC on every {stride}th left edge, scaled x{stride}: {t_cand:.2f}s + {t_ncc:.2f}s (the reference "
                    f"runs its NCC and disparity loops serially; the port runs them on all {cores} threads)"),
         "seconds_per_pair": total,
     }
+    return record, dict(left=Lp, right=Rp, stride=stride, row_ptr=rp, col_idx=ci, sims=sims, keep=keep)
+
+
+def check_against_oracle(out, chk):
+    """Every edge of both images bit for bit, and the CSR rows / NCC scores of every `stride`-th left edge."""
+    def same(a, b):
+        return a.shape == b.shape and bool(((a.view(np.uint64) == b.view(np.uint64)) | (np.isnan(a) & np.isnan(b))).all())
+    for side in ("left", "right"):
+        for f in ("x", "y", "theta"):
+            if not same(out[side][f].copy(), chk[side][f].copy()):
+                return f"{side}.{f} differs from the oracle"
+        if not (out[side]["index"] == chk[side]["index"]).all():
+            return f"{side}.index differs from the oracle"
+    rp = out["row_ptr"].astype(np.int64)
+    rows = np.arange(0, len(out["left"]), chk["stride"])
+    beg, end = rp[rows], rp[rows + 1]
+    if not np.array_equal(np.concatenate([[0], np.cumsum(end - beg)]), chk["row_ptr"].astype(np.int64)):
+        return "candidate counts of the sampled rows differ from the oracle"
+    idx = np.concatenate([np.arange(b, e) for b, e in zip(beg, end)]) if len(rows) else np.zeros(0, np.int64)
+    if not np.array_equal(out["col_idx"][idx], chk["col_idx"]):
+        return "candidate indices of the sampled rows differ from the oracle"
+    if not same(np.ascontiguousarray(out["sims"][idx]), np.ascontiguousarray(chk["sims"])):
+        return "NCC scores of the sampled rows differ from the oracle"
+    if not np.array_equal(out["keep"][idx], chk["keep"]):
+        return "NCC keep flags of the sampled rows differ from the oracle"
+    return None
+
+
+def frame_loop(ctx, params, pool, nslots, steps, upload, fetch):
+    """`steps` pairs with `nslots` in flight; upload: a NEW pair from host memory per step; fetch: every result array
+    copied back.  Returns (seconds, bytes fetched per pair)."""
+    t0 = time.perf_counter()
+    sub = done = 0
+    nbytes = 0
+    while sub < min(nslots, steps):
+        if upload:
+            ctx.stereo_upload(*pool[sub % len(pool)], slot=sub % nslots)
+        ctx.stereo_submit(params, slot=sub % nslots)
+        sub += 1
+    while done < steps:
+        k = done % nslots
+        cnt = ctx.stereo_wait(slot=k)
+        done += 1
+        if fetch:
+            out = ctx.stereo_fetch(cnt, slot=k)
+            nbytes += sum(v.nbytes for v in out.values() if v is not None)
+        if sub < steps:
+            if upload:
+                ctx.stereo_upload(*pool[sub % len(pool)], slot=k)
+            ctx.stereo_submit(params, slot=k)
+            sub += 1
+    return time.perf_counter() - t0, nbytes / max(1, steps)
 
 
 def main():
@@ -118,12 +212,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="kitti", choices=sorted(WORKLOADS),
+                    help="kitti = the headline (BASELINE.json configs[1]); euroc / eth3d = the other reference shapes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true", help="skip the result check after the timed region (profiling runs)")
+    ap.add_argument("--no-transfer-legs", action="store_true", help="skip the with_h2d / with_h2d_d2h loops")
     ap.add_argument("--toed-mode", default="hybrid", choices=["strict", "hybrid"],
                     help="strict: direct-form convolution at every pixel; hybrid: separable screen + exact "
                          "re-evaluation of the candidates (bit-identical edges, ~3x less work)")
-    ap.add_argument("--profile-every", type=int, default=4,
-                    help="bracket the kernels of every N-th pair of the timed region with HIP events")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for the barrier / max (nccl = RCCL)")
     ap.add_argument("--streams", type=int, default=3, help="stereo pairs kept in flight per GPU (slots / HIP streams)")
     args = ap.parse_args()
@@ -143,10 +239,12 @@ def main():
             dist.init_process_group(args.dist_backend)
     reduce_device = f"cuda:{device}" if args.dist_backend == "nccl" else "cpu"
 
+    wl = WORKLOADS[args.workload]
+    H, W = synth.SHAPES[wl["cfg"]]
     # one sequence per GPU: its own scene and noise seeds
-    left, right = synth.stereo_pair("s2", H, W, **sharding.rank_workload(rank))
-    cal = synth.CALIB["kitti"]
-    F = synth.fundamental_21(cal["K"], cal["K"], cal["R21"], cal["T21"])
+    seq = dict(sharding.rank_workload(rank), disparity=wl["disparity"])
+    left, right = synth.stereo_pair("s2", H, W, **seq)
+    F = synth.fundamental_for(wl["cfg"])
 
     # one context per GPU; --streams S keeps S pairs in flight from this one host thread (S slots, one HIP stream
     # each): submit enqueues a whole pair without host synchronisation, wait blocks on that pair only
@@ -166,56 +264,80 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    ctx.profile_reset()
-    ctx.profile_enable(True, every=args.profile_every)   # HIP events around the kernels of every N-th pair
+    def tup(c):
+        return (c.n_left, c.n_right, c.n_total_left, c.n_total_right, c.n_pairs, c.n_matches)
+
+    # ---- the timed region: submit / wait only ----------------------------------------------------------------
+    ctx.profile_enable(False)
+    seen = set()
     barrier()
     t0 = time.perf_counter()
     submitted = completed = 0
     while submitted < min(nslots, args.steps):
         ctx.stereo_submit(params, slot=submitted % nslots)
         submitted += 1
+    last_slot = 0
     while completed < args.steps:                 # EXACTLY args.steps pairs
         k = completed % nslots
         counts = ctx.stereo_wait(slot=k)
+        seen.add(tup(counts))
+        last_slot = k
         completed += 1
         if submitted < args.steps:
             ctx.stereo_submit(params, slot=k)
             submitted += 1
     barrier()
     dt = time.perf_counter() - t0
-    ctx.profile_enable(False)
-    prof = ctx.profile_get()
+    dt = sharding.max_over_ranks(dt, dist, reduce_device)
 
-    # Outside the timed region: a few pairs one at a time with events on every pair.  In the timed region several pairs
-    # overlap on the GPU, so an event-bracketed "launch duration" there includes time shared with other pairs' kernels;
-    # the one-at-a-time durations are the ones a rocprofv3 trace of `--streams 1` reproduces (profiles/).
-    serial = None
-    if rank == 0 and nslots > 1:
+    # ---- what the timed region produced (every rank checks its own sequence) ---------------------------------
+    problems = []
+    out = None
+    if not args.no_verify:
+        if len(seen) != 1:
+            problems.append(f"counts changed between steps of the timed region: {sorted(seen)}")
+        out = ctx.stereo_fetch(counts, slot=last_slot)
+        if int(out["keep"].sum()) != counts.n_matches or len(out["col_idx"]) != counts.n_pairs:
+            problems.append("fetched arrays disagree with the counts of the run")
+        if args.workload == "kitti" and rank == 0:
+            got = dict(xyi_left=xyi_hash(out["left"]), xyi_right=xyi_hash(out["right"]), n_left=counts.n_left,
+                       n_right=counts.n_right, n_pairs=counts.n_pairs, n_matches=counts.n_matches)
+            for key, want in KITTI_KAT.items():
+                if got[key] != want:
+                    problems.append(f"{key}: {got[key]} != known answer {want}")
+
+    # ---- per-kernel device time, pairs one at a time, HIP events around every kernel (outside the timed region) -
+    prof = None
+    if rank == 0:
         ctx.profile_reset()
         ctx.profile_enable(True, every=1)
-        for _ in range(min(8, args.steps)):
+        for _ in range(min(8, max(1, args.steps))):
             ctx.stereo_submit(params, slot=0)
             ctx.stereo_wait(slot=0)
         ctx.profile_enable(False)
-        serial = ctx.profile_get()
+        prof = ctx.profile_get()
 
-    dt = sharding.max_over_ranks(dt, dist, reduce_device)
+    # ---- PCIe-inclusive loops (never `value`) -------------------------------------------------------------------
+    legs = None
+    if rank == 0 and world == 1 and not args.no_transfer_legs:
+        pool = [synth.stereo_pair("s2", H, W, scene=seq["scene"], noise_base=seq["noise_base"] + 10 * k,
+                                  disparity=seq["disparity"]) for k in range(4)]
+        n_leg = max(nslots, min(args.steps, 60))
+        frame_loop(ctx, params, pool, nslots, nslots, True, False)            # touch the pool once
+        t_up, _ = frame_loop(ctx, params, pool, nslots, n_leg, True, False)
+        t_all, mb = frame_loop(ctx, params, pool, nslots, n_leg, True, True)
+        legs = {"with_h2d": n_leg / t_up, "with_h2d_d2h": n_leg / t_all, "d2h_bytes_per_pair": mb, "pairs": n_leg,
+                "note": "a new pair uploaded from pageable host memory per step (0.93 MB); d2h = both edge lists, CSR, "
+                        "four scores + best + keep per candidate pair, into numpy arrays"}
+        for k in range(nslots):                                               # restore the resident workload
+            ctx.stereo_upload(left, right, slot=k)
 
     if rank == 0:
-        sampled = max(1, prof["epi_lines"][1])            # pairs of the timed region whose kernels were bracketed
-        kernels = {k: {"ms_per_step": v[0] / sampled, "launches_per_step": v[1] / sampled}
-                   for k, v in prof.items() if v[1]}
-        # dominant kernel = largest device time per pair.  Ranked on the one-at-a-time durations when several pairs are
-        # in flight (overlapped intervals include the other pairs' kernels and reshuffle the ranking from run to run);
-        # its duration in the timed region is still what `roofline` is computed from.
-        if serial is not None:
-            n_ser = max(1, serial["epi_lines"][1])
-            dom = max((k for k in kernels if serial.get(k, (0, 0))[1]), key=lambda k: serial[k][0] / n_ser)
-        else:
-            dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
-        dom_ms, dom_n = prof[dom]
-        dom_avg_s = dom_ms * 1e-3 / max(1, dom_n)
-        alg_bytes = algorithmic_bytes_per_pair(counts.n_left, counts.n_right, counts.n_pairs)
+        n_ser = max(1, prof["epi_lines"][1])
+        kernels = {k: {"ms_per_step": v[0] / n_ser, "launches_per_step": v[1] / n_ser} for k, v in prof.items() if v[1]}
+        dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
+        dom_avg_s = prof[dom][0] * 1e-3 / max(1, prof[dom][1])
+        alg_bytes = algorithmic_bytes_per_pair(H, W, counts.n_left, counts.n_right, counts.n_pairs)
         achieved_gbs = alg_bytes / dom_avg_s / 1e9
         stats = ctx.toed_stats(0)
         n_cand = stats["left"]["n_candidates"] + stats["right"]["n_candidates"]
@@ -242,8 +364,7 @@ def main():
             fp64_peak, fp64_bound = 2 * FP64_VALU_PEAK_NOFMA_TF, "valu_fp64_fma"
         else:
             ops, executed, ops_note = None, None, "not an fp64-ALU kernel"
-        traffic = pmc_traffic(dom, args.toed_mode)
-        out = {
+        result = {
             "metric": "stereo pairs/sec (TOED+NCC match) on KITTI 1241x376; achieved HBM GB/s",
             "value": sharding.job_throughput(world, args.steps, dt),
             "unit": "stereo pairs/s",
@@ -251,46 +372,57 @@ def main():
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "configs[1]: single KITTI-shaped stereo pair 1241x376 (generator S2, scene 7+rank, "
-                                   "12 px disparity), TOED both images (fp64, no FMA, bit-exact) + epipolar/"
-                                   "disparity/orientation candidate search + NCC, resident in HBM, replayed",
+            "config": {"workload": wl["label"], "shape": f"{W}x{H}",
                        "toed_mode": args.toed_mode,
                        "edges_left": counts.n_left, "edges_right": counts.n_right,
                        "toed_candidates": n_cand if args.toed_mode == "hybrid" else None,
                        "candidate_pairs": counts.n_pairs, "ncc_matches": counts.n_matches,
-                       "pairs_in_flight_per_gpu": nslots, "pairs_with_kernel_events": sampled,
+                       "pairs_in_flight_per_gpu": nslots,
                        "parallelism": f"{world} independent sequence(s), one per GPU, no collective"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved_gbs, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                         "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, args.toed_mode),
+                         "traffic_source": f"profiles/kernel_pmc_{args.toed_mode}.json (committed rocprofv3 PMC passes, "
+                                           "FETCH_SIZE x 2 + WRITE_SIZE per launch; not measured in this run)",
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": dom_avg_s * 1e3,
-                         "note": "this path is FP64-VALU-bound, not HBM-bound (SURVEY.md 8(d)); see roofline_fp64. "
-                                 "avg_launch_ms is measured with pairs overlapping on the GPU when pairs_in_flight > 1"},
+                         "note": "achieved = the whole pair's algorithmic bytes (SURVEY.md 8(d)) / the dominant kernel's "
+                                 "launch duration: the contract's formula, not a bandwidth this kernel moves.  The path is "
+                                 "FP64-VALU-bound, not HBM-bound; see roofline_fp64.  Durations: HIP events, pairs one at a "
+                                 "time, after the timed region."},
             "kernels": kernels,
         }
-        if serial is not None and serial[dom][1]:
-            one = serial[dom][0] * 1e-3 / serial[dom][1]
-            out["roofline"]["avg_launch_ms_one_in_flight"] = one * 1e3
-            out["roofline"]["achieved_one_in_flight"] = alg_bytes / one / 1e9
-            out["kernels_one_in_flight"] = {k: {"ms_per_step": v[0] / max(1, serial["epi_lines"][1])}
-                                            for k, v in serial.items() if v[1]}
+        if args.workload != "kitti":
+            result["metric"] = f"stereo pairs/sec (TOED+NCC match) on {wl['cfg']} {W}x{H}; achieved HBM GB/s"
         if ops is not None:
             tf = ops / dom_avg_s / 1e12
-            out["roofline_fp64"] = {"bound": fp64_bound, "kernel": dom, "achieved": tf,
-                                    "peak": fp64_peak, "unit": "TFLOP/s", "frac": tf / fp64_peak,
-                                    "ops_per_launch": ops, "executed_ops_per_launch": executed,
-                                    "executed_frac": executed / dom_avg_s / 1e12 / fp64_peak,
-                                    "note": ops_note + "; peak = 78.6 TFLOP/s vendor FP64 vector (FMA), halved where mul "
-                                                       "and add must stay separate operations"}
-            if serial is not None and serial[dom][1]:
-                one = serial[dom][0] * 1e-3 / serial[dom][1]
-                out["roofline_fp64"]["frac_one_in_flight"] = ops / one / 1e12 / fp64_peak
+            result["roofline_fp64"] = {"bound": fp64_bound, "kernel": dom, "achieved": tf,
+                                       "peak": fp64_peak, "unit": "TFLOP/s", "frac": tf / fp64_peak,
+                                       "ops_per_launch": ops, "executed_ops_per_launch": executed,
+                                       "executed_frac": executed / dom_avg_s / 1e12 / fp64_peak,
+                                       "note": ops_note + "; peak = 78.6 TFLOP/s vendor FP64 vector (FMA), halved where mul "
+                                                          "and add must stay separate operations"}
+        if legs is not None:
+            result.update(legs)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(left, right, F)
-            out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
-        print(json.dumps(out))
+            rec, chk = cpu_baseline(left, right, F)
+            result["cpu_baseline"] = rec
+            result["gpu_over_cpu"] = result["value"] / rec["value"]
+            if out is not None:
+                bad = check_against_oracle(out, chk)
+                if bad:
+                    problems.append(bad)
+                result["verified_against_cpu_baseline"] = bad is None
+        if not args.no_verify:
+            result["verified"] = not problems
+            if problems:
+                result["verification_failures"] = problems
+        print(json.dumps(result))
+    elif problems:
+        print(f"[rank {rank}] verification failed: {problems}", file=sys.stderr)
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()
+    if problems:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

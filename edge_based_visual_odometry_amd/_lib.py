@@ -42,6 +42,7 @@ ABI_SYMBOLS = (
     "ebvo_profile_reset", "ebvo_profile_get", "ebvo_fp64_peak",
     "ebvo_gn_default_params", "ebvo_sobel_gradients", "ebvo_gn_refine_stereo", "ebvo_stereo_refine",
     "ebvo_stereo_fetch_refined", "ebvo_gn_refine_temporal", "ebvo_finalize_pairs", "ebvo_bnb_test", "ebvo_keep_best", "ebvo_epipolar_shift", "ebvo_cluster_rows", "ebvo_stereo_finalize", "ebvo_stereo_fetch_final",
+    "ebvo_debug_set",
 )
 
 
@@ -134,6 +135,7 @@ def load_library() -> C.CDLL:
     lib.ebvo_profile_reset.argtypes = [vp]
     lib.ebvo_profile_get.argtypes = [vp, C.POINTER(KernelTime), C.POINTER(i32)]
     lib.ebvo_fp64_peak.argtypes = [vp, i32, C.POINTER(dbl), C.POINTER(dbl)]
+    lib.ebvo_debug_set.argtypes = [vp, i32, i32]
     lib.ebvo_gn_default_params.restype = None
     lib.ebvo_gn_default_params.argtypes = [C.POINTER(GnParams)]
     lib.ebvo_sobel_gradients.argtypes = [vp, vp, i32, i32, ssz, vp, vp]

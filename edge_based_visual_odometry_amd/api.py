@@ -396,6 +396,10 @@ class Context:
         return dict(left=left, right=right, row_ptr=row_ptr, col_idx=col, sims=sims, best=best, keep=keep,
                     left_patches=lp)
 
+    def debug_set(self, key: int, value: int):
+        """Test hooks (ebvo_debug_set): 0 = attempts of the regrow loop, 1 = force N overflowed results."""
+        self._check(self.lib.ebvo_debug_set(self._ctx, key, value), "ebvo_debug_set")
+
     # -- profiling -----------------------------------------------------------------------------
     def profile_enable(self, on: bool = True, every: int = 1):
         """every = N > 1: bracket only every N-th pair submitted to the device pipeline."""

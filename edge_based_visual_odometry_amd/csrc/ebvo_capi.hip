@@ -120,6 +120,7 @@ static void slot_destroy(Slot *s)
     {
         ImageWS &ws = s->im[k];
         (void)hipFree(ws.img_base);
+        (void)hipFree(ws.pix2);
         (void)hipFree(ws.maps);
         (void)hipFree(ws.flag);
         (void)hipFree(ws.row_cnt);
@@ -181,6 +182,8 @@ static int slot_create(ebvo_ctx *ctx, Slot **out)
         // not wait for -- the zero fill could land after the first upload of a fresh context
         CK(hipMemsetAsync(ws.img_base, 0, (size_t)ctx->max_h * ctx->max_w + 128, s->stream));
         ws.img = ws.img_base + 64;
+        CK(hipMalloc(&ws.pix2, sizeof(uint16_t) * ((size_t)ctx->max_h * ctx->max_w + 64)));
+        CK(hipMemsetAsync(ws.pix2, 0, sizeof(uint16_t) * ((size_t)ctx->max_h * ctx->max_w + 64), s->stream));
         CK(hipMalloc(&ws.maps, sizeof(double) * np2 * PL_NUM));
         CK(hipMalloc(&ws.flag, np2));
         CK(hipMalloc(&ws.row_cnt, sizeof(int32_t) * 2 * H2));
@@ -348,23 +351,40 @@ static int host_slot(ebvo_ctx *ctx, Slot **out)
 }
 
 // run TOED on n_img resident images of the slot and read the counts back (synchronises)
+namespace
+{
+struct EventTriple // destroyed on every return path
+{
+    hipEvent_t e[3] = {nullptr, nullptr, nullptr};
+    ~EventTriple()
+    {
+        for (hipEvent_t ev : e)
+            if (ev)
+                (void)hipEventDestroy(ev);
+    }
+};
+} // namespace
+
 static int toed_sync(ebvo_ctx *ctx, Slot &s, int n_img, int h, int w, float *ms_conv, float *ms_nms)
 {
-    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+    EventTriple ev;
     const bool timed = ms_conv || ms_nms;
     if (timed)
-    {
-        EBVO_HIP(ctx, hipEventCreate(&e0));
-        EBVO_HIP(ctx, hipEventCreate(&e1));
-        EBVO_HIP(ctx, hipEventCreate(&e2));
-    }
-    int rc = toed_enqueue(ctx, s, n_img, h, w, e0, e1, e2);
+        for (hipEvent_t &e : ev.e)
+            EBVO_HIP(ctx, hipEventCreate(&e));
+    int rc = toed_enqueue(ctx, s, n_img, h, w, ev.e[0], ev.e[1], ev.e[2]);
     if (rc)
         return rc;
-    int32_t hc[4] = {0, 0, 0, 0};
-    for (int k = 0; k < n_img; ++k)
-        EBVO_HIP(ctx, hipMemcpyAsync(hc + 2 * k, s.im[k].counts, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s.stream));
-    EBVO_HIP(ctx, hipStreamSynchronize(s.stream));
+    // the counts travel through the slot's pinned record, never through this stack frame: a failure between the
+    // enqueue of a copy and the synchronisation cannot leave a DMA pointing at dead memory
+    int32_t *hc = reinterpret_cast<int32_t *>(s.h_result);
+    static_assert(sizeof(PairResult) >= 4 * sizeof(int32_t), "pinned record too small for the TOED counts");
+    hipError_t e = hipSuccess;
+    for (int k = 0; k < n_img && e == hipSuccess; ++k)
+        e = hipMemcpyAsync(hc + 2 * k, s.im[k].counts, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s.stream);
+    const hipError_t es = hipStreamSynchronize(s.stream); // also on failure: nothing may stay in flight
+    if (e != hipSuccess || es != hipSuccess)
+        return ebvo_fail_hip(ctx, e != hipSuccess ? e : es, "TOED count read-back", __FILE__, __LINE__);
     for (int k = 0; k < n_img; ++k)
     {
         s.im[k].n_total = hc[2 * k];
@@ -373,13 +393,10 @@ static int toed_sync(ebvo_ctx *ctx, Slot &s, int n_img, int h, int w, float *ms_
     if (timed)
     {
         float a = 0, b = 0;
-        EBVO_HIP(ctx, hipEventElapsedTime(&a, e0, e1));
-        EBVO_HIP(ctx, hipEventElapsedTime(&b, e1, e2));
+        EBVO_HIP(ctx, hipEventElapsedTime(&a, ev.e[0], ev.e[1]));
+        EBVO_HIP(ctx, hipEventElapsedTime(&b, ev.e[1], ev.e[2]));
         if (ms_conv) *ms_conv = a;
         if (ms_nms) *ms_nms = b;
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
-        (void)hipEventDestroy(e2);
     }
     return EBVO_OK;
 }
@@ -506,11 +523,20 @@ extern "C" int ebvo_epi_candidates(ebvo_ctx *ctx, const ebvo_edge *L, int nL, co
     if ((rc = match_candidates_enqueue(ctx, s, dL, nL, nullptr, dR, nR, nullptr, 0, (const double *)s.lines.p, epi_thr,
                                        max_disp, orient_thr_deg, stage_mask, false)))
         return rc;
-    unsigned long long h_total = 0;
-    EBVO_HIP(ctx, hipMemcpyAsync(&h_total, s.d_total, sizeof(h_total), hipMemcpyDeviceToHost, s.stream));
-    EBVO_HIP(ctx, hipMemcpyAsync(row_ptr, s.row_ptr.p, sizeof(int32_t) * ((size_t)nL + 1), hipMemcpyDeviceToHost,
-                                 s.stream));
-    EBVO_HIP(ctx, hipStreamSynchronize(s.stream));
+    // the total lands in the slot's pinned record (not in this stack frame); on any failure the stream is drained
+    // before returning so that no copy into the caller's row_ptr stays in flight
+    unsigned long long *h_total_p = reinterpret_cast<unsigned long long *>(s.h_result);
+    {
+        hipError_t e1 = hipMemcpyAsync(h_total_p, s.d_total, sizeof(*h_total_p), hipMemcpyDeviceToHost, s.stream);
+        hipError_t e2 = e1 == hipSuccess ? hipMemcpyAsync(row_ptr, s.row_ptr.p, sizeof(int32_t) * ((size_t)nL + 1),
+                                                          hipMemcpyDeviceToHost, s.stream)
+                                         : hipSuccess;
+        hipError_t e3 = hipStreamSynchronize(s.stream);
+        if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess)
+            return ebvo_fail_hip(ctx, e1 != hipSuccess ? e1 : (e2 != hipSuccess ? e2 : e3), "candidate total read-back",
+                                 __FILE__, __LINE__);
+    }
+    const unsigned long long h_total = *h_total_p;
     if (h_total > 0x7fffffffull)
     {
         ctx->last_error = "candidate list exceeds 2^31-1 pairs";
@@ -850,7 +876,7 @@ extern "C" int ebvo_stereo_upload_slot(ebvo_ctx *ctx, int slot, const uint8_t *i
     Slot &s = *sp;
     if (s.in_flight)
         return EBVO_ERR_STATE;
-    s.have_pair = s.have_run = false;
+    s.have_pair = s.have_run = s.have_refined = s.have_final = false; // results of the previous pair are gone
     if ((rc = upload_image(ctx, s, 0, img_left, h, w, stride_left)))
         return rc;
     if ((rc = upload_image(ctx, s, 1, img_right, h, w, stride_right)))
@@ -881,9 +907,7 @@ static int ensure_pipeline_buffers(ebvo_ctx *ctx, Slot &s, int64_t cap_pairs)
         return rc;
     if ((rc = ebvo_grow(ctx, s, s.patches_flag, 2 * ce)))
         return rc;
-    if ((rc = ebvo_grow(ctx, s, s.patches_norm_r, sizeof(float) * 98 * ce)))
-        return rc;
-    if ((rc = ebvo_grow(ctx, s, s.patches_flag_r, 2 * ce)))
+    if ((rc = ebvo_grow(ctx, s, s.patches_norm_r, match_right_bank_bytes(ctx->cap_edges))))
         return rc;
     if ((rc = ebvo_grow(ctx, s, s.sincos, sizeof(double) * 2 * ce)))
         return rc;
@@ -903,7 +927,7 @@ static int ensure_pipeline_buffers(ebvo_ctx *ctx, Slot &s, int64_t cap_pairs)
     return EBVO_OK;
 }
 
-// lines -> candidates (count, scan, fill) -> patch banks -> NCC -> result record; no host synchronisation
+// lines -> candidates (count, scan, fill) -> right patch bank -> LDS-tiled NCC -> result record; no host synchronisation
 static int enqueue_matching(ebvo_ctx *ctx, Slot &s)
 {
     const ebvo_stereo_params &p = s.params;
@@ -916,9 +940,7 @@ static int enqueue_matching(ebvo_ctx *ctx, Slot &s)
                                        (const double *)s.lines.p, p.epi_thr, p.max_disp, p.orient_thr_deg, p.stage_mask,
                                        true)))
         return rc;
-    if ((rc = match_patch_banks_enqueue(ctx, s, h, w, ce)))
-        return rc;
-    if ((rc = match_ncc_banked_enqueue(ctx, s, 0, d_nL, ce, 0, p.ncc_thr)))
+    if ((rc = match_ncc_resident_enqueue(ctx, s, h, w, ce, p.ncc_thr)))
         return rc;
     return match_pair_result_enqueue(ctx, s);
 }
@@ -967,7 +989,9 @@ extern "C" int ebvo_stereo_wait(ebvo_ctx *ctx, int slot, ebvo_stereo_counts *cou
         Slot &s;
         ~Restore() { s.prof_now = true; } // host-buffer calls on this slot are always bracketed
     } restore{s};
-    for (int attempt = 0; attempt < 4; ++attempt)
+    bool have_result = false;
+    const int max_attempts = ctx->wait_attempts > 0 ? ctx->wait_attempts : 4;
+    for (int attempt = 0; attempt < max_attempts; ++attempt)
     {
         hipError_t e = hipStreamSynchronize(s.stream);
         if (e != hipSuccess)
@@ -982,9 +1006,10 @@ extern "C" int ebvo_stereo_wait(ebvo_ctx *ctx, int slot, ebvo_stereo_counts *cou
             ctx->last_error = "internal edge capacity exceeded";
             return EBVO_ERR_CAPACITY;
         }
-        if (!r.overflow)
+        if (!r.overflow && !(ctx->force_overflow > 0 && ctx->force_overflow-- > 0))
         {
             s.result = r;
+            have_result = true;
             break;
         }
         if (r.n_pairs > 0x7fffffffll)
@@ -1000,6 +1025,15 @@ extern "C" int ebvo_stereo_wait(ebvo_ctx *ctx, int slot, ebvo_stereo_counts *cou
             s.in_flight = false;
             return rc;
         }
+    }
+    if (!have_result)
+    {
+        // every attempt reported an overflow: the last re-enqueued matching half is still running; never publish a
+        // stale s.result
+        (void)hipStreamSynchronize(s.stream);
+        s.in_flight = false;
+        ctx->last_error = "candidate buffers still too small after regrowing (ebvo_stereo_wait gave up)";
+        return EBVO_ERR_CAPACITY;
     }
     s.in_flight = false;
     s.im[0].n_kept = s.result.n_left;
@@ -1258,8 +1292,11 @@ extern "C" int ebvo_stereo_refine(ebvo_ctx *ctx, int slot, const ebvo_gn_params 
         (rc = ebvo_grow(ctx, s, s.gn_iters, sizeof(int32_t) * npz)))
         return rc;
     double *out = (double *)s.gn_out.p;
-    // the pipeline's own device arrays: left / right TOED edges, epipolar lines, CSR expansion, NCC keep flags
-    if ((rc = refine_sobel_enqueue(ctx, s, s.im[1].img, h, w, w, nullptr, nullptr, s.grad_x.p)) ||
+    // the pipeline's own device arrays: left / right TOED edges, epipolar lines, NCC keep flags; the pair -> left edge
+    // expansion of the CSR is formed here (the matching kernels themselves work per tile of rows)
+    if ((rc = ebvo_grow(ctx, s, s.pair_left, sizeof(int32_t) * npz)) ||
+        (rc = match_expand_rows_enqueue(ctx, s, (const int32_t *)s.row_ptr.p, s.result.n_left, np, (int32_t *)s.pair_left.p)) ||
+        (rc = refine_sobel_enqueue(ctx, s, s.im[1].img, h, w, w, nullptr, nullptr, s.grad_x.p)) ||
         (rc = refine_gn_stereo_enqueue(ctx, s, s.im[0].img, s.im[1].img, s.grad_x.p, h, w, s.im[0].edges, s.result.n_left,
                                        (const double *)s.lines.p, (const int32_t *)s.pair_left.p, nullptr, s.im[1].edges,
                                        (const int32_t *)s.col_idx.p, (const uint8_t *)s.keep.p, np, params->max_iter,
@@ -1387,16 +1424,24 @@ extern "C" int ebvo_stereo_finalize(ebvo_ctx *ctx, int slot, const ebvo_finalize
                                            out + 2 * nz, (uint8_t *)s.gn_valid.p, (int32_t *)s.gn_iters.p, out + 3 * nz)) ||
             (rc = glue_xy_enqueue(ctx, s, candC, out + 3 * nz, nB, true)))
             return rc;
-        // 5. clustering of the refined centres (:1450: cluster-only call) -> candA in the rows of rpA
-        if ((rc = glue_cluster_enqueue(ctx, s, candC, rpB, nL, 0, 1, cnt, candB, cluster_of)) || (rc = scan_counts(rpA, &nE)) ||
+        // 5. consolidate_redundant_edge_hypothesis(pairs, false, true) (:1483).  Against the signature (pairs, frame_idx,
+        // b_do_epipolar_shift = true, b_do_clustering = true) this binds frame_idx = 0, shift = true, cluster = true: the
+        // refined centres are shifted to the epipolar line AGAIN (:981-998) and clustered with b_cluster_by_orientation =
+        // b_do_epipolar_shift = true (:1031); rows with one candidate are not skipped on the shift branch (:1001 is the
+        // else branch only).  -> candA in the rows of rpA
+        if ((rc = glue_shift_enqueue(ctx, s, candC, (const double *)s.lines.p, left_of, nB, candA)) ||
+            (rc = glue_cluster_enqueue(ctx, s, candA, rpB, nL, 1, 0, cnt, candB, cluster_of)) || (rc = scan_counts(rpA, &nE)) ||
             (rc = glue_gather_rows_enqueue(ctx, s, rpB, cnt, nullptr, rpA, nL, candB, nullptr, candA, nullptr, nullptr)))
             return rc;
     }
     counts->n_clusters = nE;
     if (nE)
     {
-        // 6. second NCC pass on the cluster centres (:1463) -> keep2 / best2, 7. the best survivor of every row (:1472)
-        if ((rc = match_ncc_pairs_enqueue(ctx, s, s.im[1].img, h, w, w, candA, rpA, nL, nE, (const float *)s.patches_norm.p,
+        // 6. second NCC pass on the cluster centres (:1500) -> keep2 / best2, 7. the best survivor of every row (:1513).
+        // The normalised left patches (left_edge_patches, :578) are sampled here: the first pass keeps them in LDS only.
+        if ((rc = match_patches_enqueue(ctx, s, s.im[0].img, h, w, w, s.im[0].edges, nL, nullptr, 0, nullptr,
+                                        (float *)s.patches_norm.p, (uint8_t *)s.patches_flag.p)) ||
+            (rc = match_ncc_pairs_enqueue(ctx, s, s.im[1].img, h, w, w, candA, rpA, nL, nE, (const float *)s.patches_norm.p,
                                           (const uint8_t *)s.patches_flag.p, p->ncc_thr, nullptr, best2, keep2, ncc_left,
                                           sincos2)) ||
             (rc = glue_rows_from_flags_enqueue(ctx, s, rpA, nL, keep2, cnt, order)) || (rc = scan_counts(rpB, &nF)) ||
@@ -1537,6 +1582,19 @@ extern "C" int ebvo_profile_get(ebvo_ctx *ctx, ebvo_kernel_time *out, int *n)
     }
     *n = K_NUM;
     return rc;
+}
+
+extern "C" int ebvo_debug_set(ebvo_ctx *ctx, int key, int value)
+{
+    if (!ctx || value < 0)
+        return EBVO_ERR_ARG;
+    if (key == 0)
+        ctx->wait_attempts = value;
+    else if (key == 1)
+        ctx->force_overflow = value;
+    else
+        return EBVO_ERR_ARG;
+    return EBVO_OK;
 }
 
 extern "C" int ebvo_fp64_peak(ebvo_ctx *ctx, int iters, double *tflops_muladd, double *tflops_fma)

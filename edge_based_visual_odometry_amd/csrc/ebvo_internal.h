@@ -60,6 +60,7 @@ struct ImageWS
 {
     uint8_t *img = nullptr;     // h*w, tightly packed; = img_base + 64: 64 readable bytes before and after (wide loads)
     uint8_t *img_base = nullptr;
+    uint16_t *pix2 = nullptr;   // row-pair image: pix2[y*w + x] = img(y, x) | img(y + 1, x) << 8 (one 4-byte load per bilinear sample)
     double *maps = nullptr;     // PL_NUM planes of 4 x H x W
     uint8_t *flag = nullptr;    // 2H x 2W: 0 none, 1 NMS maximum, 3 maximum inside the 10-px border
     int32_t *row_cnt = nullptr; // [2][H2]   per interpolated row: all maxima, kept maxima (hybrid: even / odd column candidates)
@@ -138,6 +139,8 @@ struct ebvo_ctx
     int toed_mode = EBVO_TOED_STRICT;
     std::string last_error;
     std::vector<Slot *> slots; // slot 0 always exists; it also serves the host-buffer entry points
+    int wait_attempts = 0;     // test hook (ebvo_debug_set): attempts of ebvo_stereo_wait's regrow loop, 0 = default (4)
+    int force_overflow = 0;    // test hook: treat the next N results as overflowed
 
     // profiling (accumulated over all slots)
     bool prof = false;
@@ -195,7 +198,6 @@ int match_candidates_fill_enqueue(ebvo_ctx *ctx, Slot &s, const ebvo_edge *d_L, 
                                   const ebvo_edge *d_R, int nR, const int32_t *d_nR, int cap_edges,
                                   const double *d_lines, double epi_thr, double max_disp, double orient_thr_deg,
                                   int stage_mask);
-int match_patch_banks_enqueue(ebvo_ctx *ctx, Slot &s, int h, int w, int cap_edges);
 int match_patches_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_img, int h, int w, int pitch,
                           const ebvo_edge *d_edges, int n, const int32_t *d_n, int cap_n, float *d_raw, float *d_norm,
                           uint8_t *d_flag);
@@ -204,8 +206,9 @@ int match_ncc_pairs_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_imgR, int h
                             const float *d_left_norm, const uint8_t *d_left_flag, double thr, double *d_sims,
                             double *d_best, uint8_t *d_keep, int32_t *d_pair_left_scratch = nullptr,
                             void *d_sincos_scratch = nullptr /* n_pairs double2; NULL: the slot's own buffers */);
-int match_ncc_banked_enqueue(ebvo_ctx *ctx, Slot &s, int nL, const int32_t *d_nL, int cap_edges, int64_t n_pairs_host,
-                             double thr);
+// resident pipeline: sin/cos, right patch bank, LDS-tiled NCC of every CSR pair (sizes read on the device)
+int match_ncc_resident_enqueue(ebvo_ctx *ctx, Slot &s, int h, int w, int cap_edges, double thr);
+size_t match_right_bank_bytes(int cap_edges);
 int match_pair_result_enqueue(ebvo_ctx *ctx, Slot &s);
 // exclusive scan of n (+ n_add) int32 on the slot's stream; n_dev != nullptr: the count lives on the device, cap_n bounds it
 // zero n (<= EBVO_CLEAR_MAX) int32 arrays with one launch

@@ -1,5 +1,5 @@
 /*
- * ebvo_math.h -- portable atan2 / sincos shared by the HIP kernels and the CPU oracle.
+ * ebvo_math.h -- portable atan2 / sincos / exp shared by the HIP kernels and the CPU oracle.
  *
  * Why this exists: the reference calls libm's std::atan2 for the third-order edge
  * orientation (src/toed/cpu_toed.cpp:229) and std::sin / std::cos for the NCC patch
@@ -93,6 +93,36 @@ EBVO_MATH_CONST double ebvo_cos_tab[14][2] = {
 #define EBVO_PIO2_3_HI 0x1.3198a2e037073p-69
 #define EBVO_PIO2_3_LO 0x1.129024e088a68p-123
 #define EBVO_2_PI 0x1.45f306dc9c883p-1
+EBVO_MATH_CONST double ebvo_exp_tab[23][2] = {
+    {0x1.6b0ff72deb89dp-1, -0x1.dabf5975c0c02p-57},
+    {0x1.769652df22f7ep-1, 0x1.3445f7544e0efp-57},
+    {0x1.827a561889716p-1, -0x1.6b2eab63020c1p-57},
+    {0x1.8ebef9eac820bp-1, -0x1.797d4686c5393p-57},
+    {0x1.9b674f8f2f3d8p-1, -0x1.51bfdbb129094p-55},
+    {0x1.a876812c0877cp-1, -0x1.fd36226fadd44p-56},
+    {0x1.b5efd29f24c26p-1, 0x1.3d5fd7d70a5edp-56},
+    {0x1.c3d6a24ed8222p-1, -0x1.e1e0a76cb0685p-55},
+    {0x1.d22e6a0197c03p-1, -0x1.32ae7bdaf1116p-55},
+    {0x1.e0fabfbc702a4p-1, -0x1.8d0e700fcfb65p-56},
+    {0x1.f03f56a88b5d8p-1, -0x1.bad3fd501a227p-55},
+    {0x1.0000000000000p+0, 0x0.0p+0},
+    {0x1.08205601127edp+0, -0x1.9c7d0bdf15160p-54},
+    {0x1.1082b577d34edp+0, 0x1.f56c680678897p-54},
+    {0x1.192937074e0cdp+0, 0x1.a24f46336ea04p-54},
+    {0x1.2216045b6f5cdp+0, -0x1.8c4a5df1ec7e5p-58},
+    {0x1.2b4b58b372c79p+0, 0x1.404dd9f031676p-54},
+    {0x1.34cb8170b5835p+0, 0x1.6a7062465be33p-55},
+    {0x1.3e98deaa11dccp+0, -0x1.5722108fefcffp-54},
+    {0x1.48b5e3c3e8186p+0, 0x1.9d9ef0eda6eabp-54},
+    {0x1.5325180cfacf7p+0, 0x1.b28b660a648dap-54},
+    {0x1.5de9176045ff5p+0, 0x1.da89923298baap-55},
+    {0x1.690492cbf9433p+0, -0x1.812833f7d6e43p-55},
+};
+#define EBVO_LN2_1 0x1.62e42fee00000p-1
+#define EBVO_LN2_2 0x1.a39ef35600000p-33
+#define EBVO_LN2_3_HI 0x1.93c7673007e5fp-65
+#define EBVO_LN2_3_LO -0x1.50bf0cbcd98d6p-120
+#define EBVO_1_LN2 0x1.71547652b82fep+0
 
 /* ---- error-free transformations (Dekker / Knuth), no FMA ---- */
 
@@ -371,6 +401,59 @@ EBVO_MATH_FN void ebvo_sincos(double theta, double *sn, double *cs)
         *cs = sv;
         break;
     }
+}
+
+/*
+ * exp(x).  Replaces std::exp in the Gaussian weights of EdgeClusterer::computeGaussianAverage
+ * (src/EdgeClusterer.cpp:104) and in the refinement confidence exp(-rms / delta)
+ * (src/Stereo_Matches.cpp:1281).  x = k ln2 + j/32 + u with |u| <= 1/64: exp(j/32) from a double-double
+ * table, exp(u) by its Taylor series (u, u^2/2, u^3/6 in double-double), one rounding at the end.  Last-bit
+ * accurate for results in the normal range; results below 2^-1022 are rounded twice.
+ */
+EBVO_MATH_FN double ebvo_exp(double x)
+{
+    if (x != x)
+        return x + x;
+    if (x > 709.782712893384)
+        return 1.7976931348623157e308 * 2.0; /* +inf */
+    if (x < -745.2)
+        return 0.0;
+    double fk = x * EBVO_1_LN2;
+    int k = (int)(fk + (fk >= 0.0 ? 0.5 : -0.5));
+    double dk = (double)k;
+    /* r = x - k ln2 in double-double (k * LN2_1 and k * LN2_2 are exact) */
+    ebvo_dd r = ebvo_two_sum(x, -(dk * EBVO_LN2_1));
+    r = ebvo_dd_add_d(r, -(dk * EBVO_LN2_2));
+    ebvo_dd l3;
+    l3.hi = EBVO_LN2_3_HI;
+    l3.lo = EBVO_LN2_3_LO;
+    r = ebvo_dd_sub(r, ebvo_dd_mul_d(l3, dk));
+    double f32 = r.hi * 32.0;
+    int j = (int)(f32 + (f32 >= 0.0 ? 0.5 : -0.5));
+    if (j > 11)
+        j = 11;
+    if (j < -11)
+        j = -11;
+    ebvo_dd u = ebvo_dd_add_d(r, -((double)j * 0.03125));
+    ebvo_dd u2 = ebvo_dd_mul(u, u);
+    ebvo_dd u3 = ebvo_dd_mul(u2, u);
+    double w = u.hi;
+    double p = 1.0 / 40320.0 + w * (1.0 / 362880.0);
+    p = 1.0 / 5040.0 + w * p;
+    p = 1.0 / 720.0 + w * p;
+    p = 1.0 / 120.0 + w * p;
+    p = 1.0 / 24.0 + w * p;
+    p = ((w * w) * (w * w)) * p;
+    ebvo_dd e = ebvo_dd_add(u, ebvo_dd_mul_d(u2, 0.5));
+    e = ebvo_dd_add(e, ebvo_dd_div_d(u3, 6.0));
+    e = ebvo_dd_add_d(e, p);
+    e = ebvo_dd_add_d(e, 1.0);
+    ebvo_dd t;
+    t.hi = ebvo_exp_tab[j + 11][0];
+    t.lo = ebvo_exp_tab[j + 11][1];
+    e = ebvo_dd_mul(t, e);
+    double v = e.hi + e.lo;
+    return __builtin_ldexp(v, k); /* exact scaling (v_ldexp_f64 on the device, scalbn on the host) */
 }
 
 #endif /* EBVO_MATH_H */

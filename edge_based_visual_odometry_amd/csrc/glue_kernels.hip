@@ -152,7 +152,8 @@ __global__ void shift_kernel(const ebvo_edge *__restrict__ cand, const double *_
 
 // EdgeClusterer::performClustering for one row per thread (src/EdgeClusterer.cpp:119-302, driven by
 // consolidate_redundant_edge_hypothesis :1006-1034).  Merging decisions use sqrt / compare only and equal the
-// restatement exactly; the Gaussian weights use the device exp (<= 1 ulp from glibc's), so the centres agree to rounding.
+// restatement exactly; the Gaussian weights use csrc/ebvo_math.h's exp, the routine the oracle's portable mode calls, so the
+// centres are bit-identical to it (glibc's exp differs by 1 ulp on a fraction of inputs: <= 1e-12 px on a centre).
 __device__ inline void gaussian_average(const ebvo_edge *__restrict__ E, const int32_t *lab, int n, int label, double &gx,
                                         double &gy, double &gt)
 {
@@ -186,7 +187,7 @@ __device__ inline void gaussian_average(const ebvo_edge *__restrict__ E, const i
             const double dx = E[i].x - cx, dy = E[i].y - cy;
             const double d = sqrt(dx * dx + dy * dy);
             const double q = (d - mean) / 2.0; // CLUSTER_ORIENT_GAUSS_SIGMA
-            const double g = exp(-0.5 * (q * q));
+            const double g = ebvo_exp(-0.5 * (q * q)); // the shared routine: same bits as the oracle's portable mode
             wx += g * E[i].x;
             wy += g * E[i].y;
             wt += g * E[i].theta;

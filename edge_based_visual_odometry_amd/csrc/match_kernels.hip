@@ -27,6 +27,8 @@
 // Element-wise patch arithmetic is float (CV_32F), reductions are double.
 //
 // Compiled with -ffp-contract=off: no FMA anywhere.
+#include <cstdlib>
+
 #include "ebvo_internal.h"
 #include "ebvo_math.h"
 
@@ -675,12 +677,24 @@ __device__ inline double bilinear_nan(const uint8_t *__restrict__ img, int rows,
     return ok ? v : __builtin_nan("");
 }
 
-// 8-lane xor butterfly: ((s0+s1)+(s2+s3)) + ((s4+s5)+(s6+s7)) on every lane of the group
+// 8-lane butterfly: ((s0+s1)+(s2+s3)) + ((s4+s5)+(s6+s7)) on every lane of the group.  The partner's value arrives
+// through DPP (quad_perm for the xor-1 and xor-2 steps; row_half_mirror for the last one: lane i of an 8-lane group reads
+// lane 7 - i, which after two steps holds the sum of the OTHER quad -- IEEE addition is commutative, so A + B and B + A are
+// the same bits): register-to-register moves on the vector pipe instead of ds_bpermute round trips through the LDS.
+template <int CTRL>
+__device__ inline double dpp_f64(double v)
+{
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int plo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+    const int phi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+    return __hiloint2double(phi, plo);
+}
+
 __device__ inline double butterfly8(double s)
 {
-    s += __shfl_xor(s, 1);
-    s += __shfl_xor(s, 2);
-    s += __shfl_xor(s, 4);
+    s += dpp_f64<0xB1>(s);  // quad_perm:[1,0,3,2]
+    s += dpp_f64<0x4E>(s);  // quad_perm:[2,3,0,1]
+    s += dpp_f64<0x141>(s); // row_half_mirror
     return s;
 }
 
@@ -728,21 +742,156 @@ __global__ void sincos_edges_kernel(const ebvo_edge *__restrict__ e, DevN nd, do
     }
 }
 
-// One lane's row (7 samples) of one side of an edge's patch pair.
-// src/utility.cpp:82-93 (centres), :141-161 (grid), :206-209 (to float).
-__device__ inline void sample_row(const uint8_t *__restrict__ img, int h, int w, int pitch, double ex, double ey,
-                                  double sn, double cs, int side, int row, float p[7])
+// The same interpolation for a sample that is known to lie inside the image with both of its corner rows / columns (see
+// patch_inside): no corner tests, no address clamps, a 32-bit offset from the (wave-uniform) image base, one 24-bit
+// multiply-add for the row offset.  Bit-identical to bilinear_nan wherever both apply: the loaded bytes and every
+// floating-point operation are the same; only the integer-coordinate NaN rule remains to be selected.
+__device__ inline double bilinear_inside(const uint8_t *__restrict__ img, int pitch, double x, double y)
 {
-    const double cx = side ? ex + 5 * (-sn) : ex + 5 * (sn);
-    const double cy = side ? ey + 5 * (cs) : ey + 5 * (-cs);
-    const int i = row - 3;
+    const double x1 = floor(x), x2 = ceil(x);
+    const double yc = ceil(y), yf = floor(y);
+    const unsigned of = __umul24((unsigned)(int)yf, (unsigned)pitch) + (unsigned)(int)x1; // row floor(y)
+    const unsigned oc = of + (unsigned)pitch; // row ceil(y) (= floor(y) + 1 unless y is an integer: NaN then, whatever is read)
+    unsigned short p1, p2;
+    __builtin_memcpy(&p1, img + oc, 2);
+    __builtin_memcpy(&p2, img + of, 2);
+    const double I11 = (double)(p1 & 0xff);
+    const double I21 = (double)(p1 >> 8);
+    const double I12 = (double)(p2 & 0xff);
+    const double I22 = (double)(p2 >> 8);
+    const double wxa = x2 - x;
+    const double wxb = x - x1;
+    const double wya = -(yf - y);
+    const double wyb = -(y - yc);
+    const double f1 = wxa * I11 + wxb * I21;
+    const double f2 = wxa * I12 + wxb * I22;
+    const double v = wya * f1 + wyb * f2;
+    const bool ok = (x2 != x1) && (yf != yc); // include/utility.h:101-103: 0/0 for an integer coordinate
+    return ok ? v : __builtin_nan("");
+}
+
+// Row-pair image: pix2[y * pitch + x] = img(y, x) | img(y + 1, x) << 8.  The four corners of a sample are then FOUR
+// CONSECUTIVE BYTES at offset 2 * (floor(y) * pitch + floor(x)): one 4-byte load per sample instead of two 2-byte loads.
+// The sampling is address-divergent (every lane its own cache line): the texture addresser retires about one lane
+// address per cycle and CU, which is what bounds the sampling kernels (GRBM_TA_BUSY, profiles/), so halving the load
+// count halves that bound.  Same bytes, same arithmetic as bilinear_inside.
+__device__ inline double bilinear_inside2(const uint16_t *__restrict__ pix2, int pitch, double x, double y)
+{
+    const double x1 = floor(x), x2 = ceil(x);
+    const double yc = ceil(y), yf = floor(y);
+    const unsigned of = __umul24((unsigned)(int)yf, (unsigned)pitch) + (unsigned)(int)x1;
+    unsigned q;
+    __builtin_memcpy(&q, reinterpret_cast<const uint8_t *>(pix2) + 2u * of, 4);
+    const double I12 = (double)(q & 0xffu);         // (floor y, x1)
+    const double I11 = (double)((q >> 8) & 0xffu);  // (ceil y,  x1)
+    const double I22 = (double)((q >> 16) & 0xffu); // (floor y, x2)
+    const double I21 = (double)(q >> 24);           // (ceil y,  x2)
+    const double wxa = x2 - x;
+    const double wxb = x - x1;
+    const double wya = -(yf - y);
+    const double wyb = -(y - yc);
+    const double f1 = wxa * I11 + wxb * I21;
+    const double f2 = wxa * I12 + wxb * I22;
+    const double v = wya * f1 + wyb * f2;
+    const bool ok = (x2 != x1) && (yf != yc); // include/utility.h:101-103: 0/0 for an integer coordinate
+    return ok ? v : __builtin_nan("");
+}
+
+__global__ __launch_bounds__(256) void row_pairs_kernel(const uint8_t *__restrict__ img0, const uint8_t *__restrict__ img1,
+                                                        uint16_t *__restrict__ out0, uint16_t *__restrict__ out1, int h,
+                                                        int w)
+{
+    const uint8_t *__restrict__ img = blockIdx.y ? img1 : img0;
+    uint16_t *__restrict__ out = blockIdx.y ? out1 : out0;
+    const int n = h * w;
+    // four pixels per thread; the image buffers have readable padding behind the last pixel (ebvo_capi.hip: img_base)
+    for (int o = (blockIdx.x * blockDim.x + threadIdx.x) * 4; o < n; o += gridDim.x * blockDim.x * 4)
+    {
+        unsigned a, b = 0;
+        __builtin_memcpy(&a, img + o, 4);
+        if (o + w + 3 < n)
+            __builtin_memcpy(&b, img + o + w, 4);
+        else
+        {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (o + w + t < n)
+                    b |= (unsigned)img[o + w + t] << (8 * t);
+        }
+        uint2 r;
+        r.x = (a & 0xffu) | ((b & 0xffu) << 8) | ((a & 0xff00u) << 8) | ((b & 0xff00u) << 16);
+        r.y = ((a >> 16) & 0xffu) | (((b >> 16) & 0xffu) << 8) | ((a >> 24) << 16) | ((b >> 24) << 24);
+        if (o + 3 < n)
+            __builtin_memcpy(out + o, &r, 8);
+        else
+            for (int t = 0; t < 4 && o + t < n; ++t)
+                out[o + t] = (uint16_t)(t < 2 ? (r.x >> (16 * t)) : (r.y >> (16 * (t - 2))));
+    }
+}
+
+// True if every sample of both patches of an edge at (ex, ey) has its four corners inside the image: a sample lies within
+// 5 + 3 sqrt(2) = 9.243 px of the edge in each coordinate (|sin|, |cos| <= 1), and its corners within one more pixel on
+// the ceil side.  The small slack covers the rounding of the coordinate arithmetic.  (A kept TOED edge has
+// 10 < x < W - 10: nearly always true, but not on the last quarter pixel, hence a test and not an assumption.)
+__device__ inline bool patch_inside(int h, int w, double ex, double ey)
+{
+    return ex >= 9.3 && ey >= 9.3 && ex <= (double)w - 10.3 && ey <= (double)h - 10.3;
+}
+
+struct Row7
+{
+    float v[7];
+};
+
+// the general interpolation (corner tests, NaN outside the image) for the rare wave that holds an edge next to the image
+// border: out of line, so that its registers and code do not weigh on the common path
+__device__ __noinline__ Row7 sample_row_border(const uint8_t *__restrict__ img, int h, int w, int pitch, double cx, double cy,
+                                               double sn, double cs, int i)
+{
+    Row7 r;
 #pragma unroll
     for (int c = 0; c < 7; ++c)
     {
         const int j = c - 3;
         const double x = cs * (i)-sn * (j) + cx;
         const double y = sn * (i) + cs * (j) + cy;
-        p[c] = (float)bilinear_nan(img, h, w, pitch, x, y);
+        r.v[c] = (float)bilinear_nan(img, h, w, pitch, x, y);
+    }
+    return r;
+}
+
+// One lane's row (7 samples) of one side of an edge's patch pair.
+// src/utility.cpp:82-93 (centres), :141-161 (grid), :206-209 (to float).
+// `active` lanes sample; the fast interpolation is taken when it applies to every sampling lane of the wave.
+template <bool PIX2 = false>
+__device__ inline void sample_row(const uint8_t *__restrict__ img, int h, int w, int pitch, double ex, double ey,
+                                  double sn, double cs, int side, int row, float p[7], bool active = true,
+                                  const uint16_t *__restrict__ pix2 = nullptr /* PIX2: the row-pair image of img */)
+{
+    const double cx = side ? ex + 5 * (-sn) : ex + 5 * (sn);
+    const double cy = side ? ey + 5 * (cs) : ey + 5 * (-cs);
+    const int i = row - 3;
+    if (__all(!active || patch_inside(h, w, ex, ey)))
+    {
+        if (active)
+        {
+#pragma unroll
+            for (int c = 0; c < 7; ++c)
+            {
+                const int j = c - 3;
+                const double x = cs * (i)-sn * (j) + cx;
+                const double y = sn * (i) + cs * (j) + cy;
+                p[c] = (float)(PIX2 ? bilinear_inside2(pix2, pitch, x, y) : bilinear_inside(img, pitch, x, y));
+            }
+        }
+        return;
+    }
+    if (active)
+    {
+        const Row7 r = sample_row_border(img, h, w, pitch, cx, cy, sn, cs, i);
+#pragma unroll
+        for (int c = 0; c < 7; ++c)
+            p[c] = r.v[c];
     }
 }
 
@@ -780,17 +929,21 @@ __device__ inline bool normalise_rows(bool active, const float p[7], float nrm[7
     return ss < 1e-10;
 }
 
+// One lane's seven terms of a 49-term dot product, accumulated left to right in double.  The product of two floats is
+// exact in double (24 + 24 significand bits), so fma(a, b, s) rounds exactly what s + a * b rounds: the explicit fma
+// below returns the bits of the reference's separate multiply and add at half the instructions.
+__device__ inline double dot7(const float a[7], const float b[7])
+{
+    double s = (double)a[0] * (double)b[0];
+#pragma unroll
+    for (int c = 1; c < 7; ++c)
+        s = __builtin_fma((double)a[c], (double)b[c], s);
+    return s;
+}
+
 __device__ inline double dot_rows(bool active, const float a[7], const float b[7])
 {
-    double s = 0.0;
-    if (active)
-    {
-        s = (double)a[0] * (double)b[0];
-#pragma unroll
-        for (int c = 1; c < 7; ++c)
-            s += (double)a[c] * (double)b[c];
-    }
-    return butterfly8(s);
+    return butterfly8(active ? dot7(a, b) : 0.0);
 }
 
 __device__ inline double max4(double a, double b, double c, double d)
@@ -825,8 +978,10 @@ __global__ __launch_bounds__(256) void patches_kernel(PatchBatch B, int h, int w
 #pragma unroll
         for (int c = 0; c < 7; ++c)
             p[c] = 0.0f;
-        if (active)
-            sample_row(img, h, w, pitch, edges[e].x, edges[e].y, sc[e].x, sc[e].y, side, row, p);
+        {
+            const int ec = active ? e : 0; // inactive lanes read edge 0 (always present when the kernel has work) and discard it
+            sample_row(img, h, w, pitch, edges[ec].x, edges[ec].y, sc[ec].x, sc[ec].y, side, row, p, active);
+        }
         const bool sent = normalise_rows(active, p, nr);
         if (active)
         {
@@ -871,8 +1026,10 @@ __global__ __launch_bounds__(256) void ncc_pairs_kernel(const uint8_t *__restric
     int li = 0;
     if (valid)
         li = pair_left[k];
-    if (active)
-        sample_row(imgR, h, w, pitch, Rc[k].x, Rc[k].y, sc[k].x, sc[k].y, side, row, p);
+    {
+        const int64_t kc = active ? k : 0;
+        sample_row(imgR, h, w, pitch, Rc[kc].x, Rc[kc].y, sc[kc].x, sc[kc].y, side, row, p, active);
+    }
     const bool rsent = normalise_rows(active, p, rn);
     // this lane's row of the left plus / minus normalised patches
     float lp[7], lm[7];
@@ -937,91 +1094,214 @@ __global__ void expand_rows_kernel(const int32_t *__restrict__ row_ptr, DevN nLd
             pair_left[k] = i;
 }
 
-// NCC of (left edge, right TOED edge) pairs from precomputed normalised-patch banks (device pipeline: every
-// right edge is a candidate of ~5 left edges, so its patches are sampled and normalised once, not per pair).
-// Same arithmetic as ncc_pairs_kernel: the normalised rows are identical, the four dots use the same order.
-__global__ __launch_bounds__(256) void ncc_banked_kernel(const float *__restrict__ left_norm,
-                                                         const uint8_t *__restrict__ left_flag,
-                                                         const float *__restrict__ right_norm,
-                                                         const uint8_t *__restrict__ right_flag,
-                                                         const int32_t *__restrict__ pair_left,
-                                                         const int32_t *__restrict__ col_idx, DevPairs np, double thr,
-                                                         double *__restrict__ sims, double *__restrict__ best,
-                                                         uint8_t *__restrict__ keep, int32_t *__restrict__ match_part)
+// ---- NCC of the resident pipeline: left patches staged in LDS, right patches from a padded bank ----------------------
+// Every right TOED edge is a candidate of ~5 left edges spread over two or three interpolated rows, so its two patches are
+// sampled and normalised ONCE into a bank; every left edge's patches are needed by its own CSR row only, so they never
+// leave the workgroup that samples them.
+//   right bank : per edge 2 sides x 8 rows x 8 floats = 512 B.  A lane owns one 32-byte row: two aligned 16-byte
+//                accesses instead of seven dwords (the gather is address-divergent: the texture path charges per load
+//                instruction and per 128-byte line touched).  Slot [7] of every row carries the side's sentinel flag
+//                (sum of squares < 1e-10, src/utility.cpp:170), row 7 is never touched.
+//   ncc_tile   : a WAVE owns NW consecutive left edges = a contiguous range of CSR pairs.  Phase 1 samples and
+//                normalises their patches into LDS (same layout as a bank entry, 7 rows), phase 2 walks the pairs of the
+//                tile, eight lanes per pair (lane r = row r of all four patches): four 16-byte loads of the right rows,
+//                four ds_read_b128 of the left rows, four 49-term dots in the canonical order (dot7 + butterfly8).  Arithmetic identical to
+//                ncc_pairs_kernel / the oracle: the normalised rows are the same floats, the reductions the same order.
+constexpr int BANK_SIDE = 64;   // floats per side of a bank entry
+constexpr int BANK_EDGE = 128;  // floats per edge
+constexpr int NCC_NW = 4;       // left edges per wave (one sampling round: four 16-lane groups)
+constexpr int NCC_WPE = 5;      // waves per SIMD the tile kernel is compiled for
+
+__global__ __launch_bounds__(256) void right_bank_kernel(const uint8_t *__restrict__ img,
+                                                         const uint16_t *__restrict__ pix2, int h, int w, int pitch,
+                                                         const ebvo_edge *__restrict__ edges,
+                                                         const double2 *__restrict__ sc, DevN nd,
+                                                         float *__restrict__ bank)
 {
-    __shared__ int s_mc[4];
-    int mc = 0; // kept pairs seen by this thread; summed per block into match_part[blockIdx.x] (no atomics)
-    const int64_t n_pairs = devpairs(np);
-    const int64_t groups = ((int64_t)gridDim.x * blockDim.x) >> 4;
-    // XCD-aware block order: workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  Consecutive pairs
-    // share their left edge and neighbouring right edges, so every XCD gets a CONTIGUOUS eighth of each sweep of pairs:
-    // its slice of the patch banks then stays in its L2 instead of all eight L2s streaming the whole bank from HBM.
-    int vb = blockIdx.x;
-    if ((gridDim.x & 7) == 0)
-        vb = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-    const int64_t t = (int64_t)vb * blockDim.x + threadIdx.x;
-    const int g = (int)(t & 15), side = g >> 3, row = g & 7;
-    const int64_t iters = (n_pairs + groups - 1) / groups;
-    for (int64_t it = 0; it < iters; ++it)
+    const int n = devn(nd);
+    const int groups = (gridDim.x * blockDim.x) >> 4;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int g = t & 15, side = g >> 3, row = g & 7;
+    const int iters = (n + groups - 1) / groups;
+    for (int it = 0; it < iters; ++it)
     {
-        const int64_t k = it * groups + (t >> 4);
-        const bool valid = k < n_pairs;
-        const bool active = valid && row < 7;
-        float rn[7], lp[7], lm[7];
+        const int e = it * groups + (t >> 4);
+        const bool active = e < n && row < 7;
+        float p[7], nr[7];
 #pragma unroll
         for (int c = 0; c < 7; ++c)
-            rn[c] = lp[c] = lm[c] = 0.0f;
-        int li = 0, ri = 0;
-        if (valid)
+            p[c] = 0.0f;
         {
-            li = pair_left[k];
-            ri = col_idx[k];
+            const int ec = active ? e : 0; // inactive lanes read edge 0 (always present when the kernel has work) and discard it
+            sample_row<true>(img, h, w, pitch, edges[ec].x, edges[ec].y, sc[ec].x, sc[ec].y, side, row, p, active, pix2);
         }
+        const bool sent = normalise_rows(active, p, nr);
         if (active)
         {
-            const float *rr = right_norm + (size_t)ri * 98 + side * 49 + row * 7;
-            const float *ln = left_norm + (size_t)li * 98 + row * 7;
+            float4 *dst = reinterpret_cast<float4 *>(bank + (size_t)e * BANK_EDGE + side * BANK_SIDE + row * 8);
+            dst[0] = make_float4(nr[0], nr[1], nr[2], nr[3]);
+            dst[1] = make_float4(nr[4], nr[5], nr[6], sent ? 1.0f : 0.0f);
+        }
+    }
+}
+
+// wave-synchronous exchange through LDS: the writes of this wave are complete and visible to its other lanes
+__device__ inline void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// One WAVE owns NW consecutive left edges (a contiguous range of CSR pairs): no workgroup barrier anywhere, so waves in
+// their sampling phase and waves in their scoring phase overlap freely on a SIMD.
+template <int NW, int WPE>
+__global__ __launch_bounds__(256, WPE) void ncc_tile_kernel(const uint8_t *__restrict__ imgL,
+                                                            const uint16_t *__restrict__ pix2L, int h, int w, int pitch,
+                                                       const ebvo_edge *__restrict__ L, const double2 *__restrict__ scL,
+                                                       DevN nLd, const int32_t *__restrict__ row_ptr,
+                                                       const int32_t *__restrict__ col_idx,
+                                                       const float *__restrict__ rbank, int64_t cap, double thr,
+                                                       double *__restrict__ sims, double *__restrict__ best,
+                                                       uint8_t *__restrict__ keep, int32_t *__restrict__ match_part)
+{
+    static_assert(NW % 4 == 0 && NW <= 32, "four 16-lane groups sample the tile");
+    __shared__ __attribute__((aligned(16))) float s_left_all[4][NW * 2 * 7 * 8];
+    __shared__ int s_mc;
+    const int nL = devn(nLd);
+    const int ntiles = (nL + NW - 1) / NW;
+    // XCD-aware tile order: workgroups b and b + 8 share an XCD (and its L2).  XCD x walks the x-th contiguous eighth of the
+    // tiles (whatever the edge count turns out to be: the grid is sized by capacity), so the slice of the right bank its
+    // pairs touch stays in ITS L2 and all eight XCDs get equal shares.  Requires gridDim.x % 8 == 0 (the host rounds).
+    const int per_xcd = (ntiles + 7) >> 3;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
+    const int t_begin = xcd * per_xcd, t_end = t_begin + per_xcd < ntiles ? t_begin + per_xcd : ntiles;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g = lane & 15, side = g >> 3, row = g & 7, r8 = lane & 7;
+    float *s_left = s_left_all[wave];
+    if (threadIdx.x == 0)
+        s_mc = 0;
+    int mc = 0; // kept pairs seen by this lane
+    for (int tile = t_begin + slot * 4 + wave; tile < t_end; tile += slots * 4)
+    {
+        const int e0 = tile * NW;
+        const int rows = nL - e0 < NW ? nL - e0 : NW;
+        // CSR offsets of the tile's rows, clamped to the capacity of the pair buffers; lane t holds rp[t]
+        int rp_l = 0;
+        if (lane <= NW)
+        {
+            const int64_t v = row_ptr[e0 + (lane < rows ? lane : rows)];
+            rp_l = (int)(v < cap ? v : cap);
+        }
+        // phase 1: the tile's left patches (src/Stereo_Matches.cpp:578), normalised as get_patch_similarity does
+#pragma unroll 1
+        for (int q = 0; q < NW / 4; ++q)
+        {
+            const int el = q * 4 + (lane >> 4), e = e0 + el;
+            const bool active = el < rows && row < 7;
+            float p[7], nr[7];
 #pragma unroll
             for (int c = 0; c < 7; ++c)
+                p[c] = 0.0f;
             {
-                rn[c] = rr[c];
-                lp[c] = ln[c];
-                lm[c] = ln[49 + c];
+                const int ec = active ? e : 0;
+                sample_row<true>(imgL, h, w, pitch, L[ec].x, L[ec].y, scL[ec].x, scL[ec].y, side, row, p, active, pix2L);
+            }
+            const bool sent = normalise_rows(active, p, nr);
+            if (active)
+            {
+                float4 *dst = reinterpret_cast<float4 *>(&s_left[((el * 2 + side) * 7 + row) * 8]);
+                dst[0] = make_float4(nr[0], nr[1], nr[2], nr[3]);
+                dst[1] = make_float4(nr[4], nr[5], nr[6], sent ? 1.0f : 0.0f);
             }
         }
-        const double d_lp = dot_rows(active, lp, rn);
-        const double d_lm = dot_rows(active, lm, rn);
-        const double o_lp = __shfl_xor(d_lp, 8), o_lm = __shfl_xor(d_lm, 8);
-        if (valid && g == 0)
+        wave_lds_sync();
+        // row starts as wave-uniform scalars (v_readlane; __shfl would be a ds_bpermute through the LDS pipe each)
+        int rps[NW + 1];
+#pragma unroll
+        for (int t = 0; t <= NW; ++t)
+            rps[t] = __builtin_amdgcn_readlane(rp_l, t);
+        const int k0 = rps[0], k1 = rps[NW]; // lanes beyond `rows` hold rp[rows]
+        // phase 2: EIGHT lanes per pair (src/Stereo_Matches.cpp:585-608): lane r holds row r of R+, R-, L+, L-
+        for (int kb = k0; kb < k1; kb += 8)
         {
-            const bool lsent_p = left_flag[(size_t)li * 2] != 0, lsent_m = left_flag[(size_t)li * 2 + 1] != 0;
-            const bool rsent_p = right_flag[(size_t)ri * 2] != 0, rsent_m = right_flag[(size_t)ri * 2 + 1] != 0;
-            const double pp = (lsent_p || rsent_p) ? -1.0 : d_lp;
-            const double npv = (lsent_m || rsent_p) ? -1.0 : d_lm;
-            const double pn = (lsent_p || rsent_m) ? -1.0 : o_lp;
-            const double nn = (lsent_m || rsent_m) ? -1.0 : o_lm;
-            const double b = max4(pp, nn, pn, npv);
-            if (sims)
+            const int k = kb + (lane >> 3);
+            const bool valid = k < k1;
+            const bool active = valid && r8 < 7;
+            // local row of pair k: the number of row starts rp[1 .. rows - 1] at or below k
+            int el = 0;
+#pragma unroll
+            for (int t = 1; t < NW; ++t)
+                el += (t < rows && k >= rps[t]) ? 1 : 0;
+            float4 a0 = make_float4(0, 0, 0, 0), a1 = a0, b0 = a0, b1 = a0, p0 = a0, p1 = a0, m0 = a0, m1 = a0;
+            if (active)
             {
-                sims[k * 4 + 0] = pp;
-                sims[k * 4 + 1] = nn;
-                sims[k * 4 + 2] = pn;
-                sims[k * 4 + 3] = npv;
+                const int ri = col_idx[k];
+                const float4 *rr = reinterpret_cast<const float4 *>(rbank + (size_t)ri * BANK_EDGE + r8 * 8);
+                a0 = rr[0];
+                a1 = rr[1];
+                b0 = rr[BANK_SIDE / 4];
+                b1 = rr[BANK_SIDE / 4 + 1];
+                const float4 *lp4 = reinterpret_cast<const float4 *>(&s_left[((el * 2 + 0) * 7 + r8) * 8]);
+                const float4 *lm4 = reinterpret_cast<const float4 *>(&s_left[((el * 2 + 1) * 7 + r8) * 8]);
+                p0 = lp4[0];
+                p1 = lp4[1];
+                m0 = lm4[0];
+                m1 = lm4[1];
             }
-            if (best)
+            const float rp_[7] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z};
+            const float rm_[7] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z};
+            const float lp[7] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z};
+            const float lm[7] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z};
+            // four dots of this lane's rows, column by column (each accumulator sees its terms left to right, as dot7)
+            double s_pp, s_nn, s_pn, s_np;
+            {
+                const double lpd = (double)lp[0], lmd = (double)lm[0], rpd = (double)rp_[0], rmd = (double)rm_[0];
+                s_pp = lpd * rpd; // L+ . R+
+                s_nn = lmd * rmd; // L- . R-
+                s_pn = lpd * rmd; // L+ . R-
+                s_np = lmd * rpd; // L- . R+
+            }
+#pragma unroll
+            for (int c = 1; c < 7; ++c)
+            {
+                const double lpd = (double)lp[c], lmd = (double)lm[c], rpd = (double)rp_[c], rmd = (double)rm_[c];
+                s_pp = __builtin_fma(lpd, rpd, s_pp);
+                s_nn = __builtin_fma(lmd, rmd, s_nn);
+                s_pn = __builtin_fma(lpd, rmd, s_pn);
+                s_np = __builtin_fma(lmd, rpd, s_np);
+            }
+            const double d_pp = butterfly8(active ? s_pp : 0.0);
+            const double d_nn = butterfly8(active ? s_nn : 0.0);
+            const double d_pn = butterfly8(active ? s_pn : 0.0);
+            const double d_np = butterfly8(active ? s_np : 0.0);
+            if (valid && r8 == 0)
+            {
+                const bool lsent_p = p1.w != 0.0f, lsent_m = m1.w != 0.0f;
+                const bool rsent_p = a1.w != 0.0f, rsent_m = b1.w != 0.0f;
+                const double pp = (lsent_p || rsent_p) ? -1.0 : d_pp; // src/utility.cpp:170-172
+                const double nn = (lsent_m || rsent_m) ? -1.0 : d_nn;
+                const double pn = (lsent_p || rsent_m) ? -1.0 : d_pn;
+                const double npv = (lsent_m || rsent_p) ? -1.0 : d_np;
+                const double b = max4(pp, nn, pn, npv); // src/Stereo_Matches.cpp:596
+                double4 *sp = reinterpret_cast<double4 *>(sims + (size_t)k * 4);
+                *sp = make_double4(pp, nn, pn, npv);
                 best[k] = b;
-            if (keep)
-                keep[k] = (b > thr) ? 1 : 0;
-            mc += (b > thr) ? 1 : 0;
+                const bool m = b > thr; // :597
+                keep[k] = m ? 1 : 0;
+                mc += m ? 1 : 0;
+            }
         }
+        wave_lds_sync(); // the next tile's patches overwrite s_left
     }
     for (int d = 32; d > 0; d >>= 1)
         mc += __shfl_down(mc, d);
-    if ((threadIdx.x & 63) == 0)
-        s_mc[threadIdx.x >> 6] = mc;
+    __syncthreads();
+    if (lane == 0 && mc)
+        atomicAdd(&s_mc, mc);
     __syncthreads();
     if (threadIdx.x == 0)
-        match_part[blockIdx.x] = s_mc[0] + s_mc[1] + s_mc[2] + s_mc[3];
+        match_part[blockIdx.x] = s_mc;
 }
 
 // Last kernel of a device-resident pair: gathers every count the host wants into one record (PairResult,
@@ -1345,33 +1625,6 @@ int match_patches_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_img, int h, i
     return EBVO_OK;
 }
 
-// Normalised-patch banks (and sentinel flags) of the left and the right TOED edges of the resident pair: one sin/cos
-// launch and one sampling launch for both images.  The raw left patches are only produced when the host fetches them.
-int match_patch_banks_enqueue(ebvo_ctx *ctx, Slot &s, int h, int w, int cap_edges)
-{
-    int rc;
-    if ((rc = ebvo_grow(ctx, s, s.sincos, sizeof(double2) * 2 * (size_t)cap_edges)))
-        return rc;
-    PatchBatch B{};
-    for (int k = 0; k < 2; ++k)
-    {
-        B.img[k] = s.im[k].img;
-        B.edges[k] = s.im[k].edges;
-        B.n[k] = DevN{0, s.im[k].counts + 1};
-        B.sc[k] = (double2 *)s.sincos.p + (size_t)k * cap_edges;
-    }
-    B.norm[0] = (float *)s.patches_norm.p;
-    B.flag[0] = (uint8_t *)s.patches_flag.p;
-    B.norm[1] = (float *)s.patches_norm_r.p;
-    B.flag[1] = (uint8_t *)s.patches_flag_r.p;
-    ProfScope ps(ctx, s, K_PATCHES);
-    hipLaunchKernelGGL(sincos_batch_kernel, dim3(blocks_for(cap_edges, 256, 512), 2), dim3(256), 0, s.stream, B);
-    hipLaunchKernelGGL(patches_kernel, dim3(blocks_for((int64_t)cap_edges * 16, 256, 896), 2), dim3(256), 0, s.stream, B,
-                       h, w, w);
-    EBVO_HIP(ctx, hipGetLastError());
-    return EBVO_OK;
-}
-
 int match_ncc_pairs_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_imgR, int h, int w, int pitchR,
                             const ebvo_edge *d_Rc, const int32_t *d_row_ptr, int nL, int64_t n_pairs,
                             const float *d_left_norm, const uint8_t *d_left_flag, double thr, double *d_sims,
@@ -1404,34 +1657,48 @@ int match_ncc_pairs_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_imgR, int h
     return EBVO_OK;
 }
 
-// NCC of the CSR pairs in s.row_ptr / s.col_idx from the banks s.patches_norm(_r) / s.patches_flag(_r)
-int match_ncc_banked_enqueue(ebvo_ctx *ctx, Slot &s, int nL, const int32_t *d_nL, int cap_edges, int64_t n_pairs_host,
-                             double thr)
+// NCC of the CSR pairs in s.row_ptr / s.col_idx of the resident pair: sin/cos of both edge lists, the right bank, the
+// tile kernel.  s.patches_norm_r holds the right bank (BANK_EDGE floats per edge).
+int match_ncc_resident_enqueue(ebvo_ctx *ctx, Slot &s, int h, int w, int cap_edges, double thr)
 {
-    s.n_match_part = 0;
-    if (!d_nL && (n_pairs_host <= 0 || nL <= 0))
-        return EBVO_OK;
-    const DevN nLd{nL, d_nL};
-    const DevPairs np{n_pairs_host, d_nL ? (const int32_t *)s.row_ptr.p : nullptr, nLd, s.cap_pairs};
-    const int64_t cap_items = d_nL ? s.cap_pairs : n_pairs_host;
+    int rc;
+    if ((rc = ebvo_grow(ctx, s, s.sincos, sizeof(double2) * 2 * (size_t)cap_edges)))
+        return rc;
+    PatchBatch B{};
+    for (int k = 0; k < 2; ++k)
     {
-        ProfScope ps(ctx, s, K_MISC);
-        hipLaunchKernelGGL(expand_rows_kernel, dim3(blocks_for(d_nL ? cap_edges : nL, 256, 512)), dim3(256), 0, s.stream,
-                           (const int32_t *)s.row_ptr.p, nLd, (int32_t *)s.pair_left.p, s.cap_pairs);
+        B.img[k] = s.im[k].img;
+        B.edges[k] = s.im[k].edges;
+        B.n[k] = DevN{0, s.im[k].counts + 1};
+        B.sc[k] = (double2 *)s.sincos.p + (size_t)k * cap_edges;
+    }
+    const DevN nLd{0, s.im[0].counts + 1}, nRd{0, s.im[1].counts + 1};
+    {
+        ProfScope ps(ctx, s, K_PATCHES);
+        hipLaunchKernelGGL(row_pairs_kernel, dim3(blocks_for(((int64_t)h * w + 3) / 4, 256, 512), 2), dim3(256), 0, s.stream,
+                           (const uint8_t *)s.im[0].img, (const uint8_t *)s.im[1].img, s.im[0].pix2, s.im[1].pix2, h, w);
+        hipLaunchKernelGGL(sincos_batch_kernel, dim3(blocks_for(cap_edges, 256, 512), 2), dim3(256), 0, s.stream, B);
+        hipLaunchKernelGGL(right_bank_kernel, dim3(blocks_for((int64_t)cap_edges * 16, 256, 1024)), dim3(256), 0, s.stream,
+                           (const uint8_t *)s.im[1].img, (const uint16_t *)s.im[1].pix2, h, w, w, (const ebvo_edge *)s.im[1].edges, (const double2 *)B.sc[1],
+                           nRd, (float *)s.patches_norm_r.p);
     }
     {
         ProfScope ps(ctx, s, K_NCC_PAIRS);
-        const int nblk = blocks_for(cap_items * 16, 256, EBVO_MATCH_PARTS);
+        int nblk = (int)blocks_for(cap_edges, NCC_NW * 4, EBVO_MATCH_PARTS);
+        nblk = nblk < 8 ? 8 : (nblk & ~7); // the XCD-aware order needs a multiple of 8 (tiles are walked grid-stride)
         s.n_match_part = nblk;
-        hipLaunchKernelGGL(ncc_banked_kernel, dim3(nblk), dim3(256), 0, s.stream,
-                           (const float *)s.patches_norm.p, (const uint8_t *)s.patches_flag.p,
-                           (const float *)s.patches_norm_r.p, (const uint8_t *)s.patches_flag_r.p,
-                           (const int32_t *)s.pair_left.p, (const int32_t *)s.col_idx.p, np, thr, (double *)s.sims.p,
-                           (double *)s.best.p, (uint8_t *)s.keep.p, s.d_matches);
+        // NW = 4 left edges per wave, at most 5 waves per SIMD: measured best of {4, 8, 16} x {4, 5, 6, 8} (a bigger tile
+        // serialises more sampling rounds in one wave; a higher occupancy target spills)
+        hipLaunchKernelGGL((ncc_tile_kernel<NCC_NW, NCC_WPE>), dim3(nblk), dim3(256), 0, s.stream, (const uint8_t *)s.im[0].img,
+                           (const uint16_t *)s.im[0].pix2, h, w, w, (const ebvo_edge *)s.im[0].edges, (const double2 *)B.sc[0],
+                           nLd, (const int32_t *)s.row_ptr.p, (const int32_t *)s.col_idx.p, (const float *)s.patches_norm_r.p,
+                           s.cap_pairs, thr, (double *)s.sims.p, (double *)s.best.p, (uint8_t *)s.keep.p, s.d_matches);
     }
     EBVO_HIP(ctx, hipGetLastError());
     return EBVO_OK;
 }
+
+size_t match_right_bank_bytes(int cap_edges) { return sizeof(float) * BANK_EDGE * (size_t)cap_edges; }
 
 int match_pair_result_enqueue(ebvo_ctx *ctx, Slot &s)
 {

@@ -10,8 +10,8 @@
 // reference (doubles, no FMA contraction; the 49-term sums are sequential), so one thread owns one (left edge,
 // candidate) pair within an iteration.  Nothing is staged: a thread re-samples instead of storing (the 98 centred left
 // samples and the 3 x 98 right samples of an iteration would need ~2 KB per thread); re-evaluating a bilinear sample
-// returns the same bits, so the result is unchanged.  Only exp() (confidence) comes
-// from the device math library (<= 1 ulp from glibc's); cos/sin are csrc/ebvo_math.h's correctly rounded pair.
+// returns the same bits, so the result is unchanged.  exp() (confidence) and cos/sin are csrc/ebvo_math.h's shared
+// routines (the oracle's portable mode calls the same code): every output is bit-identical to the restatement.
 #include <hip/hip_runtime.h>
 
 #include "ebvo_internal.h"
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(256) void gn_iter_kernel(GnArgs A, int it)
                 {
                     A.valid[k] = is_outlier ? 0 : 1;
                     A.score[k] = rms;
-                    A.conf[k] = exp(-rms / A.huber);
+                    A.conf[k] = ebvo_exp(-rms / A.huber);
                     done_iters = it + 1;
                 }
                 else

@@ -393,6 +393,10 @@ int ebvo_profile_enable(ebvo_ctx *ctx, int on);
 int ebvo_profile_reset(ebvo_ctx *ctx);
 int ebvo_profile_get(ebvo_ctx *ctx, ebvo_kernel_time *out /* EBVO_MAX_KERNELS */, int *n);
 
+/* Test hooks, not part of the drop-in surface.  key 0: attempts of the regrow loop of ebvo_stereo_wait (0 = default 4);
+ * key 1: treat the next `value` pair results as "candidate buffers overflowed" (exercises the regrow / give-up path). */
+int ebvo_debug_set(ebvo_ctx *ctx, int key, int value);
+
 /* Raw FP64 vector-ALU microbenchmark (mul + add, no FMA) used to anchor the compute roofline:
  * returns achieved TFLOP/s over `iters` launches. */
 int ebvo_fp64_peak(ebvo_ctx *ctx, int iters, double *tflops_muladd, double *tflops_fma);

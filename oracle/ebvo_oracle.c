@@ -709,7 +709,7 @@ static void gn_stereo_one(const uint8_t *imgL, const uint8_t *imgR, const float 
         {
             *valid = is_outlier ? 0 : 1;
             *score = rms;
-            *conf = exp(-rms / huber);
+            *conf = math_mode == ORC_MATH_LIBM ? exp(-rms / huber) : ebvo_exp(-rms / huber);
             ++iter;
             break;
         }
@@ -1193,7 +1193,8 @@ void orc_epipolar_shift(const orc_edge *cand, const double *lines, const int32_t
  * average edge per cluster (weights exp(-0.5 ((d - mean d) / 2)^2) of the distance to the centroid), clusters ordered
  * by label.  Rows with a single candidate are left alone when skip_single is set (the cluster-only call, :998-999).
  * Outputs: new_count[nL]; centres[row_ptr[i] + c] for c < new_count[i]; cluster_of[k] = cluster index of candidate k. */
-static void gaussian_average(const orc_edge *E, const int32_t *lab, int n, int label, double *gx, double *gy, double *gt)
+static void gaussian_average(const orc_edge *E, const int32_t *lab, int n, int label, int math_mode, double *gx, double *gy,
+                             double *gt)
 {
     double sx = 0, sy = 0;
     int count = 0;
@@ -1225,7 +1226,8 @@ static void gaussian_average(const orc_edge *E, const int32_t *lab, int n, int l
             const double dx = E[i].x - cx, dy = E[i].y - cy;
             const double d = sqrt(dx * dx + dy * dy);
             const double q = (d - mean) / 2.0; /* CLUSTER_ORIENT_GAUSS_SIGMA */
-            const double g = exp(-0.5 * (q * q)); /* std::pow(q, 2) */
+            const double a = -0.5 * (q * q); /* std::pow(q, 2) */
+            const double g = math_mode == ORC_MATH_LIBM ? exp(a) : ebvo_exp(a);
             wx += g * E[i].x;
             wy += g * E[i].y;
             wt += g * E[i].theta;
@@ -1237,7 +1239,7 @@ static void gaussian_average(const orc_edge *E, const int32_t *lab, int n, int l
 }
 
 void orc_cluster_rows(const orc_edge *cand, const int32_t *row_ptr, int nL, int by_orientation, int skip_single,
-                      int32_t *new_count, orc_edge *centres, int32_t *cluster_of)
+                      int math_mode, int32_t *new_count, orc_edge *centres, int32_t *cluster_of)
 {
     const double orient_thr = 20.0 * M_PI / 180.0; /* deg_to_rad(CLUSTER_ORIENT_THRESH) */
     for (int r = 0; r < nL; r++)
@@ -1305,7 +1307,7 @@ void orc_cluster_rows(const orc_edge *cand, const int32_t *row_ptr, int nL, int 
             if (!present)
                 continue;
             double gx, gy, gt;
-            gaussian_average(E, lab, n, l, &gx, &gy, &gt);
+            gaussian_average(E, lab, n, l, math_mode, &gx, &gy, &gt);
             orc_edge c;
             c.x = gx;
             c.y = gy;
@@ -1340,6 +1342,12 @@ void orc_atan2_v(const double *y, const double *x, int n, int math_mode, double 
 {
     for (int k = 0; k < n; k++)
         out[k] = math_mode == ORC_MATH_LIBM ? atan2(y[k], x[k]) : ebvo_atan2(y[k], x[k]);
+}
+
+void orc_exp_v(const double *x, int n, int math_mode, double *out)
+{
+    for (int k = 0; k < n; k++)
+        out[k] = math_mode == ORC_MATH_LIBM ? exp(x[k]) : ebvo_exp(x[k]);
 }
 
 void orc_sincos_v(const double *t, int n, int math_mode, double *s, double *c)

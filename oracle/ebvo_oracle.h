@@ -95,6 +95,7 @@ void orc_ncc_quads(const float *kfL, const float *kfR, const float *cfL, const f
 /* element-wise math in the chosen mode (for tests of ebvo_math.h) */
 void orc_atan2_v(const double *y, const double *x, int n, int math_mode, double *out);
 void orc_sincos_v(const double *t, int n, int math_mode, double *s, double *c);
+void orc_exp_v(const double *x, int n, int math_mode, double *out);
 
 /* FNV-1a-64 helpers used by the known-answer tests. */
 uint64_t orc_fnv1a64(const uint8_t *bytes, size_t n);
@@ -144,7 +145,7 @@ void orc_epipolar_shift(const orc_edge *cand, const double *lines, const int32_t
 
 /* EdgeClusterer::performClustering per CSR row (src/EdgeClusterer.cpp:119-302; consolidate_redundant_edge_hypothesis
  * :1006-1034).  PARITY UNPINNED. */
-void orc_cluster_rows(const orc_edge *cand, const int32_t *row_ptr, int nL, int by_orientation, int skip_single,
+void orc_cluster_rows(const orc_edge *cand, const int32_t *row_ptr, int nL, int by_orientation, int skip_single, int math_mode,
                       int32_t *new_count, orc_edge *centres, int32_t *cluster_of);
 
 #ifdef __cplusplus

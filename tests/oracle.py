@@ -195,13 +195,13 @@ def epipolar_shift(cand, lines, row_ptr, math_mode=PORTABLE):
     return out
 
 
-def cluster_rows(cand, row_ptr, by_orientation=False, skip_single=True):
+def cluster_rows(cand, row_ptr, by_orientation=False, skip_single=True, math_mode=PORTABLE):
     cand = np.ascontiguousarray(cand, dtype=EDGE_DTYPE)
     row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int32)
     cnt = np.zeros(len(row_ptr) - 1, dtype=np.int32)
     centres = np.zeros(len(cand), dtype=EDGE_DTYPE)
     cluster_of = np.full(len(cand), -1, dtype=np.int32)
-    lib().orc_cluster_rows(_p(cand), _p(row_ptr), len(row_ptr) - 1, int(by_orientation), int(skip_single), _p(cnt),
+    lib().orc_cluster_rows(_p(cand), _p(row_ptr), len(row_ptr) - 1, int(by_orientation), int(skip_single), math_mode, _p(cnt),
                            _p(centres), _p(cluster_of))
     return cnt, centres, cluster_of
 
@@ -237,3 +237,10 @@ def sincos_v(t, math_mode):
     s, c = np.zeros(len(t)), np.zeros(len(t))
     lib().orc_sincos_v(_p(t), len(t), math_mode, _p(s), _p(c))
     return s, c
+
+
+def exp_v(x, math_mode):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.zeros(len(x))
+    lib().orc_exp_v(_p(x), len(x), math_mode, _p(out))
+    return out

@@ -138,6 +138,55 @@ def test_pipeline_grows_pair_buffers_on_overflow():
         assert (c2.n_pairs, c2.n_matches) == (c.n_pairs, c.n_matches)
 
 
+def test_wait_gives_up_with_capacity_error_and_recovers(ctx):
+    """Every attempt of the regrow loop reports an overflow (forced through the test hook): ebvo_stereo_wait must not
+    publish stale counts -- it returns EBVO_ERR_CAPACITY, the slot has no results, and the next run is unaffected."""
+    from edge_based_visual_odometry_amd._lib import EbvoError, EBVO_ERR_CAPACITY, EBVO_ERR_STATE
+    l, r = synth.stereo_pair("s2", 64, 96)
+    p = ctx.default_params(F_KITTI)
+    ctx.stereo_upload(l, r)
+    good = ctx.stereo_run(p)
+    ref = ctx.stereo_fetch(good)
+    ctx.debug_set(0, 2)                            # two attempts ...
+    ctx.debug_set(1, 2)                            # ... both "overflow"
+    try:
+        ctx.stereo_submit(p)
+        with pytest.raises(EbvoError) as ei:
+            ctx.stereo_wait()
+        assert ei.value.status == EBVO_ERR_CAPACITY
+        with pytest.raises(EbvoError) as ei:
+            ctx.stereo_fetch(good)                 # no results were published
+        assert ei.value.status == EBVO_ERR_STATE
+        ctx.debug_set(1, 1)                        # one forced overflow, then the real result: the regrow path itself
+        c = ctx.stereo_run(p)
+        out = ctx.stereo_fetch(c)
+    finally:
+        ctx.debug_set(0, 0)
+        ctx.debug_set(1, 0)
+    assert (c.n_pairs, c.n_matches) == (good.n_pairs, good.n_matches)
+    for key in ("row_ptr", "col_idx", "sims", "keep"):
+        assert_bit_equal(out[key], ref[key], key)
+
+
+def test_upload_invalidates_refined_and_final_results(ctx):
+    from edge_based_visual_odometry_amd._lib import EbvoError, EBVO_ERR_STATE
+    l, r = synth.stereo_pair("s2", 64, 96)
+    ctx.stereo_upload(l, r)
+    c = ctx.stereo_run(ctx.default_params(F_KITTI))
+    ctx.stereo_refine(c)
+    ctx.stereo_upload(l, r)                        # a new pair: the refinement of the old one is gone
+    with pytest.raises(EbvoError) as ei:
+        ctx._check(ctx.lib.ebvo_stereo_fetch_refined(ctx._ctx, 0, None, None, None, None, None, None),
+                   "ebvo_stereo_fetch_refined")
+    assert ei.value.status == EBVO_ERR_STATE
+    ctx.stereo_run(ctx.default_params(F_KITTI))
+    ctx.stereo_finalize(None)
+    ctx.stereo_upload(l, r)
+    with pytest.raises(EbvoError) as ei:
+        ctx._check(ctx.lib.ebvo_stereo_fetch_final(ctx._ctx, 0, None, None, None, None), "ebvo_stereo_fetch_final")
+    assert ei.value.status == EBVO_ERR_STATE
+
+
 def test_submit_wait_state_machine(ctx):
     from edge_based_visual_odometry_amd._lib import EbvoError, EBVO_ERR_STATE
     l, r = synth.stereo_pair("s2", 64, 96)

@@ -1,4 +1,4 @@
-"""csrc/ebvo_math.h (the atan2 / sincos both the oracle's portable mode and the HIP kernels use)
+"""csrc/ebvo_math.h (the atan2 / sincos / exp both the oracle's portable mode and the HIP kernels use)
 against glibc: identical except where glibc itself is not correctly rounded (<= 1 ulp, rare)."""
 import numpy as np
 
@@ -35,3 +35,20 @@ def test_sincos_agrees_with_libm():
         diff = a != b
         assert diff.mean() < 4e-3
         assert (np.abs(a - b)[diff] <= np.spacing(np.abs(b[diff]))).all()
+
+
+def test_exp_agrees_with_libm_and_mpmath():
+    import mpmath as mp
+    rng = np.random.default_rng(2)
+    x = np.concatenate([-rng.uniform(0, 90, 200_000), rng.uniform(-2, 2, 100_000), -rng.exponential(1e-3, 50_000),
+                        np.array([0.0, -0.0, -1e-300, -745.0, -746.0, 709.0, 710.0, -np.inf, np.inf, 1e-17, -0.5])])
+    a, b = orc.exp_v(x, orc.PORTABLE), orc.exp_v(x, orc.LIBM)
+    diff = a != b
+    assert diff.mean() < 2e-3
+    assert (np.abs(a - b)[diff] <= np.spacing(np.abs(b[diff]))).all()
+    assert np.isnan(orc.exp_v(np.array([np.nan]), orc.PORTABLE)).all()
+    # where the two disagree the shared routine is the correctly rounded one
+    mp.mp.prec = 200
+    for xv, av, bv in list(zip(x[diff], a[diff], b[diff]))[:200]:
+        exact = mp.exp(mp.mpf(float(xv)))
+        assert abs(mp.mpf(float(av)) - exact) <= abs(mp.mpf(float(bv)) - exact)

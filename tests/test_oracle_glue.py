@@ -176,7 +176,7 @@ def test_cluster_rows_matches_python_reading():
         cand["theta"][b:b + n] = rng.choice([0.3, 0.5, 1.2], n) + rng.uniform(-0.05, 0.05, n)
     for by_orient in (False, True):
         for skip in (True, False):
-            cnt, centres, cof = orc.cluster_rows(cand, rp, by_orient, skip)
+            cnt, centres, cof = orc.cluster_rows(cand, rp, by_orient, skip, orc.LIBM)   # math.exp below is glibc's
             for i in range(len(lens)):
                 b, n = rp[i], lens[i]
                 if n == 0:

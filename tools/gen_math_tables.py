@@ -48,3 +48,18 @@ p3hi, p3lo = dd(p3)
 print(f"#define EBVO_PIO2_1 {fmt(p1)}\n#define EBVO_PIO2_2 {fmt(p2)}")
 print(f"#define EBVO_PIO2_3_HI {fmt(p3hi)}\n#define EBVO_PIO2_3_LO {fmt(p3lo)}")
 print(f"#define EBVO_2_PI {fmt(2 / mp.pi)}")
+
+# ---- exp: exp(j/32) for j = -11 .. 11, and the Cody-Waite split of ln 2 ----
+print("EBVO_MATH_CONST double ebvo_exp_tab[23][2] = {")
+for j in range(-11, 12):
+    hi, lo = dd(mp.exp(mp.mpf(j) / 32))
+    print(f"    {{{fmt(hi)}, {fmt(lo)}}},")
+print("};")
+l2 = mp.log(2)
+l1 = chop(l2, 32)
+l2b = chop(l2 - l1, 32)
+l3 = l2 - l1 - l2b
+l3hi, l3lo = dd(l3)
+print(f"#define EBVO_LN2_1 {fmt(l1)}\n#define EBVO_LN2_2 {fmt(l2b)}")
+print(f"#define EBVO_LN2_3_HI {fmt(l3hi)}\n#define EBVO_LN2_3_LO {fmt(l3lo)}")
+print(f"#define EBVO_1_LN2 {fmt(1 / l2)}")

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """GPU occupancy of a multi-slot run from a rocprofv3 --kernel-trace database.
 
-usage: tools/rocprof_timeline.py <results.db> [skip-fraction]
+usage: tools/rocprof_timeline.py <results.db> [skip-fraction [until-fraction]]
 Prints, over the steady-state part of the run: the fraction of wall time with 0, 1, 2, ... kernels resident, the
 per-kernel average duration when alone on the device vs overlapped, and the gaps between consecutive kernels of
 one stream (dispatch latency the stream pays between dependent kernels).
@@ -14,8 +14,9 @@ db = sqlite3.connect(sys.argv[1])
 skip = float(sys.argv[2]) if len(sys.argv) > 2 else 0.3
 rows = db.execute("select name, stream_id, queue_id, start, end from kernels order by start").fetchall()
 t0, t1 = rows[0][3], max(r[4] for r in rows)
-lo = t0 + (t1 - t0) * skip
-rows = [r for r in rows if r[3] >= lo]
+until = float(sys.argv[3]) if len(sys.argv) > 3 else 1.0
+lo, hi = t0 + (t1 - t0) * skip, t0 + (t1 - t0) * until
+rows = [r for r in rows if r[3] >= lo and r[4] <= hi]
 t0, t1 = rows[0][3], max(r[4] for r in rows)
 ev = []
 for n, s, q, a, b in rows:
