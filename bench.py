@@ -182,28 +182,50 @@ def check_against_oracle(out, chk):
 
 
 def frame_loop(ctx, params, pool, nslots, steps, upload, fetch):
-    """`steps` pairs with `nslots` in flight; upload: a NEW pair from host memory per step; fetch: every result array
-    copied back.  Returns (seconds, bytes fetched per pair)."""
+    """`steps` pairs with `nslots` in flight; upload: a NEW pair from host memory per step; fetch: None, or the selection
+    (ebvo_hip.h EBVO_FETCH_*) copied back through the slot's page-locked staging (ebvo_stereo_fetch_begin / _end: the copy
+    of pair k runs while the other slots compute; slot k is resubmitted once its results have been read), or "pageable":
+    every array copied synchronously into fresh numpy arrays (ebvo_stereo_fetch).  Returns (seconds, bytes per pair)."""
     t0 = time.perf_counter()
     sub = done = 0
     nbytes = 0
-    while sub < min(nslots, steps):
-        if upload:
-            ctx.stereo_upload(*pool[sub % len(pool)], slot=sub % nslots)
-        ctx.stereo_submit(params, slot=sub % nslots)
-        sub += 1
-    while done < steps:
-        k = done % nslots
-        cnt = ctx.stereo_wait(slot=k)
-        done += 1
-        if fetch:
-            out = ctx.stereo_fetch(cnt, slot=k)
-            nbytes += sum(v.nbytes for v in out.values() if v is not None)
+
+    def launch(k):
+        nonlocal sub
         if sub < steps:
             if upload:
                 ctx.stereo_upload(*pool[sub % len(pool)], slot=k)
             ctx.stereo_submit(params, slot=k)
             sub += 1
+
+    def consume(k):
+        nonlocal nbytes
+        out = ctx.stereo_fetch_end(slot=k)
+        nbytes += sum(v.nbytes for v in out.values() if v is not None)
+        if out["keep"] is not None and int(out["keep"][-1]) > 1:      # touch the data
+            raise RuntimeError("keep flag out of range")
+
+    for k in range(min(nslots, steps)):
+        launch(k)
+    pending = None
+    while done < steps:
+        k = done % nslots
+        cnt = ctx.stereo_wait(slot=k)
+        done += 1
+        if fetch == "pageable":
+            out = ctx.stereo_fetch(cnt, slot=k)
+            nbytes += sum(v.nbytes for v in out.values() if v is not None)
+            launch(k)
+        elif fetch:
+            ctx.stereo_fetch_begin(slot=k, what=fetch)
+            if pending is not None:
+                consume(pending)
+                launch(pending)
+            pending = k
+        else:
+            launch(k)
+    if pending is not None:
+        consume(pending)
     return time.perf_counter() - t0, nbytes / max(1, steps)
 
 
@@ -322,13 +344,37 @@ def main():
     if rank == 0 and world == 1 and not args.no_transfer_legs:
         pool = [synth.stereo_pair("s2", H, W, scene=seq["scene"], noise_base=seq["noise_base"] + 10 * k,
                                   disparity=seq["disparity"]) for k in range(4)]
+        from edge_based_visual_odometry_amd import _lib as L_
         n_leg = max(nslots, min(args.steps, 60))
-        frame_loop(ctx, params, pool, nslots, nslots, True, False)            # touch the pool once
-        t_up, _ = frame_loop(ctx, params, pool, nslots, n_leg, True, False)
-        t_all, mb = frame_loop(ctx, params, pool, nslots, n_leg, True, True)
-        legs = {"with_h2d": n_leg / t_up, "with_h2d_d2h": n_leg / t_all, "d2h_bytes_per_pair": mb, "pairs": n_leg,
-                "note": "a new pair uploaded from pageable host memory per step (0.93 MB); d2h = both edge lists, CSR, "
-                        "four scores + best + keep per candidate pair, into numpy arrays"}
+        frame_loop(ctx, params, pool, nslots, nslots, True, None)             # touch the pool once
+        t_up, _ = frame_loop(ctx, params, pool, nslots, n_leg, True, None)
+        t_def, mb_def = frame_loop(ctx, params, pool, nslots, n_leg, True, L_.FETCH_DEFAULT)
+        t_all, mb_all = frame_loop(ctx, params, pool, nslots, n_leg, True, L_.FETCH_ALL)
+        t_pg, mb_pg = frame_loop(ctx, params, pool, nslots, max(nslots, n_leg // 3), True, "pageable")
+        # the drop-in path: what main_VO executes through integration/*.cpp -- host-buffer entry points, results in host
+        # arrays, one call after the other (src/Pipeline.cpp:24-29, :109-145): TOED of both images, epipolar lines,
+        # candidate search (the three geometric stages in one call), NCC with left patches
+        n_b = 5
+        tb = time.perf_counter()
+        for k in range(n_b):
+            bl, br = pool[k % len(pool)]
+            eL, eR, _ = ctx.toed_pair(bl, br)
+            lines_b = ctx.epipolar_lines(F, eL)
+            rp_b, ci_b = ctx.epi_candidates(eL, eR, lines_b)
+            ctx.ncc_pairs(bl, br, eL, eR[ci_b], rp_b, want_left_patches=True)
+        t_b = (time.perf_counter() - tb) / n_b
+        legs = {"boundary_pairs_per_s": 1.0 / t_b,
+                "boundary_note": "the stage-wise drop-in sequence through the host-buffer C entry points (ebvo_toed_pair, "
+                                 "ebvo_epipolar_lines, ebvo_epi_candidates with all three stages, ebvo_ncc_pairs with left "
+                                 "patches), every input and output in pageable host arrays, no overlap between calls",
+                "with_h2d": n_leg / t_up, "with_h2d_d2h": n_leg / t_def, "d2h_bytes_per_pair": mb_def,
+                "with_h2d_d2h_all_scores": n_leg / t_all, "d2h_bytes_per_pair_all_scores": mb_all,
+                "with_h2d_d2h_pageable_copies": max(nslots, n_leg // 3) / t_pg, "transfer_leg_pairs": n_leg,
+                "transfer_note": "a new pair uploaded from pageable host memory per step (0.93 MB).  d2h = both edge lists, the "
+                                 "CSR candidate lists, best score and keep flag per pair through the slot's page-locked staging "
+                                 "(ebvo_stereo_fetch_begin / _end, the copy overlaps the other slots' kernels); all_scores adds "
+                                 "the four scores per pair; pageable_copies = every array into fresh numpy arrays with "
+                                 "synchronous copies (round 1's 343 pairs/s)"}
         for k in range(nslots):                                               # restore the resident workload
             ctx.stereo_upload(left, right, slot=k)
 

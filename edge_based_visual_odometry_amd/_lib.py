@@ -42,7 +42,7 @@ ABI_SYMBOLS = (
     "ebvo_profile_reset", "ebvo_profile_get", "ebvo_fp64_peak",
     "ebvo_gn_default_params", "ebvo_sobel_gradients", "ebvo_gn_refine_stereo", "ebvo_stereo_refine",
     "ebvo_stereo_fetch_refined", "ebvo_gn_refine_temporal", "ebvo_finalize_pairs", "ebvo_bnb_test", "ebvo_keep_best", "ebvo_epipolar_shift", "ebvo_cluster_rows", "ebvo_stereo_finalize", "ebvo_stereo_fetch_final",
-    "ebvo_debug_set",
+    "ebvo_debug_set", "ebvo_stereo_fetch_begin", "ebvo_stereo_fetch_end",
 )
 
 
@@ -72,6 +72,15 @@ class FinalizeCounts(C.Structure):
 class StereoCounts(C.Structure):
     _fields_ = [("n_left", C.c_int32), ("n_right", C.c_int32), ("n_total_left", C.c_int32),
                 ("n_total_right", C.c_int32), ("n_pairs", C.c_int64), ("n_matches", C.c_int64)]
+
+
+class StereoView(C.Structure):
+    _fields_ = [("left", C.c_void_p), ("right", C.c_void_p), ("row_ptr", C.c_void_p), ("col_idx", C.c_void_p),
+                ("sims", C.c_void_p), ("best", C.c_void_p), ("keep", C.c_void_p), ("n_left", C.c_int32),
+                ("n_right", C.c_int32), ("n_pairs", C.c_int64)]
+
+
+FETCH_EDGES, FETCH_CSR, FETCH_BEST, FETCH_KEEP, FETCH_SIMS, FETCH_DEFAULT, FETCH_ALL = 1, 2, 4, 8, 16, 15, 31
 
 
 class KernelTime(C.Structure):
@@ -136,6 +145,8 @@ def load_library() -> C.CDLL:
     lib.ebvo_profile_get.argtypes = [vp, C.POINTER(KernelTime), C.POINTER(i32)]
     lib.ebvo_fp64_peak.argtypes = [vp, i32, C.POINTER(dbl), C.POINTER(dbl)]
     lib.ebvo_debug_set.argtypes = [vp, i32, i32]
+    lib.ebvo_stereo_fetch_begin.argtypes = [vp, i32, i32]
+    lib.ebvo_stereo_fetch_end.argtypes = [vp, i32, C.POINTER(StereoView)]
     lib.ebvo_gn_default_params.restype = None
     lib.ebvo_gn_default_params.argtypes = [C.POINTER(GnParams)]
     lib.ebvo_sobel_gradients.argtypes = [vp, vp, i32, i32, ssz, vp, vp]

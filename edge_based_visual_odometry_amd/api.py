@@ -396,6 +396,28 @@ class Context:
         return dict(left=left, right=right, row_ptr=row_ptr, col_idx=col, sims=sims, best=best, keep=keep,
                     left_patches=lp)
 
+    def stereo_fetch_begin(self, slot: int = 0, what: int = _lib.FETCH_DEFAULT):
+        """Enqueue the device-to-host copies of a finished pair's results into the slot's page-locked staging."""
+        self._check(self.lib.ebvo_stereo_fetch_begin(self._ctx, slot, what), "ebvo_stereo_fetch_begin")
+
+    def stereo_fetch_end(self, slot: int = 0) -> dict:
+        """Wait for the copies and return numpy VIEWS of the page-locked arrays (valid until the slot is reused)."""
+        v = _lib.StereoView()
+        self._check(self.lib.ebvo_stereo_fetch_end(self._ctx, slot, C.byref(v)), "ebvo_stereo_fetch_end")
+
+        def view(ptr_, count, dtype):
+            if not ptr_ or count == 0:
+                return None if not ptr_ else np.zeros(0, dtype=dtype)
+            nbytes = int(count) * np.dtype(dtype).itemsize
+            buf = (C.c_ubyte * nbytes).from_address(ptr_)
+            return np.frombuffer(buf, dtype=dtype, count=int(count))
+
+        sims = view(v.sims, v.n_pairs * 4, np.float64)
+        return dict(left=view(v.left, v.n_left, EDGE_DTYPE), right=view(v.right, v.n_right, EDGE_DTYPE),
+                    row_ptr=view(v.row_ptr, v.n_left + 1, np.int32), col_idx=view(v.col_idx, v.n_pairs, np.int32),
+                    sims=None if sims is None else sims.reshape(-1, 4), best=view(v.best, v.n_pairs, np.float64),
+                    keep=view(v.keep, v.n_pairs, np.uint8))
+
     def debug_set(self, key: int, value: int):
         """Test hooks (ebvo_debug_set): 0 = attempts of the regrow loop, 1 = force N overflowed results."""
         self._check(self.lib.ebvo_debug_set(self._ctx, key, value), "ebvo_debug_set")

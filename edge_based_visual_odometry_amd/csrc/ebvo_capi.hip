@@ -151,6 +151,8 @@ static void slot_destroy(Slot *s)
     (void)hipFree(s->d_result);
     if (s->h_result)
         (void)hipHostFree(s->h_result);
+    if (s->h_arena)
+        (void)hipHostFree(s->h_arena);
     if (s->stream)
         (void)hipStreamDestroy(s->stream);
     delete s;
@@ -346,6 +348,7 @@ static int host_slot(ebvo_ctx *ctx, Slot **out)
         return EBVO_ERR_STATE;
     }
     s.have_pair = s.have_run = s.have_refined = s.have_final = false;
+    s.fetch_what = 0;
     *out = &s;
     return EBVO_OK;
 }
@@ -877,6 +880,10 @@ extern "C" int ebvo_stereo_upload_slot(ebvo_ctx *ctx, int slot, const uint8_t *i
     if (s.in_flight)
         return EBVO_ERR_STATE;
     s.have_pair = s.have_run = s.have_refined = s.have_final = false; // results of the previous pair are gone
+    if (s.fetch_pending) // a result copy of the previous pair is still reading the buffers
+        EBVO_HIP(ctx, hipStreamSynchronize(s.stream));
+    s.fetch_pending = false;
+    s.fetch_what = 0;
     if ((rc = upload_image(ctx, s, 0, img_left, h, w, stride_left)))
         return rc;
     if ((rc = upload_image(ctx, s, 1, img_right, h, w, stride_right)))
@@ -956,6 +963,8 @@ extern "C" int ebvo_stereo_submit(ebvo_ctx *ctx, int slot, const ebvo_stereo_par
     EBVO_HIP(ctx, hipSetDevice(ctx->device));
     int rc;
     s.have_run = s.have_refined = s.have_final = false;
+    s.fetch_pending = false; // stream order: the kernels below run after any copy still enqueued on this stream
+    s.fetch_what = 0;
     s.params = *p;
     s.prof_now = ctx->prof && (ctx->prof_submits++ % ctx->prof_every == 0);
     {
@@ -1535,6 +1544,95 @@ extern "C" int ebvo_stereo_fetch_slot(ebvo_ctx *ctx, int slot, ebvo_edge *left, 
         EBVO_HIP(ctx, hipMemcpyAsync(left_patches, s.patches_raw.p, sizeof(float) * 98 * nL, hipMemcpyDeviceToHost, st));
     }
     EBVO_HIP(ctx, hipStreamSynchronize(st));
+    return EBVO_OK;
+}
+
+
+// ---- results through page-locked memory, no staging copy on the host ------------------------------------------------
+extern "C" int ebvo_stereo_fetch_begin(ebvo_ctx *ctx, int slot, int what)
+{
+    Slot *sp;
+    if (get_slot(ctx, slot, &sp) || what <= 0 || (what & ~EBVO_FETCH_ALL))
+        return EBVO_ERR_ARG;
+    Slot &s = *sp;
+    if (!s.have_run || s.in_flight)
+        return EBVO_ERR_STATE;
+    EBVO_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t nL = (size_t)s.result.n_left, nR = (size_t)s.result.n_right, np = (size_t)s.result.n_pairs;
+    const size_t sizes[7] = {(what & EBVO_FETCH_EDGES) ? sizeof(ebvo_edge) * nL : 0,
+                             (what & EBVO_FETCH_EDGES) ? sizeof(ebvo_edge) * nR : 0,
+                             (what & EBVO_FETCH_CSR) ? sizeof(int32_t) * (nL + 1) : 0,
+                             (what & EBVO_FETCH_CSR) ? sizeof(int32_t) * np : 0,
+                             (what & EBVO_FETCH_SIMS) ? sizeof(double) * 4 * np : 0,
+                             (what & EBVO_FETCH_BEST) ? sizeof(double) * np : 0,
+                             (what & EBVO_FETCH_KEEP) ? np : 0};
+    size_t total = 0;
+    for (int k = 0; k < 7; ++k)
+    {
+        s.fetch_off[k] = total;
+        total += (sizes[k] + 63) & ~(size_t)63;
+    }
+    if (total > s.h_arena_bytes)
+    {
+        if (s.fetch_pending)
+            EBVO_HIP(ctx, hipStreamSynchronize(s.stream));
+        if (s.h_arena)
+            (void)hipHostFree(s.h_arena);
+        s.h_arena = nullptr;
+        s.h_arena_bytes = 0;
+        const size_t want = total + total / 4 + 4096;
+        if (hipHostMalloc(&s.h_arena, want) != hipSuccess)
+        {
+            (void)hipGetLastError();
+            ctx->last_error = "hipHostMalloc failed (page-locked result staging)";
+            return EBVO_ERR_NOMEM;
+        }
+        s.h_arena_bytes = want;
+    }
+    const void *src[7] = {s.im[0].edges, s.im[1].edges, s.row_ptr.p, s.col_idx.p, s.sims.p, s.best.p, s.keep.p};
+    char *base = static_cast<char *>(s.h_arena);
+    for (int k = 0; k < 7; ++k)
+        if (sizes[k])
+            EBVO_HIP(ctx, hipMemcpyAsync(base + s.fetch_off[k], src[k], sizes[k], hipMemcpyDeviceToHost, s.stream));
+    s.fetch_what = what;
+    s.fetch_pending = true;
+    return EBVO_OK;
+}
+
+extern "C" int ebvo_stereo_fetch_end(ebvo_ctx *ctx, int slot, ebvo_stereo_view *view)
+{
+    Slot *sp;
+    if (!view || get_slot(ctx, slot, &sp))
+        return EBVO_ERR_ARG;
+    Slot &s = *sp;
+    if (!s.have_run || s.in_flight || !s.fetch_what)
+        return EBVO_ERR_STATE;
+    EBVO_HIP(ctx, hipSetDevice(ctx->device));
+    if (s.fetch_pending)
+        EBVO_HIP(ctx, hipStreamSynchronize(s.stream));
+    s.fetch_pending = false;
+    const char *base = static_cast<const char *>(s.h_arena);
+    const int what = s.fetch_what;
+    memset(view, 0, sizeof *view);
+    view->n_left = s.result.n_left;
+    view->n_right = s.result.n_right;
+    view->n_pairs = s.result.n_pairs;
+    if (what & EBVO_FETCH_EDGES)
+    {
+        view->left = reinterpret_cast<const ebvo_edge *>(base + s.fetch_off[0]);
+        view->right = reinterpret_cast<const ebvo_edge *>(base + s.fetch_off[1]);
+    }
+    if (what & EBVO_FETCH_CSR)
+    {
+        view->row_ptr = reinterpret_cast<const int32_t *>(base + s.fetch_off[2]);
+        view->col_idx = reinterpret_cast<const int32_t *>(base + s.fetch_off[3]);
+    }
+    if (what & EBVO_FETCH_SIMS)
+        view->sims = reinterpret_cast<const double *>(base + s.fetch_off[4]);
+    if (what & EBVO_FETCH_BEST)
+        view->best = reinterpret_cast<const double *>(base + s.fetch_off[5]);
+    if (what & EBVO_FETCH_KEEP)
+        view->keep = reinterpret_cast<const uint8_t *>(base + s.fetch_off[6]);
     return EBVO_OK;
 }
 

@@ -124,6 +124,11 @@ struct Slot
     int32_t *d_sizes = nullptr;          // [4] host-provided sizes for the host-buffer entry points
     double *d_F = nullptr;               // 9 doubles
     PairResult *d_result = nullptr, *h_result = nullptr; // h_result is pinned
+    void *h_arena = nullptr;             // pinned staging of ebvo_stereo_fetch_begin / _end
+    size_t h_arena_bytes = 0;
+    int fetch_what = 0;                  // arrays in flight to / present in h_arena
+    bool fetch_pending = false;          // copies enqueued, not yet waited for
+    size_t fetch_off[7] = {0};           // left, right, row_ptr, col_idx, sims, best, keep
     ebvo_stereo_params params{};
     PairResult result{};                 // last completed result
 

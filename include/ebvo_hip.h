@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define EBVO_ABI_VERSION 2 /* 2: photometric refinement, stage glue, finalisation, resident chain */
+#define EBVO_ABI_VERSION 3 /* 2: photometric refinement, stage glue, finalisation, resident chain; 3: pinned result views */
 
 typedef struct ebvo_ctx ebvo_ctx;
 
@@ -378,6 +378,36 @@ int ebvo_stereo_submit(ebvo_ctx *ctx, int slot, const ebvo_stereo_params *p);
 int ebvo_stereo_wait(ebvo_ctx *ctx, int slot, ebvo_stereo_counts *counts);
 int ebvo_stereo_fetch_slot(ebvo_ctx *ctx, int slot, ebvo_edge *left, ebvo_edge *right, int32_t *row_ptr,
                            int32_t *col_idx, double *sims, double *best, uint8_t *keep, float *left_patches);
+
+/* Results of a finished pair WITHOUT a staging copy on the host: ebvo_stereo_fetch_begin enqueues the device-to-host copies
+ * of the selected arrays into page-locked memory owned by the slot and returns at once (the copy engine works while
+ * other slots compute); ebvo_stereo_fetch_end waits for them and hands out read-only pointers, valid until the next
+ * upload / submit / host-buffer call on that slot.  What the stage-wise reference code consumes per pair is the default
+ * selection (both edge lists, the CSR candidate lists, best score and keep flag per pair: ~16 MB at 126 k edges per
+ * image); the four individual scores are another 32 bytes per pair. */
+enum
+{
+    EBVO_FETCH_EDGES = 1, /* left, right */
+    EBVO_FETCH_CSR = 2,   /* row_ptr, col_idx */
+    EBVO_FETCH_BEST = 4,
+    EBVO_FETCH_KEEP = 8,
+    EBVO_FETCH_SIMS = 16,
+    EBVO_FETCH_DEFAULT = 15,
+    EBVO_FETCH_ALL = 31
+};
+typedef struct ebvo_stereo_view
+{
+    const ebvo_edge *left, *right; /* n_left, n_right */
+    const int32_t *row_ptr;        /* n_left + 1 */
+    const int32_t *col_idx;        /* n_pairs */
+    const double *sims;            /* n_pairs x 4 (pp, nn, pn, np) */
+    const double *best;            /* n_pairs */
+    const uint8_t *keep;           /* n_pairs */
+    int32_t n_left, n_right;
+    int64_t n_pairs;
+} ebvo_stereo_view; /* pointers of arrays that were not selected are NULL */
+int ebvo_stereo_fetch_begin(ebvo_ctx *ctx, int slot, int what);
+int ebvo_stereo_fetch_end(ebvo_ctx *ctx, int slot, ebvo_stereo_view *view);
 
 /* Per-kernel device timing (HIP events on the slots' streams, accumulated). */
 #define EBVO_MAX_KERNELS 24
