@@ -43,6 +43,7 @@ ABI_SYMBOLS = (
     "ebvo_gn_default_params", "ebvo_sobel_gradients", "ebvo_gn_refine_stereo", "ebvo_stereo_refine",
     "ebvo_stereo_fetch_refined", "ebvo_gn_refine_temporal", "ebvo_finalize_pairs", "ebvo_bnb_test", "ebvo_keep_best", "ebvo_epipolar_shift", "ebvo_cluster_rows", "ebvo_stereo_finalize", "ebvo_stereo_fetch_final",
     "ebvo_debug_set", "ebvo_stereo_fetch_begin", "ebvo_stereo_fetch_end",
+    "ebvo_undistort", "ebvo_stereo_set_undistort",
 )
 
 
@@ -72,6 +73,11 @@ class FinalizeCounts(C.Structure):
 class StereoCounts(C.Structure):
     _fields_ = [("n_left", C.c_int32), ("n_right", C.c_int32), ("n_total_left", C.c_int32),
                 ("n_total_right", C.c_int32), ("n_pairs", C.c_int64), ("n_matches", C.c_int64)]
+
+
+class UndistortParams(C.Structure):
+    _fields_ = [("K_left", C.c_double * 4), ("K_right", C.c_double * 4), ("dist_left", C.c_double * 5),
+                ("dist_right", C.c_double * 5), ("n_dist", C.c_int), ("reserved", C.c_int)]
 
 
 class StereoView(C.Structure):
@@ -146,6 +152,8 @@ def load_library() -> C.CDLL:
     lib.ebvo_fp64_peak.argtypes = [vp, i32, C.POINTER(dbl), C.POINTER(dbl)]
     lib.ebvo_debug_set.argtypes = [vp, i32, i32]
     lib.ebvo_stereo_fetch_begin.argtypes = [vp, i32, i32]
+    lib.ebvo_undistort.argtypes = [vp, vp, i32, i32, ssz, vp, vp, i32, vp, ssz]
+    lib.ebvo_stereo_set_undistort.argtypes = [vp, C.POINTER(UndistortParams)]
     lib.ebvo_stereo_fetch_end.argtypes = [vp, i32, C.POINTER(StereoView)]
     lib.ebvo_gn_default_params.restype = None
     lib.ebvo_gn_default_params.argtypes = [C.POINTER(GnParams)]

@@ -158,6 +158,33 @@ class Context:
         self._check(rc, "ebvo_ncc_pairs")
         return sims, best, keep, lp
 
+    # -- cv::undistort (src/Pipeline.cpp:78-79) ---------------------------------------------------------
+    def undistort(self, img, K, dist):
+        img = _u8(img)
+        h, w = img.shape
+        K = np.ascontiguousarray(K, dtype=np.float64).reshape(4)
+        dist = np.ascontiguousarray(dist, dtype=np.float64).reshape(-1)
+        out = np.zeros((h, w), dtype=np.uint8)
+        self._check(self.lib.ebvo_undistort(self._ctx, ptr(img), h, w, img.strides[0], ptr(K), ptr(dist), len(dist), ptr(out),
+                                            out.strides[0]), "ebvo_undistort")
+        return out
+
+    def set_undistort(self, K_left=None, dist_left=None, K_right=None, dist_right=None):
+        """Resident pipeline: undistort the uploaded pair (TOED / refinement on the result, NCC on the raw images).
+        No arguments: off."""
+        if K_left is None:
+            self._check(self.lib.ebvo_stereo_set_undistort(self._ctx, None), "ebvo_stereo_set_undistort")
+            return
+        p = _lib.UndistortParams()
+        n = len(dist_left)
+        assert len(dist_right) == n and n in (4, 5)
+        for k in range(4):
+            p.K_left[k], p.K_right[k] = float(K_left[k]), float(K_right[k])
+        for k in range(n):
+            p.dist_left[k], p.dist_right[k] = float(dist_left[k]), float(dist_right[k])
+        p.n_dist = n
+        self._check(self.lib.ebvo_stereo_set_undistort(self._ctx, C.byref(p)), "ebvo_stereo_set_undistort")
+
     # -- util_compute_Img_Gradients (include/utility.h:131-141) -----------------------------------
     def sobel_gradients(self, img):
         img = _u8(img)

@@ -121,6 +121,8 @@ static void slot_destroy(Slot *s)
         ImageWS &ws = s->im[k];
         (void)hipFree(ws.img_base);
         (void)hipFree(ws.pix2);
+        (void)hipFree(ws.raw_base);
+        (void)hipFree(ws.undist_xs);
         (void)hipFree(ws.maps);
         (void)hipFree(ws.flag);
         (void)hipFree(ws.row_cnt);
@@ -137,7 +139,7 @@ static void slot_destroy(Slot *s)
         (void)hipFree(ws.cand_lists);
         (void)hipFree(ws.cand_lcount);
     }
-    GrowBuf *bufs[] = {&s->lines,        &s->boxes_chunk,  &s->boxes_group,    &s->cand_cnt,       &s->cand_stage, &s->cand_tileflag, &s->row_ptr, &s->grad_x, &s->grad_y, &s->gn_xy, &s->gn_out, &s->gn_valid, &s->gn_iters, &s->gn_state, &s->gn_lists, &s->fin_i32, &s->fin_edges, &s->fin_f64, &s->fin_u8, &s->fin_out,
+    GrowBuf *bufs[] = {&s->lines,        &s->boxes_chunk,  &s->boxes_group,    &s->cand_cnt,       &s->cand_stage, &s->cand_tileflag, &s->row_ptr, &s->grad_x, &s->grad_y, &s->gn_xy, &s->gn_out, &s->gn_valid, &s->gn_iters, &s->gn_state, &s->gn_lists, &s->gn_pack, &s->fin_i32, &s->fin_edges, &s->fin_f64, &s->fin_u8, &s->fin_out,
                        &s->scan_tmp,     &s->col_idx,      &s->rc_edges,       &s->sims,           &s->best,
                        &s->keep,         &s->patches_raw,  &s->patches_norm,   &s->patches_flag,   &s->patches_norm_r,
                        &s->patches_flag_r, &s->pair_left,  &s->sincos,         &s->scratch_b,      &s->scratch_c,
@@ -186,6 +188,13 @@ static int slot_create(ebvo_ctx *ctx, Slot **out)
         ws.img = ws.img_base + 64;
         CK(hipMalloc(&ws.pix2, sizeof(uint16_t) * ((size_t)ctx->max_h * ctx->max_w + 64)));
         CK(hipMemsetAsync(ws.pix2, 0, sizeof(uint16_t) * ((size_t)ctx->max_h * ctx->max_w + 64), s->stream));
+        CK(hipMalloc(&ws.undist_xs, sizeof(double) * (size_t)ctx->max_w));
+        if (ctx->undist_on)
+        {
+            CK(hipMalloc(&ws.raw_base, (size_t)ctx->max_h * ctx->max_w + 128));
+            CK(hipMemsetAsync(ws.raw_base, 0, (size_t)ctx->max_h * ctx->max_w + 128, s->stream));
+            ws.raw = ws.raw_base + 64;
+        }
         CK(hipMalloc(&ws.maps, sizeof(double) * np2 * PL_NUM));
         CK(hipMalloc(&ws.flag, np2));
         CK(hipMalloc(&ws.row_cnt, sizeof(int32_t) * 2 * H2));
@@ -324,16 +333,17 @@ static int check_size(ebvo_ctx *ctx, int h, int w)
     return EBVO_OK;
 }
 
-static int upload_image(ebvo_ctx *ctx, Slot &s, int k, const uint8_t *img, int h, int w, ptrdiff_t stride)
+static int upload_image(ebvo_ctx *ctx, Slot &s, int k, const uint8_t *img, int h, int w, ptrdiff_t stride, bool to_raw = false)
 {
     if (stride < w)
         return EBVO_ERR_ARG;
+    uint8_t *dst = to_raw ? s.im[k].raw : s.im[k].img;
     // a tightly packed image is ONE linear copy: the 2-D copy of pageable memory is staged row by row (measured 3 ms
     // per KITTI image against 0.1 ms)
     if (stride == (ptrdiff_t)w)
-        EBVO_HIP(ctx, hipMemcpyAsync(s.im[k].img, img, (size_t)w * h, hipMemcpyHostToDevice, s.stream));
+        EBVO_HIP(ctx, hipMemcpyAsync(dst, img, (size_t)w * h, hipMemcpyHostToDevice, s.stream));
     else
-        EBVO_HIP(ctx, hipMemcpy2DAsync(s.im[k].img, (size_t)w, img, (size_t)stride, (size_t)w, (size_t)h,
+        EBVO_HIP(ctx, hipMemcpy2DAsync(dst, (size_t)w, img, (size_t)stride, (size_t)w, (size_t)h,
                                        hipMemcpyHostToDevice, s.stream));
     return EBVO_OK;
 }
@@ -348,6 +358,7 @@ static int host_slot(ebvo_ctx *ctx, Slot **out)
         return EBVO_ERR_STATE;
     }
     s.have_pair = s.have_run = s.have_refined = s.have_final = false;
+    s.undist_pair = false;
     s.fetch_what = 0;
     *out = &s;
     return EBVO_OK;
@@ -884,9 +895,10 @@ extern "C" int ebvo_stereo_upload_slot(ebvo_ctx *ctx, int slot, const uint8_t *i
         EBVO_HIP(ctx, hipStreamSynchronize(s.stream));
     s.fetch_pending = false;
     s.fetch_what = 0;
-    if ((rc = upload_image(ctx, s, 0, img_left, h, w, stride_left)))
+    s.undist_pair = ctx->undist_on; // the pair goes to the raw buffers; submit undistorts it into img
+    if ((rc = upload_image(ctx, s, 0, img_left, h, w, stride_left, s.undist_pair)))
         return rc;
-    if ((rc = upload_image(ctx, s, 1, img_right, h, w, stride_right)))
+    if ((rc = upload_image(ctx, s, 1, img_right, h, w, stride_right, s.undist_pair)))
         return rc;
     EBVO_HIP(ctx, hipStreamSynchronize(s.stream));
     s.cur_h = h;
@@ -975,6 +987,15 @@ extern "C" int ebvo_stereo_submit(ebvo_ctx *ctx, int slot, const ebvo_stereo_par
             return rc;
     }
     EBVO_HIP(ctx, hipMemcpyAsync(s.d_F, s.params.F21, sizeof(double) * 9, hipMemcpyHostToDevice, s.stream));
+    if (s.undist_pair) // cv::undistort of both raw images (src/Pipeline.cpp:78-79); TOED runs on the result (:93, :97)
+    {
+        const ebvo_undistort_params &u = ctx->undist;
+        if ((rc = refine_undistort_enqueue(ctx, s, s.im[0].raw, s.cur_w, s.cur_h, s.cur_w, u.K_left, u.dist_left, u.n_dist,
+                                           s.im[0].undist_xs, s.im[0].img, s.cur_w)) ||
+            (rc = refine_undistort_enqueue(ctx, s, s.im[1].raw, s.cur_w, s.cur_h, s.cur_w, u.K_right, u.dist_right, u.n_dist,
+                                           s.im[1].undist_xs, s.im[1].img, s.cur_w)))
+            return rc;
+    }
     if ((rc = toed_enqueue(ctx, s, 2, s.cur_h, s.cur_w, nullptr, nullptr, nullptr)))
         return rc;
     if ((rc = enqueue_matching(ctx, s)))
@@ -1448,9 +1469,9 @@ extern "C" int ebvo_stereo_finalize(ebvo_ctx *ctx, int slot, const ebvo_finalize
     {
         // 6. second NCC pass on the cluster centres (:1500) -> keep2 / best2, 7. the best survivor of every row (:1513).
         // The normalised left patches (left_edge_patches, :578) are sampled here: the first pass keeps them in LDS only.
-        if ((rc = match_patches_enqueue(ctx, s, s.im[0].img, h, w, w, s.im[0].edges, nL, nullptr, 0, nullptr,
+        if ((rc = match_patches_enqueue(ctx, s, ncc_img(s, 0), h, w, w, s.im[0].edges, nL, nullptr, 0, nullptr,
                                         (float *)s.patches_norm.p, (uint8_t *)s.patches_flag.p)) ||
-            (rc = match_ncc_pairs_enqueue(ctx, s, s.im[1].img, h, w, w, candA, rpA, nL, nE, (const float *)s.patches_norm.p,
+            (rc = match_ncc_pairs_enqueue(ctx, s, ncc_img(s, 1), h, w, w, candA, rpA, nL, nE, (const float *)s.patches_norm.p,
                                           (const uint8_t *)s.patches_flag.p, p->ncc_thr, nullptr, best2, keep2, ncc_left,
                                           sincos2)) ||
             (rc = glue_rows_from_flags_enqueue(ctx, s, rpA, nL, keep2, cnt, order)) || (rc = scan_counts(rpB, &nF)) ||
@@ -1537,7 +1558,7 @@ extern "C" int ebvo_stereo_fetch_slot(ebvo_ctx *ctx, int slot, ebvo_edge *left, 
     {
         // the pipeline keeps only the normalised banks; the raw left patches (what the reference stores per match,
         // src/Stereo_Matches.cpp:1622) are sampled when they are asked for
-        int rc = match_patches_enqueue(ctx, s, s.im[0].img, s.cur_h, s.cur_w, s.cur_w, s.im[0].edges, (int)nL, nullptr, 0,
+        int rc = match_patches_enqueue(ctx, s, ncc_img(s, 0), s.cur_h, s.cur_w, s.cur_w, s.im[0].edges, (int)nL, nullptr, 0,
                                        (float *)s.patches_raw.p, nullptr, nullptr);
         if (rc)
             return rc;
@@ -1547,6 +1568,65 @@ extern "C" int ebvo_stereo_fetch_slot(ebvo_ctx *ctx, int slot, ebvo_edge *left, 
     return EBVO_OK;
 }
 
+
+
+// ---- input side: cv::undistort ---------------------------------------------------------------------------------
+extern "C" int ebvo_undistort(ebvo_ctx *ctx, const uint8_t *img, int h, int w, ptrdiff_t stride, const double K[4],
+                              const double *dist, int n_dist, uint8_t *out, ptrdiff_t out_stride)
+{
+    if (!ctx || !img || !out || !K || n_dist < 0 || n_dist > 5 || (n_dist > 0 && !dist) || out_stride < w)
+        return EBVO_ERR_ARG;
+    EBVO_HIP(ctx, hipSetDevice(ctx->device));
+    int rc;
+    Slot *sp;
+    if ((rc = check_size(ctx, h, w)) || (rc = host_slot(ctx, &sp)))
+        return rc;
+    Slot &s = *sp;
+    if ((rc = upload_image(ctx, s, 0, img, h, w, stride)) ||
+        (rc = refine_undistort_enqueue(ctx, s, s.im[0].img, w, h, w, K, dist, n_dist, s.im[0].undist_xs, s.im[1].img, w)))
+        return rc;
+    if (out_stride == (ptrdiff_t)w)
+        EBVO_HIP(ctx, hipMemcpyAsync(out, s.im[1].img, (size_t)w * h, hipMemcpyDeviceToHost, s.stream));
+    else
+        EBVO_HIP(ctx, hipMemcpy2DAsync(out, (size_t)out_stride, s.im[1].img, (size_t)w, (size_t)w, (size_t)h,
+                                       hipMemcpyDeviceToHost, s.stream));
+    EBVO_HIP(ctx, hipStreamSynchronize(s.stream));
+    return EBVO_OK;
+}
+
+extern "C" int ebvo_stereo_set_undistort(ebvo_ctx *ctx, const ebvo_undistort_params *p)
+{
+    if (!ctx || (p && (p->n_dist < 0 || p->n_dist > 5)))
+        return EBVO_ERR_ARG;
+    for (Slot *s : ctx->slots)
+        if (s->in_flight)
+            return EBVO_ERR_STATE;
+    EBVO_HIP(ctx, hipSetDevice(ctx->device));
+    if (!p)
+    {
+        ctx->undist_on = false;
+        return EBVO_OK;
+    }
+    for (Slot *s : ctx->slots)
+        for (int k = 0; k < 2; ++k)
+            if (!s->im[k].raw_base)
+            {
+                const size_t bytes = (size_t)ctx->max_h * ctx->max_w + 128;
+                if (hipMalloc(&s->im[k].raw_base, bytes) != hipSuccess)
+                {
+                    (void)hipGetLastError();
+                    return EBVO_ERR_NOMEM;
+                }
+                EBVO_HIP(ctx, hipMemsetAsync(s->im[k].raw_base, 0, bytes, s->stream));
+                EBVO_HIP(ctx, hipStreamSynchronize(s->stream));
+                s->im[k].raw = s->im[k].raw_base + 64;
+            }
+    ctx->undist = *p;
+    ctx->undist_on = true;
+    for (Slot *s : ctx->slots) // pairs uploaded before the switch went to img: they must be uploaded again
+        s->have_pair = s->have_run = s->have_refined = s->have_final = false;
+    return EBVO_OK;
+}
 
 // ---- results through page-locked memory, no staging copy on the host ------------------------------------------------
 extern "C" int ebvo_stereo_fetch_begin(ebvo_ctx *ctx, int slot, int what)

@@ -60,6 +60,9 @@ struct ImageWS
 {
     uint8_t *img = nullptr;     // h*w, tightly packed; = img_base + 64: 64 readable bytes before and after (wide loads)
     uint8_t *img_base = nullptr;
+    uint8_t *raw_base = nullptr, *raw = nullptr; // the image as uploaded when the context undistorts (ebvo_stereo_set_undistort):
+                                                 // TOED and the refinement run on img (undistorted), NCC samples raw
+    double *undist_xs = nullptr;                 // [max_w] row sequence of the undistortion map
     uint16_t *pix2 = nullptr;   // row-pair image: pix2[y*w + x] = img(y, x) | img(y + 1, x) << 8 (one 4-byte load per bilinear sample)
     double *maps = nullptr;     // PL_NUM planes of 4 x H x W
     uint8_t *flag = nullptr;    // 2H x 2W: 0 none, 1 NMS maximum, 3 maximum inside the 10-px border
@@ -106,9 +109,10 @@ struct Slot
     ImageWS im[2];
     int cur_h = 0, cur_w = 0;
     bool have_pair = false, have_run = false, in_flight = false, have_refined = false;
+    bool undist_pair = false; // the resident pair was uploaded raw and is undistorted by the pipeline (im[k].raw -> im[k].img)
 
     // matching workspace
-    GrowBuf grad_x, grad_y, gn_xy, gn_out, gn_valid, gn_iters, gn_state, gn_lists; // photometric refinement (refine_kernels.hip)
+    GrowBuf grad_x, grad_y, gn_xy, gn_out, gn_valid, gn_iters, gn_state, gn_lists, gn_pack; // photometric refinement (refine_kernels.hip)
     GrowBuf fin_i32, fin_edges, fin_f64, fin_u8, fin_out; // ebvo_stereo_finalize: CSRs, candidate lists, scores, final rows
     int n_final = 0;
     bool have_final = false, final_has_rows = false;
@@ -136,6 +140,9 @@ struct Slot
     bool prof_now = true; // this submission is one of the sampled ones
 };
 
+// the image the NCC passes sample: the RAW one (src/Stereo_Matches.cpp:562-563)
+inline const uint8_t *ncc_img(const Slot &s, int k) { return s.undist_pair ? s.im[k].raw : s.im[k].img; }
+
 struct ebvo_ctx
 {
     int device = 0;
@@ -144,6 +151,8 @@ struct ebvo_ctx
     int toed_mode = EBVO_TOED_STRICT;
     std::string last_error;
     std::vector<Slot *> slots; // slot 0 always exists; it also serves the host-buffer entry points
+    bool undist_on = false;    // ebvo_stereo_set_undistort
+    ebvo_undistort_params undist{};
     int wait_attempts = 0;     // test hook (ebvo_debug_set): attempts of ebvo_stereo_wait's regrow loop, 0 = default (4)
     int force_overflow = 0;    // test hook: treat the next N results as overflowed
 
@@ -246,6 +255,8 @@ int glue_final_pairs_enqueue(ebvo_ctx *ctx, Slot &s, const int32_t *d_rp_in, con
 // refine_kernels.hip
 int refine_sobel_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_img, int h, int w, int pitch, float *d_gx, float *d_gy,
                          void *d_gxy /* optional interleaved float2 plane */);
+int refine_undistort_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_src, int pitch, int h, int w, const double K[4],
+                             const double *dist, int n_dist, double *d_xs, uint8_t *d_dst, int dpitch);
 int refine_gn_stereo_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_imgL, const uint8_t *d_imgR, const void *d_gxy,
                              int h, int w, const ebvo_edge *d_L, int nL, const double *d_lines,
                              const int32_t *d_pair_left, const double *d_cand_xy /* or NULL with R + col_idx */,

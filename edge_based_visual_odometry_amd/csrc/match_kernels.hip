@@ -1667,7 +1667,7 @@ int match_ncc_resident_enqueue(ebvo_ctx *ctx, Slot &s, int h, int w, int cap_edg
     PatchBatch B{};
     for (int k = 0; k < 2; ++k)
     {
-        B.img[k] = s.im[k].img;
+        B.img[k] = ncc_img(s, k);
         B.edges[k] = s.im[k].edges;
         B.n[k] = DevN{0, s.im[k].counts + 1};
         B.sc[k] = (double2 *)s.sincos.p + (size_t)k * cap_edges;
@@ -1676,10 +1676,10 @@ int match_ncc_resident_enqueue(ebvo_ctx *ctx, Slot &s, int h, int w, int cap_edg
     {
         ProfScope ps(ctx, s, K_PATCHES);
         hipLaunchKernelGGL(row_pairs_kernel, dim3(blocks_for(((int64_t)h * w + 3) / 4, 256, 512), 2), dim3(256), 0, s.stream,
-                           (const uint8_t *)s.im[0].img, (const uint8_t *)s.im[1].img, s.im[0].pix2, s.im[1].pix2, h, w);
+                           ncc_img(s, 0), ncc_img(s, 1), s.im[0].pix2, s.im[1].pix2, h, w);
         hipLaunchKernelGGL(sincos_batch_kernel, dim3(blocks_for(cap_edges, 256, 512), 2), dim3(256), 0, s.stream, B);
         hipLaunchKernelGGL(right_bank_kernel, dim3(blocks_for((int64_t)cap_edges * 16, 256, 1024)), dim3(256), 0, s.stream,
-                           (const uint8_t *)s.im[1].img, (const uint16_t *)s.im[1].pix2, h, w, w, (const ebvo_edge *)s.im[1].edges, (const double2 *)B.sc[1],
+                           ncc_img(s, 1), (const uint16_t *)s.im[1].pix2, h, w, w, (const ebvo_edge *)s.im[1].edges, (const double2 *)B.sc[1],
                            nRd, (float *)s.patches_norm_r.p);
     }
     {
@@ -1689,7 +1689,7 @@ int match_ncc_resident_enqueue(ebvo_ctx *ctx, Slot &s, int h, int w, int cap_edg
         s.n_match_part = nblk;
         // NW = 4 left edges per wave, at most 5 waves per SIMD: measured best of {4, 8, 16} x {4, 5, 6, 8} (a bigger tile
         // serialises more sampling rounds in one wave; a higher occupancy target spills)
-        hipLaunchKernelGGL((ncc_tile_kernel<NCC_NW, NCC_WPE>), dim3(nblk), dim3(256), 0, s.stream, (const uint8_t *)s.im[0].img,
+        hipLaunchKernelGGL((ncc_tile_kernel<NCC_NW, NCC_WPE>), dim3(nblk), dim3(256), 0, s.stream, ncc_img(s, 0),
                            (const uint16_t *)s.im[0].pix2, h, w, w, (const ebvo_edge *)s.im[0].edges, (const double2 *)B.sc[0],
                            nLd, (const int32_t *)s.row_ptr.p, (const int32_t *)s.col_idx.p, (const float *)s.patches_norm_r.p,
                            s.cap_pairs, thr, (double *)s.sims.p, (double *)s.best.p, (uint8_t *)s.keep.p, s.d_matches);

@@ -51,6 +51,97 @@ __global__ void sobel_kernel(const uint8_t *__restrict__ img, int h, int w, int 
         gxy[(size_t)y * w + x] = make_float2(fx, fy);
 }
 
+
+// ---- cv::undistort (src/Pipeline.cpp:78-79), input side of the path --------------------------
+// OpenCV 4.x restated (modules/calib3d/src/undistort.dispatch.cpp: cv::undistort + the scalar loop of
+// initUndistortRectifyMap with CV_16SC2 maps; modules/imgproc/src/imgwarp.cpp: remapBilinear, 8-bit, BORDER_CONSTANT 0);
+// same restatement as oracle/ebvo_oracle.c: orc_undistort, PARITY UNPINNED.  The maps are never materialised:
+//   - the image is cut into stripes of max(1, 4096 / cols) rows, each with its own camera matrix (cy - y0) inverted in
+//     closed form (cv::invert, 3x3);
+//   - along a row OpenCV advances (_x, _y, _w) by REPEATED ADDITION of the inverse's first column.  With R = I and a
+//     pinhole K that column is (ir0, +-0, +-0) and the row start of _x is ir[2] for every row of every stripe, so the
+//     running sums _x[j] are one sequence of `cols` doubles: undistort_row_kernel forms it with the same additions (one
+//     thread), every pixel thread then picks its entry -- bit-identical to the sequential loop;
+//   - u, v -> fixed point with 5 fractional bits (round half to even), integer bilinear weights, (sum + 2^14) >> 15.
+struct UndistortArgs
+{
+    double fx, fy, u0, v0, k1, k2, p1, p2, k3;
+    int h, w, ss0;
+};
+
+__device__ inline void inv3x3_cv(const double a[9], double b[9])
+{
+    double d = a[0] * (a[4] * a[8] - a[5] * a[7]) - a[1] * (a[3] * a[8] - a[5] * a[6]) + a[2] * (a[3] * a[7] - a[4] * a[6]);
+    d = 1. / d;
+    b[0] = (a[4] * a[8] - a[5] * a[7]) * d;
+    b[1] = (a[2] * a[7] - a[1] * a[8]) * d;
+    b[2] = (a[1] * a[5] - a[2] * a[4]) * d;
+    b[3] = (a[5] * a[6] - a[3] * a[8]) * d;
+    b[4] = (a[0] * a[8] - a[2] * a[6]) * d;
+    b[5] = (a[2] * a[3] - a[0] * a[5]) * d;
+    b[6] = (a[3] * a[7] - a[4] * a[6]) * d;
+    b[7] = (a[1] * a[6] - a[0] * a[7]) * d;
+    b[8] = (a[0] * a[4] - a[1] * a[3]) * d;
+}
+
+__global__ void undistort_row_kernel(UndistortArgs A, double *__restrict__ xs)
+{
+    if (blockIdx.x || threadIdx.x)
+        return;
+    const double Ar[9] = {A.fx, 0, A.u0, 0, A.fy, A.v0, 0, 0, 1};
+    double ir[9];
+    inv3x3_cv(Ar, ir);
+    double _x = 0 * ir[1] + ir[2];
+    for (int j = 0; j < A.w; ++j, _x += ir[0])
+        xs[j] = _x;
+}
+
+__device__ inline int cv_round_sat(double v)
+{
+    if (!(v > -2147483648.0))
+        return (int)(-2147483647 - 1);
+    if (!(v < 2147483647.0))
+        return 2147483647;
+    return (int)rint(v); // round to nearest, ties to even
+}
+
+__global__ __launch_bounds__(256) void undistort_kernel(const uint8_t *__restrict__ src, int pitch, UndistortArgs A,
+                                                        const double *__restrict__ xs, uint8_t *__restrict__ dst,
+                                                        int dpitch)
+{
+    const int j = blockIdx.x * 64 + (threadIdx.x & 63), r = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (j >= A.w || r >= A.h)
+        return;
+    const int y0 = (r / A.ss0) * A.ss0, i = r - y0;
+    const double Ar[9] = {A.fx, 0, A.u0, 0, A.fy, A.v0 - y0, 0, 0, 1};
+    double ir[9];
+    inv3x3_cv(Ar, ir);
+    const double _x = xs[j], _y = i * ir[4] + ir[5], _w = i * ir[7] + ir[8]; // ir[3], ir[6] are +-0: the row steps leave them
+    const double ww = 1. / _w, x = _x * ww, y = _y * ww;
+    const double x2 = x * x, y2 = y * y;
+    const double r2 = x2 + y2, _2xy = 2 * x * y;
+    const double kr = (1 + ((A.k3 * r2 + A.k2) * r2 + A.k1) * r2) / (1 + ((0.0 * r2 + 0.0) * r2 + 0.0) * r2);
+    const double xd = (x * kr + A.p1 * _2xy + A.p2 * (r2 + 2 * x2) + 0.0 * r2 + 0.0 * r2 * r2);
+    const double yd = (y * kr + A.p1 * (r2 + 2 * y2) + A.p2 * _2xy + 0.0 * r2 + 0.0 * r2 * r2);
+    const double t0 = 1.0 * xd + 0.0 * yd + 0.0 * 1.0, t1 = 0.0 * xd + 1.0 * yd + 0.0 * 1.0, t2 = 0.0 * xd + 0.0 * yd + 1.0 * 1.0;
+    const double invProj = t2 ? 1. / t2 : 1;
+    const double u = A.fx * invProj * t0 + A.u0;
+    const double v = A.fy * invProj * t1 + A.v0;
+    const int iu = cv_round_sat(u * 32), iv = cv_round_sat(v * 32);
+    const int sx = (short)(iu >> 5), sy = (short)(iv >> 5);
+    const int fxi = iu & 31, fyi = iv & 31;
+    const int w00 = (32 - fyi) * (32 - fxi) * 32, w01 = (32 - fyi) * fxi * 32, w10 = fyi * (32 - fxi) * 32, w11 = fyi * fxi * 32;
+    const bool cx0 = sx >= 0 && sx < A.w, cx1 = sx + 1 >= 0 && sx + 1 < A.w, ry0 = sy >= 0 && sy < A.h,
+               ry1 = sy + 1 >= 0 && sy + 1 < A.h;
+    const int v00 = (cx0 && ry0) ? src[(size_t)sy * pitch + sx] : 0;
+    const int v01 = (cx1 && ry0) ? src[(size_t)sy * pitch + sx + 1] : 0;
+    const int v10 = (cx0 && ry1) ? src[(size_t)(sy + 1) * pitch + sx] : 0;
+    const int v11 = (cx1 && ry1) ? src[(size_t)(sy + 1) * pitch + sx + 1] : 0;
+    const int acc = v00 * w00 + v01 * w01 + v10 * w10 + v11 * w11;
+    const int o = (acc + (1 << 14)) >> 15;
+    dst[(size_t)r * dpitch + j] = (uint8_t)(o < 0 ? 0 : (o > 255 ? 255 : o));
+}
+
 // util_bilinear_Sample_F (include/utility.h:160-173): corner indices and weights, shared by every image sampled at
 // one point
 __device__ inline void tap_at(double x, double y, int w, int h, int &x0, int &x1, int &y0, int &y1, double &a, double &b)
@@ -110,10 +201,70 @@ __device__ inline float sample_u8(const uint8_t *__restrict__ img, int pitch, in
     return blend(a, b, c.v00, c.v10, c.v01, c.v11);
 }
 
+// ---- packed corner planes of the stereo refinement ----------------------------------------------------------------
+// The refinement samples three planes (intensity, Sobel gx, Sobel gy) bilinearly at ~3.7 M x 98 points per pair, every
+// lane at its own address: the texture addresser retires about one lane address per cycle and CU (GRBM_TA_BUSY 89 %,
+// profiles/r02_pmc_sq_chain.txt), so the LOAD COUNT per point is the bound -- it was 6 (two 2-byte intensity loads in
+// each of the two passes, two 16-byte gradient loads).  Here every pixel position (y0, x0) gets, precomputed once per
+// image, everything a bilinear tap at floor = (x0, y0) reads, with util_bilinear_Sample_F's clamps x1 = min(x0 + 1, w - 1),
+// y1 = min(y0 + 1, h - 1) (include/utility.h:166-167) baked in:
+//   pix4[y0 * w + x0] = I(x0,y0) | I(x1,y0) << 8 | I(x0,y1) << 16 | I(x1,y1) << 24                 (4 bytes)
+//   rec [y0 * w + x0] = eight 16-bit words: (8 gx) << 5 | I low 5 bits, (8 gy) << 5 | I high 3 bits per corner  (16 bytes)
+// (8 x Sobel / 8 is an integer in [-1020, 1020]: 11 bits; the float the reference reads is that integer times 0.125,
+// exactly).  One 4-byte load per point in the mean pass, one 16-byte load in the residual pass: 2 instead of 6.
+__device__ inline void sobel_at(const uint8_t *__restrict__ img, int h, int w, int pitch, int x, int y, int &sx, int &sy)
+{
+    const uint8_t *r0 = img + (size_t)reflect101(y - 1, h) * pitch, *r1 = img + (size_t)y * pitch,
+                  *r2 = img + (size_t)reflect101(y + 1, h) * pitch;
+    const int xm = reflect101(x - 1, w), xp = reflect101(x + 1, w);
+    sx = (r0[xp] - r0[xm]) + 2 * (r1[xp] - r1[xm]) + (r2[xp] - r2[xm]);
+    sy = (r2[xm] - r0[xm]) + 2 * (r2[x] - r0[x]) + (r2[xp] - r0[xp]);
+}
+
+__global__ __launch_bounds__(256) void gn_pack_kernel(const uint8_t *__restrict__ img, int h, int w, int pitch,
+                                                      uint32_t *__restrict__ pix4, uint4 *__restrict__ rec)
+{
+    const int x0 = blockIdx.x * 64 + (threadIdx.x & 63), y0 = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x0 >= w || y0 >= h)
+        return;
+    const int x1 = min(x0 + 1, w - 1), y1 = min(y0 + 1, h - 1);
+    const int cx[4] = {x0, x1, x0, x1}, cy[4] = {y0, y0, y1, y1};
+    unsigned I[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        I[c] = img[(size_t)cy[c] * pitch + cx[c]];
+    pix4[(size_t)y0 * w + x0] = I[0] | (I[1] << 8) | (I[2] << 16) | (I[3] << 24);
+    if (!rec)
+        return;
+    unsigned wd[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+    {
+        int sx, sy;
+        sobel_at(img, h, w, pitch, cx[c], cy[c], sx, sy);
+        const unsigned wx = (((unsigned)sx << 5) & 0xffe0u) | (I[c] & 31u);
+        const unsigned wy = (((unsigned)sy << 5) & 0xffe0u) | (I[c] >> 5);
+        wd[c] = wx | (wy << 16);
+    }
+    rec[(size_t)y0 * w + x0] = make_uint4(wd[0], wd[1], wd[2], wd[3]);
+}
+
+// util_bilinear_Sample_F of the intensity at (x, y) from the packed plane
+__device__ inline float sample_pix4(const uint32_t *__restrict__ pix4, int w, int h, double x, double y)
+{
+    int x0, x1, y0, y1;
+    double a, b;
+    tap_at(x, y, w, h, x0, x1, y0, y1, a, b);
+    const uint32_t q = pix4[(size_t)y0 * w + x0];
+    return blend(a, b, (float)(q & 0xffu), (float)((q >> 8) & 0xffu), (float)((q >> 16) & 0xffu), (float)(q >> 24));
+}
+
 struct GnArgs
 {
     const uint8_t *imgL, *imgR;
-    const float2 *gxy;    // interleaved Sobel planes (gx, gy) of the right image, pitch w
+    const float2 *gxy;    // (unused by the stereo kernels: they read the packed planes below)
+    const uint32_t *pix4L, *pix4R; // packed corner intensities of the left / right image (gn_pack_kernel)
+    const uint4 *recR;             // packed corner intensities + Sobel gradients of the right image
     int h, w;
     const ebvo_edge *L;       // left edges
     const double *lines;      // nL x 3
@@ -190,7 +341,7 @@ __global__ __launch_bounds__(256) void gn_left_kernel(GnArgs A)
 #pragma unroll
                 for (int b = -3; b <= 3; ++b)
                 {
-                    const float v = sample_u8(A.imgL, w, w, h, cx + ct * a - st * b, cy + st * a + ct * b);
+                    const float v = sample_pix4(A.pix4L, w, h, cx + ct * a - st * b, cy + st * a + ct * b);
                     A.left_rec[(size_t)i * 98 + sd * 49 + (a + 3) * 7 + (b + 3)] = v;
                     sum += (double)v;
                 }
@@ -277,7 +428,7 @@ __global__ __launch_bounds__(256) void gn_iter_kernel(GnArgs A, int it)
                 for (int i = -3; i <= 3; ++i)
 #pragma unroll
                     for (int j = -3; j <= 3; ++j)
-                        sum += (double)sample_u8(A.imgR, w, w, h, cx + ct * i - st * j, cy + st * i + ct * j);
+                        sum += (double)sample_pix4(A.pix4R, w, h, cx + ct * i - st * j, cy + st * i + ct * j);
                 meanR[sd] = sum / 49;
             }
             double H = 0.0, b = 0.0, cost = 0.0;
@@ -289,21 +440,26 @@ __global__ __launch_bounds__(256) void gn_iter_kernel(GnArgs A, int it)
                 const double cy = (sd ? ry - ny * side : ry + ny * side) + shy;
 #pragma unroll 1
                 for (int i = -3; i <= 3; ++i)
-#pragma unroll 1
+#pragma unroll // the seven 16-byte loads of a patch row are independent: all in flight together
                     for (int j = -3; j <= 3; ++j)
                     {
                         const double Lf = (double)lrec[(i + 3) * 7 + (j + 3)]; // sampled once by gn_left_kernel
                         int x0, x1, y0, y1;
                         double wa, wb;
                         tap_at(cx + ct * i - st * j, cy + st * i + ct * j, w, h, x0, x1, y0, y1, wa, wb);
-                        const int xa = min(x0, w - 2);
-                        const bool shifted = xa != x0; // right border: x1 == x0 == w - 1
-                        const Corners ci = corners_u8(A.imgR, w, w, x0, x1, y0, y1);
-                        const float4 g0 = *reinterpret_cast<const float4 *>(A.gxy + (size_t)y0 * w + xa);
-                        const float4 g1 = *reinterpret_cast<const float4 *>(A.gxy + (size_t)y1 * w + xa);
-                        const double Rf = (double)blend(wa, wb, ci.v00, ci.v10, ci.v01, ci.v11);
-                        const double gxv = (double)blend(wa, wb, shifted ? g0.z : g0.x, g0.z, shifted ? g1.z : g1.x, g1.z);
-                        const double gyv = (double)blend(wa, wb, shifted ? g0.w : g0.y, g0.w, shifted ? g1.w : g1.y, g1.w);
+                        const uint4 q = A.recR[(size_t)y0 * w + x0]; // the four corners: intensity, 8 gx, 8 gy
+                        const unsigned wd[4] = {q.x, q.y, q.z, q.w};
+                        float iv[4], gxc[4], gyc[4];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                        {
+                            iv[c] = (float)((wd[c] & 31u) | ((wd[c] >> 11) & 0xe0u));
+                            gxc[c] = (float)(((int)(wd[c] << 16)) >> 21) * 0.125f; // bits 5..15, sign-extended
+                            gyc[c] = (float)(((int)wd[c]) >> 21) * 0.125f;         // bits 21..31
+                        }
+                        const double Rf = (double)blend(wa, wb, iv[0], iv[1], iv[2], iv[3]);
+                        const double gxv = (double)blend(wa, wb, gxc[0], gxc[1], gxc[2], gxc[3]);
+                        const double gyv = (double)blend(wa, wb, gyc[0], gyc[1], gyc[2], gyc[3]);
                         const double r = (Lf - meanL[sd]) - (Rf - meanR[sd]);
                         const double g = -gxv * ex + gyv * ey; // :1237
                         const double absr = fabs(r);
@@ -627,6 +783,34 @@ __global__ void finalize_pairs_kernel(FinalCalib C, const ebvo_edge *__restrict_
 
 } // namespace
 
+
+// cv::undistort of one resident image: d_src (pitch) -> d_dst (dpitch); d_xs: scratch of w doubles
+int refine_undistort_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_src, int pitch, int h, int w, const double K[4],
+                             const double *dist, int n_dist, double *d_xs, uint8_t *d_dst, int dpitch)
+{
+    UndistortArgs A;
+    A.fx = K[0];
+    A.fy = K[1];
+    A.u0 = K[2];
+    A.v0 = K[3];
+    A.k1 = n_dist > 0 ? dist[0] : 0.0;
+    A.k2 = n_dist > 1 ? dist[1] : 0.0;
+    A.p1 = n_dist > 2 ? dist[2] : 0.0;
+    A.p2 = n_dist > 3 ? dist[3] : 0.0;
+    A.k3 = n_dist > 4 ? dist[4] : 0.0;
+    A.h = h;
+    A.w = w;
+    int ss0 = (1 << 12) / (w > 1 ? w : 1);
+    ss0 = ss0 < 1 ? 1 : (ss0 > h ? h : ss0);
+    A.ss0 = ss0;
+    ProfScope ps(ctx, s, K_SOBEL);
+    hipLaunchKernelGGL(undistort_row_kernel, dim3(1), dim3(64), 0, s.stream, A, d_xs);
+    hipLaunchKernelGGL(undistort_kernel, dim3((w + 63) / 64, (h + 3) / 4), dim3(256), 0, s.stream, d_src, pitch, A,
+                       (const double *)d_xs, d_dst, dpitch);
+    EBVO_HIP(ctx, hipGetLastError());
+    return EBVO_OK;
+}
+
 int refine_sobel_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_img, int h, int w, int pitch, float *d_gx, float *d_gy,
                          void *d_gxy)
 {
@@ -655,14 +839,21 @@ int refine_gn_stereo_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_imgL, cons
     const size_t nl = (size_t)nL;
     if (nL <= 0)
         return EBVO_ERR_ARG;
+    const size_t npx = (size_t)h * w;
     if ((rc = ebvo_grow(ctx, s, s.gn_state, sizeof(double) * 4 * nl + sizeof(float) * 98 * nl)) ||
-        (rc = ebvo_grow(ctx, s, s.gn_lists, sizeof(int32_t) * (2 * np + (size_t)max_iter + 2))))
+        (rc = ebvo_grow(ctx, s, s.gn_lists, sizeof(int32_t) * (2 * np + (size_t)max_iter + 2))) ||
+        (rc = ebvo_grow(ctx, s, s.gn_pack, (sizeof(uint4) + 2 * sizeof(uint32_t)) * npx)))
         return rc;
     GnArgs A{};
     A.nL = nL;
     A.imgL = d_imgL;
     A.imgR = d_imgR;
     A.gxy = (const float2 *)d_gxy;
+    uint4 *recR = (uint4 *)s.gn_pack.p;
+    uint32_t *pix4R = (uint32_t *)(recR + npx), *pix4L = pix4R + npx;
+    A.recR = recR;
+    A.pix4R = pix4R;
+    A.pix4L = pix4L;
     A.h = h;
     A.w = w;
     A.L = d_L;
@@ -691,6 +882,11 @@ int refine_gn_stereo_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_imgL, cons
     ProfScope ps(ctx, s, K_GN_REFINE);
     EBVO_HIP(ctx, hipMemsetAsync(A.counts, 0, sizeof(int32_t) * ((size_t)max_iter + 2), s.stream));
     const unsigned blocks = (unsigned)((n_pairs + 255) / 256 < 4096 ? (n_pairs + 255) / 256 : 4096);
+    {
+        const dim3 pg((w + 63) / 64, (h + 3) / 4);
+        hipLaunchKernelGGL(gn_pack_kernel, pg, dim3(256), 0, s.stream, d_imgL, h, w, w, pix4L, (uint4 *)nullptr);
+        hipLaunchKernelGGL(gn_pack_kernel, pg, dim3(256), 0, s.stream, d_imgR, h, w, w, pix4R, recR);
+    }
     hipLaunchKernelGGL(gn_left_kernel, dim3((unsigned)((nL + 255) / 256 < 2048 ? (nL + 255) / 256 : 2048)), dim3(256), 0,
                        s.stream, A);
     hipLaunchKernelGGL(gn_init_kernel, dim3(blocks), dim3(256), 0, s.stream, A);

@@ -98,7 +98,10 @@ CALIB = {
                   R21=((0.999997256477450, 0.002312067192420, 0.000376008102351),
                        (-0.002317135723285, 0.999898048506528, 0.014089835846697),
                        (-0.000343393120589, -0.014090668452670, 0.999900662638179)),
-                  T21=(-0.110073808127139, 0.000399121547014534, -0.000853702503351098)),
+                  T21=(-0.110073808127139, 0.000399121547014534, -0.000853702503351098),
+                  # config/euroc.yaml:13, :18: k1 k2 p1 p2
+                  dist=(-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05),
+                  dist_right=(-0.28368365, 0.07451284, -0.00010473, -3.55590700e-05)),
     # config/eth3d_delivery_area.yaml:10-28
     "eth3d": dict(K=(541.764, 541.764, 553.869, 232.396), K_right=(541.764, 541.764, 553.869, 232.396),
                   R21=((1.0, 0.0, 0.0), (0.0, 1.0, 0.0), (0.0, 0.0, 1.0)),

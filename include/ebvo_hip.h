@@ -155,6 +155,27 @@ int ebvo_ncc_pairs(ebvo_ctx *ctx, const uint8_t *imgL, const uint8_t *imgR, int 
                    const int32_t *row_ptr, double thr, float *left_patches, double *sims, double *best,
                    uint8_t *keep);
 
+/* ---- input side (OpenCV is not part of the reference tree: parity unpinned) -------------- */
+
+/* cv::undistort(img, out, K, dist) as Pipeline::prepare_Stereo_Images calls it (src/Pipeline.cpp:78-79: no new camera
+ * matrix; K = fx fy cx cy of include/Dataset.h get_*_calib_matrix_cvMat, dist = k1 k2 p1 p2 [k3], n_dist = 4 or 5,
+ * include/Dataset.h:396-397).  OpenCV 4.x restated: stripe-wise maps with 5 fractional bits, fixed-point bilinear
+ * remap, constant-0 border.  Zero distortion returns the input image. */
+int ebvo_undistort(ebvo_ctx *ctx, const uint8_t *img, int h, int w, ptrdiff_t stride, const double K[4], const double *dist,
+                   int n_dist, uint8_t *out, ptrdiff_t out_stride);
+
+/* The resident pipeline undistorts the uploaded pair itself: TOED, the refinement and the output geometry then run on the
+ * undistorted images while the NCC passes sample the RAW ones, exactly as the reference does (src/Pipeline.cpp:93-97 vs
+ * src/Stereo_Matches.cpp:562-563).  p = NULL switches it off (KITTI, ETH3D: zero distortion, same result either way). */
+typedef struct ebvo_undistort_params
+{
+    double K_left[4], K_right[4];       /* fx fy cx cy */
+    double dist_left[5], dist_right[5]; /* k1 k2 p1 p2 k3 */
+    int n_dist;                         /* 4 or 5 */
+    int reserved;
+} ebvo_undistort_params;
+int ebvo_stereo_set_undistort(ebvo_ctx *ctx, const ebvo_undistort_params *p);
+
 /* ---- photometric refinement (no fixture of the reference pins it) -------------------- */
 
 /* Defaults of Stereo_Matches::min_Edge_Photometric_Residual_by_Gauss_Newton_along_EpipolarLine

@@ -1392,3 +1392,105 @@ uint64_t orc_edge_hash(const orc_edge *e, int n, int with_theta)
     }
     return h;
 }
+
+/* ------------------------------------------------------------------------------------ */
+/* cv::undistort(src, dst, K, dist) as Pipeline::prepare_Stereo_Images calls it            */
+/* (src/Pipeline.cpp:78-79: no new camera matrix, four distortion coefficients             */
+/* k1 k2 p1 p2, include/Dataset.h:396-397).  OpenCV is not in the reference tree: this      */
+/* restates the published OpenCV 4.x source (modules/calib3d/src/undistort.dispatch.cpp     */
+/* cv::undistort + the scalar loop of initUndistortRectifyMap with CV_16SC2 maps, and       */
+/* modules/imgproc/src/imgwarp.cpp remapBilinear for 8-bit images, BORDER_CONSTANT 0).      */
+/* PARITY UNPINNED: the reference holds no undistorted image; x86 builds of OpenCV may      */
+/* take an AVX2 line kernel for the maps whose rounding can differ in the last bit of u, v. */
+/*   - the image is processed in stripes of max(1, 4096 / cols) rows; per stripe the        */
+/*     camera matrix has cy - y0 and is inverted with the closed 3x3 form;                  */
+/*   - along a row (_x, _y, _w) advance by repeated addition of the first column of the     */
+/*     inverse (here: only _x changes, by ir[0]);                                           */
+/*   - u, v -> fixed point with 5 fractional bits (cvRound = round half to even),           */
+/*   - bilinear weights are the exact products (32 - fx)(32 - fy) * 32 ..., result          */
+/*     (sum + 2^14) >> 15; taps outside the image read 0.                                   */
+/* dist: k1 k2 p1 p2 [k3] (n_dist = 4 or 5).                                                */
+/* ------------------------------------------------------------------------------------ */
+static void inv3x3(const double a[9], double b[9])
+{
+    /* cv::invert, 3x3 CV_64F closed form (modules/core/src/lapack.cpp) */
+    double d = a[0] * (a[4] * a[8] - a[5] * a[7]) - a[1] * (a[3] * a[8] - a[5] * a[6]) + a[2] * (a[3] * a[7] - a[4] * a[6]);
+    d = 1. / d;
+    b[0] = (a[4] * a[8] - a[5] * a[7]) * d;
+    b[1] = (a[2] * a[7] - a[1] * a[8]) * d;
+    b[2] = (a[1] * a[5] - a[2] * a[4]) * d;
+    b[3] = (a[5] * a[6] - a[3] * a[8]) * d;
+    b[4] = (a[0] * a[8] - a[2] * a[6]) * d;
+    b[5] = (a[2] * a[3] - a[0] * a[5]) * d;
+    b[6] = (a[3] * a[7] - a[4] * a[6]) * d;
+    b[7] = (a[1] * a[6] - a[0] * a[7]) * d;
+    b[8] = (a[0] * a[4] - a[1] * a[3]) * d;
+}
+
+static int cv_round_sat(double v)
+{
+    /* saturate_cast<int>(double) = cvRound: round to nearest, ties to even (lrint in the default rounding mode) */
+    if (!(v > -2147483648.0))
+        return (int)(-2147483647 - 1);
+    if (!(v < 2147483647.0))
+        return 2147483647;
+    return (int)nearbyint(v);
+}
+
+void orc_undistort(const uint8_t *img, int h, int w, ptrdiff_t stride, const double K[4], const double *dist, int n_dist,
+                   uint8_t *out, ptrdiff_t out_stride)
+{
+    const double fx = K[0], fy = K[1], u0 = K[2], v0 = K[3];
+    const double k1 = n_dist > 0 ? dist[0] : 0, k2 = n_dist > 1 ? dist[1] : 0, p1 = n_dist > 2 ? dist[2] : 0,
+                 p2 = n_dist > 3 ? dist[3] : 0, k3 = n_dist > 4 ? dist[4] : 0;
+    const double k4 = 0, k5 = 0, k6 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0;
+    int ss0 = (1 << 12) / (w > 1 ? w : 1);
+    if (ss0 < 1)
+        ss0 = 1;
+    if (ss0 > h)
+        ss0 = h;
+    for (int y0 = 0; y0 < h; y0 += ss0)
+    {
+        const int ss = ss0 < h - y0 ? ss0 : h - y0;
+        const double Ar[9] = {fx, 0, u0, 0, fy, v0 - y0, 0, 0, 1};
+        double ir[9];
+        inv3x3(Ar, ir);
+        for (int i = 0; i < ss; i++)
+        {
+            double _x = i * ir[1] + ir[2], _y = i * ir[4] + ir[5], _w = i * ir[7] + ir[8];
+            uint8_t *D = out + (ptrdiff_t)(y0 + i) * out_stride;
+            for (int j = 0; j < w; j++, _x += ir[0], _y += ir[3], _w += ir[6])
+            {
+                const double ww = 1. / _w, x = _x * ww, y = _y * ww;
+                const double x2 = x * x, y2 = y * y;
+                const double r2 = x2 + y2, _2xy = 2 * x * y;
+                const double kr = (1 + ((k3 * r2 + k2) * r2 + k1) * r2) / (1 + ((k6 * r2 + k5) * r2 + k4) * r2);
+                const double xd = (x * kr + p1 * _2xy + p2 * (r2 + 2 * x2) + s1 * r2 + s2 * r2 * r2);
+                const double yd = (y * kr + p1 * (r2 + 2 * y2) + p2 * _2xy + s3 * r2 + s4 * r2 * r2);
+                /* matTilt = identity: vecTilt = (xd, yd, 1) with the products of Matx * Vec written out */
+                const double t0 = 1.0 * xd + 0.0 * yd + 0.0 * 1.0, t1 = 0.0 * xd + 1.0 * yd + 0.0 * 1.0,
+                             t2 = 0.0 * xd + 0.0 * yd + 1.0 * 1.0;
+                const double invProj = t2 ? 1. / t2 : 1;
+                const double u = fx * invProj * t0 + u0;
+                const double v = fy * invProj * t1 + v0;
+                const int iu = cv_round_sat(u * 32), iv = cv_round_sat(v * 32);
+                const int sx = (short)(iu >> 5), sy = (short)(iv >> 5); /* CV_16SC2 */
+                const int fxi = iu & 31, fyi = iv & 31;
+                const int w00 = (32 - fyi) * (32 - fxi) * 32, w01 = (32 - fyi) * fxi * 32, w10 = fyi * (32 - fxi) * 32,
+                          w11 = fyi * fxi * 32; /* BilinearTab_i: exact, sums to 2^15 */
+                int v00 = 0, v01 = 0, v10 = 0, v11 = 0;
+                if (sx >= 0 && sx < w && sy >= 0 && sy < h)
+                    v00 = img[(ptrdiff_t)sy * stride + sx];
+                if (sx + 1 >= 0 && sx + 1 < w && sy >= 0 && sy < h)
+                    v01 = img[(ptrdiff_t)sy * stride + sx + 1];
+                if (sx >= 0 && sx < w && sy + 1 >= 0 && sy + 1 < h)
+                    v10 = img[(ptrdiff_t)(sy + 1) * stride + sx];
+                if (sx + 1 >= 0 && sx + 1 < w && sy + 1 >= 0 && sy + 1 < h)
+                    v11 = img[(ptrdiff_t)(sy + 1) * stride + sx + 1];
+                const int acc = v00 * w00 + v01 * w01 + v10 * w10 + v11 * w11;
+                int r = (acc + (1 << 14)) >> 15;
+                D[j] = (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r));
+            }
+        }
+    }
+}

@@ -148,6 +148,10 @@ void orc_epipolar_shift(const orc_edge *cand, const double *lines, const int32_t
 void orc_cluster_rows(const orc_edge *cand, const int32_t *row_ptr, int nL, int by_orientation, int skip_single, int math_mode,
                       int32_t *new_count, orc_edge *centres, int32_t *cluster_of);
 
+/* cv::undistort as src/Pipeline.cpp:78-79 calls it (OpenCV 4.x restated; PARITY UNPINNED).  K = fx fy cx cy. */
+void orc_undistort(const uint8_t *img, int h, int w, ptrdiff_t stride, const double K[4], const double *dist, int n_dist,
+                   uint8_t *out, ptrdiff_t out_stride);
+
 #ifdef __cplusplus
 }
 #endif

@@ -244,3 +244,15 @@ def exp_v(x, math_mode):
     out = np.zeros(len(x))
     lib().orc_exp_v(_p(x), len(x), math_mode, _p(out))
     return out
+
+
+def undistort(img, K, dist):
+    """cv::undistort(img, K, dist) restated (oracle/ebvo_oracle.c: orc_undistort).  K = (fx, fy, cx, cy)."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w = img.shape
+    K = np.ascontiguousarray(K, dtype=np.float64).reshape(4)
+    dist = np.ascontiguousarray(dist, dtype=np.float64).reshape(-1)
+    out = np.zeros_like(img)
+    lib().orc_undistort(_p(img), h, w, C.c_ssize_t(img.strides[0]), _p(K), _p(dist), len(dist), _p(out),
+                        C.c_ssize_t(out.strides[0]))
+    return out
