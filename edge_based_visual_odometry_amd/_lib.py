@@ -43,7 +43,7 @@ ABI_SYMBOLS = (
     "ebvo_gn_default_params", "ebvo_sobel_gradients", "ebvo_gn_refine_stereo", "ebvo_stereo_refine",
     "ebvo_stereo_fetch_refined", "ebvo_gn_refine_temporal", "ebvo_finalize_pairs", "ebvo_bnb_test", "ebvo_keep_best", "ebvo_epipolar_shift", "ebvo_cluster_rows", "ebvo_stereo_finalize", "ebvo_stereo_fetch_final",
     "ebvo_debug_set", "ebvo_stereo_fetch_begin", "ebvo_stereo_fetch_end",
-    "ebvo_undistort", "ebvo_stereo_set_undistort",
+    "ebvo_undistort", "ebvo_stereo_set_undistort", "ebvo_sift_descriptors", "ebvo_sift_min_distances",
 )
 
 
@@ -62,12 +62,13 @@ class GnParams(C.Structure):
 
 
 class FinalizeParams(C.Structure):
-    _fields_ = [("bnb_ratio", C.c_double), ("ncc_thr", C.c_double), ("gn", GnParams)]
+    _fields_ = [("bnb_ratio", C.c_double), ("ncc_thr", C.c_double), ("gn", GnParams), ("use_sift", C.c_int),
+                ("reserved", C.c_int), ("sift_thr", C.c_double), ("bnb_sift", C.c_double)]
 
 
 class FinalizeCounts(C.Structure):
     _fields_ = [("n_ncc", C.c_int32), ("n_bnb", C.c_int32), ("n_clusters", C.c_int32), ("n_ncc2", C.c_int32),
-                ("n_final", C.c_int32)]
+                ("n_final", C.c_int32), ("n_sift", C.c_int32)]
 
 
 class StereoCounts(C.Structure):
@@ -152,6 +153,8 @@ def load_library() -> C.CDLL:
     lib.ebvo_fp64_peak.argtypes = [vp, i32, C.POINTER(dbl), C.POINTER(dbl)]
     lib.ebvo_debug_set.argtypes = [vp, i32, i32]
     lib.ebvo_stereo_fetch_begin.argtypes = [vp, i32, i32]
+    lib.ebvo_sift_descriptors.argtypes = [vp, vp, i32, i32, ssz, vp, i32, vp]
+    lib.ebvo_sift_min_distances.argtypes = [vp, vp, i32, vp, vp, vp]
     lib.ebvo_undistort.argtypes = [vp, vp, i32, i32, ssz, vp, vp, i32, vp, ssz]
     lib.ebvo_stereo_set_undistort.argtypes = [vp, C.POINTER(UndistortParams)]
     lib.ebvo_stereo_fetch_end.argtypes = [vp, i32, C.POINTER(StereoView)]

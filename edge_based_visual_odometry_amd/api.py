@@ -310,12 +310,34 @@ class Context:
                     "ebvo_finalize_pairs")
         return out
 
-    def stereo_finalize(self, calib=None, slot=0, bnb_ratio=0.9, ncc_thr=0.6, **gn):
+    # -- cv::SIFT::compute at the +-8 px points of every edge / apply_SIFT_filtering's score ---------------------------
+    def sift_descriptors(self, img, edges) -> np.ndarray:
+        img = _u8(img)
+        h, w = img.shape
+        edges = _edges(edges)
+        out = np.zeros((len(edges), 2, 128), dtype=np.float32)
+        self._check(self.lib.ebvo_sift_descriptors(self._ctx, ptr(img), h, w, img.strides[0], ptr(edges), len(edges), ptr(out)),
+                    "ebvo_sift_descriptors")
+        return out
+
+    def sift_min_distances(self, left_desc, cand_desc, row_ptr) -> np.ndarray:
+        left_desc = np.ascontiguousarray(left_desc, dtype=np.float32).reshape(-1, 2, 128)
+        cand_desc = np.ascontiguousarray(cand_desc, dtype=np.float32).reshape(-1, 2, 128)
+        row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int32)
+        assert len(row_ptr) == len(left_desc) + 1 and int(row_ptr[-1]) == len(cand_desc)
+        out = np.zeros(len(cand_desc))
+        self._check(self.lib.ebvo_sift_min_distances(self._ctx, ptr(left_desc), len(left_desc), ptr(cand_desc), ptr(row_ptr),
+                                                     ptr(out)), "ebvo_sift_min_distances")
+        return out
+
+    def stereo_finalize(self, calib=None, slot=0, bnb_ratio=0.9, ncc_thr=0.6, use_sift=False, sift_thr=500.0, bnb_sift=0.4,
+                        **gn):
         """BNB -> shift -> refine -> cluster -> NCC -> best on the resident pair.  calib = (K_left, K_right, R21, T21) adds the
         output-file rows.  Returns (counts dict, dict(left_index, right, score[, rows]))."""
         from ._lib import FinalizeCounts, FinalizeParams, StereoCalib
         p = FinalizeParams()
         p.bnb_ratio, p.ncc_thr, p.gn = bnb_ratio, ncc_thr, self._gn_params(**gn)
+        p.use_sift, p.sift_thr, p.bnb_sift = int(bool(use_sift)), sift_thr, bnb_sift
         cal = None
         if calib is not None:
             cal = StereoCalib()
@@ -331,7 +353,8 @@ class Context:
                                                      ptr(out["score"]), ptr(rows)), "ebvo_stereo_fetch_final")
         if rows is not None:
             out["rows"] = rows
-        return {k: getattr(cnt, k) for k in ("n_ncc", "n_bnb", "n_clusters", "n_ncc2", "n_final")}, out
+        keys = ("n_sift",) * bool(use_sift) + ("n_ncc", "n_bnb", "n_clusters", "n_ncc2", "n_final")
+        return {k: getattr(cnt, k) for k in keys}, out
 
     def stereo_refine(self, counts, slot=0, **kw):
         """Refine every kept match of the resident pair on the device; returns the per-pair outputs (n_pairs entries,

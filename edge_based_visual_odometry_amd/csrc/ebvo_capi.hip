@@ -10,7 +10,7 @@
 
 const char *const g_kernel_names[K_NUM] = {
     "toed_conv",   "toed_nms",   "toed_rowscan", "toed_compact", "toed_finalize", "toed_exact_centre", "toed_exact_mags", "cand_boxes", "epi_lines",
-    "cand_count",  "scan",       "cand_fill",    "edge_patches", "ncc_pairs",     "ncc_stored", "misc", "sobel", "gn_refine"};
+    "cand_count",  "scan",       "cand_fill",    "edge_patches", "ncc_pairs",     "ncc_stored", "misc", "sobel", "gn_refine", "sift"};
 
 // ------------------------------------------------------------------------------------------
 int ebvo_fail_hip(ebvo_ctx *ctx, hipError_t e, const char *what, const char *file, int line)
@@ -139,7 +139,7 @@ static void slot_destroy(Slot *s)
         (void)hipFree(ws.cand_lists);
         (void)hipFree(ws.cand_lcount);
     }
-    GrowBuf *bufs[] = {&s->lines,        &s->boxes_chunk,  &s->boxes_group,    &s->cand_cnt,       &s->cand_stage, &s->cand_tileflag, &s->row_ptr, &s->grad_x, &s->grad_y, &s->gn_xy, &s->gn_out, &s->gn_valid, &s->gn_iters, &s->gn_state, &s->gn_lists, &s->gn_pack, &s->fin_i32, &s->fin_edges, &s->fin_f64, &s->fin_u8, &s->fin_out,
+    GrowBuf *bufs[] = {&s->lines,        &s->boxes_chunk,  &s->boxes_group,    &s->cand_cnt,       &s->cand_stage, &s->cand_tileflag, &s->row_ptr, &s->grad_x, &s->grad_y, &s->gn_xy, &s->gn_out, &s->gn_valid, &s->gn_iters, &s->gn_state, &s->gn_lists, &s->gn_pack, &s->sift_img, &s->sift_desc, &s->sift_f32, &s->sift_dist, &s->fin_i32, &s->fin_edges, &s->fin_f64, &s->fin_u8, &s->fin_out,
                        &s->scan_tmp,     &s->col_idx,      &s->rc_edges,       &s->sims,           &s->best,
                        &s->keep,         &s->patches_raw,  &s->patches_norm,   &s->patches_flag,   &s->patches_norm_r,
                        &s->patches_flag_r, &s->pair_left,  &s->sincos,         &s->scratch_b,      &s->scratch_c,
@@ -1384,7 +1384,7 @@ extern "C" int ebvo_stereo_finalize(ebvo_ctx *ctx, int slot, const ebvo_finalize
 {
     Slot *sp;
     if (!p || !counts || !(p->bnb_ratio >= 0) || !(p->ncc_thr == p->ncc_thr) || p->gn.max_iter < 1 || !(p->gn.tol >= 0) ||
-        !(p->gn.huber_delta > 0) || get_slot(ctx, slot, &sp))
+        !(p->gn.huber_delta > 0) || (p->use_sift && (!(p->sift_thr > 0) || !(p->bnb_sift >= 0))) || get_slot(ctx, slot, &sp))
         return EBVO_ERR_ARG;
     Slot &s = *sp;
     if (!s.have_run || s.in_flight)
@@ -1406,7 +1406,7 @@ extern "C" int ebvo_stereo_finalize(ebvo_ctx *ctx, int slot, const ebvo_finalize
     // carve the work buffers: everything is bounded by the pair count of the run (each stage only shrinks the lists)
     if ((rc = ebvo_grow(ctx, s, s.fin_i32, sizeof(int32_t) * (4 * nLz + 4 * nz))) ||
         (rc = ebvo_grow(ctx, s, s.fin_edges, sizeof(ebvo_edge) * (3 * nz + 2 * nLz))) ||
-        (rc = ebvo_grow(ctx, s, s.fin_f64, sizeof(double) * (3 * nz + nLz) + 16 * nz)) ||
+        (rc = ebvo_grow(ctx, s, s.fin_f64, sizeof(double) * (5 * nz + nLz) + 16 * nz)) ||
         (rc = ebvo_grow(ctx, s, s.fin_u8, nz)) || (rc = ebvo_grow(ctx, s, s.fin_out, sizeof(double) * 16 * nLz)) ||
         (rc = ebvo_grow(ctx, s, s.grad_x, 2 * sizeof(float) * (size_t)h * w + 64)) ||
         (rc = ebvo_grow(ctx, s, s.gn_xy, sizeof(double) * 2 * nz)) || (rc = ebvo_grow(ctx, s, s.gn_out, sizeof(double) * 5 * nz)) ||
@@ -1417,7 +1417,8 @@ extern "C" int ebvo_stereo_finalize(ebvo_ctx *ctx, int slot, const ebvo_finalize
     ebvo_edge *candA = (ebvo_edge *)s.fin_edges.p, *candB = candA + nz, *candC = candB + nz, *fin_l = candC + nz,
               *fin_r = fin_l + nLz;
     double *scoreA = (double *)s.fin_f64.p, *scoreB = scoreA + nz, *best2 = scoreB + nz, *fin_score = best2 + nz;
-    void *sincos2 = fin_score + nLz; // n0 double2
+    double *confA = fin_score + nLz, *confB = confA + nz; // SIFT distances carried through the Best-Nearly-Best tests
+    void *sincos2 = confB + nz; // n0 double2
     uint8_t *keep2 = (uint8_t *)s.fin_u8.p;
     const int32_t *rp0 = (const int32_t *)s.row_ptr.p;
     hipStream_t st = s.stream;
@@ -1428,17 +1429,66 @@ extern "C" int ebvo_stereo_finalize(ebvo_ctx *ctx, int slot, const ebvo_finalize
         return r ? r : read_i32(ctx, s, rp_out + nL, total);
     };
     int32_t nA = 0, nB = 0, nE = 0, nF = 0, nG = 0;
+    const uint8_t *keep1 = (const uint8_t *)s.keep.p;
+    const double *conf0 = nullptr; // SIFT distance per pair of the run (refine_confidences, :757)
+    if (p->use_sift)
+    {
+        // 0. augment_Edge_Data (:1410) + apply_SIFT_filtering (:1414): descriptors of every left and right TOED edge on the
+        // undistorted images (each right edge once, not once per left edge that lists it), the smallest of the four
+        // distances per candidate pair, dist < thr.  NCC scores do not depend on which pairs survive, so the SIFT filter
+        // applied to the NCC-scored pairs of the run selects the reference's SIFT-then-NCC survivors.
+        const int nR = s.result.n_right;
+        const size_t npx = (size_t)h * w;
+        if ((rc = ebvo_grow(ctx, s, s.sift_img, sizeof(float) * 2 * npx)) ||
+            (rc = ebvo_grow(ctx, s, s.sift_desc, 256 * ((size_t)nL + (size_t)nR))) ||
+            (rc = ebvo_grow(ctx, s, s.sift_dist, sizeof(double) * nz + 2 * nz)) ||
+            (rc = ebvo_grow(ctx, s, s.pair_left, sizeof(int32_t) * nz)))
+            return rc;
+        float *tmp = (float *)s.sift_img.p, *base = tmp + npx;
+        uint8_t *dL = (uint8_t *)s.sift_desc.p, *dR = dL + 256 * (size_t)nL;
+        double *dist = (double *)s.sift_dist.p;
+        uint8_t *ok = (uint8_t *)(dist + nz), *both = ok + nz;
+        if ((rc = sift_base_enqueue(ctx, s, s.im[0].img, h, w, w, tmp, base)) ||
+            (rc = sift_descriptors_enqueue(ctx, s, base, h, w, s.im[0].edges, nL, nullptr, dL)) ||
+            (rc = sift_base_enqueue(ctx, s, s.im[1].img, h, w, w, tmp, base)) ||
+            (rc = sift_descriptors_enqueue(ctx, s, base, h, w, s.im[1].edges, nR, nullptr, dR)) ||
+            (rc = match_expand_rows_enqueue(ctx, s, rp0, nL, n0, (int32_t *)s.pair_left.p)) ||
+            (rc = sift_distances_enqueue(ctx, s, dL, dR, (const int32_t *)s.pair_left.p, (const int32_t *)s.col_idx.p, n0,
+                                         p->sift_thr, dist, ok)) ||
+            (rc = sift_and_flags_enqueue(ctx, s, ok, (const uint8_t *)s.keep.p, n0, both)))
+            return rc;
+        int32_t nS = 0;
+        if ((rc = glue_rows_from_flags_enqueue(ctx, s, rp0, nL, ok, cnt, order)) || (rc = scan_counts(rpA, &nS)))
+            return rc;
+        counts->n_sift = nS;
+        keep1 = both;
+        conf0 = dist;
+    }
     // 1. the kept NCC matches as a CSR list of right TOED edges with their scores (apply_NCC_Filtering's output, :597-607)
-    if ((rc = glue_rows_from_flags_enqueue(ctx, s, rp0, nL, (const uint8_t *)s.keep.p, cnt, order)) ||
-        (rc = scan_counts(rpA, &nA)) ||
+    if ((rc = glue_rows_from_flags_enqueue(ctx, s, rp0, nL, keep1, cnt, order)) || (rc = scan_counts(rpA, &nA)) ||
         (rc = glue_gather_rows_enqueue(ctx, s, rp0, cnt, order, rpA, nL, s.im[1].edges, (const int32_t *)s.col_idx.p, candA,
-                                       (const double *)s.best.p, scoreA)))
+                                       (const double *)s.best.p, scoreA)) ||
+        (conf0 && (rc = glue_gather_rows_enqueue(ctx, s, rp0, cnt, order, rpA, nL, nullptr, nullptr, nullptr, conf0, confA))))
         return rc;
     counts->n_ncc = nA;
-    // 2. Best-Nearly-Best test on the NCC scores (:1418)
+    // 2. Best-Nearly-Best test on the NCC scores (:1440) ...
     if (nA && ((rc = glue_bnb_enqueue(ctx, s, rpA, nL, scoreA, p->bnb_ratio, 1, cnt, order)) || (rc = scan_counts(rpB, &nB)) ||
-               (rc = glue_gather_rows_enqueue(ctx, s, rpA, cnt, order, rpB, nL, candA, nullptr, candB, scoreA, scoreB))))
+               (rc = glue_gather_rows_enqueue(ctx, s, rpA, cnt, order, rpB, nL, candA, nullptr, candB, scoreA, scoreB)) ||
+               (conf0 && (rc = glue_gather_rows_enqueue(ctx, s, rpA, cnt, order, rpB, nL, nullptr, nullptr, nullptr, confA, confB)))))
         return rc;
+    if (conf0 && nB)
+    {
+        // ... and on the SIFT distances, lower is better (:1452).  The survivors return to candB / rpB.
+        int32_t nB2 = 0;
+        if ((rc = glue_bnb_enqueue(ctx, s, rpB, nL, confB, p->bnb_sift, 0, cnt, order)) || (rc = scan_counts(rpA, &nB2)) ||
+            (rc = glue_gather_rows_enqueue(ctx, s, rpB, cnt, order, rpA, nL, candB, nullptr, candA, scoreB, scoreA)) ||
+            (rc = hipMemcpyAsync(rpB, rpA, sizeof(int32_t) * nLz, hipMemcpyDeviceToDevice, st) == hipSuccess ? EBVO_OK : EBVO_ERR_HIP) ||
+            (nB2 && (rc = hipMemcpyAsync(candB, candA, sizeof(ebvo_edge) * (size_t)nB2, hipMemcpyDeviceToDevice, st) == hipSuccess
+                              ? EBVO_OK
+                              : EBVO_ERR_HIP)))
+            return rc;
+        nB = nB2;
+    }
     counts->n_bnb = nB;
     if (nB)
     {
@@ -1569,6 +1619,72 @@ extern "C" int ebvo_stereo_fetch_slot(ebvo_ctx *ctx, int slot, ebvo_edge *left, 
 }
 
 
+
+
+// ---- fixed-scale SIFT descriptors and the descriptor-distance score ---------------------------------------------------
+extern "C" int ebvo_sift_descriptors(ebvo_ctx *ctx, const uint8_t *img, int h, int w, ptrdiff_t stride, const ebvo_edge *edges,
+                                     int n, float *desc)
+{
+    if (!ctx || !img || n < 0 || (n > 0 && (!edges || !desc)))
+        return EBVO_ERR_ARG;
+    EBVO_HIP(ctx, hipSetDevice(ctx->device));
+    int rc;
+    Slot *sp;
+    if ((rc = check_size(ctx, h, w)) || (rc = host_slot(ctx, &sp)))
+        return rc;
+    Slot &s = *sp;
+    if (n == 0)
+        return EBVO_OK;
+    const size_t npx = (size_t)h * w, nz = (size_t)n;
+    if ((rc = upload_image(ctx, s, 0, img, h, w, stride)) || (rc = ebvo_grow(ctx, s, s.sift_img, sizeof(float) * 2 * npx)) ||
+        (rc = ebvo_grow(ctx, s, s.scratch_b, sizeof(ebvo_edge) * nz)) ||
+        (rc = ebvo_grow(ctx, s, s.sift_f32, sizeof(float) * 256 * nz)))
+        return rc;
+    EBVO_HIP(ctx, hipMemcpyAsync(s.scratch_b.p, edges, sizeof(ebvo_edge) * nz, hipMemcpyHostToDevice, s.stream));
+    float *tmp = (float *)s.sift_img.p, *base = tmp + npx;
+    if ((rc = sift_base_enqueue(ctx, s, s.im[0].img, h, w, w, tmp, base)) ||
+        (rc = sift_descriptors_enqueue(ctx, s, base, h, w, (const ebvo_edge *)s.scratch_b.p, n, (float *)s.sift_f32.p, nullptr)))
+        return rc;
+    EBVO_HIP(ctx, hipMemcpyAsync(desc, s.sift_f32.p, sizeof(float) * 256 * nz, hipMemcpyDeviceToHost, s.stream));
+    EBVO_HIP(ctx, hipStreamSynchronize(s.stream));
+    return EBVO_OK;
+}
+
+extern "C" int ebvo_sift_min_distances(ebvo_ctx *ctx, const float *left_desc, int nL, const float *cand_desc,
+                                       const int32_t *row_ptr, double *dist)
+{
+    int64_t np = 0;
+    if (!ctx || check_csr(row_ptr, nL, &np) || (np > 0 && (!left_desc || !cand_desc || !dist)))
+        return EBVO_ERR_ARG;
+    EBVO_HIP(ctx, hipSetDevice(ctx->device));
+    int rc;
+    Slot *sp;
+    if ((rc = host_slot(ctx, &sp)))
+        return rc;
+    Slot &s = *sp;
+    if (np == 0)
+        return EBVO_OK;
+    const size_t npz = (size_t)np, nLz = (size_t)nL;
+    if ((rc = ebvo_grow(ctx, s, s.sift_f32, sizeof(float) * 256 * (npz + nLz))) ||
+        (rc = ebvo_grow(ctx, s, s.sift_desc, 256 * (npz + nLz))) ||
+        (rc = ebvo_grow(ctx, s, s.row_ptr, sizeof(int32_t) * (nLz + 1))) ||
+        (rc = ebvo_grow(ctx, s, s.pair_left, sizeof(int32_t) * npz)) || (rc = ebvo_grow(ctx, s, s.sift_dist, sizeof(double) * npz)))
+        return rc;
+    hipStream_t st = s.stream;
+    float *fl = (float *)s.sift_f32.p, *fc = fl + 256 * nLz;
+    uint8_t *ul = (uint8_t *)s.sift_desc.p, *uc = ul + 256 * nLz;
+    EBVO_HIP(ctx, hipMemcpyAsync(fl, left_desc, sizeof(float) * 256 * nLz, hipMemcpyHostToDevice, st));
+    EBVO_HIP(ctx, hipMemcpyAsync(fc, cand_desc, sizeof(float) * 256 * npz, hipMemcpyHostToDevice, st));
+    EBVO_HIP(ctx, hipMemcpyAsync(s.row_ptr.p, row_ptr, sizeof(int32_t) * (nLz + 1), hipMemcpyHostToDevice, st));
+    if ((rc = sift_to_u8_enqueue(ctx, s, fl, (int64_t)(256 * (nLz + npz)), ul)) ||
+        (rc = match_expand_rows_enqueue(ctx, s, (const int32_t *)s.row_ptr.p, nL, np, (int32_t *)s.pair_left.p)) ||
+        (rc = sift_distances_enqueue(ctx, s, ul, uc, (const int32_t *)s.pair_left.p, nullptr, np, EBVO_SIFT_THRESHOLD,
+                                     (double *)s.sift_dist.p, nullptr)))
+        return rc;
+    EBVO_HIP(ctx, hipMemcpyAsync(dist, s.sift_dist.p, sizeof(double) * npz, hipMemcpyDeviceToHost, st));
+    EBVO_HIP(ctx, hipStreamSynchronize(st));
+    return EBVO_OK;
+}
 
 // ---- input side: cv::undistort ---------------------------------------------------------------------------------
 extern "C" int ebvo_undistort(ebvo_ctx *ctx, const uint8_t *img, int h, int w, ptrdiff_t stride, const double K[4],

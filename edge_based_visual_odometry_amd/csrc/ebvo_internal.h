@@ -31,6 +31,7 @@ enum KernelId
     K_MISC,
     K_SOBEL,
     K_GN_REFINE,
+    K_SIFT,
     K_NUM
 };
 static_assert(K_NUM <= EBVO_MAX_KERNELS, "grow EBVO_MAX_KERNELS");
@@ -113,6 +114,7 @@ struct Slot
 
     // matching workspace
     GrowBuf grad_x, grad_y, gn_xy, gn_out, gn_valid, gn_iters, gn_state, gn_lists, gn_pack; // photometric refinement (refine_kernels.hip)
+    GrowBuf sift_img, sift_desc, sift_f32, sift_dist; // SIFT: blurred levels, descriptor banks, per-pair distances (sift_kernels.hip)
     GrowBuf fin_i32, fin_edges, fin_f64, fin_u8, fin_out; // ebvo_stereo_finalize: CSRs, candidate lists, scores, final rows
     int n_final = 0;
     bool have_final = false, final_has_rows = false;
@@ -269,6 +271,14 @@ int refine_gn_temporal_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_imgK, co
                                int h, int w, const ebvo_edge *d_kf, const ebvo_edge *d_cf, const double *d_init, int64_t n,
                                int max_iter, double tol, double huber, double *d_disp, double *d_score, uint8_t *d_valid,
                                int32_t *d_iters);
+// sift_kernels.hip
+int sift_base_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_img, int h, int w, int pitch, float *d_tmp, float *d_base);
+int sift_descriptors_enqueue(ebvo_ctx *ctx, Slot &s, const float *d_base, int h, int w, const ebvo_edge *d_edges, int n,
+                             float *d_desc_f, uint8_t *d_desc_u8);
+int sift_to_u8_enqueue(ebvo_ctx *ctx, Slot &s, const float *d_f, int64_t n, uint8_t *d_u8);
+int sift_distances_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_left, const uint8_t *d_cand, const int32_t *d_pair_left,
+                           const int32_t *d_cand_index, int64_t n_pairs, double thr, double *d_dist, uint8_t *d_ok);
+int sift_and_flags_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_a, const uint8_t *d_b, int64_t n, uint8_t *d_out);
 int match_expand_rows_enqueue(ebvo_ctx *ctx, Slot &s, const int32_t *d_row_ptr, int nL, int64_t n_pairs, int32_t *d_pair_left);
 int match_ncc_stored_enqueue(ebvo_ctx *ctx, Slot &s, const float *d_A, const float *d_B, int n, double *d_sim);
 int misc_fp64_peak(ebvo_ctx *ctx, Slot &s, int iters, double *tf_muladd, double *tf_fma);

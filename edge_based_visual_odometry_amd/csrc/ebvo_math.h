@@ -456,4 +456,63 @@ EBVO_MATH_FN double ebvo_exp(double x)
     return __builtin_ldexp(v, k); /* exact scaling (v_ldexp_f64 on the device, scalbn on the host) */
 }
 
+/*
+ * Single-precision helpers of the fixed-scale SIFT descriptor (cv::SIFT::compute at given keypoints; OpenCV is not in the
+ * reference tree, see oracle/ebvo_oracle.c: orc_sift_*).  OpenCV evaluates the Gaussian sample weights with its own
+ * table-driven hal::exp32f and the gradient orientations with hal::fastAtan2, both approximations whose last bits depend
+ * on the build (SIMD width, FMA); here both sides (oracle and kernels) call these two routines, float arithmetic with
+ * separate multiply and add:
+ *   ebvo_expf          exp(x) by Cody-Waite reduction and a degree-6 Taylor polynomial, about 1 ulp;
+ *   ebvo_fast_atan2_deg  OpenCV's published fastAtan2 polynomial (degrees in [0, 360), max error ~0.3 degrees),
+ *                        modules/core/src/mathfuncs_core.simd.hpp: atan_f32.
+ */
+EBVO_MATH_FN float ebvo_expf(float x)
+{
+    if (x != x)
+        return x;
+    if (x > 88.0f)
+        return 3.4028234663852886e38f * 2.0f;
+    if (x < -87.0f)
+        return 0.0f;
+    const float fk = x * 1.44269504088896341f;
+    const int k = (int)(fk + (fk >= 0.0f ? 0.5f : -0.5f));
+    const float dk = (float)k;
+    const float r = (x - dk * 0.693359375f) - dk * -2.12194440e-4f;
+    float p = 1.0f / 720.0f;
+    p = p * r + 1.0f / 120.0f;
+    p = p * r + 1.0f / 24.0f;
+    p = p * r + 1.0f / 6.0f;
+    p = p * r + 0.5f;
+    p = p * r + 1.0f;
+    p = p * r + 1.0f;
+    return __builtin_ldexpf(p, k);
+}
+
+EBVO_MATH_FN float ebvo_fast_atan2_deg(float y, float x)
+{
+    const float p1 = 0.9997878412794807f * (float)(180 / 3.14159265358979323846);
+    const float p3 = -0.3258083974640975f * (float)(180 / 3.14159265358979323846);
+    const float p5 = 0.1555786518463281f * (float)(180 / 3.14159265358979323846);
+    const float p7 = -0.04432655554792128f * (float)(180 / 3.14159265358979323846);
+    const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
+    float a, c, c2;
+    if (ax >= ay)
+    {
+        c = ay / (ax + (float)2.2204460492503131e-16);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    else
+    {
+        c = ax / (ay + (float)2.2204460492503131e-16);
+        c2 = c * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0)
+        a = 180.f - a;
+    if (y < 0)
+        a = 360.f - a;
+    return a;
+}
+
 #endif /* EBVO_MATH_H */

@@ -1,0 +1,363 @@
+// sift_kernels.hip -- fixed-scale SIFT descriptors at the +-8 px points of every edge and the descriptor-distance filter.
+//
+// Replaces, in the reference (OpenCV's cv::SIFT is third-party and absent from the reference tree:
+// PARITY UNPINNED, restated from the published OpenCV 4.x source, see oracle/ebvo_oracle.c: orc_sift_*):
+//   Stereo_Matches::augment_Edge_Data            src/Stereo_Matches.cpp:655-689   (cv::SIFT::compute per left edge)
+//   Stereo_Matches::apply_SIFT_filtering         :691-787                          (compute per candidate + min L2 distance)
+//   finalize_stereo_edge_mates (descriptors)     :1627-1635
+//
+// A cv::KeyPoint(pt, size 1, angle) has octave 0 and layer 0, so cv::SIFT::compute builds one octave and reads the
+// descriptor from its first level: GaussianBlur(float(image), sigma = sqrt(1.6^2 - 0.5^2), 13 taps, reflect-101).  The
+// reference rebuilds that pyramid once per EDGE (a full-image blur per call: SURVEY.md calls it the real CPU bottleneck);
+// here the level is formed once per image (sift_blur_*), and every keypoint is one thread:
+//   - 11 x 11 window of central differences around the rounded point, rotated into the keypoint frame (hist_width 1.5),
+//   - tri-linear accumulation into the (4 + 2) x (4 + 2) x (8 + 2) histogram IN SAMPLE ORDER (the scalar loop of
+//     calcSIFTDescriptor: float additions are not associative, so the order is part of the result).  The histogram is
+//     private to the thread and lives in LDS: hist[bin][lane], 360 x 64 floats = 90 KB per 64-thread workgroup.  Lane l
+//     only ever touches column l: whatever bins the lanes address, the 64 accesses of a wave fall on 64 different banks;
+//   - circular orientation wrap, 0.2 clipping, x 512, round to 0 .. 255.
+// The one-wave-per-CU occupancy this costs is accepted: the alternative orders (LDS atomics, per-cell ownership) either
+// change the bits from run to run or multiply the work.
+//
+// Compiled with -ffp-contract=off (float multiply and add stay separate, as in the oracle).
+#include "ebvo_internal.h"
+#include "ebvo_math.h"
+
+namespace
+{
+
+struct Taps13
+{
+    float k[13];
+};
+
+__device__ inline int reflect101(int p, int n)
+{
+    if (n == 1)
+        return 0;
+    while (p < 0 || p >= n)
+        p = p < 0 ? -p : 2 * (n - 1) - p;
+    return p;
+}
+
+// row pass: taps in ascending order (cv::RowFilter), float
+__global__ __launch_bounds__(256) void sift_blur_rows_kernel(const uint8_t *__restrict__ img, int h, int w, int pitch, Taps13 T,
+                                                             float *__restrict__ tmp)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h)
+        return;
+    const uint8_t *row = img + (size_t)y * pitch;
+    float s = (float)row[reflect101(x - 6, w)] * T.k[0];
+#pragma unroll
+    for (int t = 1; t < 13; ++t)
+        s += (float)row[reflect101(x - 6 + t, w)] * T.k[t];
+    tmp[(size_t)y * w + x] = s;
+}
+
+// column pass: centre first, then the symmetric pairs (cv::SymmColumnFilter)
+__global__ __launch_bounds__(256) void sift_blur_cols_kernel(const float *__restrict__ tmp, int h, int w, Taps13 T,
+                                                             float *__restrict__ base)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h)
+        return;
+    float s = T.k[6] * tmp[(size_t)y * w + x];
+#pragma unroll
+    for (int t = 1; t <= 6; ++t)
+        s += T.k[6 + t] * (tmp[(size_t)reflect101(y + t, h) * w + x] + tmp[(size_t)reflect101(y - t, h) * w + x]);
+    base[(size_t)y * w + x] = s;
+}
+
+constexpr int SD = 4, SN = 8;                                  // SIFT_DESCR_WIDTH, SIFT_DESCR_HIST_BINS
+constexpr int SHIST = (SD + 2) * (SD + 2) * (SN + 2);          // 360
+constexpr float FLT_EPS = 1.1920928955078125e-07f;
+
+__device__ inline int cv_round_f(float v) { return (int)rintf(v); }
+
+// calcSIFTDescriptor (modules/features2d/src/sift.simd.hpp), one thread per keypoint (edge e, side sd)
+__global__ __launch_bounds__(64) void sift_desc_kernel(const float *__restrict__ base, int rows, int cols,
+                                                       const ebvo_edge *__restrict__ edges, int n_edges,
+                                                       float *__restrict__ desc_f, uint8_t *__restrict__ desc_u8)
+{
+    __shared__ float hist[SHIST * 64];
+    const int lane = threadIdx.x;
+    const int n_kp = n_edges * 2;
+    for (int base_kp = blockIdx.x * 64; base_kp < n_kp; base_kp += gridDim.x * 64)
+    {
+        const int kp = base_kp + lane;
+        if (kp >= n_kp)
+            continue; // no barrier below: every lane owns its own histogram column
+        const int e = kp >> 1, sd = kp & 1;
+        const ebvo_edge ed = edges[e];
+        double sn, cs;
+        ebvo_sincos(ed.theta, &sn, &cs);
+        // get_Orthogonal_Shifted_Points(edge, 8), src/utility.cpp:128-139; cv::KeyPoint takes a Point2f
+        const double pxd = sd ? ed.x + 8 * (-sn) : ed.x + 8 * (sn);
+        const double pyd = sd ? ed.y + 8 * (cs) : ed.y + 8 * (-cs);
+        const float ptx = (float)pxd, pty = (float)pyd;
+        const float kp_angle = (float)(180 / 3.14159265358979323846 * ed.theta);
+        float ori = 360.f - kp_angle;
+        if (fabsf(ori - 360.f) < FLT_EPS)
+            ori = 0.f;
+        const int px = cv_round_f(ptx), py = cv_round_f(pty);
+        const float arg = ori * (float)(3.14159265358979323846 / 180);
+        double sd_, cd_;
+        ebvo_sincos((double)arg, &sd_, &cd_);
+        float cos_t = (float)cd_, sin_t = (float)sd_;
+        const float bins_per_rad = SN / 360.f;
+        const float exp_scale = -1.f / (SD * SD * 0.5f);
+        const float hist_width = 3.0f * 0.5f;
+        int radius = cv_round_f(hist_width * 1.4142135623730951f * (SD + 1) * 0.5f);
+        const int diag = (int)sqrt(((double)cols) * cols + ((double)rows) * rows);
+        radius = radius < diag ? radius : diag;
+        cos_t /= hist_width;
+        sin_t /= hist_width;
+        float *H = hist + lane;
+        for (int b = 0; b < SHIST; ++b)
+            H[b * 64] = 0.f;
+        for (int i = -radius; i <= radius; ++i)
+            for (int j = -radius; j <= radius; ++j)
+            {
+                const float c_rot = j * cos_t - i * sin_t;
+                const float r_rot = j * sin_t + i * cos_t;
+                float rbin = r_rot + SD / 2 - 0.5f;
+                float cbin = c_rot + SD / 2 - 0.5f;
+                const int r = py + i, c = px + j;
+                if (rbin > -1 && rbin < SD && cbin > -1 && cbin < SD && r > 0 && r < rows - 1 && c > 0 && c < cols - 1)
+                {
+                    const float dx = base[(size_t)r * cols + c + 1] - base[(size_t)r * cols + c - 1];
+                    const float dy = base[(size_t)(r - 1) * cols + c] - base[(size_t)(r + 1) * cols + c];
+                    const float wexp = (c_rot * c_rot + r_rot * r_rot) * exp_scale;
+                    const float Ori = ebvo_fast_atan2_deg(dy, dx);
+                    const float Mag = sqrtf(dx * dx + dy * dy);
+                    const float W = ebvo_expf(wexp);
+                    float obin = (Ori - ori) * bins_per_rad;
+                    const float mag = Mag * W;
+                    const int r0 = (int)floorf(rbin), c0 = (int)floorf(cbin);
+                    int o0 = (int)floorf(obin);
+                    rbin -= r0;
+                    cbin -= c0;
+                    obin -= o0;
+                    if (o0 < 0)
+                        o0 += SN;
+                    if (o0 >= SN)
+                        o0 -= SN;
+                    const float v_r1 = mag * rbin, v_r0 = mag - v_r1;
+                    const float v_rc11 = v_r1 * cbin, v_rc10 = v_r1 - v_rc11;
+                    const float v_rc01 = v_r0 * cbin, v_rc00 = v_r0 - v_rc01;
+                    const float v_rco111 = v_rc11 * obin, v_rco110 = v_rc11 - v_rco111;
+                    const float v_rco101 = v_rc10 * obin, v_rco100 = v_rc10 - v_rco101;
+                    const float v_rco011 = v_rc01 * obin, v_rco010 = v_rc01 - v_rco011;
+                    const float v_rco001 = v_rc00 * obin, v_rco000 = v_rc00 - v_rco001;
+                    const int idx = ((r0 + 1) * (SD + 2) + c0 + 1) * (SN + 2) + o0;
+                    H[(idx)*64] += v_rco000;
+                    H[(idx + 1) * 64] += v_rco001;
+                    H[(idx + (SN + 2)) * 64] += v_rco010;
+                    H[(idx + (SN + 3)) * 64] += v_rco011;
+                    H[(idx + (SD + 2) * (SN + 2)) * 64] += v_rco100;
+                    H[(idx + (SD + 2) * (SN + 2) + 1) * 64] += v_rco101;
+                    H[(idx + (SD + 3) * (SN + 2)) * 64] += v_rco110;
+                    H[(idx + (SD + 3) * (SN + 2) + 1) * 64] += v_rco111;
+                }
+            }
+        // the orientation histograms are circular; the 4 x 4 x 8 interior is the raw descriptor (kept in place)
+        float nrm2 = 0;
+        for (int i = 0; i < SD; ++i)
+            for (int j = 0; j < SD; ++j)
+            {
+                const int idx = ((i + 1) * (SD + 2) + (j + 1)) * (SN + 2);
+                H[idx * 64] += H[(idx + SN) * 64];
+                H[(idx + 1) * 64] += H[(idx + SN + 1) * 64];
+            }
+        for (int i = 0; i < SD; ++i)
+            for (int j = 0; j < SD; ++j)
+                for (int k = 0; k < SN; ++k)
+                {
+                    const float v = H[(((i + 1) * (SD + 2) + (j + 1)) * (SN + 2) + k) * 64];
+                    nrm2 += v * v;
+                }
+        const float thr = sqrtf(nrm2) * 0.2f;
+        nrm2 = 0;
+        for (int i = 0; i < SD; ++i)
+            for (int j = 0; j < SD; ++j)
+                for (int k = 0; k < SN; ++k)
+                {
+                    float *p = &H[(((i + 1) * (SD + 2) + (j + 1)) * (SN + 2) + k) * 64];
+                    const float val = *p < thr ? *p : thr;
+                    *p = val;
+                    nrm2 += val * val;
+                }
+        const float sq = sqrtf(nrm2);
+        nrm2 = 512.f / (sq > FLT_EPS ? sq : FLT_EPS);
+        for (int i = 0; i < SD; ++i)
+            for (int j = 0; j < SD; ++j)
+                for (int k = 0; k < SN; ++k)
+                {
+                    int v = cv_round_f(H[(((i + 1) * (SD + 2) + (j + 1)) * (SN + 2) + k) * 64] * nrm2);
+                    v = v < 0 ? 0 : (v > 255 ? 255 : v);
+                    const size_t o = (size_t)kp * 128 + (i * SD + j) * SN + k;
+                    if (desc_f)
+                        desc_f[o] = (float)v;
+                    if (desc_u8)
+                        desc_u8[o] = (uint8_t)v;
+                }
+    }
+}
+
+// float descriptors (host-buffer call) -> bytes
+__global__ void sift_to_u8_kernel(const float *__restrict__ f, int64_t n, uint8_t *__restrict__ u)
+{
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x)
+        u[k] = (uint8_t)f[k];
+}
+
+// apply_SIFT_filtering's score (src/Stereo_Matches.cpp:736-740): min of the four L2 distances between the two descriptors
+// of the left edge and the two of the candidate.  Descriptor entries are integers 0 .. 255: the sums of squares are exact
+// in any order, the distance is sqrt of an exact integer.  Sixteen lanes per pair, eight bytes per lane and descriptor.
+__global__ __launch_bounds__(256) void sift_dist_kernel(const uint8_t *__restrict__ left, const uint8_t *__restrict__ cand,
+                                                        const int32_t *__restrict__ pair_left,
+                                                        const int32_t *__restrict__ cand_index /* NULL: pair k -> cand k */,
+                                                        int64_t n_pairs, double thr, double *__restrict__ dist,
+                                                        uint8_t *__restrict__ ok)
+{
+    const int64_t groups = ((int64_t)gridDim.x * blockDim.x) >> 4;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int g = (int)(t & 15);
+    for (int64_t k = t >> 4; k < ((n_pairs + groups - 1) / groups) * groups; k += groups)
+    {
+        const bool valid = k < n_pairs;
+        unsigned s[4] = {0, 0, 0, 0};
+        if (valid)
+        {
+            const size_t li = (size_t)pair_left[k], ri = cand_index ? (size_t)cand_index[k] : (size_t)k;
+            unsigned long long a[2], b[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+            {
+                a[q] = *reinterpret_cast<const unsigned long long *>(left + (li * 2 + q) * 128 + g * 8);
+                b[q] = *reinterpret_cast<const unsigned long long *>(cand + (ri * 2 + q) * 128 + g * 8);
+            }
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) // :736-739 order: (L1,R1), (L2,R1), (L1,R2), (L2,R2)
+            {
+                const unsigned long long x = a[tt & 1], y = b[tt >> 1];
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                {
+                    const int d = (int)((x >> (8 * q)) & 0xff) - (int)((y >> (8 * q)) & 0xff);
+                    s[tt] += (unsigned)(d * d);
+                }
+            }
+        }
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+            for (int m = 1; m < 16; m <<= 1)
+                s[tt] += __shfl_xor(s[tt], m);
+        if (valid && g == 0)
+        {
+            double best = sqrt((double)s[0]);
+#pragma unroll
+            for (int tt = 1; tt < 4; ++tt)
+            {
+                const double d = sqrt((double)s[tt]);
+                if (d < best)
+                    best = d;
+            }
+            if (dist)
+                dist[k] = best;
+            if (ok)
+                ok[k] = best < thr ? 1 : 0; // :752
+        }
+    }
+}
+
+__global__ void and_flags_kernel(const uint8_t *__restrict__ a, const uint8_t *__restrict__ b, int64_t n, uint8_t *__restrict__ o)
+{
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x)
+        o[k] = (a[k] && b[k]) ? 1 : 0;
+}
+
+Taps13 host_taps()
+{
+    // createInitialImage: sig_diff = sqrtf(max(sigma^2 - 0.5^2, 0.01f)) in float; getGaussianKernel(13, sig_diff, CV_32F)
+    const float sigma = 1.6f;
+    const float v = sigma * sigma - 0.5f * 0.5f;
+    const float sd = sqrtf(v > 0.01f ? v : 0.01f);
+    const double sigmaX = (double)sd, scale2X = -0.5 / (sigmaX * sigmaX);
+    double kd[13], sum = 0;
+    for (int i = 0; i < 13; ++i)
+    {
+        const double x = i - (13 - 1) * 0.5;
+        kd[i] = exp(scale2X * x * x);
+        sum += kd[i];
+    }
+    sum = 1. / sum;
+    Taps13 T;
+    for (int i = 0; i < 13; ++i)
+        T.k[i] = (float)(kd[i] * sum);
+    return T;
+}
+
+inline unsigned grid1d(int64_t items, int per_block, int max_blocks)
+{
+    int64_t b = (items + per_block - 1) / per_block;
+    b = b < 1 ? 1 : (b > max_blocks ? max_blocks : b);
+    return (unsigned)b;
+}
+
+} // namespace
+
+// gpyr[0] of cv::SIFT::compute for a resident image: d_tmp, d_base are h x w floats
+int sift_base_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_img, int h, int w, int pitch, float *d_tmp, float *d_base)
+{
+    static const Taps13 T = host_taps();
+    ProfScope ps(ctx, s, K_SIFT);
+    const dim3 g((w + 63) / 64, (h + 3) / 4);
+    hipLaunchKernelGGL(sift_blur_rows_kernel, g, dim3(256), 0, s.stream, d_img, h, w, pitch, T, d_tmp);
+    hipLaunchKernelGGL(sift_blur_cols_kernel, g, dim3(256), 0, s.stream, (const float *)d_tmp, h, w, T, d_base);
+    EBVO_HIP(ctx, hipGetLastError());
+    return EBVO_OK;
+}
+
+int sift_descriptors_enqueue(ebvo_ctx *ctx, Slot &s, const float *d_base, int h, int w, const ebvo_edge *d_edges, int n,
+                             float *d_desc_f, uint8_t *d_desc_u8)
+{
+    if (n <= 0)
+        return EBVO_OK;
+    ProfScope ps(ctx, s, K_SIFT);
+    hipLaunchKernelGGL(sift_desc_kernel, dim3(grid1d((int64_t)n * 2, 64, 1 << 20)), dim3(64), 0, s.stream, d_base, h, w, d_edges,
+                       n, d_desc_f, d_desc_u8);
+    EBVO_HIP(ctx, hipGetLastError());
+    return EBVO_OK;
+}
+
+int sift_to_u8_enqueue(ebvo_ctx *ctx, Slot &s, const float *d_f, int64_t n, uint8_t *d_u8)
+{
+    if (n <= 0)
+        return EBVO_OK;
+    hipLaunchKernelGGL(sift_to_u8_kernel, dim3(grid1d(n, 256, 4096)), dim3(256), 0, s.stream, d_f, n, d_u8);
+    EBVO_HIP(ctx, hipGetLastError());
+    return EBVO_OK;
+}
+
+int sift_distances_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_left, const uint8_t *d_cand, const int32_t *d_pair_left,
+                           const int32_t *d_cand_index, int64_t n_pairs, double thr, double *d_dist, uint8_t *d_ok)
+{
+    if (n_pairs <= 0)
+        return EBVO_OK;
+    ProfScope ps(ctx, s, K_SIFT);
+    hipLaunchKernelGGL(sift_dist_kernel, dim3(grid1d(n_pairs * 16, 256, 4096)), dim3(256), 0, s.stream, d_left, d_cand,
+                       d_pair_left, d_cand_index, n_pairs, thr, d_dist, d_ok);
+    EBVO_HIP(ctx, hipGetLastError());
+    return EBVO_OK;
+}
+
+int sift_and_flags_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_a, const uint8_t *d_b, int64_t n, uint8_t *d_out)
+{
+    if (n <= 0)
+        return EBVO_OK;
+    hipLaunchKernelGGL(and_flags_kernel, dim3(grid1d(n, 256, 4096)), dim3(256), 0, s.stream, d_a, d_b, n, d_out);
+    EBVO_HIP(ctx, hipGetLastError());
+    return EBVO_OK;
+}

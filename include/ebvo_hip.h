@@ -31,7 +31,8 @@
 extern "C" {
 #endif
 
-#define EBVO_ABI_VERSION 3 /* 2: photometric refinement, stage glue, finalisation, resident chain; 3: pinned result views */
+#define EBVO_ABI_VERSION 3 /* 2: photometric refinement, stage glue, finalisation, resident chain; 3: pinned result views,
+                              undistortion, SIFT descriptors, SIFT stages of the chain */
 
 typedef struct ebvo_ctx ebvo_ctx;
 
@@ -176,6 +177,30 @@ typedef struct ebvo_undistort_params
 } ebvo_undistort_params;
 int ebvo_stereo_set_undistort(ebvo_ctx *ctx, const ebvo_undistort_params *p);
 
+/* ---- fixed-scale SIFT descriptors (cv::SIFT is third-party: parity unpinned) --------------- */
+
+#define EBVO_SIFT_THRESHOLD 500.0 /* include/definitions.h:40 */
+#define EBVO_SIFT_DESC_LEN 128
+
+/*
+ * Replaces the cv::SIFT::create()->compute(image, {kp1, kp2}, desc) calls of Stereo_Matches::augment_Edge_Data
+ * (src/Stereo_Matches.cpp:655-689), apply_SIFT_filtering (:716-727) and finalize_stereo_edge_mates (:1627-1635): the
+ * descriptors at the two points 8 px either side of every edge (get_Orthogonal_Shifted_Points(edge, 8)), keypoint size 1,
+ * angle 180 / pi * theta.  OpenCV 4.x restated: first pyramid level = GaussianBlur(sigma sqrt(1.6^2 - 0.5^2)) of the
+ * image, formed ONCE per call instead of once per edge; 4 x 4 x 8 histogram over an 11 x 11 window; values 0 .. 255
+ * stored as floats like cv::SIFT's CV_32F descriptors.
+ *   img : the undistorted CV_8UC1 image;  desc : n x 2 x 128 floats (plus point, minus point)
+ */
+int ebvo_sift_descriptors(ebvo_ctx *ctx, const uint8_t *img, int h, int w, ptrdiff_t stride, const ebvo_edge *edges, int n,
+                          float *desc);
+
+/* The score of Stereo_Matches::apply_SIFT_filtering (:736-740): per candidate pair the smallest of the four L2 distances
+ * between the two descriptors of the left edge and the two of the candidate.  left_desc: nL x 2 x 128, cand_desc: one
+ * descriptor pair per PAIR (n_pairs x 2 x 128, the order of the CSR lists); dist: n_pairs doubles.  The filter keeps
+ * dist < EBVO_SIFT_THRESHOLD and stores dist as refine_confidences (:752-757). */
+int ebvo_sift_min_distances(ebvo_ctx *ctx, const float *left_desc, int nL, const float *cand_desc, const int32_t *row_ptr,
+                            double *dist);
+
 /* ---- photometric refinement (no fixture of the reference pins it) -------------------- */
 
 /* Defaults of Stereo_Matches::min_Edge_Photometric_Residual_by_Gauss_Newton_along_EpipolarLine
@@ -312,24 +337,32 @@ int ebvo_stereo_fetch_refined(ebvo_ctx *ctx, int slot, double *alpha, double *sc
 /*
  * The stages of get_Stereo_Edge_Pairs after the NCC pass (src/Stereo_Matches.cpp:1418-1481), without SIFT, on the pair
  * resident in `slot` and without the candidate lists leaving the device:
- *   kept NCC matches -> apply_Best_Nearly_Best_Test(BNB_NCC) -> epipolar shift -> refine_edge_disparity ->
- *   clustering -> apply_NCC_Filtering on the cluster centres -> best candidate per row -> rows with a match
+ *   [SIFT filter ->] kept NCC matches -> apply_Best_Nearly_Best_Test(BNB_NCC) [-> (BNB_SIFT)] -> epipolar shift ->
+ *   refine_edge_disparity -> epipolar shift + clustering by orientation (:1483 as its arguments bind) ->
+ *   apply_NCC_Filtering on the cluster centres -> best candidate per row -> rows with a match
  * and, if calib is given, the 16 numbers of the output file per final pair.  Each stage is the kernel behind the
  * corresponding host-buffer entry point (ebvo_bnb_test, ebvo_epipolar_shift, ebvo_gn_refine_stereo,
  * ebvo_cluster_rows, ebvo_ncc_pairs, ebvo_keep_best, ebvo_finalize_pairs), so the result equals chaining those calls
- * on the fetched data.  The SIFT filter and the BNB test on SIFT distances of the reference (:1400, :1427) need OpenCV
- * and stay on the host; a caller that wants them runs the entry points one by one instead.
+ * on the fetched data.  With use_sift the SIFT filter (:1414) and the BNB test on the SIFT distances (:1452) run too
+ * (ebvo_sift_descriptors / ebvo_sift_min_distances on the resident pair): the chain is then get_Stereo_Edge_Pairs stage for
+ * stage.  (The NCC of a pair does not depend on which other pairs survive, so filtering by SIFT after the first NCC pass
+ * of ebvo_stereo_run selects the same pairs, with the same scores, as the reference's SIFT-then-NCC order.)
  */
 typedef struct
 {
     double bnb_ratio; /* EBVO_BNB_NCC */
     double ncc_thr;   /* EBVO_NCC_THRESH, second pass */
     ebvo_gn_params gn;
+    int use_sift;     /* 1: SIFT filter (:1414) and Best-Nearly-Best on the SIFT distances (:1452) are part of the chain */
+    int reserved;
+    double sift_thr;  /* EBVO_SIFT_THRESHOLD */
+    double bnb_sift;  /* EBVO_BNB_SIFT */
 } ebvo_finalize_params;
 
 typedef struct
 {
-    int32_t n_ncc, n_bnb, n_clusters, n_ncc2, n_final; /* candidates surviving each stage */
+    int32_t n_ncc, n_bnb, n_clusters, n_ncc2, n_final; /* candidates surviving each stage (n_ncc: SIFT and NCC filter) */
+    int32_t n_sift;                                    /* candidates passing the SIFT filter alone (use_sift) */
 } ebvo_finalize_counts;
 
 int ebvo_stereo_finalize(ebvo_ctx *ctx, int slot, const ebvo_finalize_params *params, const ebvo_stereo_calib *calib,
@@ -431,7 +464,7 @@ int ebvo_stereo_fetch_begin(ebvo_ctx *ctx, int slot, int what);
 int ebvo_stereo_fetch_end(ebvo_ctx *ctx, int slot, ebvo_stereo_view *view);
 
 /* Per-kernel device timing (HIP events on the slots' streams, accumulated). */
-#define EBVO_MAX_KERNELS 24
+#define EBVO_MAX_KERNELS 24 /* >= the number of kernel ids (ebvo_internal.h) */
 typedef struct ebvo_kernel_time
 {
     const char *name;

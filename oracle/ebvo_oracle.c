@@ -1494,3 +1494,245 @@ void orc_undistort(const uint8_t *img, int h, int w, ptrdiff_t stride, const dou
         }
     }
 }
+
+/* ------------------------------------------------------------------------------------ */
+/* Fixed-scale SIFT descriptors at the two +-8 px points of an edge                        */
+/* (Stereo_Matches::augment_Edge_Data src/Stereo_Matches.cpp:655-689, apply_SIFT_filtering  */
+/* :691-787, finalize_stereo_edge_mates :1627-1635: cv::SIFT::create()->compute(image, {kp1, */
+/* kp2}, desc) with cv::KeyPoint(pt, size = 1, angle = 180 / M_PI * theta)).               */
+/* OpenCV is not in the reference tree: this restates the published OpenCV 4.x source       */
+/* (modules/features2d/src/sift.dispatch.cpp detectAndCompute with useProvidedKeypoints,    */
+/* createInitialImage; sift.simd.hpp calcSIFTDescriptor).  PARITY UNPINNED.                 */
+/*   - a KeyPoint built this way has octave 0, layer 0: firstOctave = 0, one octave, and    */
+/*     the descriptor is taken from gpyr[0] = GaussianBlur(float(image), sigma =            */
+/*     sqrt(1.6^2 - 0.5^2), 13 taps, reflect-101) -- no pyramid level matters;             */
+/*   - scl = size * 0.5 = 0.5: hist_width 1.5, radius 5: an 11 x 11 window of central       */
+/*     differences, 4 x 4 x 8 tri-linear histogram, 0.2 clipping, x 512, rounded to 0..255. */
+/* Arithmetic fixed where OpenCV leaves it to the build: separable blur in float, row pass   */
+/* taps in ascending order, column pass centre first then symmetric pairs, no FMA;          */
+/* hal::exp32f -> ebvo_expf, hal::fastAtan2 -> its published polynomial (ebvo_math.h);      */
+/* cosf / sinf -> the shared correctly rounded pair, rounded to float; histogram updates in  */
+/* sample order (the scalar loop of calcSIFTDescriptor).                                    */
+/* ------------------------------------------------------------------------------------ */
+static int reflect101_i(int p, int n)
+{
+    if (n == 1)
+        return 0;
+    while (p < 0 || p >= n)
+        p = p < 0 ? -p : 2 * (n - 1) - p;
+    return p;
+}
+
+void orc_sift_kernel13(float k[13])
+{
+    /* sig_diff = sqrtf(max(sigma^2 - 0.5^2, 0.01f)) in float (createInitialImage); getGaussianKernel(13, sig_diff) */
+    const float sigma = 1.6f;
+    const float sd = sqrtf(sigma * sigma - 0.5f * 0.5f > 0.01f ? sigma * sigma - 0.5f * 0.5f : 0.01f);
+    const double sigmaX = (double)sd, scale2X = -0.5 / (sigmaX * sigmaX);
+    double kd[13], sum = 0;
+    for (int i = 0; i < 13; i++)
+    {
+        const double x = i - (13 - 1) * 0.5;
+        kd[i] = exp(scale2X * x * x);
+        sum += kd[i];
+    }
+    sum = 1. / sum;
+    for (int i = 0; i < 13; i++)
+        k[i] = (float)(kd[i] * sum);
+}
+
+void orc_sift_base(const uint8_t *img, int h, int w, ptrdiff_t stride, float *base)
+{
+    float k[13];
+    orc_sift_kernel13(k);
+    float *tmp = (float *)malloc(sizeof(float) * (size_t)h * w);
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++)
+        {
+            float s = (float)img[(ptrdiff_t)y * stride + reflect101_i(x - 6, w)] * k[0];
+            for (int t = 1; t < 13; t++)
+                s += (float)img[(ptrdiff_t)y * stride + reflect101_i(x - 6 + t, w)] * k[t];
+            tmp[(size_t)y * w + x] = s;
+        }
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++)
+        {
+            float s = k[6] * tmp[(size_t)y * w + x];
+            for (int t = 1; t <= 6; t++)
+                s += k[6 + t] * (tmp[(size_t)reflect101_i(y + t, h) * w + x] + tmp[(size_t)reflect101_i(y - t, h) * w + x]);
+            base[(size_t)y * w + x] = s;
+        }
+    free(tmp);
+}
+
+static int cv_round_f(float v) { return (int)nearbyintf(v); }
+
+static void sift_descriptor_one(const float *base, int rows, int cols, float ptx, float pty, float kp_angle, int math_mode,
+                                float *dst)
+{
+    enum { d = 4, n = 8 };
+    float ori = 360.f - kp_angle;
+    if (fabsf(ori - 360.f) < 1.1920928955078125e-07f)
+        ori = 0.f;
+    const int px = cv_round_f(ptx), py = cv_round_f(pty);
+    const float arg = ori * (float)(M_PI / 180);
+    float cos_t, sin_t;
+    if (math_mode == ORC_MATH_LIBM)
+    {
+        cos_t = cosf(arg);
+        sin_t = sinf(arg);
+    }
+    else
+    {
+        double sd_, cd_;
+        ebvo_sincos((double)arg, &sd_, &cd_);
+        cos_t = (float)cd_;
+        sin_t = (float)sd_;
+    }
+    const float bins_per_rad = n / 360.f;
+    const float exp_scale = -1.f / (d * d * 0.5f);
+    const float hist_width = 3.0f * 0.5f;
+    int radius = cv_round_f(hist_width * 1.4142135623730951f * (d + 1) * 0.5f);
+    const int diag = (int)sqrt(((double)cols) * cols + ((double)rows) * rows);
+    if (radius > diag)
+        radius = diag;
+    cos_t /= hist_width;
+    sin_t /= hist_width;
+    float hist[(d + 2) * (d + 2) * (n + 2)];
+    for (int i = 0; i < (d + 2) * (d + 2) * (n + 2); i++)
+        hist[i] = 0.f;
+    for (int i = -radius; i <= radius; i++)
+        for (int j = -radius; j <= radius; j++)
+        {
+            const float c_rot = j * cos_t - i * sin_t;
+            const float r_rot = j * sin_t + i * cos_t;
+            float rbin = r_rot + d / 2 - 0.5f;
+            float cbin = c_rot + d / 2 - 0.5f;
+            const int r = py + i, c = px + j;
+            if (rbin > -1 && rbin < d && cbin > -1 && cbin < d && r > 0 && r < rows - 1 && c > 0 && c < cols - 1)
+            {
+                const float dx = (float)(base[(size_t)r * cols + c + 1] - base[(size_t)r * cols + c - 1]);
+                const float dy = (float)(base[(size_t)(r - 1) * cols + c] - base[(size_t)(r + 1) * cols + c]);
+                const float wexp = (c_rot * c_rot + r_rot * r_rot) * exp_scale;
+                const float Ori = ebvo_fast_atan2_deg(dy, dx);
+                const float Mag = sqrtf(dx * dx + dy * dy);
+                const float W = math_mode == ORC_MATH_LIBM ? expf(wexp) : ebvo_expf(wexp);
+                float obin = (Ori - ori) * bins_per_rad;
+                const float mag = Mag * W;
+                const int r0 = (int)floorf(rbin), c0 = (int)floorf(cbin);
+                int o0 = (int)floorf(obin);
+                rbin -= r0;
+                cbin -= c0;
+                obin -= o0;
+                if (o0 < 0)
+                    o0 += n;
+                if (o0 >= n)
+                    o0 -= n;
+                const float v_r1 = mag * rbin, v_r0 = mag - v_r1;
+                const float v_rc11 = v_r1 * cbin, v_rc10 = v_r1 - v_rc11;
+                const float v_rc01 = v_r0 * cbin, v_rc00 = v_r0 - v_rc01;
+                const float v_rco111 = v_rc11 * obin, v_rco110 = v_rc11 - v_rco111;
+                const float v_rco101 = v_rc10 * obin, v_rco100 = v_rc10 - v_rco101;
+                const float v_rco011 = v_rc01 * obin, v_rco010 = v_rc01 - v_rco011;
+                const float v_rco001 = v_rc00 * obin, v_rco000 = v_rc00 - v_rco001;
+                const int idx = ((r0 + 1) * (d + 2) + c0 + 1) * (n + 2) + o0;
+                hist[idx] += v_rco000;
+                hist[idx + 1] += v_rco001;
+                hist[idx + (n + 2)] += v_rco010;
+                hist[idx + (n + 3)] += v_rco011;
+                hist[idx + (d + 2) * (n + 2)] += v_rco100;
+                hist[idx + (d + 2) * (n + 2) + 1] += v_rco101;
+                hist[idx + (d + 3) * (n + 2)] += v_rco110;
+                hist[idx + (d + 3) * (n + 2) + 1] += v_rco111;
+            }
+        }
+    float raw[d * d * n];
+    for (int i = 0; i < d; i++)
+        for (int j = 0; j < d; j++)
+        {
+            const int idx = ((i + 1) * (d + 2) + (j + 1)) * (n + 2);
+            hist[idx] += hist[idx + n];
+            hist[idx + 1] += hist[idx + n + 1];
+            for (int k = 0; k < n; k++)
+                raw[(i * d + j) * n + k] = hist[idx + k];
+        }
+    float nrm2 = 0;
+    const int len = d * d * n;
+    for (int k = 0; k < len; k++)
+        nrm2 += raw[k] * raw[k];
+    const float thr = sqrtf(nrm2) * 0.2f;
+    nrm2 = 0;
+    for (int i = 0; i < len; i++)
+    {
+        const float val = raw[i] < thr ? raw[i] : thr;
+        raw[i] = val;
+        nrm2 += val * val;
+    }
+    const float sq = sqrtf(nrm2);
+    nrm2 = 512.f / (sq > 1.1920928955078125e-07f ? sq : 1.1920928955078125e-07f);
+    for (int k = 0; k < len; k++)
+    {
+        const int v = cv_round_f(raw[k] * nrm2); /* saturate_cast<uchar>(float) */
+        dst[k] = (float)(v < 0 ? 0 : (v > 255 ? 255 : v));
+    }
+}
+
+/* desc: n x 2 x 128 floats (descriptor of the plus point, then of the minus point), values 0 .. 255 */
+void orc_sift_descriptors(const uint8_t *img, int h, int w, ptrdiff_t stride, const orc_edge *edges, int n, int math_mode,
+                          int nthreads, float *desc)
+{
+    float *base = (float *)malloc(sizeof(float) * (size_t)h * w);
+    orc_sift_base(img, h, w, stride, base);
+    if (nthreads > 0)
+        omp_set_num_threads(nthreads);
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int e = 0; e < n; e++)
+    {
+        double sn, cs;
+        if (math_mode == ORC_MATH_LIBM)
+        {
+            sn = sin(edges[e].theta);
+            cs = cos(edges[e].theta);
+        }
+        else
+            ebvo_sincos(edges[e].theta, &sn, &cs);
+        const float kp_angle = (float)(180 / M_PI * edges[e].theta);
+        for (int sd = 0; sd < 2; sd++)
+        {
+            /* get_Orthogonal_Shifted_Points(edge, 8), src/utility.cpp:128-139; cv::KeyPoint takes a Point2f */
+            const double px = sd ? edges[e].x + 8 * (-sn) : edges[e].x + 8 * (sn);
+            const double py = sd ? edges[e].y + 8 * (cs) : edges[e].y + 8 * (-cs);
+            sift_descriptor_one(base, h, w, (float)px, (float)py, kp_angle, math_mode, desc + ((size_t)e * 2 + sd) * 128);
+        }
+    }
+    free(base);
+}
+
+/* apply_SIFT_filtering's score (src/Stereo_Matches.cpp:736-740): min of the four L2 distances between the two
+ * descriptors of the left edge and the two of the candidate; cand_desc holds one descriptor pair per PAIR. */
+void orc_sift_min_distances(const float *left_desc, const float *cand_desc, const int32_t *row_ptr, int nL, double *dist)
+{
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int i = 0; i < nL; i++)
+        for (int k = row_ptr[i]; k < row_ptr[i + 1]; k++)
+        {
+            double best = 0;
+            /* :736-739 order: (L1,R1), (L2,R1), (L1,R2), (L2,R2) */
+            for (int t = 0; t < 4; t++)
+            {
+                const float *a = left_desc + ((size_t)i * 2 + (t & 1)) * 128, *b = cand_desc + ((size_t)k * 2 + (t >> 1)) * 128;
+                double s = 0;
+                for (int q = 0; q < 128; q++)
+                {
+                    const float v = a[q] - b[q];
+                    s += (double)v * v;
+                }
+                const double dd = sqrt(s);
+                if (t == 0 || dd < best)
+                    best = dd;
+            }
+            dist[k] = best;
+        }
+}

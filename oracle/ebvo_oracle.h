@@ -152,6 +152,14 @@ void orc_cluster_rows(const orc_edge *cand, const int32_t *row_ptr, int nL, int 
 void orc_undistort(const uint8_t *img, int h, int w, ptrdiff_t stride, const double K[4], const double *dist, int n_dist,
                    uint8_t *out, ptrdiff_t out_stride);
 
+/* cv::SIFT descriptors at the +-8 px points of every edge and apply_SIFT_filtering's score (OpenCV 4.x restated; PARITY
+ * UNPINNED).  desc: n x 2 x 128 floats. */
+void orc_sift_kernel13(float k[13]);
+void orc_sift_base(const uint8_t *img, int h, int w, ptrdiff_t stride, float *base);
+void orc_sift_descriptors(const uint8_t *img, int h, int w, ptrdiff_t stride, const orc_edge *edges, int n, int math_mode,
+                          int nthreads, float *desc);
+void orc_sift_min_distances(const float *left_desc, const float *cand_desc, const int32_t *row_ptr, int nL, double *dist);
+
 #ifdef __cplusplus
 }
 #endif

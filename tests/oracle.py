@@ -256,3 +256,30 @@ def undistort(img, K, dist):
     lib().orc_undistort(_p(img), h, w, C.c_ssize_t(img.strides[0]), _p(K), _p(dist), len(dist), _p(out),
                         C.c_ssize_t(out.strides[0]))
     return out
+
+
+def sift_base(img):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w = img.shape
+    out = np.zeros((h, w), dtype=np.float32)
+    lib().orc_sift_base(_p(img), h, w, C.c_ssize_t(img.strides[0]), _p(out))
+    return out
+
+
+def sift_descriptors(img, edges, math_mode=PORTABLE, nthreads=0):
+    """cv::SIFT descriptors at the +-8 px points of every edge: (n, 2, 128) float32, values 0..255."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w = img.shape
+    e = np.ascontiguousarray(edges, dtype=EDGE_DTYPE)
+    out = np.zeros((len(e), 2, 128), dtype=np.float32)
+    lib().orc_sift_descriptors(_p(img), h, w, C.c_ssize_t(img.strides[0]), _p(e), len(e), math_mode, nthreads, _p(out))
+    return out
+
+
+def sift_min_distances(left_desc, cand_desc, row_ptr):
+    left_desc = np.ascontiguousarray(left_desc, dtype=np.float32).reshape(-1, 2, 128)
+    cand_desc = np.ascontiguousarray(cand_desc, dtype=np.float32).reshape(-1, 2, 128)
+    row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int32)
+    out = np.zeros(len(cand_desc))
+    lib().orc_sift_min_distances(_p(left_desc), _p(cand_desc), _p(row_ptr), len(row_ptr) - 1, _p(out))
+    return out

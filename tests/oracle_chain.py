@@ -3,9 +3,9 @@ functions of the CPU restatement (oracle/ebvo_oracle.c), stage for stage, plus t
 (:1656-1699).  Test infrastructure: the device-resident chain (ebvo_stereo_finalize) is compared with THIS, not with
 the HIP entry points.
 
-The SIFT filter and the BNB test on SIFT distances (:1410-1414, :1452) are included when `sift` is given (a callable that
-returns the per-pair SIFT distance); without it the chain is the reference's with those two stages left out, which is
-what ebvo_stereo_finalize computes when its SIFT stages are disabled.
+The SIFT filter and the BNB test on SIFT distances (:1410-1414, :1452) are included with sift=True (the oracle's restated
+cv::SIFT descriptors); without it the chain is the reference's with those two stages left out, which is what
+ebvo_stereo_finalize computes with use_sift = 0.
 """
 from __future__ import annotations
 
@@ -39,7 +39,7 @@ def filter_rows(rp, mask):
 
 
 def stereo_edge_pairs(left_img, right_img, F, calib=None, bnb_ratio=0.9, ncc_thr=0.6, stage1=None, right_img_undist=None,
-                      left_img_undist=None, sift=None, sift_thr=500.0, bnb_sift=0.4, cluster_args=(True, False)):
+                      left_img_undist=None, sift=False, sift_thr=500.0, bnb_sift=0.4, cluster_args=(True, False)):
     """Runs the whole chain on the oracle.  stage1 = dict(left, right, row_ptr, col_idx, best, keep) may carry the
     results of TOED + candidates + first NCC pass if the caller already has them (they are oracle outputs too).
     left/right_img_undist: the undistorted images TOED and the refinement run on (None: the same as the raw ones, which
@@ -58,16 +58,16 @@ def stereo_edge_pairs(left_img, right_img, F, calib=None, bnb_ratio=0.9, ncc_thr
     nL = len(L)
     counts = {}
     conf = None
-    if sift is not None:
-        # SIFT filter BEFORE the NCC pass (:1414): pairs whose smallest descriptor distance is >= sift_thr are dropped;
-        # the distance is carried as refine_confidences (:757, :602)
-        d = sift(L, R[ci], rp)
+    if sift:
+        # augment_Edge_Data (:1410) + apply_SIFT_filtering (:1414), on the UNDISTORTED images: pairs whose smallest
+        # descriptor distance is >= sift_thr are dropped before the NCC filter; the distance is carried as
+        # refine_confidences (:757, :602).  NCC scores are per pair, so masking the already scored pairs is the same.
+        dl, dr = orc.sift_descriptors(lu, L), orc.sift_descriptors(ru, R)
+        d = orc.sift_min_distances(dl, dr[ci], rp)
         ok = d < sift_thr
-        rp0 = filter_rows(rp, ok)
-        ci0, d0 = ci[ok], d[ok]
-        sims, best, keep, _ = orc.ncc_pairs(left_img, right_img, L, R[ci0], rp0, ncc_thr)
-        rp, ci, conf = rp0, ci0, d0
         counts["n_sift"] = int(ok.sum())
+        keep = (keep.astype(bool) & ok).astype(np.uint8)
+        conf = d
     k = keep.astype(bool)
     cand = R[ci[k]].copy()
     cand["index"] = 0

@@ -50,10 +50,10 @@ def _oracle(name):
 
 
 @functools.lru_cache(maxsize=None)
-def _oracle_chain(name, by_orientation=True, skip_single=False):
+def _oracle_chain(name, by_orientation=True, skip_single=False, sift=False):
     o = _oracle(name)
     return oracle_chain.stereo_edge_pairs(o["l"], o["r"], o["F"], _calib(PAIRS[name][0]), stage1=o,
-                                          cluster_args=(by_orientation, skip_single))
+                                          cluster_args=(by_orientation, skip_single), sift=sift)
 
 
 @pytest.mark.parametrize("name", list(PAIRS))
@@ -99,3 +99,20 @@ def test_resident_chain_equals_oracle_chain(ctx, name):
     other = _oracle_chain(name, False, True)
     assert other["counts"]["n_clusters"] != ref["counts"]["n_clusters"] or not np.array_equal(
         other["right"]["x"], ref["right"]["x"])
+
+
+def test_resident_chain_with_sift_equals_oracle_chain_at_kitti_size(ctx):
+    """get_Stereo_Edge_Pairs stage for stage, the SIFT filter (500) and the Best-Nearly-Best test on the SIFT distances
+    (0.4) included: ~252 k descriptors per image, every candidate pair scored."""
+    o = _oracle("kitti")
+    ref = _oracle_chain("kitti", sift=True)
+    ctx.stereo_upload(o["l"], o["r"])
+    ctx.stereo_run(ctx.default_params(o["F"]))
+    counts, fin = ctx.stereo_finalize(_calib("kitti"), use_sift=True)
+    assert counts == ref["counts"]
+    assert_bit_equal(fin["left_index"], ref["left_index"], "left_index")
+    assert_edges_equal(fin["right"], ref["right"], "right centre")
+    assert_bit_equal(fin["score"], ref["score"], "score")
+    assert_bit_equal(fin["rows"], ref["rows"], "rows")
+    d = o["left"]["x"][fin["left_index"]] - fin["right"]["x"]
+    assert np.median(np.abs(d - 12.0)) < 0.1
