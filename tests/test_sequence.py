@@ -1,0 +1,109 @@
+"""include/ebvo/sequence.hpp (PNG decode, dataset iterators, batched feeder) through tests/cpp/sequence_demo.cpp.
+The decoder is checked on the CPU against PIL-written files; the feeder on the GPU against the Python driver."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from edge_based_visual_odometry_amd import _lib, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "cpp", "sequence_demo.cpp")
+EXE = os.path.join(ROOT, "tests", "cpp", "sequence_demo")
+
+
+def build_demo():
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), SRC, "-o", EXE,
+                           "-L", libdir, "-lebvo_hip", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-lz", "-lpthread"])
+
+
+def fnv(a):
+    return synth.img_fnv(a)
+
+
+def decode(path):
+    p = subprocess.run([EXE, "decode", str(path)], capture_output=True, text=True)
+    return p.returncode, p.stdout.strip()
+
+
+def test_png_decoder_against_pil(tmp_path):
+    from PIL import Image
+    build_demo()
+    img = synth.s2_image(61, 83, noise_seed=9)
+    # grayscale, every compression level (PIL picks the scanline filters adaptively), gray + alpha
+    for k, kw in enumerate([dict(compress_level=0), dict(compress_level=1), dict(compress_level=9), dict(optimize=True)]):
+        f = tmp_path / f"g{k}.png"
+        Image.fromarray(img, "L").save(f, **kw)
+        assert decode(f) == (0, f"83 61 {fnv(img)}")
+    la = np.stack([img, np.full_like(img, 200)], -1)
+    Image.fromarray(la, "LA").save(tmp_path / "la.png")
+    assert decode(tmp_path / "la.png") == (0, f"83 61 {fnv(img)}")
+    # RGB / RGBA: OpenCV's fixed-point BGR -> gray weights
+    rgb = np.stack([img, np.roll(img, 3, 0), 255 - img], -1).astype(np.uint8)
+    want = ((rgb[..., 0].astype(np.int64) * 4899 + rgb[..., 1].astype(np.int64) * 9617 + rgb[..., 2].astype(np.int64) * 1868
+             + 8192) >> 14).astype(np.uint8)
+    Image.fromarray(rgb, "RGB").save(tmp_path / "rgb.png")
+    assert decode(tmp_path / "rgb.png") == (0, f"83 61 {fnv(want)}")
+    rgba = np.concatenate([rgb, np.full(img.shape + (1,), 255, np.uint8)], -1)
+    Image.fromarray(rgba, "RGBA").save(tmp_path / "rgba.png")
+    assert decode(tmp_path / "rgba.png") == (0, f"83 61 {fnv(want)}")
+    # refused: 16-bit and paletted files; corrupt and missing files
+    Image.fromarray((img.astype(np.uint16) * 257)).save(tmp_path / "g16.png")
+    rc, msg = decode(tmp_path / "g16.png")
+    assert rc == 2 and "supported" in msg
+    Image.fromarray(img, "L").convert("P").save(tmp_path / "pal.png")
+    assert decode(tmp_path / "pal.png")[0] == 2
+    data = bytearray((tmp_path / "g1.png").read_bytes())
+    data[len(data) // 2] ^= 0x55
+    (tmp_path / "bad.png").write_bytes(bytes(data))
+    rc, msg = decode(tmp_path / "bad.png")
+    assert rc == 2 and ("checksum" in msg or "zlib" in msg)
+    assert decode(tmp_path / "nope.png")[0] == 2
+
+
+@pytest.mark.gpu
+def test_kitti_feeder_equals_python_driver(tmp_path):
+    from PIL import Image
+    from edge_based_visual_odometry_amd.api import Context
+    build_demo()
+    h, w, n = 120, 200, 7
+    os.makedirs(tmp_path / "image_0")
+    os.makedirs(tmp_path / "image_1")
+    pairs = [synth.stereo_pair("s2", h, w, noise_base=10 * k) for k in range(n)]
+    for k, (l, r) in enumerate(pairs):
+        Image.fromarray(l, "L").save(tmp_path / "image_0" / f"{k:06d}.png")
+        Image.fromarray(r, "L").save(tmp_path / "image_1" / f"{k:06d}.png")
+    out = subprocess.run([EXE, "kitti", str(tmp_path), "3"], capture_output=True, text=True, check=True).stdout.split("\n")
+    assert out[n].startswith(f"pairs {n} status 0")
+    fx, T = 718.856, 0.54
+    F = np.array([[0, 0, 0], [0, 0, -T / fx], [0, T / fx, 0]])
+    with Context(h, w, toed_mode="hybrid") as c:
+        for k, (l, r) in enumerate(pairs):
+            c.stereo_upload(l, r)
+            cnt = c.stereo_run(c.default_params(F))
+            assert out[k] == f"{k} {cnt.n_left} {cnt.n_right} {cnt.n_pairs} {cnt.n_matches}"
+
+
+@pytest.mark.gpu
+def test_euroc_feeder_reads_the_csv(tmp_path):
+    from PIL import Image
+    build_demo()
+    h, w = 96, 160
+    os.makedirs(tmp_path / "cam0")
+    os.makedirs(tmp_path / "cam1")
+    stamps = ["1403715273262142976", "1403715273312143104", "1403715273362142976"]
+    with open(tmp_path / "data.csv", "w") as f:
+        f.write("#timestamp [ns],filename\n")
+        for t in stamps + ["1403715273412143104"]:                      # the last pair has no images: skipped
+            f.write(f"{t},{t}.png\n")
+    for k, t in enumerate(stamps):
+        l, r = synth.stereo_pair("s2", h, w, noise_base=10 * k)
+        Image.fromarray(l, "L").save(tmp_path / "cam0" / f"{t}.png")
+        Image.fromarray(r, "L").save(tmp_path / "cam1" / f"{t}.png")
+    p = subprocess.run([EXE, "euroc", str(tmp_path / "data.csv"), str(tmp_path / "cam0") + "/", str(tmp_path / "cam1") + "/", "2"],
+                       capture_output=True, text=True, check=True)
+    lines = p.stdout.strip().split("\n")
+    assert lines[-1].startswith("pairs 3 status 0") and len(lines) == 4
+    assert "Skipping image pair: 1403715273412143104" in p.stderr
