@@ -446,6 +446,27 @@ class Context:
         return dict(left=left, right=right, row_ptr=row_ptr, col_idx=col, sims=sims, best=best, keep=keep,
                     left_patches=lp)
 
+    # -- temporal quads against the keyframe (src/Temporal_Matches.cpp:335-469) -----------------------------------
+    def temporal_set_keyframe(self, slot: int = 0):
+        self._check(self.lib.ebvo_temporal_set_keyframe(self._ctx, slot), "ebvo_temporal_set_keyframe")
+
+    def temporal_match(self, slot: int = 0, fetch: bool = True, **kw):
+        p = _lib.TemporalParams()
+        self.lib.ebvo_temporal_default_params(C.byref(p))
+        for k, v in kw.items():
+            setattr(p, k, v)
+        c = _lib.TemporalCounts()
+        self._check(self.lib.ebvo_temporal_match(self._ctx, slot, C.byref(p), C.byref(c)), "ebvo_temporal_match")
+        counts = dict(n_kf=c.n_kf, n_cf=c.n_cf, n_candidates=c.n_candidates, n_kept=c.n_kept)
+        if not fetch:
+            return counts, None
+        n = c.n_candidates
+        out = dict(row_ptr=np.zeros(c.n_kf + 1, dtype=np.int32), col_idx=np.zeros(n, dtype=np.int32), sim_left=np.zeros(n),
+                   sim_right=np.zeros(n), keep=np.zeros(n, dtype=np.uint8))
+        self._check(self.lib.ebvo_temporal_fetch(self._ctx, slot, ptr(out["row_ptr"]), ptr(out["col_idx"]), ptr(out["sim_left"]),
+                                                 ptr(out["sim_right"]), ptr(out["keep"])), "ebvo_temporal_fetch")
+        return counts, out
+
     def stereo_fetch_begin(self, slot: int = 0, what: int = _lib.FETCH_DEFAULT):
         """Enqueue the device-to-host copies of a finished pair's results into the slot's page-locked staging."""
         self._check(self.lib.ebvo_stereo_fetch_begin(self._ctx, slot, what), "ebvo_stereo_fetch_begin")

@@ -139,7 +139,7 @@ static void slot_destroy(Slot *s)
         (void)hipFree(ws.cand_lists);
         (void)hipFree(ws.cand_lcount);
     }
-    GrowBuf *bufs[] = {&s->lines,        &s->boxes_chunk,  &s->boxes_group,    &s->cand_cnt,       &s->cand_stage, &s->cand_tileflag, &s->row_ptr, &s->grad_x, &s->grad_y, &s->gn_xy, &s->gn_out, &s->gn_valid, &s->gn_iters, &s->gn_state, &s->gn_lists, &s->gn_pack, &s->sift_img, &s->sift_desc, &s->sift_f32, &s->sift_dist, &s->fin_i32, &s->fin_edges, &s->fin_f64, &s->fin_u8, &s->fin_out,
+    GrowBuf *bufs[] = {&s->lines,        &s->boxes_chunk,  &s->boxes_group,    &s->cand_cnt,       &s->cand_stage, &s->cand_tileflag, &s->row_ptr, &s->grad_x, &s->grad_y, &s->gn_xy, &s->gn_out, &s->gn_valid, &s->gn_iters, &s->gn_state, &s->gn_lists, &s->gn_pack, &s->sift_img, &s->sift_desc, &s->sift_f32, &s->sift_dist, &s->tq_i32, &s->tq_cols, &s->tq_f64, &s->tq_u8, &s->tq_cells, &s->fin_i32, &s->fin_edges, &s->fin_f64, &s->fin_u8, &s->fin_out,
                        &s->scan_tmp,     &s->col_idx,      &s->rc_edges,       &s->sims,           &s->best,
                        &s->keep,         &s->patches_raw,  &s->patches_norm,   &s->patches_flag,   &s->patches_norm_r,
                        &s->patches_flag_r, &s->pair_left,  &s->sincos,         &s->scratch_b,      &s->scratch_c,
@@ -279,6 +279,12 @@ extern "C" void ebvo_ctx_destroy(ebvo_ctx *ctx)
         (void)hipEventDestroy(pe.a);
         (void)hipEventDestroy(pe.b);
     }
+    (void)hipFree(ctx->kf_L);
+    (void)hipFree(ctx->kf_R);
+    (void)hipFree(ctx->kf_Ln);
+    (void)hipFree(ctx->kf_Rn);
+    (void)hipFree(ctx->kf_Lf);
+    (void)hipFree(ctx->kf_Rf);
     delete ctx;
 }
 
@@ -891,6 +897,7 @@ extern "C" int ebvo_stereo_upload_slot(ebvo_ctx *ctx, int slot, const uint8_t *i
     if (s.in_flight)
         return EBVO_ERR_STATE;
     s.have_pair = s.have_run = s.have_refined = s.have_final = false; // results of the previous pair are gone
+    s.tq_n = -1;
     if (s.fetch_pending) // a result copy of the previous pair is still reading the buffers
         EBVO_HIP(ctx, hipStreamSynchronize(s.stream));
     s.fetch_pending = false;
@@ -1392,6 +1399,7 @@ extern "C" int ebvo_stereo_finalize(ebvo_ctx *ctx, int slot, const ebvo_finalize
     EBVO_HIP(ctx, hipSetDevice(ctx->device));
     memset(counts, 0, sizeof *counts);
     s.have_final = s.have_refined = false; // the refinement buffers are reused
+    s.tq_n = -1;
 
     s.n_final = 0;
     const int nL = s.result.n_left, h = s.cur_h, w = s.cur_w;
@@ -1741,6 +1749,178 @@ extern "C" int ebvo_stereo_set_undistort(ebvo_ctx *ctx, const ebvo_undistort_par
     ctx->undist_on = true;
     for (Slot *s : ctx->slots) // pairs uploaded before the switch went to img: they must be uploaded again
         s->have_pair = s->have_run = s->have_refined = s->have_final = false;
+    return EBVO_OK;
+}
+
+
+// ---- temporal quads against the keyframe ---------------------------------------------------------------------------
+extern "C" void ebvo_temporal_default_params(ebvo_temporal_params *p)
+{
+    if (!p)
+        return;
+    memset(p, 0, sizeof *p);
+    p->cell_size = 15;
+    p->grid_radius = 30.0;
+    p->orient_thr_deg = 10.0;
+    p->ncc_thr = EBVO_NCC_THRESH_TEMPORAL;
+}
+
+// the final mates of a finalized slot: left edges, right centre edges (carved by ebvo_stereo_finalize)
+static void final_mates(Slot &s, const ebvo_edge **fl, const ebvo_edge **fr)
+{
+    const size_t nz = (size_t)s.result.n_pairs, nLz = (size_t)s.result.n_left + 1;
+    *fl = (const ebvo_edge *)s.fin_edges.p + 3 * nz;
+    *fr = *fl + nLz;
+}
+
+extern "C" int ebvo_temporal_set_keyframe(ebvo_ctx *ctx, int slot)
+{
+    Slot *sp;
+    if (get_slot(ctx, slot, &sp))
+        return EBVO_ERR_ARG;
+    Slot &s = *sp;
+    if (!s.have_final || s.in_flight)
+        return EBVO_ERR_STATE;
+    EBVO_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t n = (size_t)s.n_final;
+    if (n > ctx->kf_cap)
+    {
+        EBVO_HIP(ctx, hipDeviceSynchronize());
+        for (void *p : {(void *)ctx->kf_L, (void *)ctx->kf_R, (void *)ctx->kf_Ln, (void *)ctx->kf_Rn, (void *)ctx->kf_Lf, (void *)ctx->kf_Rf})
+            (void)hipFree(p);
+        ctx->kf_L = ctx->kf_R = nullptr;
+        ctx->kf_Ln = ctx->kf_Rn = nullptr;
+        ctx->kf_Lf = ctx->kf_Rf = nullptr;
+        ctx->kf_cap = 0;
+        const size_t cap = n + n / 4 + 64;
+        if (hipMalloc(&ctx->kf_L, sizeof(ebvo_edge) * cap) != hipSuccess || hipMalloc(&ctx->kf_R, sizeof(ebvo_edge) * cap) != hipSuccess ||
+            hipMalloc(&ctx->kf_Ln, sizeof(float) * 98 * cap) != hipSuccess || hipMalloc(&ctx->kf_Rn, sizeof(float) * 98 * cap) != hipSuccess ||
+            hipMalloc(&ctx->kf_Lf, 2 * cap) != hipSuccess || hipMalloc(&ctx->kf_Rf, 2 * cap) != hipSuccess)
+        {
+            (void)hipGetLastError();
+            ctx->last_error = "hipMalloc failed (keyframe store)";
+            return EBVO_ERR_NOMEM;
+        }
+        ctx->kf_cap = cap;
+    }
+    ctx->kf_n = (int)n;
+    if (n == 0)
+        return EBVO_OK;
+    const ebvo_edge *fl, *fr;
+    final_mates(s, &fl, &fr);
+    int rc;
+    EBVO_HIP(ctx, hipMemcpyAsync(ctx->kf_L, fl, sizeof(ebvo_edge) * n, hipMemcpyDeviceToDevice, s.stream));
+    EBVO_HIP(ctx, hipMemcpyAsync(ctx->kf_R, fr, sizeof(ebvo_edge) * n, hipMemcpyDeviceToDevice, s.stream));
+    // left_edge_patches: raw left image (src/Stereo_Matches.cpp:578, :1621); right_edge_patches: undistorted right (:1622)
+    if ((rc = match_patches_enqueue(ctx, s, ncc_img(s, 0), s.cur_h, s.cur_w, s.cur_w, ctx->kf_L, (int)n, nullptr, 0, nullptr, ctx->kf_Ln,
+                                    ctx->kf_Lf)) ||
+        (rc = match_patches_enqueue(ctx, s, s.im[1].img, s.cur_h, s.cur_w, s.cur_w, ctx->kf_R, (int)n, nullptr, 0, nullptr, ctx->kf_Rn,
+                                    ctx->kf_Rf)))
+        return rc;
+    EBVO_HIP(ctx, hipStreamSynchronize(s.stream));
+    return EBVO_OK;
+}
+
+extern "C" int ebvo_temporal_match(ebvo_ctx *ctx, int slot, const ebvo_temporal_params *p, ebvo_temporal_counts *counts)
+{
+    Slot *sp;
+    if (!p || !counts || p->cell_size < 1 || !(p->grid_radius >= 0) || !(p->orient_thr_deg >= 0) || get_slot(ctx, slot, &sp))
+        return EBVO_ERR_ARG;
+    Slot &s = *sp;
+    if (!s.have_final || s.in_flight || ctx->kf_n < 0)
+        return EBVO_ERR_STATE;
+    EBVO_HIP(ctx, hipSetDevice(ctx->device));
+    memset(counts, 0, sizeof *counts);
+    const int n_kf = ctx->kf_n, n_cf = s.n_final, h = s.cur_h, w = s.cur_w;
+    counts->n_kf = n_kf;
+    counts->n_cf = n_cf;
+    s.tq_n = 0;
+    s.tq_n_kf = n_kf;
+    int rc;
+    const size_t nk1 = (size_t)n_kf + 1;
+    if ((rc = ebvo_grow(ctx, s, s.tq_i32, sizeof(int32_t) * (2 * nk1 + 2) + 16)))
+        return rc;
+    int32_t *cnt = (int32_t *)s.tq_i32.p, *rp = cnt + nk1;
+    unsigned long long *d_kept = (unsigned long long *)(((uintptr_t)(rp + nk1) + 7) & ~(uintptr_t)7); // 8-byte aligned counter
+    EBVO_HIP(ctx, hipMemsetAsync(cnt, 0, sizeof(int32_t) * 2 * nk1, s.stream));
+    if (n_kf == 0 || n_cf == 0)
+    {
+        EBVO_HIP(ctx, hipStreamSynchronize(s.stream));
+        return EBVO_OK;
+    }
+    const ebvo_edge *cfL, *cfR;
+    final_mates(s, &cfL, &cfR);
+    const int cell = p->cell_size, gw = (w + cell - 1) / cell, gh = (h + cell - 1) / cell;
+    const int sr = (int)ceil(p->grid_radius / cell);
+    if ((rc = ebvo_grow(ctx, s, s.tq_cells, match_temporal_cells_bytes(n_cf) + match_temporal_boxes_bytes(n_cf) + 64)))
+        return rc;
+    void *cells = s.tq_cells.p;
+    void *boxes = (char *)cells + ((match_temporal_cells_bytes(n_cf) + 63) & ~(size_t)63);
+    if ((rc = match_temporal_cells_enqueue(ctx, s, cfL, cfR, n_cf, cell, gw, gh, cells, boxes)) ||
+        (rc = match_temporal_candidates_enqueue(ctx, s, ctx->kf_L, ctx->kf_R, n_kf, cfL, cfR, cells, boxes, n_cf, cell, sr, gw, gh,
+                                                p->orient_thr_deg, cnt, nullptr, nullptr, 0)) ||
+        (rc = ebvo_device_scan(ctx, s, cnt, rp, n_kf, nullptr, 1, n_kf + 1)))
+        return rc;
+    int32_t nq = 0;
+    if ((rc = read_i32(ctx, s, rp + n_kf, &nq)))
+        return rc;
+    counts->n_candidates = nq;
+    s.tq_n = nq;
+    if (nq == 0)
+        return EBVO_OK;
+    const size_t nqz = (size_t)nq, ncz = (size_t)n_cf;
+    if ((rc = ebvo_grow(ctx, s, s.tq_cols, sizeof(int32_t) * 2 * nqz)) || (rc = ebvo_grow(ctx, s, s.tq_f64, sizeof(double) * 2 * nqz)) ||
+        (rc = ebvo_grow(ctx, s, s.tq_u8, 2 * ncz + nqz + 64)) || (rc = ebvo_grow(ctx, s, s.patches_raw, sizeof(float) * 98 * ncz)) ||
+        (rc = ebvo_grow(ctx, s, s.patches_norm, sizeof(float) * 98 * ncz)) || (rc = ebvo_grow(ctx, s, s.patches_flag, 2 * ncz)))
+        return rc;
+    int32_t *col = (int32_t *)s.tq_cols.p, *quad_kf = col + nqz;
+    double *sim_l = (double *)s.tq_f64.p, *sim_r = sim_l + nqz;
+    uint8_t *flagR = (uint8_t *)s.tq_u8.p, *keep = flagR + ((2 * ncz + 63) & ~(size_t)63);
+    float *cfLn = (float *)s.patches_norm.p, *cfRn = (float *)s.patches_raw.p;
+    uint8_t *cfLf = (uint8_t *)s.patches_flag.p;
+    if ((rc = match_temporal_candidates_enqueue(ctx, s, ctx->kf_L, ctx->kf_R, n_kf, cfL, cfR, cells, boxes, n_cf, cell, sr, gw, gh,
+                                                p->orient_thr_deg, nullptr, rp, col, nq)) ||
+        (rc = match_expand_rows_enqueue(ctx, s, rp, n_kf, nq, quad_kf)) ||
+        (rc = match_patches_enqueue(ctx, s, ncc_img(s, 0), h, w, w, cfL, n_cf, nullptr, 0, nullptr, cfLn, cfLf)) ||
+        (rc = match_patches_enqueue(ctx, s, s.im[1].img, h, w, w, cfR, n_cf, nullptr, 0, nullptr, cfRn, flagR)) ||
+        (rc = match_ncc_quads_indexed_enqueue(ctx, s, ctx->kf_Ln, ctx->kf_Lf, ctx->kf_Rn, ctx->kf_Rf, cfLn, cfLf, cfRn, flagR, quad_kf,
+                                              col, nq, p->ncc_thr, sim_l, sim_r, keep)) ||
+        (rc = match_count_flags_enqueue(ctx, s, keep, nq, d_kept)))
+        return rc;
+    unsigned long long kept = 0;
+    EBVO_HIP(ctx, hipMemcpyAsync(s.h_result, d_kept, sizeof kept, hipMemcpyDeviceToHost, s.stream));
+    EBVO_HIP(ctx, hipStreamSynchronize(s.stream));
+    memcpy(&kept, s.h_result, sizeof kept);
+    counts->n_kept = (int64_t)kept;
+    return EBVO_OK;
+}
+
+extern "C" int ebvo_temporal_fetch(ebvo_ctx *ctx, int slot, int32_t *row_ptr, int32_t *col_idx, double *sim_left, double *sim_right,
+                                   uint8_t *keep)
+{
+    Slot *sp;
+    if (get_slot(ctx, slot, &sp))
+        return EBVO_ERR_ARG;
+    Slot &s = *sp;
+    if (s.tq_n < 0 || s.in_flight)
+        return EBVO_ERR_STATE;
+    EBVO_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t nk1 = (size_t)s.tq_n_kf + 1, nq = (size_t)s.tq_n, ncz = (size_t)s.n_final;
+    hipStream_t st = s.stream;
+    if (row_ptr)
+        EBVO_HIP(ctx, hipMemcpyAsync(row_ptr, (const int32_t *)s.tq_i32.p + nk1, sizeof(int32_t) * nk1, hipMemcpyDeviceToHost, st));
+    if (nq)
+    {
+        if (col_idx)
+            EBVO_HIP(ctx, hipMemcpyAsync(col_idx, s.tq_cols.p, sizeof(int32_t) * nq, hipMemcpyDeviceToHost, st));
+        if (sim_left)
+            EBVO_HIP(ctx, hipMemcpyAsync(sim_left, s.tq_f64.p, sizeof(double) * nq, hipMemcpyDeviceToHost, st));
+        if (sim_right)
+            EBVO_HIP(ctx, hipMemcpyAsync(sim_right, (const double *)s.tq_f64.p + nq, sizeof(double) * nq, hipMemcpyDeviceToHost, st));
+        if (keep)
+            EBVO_HIP(ctx, hipMemcpyAsync(keep, (const uint8_t *)s.tq_u8.p + ((2 * ncz + 63) & ~(size_t)63), nq, hipMemcpyDeviceToHost, st));
+    }
+    EBVO_HIP(ctx, hipStreamSynchronize(st));
     return EBVO_OK;
 }
 

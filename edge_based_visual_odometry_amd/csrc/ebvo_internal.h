@@ -114,6 +114,9 @@ struct Slot
 
     // matching workspace
     GrowBuf grad_x, grad_y, gn_xy, gn_out, gn_valid, gn_iters, gn_state, gn_lists, gn_pack; // photometric refinement (refine_kernels.hip)
+    GrowBuf tq_i32, tq_cols, tq_f64, tq_u8, tq_cells; // temporal quads of the slot's pair against the keyframe
+    int tq_n_kf = 0;
+    int64_t tq_n = -1;                       // -1: none
     GrowBuf sift_img, sift_desc, sift_f32, sift_dist; // SIFT: blurred levels, descriptor banks, per-pair distances (sift_kernels.hip)
     GrowBuf fin_i32, fin_edges, fin_f64, fin_u8, fin_out; // ebvo_stereo_finalize: CSRs, candidate lists, scores, final rows
     int n_final = 0;
@@ -153,6 +156,12 @@ struct ebvo_ctx
     int toed_mode = EBVO_TOED_STRICT;
     std::string last_error;
     std::vector<Slot *> slots; // slot 0 always exists; it also serves the host-buffer entry points
+    // keyframe of the temporal stage (ebvo_temporal_set_keyframe): final stereo mates and their stored patches, device-resident
+    int kf_n = -1;             // -1: no keyframe
+    ebvo_edge *kf_L = nullptr, *kf_R = nullptr;
+    float *kf_Ln = nullptr, *kf_Rn = nullptr;   // [n][2][49] normalised patches (left image raw, right image undistorted)
+    uint8_t *kf_Lf = nullptr, *kf_Rf = nullptr; // [n][2] sentinel flags
+    size_t kf_cap = 0;
     bool undist_on = false;    // ebvo_stereo_set_undistort
     ebvo_undistort_params undist{};
     int wait_attempts = 0;     // test hook (ebvo_debug_set): attempts of ebvo_stereo_wait's regrow loop, 0 = default (4)
@@ -226,6 +235,20 @@ int match_ncc_pairs_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_imgR, int h
 int match_ncc_resident_enqueue(ebvo_ctx *ctx, Slot &s, int h, int w, int cap_edges, double thr);
 size_t match_right_bank_bytes(int cap_edges);
 int match_pair_result_enqueue(ebvo_ctx *ctx, Slot &s);
+// temporal quads (Temporal_Matches): cells + chunk boxes of the current-frame mates, candidate count / fill, indexed NCC
+int match_temporal_cells_enqueue(ebvo_ctx *ctx, Slot &s, const ebvo_edge *d_cfL, const ebvo_edge *d_cfR, int n_cf, int cell, int gw,
+                                 int gh, void *d_cells, void *d_boxes);
+size_t match_temporal_cells_bytes(int n_cf);
+size_t match_temporal_boxes_bytes(int n_cf);
+int match_temporal_candidates_enqueue(ebvo_ctx *ctx, Slot &s, const ebvo_edge *d_kfL, const ebvo_edge *d_kfR, int n_kf,
+                                      const ebvo_edge *d_cfL, const ebvo_edge *d_cfR, const void *d_cells, const void *d_boxes,
+                                      int n_cf, int cell, int sr, int gw, int gh, double orient_thr, int32_t *d_cnt,
+                                      const int32_t *d_row_ptr, int32_t *d_col_idx, int64_t cap);
+int match_count_flags_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_flags, int64_t n, unsigned long long *d_out);
+int match_ncc_quads_indexed_enqueue(ebvo_ctx *ctx, Slot &s, const float *kfLn, const uint8_t *kfLf, const float *kfRn,
+                                    const uint8_t *kfRf, const float *cfLn, const uint8_t *cfLf, const float *cfRn,
+                                    const uint8_t *cfRf, const int32_t *d_quad_kf, const int32_t *d_quad_cf, int64_t n_quads,
+                                    double thr, double *d_sim_left, double *d_sim_right, uint8_t *d_keep);
 // exclusive scan of n (+ n_add) int32 on the slot's stream; n_dev != nullptr: the count lives on the device, cap_n bounds it
 // zero n (<= EBVO_CLEAR_MAX) int32 arrays with one launch
 int ebvo_clear_enqueue(ebvo_ctx *ctx, Slot &s, int32_t *const ptrs[], const int counts[], int n);

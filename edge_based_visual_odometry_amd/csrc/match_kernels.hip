@@ -1304,6 +1304,215 @@ __global__ __launch_bounds__(256, WPE) void ncc_tile_kernel(const uint8_t *__res
         match_part[blockIdx.x] = s_mc;
 }
 
+
+// ---- temporal quads: candidate search and NCC on stored patches (Temporal_Matches, configs[2]) -----------------------
+// apply_spatial_grid_filtering_quads + apply_orientation_filtering_quads (src/Temporal_Matches.cpp:335-414) decide, per
+// keyframe stereo mate, which current-frame mates are candidates: the mate's LEFT edge lies in a grid cell (15 px,
+// include/definitions.h:45) within +-ceil(30 / 15) cells of the keyframe mate's left edge, its RIGHT edge likewise
+// relative to the keyframe mate's right edge (SpatialGrid::getCandidatesWithinRadius, include/Dataset.h:92-113: whole
+// cells, no distance test), and both orientation differences pass the 10-degree test.  An integer predicate on four
+// cell coordinates + two angle tests: mates are summarised in chunks of 64 by the bounding box of their cells (the
+// final mates are in raster order of their left edge, so nearly all chunks are rejected by one box test); a thread
+// owns one keyframe mate.  Candidates come out in ascending current-frame mate index.
+struct MateCells
+{
+    short lx, ly, rx, ry; // -30000: the edge is outside the grid and is never returned by a query
+};
+struct CellBox
+{
+    short lo[4], hi[4];
+};
+constexpr int TCHUNK = 64;
+
+__device__ inline short cell_of(double v, int cell, int n_cells)
+{
+    const int c = (int)v / cell; // static_cast<int>(location.x) / cell_size
+    return (c >= 0 && c < n_cells) ? (short)c : (short)-30000;
+}
+
+__global__ void mate_cells_kernel(const ebvo_edge *__restrict__ L, const ebvo_edge *__restrict__ R, int n, int cell, int gw,
+                                  int gh, MateCells *__restrict__ out, CellBox *__restrict__ boxes)
+{
+    // one wave per chunk of 64 mates: cells + the chunk's box
+    const int lane = threadIdx.x & 63;
+    const int nchunks = (n + TCHUNK - 1) / TCHUNK;
+    for (int ch = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); ch < nchunks; ch += gridDim.x * (blockDim.x >> 6))
+    {
+        const int j = ch * TCHUNK + lane;
+        int v[4] = {30000, 30000, 30000, 30000}, u[4] = {-30000, -30000, -30000, -30000};
+        if (j < n)
+        {
+            MateCells m;
+            m.lx = cell_of(L[j].x, cell, gw);
+            m.ly = cell_of(L[j].y, cell, gh);
+            m.rx = cell_of(R[j].x, cell, gw);
+            m.ry = cell_of(R[j].y, cell, gh);
+            // a mate is in the left grid only if BOTH left cells are inside (src/Temporal_Matches.cpp:31-34), same on the right
+            if (m.lx < 0 || m.ly < 0)
+                m.lx = m.ly = -30000;
+            if (m.rx < 0 || m.ry < 0)
+                m.rx = m.ry = -30000;
+            out[j] = m;
+            v[0] = u[0] = m.lx;
+            v[1] = u[1] = m.ly;
+            v[2] = u[2] = m.rx;
+            v[3] = u[3] = m.ry;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            for (int d = 32; d > 0; d >>= 1)
+            {
+                v[q] = min(v[q], __shfl_xor(v[q], d));
+                u[q] = max(u[q], __shfl_xor(u[q], d));
+            }
+        if (lane == 0)
+        {
+            CellBox b;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+            {
+                b.lo[q] = (short)v[q];
+                b.hi[q] = (short)u[q];
+            }
+            boxes[ch] = b;
+        }
+    }
+}
+
+__device__ inline bool orient_close(double a, double b, double thr)
+{
+    double od = fabs((a - b) * 0x1.ca5dc1a63c1f8p+5 /* rad_to_deg: theta * (180.0 / M_PI) */);
+    if (od > 180.0)
+        od = 360.0 - od;
+    return od < thr || fabs(od - 180.0) < thr;
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void temporal_candidates_kernel(const ebvo_edge *__restrict__ kfL,
+                                                                  const ebvo_edge *__restrict__ kfR, int n_kf,
+                                                                  const ebvo_edge *__restrict__ cfL,
+                                                                  const ebvo_edge *__restrict__ cfR,
+                                                                  const MateCells *__restrict__ cells,
+                                                                  const CellBox *__restrict__ boxes, int n_cf, int cell, int sr,
+                                                                  int gw, int gh, double orient_thr,
+                                                                  int32_t *__restrict__ cnt, const int32_t *__restrict__ row_ptr,
+                                                                  int32_t *__restrict__ col_idx, int64_t cap)
+{
+    const int nchunks = (n_cf + TCHUNK - 1) / TCHUNK;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_kf; i += gridDim.x * blockDim.x)
+    {
+        const ebvo_edge kl = kfL[i], kr = kfR[i];
+        // the query cells are not clipped (include/Dataset.h:95-96); neighbour cells outside the grid hold nothing
+        const int q[4] = {(int)kl.x / cell, (int)kl.y / cell, (int)kr.x / cell, (int)kr.y / cell};
+        int c = 0;
+        int64_t o = FILL ? row_ptr[i] : 0;
+        for (int ch = 0; ch < nchunks; ++ch)
+        {
+            const CellBox b = boxes[ch];
+            bool hit = true;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                hit = hit && q[t] - sr <= b.hi[t] && q[t] + sr >= b.lo[t];
+            if (!hit)
+                continue;
+            const int jend = min(n_cf, (ch + 1) * TCHUNK);
+            for (int j = ch * TCHUNK; j < jend; ++j)
+            {
+                const MateCells m = cells[j];
+                if (abs(m.lx - q[0]) <= sr && abs(m.ly - q[1]) <= sr && abs(m.rx - q[2]) <= sr && abs(m.ry - q[3]) <= sr &&
+                    orient_close(kl.theta, cfL[j].theta, orient_thr) && orient_close(kr.theta, cfR[j].theta, orient_thr))
+                {
+                    if (FILL)
+                    {
+                        if (o < cap)
+                            col_idx[o] = j;
+                        ++o;
+                    }
+                    ++c;
+                }
+            }
+        }
+        if (!FILL)
+            cnt[i] = c;
+    }
+    (void)gw;
+    (void)gh;
+}
+
+// apply_NCC_filtering_quads (src/Temporal_Matches.cpp:416-469) on mates' stored patches, by index: banks of normalised
+// patches [mate][2][49] + sentinel flags [mate][2] (patches_kernel).  Sixteen lanes per quad: lanes 0-7 the left-image
+// patches, lanes 8-15 the right-image ones; lane r holds row r of the four patches involved.
+__global__ __launch_bounds__(256) void ncc_quads_indexed_kernel(const float *__restrict__ kfLn, const uint8_t *__restrict__ kfLf,
+                                                                const float *__restrict__ kfRn, const uint8_t *__restrict__ kfRf,
+                                                                const float *__restrict__ cfLn, const uint8_t *__restrict__ cfLf,
+                                                                const float *__restrict__ cfRn, const uint8_t *__restrict__ cfRf,
+                                                                const int32_t *__restrict__ quad_kf,
+                                                                const int32_t *__restrict__ quad_cf, int64_t n_quads, double thr,
+                                                                double *__restrict__ sim_left, double *__restrict__ sim_right,
+                                                                uint8_t *__restrict__ keep)
+{
+    const int64_t groups = ((int64_t)gridDim.x * blockDim.x) >> 4;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int g = (int)(t & 15), img = g >> 3, row = g & 7;
+    const int64_t iters = (n_quads + groups - 1) / groups;
+    for (int64_t it = 0; it < iters; ++it)
+    {
+        const int64_t k = it * groups + (t >> 4);
+        const bool valid = k < n_quads;
+        const bool active = valid && row < 7;
+        float a1[7], a2[7], b1[7], b2[7];
+#pragma unroll
+        for (int c = 0; c < 7; ++c)
+            a1[c] = a2[c] = b1[c] = b2[c] = 0.0f;
+        size_t ik = 0, ic = 0;
+        if (valid)
+        {
+            ik = (size_t)quad_kf[k];
+            ic = (size_t)quad_cf[k];
+        }
+        const float *kn = img ? kfRn : kfLn, *cn = img ? cfRn : cfLn;
+        if (active)
+        {
+#pragma unroll
+            for (int c = 0; c < 7; ++c)
+            {
+                a1[c] = kn[ik * 98 + row * 7 + c];      // keyframe .first
+                a2[c] = kn[ik * 98 + 49 + row * 7 + c]; // keyframe .second
+                b1[c] = cn[ic * 98 + row * 7 + c];
+                b2[c] = cn[ic * 98 + 49 + row * 7 + c];
+            }
+        }
+        const double d11 = dot_rows(active, a1, b1), d12 = dot_rows(active, a1, b2), d21 = dot_rows(active, a2, b1),
+                     d22 = dot_rows(active, a2, b2);
+        double sim = 0.0;
+        if (valid && row == 0)
+        {
+            const uint8_t *kf = img ? kfRf : kfLf, *cf = img ? cfRf : cfLf;
+            const bool ka = kf[ik * 2] != 0, kb = kf[ik * 2 + 1] != 0, ca = cf[ic * 2] != 0, cb = cf[ic * 2 + 1] != 0;
+            // :441-450 order: (first, first), (first, second), (second, first), (second, second); -1 for a flat patch
+            sim = max4((ka || ca) ? -1.0 : d11, (ka || cb) ? -1.0 : d12, (kb || ca) ? -1.0 : d21, (kb || cb) ? -1.0 : d22);
+        }
+        const double sim_r = __shfl_xor(sim, 8);
+        if (valid && g == 0)
+        {
+            sim_left[k] = sim;
+            sim_right[k] = sim_r;
+            keep[k] = (sim > thr && sim_r > thr) ? 1 : 0; // :452
+        }
+    }
+}
+
+__global__ void count_flags_kernel(const uint8_t *__restrict__ f, int64_t n, unsigned long long *__restrict__ out)
+{
+    unsigned long long c = 0;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x)
+        c += f[k] ? 1 : 0;
+    for (int d = 32; d > 0; d >>= 1)
+        c += __shfl_down(c, d);
+    if ((threadIdx.x & 63) == 0 && c)
+        atomicAdd(out, c); // integer sum: order-independent
+}
+
 // Last kernel of a device-resident pair: gathers every count the host wants into one record (PairResult,
 // ebvo_internal.h).
 __global__ void pair_result_kernel(const int32_t *__restrict__ cntL, const int32_t *__restrict__ cntR,
@@ -1699,6 +1908,67 @@ int match_ncc_resident_enqueue(ebvo_ctx *ctx, Slot &s, int h, int w, int cap_edg
 }
 
 size_t match_right_bank_bytes(int cap_edges) { return sizeof(float) * BANK_EDGE * (size_t)cap_edges; }
+
+
+// temporal candidate search: count (FILL = false: cnt[n_kf]) or fill (row_ptr given); cells / boxes of the current-frame mates
+int match_temporal_cells_enqueue(ebvo_ctx *ctx, Slot &s, const ebvo_edge *d_cfL, const ebvo_edge *d_cfR, int n_cf, int cell, int gw,
+                                 int gh, void *d_cells, void *d_boxes)
+{
+    if (n_cf <= 0)
+        return EBVO_OK;
+    ProfScope ps(ctx, s, K_CAND_COUNT);
+    hipLaunchKernelGGL(mate_cells_kernel, dim3(blocks_for((n_cf + TCHUNK - 1) / TCHUNK, 4, 1024)), dim3(256), 0, s.stream, d_cfL,
+                       d_cfR, n_cf, cell, gw, gh, (MateCells *)d_cells, (CellBox *)d_boxes);
+    EBVO_HIP(ctx, hipGetLastError());
+    return EBVO_OK;
+}
+
+size_t match_temporal_cells_bytes(int n_cf) { return sizeof(MateCells) * (size_t)n_cf; }
+size_t match_temporal_boxes_bytes(int n_cf) { return sizeof(CellBox) * ((size_t)(n_cf + TCHUNK - 1) / TCHUNK + 1); }
+
+int match_temporal_candidates_enqueue(ebvo_ctx *ctx, Slot &s, const ebvo_edge *d_kfL, const ebvo_edge *d_kfR, int n_kf,
+                                      const ebvo_edge *d_cfL, const ebvo_edge *d_cfR, const void *d_cells, const void *d_boxes,
+                                      int n_cf, int cell, int sr, int gw, int gh, double orient_thr, int32_t *d_cnt,
+                                      const int32_t *d_row_ptr, int32_t *d_col_idx, int64_t cap)
+{
+    if (n_kf <= 0)
+        return EBVO_OK;
+    ProfScope ps(ctx, s, d_row_ptr ? K_CAND_FILL : K_CAND_COUNT);
+    const unsigned nb = blocks_for(n_kf, 256, 4096);
+    if (d_row_ptr)
+        hipLaunchKernelGGL(temporal_candidates_kernel<true>, dim3(nb), dim3(256), 0, s.stream, d_kfL, d_kfR, n_kf, d_cfL, d_cfR,
+                           (const MateCells *)d_cells, (const CellBox *)d_boxes, n_cf, cell, sr, gw, gh, orient_thr, d_cnt,
+                           d_row_ptr, d_col_idx, cap);
+    else
+        hipLaunchKernelGGL(temporal_candidates_kernel<false>, dim3(nb), dim3(256), 0, s.stream, d_kfL, d_kfR, n_kf, d_cfL, d_cfR,
+                           (const MateCells *)d_cells, (const CellBox *)d_boxes, n_cf, cell, sr, gw, gh, orient_thr, d_cnt,
+                           d_row_ptr, d_col_idx, cap);
+    EBVO_HIP(ctx, hipGetLastError());
+    return EBVO_OK;
+}
+
+int match_count_flags_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_flags, int64_t n, unsigned long long *d_out)
+{
+    EBVO_HIP(ctx, hipMemsetAsync(d_out, 0, sizeof(unsigned long long), s.stream));
+    if (n > 0)
+        hipLaunchKernelGGL(count_flags_kernel, dim3(blocks_for(n, 256, 1024)), dim3(256), 0, s.stream, d_flags, n, d_out);
+    EBVO_HIP(ctx, hipGetLastError());
+    return EBVO_OK;
+}
+
+int match_ncc_quads_indexed_enqueue(ebvo_ctx *ctx, Slot &s, const float *kfLn, const uint8_t *kfLf, const float *kfRn,
+                                    const uint8_t *kfRf, const float *cfLn, const uint8_t *cfLf, const float *cfRn,
+                                    const uint8_t *cfRf, const int32_t *d_quad_kf, const int32_t *d_quad_cf, int64_t n_quads,
+                                    double thr, double *d_sim_left, double *d_sim_right, uint8_t *d_keep)
+{
+    if (n_quads <= 0)
+        return EBVO_OK;
+    ProfScope ps(ctx, s, K_NCC_STORED);
+    hipLaunchKernelGGL(ncc_quads_indexed_kernel, dim3(blocks_for(n_quads * 16, 256, 8192)), dim3(256), 0, s.stream, kfLn, kfLf, kfRn,
+                       kfRf, cfLn, cfLf, cfRn, cfRf, d_quad_kf, d_quad_cf, n_quads, thr, d_sim_left, d_sim_right, d_keep);
+    EBVO_HIP(ctx, hipGetLastError());
+    return EBVO_OK;
+}
 
 int match_pair_result_enqueue(ebvo_ctx *ctx, Slot &s)
 {

@@ -389,6 +389,39 @@ int ebvo_ncc_patches(ebvo_ctx *ctx, const float *A, const float *B, int n, doubl
 int ebvo_ncc_quads(ebvo_ctx *ctx, const float *kfL, const float *kfR, const float *cfL, const float *cfR,
                    int n, double thr, double *sim_left, double *sim_right, uint8_t *keep);
 
+/* ---- temporal quads on the resident pairs (Temporal_Matches; BASELINE configs[2]) -------------------------------- */
+/* The part of Temporal_Matches::get_Temporal_Edge_Pairs_from_Quads (src/Temporal_Matches.cpp:168-218) that does not
+ * need ground-truth poses: for every stereo mate of the keyframe the candidate mates of the current frame
+ * (apply_spatial_grid_filtering_quads :335-383: left edge within +-ceil(radius / cell) grid cells of the keyframe
+ * mate's left edge AND right edge likewise, whole cells as SpatialGrid::getCandidatesWithinRadius returns them;
+ * apply_orientation_filtering_quads :385-414: both orientation differences within the threshold) and
+ * apply_NCC_filtering_quads (:416-469) on the mates' stored patches: left_edge_patches from the raw left image, right
+ * patches from the undistorted right image at the final right edge (src/Stereo_Matches.cpp:1621-1622).
+ * Mates = the final pairs of ebvo_stereo_finalize on a slot.  Candidates are listed in ascending current-frame mate
+ * index (the reference lists them cell by cell; the temporal results are sets). */
+typedef struct ebvo_temporal_params
+{
+    int cell_size;         /* GRID_SIZE 15, include/definitions.h:45 */
+    int reserved;
+    double grid_radius;    /* 30, src/Temporal_Matches.cpp:184 */
+    double orient_thr_deg; /* 10, :188 */
+    double ncc_thr;        /* EBVO_NCC_THRESH_TEMPORAL 0.8, :192 */
+} ebvo_temporal_params;
+typedef struct ebvo_temporal_counts
+{
+    int32_t n_kf, n_cf;   /* keyframe / current-frame mates */
+    int64_t n_candidates; /* quads after the grid and orientation filters */
+    int64_t n_kept;       /* quads with both NCC maxima above the threshold */
+} ebvo_temporal_counts;
+void ebvo_temporal_default_params(ebvo_temporal_params *p);
+/* the final mates of `slot` (after ebvo_stereo_finalize) become the keyframe (src/Pipeline.cpp:133-138: frame 0) */
+int ebvo_temporal_set_keyframe(ebvo_ctx *ctx, int slot);
+/* quads of the keyframe against the final mates of `slot` */
+int ebvo_temporal_match(ebvo_ctx *ctx, int slot, const ebvo_temporal_params *p, ebvo_temporal_counts *counts);
+/* row_ptr: n_kf + 1; col_idx / sim_left / sim_right / keep: n_candidates.  Any pointer may be NULL. */
+int ebvo_temporal_fetch(ebvo_ctx *ctx, int slot, int32_t *row_ptr, int32_t *col_idx, double *sim_left, double *sim_right,
+                        uint8_t *keep);
+
 /* ---------------------------------------------------------------------------------------- */
 /* Device-resident stereo pipeline: TOED(left) + TOED(right) + candidates + NCC of one pair,  */
 /* images and every intermediate in HBM.  This is what bench.py times.                        */

@@ -1736,3 +1736,49 @@ void orc_sift_min_distances(const float *left_desc, const float *cand_desc, cons
             dist[k] = best;
         }
 }
+
+/* ------------------------------------------------------------------------------------ */
+/* Temporal quads: candidate current-frame mates of every keyframe mate                    */
+/* (apply_spatial_grid_filtering_quads + apply_orientation_filtering_quads,               */
+/* src/Temporal_Matches.cpp:335-414; SpatialGrid, include/Dataset.h:22-113; grid fill       */
+/* src/Temporal_Matches.cpp:18-55).  Brute force over all current-frame mates, candidates    */
+/* in ascending mate index.  PARITY UNPINNED (no fixture in the reference).                 */
+/* ------------------------------------------------------------------------------------ */
+static int orient_close_deg(double a, double b, double thr)
+{
+    double od = fabs((a - b) * (180.0 / M_PI)); /* rad_to_deg, include/utility.h:288-291 */
+    if (od > 180.0)
+        od = 360.0 - od;
+    return od < thr || fabs(od - 180.0) < thr;
+}
+
+int orc_temporal_candidates(const orc_edge *kfL, const orc_edge *kfR, int n_kf, const orc_edge *cfL, const orc_edge *cfR, int n_cf,
+                            int img_w, int img_h, int cell, double radius, double orient_thr_deg, int32_t *row_ptr,
+                            int32_t *col_idx, int64_t cap, int64_t *n_out)
+{
+    const int gw = (img_w + cell - 1) / cell, gh = (img_h + cell - 1) / cell; /* SpatialGrid(img_width, img_height, cell) */
+    const int sr = (int)ceil(radius / cell);
+    int64_t n = 0;
+    for (int i = 0; i < n_kf; i++)
+    {
+        row_ptr[i] = (int32_t)n;
+        const int qlx = (int)kfL[i].x / cell, qly = (int)kfL[i].y / cell, qrx = (int)kfR[i].x / cell, qry = (int)kfR[i].y / cell;
+        for (int j = 0; j < n_cf; j++)
+        {
+            const int lx = (int)cfL[j].x / cell, ly = (int)cfL[j].y / cell, rx = (int)cfR[j].x / cell, ry = (int)cfR[j].y / cell;
+            /* in the left grid at all? (:31-34)  in a neighbour cell of the query that exists? (Dataset.h:104-105) */
+            if (!(lx >= 0 && lx < gw && ly >= 0 && ly < gh) || !(rx >= 0 && rx < gw && ry >= 0 && ry < gh))
+                continue;
+            if (abs(lx - qlx) > sr || abs(ly - qly) > sr || abs(rx - qrx) > sr || abs(ry - qry) > sr)
+                continue;
+            if (!orient_close_deg(kfL[i].theta, cfL[j].theta, orient_thr_deg) || !orient_close_deg(kfR[i].theta, cfR[j].theta, orient_thr_deg))
+                continue;
+            if (col_idx && n < cap)
+                col_idx[n] = j;
+            n++;
+        }
+    }
+    row_ptr[n_kf] = (int32_t)n;
+    *n_out = n;
+    return (col_idx && n > cap) ? -2 : 0;
+}

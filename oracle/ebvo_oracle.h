@@ -160,6 +160,11 @@ void orc_sift_descriptors(const uint8_t *img, int h, int w, ptrdiff_t stride, co
                           int nthreads, float *desc);
 void orc_sift_min_distances(const float *left_desc, const float *cand_desc, const int32_t *row_ptr, int nL, double *dist);
 
+/* temporal candidate quads (src/Temporal_Matches.cpp:335-414), ascending current-frame mate index; PARITY UNPINNED */
+int orc_temporal_candidates(const orc_edge *kfL, const orc_edge *kfR, int n_kf, const orc_edge *cfL, const orc_edge *cfR, int n_cf,
+                            int img_w, int img_h, int cell, double radius, double orient_thr_deg, int32_t *row_ptr,
+                            int32_t *col_idx, int64_t cap, int64_t *n_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -283,3 +283,17 @@ def sift_min_distances(left_desc, cand_desc, row_ptr):
     out = np.zeros(len(cand_desc))
     lib().orc_sift_min_distances(_p(left_desc), _p(cand_desc), _p(row_ptr), len(row_ptr) - 1, _p(out))
     return out
+
+
+def temporal_candidates(kfL, kfR, cfL, cfR, img_w, img_h, cell=15, radius=30.0, orient_thr_deg=10.0):
+    arrs = [np.ascontiguousarray(a, dtype=EDGE_DTYPE) for a in (kfL, kfR, cfL, cfR)]
+    n_kf, n_cf = len(arrs[0]), len(arrs[2])
+    row_ptr = np.zeros(n_kf + 1, dtype=np.int32)
+    n = C.c_int64()
+    f = lib().orc_temporal_candidates
+    args = (_p(arrs[0]), _p(arrs[1]), n_kf, _p(arrs[2]), _p(arrs[3]), n_cf, img_w, img_h, cell, C.c_double(radius),
+            C.c_double(orient_thr_deg), _p(row_ptr))
+    f(*args, None, C.c_int64(0), C.byref(n))
+    col = np.zeros(max(1, n.value), dtype=np.int32)
+    assert f(*args, _p(col), C.c_int64(len(col)), C.byref(n)) == 0
+    return row_ptr, col[: n.value].copy()

@@ -1,0 +1,88 @@
+"""Temporal quads on the resident pairs (ebvo_temporal_set_keyframe / _match): candidate lists against the brute-force
+restatement of the grid + orientation filters (src/Temporal_Matches.cpp:335-414), and the NCC of every candidate quad on
+the mates' stored patches against the oracle's apply_NCC_filtering_quads (:416-469) -- every quad, bit for bit."""
+import numpy as np
+import pytest
+
+from edge_based_visual_odometry_amd import synth
+from tests import oracle as orc
+from tests.util import assert_bit_equal, assert_edges_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def _frame(ctx, h, w, k, F, calib, undist=None):
+    """frame k of SURVEY 8(d) config 3: scene 7, noise seeds (2k + 1, 2k + 2), global shift of k px"""
+    l, r = synth.stereo_pair("s2", h, w, scene=7, noise_base=2 * k, disparity=9)
+    l, r = np.roll(l, k, axis=1), np.roll(r, k, axis=1)
+    ctx.stereo_upload(l, r)
+    ctx.stereo_run(ctx.default_params(F))
+    counts, fin = ctx.stereo_finalize(calib)
+    return l, r, fin
+
+
+@pytest.mark.parametrize("undist", [False, True])
+def test_temporal_quads_equal_oracle(ctx, undist):
+    h, w = 240, 376
+    ce = synth.CALIB["euroc"]
+    K = tuple(v / 2 for v in ce["K"])
+    Kr = tuple(v / 2 for v in ce["K_right"])
+    F = synth.fundamental_21(K, Kr, ce["R21"], ce["T21"])
+    calib = ([K[0], 0, K[2], 0, K[1], K[3], 0, 0, 1], [Kr[0], 0, Kr[2], 0, Kr[1], Kr[3], 0, 0, 1], ce["R21"], ce["T21"])
+    if undist:
+        ctx.set_undistort(K, ce["dist"], Kr, ce["dist_right"])
+    try:
+        l0, r0, kf = _frame(ctx, h, w, 0, F, calib)
+        ctx.temporal_set_keyframe()
+        # keyframe mates as the host sees them: left TOED edge of every final pair + its right centre
+        ctx.stereo_upload(l0, r0)
+        c0 = ctx.stereo_run(ctx.default_params(F))
+        left0 = ctx.stereo_fetch(c0)["left"]
+        _, kf = ctx.stereo_finalize(calib)
+        kfL, kfR = left0[kf["left_index"]], kf["right"]
+        l3, r3, _ = _frame(ctx, h, w, 3, F, calib)
+        c3 = ctx.stereo_run(ctx.default_params(F))
+        left3 = ctx.stereo_fetch(c3)["left"]
+        _, cf = ctx.stereo_finalize(calib)
+        cfL, cfR = left3[cf["left_index"]], cf["right"]
+        counts, q = ctx.temporal_match()
+    finally:
+        if undist:
+            ctx.set_undistort()
+    assert counts["n_kf"] == len(kfL) and counts["n_cf"] == len(cfL) and counts["n_kf"] > 1000
+    orp, oci = orc.temporal_candidates(kfL, kfR, cfL, cfR, w, h)
+    assert_bit_equal(q["row_ptr"], orp, "row_ptr")
+    assert_bit_equal(q["col_idx"], oci, "col_idx")
+    assert counts["n_candidates"] == len(oci) > 10 * counts["n_kf"]
+    # stored patches: left from the RAW left image, right from the UNDISTORTED right image
+    ru0 = orc.undistort(r0, Kr, ce["dist_right"]) if undist else r0
+    ru3 = orc.undistort(r3, Kr, ce["dist_right"]) if undist else r3
+    pkL, pkR = orc.edge_patches(l0, kfL), orc.edge_patches(ru0, kfR)
+    pcL, pcR = orc.edge_patches(l3, cfL), orc.edge_patches(ru3, cfR)
+    rows = np.repeat(np.arange(len(kfL)), np.diff(orp))
+    sl, sr, keep = orc.ncc_quads(pkL[rows], pkR[rows], pcL[oci], pcR[oci], 0.8)
+    assert_bit_equal(q["sim_left"], sl, "sim_left")
+    assert_bit_equal(q["sim_right"], sr, "sim_right")
+    assert_bit_equal(q["keep"], keep, "keep")
+    assert counts["n_kept"] == int(keep.sum()) > 100
+    # the scene moved by 3 px: the kept quads are that motion
+    dx = cfL["x"][oci[keep.astype(bool)]] - kfL["x"][rows[keep.astype(bool)]]
+    assert abs(np.median(dx) - 3.0) < 1.0
+
+
+def test_temporal_state_machine(ctx):
+    from edge_based_visual_odometry_amd._lib import EbvoError, EBVO_ERR_STATE
+    l, r = synth.stereo_pair("s2", 96, 160)
+    F = synth.fundamental_for("kitti")
+    ctx.stereo_upload(l, r)
+    ctx.stereo_run(ctx.default_params(F))
+    with pytest.raises(EbvoError) as ei:
+        ctx.temporal_set_keyframe()                     # not finalized
+    assert ei.value.status == EBVO_ERR_STATE
+    ctx.stereo_finalize(None)
+    ctx.temporal_set_keyframe()
+    counts, q = ctx.temporal_match()                    # a frame against itself
+    assert counts["n_kf"] == counts["n_cf"] and counts["n_kept"] >= counts["n_kf"] * 0.9
+    ctx.stereo_upload(l, r)
+    with pytest.raises(EbvoError):
+        ctx.temporal_match()                            # the new pair has no final mates yet
