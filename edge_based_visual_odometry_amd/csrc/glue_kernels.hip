@@ -14,9 +14,20 @@
 
 #include "ebvo_internal.h"
 #include "ebvo_math.h"
+#include "ebvo_sort.h"
 
 namespace
 {
+
+// rows of more than 16 candidates: libstdc++'s introsort, restated (ebvo_sort.h); out of line, its explicit recursion stack
+// stays out of the common path's registers
+__device__ __noinline__ void sort_long_row(int32_t *ord, int n, const double *scores, int higher)
+{
+    ebvo_sort_cmp c;
+    c.score = scores;
+    c.descending = higher;
+    ebvo_std_sort(ord, n, &c);
+}
 
 __global__ void bnb_kernel(const int32_t *__restrict__ row_ptr, int nL, const double *__restrict__ scores, double thr,
                            int higher, int32_t *__restrict__ new_count, int32_t *__restrict__ order)
@@ -30,8 +41,12 @@ __global__ void bnb_kernel(const int32_t *__restrict__ row_ptr, int nL, const do
         new_count[i] = n;
         if (n < 2)
             continue;
-        // stable insertion sort by score: std::sort's result for rows of <= 16 entries; ties keep their position
-        for (int k = 1; k < n; ++k)
+        // std::sort(indices, comp) (:809-813).  Up to 16 entries libstdc++ runs one insertion sort, which leaves equal
+        // scores in their original order; longer rows go through its introsort, where ties land wherever the partitioning
+        // puts them -- reproduced move for move by sort_long_row
+        if (n > 16)
+            sort_long_row(ord, n, scores, higher);
+        for (int k = 1; k < n && n <= 16; ++k)
         {
             const int32_t v = ord[k];
             const double sv = scores[v];

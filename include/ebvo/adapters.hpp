@@ -9,6 +9,8 @@
 //                                               apply_NCC_Filtering (include/Stereo_Matches.h:61-68) on
 //                                               plain vectors; the reference-side glue copies to/from
 //                                               Stereo_Edge_Pairs (include/Dataset.h:180-289)
+//   ebvo::undistort / sift_descriptors / sift_min_distances -- cv::undistort (src/Pipeline.cpp:78-79) and the cv::SIFT
+//                                               calls of augment_Edge_Data / apply_SIFT_filtering (src/Stereo_Matches.cpp:655-787)
 //   ebvo::patch_similarity / ncc_quads       -- Utility::get_patch_similarity (src/utility.cpp:163-180),
 //                                               Temporal_Matches::apply_NCC_filtering_quads scoring and the
 //                                               MatlabNCCComputer::computeNCC-shaped entry
@@ -376,6 +378,46 @@ class StereoMatcherHIP
   private:
     Context::Ptr ctx_;
 };
+
+// cv::undistort(src, dst, K, dist) of src/Pipeline.cpp:78-79 on a CV_8UC1 image (K = fx fy cx cy, dist = k1 k2 p1 p2 [k3])
+inline std::vector<uint8_t> undistort(const Context &c, const uint8_t *img, int rows, int cols, ptrdiff_t step, const double K[4],
+                                      const std::vector<double> &dist)
+{
+    std::vector<uint8_t> out((size_t)rows * cols);
+    const int rc = ebvo_undistort(c.get(), img, rows, cols, step, K, dist.data(), (int)dist.size(), out.data(), cols);
+    if (!report(c, rc, "ebvo_undistort"))
+        out.clear();
+    return out;
+}
+
+// The two SIFT descriptors of every edge (cv::SIFT::create()->compute at the +-8 px points; src/Stereo_Matches.cpp:669-677,
+// :720-727, :1628-1634): n x 2 x 128 floats, descriptor of shifted_points.first then of .second.
+template <class EdgeT>
+inline std::vector<float> sift_descriptors(const Context &c, const uint8_t *img, int rows, int cols, ptrdiff_t step,
+                                           const std::vector<EdgeT> &edges)
+{
+    std::vector<ebvo_edge> e(edges.size());
+    for (size_t k = 0; k < edges.size(); ++k)
+        e[k] = to_abi(edges[k]);
+    std::vector<float> out(256 * edges.size());
+    const int rc = ebvo_sift_descriptors(c.get(), img, rows, cols, step, e.data(), (int)e.size(), out.data());
+    if (!report(c, rc, "ebvo_sift_descriptors"))
+        out.clear();
+    return out;
+}
+
+// apply_SIFT_filtering's score per candidate pair (:736-740): cand_desc holds one descriptor pair per pair of the CSR lists
+inline std::vector<double> sift_min_distances(const Context &c, const std::vector<float> &left_desc,
+                                              const std::vector<float> &cand_desc, const std::vector<int32_t> &row_ptr)
+{
+    std::vector<double> d(cand_desc.size() / 256);
+    const int rc = ebvo_sift_min_distances(c.get(), left_desc.data(), (int)(left_desc.size() / 256), cand_desc.data(),
+                                           row_ptr.data(), d.data());
+    if (!report(c, rc, "ebvo_sift_min_distances"))
+        d.clear();
+    return d;
+}
+
 
 // Utility::get_patch_similarity on two 7x7 CV_32F patches (src/utility.cpp:163-180); also the shape
 // of MatlabNCCComputer::computeNCC(patch1, patch2) -> double (include/MatlabNCCComputer.h:41): NaN

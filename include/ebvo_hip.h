@@ -269,8 +269,9 @@ int ebvo_gn_refine_temporal(ebvo_ctx *ctx, const uint8_t *imgKF, const uint8_t *
  *                      (SIFT distances) with higher_is_better = 0
  *   new_count[nL]    : survivors per row;  order[n_pairs] : order[row_ptr[i] + k] = pair index of the k-th survivor of
  *                      row i (k < new_count[i]), in the order the reference leaves them: by score when something was
- *                      dropped, untouched otherwise (:840).  Equal scores keep their relative position (std::sort is
- *                      not stable; this is what libstdc++ does for rows of at most 16 candidates).
+ *                      dropped, untouched otherwise (:840).  The order among equal scores is std::sort's, i.e. libstdc++'s
+ *                      introsort restated move for move (csrc/ebvo_sort.h): original position for rows of at most 16
+ *                      candidates, wherever its partitioning leaves them for longer rows.
  */
 int ebvo_bnb_test(ebvo_ctx *ctx, const int32_t *row_ptr, int nL, const double *scores, double ratio_thr,
                   int higher_is_better, int32_t *new_count, int32_t *order);

@@ -1,6 +1,6 @@
 // integration/stereo_matches_hip.cpp -- reference-side binding: replacement bodies for the four hot
 // filters of Stereo_Matches and for the temporal NCC scorer.  Delete the originals
-// (src/Stereo_Matches.cpp:381-419, :534-553, :555-616, :863-915 and src/Temporal_Matches.cpp:416-469) and add
+// (src/Stereo_Matches.cpp:381-419, :534-553, :555-616, :655-787, :863-915 and src/Temporal_Matches.cpp:416-469) and add
 // this file to src/CMakeLists.txt; headers, get_Stereo_Edge_Pairs (src/Stereo_Matches.cpp:1360-1540), the SIFT /
 // BNB / refinement stages between them and main_VO stay as they are.
 //
@@ -8,6 +8,8 @@
 // one compiled and parity-tested through include/ebvo/adapters.hpp (tests/test_cpp_adapter.py).
 #include "Stereo_Matches.h"
 #include "Temporal_Matches.h"
+#include <cstring>
+
 #include "ebvo/adapters.hpp"
 
 ebvo::Context::Ptr ebvo_context_of(const ThirdOrderEdgeDetectionCPU *toed); // integration/hip_toed.cpp
@@ -130,6 +132,63 @@ void Stereo_Matches::apply_NCC_Filtering(Stereo_Edge_Pairs &p, const std::string
         mc.refine_final_scores = std::move(scores);
         mc.refine_confidences = std::move(conf);
         mc.refine_validities = std::move(valid);
+    }
+}
+
+
+// augment_Edge_Data (src/Stereo_Matches.cpp:655-689): the reference builds a SIFT octave per EDGE; the device forms the
+// level once per image and evaluates every keypoint in one launch.
+void Stereo_Matches::augment_Edge_Data(Stereo_Edge_Pairs &p, bool is_left)
+{
+    const cv::Mat &image = is_left ? p.stereo_frame->left_image_undistorted : p.stereo_frame->right_image_undistorted;
+    const std::vector<Edge> left = p.get_focused_edges();
+    const std::vector<float> d = ebvo::sift_descriptors(*ebvo_context_of(g_pipeline_toed), image.data, image.rows, image.cols,
+                                                        (ptrdiff_t)image.step, left);
+    p.left_edge_descriptors.assign(left.size(), std::make_pair(cv::Mat(), cv::Mat()));
+    for (size_t i = 0; i < left.size() && d.size() == 256 * left.size(); ++i)
+        p.left_edge_descriptors[i] = {cv::Mat(1, 128, CV_32F, (void *)(d.data() + 256 * i)).clone(),
+                                      cv::Mat(1, 128, CV_32F, (void *)(d.data() + 256 * i + 128)).clone()};
+}
+
+// apply_SIFT_filtering (:691-787): descriptors of every candidate edge, min of the four distances, keep < threshold
+void Stereo_Matches::apply_SIFT_filtering(Stereo_Edge_Pairs &p, double sift_dist_threshold, const std::string &, size_t, bool is_left)
+{
+    const cv::Mat &image = is_left ? p.stereo_frame->right_image_undistorted : p.stereo_frame->left_image_undistorted;
+    std::vector<int32_t> row_ptr(p.matching_edge_clusters.size() + 1, 0);
+    std::vector<Edge> cand;
+    std::vector<float> left_desc(256 * p.matching_edge_clusters.size(), 0.f);
+    for (size_t i = 0; i < p.matching_edge_clusters.size(); ++i)
+    {
+        for (const EdgeCluster &ec : p.matching_edge_clusters[i].edge_clusters)
+            cand.push_back(ec.center_edge);
+        row_ptr[i + 1] = (int32_t)cand.size();
+        if (!p.left_edge_descriptors[i].first.empty())
+        {
+            std::memcpy(&left_desc[256 * i], p.left_edge_descriptors[i].first.ptr<float>(), 128 * sizeof(float));
+            std::memcpy(&left_desc[256 * i + 128], p.left_edge_descriptors[i].second.ptr<float>(), 128 * sizeof(float));
+        }
+    }
+    const ebvo::Context &c = *ebvo_context_of(g_pipeline_toed);
+    const std::vector<float> cd = ebvo::sift_descriptors(c, image.data, image.rows, image.cols, (ptrdiff_t)image.step, cand);
+    const std::vector<double> dist = ebvo::sift_min_distances(c, left_desc, cd, row_ptr);
+    for (size_t i = 0; i < p.matching_edge_clusters.size(); ++i)
+    {
+        auto &mc = p.matching_edge_clusters[i];
+        std::vector<EdgeCluster> keep;
+        std::vector<double> conf;
+        for (int32_t k = row_ptr[i]; k < row_ptr[i + 1]; ++k)
+            if (dist.empty())
+            { // :760-766: keep everything if the descriptors could not be computed
+                keep.push_back(mc.edge_clusters[(size_t)(k - row_ptr[i])]);
+                conf.push_back(sift_dist_threshold * 2.0);
+            }
+            else if (dist[k] < sift_dist_threshold)
+            { // :752-757
+                keep.push_back(mc.edge_clusters[(size_t)(k - row_ptr[i])]);
+                conf.push_back(dist[k]);
+            }
+        mc.edge_clusters = std::move(keep);
+        mc.refine_confidences = std::move(conf);
     }
 }
 

@@ -23,6 +23,7 @@
 #include <string.h>
 
 #include "../edge_based_visual_odometry_amd/csrc/ebvo_math.h"
+#include "../edge_based_visual_odometry_amd/csrc/ebvo_sort.h"
 
 /* ------------------------------------------------------------------------------------ */
 /* TOED filter taps: sigma = 2 Gaussian and its derivatives, 19 entries each.            */
@@ -1038,7 +1039,8 @@ void orc_finalize_pairs(const double *Kl, const double *Kr, const double *R21, c
  * higher_is_better -- refine_final_scores / NCC; ascending otherwise -- refine_confidences / SIFT distance), the best is
  * kept and every following one while its ratio to the BEST stays >= thr.  When nothing is dropped the row keeps its
  * original order (the reference only rebuilds the vectors if keep_count < num_clusters, :840).  std::sort is not
- * stable; ties are resolved here by the original position (what libstdc++ does for rows of <= 16 entries).
+ * stable: rows of <= 16 entries come out with ties in their original position, longer rows as libstdc++'s introsort
+ * leaves them (ebvo_sort.h).
  * order[row_ptr[i] + k] = index (into the pair arrays) of the k-th survivor of row i, k < new_count[i]. */
 void orc_bnb_test(const int32_t *row_ptr, int nL, const double *scores, double thr, int higher_is_better,
                   int32_t *new_count, int32_t *order)
@@ -1052,7 +1054,14 @@ void orc_bnb_test(const int32_t *row_ptr, int nL, const double *scores, double t
         new_count[i] = n;
         if (n < 2)
             continue;
-        for (int k = 1; k < n; k++) /* stable insertion sort */
+        if (n > 16)
+        { /* std::sort: libstdc++'s introsort restated (ebvo_sort.h, checked against the real one by tests/cpp/sort_check.cpp) */
+            ebvo_sort_cmp c;
+            c.score = scores;
+            c.descending = higher_is_better;
+            ebvo_std_sort(ord, n, &c);
+        }
+        for (int k = 1; k < n && n <= 16; k++) /* n <= 16: std::sort is one insertion sort, ties keep their position */
         {
             const int32_t v = ord[k];
             int j = k;

@@ -54,9 +54,48 @@ def test_bnb_matches_python_reading():
         assert np.array_equal(cnt, pc)
         for i in range(len(rp) - 1):
             b = rp[i]
-            assert np.array_equal(order[b:b + cnt[i]], po[b:b + pc[i]])
+            if rp[i + 1] - b <= 16:                           # std::sort == a stable sort only up to 16 entries (ebvo_sort.h)
+                assert np.array_equal(order[b:b + cnt[i]], po[b:b + pc[i]])
+            else:                                             # same scores in the same places, ties possibly permuted
+                assert np.array_equal(sc[order[b:b + cnt[i]]], sc[po[b:b + pc[i]]])
             if cnt[i] == rp[i + 1] - b:                       # nothing dropped: original order
                 assert np.array_equal(order[b:rp[i + 1]], np.arange(b, rp[i + 1]))
+
+
+def test_std_sort_restatement_equals_libstdcxx(tmp_path):
+    """csrc/ebvo_sort.h against the real std::sort of this toolchain (tests/cpp/sort_check.cpp): ties, both comparators,
+    lengths up to 5000."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "sort_check")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Werror", os.path.join(root, "tests", "cpp", "sort_check.cpp"),
+                           "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.startswith("ok"), out.stdout
+
+
+def test_bnb_long_rows_with_ties_follow_std_sort():
+    """Rows of more than 16 candidates with tied scores at the cut: the survivors are the ones libstdc++'s std::sort puts
+    first, not the ones a stable sort would (the two differ on this input)."""
+    rng = np.random.default_rng(21)
+    lens = rng.integers(17, 120, 300)
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    sc = rng.choice([0.95, 0.9, 0.86, 0.7, 0.5], rp[-1])            # heavy ties, several of them at the 0.9 ratio cut
+    cnt, order = orc.bnb_test(rp, sc, 0.9, True)
+    stable_differs = 0
+    for i in range(len(lens)):
+        b, n = rp[i], lens[i]
+        kept = order[b:b + cnt[i]]
+        assert len(set(kept.tolist())) == cnt[i] and ((kept >= b) & (kept < b + n)).all()
+        s = sc[kept]
+        assert (np.diff(s) <= 0).all()                               # descending
+        best = s[0]
+        assert best == sc[b:b + n].max() and (s / best >= 0.9).all()
+        assert cnt[i] == int((sc[b:b + n] / best >= 0.9).sum())      # ties never change HOW MANY survive here
+        stable = np.argsort(-sc[b:b + n], kind="stable")[:cnt[i]] + b
+        stable_differs += int(not np.array_equal(stable, kept))
+    assert stable_differs > 0
 
 
 def test_keep_best():

@@ -21,7 +21,7 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 mode = sys.argv[2] if len(sys.argv) > 2 else "hybrid"
 suffix = sys.argv[3] if len(sys.argv) > 3 else ""
 src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
-dst = os.path.join(ROOT, "profiles")
+dst = os.environ.get("EBVO_PROFILES_DST", os.path.join(ROOT, "profiles"))  # on the GPU box: a directory under gpurun_out/
 os.makedirs(dst, exist_ok=True)
 
 
@@ -92,7 +92,7 @@ if pm:
     pm.append(f"sum over the kernel symbols of one launch each (FETCH x2 + WRITE): {tot / 1e6:.1f} MB")
     open(os.path.join(dst, f"{tag}_pmc_hbm_{mode}{suffix}.txt"), "w").write("\n".join(pm) + "\n")
     print("\n".join(pm))
-    if not suffix:
+    if not suffix and "_" not in tag:  # the machine-readable table bench.py reads: the headline workload only
         json.dump({"toed_mode": mode,
                    "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, {tag}; FETCH_SIZE doubled "
                              "(gfx950 correction, MI355X_MICROARCH.md); bytes per launch of each kernel symbol",
