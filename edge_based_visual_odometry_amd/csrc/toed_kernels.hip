@@ -1139,20 +1139,78 @@ __device__ inline double exact_mag(const uint8_t *__restrict__ img, int h, int w
     return sqrt(fx * fx + fy * fy);
 }
 
-// S3b: exact centre of every candidate of one phase; early NMS rejects; marks the grid points whose exact |g| the NMS of
-// this candidate needs.  Adjacent candidates along a contour share two of their four neighbours and 14 % of the
-// neighbours are candidates themselves (whose |g| is computed right here): marking every distinct point once in a
-// bitmap (no-return atomicOr; one row of the bitmap per grid row) leaves 54 % of the neighbour evaluations.
-template <int SY, int SX>
-__device__ inline void centre_phase(const ExactBatch &E, const ExactTaps &L, int h, int w, int cap)
+#ifdef EBVO_WAVE_TRACE
+// developer build only (make EXTRA=-DEBVO_WAVE_TRACE): where and when every wave of an exact kernel ran
+__device__ unsigned long long g_wave_trace[2][8192 * 4];
+__device__ inline void wave_trace(int which, int wave, unsigned long long t0, int tasks)
 {
-    const int im = blockIdx.y, W2 = 2 * w, H2 = 2 * h, wpr = (W2 + 31) >> 5;
+    if ((threadIdx.x & 63) == 0 && wave < 8192)
+    {
+        const unsigned hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));  // HW_REG_HW_ID
+        const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)); // HW_REG_XCC_ID
+        unsigned long long *o = g_wave_trace[which] + (size_t)wave * 4;
+        o[0] = t0;
+        o[1] = __builtin_amdgcn_s_memrealtime();
+        o[2] = ((unsigned long long)xcc << 32) | hw;
+        o[3] = (unsigned long long)tasks;
+    }
+}
+extern "C" int ebvo_wave_trace_read(int which, unsigned long long *dst, int n_waves)
+{
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_wave_trace), (size_t)n_waves * 32, (size_t)which * 8192 * 32,
+                                    hipMemcpyDeviceToHost);
+}
+#define EBVO_TRACE_BEGIN() const unsigned long long trace_t0 = __builtin_amdgcn_s_memrealtime(); int trace_n = 0
+#define EBVO_TRACE_TASK() ++trace_n
+#define EBVO_TRACE_END(which) wave_trace(which, wave, trace_t0, trace_n)
+#else
+#define EBVO_TRACE_BEGIN()
+#define EBVO_TRACE_TASK()
+#define EBVO_TRACE_END(which)
+#endif
+
+// Work distribution of the two exact kernels.  The (phase, image) lists are cut into runs of 64 entries -- one run is one
+// wave's worth of work, and every run of a kernel costs the same -- and the runs are dealt round-robin to the waves of a
+// launch that holds exactly as many blocks as the chip keeps resident: at KITTI size every SIMD receives four runs of
+// exact_centre (tools/gpu_wave_trace.py: 1013 SIMDs with 4 runs, 11 with 3).  A grid sized for the list CAPACITY put the
+// runs into the first half of the blocks of each (image, phase) slice and left the second half of every slice empty:
+// 102.7 -> 90.6 us (centre), 82.8 -> 65.3 us (mags).  The counts live on the device, so every wave walks the (at
+// most 8) list lengths itself; all of it is wave-uniform scalar work.
+struct ExactTask
+{
+    int im, ph, k0, n;
+};
+
+__device__ inline bool exact_task(const ExactBatch &E, int n_img, int cap, int list0, int t, ExactTask &o)
+{
+    int base = 0;
+    for (int ph = 0; ph < 4; ++ph)
+        for (int im = 0; im < n_img; ++im)
+        {
+            const int n = min(E.lcount[im][list0 + ph], cap);
+            const int c = (n + 63) >> 6;
+            if (t < base + c)
+            {
+                o.im = im;
+                o.ph = ph;
+                o.k0 = (t - base) << 6;
+                o.n = n;
+                return true;
+            }
+            base += c;
+        }
+    return false;
+}
+
+template <int SY, int SX>
+__device__ inline void centre_run(const ExactBatch &E, const ExactTaps &L, int h, int w, int cap, int im, int k, int n)
+{
+    const int W2 = 2 * w, H2 = 2 * h, wpr = (W2 + 31) >> 5;
     constexpr int PH = (SY << 1) | SX;
     const int32_t *__restrict__ list = E.lists[im] + (size_t)PH * cap;
-    const int n = min(E.lcount[im][PH], cap);
     const CandData &cd = E.cd[im];
     const uint8_t *__restrict__ flag = E.flag[im];
-    for (int k = blockIdx.x * 256 + threadIdx.x; k < n; k += gridDim.x * 256)
+    if (k < n)
     {
         const int t = list[k];
         const int o = E.src[im][2 * t];
@@ -1188,18 +1246,31 @@ __device__ inline void centre_phase(const ExactBatch &E, const ExactTaps &L, int
     }
 }
 
+// S3b: exact centre of every candidate; early NMS rejects; marks the grid points whose exact |g| the NMS of the
+// candidate needs.  Adjacent candidates along a contour share two of their four neighbours and 14 % of the
+// neighbours are candidates themselves (whose |g| is computed right here): marking every distinct point once in a
+// bitmap (no-return atomicOr; one row of the bitmap per grid row) leaves 54 % of the neighbour evaluations.
 __global__ __launch_bounds__(256) void toed_exact_centre_kernel(ExactBatch E, const ToedTables *__restrict__ T, int h,
-                                                                int w, int cap)
+                                                                int w, int cap, int n_img)
 {
     __shared__ ExactTaps L;
+    EBVO_TRACE_BEGIN();
     load_exact_taps(L, T);
-    switch (blockIdx.z)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    ExactTask q;
+    for (int t = wave; exact_task(E, n_img, cap, 0, t, q); t += gridDim.x * 4)
     {
-    case 0: centre_phase<0, 0>(E, L, h, w, cap); break;
-    case 1: centre_phase<0, 1>(E, L, h, w, cap); break;
-    case 2: centre_phase<1, 0>(E, L, h, w, cap); break;
-    default: centre_phase<1, 1>(E, L, h, w, cap); break;
+        EBVO_TRACE_TASK();
+        switch (q.ph)
+        {
+        case 0: centre_run<0, 0>(E, L, h, w, cap, q.im, q.k0 + lane, q.n); break;
+        case 1: centre_run<0, 1>(E, L, h, w, cap, q.im, q.k0 + lane, q.n); break;
+        case 2: centre_run<1, 0>(E, L, h, w, cap, q.im, q.k0 + lane, q.n); break;
+        default: centre_run<1, 1>(E, L, h, w, cap, q.im, q.k0 + lane, q.n); break;
+        }
     }
+    EBVO_TRACE_END(0);
 }
 
 // S3c: the four neighbour magnitudes of every candidate of one (phase, axis) class.  The axis neighbours
@@ -1319,15 +1390,14 @@ __global__ __launch_bounds__(256) void toed_need_compact_kernel(ExactBatch E, in
     }
 }
 
-// S3c-3: exact |g| at every marked grid point, one thread per point, one phase per launch slice
+// S3c-3: exact |g| at every marked grid point, one thread per point, runs of 64 points dealt to the waves (exact_task)
 template <int SY, int SX>
-__device__ inline void mags_phase(const ExactBatch &E, const ExactTaps &L, int h, int w, int cap)
+__device__ inline void mags_run(const ExactBatch &E, const ExactTaps &L, int h, int w, int cap, int im, int k, int n)
 {
-    const int im = blockIdx.y, W2 = 2 * w;
+    const int W2 = 2 * w;
     constexpr int PH = (SY << 1) | SX;
     const int32_t *__restrict__ list = E.lists[im] + (size_t)(4 + PH) * cap;
-    const int n = min(E.lcount[im][4 + PH], cap);
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x)
+    if (k < n)
     {
         const int o = list[k];
         const int I = o / W2, J = o - I * W2;
@@ -1336,17 +1406,26 @@ __device__ inline void mags_phase(const ExactBatch &E, const ExactTaps &L, int h
 }
 
 __global__ __launch_bounds__(256) void toed_exact_mags_kernel(ExactBatch E, const ToedTables *__restrict__ T, int h,
-                                                              int w, int cap)
+                                                              int w, int cap, int n_img)
 {
     __shared__ ExactTaps L;
+    EBVO_TRACE_BEGIN();
     load_exact_taps(L, T);
-    switch (blockIdx.z)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    ExactTask q;
+    for (int t = wave; exact_task(E, n_img, cap, 4, t, q); t += gridDim.x * 4)
     {
-    case 0: mags_phase<0, 0>(E, L, h, w, cap); break;
-    case 1: mags_phase<0, 1>(E, L, h, w, cap); break;
-    case 2: mags_phase<1, 0>(E, L, h, w, cap); break;
-    default: mags_phase<1, 1>(E, L, h, w, cap); break;
+        EBVO_TRACE_TASK();
+        switch (q.ph)
+        {
+        case 0: mags_run<0, 0>(E, L, h, w, cap, q.im, q.k0 + lane, q.n); break;
+        case 1: mags_run<0, 1>(E, L, h, w, cap, q.im, q.k0 + lane, q.n); break;
+        case 2: mags_run<1, 0>(E, L, h, w, cap, q.im, q.k0 + lane, q.n); break;
+        default: mags_run<1, 1>(E, L, h, w, cap, q.im, q.k0 + lane, q.n); break;
+        }
     }
+    EBVO_TRACE_END(1);
 }
 
 // S3d: the exact NMS decision of every candidate, from exact values only
@@ -1463,6 +1542,25 @@ int toed_init_constants(ebvo_ctx *ctx)
     return EBVO_OK;
 }
 
+// blocks of 256 threads the device keeps resident at once for the exact kernels (CUs x blocks per CU): their launches
+// are exactly that large, see exact_task
+static int resident_blocks(ebvo_ctx *ctx, int which)
+{
+    static int cached[16][2];
+    int &c = cached[ctx->device & 15][which];
+    if (c == 0)
+    {
+        int per_cu = 0, cus = 0;
+        if (which == 0)
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, toed_exact_centre_kernel, 256, 0);
+        else
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, toed_exact_mags_kernel, 256, 0);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
+        c = (per_cu > 0 ? per_cu : 4) * (cus > 0 ? cus : 256);
+    }
+    return c;
+}
+
 int toed_enqueue(ebvo_ctx *ctx, Slot &s, int n_img, int h, int w, hipEvent_t ev_conv_begin, hipEvent_t ev_conv_end,
                  hipEvent_t ev_end)
 {
@@ -1557,8 +1655,8 @@ int toed_enqueue(ebvo_ctx *ctx, Slot &s, int n_img, int h, int w, hipEvent_t ev_
             const ToedTables *T = (const ToedTables *)g_tables_dev[ctx->device];
             {
                 ProfScope ps(ctx, s, K_EXACT_CENTRE);
-                hipLaunchKernelGGL(toed_exact_centre_kernel, dim3(256, n_img, 4), dim3(256), 0, s.stream, E, T, h, w,
-                                   cap);
+                hipLaunchKernelGGL(toed_exact_centre_kernel, dim3(resident_blocks(ctx, 0)), dim3(256), 0, s.stream, E, T,
+                                   h, w, cap, n_img);
             }
             {
                 ProfScope ps(ctx, s, K_COMPACT); // the lists of the distinct neighbour points
@@ -1568,7 +1666,8 @@ int toed_enqueue(ebvo_ctx *ctx, Slot &s, int n_img, int h, int w, hipEvent_t ev_
             }
             {
                 ProfScope ps(ctx, s, K_EXACT_MAGS);
-                hipLaunchKernelGGL(toed_exact_mags_kernel, dim3(256, n_img, 4), dim3(256), 0, s.stream, E, T, h, w, cap);
+                hipLaunchKernelGGL(toed_exact_mags_kernel, dim3(resident_blocks(ctx, 1)), dim3(256), 0, s.stream, E, T, h,
+                                   w, cap, n_img);
                 hipLaunchKernelGGL(toed_exact_decide_kernel, dim3(512, n_img), dim3(256), 0, s.stream, E, h, w, cap);
             }
         }

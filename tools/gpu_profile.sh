@@ -8,7 +8,7 @@
 set -u
 TAG=${1:-r02}
 MODE=${2:-hybrid}
-shift 2 2>/dev/null || true
+[ $# -gt 0 ] && shift; [ $# -gt 0 ] && shift
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"

@@ -4,7 +4,7 @@
 set -e
 SRC=$(realpath "$1"); PAT="$2"
 OUT=$(mktemp -d /tmp/isa.XXXXXX)
-( cd "$OUT" && /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -save-temps -c "$SRC" -o x.o 2>/dev/null )
+( cd "$OUT" && /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -save-temps $EXTRA -c "$SRC" -o x.o 2>/dev/null )
 S=$(ls "$OUT"/*gfx950.s)
 SYM=$(grep -oE "^_Z[A-Za-z0-9_]*${PAT}[A-Za-z0-9_]*:" "$S" | head -1 | tr -d ':')
 echo "kernel: $SYM   asm: $S"
