@@ -336,7 +336,9 @@ def main():
                     help="strict: direct-form convolution at every pixel; hybrid: separable screen + exact "
                          "re-evaluation of the candidates (bit-identical edges, ~3x less work)")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for the barrier / max (nccl = RCCL)")
-    ap.add_argument("--streams", type=int, default=3, help="stereo pairs kept in flight per GPU (slots / HIP streams)")
+    ap.add_argument("--streams", type=int, default=6,
+                    help="stereo pairs kept in flight per GPU (slots; one HIP stream each up to 3, from 4 on their kernels are "
+                         "dealt to min(4, slots - 1) streams of the context)")
     args = ap.parse_args()
 
     info = sharding.rank_info()
@@ -364,8 +366,9 @@ def main():
     if wl.get("sequence"):
         return sequence_bench(args, wl, H, W, F, device, rank, world, dist, reduce_device)
 
-    # one context per GPU; --streams S keeps S pairs in flight from this one host thread (S slots, one HIP stream
-    # each): submit enqueues a whole pair without host synchronisation, wait blocks on that pair only
+    # one context per GPU; --streams S keeps S pairs in flight from this one host thread (S slots; one HIP stream each
+    # up to three, four "lane" streams shared by all from five on): submit enqueues a whole pair without host
+    # synchronisation, wait blocks on that pair only
     nslots = max(1, args.streams)
     ctx = Context(H, W, device=device, toed_mode=args.toed_mode)
     ctx.set_slots(nslots)
@@ -442,7 +445,7 @@ def main():
                                   disparity=seq["disparity"]) for k in range(4)]
         from edge_based_visual_odometry_amd import _lib as L_
         n_leg = max(nslots, min(args.steps, 60))
-        frame_loop(ctx, params, pool, nslots, nslots, True, None)             # touch the pool once
+        frame_loop(ctx, params, pool, nslots, nslots, True, L_.FETCH_ALL)     # untimed: touches the pool, sizes the page-locked staging of every slot
         t_up, _ = frame_loop(ctx, params, pool, nslots, n_leg, True, None)
         t_def, mb_def = frame_loop(ctx, params, pool, nslots, n_leg, True, L_.FETCH_DEFAULT)
         t_all, mb_all = frame_loop(ctx, params, pool, nslots, n_leg, True, L_.FETCH_ALL)
@@ -520,6 +523,7 @@ def main():
                        "toed_candidates": n_cand if args.toed_mode == "hybrid" else None,
                        "candidate_pairs": counts.n_pairs, "ncc_matches": counts.n_matches,
                        "pairs_in_flight_per_gpu": nslots,
+                       "streams_per_gpu": nslots if nslots < 4 else min(4, nslots - 1),
                        "parallelism": f"{world} independent sequence(s), one per GPU, no collective"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved_gbs, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, args.toed_mode),

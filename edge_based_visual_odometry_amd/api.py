@@ -490,7 +490,8 @@ class Context:
                     keep=view(v.keep, v.n_pairs, np.uint8))
 
     def debug_set(self, key: int, value: int):
-        """Test hooks (ebvo_debug_set): 0 = attempts of the regrow loop, 1 = force N overflowed results."""
+        """Test hooks (ebvo_debug_set): 0 = attempts of the regrow loop, 1 = force N overflowed results, 2 = number of
+        lanes (streams the submitted pairs are dealt to when more slots are in use; 0 = one stream per slot)."""
         self._check(self.lib.ebvo_debug_set(self._ctx, key, value), "ebvo_debug_set")
 
     # -- profiling -----------------------------------------------------------------------------

@@ -109,8 +109,8 @@ static void slot_destroy(Slot *s)
 {
     if (!s)
         return;
-    if (s->stream)
-        (void)hipStreamSynchronize(s->stream);
+    if (s->own_stream) // (a pair still running on a lane is drained by ebvo_ctx_destroy before any slot goes)
+        (void)hipStreamSynchronize(s->own_stream);
     for (ProfEvent &pe : s->prof_pending)
     {
         (void)hipEventDestroy(pe.a);
@@ -155,9 +155,22 @@ static void slot_destroy(Slot *s)
         (void)hipHostFree(s->h_result);
     if (s->h_arena)
         (void)hipHostFree(s->h_arena);
-    if (s->stream)
-        (void)hipStreamDestroy(s->stream);
+    if (s->ev_done)
+        (void)hipEventDestroy(s->ev_done);
+    if (s->ev_rebind)
+        (void)hipEventDestroy(s->ev_rebind);
+    if (s->own_stream)
+        (void)hipStreamDestroy(s->own_stream);
     delete s;
+}
+
+// Result copies of ebvo_stereo_fetch_begin run on the context's copy stream: an entry point that writes buffers of the
+// slot lets them finish first (the views stay valid; ebvo_stereo_fetch_end then returns at once).
+static int drain_fetch(ebvo_ctx *ctx, Slot &s)
+{
+    if (s.fetch_pending)
+        EBVO_HIP(ctx, hipEventSynchronize(s.ev_rebind));
+    return EBVO_OK;
 }
 
 static int slot_create(ebvo_ctx *ctx, Slot **out)
@@ -176,7 +189,10 @@ static int slot_create(ebvo_ctx *ctx, Slot **out)
             return e_ == hipErrorOutOfMemory ? EBVO_ERR_NOMEM : EBVO_ERR_HIP;      \
         }                                                                          \
     } while (0)
-    CK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    CK(hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking));
+    s->stream = s->own_stream;
+    CK(hipEventCreateWithFlags(&s->ev_done, hipEventDisableTiming));
+    CK(hipEventCreateWithFlags(&s->ev_rebind, hipEventDisableTiming));
     const size_t H2 = 2 * (size_t)ctx->max_h, W2 = 2 * (size_t)ctx->max_w, np2 = H2 * W2;
     for (int k = 0; k < 2; ++k)
     {
@@ -272,8 +288,16 @@ extern "C" void ebvo_ctx_destroy(ebvo_ctx *ctx)
     if (!ctx)
         return;
     (void)hipSetDevice(ctx->device);
+    for (hipStream_t st : ctx->lane_streams) // pairs still running on a lane use the buffers of their slot
+        (void)hipStreamSynchronize(st);
+    if (ctx->copy_stream)
+        (void)hipStreamSynchronize(ctx->copy_stream);
     for (Slot *s : ctx->slots)
         slot_destroy(s);
+    for (hipStream_t st : ctx->lane_streams)
+        (void)hipStreamDestroy(st);
+    if (ctx->copy_stream)
+        (void)hipStreamDestroy(ctx->copy_stream);
     for (ProfEvent &pe : ctx->prof_free)
     {
         (void)hipEventDestroy(pe.a);
@@ -899,7 +923,7 @@ extern "C" int ebvo_stereo_upload_slot(ebvo_ctx *ctx, int slot, const uint8_t *i
     s.have_pair = s.have_run = s.have_refined = s.have_final = false; // results of the previous pair are gone
     s.tq_n = -1;
     if (s.fetch_pending) // a result copy of the previous pair is still reading the buffers
-        EBVO_HIP(ctx, hipStreamSynchronize(s.stream));
+        EBVO_HIP(ctx, hipEventSynchronize(s.ev_rebind));
     s.fetch_pending = false;
     s.fetch_what = 0;
     s.undist_pair = ctx->undist_on; // the pair goes to the raw buffers; submit undistorts it into img
@@ -968,7 +992,10 @@ static int enqueue_matching(ebvo_ctx *ctx, Slot &s)
         return rc;
     if ((rc = match_ncc_resident_enqueue(ctx, s, h, w, ce, p.ncc_thr)))
         return rc;
-    return match_pair_result_enqueue(ctx, s);
+    if ((rc = match_pair_result_enqueue(ctx, s)))
+        return rc;
+    EBVO_HIP(ctx, hipEventRecord(s.ev_done, s.stream));
+    return EBVO_OK;
 }
 
 extern "C" int ebvo_stereo_submit(ebvo_ctx *ctx, int slot, const ebvo_stereo_params *p)
@@ -982,10 +1009,46 @@ extern "C" int ebvo_stereo_submit(ebvo_ctx *ctx, int slot, const ebvo_stereo_par
     EBVO_HIP(ctx, hipSetDevice(ctx->device));
     int rc;
     s.have_run = s.have_refined = s.have_final = false;
-    s.fetch_pending = false; // stream order: the kernels below run after any copy still enqueued on this stream
+    const bool fetch_was_pending = s.fetch_pending;
+    s.fetch_pending = false; // stream order (or the event below): the kernels run after any copy still enqueued
     s.fetch_what = 0;
     s.params = *p;
     s.prof_now = ctx->prof && (ctx->prof_submits++ % ctx->prof_every == 0);
+    // lanes in use: none up to three slots (one stream each), never as many lanes as slots (a lane must be able to hold
+    // a queued pair behind the running one: four slots on four streams is the 2500 pairs/s dip)
+    const int n_lanes = ((int)ctx->slots.size() >= 4 && ctx->lanes > 0)
+                            ? (ctx->lanes < (int)ctx->slots.size() - 1 ? ctx->lanes : (int)ctx->slots.size() - 1)
+                            : 0;
+    if (n_lanes > 0)
+    {
+        // Four or more pairs in flight: their KERNELS are dealt round-robin to a few streams of the context ("lanes")
+        // instead of one stream per slot.  Measured (tools/gpu_streams_sweep.py, tools/gpu_lanes_sweep.py, KITTI pair): one
+        // stream per slot gives 2010 / 2540 / 2800 pairs/s for 1 / 2 / 3 slots and then DROPS (2500 at 4 slots, 2700 at 5;
+        // GPU_MAX_HW_QUEUES and stream priorities do not change that); three lanes give 2850-2880 for 4 ... 12 slots, four
+        // lanes 2920-2945 for 5 ... 16 slots, five and six lanes less.  Everything else a slot does (uploads, fetch copies,
+        // the later stages) stays on its own stream: ebvo_stereo_wait hands the slot back to it once the host has seen
+        // the pair complete, and the only work a slot can leave pending there -- the copies of ebvo_stereo_fetch_begin --
+        // carries an event.
+        while ((int)ctx->lane_streams.size() < n_lanes)
+        {
+            hipStream_t st = nullptr;
+            EBVO_HIP(ctx, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+            ctx->lane_streams.push_back(st);
+        }
+        hipStream_t lane = ctx->lane_streams[ctx->submit_seq++ % (uint64_t)n_lanes];
+        s.stream = lane;
+    }
+    if (fetch_was_pending) // result copies of the previous pair (on the copy stream) still read the buffers
+        EBVO_HIP(ctx, hipStreamWaitEvent(s.stream, s.ev_rebind, 0));
+    struct Unbind // a submission that fails leaves the slot on its own stream
+    {
+        Slot &s;
+        ~Unbind()
+        {
+            if (!s.in_flight)
+                s.stream = s.own_stream;
+        }
+    } unbind{s};
     {
         int64_t want = s.pipe_cap > 0 ? s.pipe_cap : 8 * (int64_t)ctx->cap_edges;
         if (want < 4096)
@@ -1024,17 +1087,23 @@ extern "C" int ebvo_stereo_wait(ebvo_ctx *ctx, int slot, ebvo_stereo_counts *cou
     struct Restore
     {
         Slot &s;
-        ~Restore() { s.prof_now = true; } // host-buffer calls on this slot are always bracketed
+        ~Restore()
+        {
+            s.prof_now = true; // host-buffer calls on this slot are always bracketed
+            if (!s.in_flight)
+                s.stream = s.own_stream; // the pair ran on a lane (ebvo_stereo_submit); the host has seen it complete
+        }
     } restore{s};
     bool have_result = false;
     const int max_attempts = ctx->wait_attempts > 0 ? ctx->wait_attempts : 4;
     for (int attempt = 0; attempt < max_attempts; ++attempt)
     {
-        hipError_t e = hipStreamSynchronize(s.stream);
+        // the event behind this pair's last kernel, not the stream: a lane may already hold the next pair of another slot
+        hipError_t e = hipEventSynchronize(s.ev_done);
         if (e != hipSuccess)
         {
             s.in_flight = false;
-            return ebvo_fail_hip(ctx, e, "hipStreamSynchronize", __FILE__, __LINE__);
+            return ebvo_fail_hip(ctx, e, "hipEventSynchronize", __FILE__, __LINE__);
         }
         const PairResult r = *s.h_result;
         if (r.n_total_left > ctx->cap_edges || r.n_total_right > ctx->cap_edges)
@@ -1067,7 +1136,7 @@ extern "C" int ebvo_stereo_wait(ebvo_ctx *ctx, int slot, ebvo_stereo_counts *cou
     {
         // every attempt reported an overflow: the last re-enqueued matching half is still running; never publish a
         // stale s.result
-        (void)hipStreamSynchronize(s.stream);
+        (void)hipEventSynchronize(s.ev_done);
         s.in_flight = false;
         ctx->last_error = "candidate buffers still too small after regrowing (ebvo_stereo_wait gave up)";
         return EBVO_ERR_CAPACITY;
@@ -1314,6 +1383,8 @@ extern "C" int ebvo_stereo_refine(ebvo_ctx *ctx, int slot, const ebvo_gn_params 
     if (!s.have_run || s.in_flight)
         return EBVO_ERR_STATE;
     EBVO_HIP(ctx, hipSetDevice(ctx->device));
+    if (int rc_f = drain_fetch(ctx, s))
+        return rc_f;
     const int64_t np = s.result.n_pairs;
     s.have_refined = false;
     if (np == 0)
@@ -1397,6 +1468,8 @@ extern "C" int ebvo_stereo_finalize(ebvo_ctx *ctx, int slot, const ebvo_finalize
     if (!s.have_run || s.in_flight)
         return EBVO_ERR_STATE;
     EBVO_HIP(ctx, hipSetDevice(ctx->device));
+    if (int rc_f = drain_fetch(ctx, s))
+        return rc_f;
     memset(counts, 0, sizeof *counts);
     s.have_final = s.have_refined = false; // the refinement buffers are reused
     s.tq_n = -1;
@@ -1782,6 +1855,8 @@ extern "C" int ebvo_temporal_set_keyframe(ebvo_ctx *ctx, int slot)
     if (!s.have_final || s.in_flight)
         return EBVO_ERR_STATE;
     EBVO_HIP(ctx, hipSetDevice(ctx->device));
+    if (int rc_f = drain_fetch(ctx, s))
+        return rc_f;
     const size_t n = (size_t)s.n_final;
     if (n > ctx->kf_cap)
     {
@@ -1830,6 +1905,8 @@ extern "C" int ebvo_temporal_match(ebvo_ctx *ctx, int slot, const ebvo_temporal_
     if (!s.have_final || s.in_flight || ctx->kf_n < 0)
         return EBVO_ERR_STATE;
     EBVO_HIP(ctx, hipSetDevice(ctx->device));
+    if (int rc_f = drain_fetch(ctx, s))
+        return rc_f;
     memset(counts, 0, sizeof *counts);
     const int n_kf = ctx->kf_n, n_cf = s.n_final, h = s.cur_h, w = s.cur_w;
     counts->n_kf = n_kf;
@@ -1951,7 +2028,7 @@ extern "C" int ebvo_stereo_fetch_begin(ebvo_ctx *ctx, int slot, int what)
     if (total > s.h_arena_bytes)
     {
         if (s.fetch_pending)
-            EBVO_HIP(ctx, hipStreamSynchronize(s.stream));
+            EBVO_HIP(ctx, hipEventSynchronize(s.ev_rebind));
         if (s.h_arena)
             (void)hipHostFree(s.h_arena);
         s.h_arena = nullptr;
@@ -1967,9 +2044,15 @@ extern "C" int ebvo_stereo_fetch_begin(ebvo_ctx *ctx, int slot, int what)
     }
     const void *src[7] = {s.im[0].edges, s.im[1].edges, s.row_ptr.p, s.col_idx.p, s.sims.p, s.best.p, s.keep.p};
     char *base = static_cast<char *>(s.h_arena);
+    // One copy stream for all slots: the pair is complete (the host has waited for it), so the copies need no ordering
+    // against kernels, and on a stream of their own they never sit in front of another pair's kernels in a hardware queue.
+    // The event marks the end of THIS slot's copies for ebvo_stereo_fetch_end and for the slot's next submission.
+    if (!ctx->copy_stream)
+        EBVO_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
     for (int k = 0; k < 7; ++k)
         if (sizes[k])
-            EBVO_HIP(ctx, hipMemcpyAsync(base + s.fetch_off[k], src[k], sizes[k], hipMemcpyDeviceToHost, s.stream));
+            EBVO_HIP(ctx, hipMemcpyAsync(base + s.fetch_off[k], src[k], sizes[k], hipMemcpyDeviceToHost, ctx->copy_stream));
+    EBVO_HIP(ctx, hipEventRecord(s.ev_rebind, ctx->copy_stream));
     s.fetch_what = what;
     s.fetch_pending = true;
     return EBVO_OK;
@@ -1985,7 +2068,7 @@ extern "C" int ebvo_stereo_fetch_end(ebvo_ctx *ctx, int slot, ebvo_stereo_view *
         return EBVO_ERR_STATE;
     EBVO_HIP(ctx, hipSetDevice(ctx->device));
     if (s.fetch_pending)
-        EBVO_HIP(ctx, hipStreamSynchronize(s.stream));
+        EBVO_HIP(ctx, hipEventSynchronize(s.ev_rebind));
     s.fetch_pending = false;
     const char *base = static_cast<const char *>(s.h_arena);
     const int what = s.fetch_what;
@@ -2066,6 +2149,8 @@ extern "C" int ebvo_debug_set(ebvo_ctx *ctx, int key, int value)
         ctx->wait_attempts = value;
     else if (key == 1)
         ctx->force_overflow = value;
+    else if (key == 2)
+        ctx->lanes = value; // 0 = one stream per slot whatever their number
     else
         return EBVO_ERR_ARG;
     return EBVO_OK;

@@ -106,7 +106,10 @@ constexpr int EBVO_MATCH_PARTS = 4096; // most blocks ncc_banked_kernel is launc
 // Everything that belongs to one HIP stream: a stereo pair in flight (or the workspace of a host-buffer call).
 struct Slot
 {
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;     // the stream the slot's work is enqueued on: its own, or a lane (ebvo_stereo_submit)
+    hipStream_t own_stream = nullptr; // created with the slot
+    hipEvent_t ev_done = nullptr;     // recorded behind the last kernel of a submitted pair
+    hipEvent_t ev_rebind = nullptr;   // orders a slot's earlier work before its first work on another lane
     ImageWS im[2];
     int cur_h = 0, cur_w = 0;
     bool have_pair = false, have_run = false, in_flight = false, have_refined = false;
@@ -164,6 +167,10 @@ struct ebvo_ctx
     size_t kf_cap = 0;
     bool undist_on = false;    // ebvo_stereo_set_undistort
     ebvo_undistort_params undist{};
+    int lanes = 4;             // streams the kernels of submitted pairs are dealt to from four slots on (ebvo_stereo_submit)
+    uint64_t submit_seq = 0;
+    std::vector<hipStream_t> lane_streams; // created on first use, owned by the context
+    hipStream_t copy_stream = nullptr;     // result copies of ebvo_stereo_fetch_begin (all slots), created on first use
     int wait_attempts = 0;     // test hook (ebvo_debug_set): attempts of ebvo_stereo_wait's regrow loop, 0 = default (4)
     int force_overflow = 0;    // test hook: treat the next N results as overflowed
 

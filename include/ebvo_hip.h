@@ -512,7 +512,10 @@ int ebvo_profile_reset(ebvo_ctx *ctx);
 int ebvo_profile_get(ebvo_ctx *ctx, ebvo_kernel_time *out /* EBVO_MAX_KERNELS */, int *n);
 
 /* Test hooks, not part of the drop-in surface.  key 0: attempts of the regrow loop of ebvo_stereo_wait (0 = default 4);
- * key 1: treat the next `value` pair results as "candidate buffers overflowed" (exercises the regrow / give-up path). */
+ * key 1: treat the next `value` pair results as "candidate buffers overflowed" (exercises the regrow / give-up path);
+ * key 2: lanes -- from four slots on, ebvo_stereo_submit deals the kernels of the pairs round-robin to
+ *        min(lanes, slots - 1) streams of the context instead of one stream per slot (default 4, the measured optimum
+ *        on MI355X; 0 = one stream per slot whatever their number). */
 int ebvo_debug_set(ebvo_ctx *ctx, int key, int value);
 
 /* Raw FP64 vector-ALU microbenchmark (mul + add, no FMA) used to anchor the compute roofline:

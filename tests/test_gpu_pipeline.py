@@ -114,6 +114,36 @@ def test_slots_overlap_and_agree(ctx):
         assert_edges_equal(ok["left"], ref["left"])
 
 
+def test_more_slots_than_lanes_agree_with_lone_runs():
+    """Five pairs in flight: the pairs are dealt to three streams (lanes) and a slot changes its stream from one
+    submission to the next; uploads, results and the pinned-copy fetch of every slot stay in order."""
+    from edge_based_visual_odometry_amd.api import Context
+    p_shapes = (120, 200)
+    with Context(*p_shapes) as c5, Context(*p_shapes) as lone:
+        c5.set_slots(5)
+        p = c5.default_params(F_KITTI)
+        for rnd in range(3):                       # the slot -> lane assignment rotates: 5 slots, 3 lanes
+            pairs = [synth.stereo_pair("s2", 120, 200, scene=3 + 5 * rnd + k, noise_base=7 * k + rnd) for k in range(5)]
+            for k, (l, r) in enumerate(pairs):
+                c5.stereo_upload(l, r, slot=k)
+                c5.stereo_submit(p, slot=k)
+            for k in (2, 0, 4, 1, 3):              # waits in another order than the submissions
+                ck = c5.stereo_wait(slot=k)
+                out = c5.stereo_fetch(ck, slot=k)
+                c5.stereo_fetch_begin(slot=k)
+                views = c5.stereo_fetch_end(slot=k)
+                lone.stereo_upload(*pairs[k])
+                c = lone.stereo_run(p)
+                ref = lone.stereo_fetch(c)
+                assert (ck.n_left, ck.n_right, ck.n_pairs, ck.n_matches) == (c.n_left, c.n_right, c.n_pairs, c.n_matches)
+                for key in ("row_ptr", "col_idx", "sims", "best", "keep"):
+                    assert_bit_equal(out[key], ref[key], f"round {rnd} slot {k} {key}")
+                assert_edges_equal(out["left"], ref["left"])
+                assert_edges_equal(out["right"], ref["right"])
+                assert_bit_equal(np.asarray(views["col_idx"]), ref["col_idx"], "pinned col_idx")
+                assert_bit_equal(np.asarray(views["best"]), ref["best"], "pinned best")
+
+
 def test_pipeline_grows_pair_buffers_on_overflow():
     """More candidates than the pair-indexed buffers hold: the library grows them and redoes the matching half."""
     from edge_based_visual_odometry_amd.api import Context

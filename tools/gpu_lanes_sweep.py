@@ -1,0 +1,32 @@
+"""Throughput of the resident loop against (pairs in flight : lanes), lanes = streams the pairs are dealt to.
+usage: gpu_lanes_sweep.py [slots:lanes ...]   (default: 8 slots, 1..6 lanes)"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from edge_based_visual_odometry_amd import synth
+from edge_based_visual_odometry_amd.api import Context
+
+h, w = synth.SHAPES["kitti"]
+F = synth.fundamental_for("kitti")
+l, r = synth.stereo_pair("s2", h, w)
+N = 240
+combos = [(int(a), int(b)) for a, b in (x.split(":") for x in sys.argv[1:])] or [(8, k) for k in (1, 2, 3, 4, 5, 6)]
+for S, lanes in combos:
+    with Context(h, w, toed_mode="hybrid") as c:
+        c.set_slots(S)
+        c.debug_set(2, lanes)
+        p = c.default_params(F)
+        for k in range(S):
+            c.stereo_upload(l, r, slot=k)
+            for _ in range(2):
+                c.stereo_submit(p, slot=k); c.stereo_wait(slot=k)
+        t0 = time.perf_counter()
+        sub = done = 0
+        while sub < S:
+            c.stereo_submit(p, slot=sub % S); sub += 1
+        while done < N:
+            k = done % S
+            c.stereo_wait(slot=k); done += 1
+            if sub < N:
+                c.stereo_submit(p, slot=k); sub += 1
+        dt = time.perf_counter() - t0
+        print(f"lanes {lanes} ({S} slots): {N / dt:8.1f} pairs/s  {dt / N * 1e3:6.3f} ms/pair", flush=True)

@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256) void k(double *out, double b)
             if (t < N)
             {
                 if (KIND == 1)
-                    asm volatile("s_add_u32 %0, %0, 1" : "+s"(sacc));
+                    asm volatile("s_add_u32 %0, %0, 1" : "+s"(sacc)::"scc");
                 if (KIND == 2)
                     asm volatile("ds_read_b128 %0, %1" : "=v"(sink) : "v"(addr));
                 if (KIND == 3)
