@@ -39,6 +39,8 @@ from edge_based_visual_odometry_amd.api import Context  # noqa: E402
 TOED_FLOPS_PER_PX = 37044            # 1,372 taps x 9 responses x 3 flops, as written in the reference
 HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: HBM3E spec
 FP64_VALU_PEAK_NOFMA_TF = 39.3       # 78.6 TFLOP/s vendor FP64 vector peak (FMA) / 2: mul and add are separate ops
+FP64_VALU_SUSTAINED_FRAC = 4.0 / 4.7 # measured: a pure v_mul_f64 / v_add_f64 stream issues one wave instruction per 4.7
+                                     # nominal cycles and SIMD, not per 4 (tools/ubench/bank_conflict.hip)
 
 WORKLOADS = {
     # BASELINE.json configs[1] (the headline), configs[2] shape / calibration, configs[3] shape / calibration
@@ -544,6 +546,8 @@ def main():
                                        "peak": fp64_peak, "unit": "TFLOP/s", "frac": tf / fp64_peak,
                                        "ops_per_launch": ops, "executed_ops_per_launch": executed,
                                        "executed_frac": executed / dom_avg_s / 1e12 / fp64_peak,
+                                       "peak_sustained_measured": fp64_peak * FP64_VALU_SUSTAINED_FRAC,
+                                       "frac_of_sustained": executed / dom_avg_s / 1e12 / (fp64_peak * FP64_VALU_SUSTAINED_FRAC),
                                        "note": ops_note + "; peak = 78.6 TFLOP/s vendor FP64 vector (FMA), halved where mul "
                                                           "and add must stay separate operations"}
         if legs is not None:

@@ -1929,12 +1929,11 @@ extern "C" int ebvo_temporal_match(ebvo_ctx *ctx, int slot, const ebvo_temporal_
     final_mates(s, &cfL, &cfR);
     const int cell = p->cell_size, gw = (w + cell - 1) / cell, gh = (h + cell - 1) / cell;
     const int sr = (int)ceil(p->grid_radius / cell);
-    if ((rc = ebvo_grow(ctx, s, s.tq_cells, match_temporal_cells_bytes(n_cf) + match_temporal_boxes_bytes(n_cf) + 64)))
+    if ((rc = ebvo_grow(ctx, s, s.tq_cells, match_temporal_grid_bytes(n_cf, gw * gh))))
         return rc;
-    void *cells = s.tq_cells.p;
-    void *boxes = (char *)cells + ((match_temporal_cells_bytes(n_cf) + 63) & ~(size_t)63);
-    if ((rc = match_temporal_cells_enqueue(ctx, s, cfL, cfR, n_cf, cell, gw, gh, cells, boxes)) ||
-        (rc = match_temporal_candidates_enqueue(ctx, s, ctx->kf_L, ctx->kf_R, n_kf, cfL, cfR, cells, boxes, n_cf, cell, sr, gw, gh,
+    void *grid = s.tq_cells.p;
+    if ((rc = match_temporal_cells_enqueue(ctx, s, cfL, cfR, n_cf, cell, gw, gh, grid)) ||
+        (rc = match_temporal_candidates_enqueue(ctx, s, ctx->kf_L, ctx->kf_R, n_kf, cfL, cfR, grid, n_cf, cell, sr, gw, gh,
                                                 p->orient_thr_deg, cnt, nullptr, nullptr, 0)) ||
         (rc = ebvo_device_scan(ctx, s, cnt, rp, n_kf, nullptr, 1, n_kf + 1)))
         return rc;
@@ -1955,7 +1954,7 @@ extern "C" int ebvo_temporal_match(ebvo_ctx *ctx, int slot, const ebvo_temporal_
     uint8_t *flagR = (uint8_t *)s.tq_u8.p, *keep = flagR + ((2 * ncz + 63) & ~(size_t)63);
     float *cfLn = (float *)s.patches_norm.p, *cfRn = (float *)s.patches_raw.p;
     uint8_t *cfLf = (uint8_t *)s.patches_flag.p;
-    if ((rc = match_temporal_candidates_enqueue(ctx, s, ctx->kf_L, ctx->kf_R, n_kf, cfL, cfR, cells, boxes, n_cf, cell, sr, gw, gh,
+    if ((rc = match_temporal_candidates_enqueue(ctx, s, ctx->kf_L, ctx->kf_R, n_kf, cfL, cfR, grid, n_cf, cell, sr, gw, gh,
                                                 p->orient_thr_deg, nullptr, rp, col, nq)) ||
         (rc = match_expand_rows_enqueue(ctx, s, rp, n_kf, nq, quad_kf)) ||
         (rc = match_patches_enqueue(ctx, s, ncc_img(s, 0), h, w, w, cfL, n_cf, nullptr, 0, nullptr, cfLn, cfLf)) ||

@@ -244,13 +244,12 @@ size_t match_right_bank_bytes(int cap_edges);
 int match_pair_result_enqueue(ebvo_ctx *ctx, Slot &s);
 // temporal quads (Temporal_Matches): cells + chunk boxes of the current-frame mates, candidate count / fill, indexed NCC
 int match_temporal_cells_enqueue(ebvo_ctx *ctx, Slot &s, const ebvo_edge *d_cfL, const ebvo_edge *d_cfR, int n_cf, int cell, int gw,
-                                 int gh, void *d_cells, void *d_boxes);
-size_t match_temporal_cells_bytes(int n_cf);
-size_t match_temporal_boxes_bytes(int n_cf);
+                                 int gh, void *d_grid);
+size_t match_temporal_grid_bytes(int n_cf, int n_cells);
 int match_temporal_candidates_enqueue(ebvo_ctx *ctx, Slot &s, const ebvo_edge *d_kfL, const ebvo_edge *d_kfR, int n_kf,
-                                      const ebvo_edge *d_cfL, const ebvo_edge *d_cfR, const void *d_cells, const void *d_boxes,
-                                      int n_cf, int cell, int sr, int gw, int gh, double orient_thr, int32_t *d_cnt,
-                                      const int32_t *d_row_ptr, int32_t *d_col_idx, int64_t cap);
+                                      const ebvo_edge *d_cfL, const ebvo_edge *d_cfR, const void *d_grid, int n_cf, int cell,
+                                      int sr, int gw, int gh, double orient_thr, int32_t *d_cnt, const int32_t *d_row_ptr,
+                                      int32_t *d_col_idx, int64_t cap);
 int match_count_flags_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_flags, int64_t n, unsigned long long *d_out);
 int match_ncc_quads_indexed_enqueue(ebvo_ctx *ctx, Slot &s, const float *kfLn, const uint8_t *kfLf, const float *kfRn,
                                     const uint8_t *kfRf, const float *cfLn, const uint8_t *cfLf, const float *cfRn,

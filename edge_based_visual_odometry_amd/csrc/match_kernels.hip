@@ -1310,19 +1310,17 @@ __global__ __launch_bounds__(256, WPE) void ncc_tile_kernel(const uint8_t *__res
 // keyframe stereo mate, which current-frame mates are candidates: the mate's LEFT edge lies in a grid cell (15 px,
 // include/definitions.h:45) within +-ceil(30 / 15) cells of the keyframe mate's left edge, its RIGHT edge likewise
 // relative to the keyframe mate's right edge (SpatialGrid::getCandidatesWithinRadius, include/Dataset.h:92-113: whole
-// cells, no distance test), and both orientation differences pass the 10-degree test.  An integer predicate on four
-// cell coordinates + two angle tests: mates are summarised in chunks of 64 by the bounding box of their cells (the
-// final mates are in raster order of their left edge, so nearly all chunks are rejected by one box test); a thread
-// owns one keyframe mate.  Candidates come out in ascending current-frame mate index.
+// cells, no distance test), and both orientation differences pass the 10-degree test.
+// The reference's two SpatialGrids become one CSR grid over the LEFT cells (mates of a cell in ascending index, the order
+// in which the reference inserts them); a thread owns one keyframe mate and walks the (2 sr + 1)^2 neighbour cells in
+// the reference's order (dy outer, dx inner): the candidates of a row come out in exactly the order of
+// `left_candidates` (src/Temporal_Matches.cpp:352, :357), the right-grid membership is the cell test on the mate's right
+// edge.  ~25 cells x ~40 mates per query instead of every mate of the five cell rows (the mates are in raster order:
+// index ranges are narrow in y but span the image in x).
 struct MateCells
 {
     short lx, ly, rx, ry; // -30000: the edge is outside the grid and is never returned by a query
 };
-struct CellBox
-{
-    short lo[4], hi[4];
-};
-constexpr int TCHUNK = 64;
 
 __device__ inline short cell_of(double v, int cell, int n_cells)
 {
@@ -1330,51 +1328,90 @@ __device__ inline short cell_of(double v, int cell, int n_cells)
     return (c >= 0 && c < n_cells) ? (short)c : (short)-30000;
 }
 
-__global__ void mate_cells_kernel(const ebvo_edge *__restrict__ L, const ebvo_edge *__restrict__ R, int n, int cell, int gw,
-                                  int gh, MateCells *__restrict__ out, CellBox *__restrict__ boxes)
+// cells of every current-frame mate + the population of the left cells
+__global__ __launch_bounds__(256) void mate_cells_kernel(const ebvo_edge *__restrict__ L, const ebvo_edge *__restrict__ R, int n,
+                                                         int cell, int gw, int gh, MateCells *__restrict__ out,
+                                                         int32_t *__restrict__ cell_cnt)
 {
-    // one wave per chunk of 64 mates: cells + the chunk's box
-    const int lane = threadIdx.x & 63;
-    const int nchunks = (n + TCHUNK - 1) / TCHUNK;
-    for (int ch = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); ch < nchunks; ch += gridDim.x * (blockDim.x >> 6))
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x)
     {
-        const int j = ch * TCHUNK + lane;
-        int v[4] = {30000, 30000, 30000, 30000}, u[4] = {-30000, -30000, -30000, -30000};
-        if (j < n)
+        MateCells m;
+        m.lx = cell_of(L[j].x, cell, gw);
+        m.ly = cell_of(L[j].y, cell, gh);
+        m.rx = cell_of(R[j].x, cell, gw);
+        m.ry = cell_of(R[j].y, cell, gh);
+        // a mate is in the left grid only if BOTH left cells are inside (src/Temporal_Matches.cpp:31-34), same on the right
+        if (m.lx < 0 || m.ly < 0)
+            m.lx = m.ly = -30000;
+        if (m.rx < 0 || m.ry < 0)
+            m.rx = m.ry = -30000;
+        out[j] = m;
+        if (m.lx >= 0)
+            atomicAdd(&cell_cnt[m.ly * gw + m.lx], 1);
+    }
+}
+
+// exclusive scan of the cell populations (one block; a grid has a few thousand cells) -> cell_start[0 .. n_cells]
+__global__ __launch_bounds__(256) void cell_scan_kernel(const int32_t *__restrict__ cnt, int n_cells, int32_t *__restrict__ start)
+{
+    __shared__ int32_t part[256];
+    const int per = (n_cells + 255) / 256;
+    const int beg = min(n_cells, (int)threadIdx.x * per), end = min(n_cells, beg + per);
+    int32_t sum = 0;
+    for (int c = beg; c < end; ++c)
+        sum += cnt[c];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        int32_t run = 0;
+        for (int t = 0; t < 256; ++t)
         {
-            MateCells m;
-            m.lx = cell_of(L[j].x, cell, gw);
-            m.ly = cell_of(L[j].y, cell, gh);
-            m.rx = cell_of(R[j].x, cell, gw);
-            m.ry = cell_of(R[j].y, cell, gh);
-            // a mate is in the left grid only if BOTH left cells are inside (src/Temporal_Matches.cpp:31-34), same on the right
-            if (m.lx < 0 || m.ly < 0)
-                m.lx = m.ly = -30000;
-            if (m.rx < 0 || m.ry < 0)
-                m.rx = m.ry = -30000;
-            out[j] = m;
-            v[0] = u[0] = m.lx;
-            v[1] = u[1] = m.ly;
-            v[2] = u[2] = m.rx;
-            v[3] = u[3] = m.ry;
+            const int32_t v = part[t];
+            part[t] = run;
+            run += v;
         }
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            for (int d = 32; d > 0; d >>= 1)
-            {
-                v[q] = min(v[q], __shfl_xor(v[q], d));
-                u[q] = max(u[q], __shfl_xor(u[q], d));
-            }
-        if (lane == 0)
+        start[n_cells] = run;
+    }
+    __syncthreads();
+    int32_t run = part[threadIdx.x];
+    for (int c = beg; c < end; ++c)
+    {
+        start[c] = run;
+        run += cnt[c];
+    }
+}
+
+// mates into their cell's segment, in arrival order (sorted next)
+__global__ __launch_bounds__(256) void cell_scatter_kernel(const MateCells *__restrict__ cells, int n, int gw,
+                                                           const int32_t *__restrict__ start, int32_t *__restrict__ fill,
+                                                           int32_t *__restrict__ list)
+{
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x)
+    {
+        const MateCells m = cells[j];
+        if (m.lx < 0)
+            continue;
+        const int c = m.ly * gw + m.lx;
+        list[start[c] + atomicAdd(&fill[c], 1)] = j;
+    }
+}
+
+// every cell's segment into ascending mate index (the reference's insertion order): rank sort, one wave per cell
+__global__ __launch_bounds__(256) void cell_sort_kernel(const int32_t *__restrict__ start, int n_cells,
+                                                        const int32_t *__restrict__ list, int32_t *__restrict__ sorted)
+{
+    const int lane = threadIdx.x & 63;
+    for (int c = blockIdx.x * 4 + (threadIdx.x >> 6); c < n_cells; c += gridDim.x * 4)
+    {
+        const int a = start[c], b = start[c + 1];
+        for (int e = a + lane; e < b; e += 64)
         {
-            CellBox b;
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-            {
-                b.lo[q] = (short)v[q];
-                b.hi[q] = (short)u[q];
-            }
-            boxes[ch] = b;
+            const int32_t v = list[e];
+            int rank = 0;
+            for (int k = a; k < b; ++k)
+                rank += list[k] < v ? 1 : 0;
+            sorted[a + rank] = v; // the indices of a cell are distinct
         }
     }
 }
@@ -1393,50 +1430,52 @@ __global__ __launch_bounds__(256) void temporal_candidates_kernel(const ebvo_edg
                                                                   const ebvo_edge *__restrict__ cfL,
                                                                   const ebvo_edge *__restrict__ cfR,
                                                                   const MateCells *__restrict__ cells,
-                                                                  const CellBox *__restrict__ boxes, int n_cf, int cell, int sr,
-                                                                  int gw, int gh, double orient_thr,
-                                                                  int32_t *__restrict__ cnt, const int32_t *__restrict__ row_ptr,
+                                                                  const int32_t *__restrict__ cell_start,
+                                                                  const int32_t *__restrict__ cell_list, int cell, int sr, int gw,
+                                                                  int gh, double orient_thr, int32_t *__restrict__ cnt,
+                                                                  const int32_t *__restrict__ row_ptr,
                                                                   int32_t *__restrict__ col_idx, int64_t cap)
 {
-    const int nchunks = (n_cf + TCHUNK - 1) / TCHUNK;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_kf; i += gridDim.x * blockDim.x)
     {
         const ebvo_edge kl = kfL[i], kr = kfR[i];
         // the query cells are not clipped (include/Dataset.h:95-96); neighbour cells outside the grid hold nothing
-        const int q[4] = {(int)kl.x / cell, (int)kl.y / cell, (int)kr.x / cell, (int)kr.y / cell};
+        const int qlx = (int)kl.x / cell, qly = (int)kl.y / cell, qrx = (int)kr.x / cell, qry = (int)kr.y / cell;
         int c = 0;
         int64_t o = FILL ? row_ptr[i] : 0;
-        for (int ch = 0; ch < nchunks; ++ch)
+        for (int dy = -sr; dy <= sr; ++dy)
         {
-            const CellBox b = boxes[ch];
-            bool hit = true;
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-                hit = hit && q[t] - sr <= b.hi[t] && q[t] + sr >= b.lo[t];
-            if (!hit)
+            const int ny = qly + dy;
+            if (ny < 0 || ny >= gh)
                 continue;
-            const int jend = min(n_cf, (ch + 1) * TCHUNK);
-            for (int j = ch * TCHUNK; j < jend; ++j)
+            for (int dx = -sr; dx <= sr; ++dx)
             {
-                const MateCells m = cells[j];
-                if (abs(m.lx - q[0]) <= sr && abs(m.ly - q[1]) <= sr && abs(m.rx - q[2]) <= sr && abs(m.ry - q[3]) <= sr &&
-                    orient_close(kl.theta, cfL[j].theta, orient_thr) && orient_close(kr.theta, cfR[j].theta, orient_thr))
+                const int nx = qlx + dx;
+                if (nx < 0 || nx >= gw)
+                    continue;
+                const int a = cell_start[ny * gw + nx], b = cell_start[ny * gw + nx + 1];
+                for (int k = a; k < b; ++k)
                 {
-                    if (FILL)
+                    const int j = cell_list[k];
+                    const MateCells m = cells[j];
+                    // right_set.count(cf_idx): the mate's right edge is in a neighbour cell of the right query
+                    if (abs(m.rx - qrx) <= sr && abs(m.ry - qry) <= sr && orient_close(kl.theta, cfL[j].theta, orient_thr) &&
+                        orient_close(kr.theta, cfR[j].theta, orient_thr))
                     {
-                        if (o < cap)
-                            col_idx[o] = j;
-                        ++o;
+                        if (FILL)
+                        {
+                            if (o < cap)
+                                col_idx[o] = j;
+                            ++o;
+                        }
+                        ++c;
                     }
-                    ++c;
                 }
             }
         }
         if (!FILL)
             cnt[i] = c;
     }
-    (void)gw;
-    (void)gh;
 }
 
 // apply_NCC_filtering_quads (src/Temporal_Matches.cpp:416-469) on mates' stored patches, by index: banks of normalised
@@ -1910,39 +1949,66 @@ int match_ncc_resident_enqueue(ebvo_ctx *ctx, Slot &s, int h, int w, int cap_edg
 size_t match_right_bank_bytes(int cap_edges) { return sizeof(float) * BANK_EDGE * (size_t)cap_edges; }
 
 
-// temporal candidate search: count (FILL = false: cnt[n_kf]) or fill (row_ptr given); cells / boxes of the current-frame mates
+// temporal candidate search: the CSR grid of the current-frame mates (cells, cell_start, cell_list inside one buffer), then
+// count (FILL = false: cnt[n_kf]) or fill (row_ptr given)
+struct TemporalGrid
+{
+    MateCells *cells;
+    int32_t *cnt, *fill, *start, *list, *sorted;
+};
+static TemporalGrid temporal_grid(void *base, int n_cf, int n_cells)
+{
+    TemporalGrid g;
+    char *p = (char *)base;
+    g.cells = (MateCells *)p;
+    p += (sizeof(MateCells) * (size_t)n_cf + 63) & ~(size_t)63;
+    g.cnt = (int32_t *)p;
+    g.fill = g.cnt + n_cells;
+    g.start = g.fill + n_cells;
+    g.list = g.start + n_cells + 1;
+    g.sorted = g.list + n_cf;
+    return g;
+}
+size_t match_temporal_grid_bytes(int n_cf, int n_cells)
+{
+    return ((sizeof(MateCells) * (size_t)n_cf + 63) & ~(size_t)63) + sizeof(int32_t) * (3 * (size_t)n_cells + 1 + 2 * (size_t)n_cf) + 64;
+}
+
 int match_temporal_cells_enqueue(ebvo_ctx *ctx, Slot &s, const ebvo_edge *d_cfL, const ebvo_edge *d_cfR, int n_cf, int cell, int gw,
-                                 int gh, void *d_cells, void *d_boxes)
+                                 int gh, void *d_grid)
 {
     if (n_cf <= 0)
         return EBVO_OK;
     ProfScope ps(ctx, s, K_CAND_COUNT);
-    hipLaunchKernelGGL(mate_cells_kernel, dim3(blocks_for((n_cf + TCHUNK - 1) / TCHUNK, 4, 1024)), dim3(256), 0, s.stream, d_cfL,
-                       d_cfR, n_cf, cell, gw, gh, (MateCells *)d_cells, (CellBox *)d_boxes);
+    const int n_cells = gw * gh;
+    const TemporalGrid g = temporal_grid(d_grid, n_cf, n_cells);
+    EBVO_HIP(ctx, hipMemsetAsync(g.cnt, 0, sizeof(int32_t) * 2 * (size_t)n_cells, s.stream)); // cnt and fill
+    const unsigned nb = blocks_for(n_cf, 256, 2048);
+    hipLaunchKernelGGL(mate_cells_kernel, dim3(nb), dim3(256), 0, s.stream, d_cfL, d_cfR, n_cf, cell, gw, gh, g.cells, g.cnt);
+    hipLaunchKernelGGL(cell_scan_kernel, dim3(1), dim3(256), 0, s.stream, g.cnt, n_cells, g.start);
+    hipLaunchKernelGGL(cell_scatter_kernel, dim3(nb), dim3(256), 0, s.stream, g.cells, n_cf, gw, g.start, g.fill, g.list);
+    hipLaunchKernelGGL(cell_sort_kernel, dim3(blocks_for(n_cells, 4, 2048)), dim3(256), 0, s.stream, g.start, n_cells, g.list,
+                       g.sorted);
     EBVO_HIP(ctx, hipGetLastError());
     return EBVO_OK;
 }
 
-size_t match_temporal_cells_bytes(int n_cf) { return sizeof(MateCells) * (size_t)n_cf; }
-size_t match_temporal_boxes_bytes(int n_cf) { return sizeof(CellBox) * ((size_t)(n_cf + TCHUNK - 1) / TCHUNK + 1); }
-
 int match_temporal_candidates_enqueue(ebvo_ctx *ctx, Slot &s, const ebvo_edge *d_kfL, const ebvo_edge *d_kfR, int n_kf,
-                                      const ebvo_edge *d_cfL, const ebvo_edge *d_cfR, const void *d_cells, const void *d_boxes,
-                                      int n_cf, int cell, int sr, int gw, int gh, double orient_thr, int32_t *d_cnt,
-                                      const int32_t *d_row_ptr, int32_t *d_col_idx, int64_t cap)
+                                      const ebvo_edge *d_cfL, const ebvo_edge *d_cfR, const void *d_grid, int n_cf, int cell,
+                                      int sr, int gw, int gh, double orient_thr, int32_t *d_cnt, const int32_t *d_row_ptr,
+                                      int32_t *d_col_idx, int64_t cap)
 {
     if (n_kf <= 0)
         return EBVO_OK;
     ProfScope ps(ctx, s, d_row_ptr ? K_CAND_FILL : K_CAND_COUNT);
+    const TemporalGrid g = temporal_grid(const_cast<void *>(d_grid), n_cf, gw * gh);
     const unsigned nb = blocks_for(n_kf, 256, 4096);
     if (d_row_ptr)
         hipLaunchKernelGGL(temporal_candidates_kernel<true>, dim3(nb), dim3(256), 0, s.stream, d_kfL, d_kfR, n_kf, d_cfL, d_cfR,
-                           (const MateCells *)d_cells, (const CellBox *)d_boxes, n_cf, cell, sr, gw, gh, orient_thr, d_cnt,
-                           d_row_ptr, d_col_idx, cap);
+                           g.cells, g.start, g.sorted, cell, sr, gw, gh, orient_thr, d_cnt, d_row_ptr, d_col_idx, cap);
     else
         hipLaunchKernelGGL(temporal_candidates_kernel<false>, dim3(nb), dim3(256), 0, s.stream, d_kfL, d_kfR, n_kf, d_cfL, d_cfR,
-                           (const MateCells *)d_cells, (const CellBox *)d_boxes, n_cf, cell, sr, gw, gh, orient_thr, d_cnt,
-                           d_row_ptr, d_col_idx, cap);
+                           g.cells, g.start, g.sorted, cell, sr, gw, gh, orient_thr, d_cnt, d_row_ptr, d_col_idx, cap);
     EBVO_HIP(ctx, hipGetLastError());
     return EBVO_OK;
 }

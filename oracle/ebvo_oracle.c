@@ -1767,27 +1767,64 @@ int orc_temporal_candidates(const orc_edge *kfL, const orc_edge *kfR, int n_kf, 
 {
     const int gw = (img_w + cell - 1) / cell, gh = (img_h + cell - 1) / cell; /* SpatialGrid(img_width, img_height, cell) */
     const int sr = (int)ceil(radius / cell);
+    /* left_spatial_grids: the mates of every cell in insertion (= index) order (src/Temporal_Matches.cpp:25-40) */
+    int32_t *start = (int32_t *)calloc((size_t)gw * gh + 1, sizeof(int32_t)), *list = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n_cf + 1));
+    int32_t *cellid = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n_cf + 1));
+    if (!start || !list || !cellid)
+    {
+        free(start);
+        free(list);
+        free(cellid);
+        return -1;
+    }
+    for (int j = 0; j < n_cf; j++)
+    {
+        const int lx = (int)cfL[j].x / cell, ly = (int)cfL[j].y / cell;
+        cellid[j] = (lx >= 0 && lx < gw && ly >= 0 && ly < gh) ? ly * gw + lx : -1;
+        if (cellid[j] >= 0)
+            start[cellid[j] + 1]++;
+    }
+    for (int c = 0; c < gw * gh; c++)
+        start[c + 1] += start[c];
+    {
+        int32_t *fill = (int32_t *)calloc((size_t)gw * gh, sizeof(int32_t));
+        for (int j = 0; j < n_cf; j++)
+            if (cellid[j] >= 0)
+                list[start[cellid[j]] + fill[cellid[j]]++] = j;
+        free(fill);
+    }
     int64_t n = 0;
     for (int i = 0; i < n_kf; i++)
     {
         row_ptr[i] = (int32_t)n;
         const int qlx = (int)kfL[i].x / cell, qly = (int)kfL[i].y / cell, qrx = (int)kfR[i].x / cell, qry = (int)kfR[i].y / cell;
-        for (int j = 0; j < n_cf; j++)
-        {
-            const int lx = (int)cfL[j].x / cell, ly = (int)cfL[j].y / cell, rx = (int)cfR[j].x / cell, ry = (int)cfR[j].y / cell;
-            /* in the left grid at all? (:31-34)  in a neighbour cell of the query that exists? (Dataset.h:104-105) */
-            if (!(lx >= 0 && lx < gw && ly >= 0 && ly < gh) || !(rx >= 0 && rx < gw && ry >= 0 && ry < gh))
-                continue;
-            if (abs(lx - qlx) > sr || abs(ly - qly) > sr || abs(rx - qrx) > sr || abs(ry - qry) > sr)
-                continue;
-            if (!orient_close_deg(kfL[i].theta, cfL[j].theta, orient_thr_deg) || !orient_close_deg(kfR[i].theta, cfR[j].theta, orient_thr_deg))
-                continue;
-            if (col_idx && n < cap)
-                col_idx[n] = j;
-            n++;
-        }
+        /* getCandidatesWithinRadius (include/Dataset.h:92-113): dy outer, dx inner, cells outside the grid skipped */
+        for (int dy = -sr; dy <= sr; dy++)
+            for (int dx = -sr; dx <= sr; dx++)
+            {
+                const int nx = qlx + dx, ny = qly + dy;
+                if (!(nx >= 0 && nx < gw && ny >= 0 && ny < gh))
+                    continue;
+                for (int k = start[ny * gw + nx]; k < start[ny * gw + nx + 1]; k++)
+                {
+                    const int j = list[k];
+                    /* right_set.count(cf_idx) (:353, :358): the mate is in the right grid, in a neighbour cell of the query */
+                    const int rx = (int)cfR[j].x / cell, ry = (int)cfR[j].y / cell;
+                    if (!(rx >= 0 && rx < gw && ry >= 0 && ry < gh) || abs(rx - qrx) > sr || abs(ry - qry) > sr)
+                        continue;
+                    if (!orient_close_deg(kfL[i].theta, cfL[j].theta, orient_thr_deg) ||
+                        !orient_close_deg(kfR[i].theta, cfR[j].theta, orient_thr_deg))
+                        continue;
+                    if (col_idx && n < cap)
+                        col_idx[n] = j;
+                    n++;
+                }
+            }
     }
     row_ptr[n_kf] = (int32_t)n;
     *n_out = n;
+    free(start);
+    free(list);
+    free(cellid);
     return (col_idx && n > cap) ? -2 : 0;
 }
