@@ -20,13 +20,14 @@
 // TOED's raster order just makes the boxes tight.  The exact predicates avoid the fp64 division and
 // square root except within 2^-50 of a threshold (see pair_passes).
 //
-// NCC.  16 lanes cooperate on one (left edge, candidate) pair: lanes 0-6 hold the rows of the
-// "plus" patch, lanes 8-14 the rows of the "minus" patch (lanes 7 and 15 carry +0.0).  A 49-term
-// reduction is a left-to-right row sum in each lane followed by a 3-step xor butterfly over the
-// 8 lanes -- exactly the canonical order of the CPU path (oracle/ebvo_oracle.c: reduce49).
-// Element-wise patch arithmetic is float (CV_32F), reductions are double.
+// NCC.  A 49-term reduction is a left-to-right row sum in each lane followed by a 3-step xor butterfly over 8 lanes --
+// exactly the canonical order of the CPU path (oracle/ebvo_oracle.c: reduce49).  Element-wise patch arithmetic is float
+// (CV_32F), reductions are double.  Host-buffer calls: 16 lanes per (left edge, candidate) pair, lanes 0-6 the rows of
+// the "plus" patch, lanes 8-14 the rows of the "minus" patch (ncc_pairs_kernel).  Resident pipeline: every right edge's
+// patches are sampled and normalised once into a bank (right_bank_kernel); a wave owns four left edges, stages their
+// patches in LDS and scores their CSR pairs eight lanes per pair (ncc_tile_kernel).
 //
-// Compiled with -ffp-contract=off: no FMA anywhere.
+// Compiled with -ffp-contract=off: no FMA contraction anywhere; the explicit fma of dot7 is exact-product accumulation.
 #include <cstdlib>
 
 #include "ebvo_internal.h"
