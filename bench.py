@@ -186,6 +186,34 @@ def check_against_oracle(out, chk):
     return None
 
 
+def dropin_loop(ctx, params, pool, calib, nslots, steps):
+    """What StereoMatcherHIP::stereo_edge_pairs does per frame (include/ebvo/adapters.hpp; the one-pass body of
+    get_Stereo_Edge_Pairs, integration/stereo_matches_hip.cpp): a NEW pair uploaded from host memory, TOED + candidates +
+    NCC, then the later stages on the device with the SIFT filter (ebvo_stereo_finalize) and the final pairs + output rows
+    copied back.  `nslots` frames in flight: the stereo pair of frame k + 1 .. is submitted before frame k is finalized."""
+    t0 = time.perf_counter()
+    sub = done = 0
+    n_final = 0
+
+    def launch(k):
+        nonlocal sub
+        if sub < steps:
+            ctx.stereo_upload(*pool[sub % len(pool)], slot=k)
+            ctx.stereo_submit(params, slot=k)
+            sub += 1
+
+    for k in range(min(nslots, steps)):
+        launch(k)
+    while done < steps:
+        k = done % nslots
+        ctx.stereo_wait(slot=k)
+        fc, fin = ctx.stereo_finalize(calib, slot=k, use_sift=True)
+        n_final += fc["n_final"]
+        done += 1
+        launch(k)
+    return time.perf_counter() - t0, n_final / max(1, steps)
+
+
 def frame_loop(ctx, params, pool, nslots, steps, upload, fetch):
     """`steps` pairs with `nslots` in flight; upload: a NEW pair from host memory per step; fetch: None, or the selection
     (ebvo_hip.h EBVO_FETCH_*) copied back through the slot's page-locked staging (ebvo_stereo_fetch_begin / _end: the copy
@@ -452,6 +480,13 @@ def main():
         t_def, mb_def = frame_loop(ctx, params, pool, nslots, n_leg, True, L_.FETCH_DEFAULT)
         t_all, mb_all = frame_loop(ctx, params, pool, nslots, n_leg, True, L_.FETCH_ALL)
         t_pg, mb_pg = frame_loop(ctx, params, pool, nslots, max(nslots, n_leg // 3), True, "pageable")
+        # the one-pass drop-in: get_Stereo_Edge_Pairs as a frame loop calls it through StereoMatcherHIP::stereo_edge_pairs
+        cal = synth.CALIB[wl["cfg"]]
+        calib = ([cal["K"][0], 0, cal["K"][2], 0, cal["K"][1], cal["K"][3], 0, 0, 1],
+                 [cal["K_right"][0], 0, cal["K_right"][2], 0, cal["K_right"][1], cal["K_right"][3], 0, 0, 1], cal["R21"], cal["T21"])
+        n_drop = max(nslots, min(args.steps, 24))
+        dropin_loop(ctx, params, pool, calib, min(nslots, 3), min(nslots, 3))                 # untimed: sizes the chain's buffers
+        t_drop, final_per_pair = dropin_loop(ctx, params, pool, calib, min(nslots, 3), n_drop)
         # the drop-in path: what main_VO executes through integration/*.cpp -- host-buffer entry points, results in host
         # arrays, one call after the other (src/Pipeline.cpp:24-29, :109-145): TOED of both images, epipolar lines,
         # candidate search (the three geometric stages in one call), NCC with left patches
@@ -464,7 +499,12 @@ def main():
             rp_b, ci_b = ctx.epi_candidates(eL, eR, lines_b)
             ctx.ncc_pairs(bl, br, eL, eR[ci_b], rp_b, want_left_patches=True)
         t_b = (time.perf_counter() - tb) / n_b
-        legs = {"boundary_pairs_per_s": 1.0 / t_b,
+        legs = {"dropin_final_pairs_per_s": n_drop / t_drop, "dropin_final_pairs_per_frame": final_per_pair,
+                "dropin_note": "get_Stereo_Edge_Pairs in one pass (StereoMatcherHIP::stereo_edge_pairs): a new pair from host "
+                               "memory per frame, TOED + candidates + NCC, SIFT filter, both Best-Nearly-Best tests, shift, "
+                               "photometric refinement, clustering, second NCC pass, best per row; final pairs + output rows "
+                               "copied back; the stereo pairs of up to three frames in flight",
+                "boundary_pairs_per_s": 1.0 / t_b,
                 "boundary_note": "the stage-wise drop-in sequence through the host-buffer C entry points (ebvo_toed_pair, "
                                  "ebvo_epipolar_lines, ebvo_epi_candidates with all three stages, ebvo_ncc_pairs with left "
                                  "patches), every input and output in pageable host arrays, no overlap between calls",

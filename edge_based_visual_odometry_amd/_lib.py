@@ -36,7 +36,7 @@ ABI_SYMBOLS = (
     "ebvo_strerror", "ebvo_last_error", "ebvo_abi_version", "ebvo_ctx_create", "ebvo_ctx_destroy",
     "ebvo_set_toed_mode", "ebvo_get_toed_mode", "ebvo_toed_stats",
     "ebvo_toed", "ebvo_toed_pair", "ebvo_epipolar_lines", "ebvo_epi_candidates", "ebvo_ncc_pairs",
-    "ebvo_edge_patches", "ebvo_ncc_patches", "ebvo_ncc_quads", "ebvo_stereo_default_params",
+    "ebvo_edge_patches", "ebvo_ncc_patches", "ebvo_ncc_quads", "ebvo_stereo_default_params", "ebvo_finalize_default_params",
     "ebvo_stereo_upload", "ebvo_stereo_run", "ebvo_stereo_fetch", "ebvo_stereo_set_slots",
     "ebvo_stereo_upload_slot", "ebvo_stereo_submit", "ebvo_stereo_wait", "ebvo_stereo_fetch_slot", "ebvo_profile_enable",
     "ebvo_profile_reset", "ebvo_profile_get", "ebvo_fp64_peak",
@@ -148,6 +148,8 @@ def load_library() -> C.CDLL:
     lib.ebvo_ncc_patches.argtypes = [vp, vp, vp, i32, vp]
     lib.ebvo_ncc_quads.argtypes = [vp, vp, vp, vp, vp, i32, dbl, vp, vp, vp]
     lib.ebvo_stereo_default_params.restype = None
+    lib.ebvo_finalize_default_params.restype = None
+    lib.ebvo_finalize_default_params.argtypes = [C.c_void_p]
     lib.ebvo_stereo_default_params.argtypes = [C.POINTER(StereoParams)]
     lib.ebvo_stereo_upload.argtypes = [vp, vp, vp, i32, i32, ssz, ssz]
     lib.ebvo_stereo_run.argtypes = [vp, C.POINTER(StereoParams), C.POINTER(StereoCounts)]

@@ -883,6 +883,19 @@ extern "C" void ebvo_stereo_default_params(ebvo_stereo_params *p)
     p->stage_mask = EBVO_STAGE_ALL;
 }
 
+extern "C" void ebvo_finalize_default_params(ebvo_finalize_params *p)
+{
+    if (!p)
+        return;
+    memset(p, 0, sizeof *p);
+    p->bnb_ratio = EBVO_BNB_NCC;
+    p->ncc_thr = EBVO_NCC_THRESH;
+    ebvo_gn_default_params(&p->gn);
+    p->use_sift = 0;
+    p->sift_thr = EBVO_SIFT_THRESHOLD;
+    p->bnb_sift = EBVO_BNB_SIFT;
+}
+
 static int get_slot(ebvo_ctx *ctx, int slot, Slot **out)
 {
     if (!ctx || slot < 0 || slot >= (int)ctx->slots.size())

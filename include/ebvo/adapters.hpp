@@ -28,6 +28,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <fstream>
+#include <cstring>
 #include <memory>
 #include <string>
 #include <utility>
@@ -372,6 +373,66 @@ class StereoMatcherHIP
                                               init_disp.data(), (int)n, &p, r.disp.data(), r.score.data(),
                                               r.validity.data(), r.iters.data());
         report(*ctx_, last_status, "ebvo_gn_refine_temporal");
+        return r;
+    }
+
+    // Stereo_Matches::get_Stereo_Edge_Pairs (src/Stereo_Matches.cpp:1360-1540) for one frame in ONE pass over the device:
+    // both TOED runs, the three geometric filters, [SIFT filter,] NCC, both Best-Nearly-Best tests, epipolar shift,
+    // photometric refinement, shift + clustering, second NCC pass, best candidate per row -- images up, final pairs down,
+    // every intermediate list stays in HBM (ebvo_stereo_upload_slot / submit / wait / finalize / fetch_final).  This is the
+    // path a frame loop takes when it does not inspect the intermediate `matching_edge_clusters` between the stages; the
+    // stage-wise calls above remain for a caller that does.
+    struct FinalPairs
+    {
+        ebvo_stereo_counts stage1{};   // TOED edges, candidate pairs after the geometric filters, NCC matches
+        ebvo_finalize_counts stages{}; // survivors of the later stages
+        std::vector<ebvo_edge> left_edges;  // all kept TOED edges of the left image (stereo_frame->left_edges)
+        std::vector<int32_t> left_index;    // per final pair: index into left_edges
+        std::vector<ebvo_edge> right;       // per final pair: the matched right edge (a refined cluster centre)
+        std::vector<double> ncc_score;      // per final pair
+        std::vector<double> out16;          // per final pair: the 16 numbers of the output row (if calib was given)
+    };
+    FinalPairs stereo_edge_pairs(const uint8_t *imgL, const uint8_t *imgR, int rows, int cols, ptrdiff_t stepL, ptrdiff_t stepR,
+                                 const double F21[9], const ebvo_stereo_calib *calib, bool use_sift = true, int slot = 0,
+                                 const ebvo_stereo_params *stereo = nullptr, const ebvo_finalize_params *fin = nullptr)
+    {
+        FinalPairs r;
+        ebvo_stereo_params sp;
+        if (stereo)
+            sp = *stereo;
+        else
+        {
+            ebvo_stereo_default_params(&sp);
+            std::memcpy(sp.F21, F21, sizeof sp.F21);
+        }
+        ebvo_finalize_params fp;
+        if (fin)
+            fp = *fin;
+        else
+        {
+            ebvo_finalize_default_params(&fp);
+            fp.use_sift = use_sift ? 1 : 0;
+        }
+        ebvo_ctx *c = ctx_->get();
+        if (!report(*ctx_, last_status = ebvo_stereo_upload_slot(c, slot, imgL, imgR, rows, cols, stepL, stepR),
+                    "ebvo_stereo_upload_slot") ||
+            !report(*ctx_, last_status = ebvo_stereo_submit(c, slot, &sp), "ebvo_stereo_submit") ||
+            !report(*ctx_, last_status = ebvo_stereo_wait(c, slot, &r.stage1), "ebvo_stereo_wait") ||
+            !report(*ctx_, last_status = ebvo_stereo_finalize(c, slot, &fp, calib, &r.stages), "ebvo_stereo_finalize"))
+            return r;
+        const size_t n = (size_t)r.stages.n_final;
+        r.left_edges.resize((size_t)r.stage1.n_left);
+        r.left_index.resize(n);
+        r.right.resize(n);
+        r.ncc_score.resize(n);
+        if (calib)
+            r.out16.resize(16 * n);
+        if (report(*ctx_, last_status = ebvo_stereo_fetch_slot(c, slot, r.left_edges.data(), nullptr, nullptr, nullptr, nullptr,
+                                                               nullptr, nullptr, nullptr),
+                   "ebvo_stereo_fetch_slot"))
+            report(*ctx_, last_status = ebvo_stereo_fetch_final(c, slot, r.left_index.data(), r.right.data(),
+                                                                r.ncc_score.data(), calib ? r.out16.data() : nullptr),
+                   "ebvo_stereo_fetch_final");
         return r;
     }
 

@@ -366,6 +366,7 @@ typedef struct
     int32_t n_sift;                                    /* candidates passing the SIFT filter alone (use_sift) */
 } ebvo_finalize_counts;
 
+void ebvo_finalize_default_params(ebvo_finalize_params *p); /* the reference's constants, use_sift = 0 */
 int ebvo_stereo_finalize(ebvo_ctx *ctx, int slot, const ebvo_finalize_params *params, const ebvo_stereo_calib *calib,
                          ebvo_finalize_counts *counts);
 /* n_final entries each: index of the left TOED edge, the matched right centre edge, its NCC score, and (if calib was
@@ -398,8 +399,9 @@ int ebvo_ncc_quads(ebvo_ctx *ctx, const float *kfL, const float *kfR, const floa
  * apply_orientation_filtering_quads :385-414: both orientation differences within the threshold) and
  * apply_NCC_filtering_quads (:416-469) on the mates' stored patches: left_edge_patches from the raw left image, right
  * patches from the undistorted right image at the final right edge (src/Stereo_Matches.cpp:1621-1622).
- * Mates = the final pairs of ebvo_stereo_finalize on a slot.  Candidates are listed in ascending current-frame mate
- * index (the reference lists them cell by cell; the temporal results are sets). */
+ * Mates = the final pairs of ebvo_stereo_finalize on a slot.  The candidates of a keyframe mate are listed in the order
+ * of the reference's `left_candidates`: neighbour cell by neighbour cell (dy outer, dx inner), ascending mate index
+ * within a cell (include/Dataset.h:92-113). */
 typedef struct ebvo_temporal_params
 {
     int cell_size;         /* GRID_SIZE 15, include/definitions.h:45 */

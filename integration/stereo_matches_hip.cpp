@@ -29,8 +29,10 @@ void keep_listed(Stereo_Edge_Pairs &p, const ebvo::CandidateLists &c)
         size_t j = 0;
         for (int32_t k = c.row_ptr[i]; k < c.row_ptr[i + 1]; ++k)
         {
-            while (cl[j].contributing_edges_toed_indices[0] != c.col_idx[k])
+            while (j < cl.size() && cl[j].contributing_edges_toed_indices[0] != c.col_idx[k])
                 ++j;
+            if (j == cl.size()) // the device list is a subsequence of the host list; anything else is a caller error
+                break;
             out.push_back(cl[j]);
         }
         cl = std::move(out);
@@ -393,5 +395,50 @@ void Temporal_Matches::apply_NCC_filtering_quads(std::vector<KF_Temporal_Edge_Qu
         quads_by_kf[i].candidate_quads.clear();
         for (auto &pr : candidate_cluster_pairs_[i])
             quads_by_kf[i].candidate_quads.push_back({&pr.first, &pr.second});
+    }
+}
+
+// ---- get_Stereo_Edge_Pairs in one pass over the device ---------------------------------------------------------------
+// The stage-wise bodies above keep `matching_edge_clusters` observable after every stage, at the price of moving the lists
+// between host and device each time (bench.py: boundary_pairs_per_s).  A frame loop that only consumes
+// `final_stereo_edge_pairs` calls this instead of get_Stereo_Edge_Pairs (src/Stereo_Matches.cpp:1360-1540): images up,
+// final pairs down, every intermediate list stays in HBM (bench.py: dropin_final_pairs_per_s).  The rows it fills are the
+// ones finalize_stereo_edge_mates (:1583-1635) builds; descriptors / patches of the final mates come from
+// ebvo::sift_descriptors / ebvo_edge_patches on the final edges when a later stage needs them.
+void get_Stereo_Edge_Pairs_resident(Stereo_Edge_Pairs &p, Dataset::Ptr dataset, std::vector<final_stereo_edge_pair> &final_pairs)
+{
+    const cv::Mat &imgL = p.stereo_frame->left_image, &imgR = p.stereo_frame->right_image;
+    Eigen::Matrix3d F21 = dataset->get_fund_mat_21(), Kl = dataset->get_left_calib_matrix(), Kr = dataset->get_right_calib_matrix(),
+                    R21 = dataset->get_relative_rot_left_to_right();
+    Eigen::Vector3d T21 = dataset->get_relative_transl_left_to_right();
+    double F[9];
+    ebvo_stereo_calib calib;
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c)
+        {
+            F[3 * r + c] = F21(r, c);
+            calib.K_left[3 * r + c] = Kl(r, c);
+            calib.K_right[3 * r + c] = Kr(r, c);
+            calib.R21[3 * r + c] = R21(r, c);
+        }
+    for (int r = 0; r < 3; ++r)
+        calib.T21[r] = T21(r);
+    auto m = matcher();
+    auto fp = m.stereo_edge_pairs(imgL.data, imgR.data, imgL.rows, imgL.cols, (ptrdiff_t)imgL.step, (ptrdiff_t)imgR.step, F, &calib,
+                                  /*use_sift=*/true);
+    final_pairs.clear();
+    final_pairs.reserve(fp.left_index.size());
+    for (size_t k = 0; k < fp.left_index.size(); ++k)
+    {
+        final_stereo_edge_pair fe;
+        const ebvo_edge &le = fp.left_edges[(size_t)fp.left_index[k]], &re = fp.right[k];
+        fe.left_edge.location = cv::Point2d(le.x, le.y);
+        fe.left_edge.orientation = le.theta;
+        fe.left_edge.index = le.index;
+        fe.right_edge.location = cv::Point2d(re.x, re.y);
+        fe.right_edge.orientation = re.theta;
+        // (Gamma_in_*_cam_coord of the reference's records come from the GROUND-TRUTH disparity, :186-190, and are left to
+        // the evaluation code; the triangulated point and tangent of the pair are fp.out16[16 k + 6 .. 11], the writer's row)
+        final_pairs.push_back(fe);
     }
 }

@@ -135,6 +135,17 @@ int main(int argc, char **argv)
     std::fwrite(clusters.new_count.data(), sizeof(int32_t), clusters.new_count.size(), o);
     std::fwrite(clusters.cluster_of.data(), sizeof(int32_t), clusters.cluster_of.size(), o);
     std::fwrite(bestsel.new_count.data(), sizeof(int32_t), bestsel.new_count.size(), o);
+    // get_Stereo_Edge_Pairs in one pass over the device (SIFT stages included): final pairs + output rows
+    auto fp = matcher.stereo_edge_pairs(left.data, right.data, h, w, (ptrdiff_t)left.step, (ptrdiff_t)right.step, F, &calib, true);
+    if (matcher.last_status != EBVO_OK || fp.left_edges.size() != left_edges.size())
+        return 9;
+    int32_t fh[7] = {fp.stages.n_sift, fp.stages.n_ncc, fp.stages.n_bnb, fp.stages.n_clusters, fp.stages.n_ncc2,
+                     fp.stages.n_final, (int32_t)fp.stage1.n_pairs};
+    std::fwrite(fh, sizeof fh, 1, o);
+    std::fwrite(fp.left_index.data(), sizeof(int32_t), fp.left_index.size(), o);
+    std::fwrite(fp.right.data(), sizeof(ebvo_edge), fp.right.size(), o);
+    std::fwrite(fp.ncc_score.data(), sizeof(double), fp.ncc_score.size(), o);
+    std::fwrite(fp.out16.data(), sizeof(double), fp.out16.size(), o);
     std::fclose(o);
     std::printf("adapter_demo ok: %zu + %zu edges, %zu pairs\n", left_edges.size(), right_edges.size(), cand.size());
     return 0;

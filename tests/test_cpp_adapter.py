@@ -56,7 +56,14 @@ def test_adapter_matches_oracle(tmp_path):
     shifted = np.frombuffer(buf, dtype=orc.EDGE_DTYPE, count=npairs, offset=off); off += 32 * npairs
     cl_cnt = np.frombuffer(buf, dtype=np.int32, count=nL, offset=off); off += 4 * nL
     cl_of = np.frombuffer(buf, dtype=np.int32, count=npairs, offset=off); off += 4 * npairs
-    best_cnt = np.frombuffer(buf, dtype=np.int32, count=nL, offset=off)
+    best_cnt = np.frombuffer(buf, dtype=np.int32, count=nL, offset=off); off += 4 * nL
+    fh = np.frombuffer(buf, dtype=np.int32, count=7, offset=off); off += 28
+    nf = int(fh[5])
+    f_left = np.frombuffer(buf, dtype=np.int32, count=nf, offset=off); off += 4 * nf
+    f_right = np.frombuffer(buf, dtype=orc.EDGE_DTYPE, count=nf, offset=off); off += 32 * nf
+    f_score = np.frombuffer(buf, dtype=np.float64, count=nf, offset=off); off += 8 * nf
+    f_rows = np.frombuffer(buf, dtype=np.float64, count=16 * nf, offset=off).reshape(-1, 16); off += 128 * nf
+    assert off == len(buf)
     ol, orr = orc.toed(l), orc.toed(r)
     assert (tL, tR) == (ol["n_total"], orr["n_total"])
     assert_edges_equal(L, ol["edges"])
@@ -97,3 +104,16 @@ def test_adapter_matches_oracle(tmp_path):
     assert len(text) == 1 + len(fin)
     for line, row in zip(text[1:], fin):
         assert line == " ".join("%g" % v for v in row)          # std::ostream default == printf %g
+    # StereoMatcherHIP::stereo_edge_pairs = get_Stereo_Edge_Pairs in one pass: against the chain of oracle functions
+    from tests import oracle_chain
+    stage1 = dict(l=l, r=r, F=F, left=ol["edges"], right=orr["edges"], row_ptr=orp, col_idx=oci, sims=osims, best=obest,
+                  keep=okeep)
+    ch = oracle_chain.stereo_edge_pairs(l, r, F, (K, K, np.eye(3).ravel(), [t, 0, 0]), stage1=stage1,
+                                        cluster_args=(True, False), sift=True)
+    want = ch["counts"]
+    assert dict(n_sift=int(fh[0]), n_ncc=int(fh[1]), n_bnb=int(fh[2]), n_clusters=int(fh[3]), n_ncc2=int(fh[4]),
+                n_final=int(fh[5])) == want and int(fh[6]) == len(oci) and nf > 100
+    assert_bit_equal(f_left, ch["left_index"], "left_index")
+    assert_edges_equal(f_right, ch["right"], "right centre")
+    assert_bit_equal(f_score, ch["score"], "score")
+    assert_bit_equal(f_rows, ch["rows"], "rows")
