@@ -13,11 +13,12 @@
 //   - 11 x 11 window of central differences around the rounded point, rotated into the keypoint frame (hist_width 1.5),
 //   - tri-linear accumulation into the (4 + 2) x (4 + 2) x (8 + 2) histogram IN SAMPLE ORDER (the scalar loop of
 //     calcSIFTDescriptor: float additions are not associative, so the order is part of the result).  The histogram is
-//     private to the thread and lives in LDS: hist[bin][lane], 360 x 64 floats = 90 KB per 64-thread workgroup.  Lane l
-//     only ever touches column l: whatever bins the lanes address, the 64 accesses of a wave fall on 64 different banks;
+//     private to the thread and lives in LDS: hist[bin][lane].  Only the 4 x 4 x (8 + 2) cells that reach the descriptor
+//     are stored (the border rows / columns of OpenCV's array are dropped at the end): 160 x 64 floats = 40 KB per
+//     64-thread workgroup, four workgroups per CU.  Lane l only ever touches column l: whatever bins the lanes address,
+//     the 64 accesses of a wave fall on 64 different banks;
 //   - circular orientation wrap, 0.2 clipping, x 512, round to 0 .. 255.
-// The one-wave-per-CU occupancy this costs is accepted: the alternative orders (LDS atomics, per-cell ownership) either
-// change the bits from run to run or multiply the work.
+// The alternative orders (LDS atomics, per-cell ownership) either change the bits from run to run or multiply the work.
 //
 // Compiled with -ffp-contract=off (float multiply and add stay separate, as in the oracle).
 #include "ebvo_internal.h"
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(256) void sift_blur_cols_kernel(const float *__rest
 }
 
 constexpr int SD = 4, SN = 8;                                  // SIFT_DESCR_WIDTH, SIFT_DESCR_HIST_BINS
-constexpr int SHIST = (SD + 2) * (SD + 2) * (SN + 2);          // 360
+constexpr int SHIST = SD * SD * (SN + 2);                      // 160: the cells that reach the descriptor (see the vote)
 constexpr float FLT_EPS = 1.1920928955078125e-07f;
 
 __device__ inline int cv_round_f(float v) { return (int)rintf(v); }
@@ -150,15 +151,41 @@ __global__ __launch_bounds__(64) void sift_desc_kernel(const float *__restrict__
                     const float v_rco101 = v_rc10 * obin, v_rco100 = v_rc10 - v_rco101;
                     const float v_rco011 = v_rc01 * obin, v_rco010 = v_rc01 - v_rco011;
                     const float v_rco001 = v_rc00 * obin, v_rco000 = v_rc00 - v_rco001;
-                    const int idx = ((r0 + 1) * (SD + 2) + c0 + 1) * (SN + 2) + o0;
-                    H[(idx)*64] += v_rco000;
-                    H[(idx + 1) * 64] += v_rco001;
-                    H[(idx + (SN + 2)) * 64] += v_rco010;
-                    H[(idx + (SN + 3)) * 64] += v_rco011;
-                    H[(idx + (SD + 2) * (SN + 2)) * 64] += v_rco100;
-                    H[(idx + (SD + 2) * (SN + 2) + 1) * 64] += v_rco101;
-                    H[(idx + (SD + 3) * (SN + 2)) * 64] += v_rco110;
-                    H[(idx + (SD + 3) * (SN + 2) + 1) * 64] += v_rco111;
+                    // The eight cells of the tri-linear vote, in the order of calcSIFTDescriptor.  Two things shape the
+                    // indexing.  (1) The border rows and columns of OpenCV's (d + 2) x (d + 2) histogram only collect what
+                    // falls outside the descriptor and are dropped at the end: they are not stored here (every kept cell
+                    // still receives its own addends in sample order), which leaves 4 x 4 x (8 + 2) floats per keypoint,
+                    // 40 KB per workgroup instead of 90.  (2) The reference passes orientations of -180 .. 180 degrees
+                    // where OpenCV expects 0 .. 360, so o0 can stay negative (down to -4) after the single "+= n": in
+                    // OpenCV's FLAT array such a vote lands in the upper bins of the previous cell (column - 1, or the
+                    // last column of the row above).  That aliasing is part of the reference's result and is reproduced
+                    // by the carry below; a vote in front of the array (undefined behaviour in OpenCV) is dropped, as
+                    // in the restatement (oracle/ebvo_oracle.c: calc_sift_descriptor).
+#define EBVO_SIFT_VOTE(dr, dc, dob, val)                                                                      \
+    {                                                                                                         \
+        int rr_ = r0 + dr, cc_ = c0 + dc, oo_ = o0 + dob; /* interior coordinates: -1 .. SD */                \
+        if (oo_ < 0)                                                                                          \
+        {                                                                                                     \
+            oo_ += SN + 2;                                                                                    \
+            cc_ -= 1;                                                                                         \
+            if (cc_ < -1)                                                                                     \
+            {                                                                                                 \
+                cc_ = SD;                                                                                     \
+                rr_ -= 1;                                                                                     \
+            }                                                                                                 \
+        }                                                                                                     \
+        if ((unsigned)rr_ < (unsigned)SD && (unsigned)cc_ < (unsigned)SD)                                     \
+            H[((rr_ * SD + cc_) * (SN + 2) + oo_) * 64] += (val);                                             \
+    }
+                    EBVO_SIFT_VOTE(0, 0, 0, v_rco000)
+                    EBVO_SIFT_VOTE(0, 0, 1, v_rco001)
+                    EBVO_SIFT_VOTE(0, 1, 0, v_rco010)
+                    EBVO_SIFT_VOTE(0, 1, 1, v_rco011)
+                    EBVO_SIFT_VOTE(1, 0, 0, v_rco100)
+                    EBVO_SIFT_VOTE(1, 0, 1, v_rco101)
+                    EBVO_SIFT_VOTE(1, 1, 0, v_rco110)
+                    EBVO_SIFT_VOTE(1, 1, 1, v_rco111)
+#undef EBVO_SIFT_VOTE
                 }
             }
         // the orientation histograms are circular; the 4 x 4 x 8 interior is the raw descriptor (kept in place)
@@ -166,7 +193,7 @@ __global__ __launch_bounds__(64) void sift_desc_kernel(const float *__restrict__
         for (int i = 0; i < SD; ++i)
             for (int j = 0; j < SD; ++j)
             {
-                const int idx = ((i + 1) * (SD + 2) + (j + 1)) * (SN + 2);
+                const int idx = (i * SD + j) * (SN + 2);
                 H[idx * 64] += H[(idx + SN) * 64];
                 H[(idx + 1) * 64] += H[(idx + SN + 1) * 64];
             }
@@ -174,7 +201,7 @@ __global__ __launch_bounds__(64) void sift_desc_kernel(const float *__restrict__
             for (int j = 0; j < SD; ++j)
                 for (int k = 0; k < SN; ++k)
                 {
-                    const float v = H[(((i + 1) * (SD + 2) + (j + 1)) * (SN + 2) + k) * 64];
+                    const float v = H[((i * SD + j) * (SN + 2) + k) * 64];
                     nrm2 += v * v;
                 }
         const float thr = sqrtf(nrm2) * 0.2f;
@@ -183,7 +210,7 @@ __global__ __launch_bounds__(64) void sift_desc_kernel(const float *__restrict__
             for (int j = 0; j < SD; ++j)
                 for (int k = 0; k < SN; ++k)
                 {
-                    float *p = &H[(((i + 1) * (SD + 2) + (j + 1)) * (SN + 2) + k) * 64];
+                    float *p = &H[((i * SD + j) * (SN + 2) + k) * 64];
                     const float val = *p < thr ? *p : thr;
                     *p = val;
                     nrm2 += val * val;
@@ -194,7 +221,7 @@ __global__ __launch_bounds__(64) void sift_desc_kernel(const float *__restrict__
             for (int j = 0; j < SD; ++j)
                 for (int k = 0; k < SN; ++k)
                 {
-                    int v = cv_round_f(H[(((i + 1) * (SD + 2) + (j + 1)) * (SN + 2) + k) * 64] * nrm2);
+                    int v = cv_round_f(H[((i * SD + j) * (SN + 2) + k) * 64] * nrm2);
                     v = v < 0 ? 0 : (v > 255 ? 255 : v);
                     const size_t o = (size_t)kp * 128 + (i * SD + j) * SN + k;
                     if (desc_f)

@@ -1646,11 +1646,22 @@ static void sift_descriptor_one(const float *base, int rows, int cols, float ptx
                 const float v_rco101 = v_rc10 * obin, v_rco100 = v_rc10 - v_rco101;
                 const float v_rco011 = v_rc01 * obin, v_rco010 = v_rc01 - v_rco011;
                 const float v_rco001 = v_rc00 * obin, v_rco000 = v_rc00 - v_rco001;
+                /* The reference hands cv::KeyPoint the edge orientation in degrees, -180 .. 180, where OpenCV expects
+                 * 0 .. 360: `ori` = 360 - angle then reaches 540 and o0 stays NEGATIVE (down to -4) after the single
+                 * "+= n" above.  OpenCV indexes its flat histogram with it all the same, so such a vote lands in the
+                 * upper bins of the PREVIOUS cell of the flat array (column - 1; bins n, n + 1 of that cell are folded
+                 * into its bins 0, 1 below).  That aliasing is part of what the reference computes and is kept.  Only a
+                 * negative flat index (first cell, o0 < 0) is dropped: in OpenCV it writes in front of the histogram,
+                 * into its own scratch arrays -- undefined behaviour that no restatement can follow. */
                 const int idx = ((r0 + 1) * (d + 2) + c0 + 1) * (n + 2) + o0;
-                hist[idx] += v_rco000;
-                hist[idx + 1] += v_rco001;
-                hist[idx + (n + 2)] += v_rco010;
-                hist[idx + (n + 3)] += v_rco011;
+                if (idx >= 0)
+                    hist[idx] += v_rco000;
+                if (idx + 1 >= 0)
+                    hist[idx + 1] += v_rco001;
+                if (idx + (n + 2) >= 0)
+                    hist[idx + (n + 2)] += v_rco010;
+                if (idx + (n + 3) >= 0)
+                    hist[idx + (n + 3)] += v_rco011;
                 hist[idx + (d + 2) * (n + 2)] += v_rco100;
                 hist[idx + (d + 2) * (n + 2) + 1] += v_rco101;
                 hist[idx + (d + 3) * (n + 2)] += v_rco110;
