@@ -387,6 +387,9 @@ static int host_slot(ebvo_ctx *ctx, Slot **out)
         ctx->last_error = "slot 0 has a submitted pair in flight; call ebvo_stereo_wait first";
         return EBVO_ERR_STATE;
     }
+    if (int rc = drain_fetch(ctx, s)) // result copies of the previous pair (copy stream) still read the slot's buffers
+        return rc;
+    s.fetch_pending = false;
     s.have_pair = s.have_run = s.have_refined = s.have_final = false;
     s.undist_pair = false;
     s.fetch_what = 0;
