@@ -186,6 +186,22 @@ def check_against_oracle(out, chk):
     return None
 
 
+# what the timing ids of `kernels` bracket (the ids are stages, HIP events around the launches of a stage)
+KERNEL_GROUPS = {
+    "hybrid": {"toed_nms": "toed_screen_fused", "toed_rowscan": "toed_rowscan_phase",
+               "toed_compact": "toed_compact_phase + toed_need_count / _rowscan / _compact",
+               "toed_exact_centre": "toed_exact_centre", "toed_exact_mags": "toed_exact_mags + toed_exact_decide",
+               "toed_finalize": "toed_cand_scatter", "scan": "scan_reduce + scan_apply (flag scans of both images, row_ptr)",
+               "cand_boxes": "boxes + clears", "epi_lines": "lines", "cand_count": "candidates<count>",
+               "cand_fill": "candidates_copy + candidates<fill>", "edge_patches": "sincos_batch + row_pairs + right_bank",
+               "ncc_pairs": "ncc_tile + pair_result"},
+    "strict": {"toed_conv": "toed_conv", "toed_nms": "toed_nms", "toed_rowscan": "toed_rowscan", "toed_compact": "toed_compact",
+               "toed_finalize": "toed_finalize", "scan": "scan_reduce + scan_apply", "cand_boxes": "boxes + clears",
+               "epi_lines": "lines", "cand_count": "candidates<count>", "cand_fill": "candidates_copy + candidates<fill>",
+               "edge_patches": "sincos_batch + row_pairs + right_bank", "ncc_pairs": "ncc_tile + pair_result"},
+}
+
+
 def dropin_loop(ctx, params, pool, calib, nslots, steps):
     """What StereoMatcherHIP::stereo_edge_pairs does per frame (include/ebvo/adapters.hpp; the one-pass body of
     get_Stereo_Edge_Pairs, integration/stereo_matches_hip.cpp): a NEW pair uploaded from host memory, TOED + candidates +
@@ -577,6 +593,7 @@ def main():
                                  "FP64-VALU-bound, not HBM-bound; see roofline_fp64.  Durations: HIP events, pairs one at a "
                                  "time, after the timed region."},
             "kernels": kernels,
+            "kernel_groups": KERNEL_GROUPS[args.toed_mode],
         }
         if args.workload != "kitti":
             result["metric"] = f"stereo pairs/sec (TOED+NCC match) on {wl['cfg']} {W}x{H}; achieved HBM GB/s"
