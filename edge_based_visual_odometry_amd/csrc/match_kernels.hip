@@ -1425,6 +1425,9 @@ __device__ inline bool orient_close(double a, double b, double thr)
     return od < thr || fabs(od - 180.0) < thr;
 }
 
+// sixteen lanes per keyframe mate: lane e tests every sixteenth mate of a cell's segment, the survivors of a step are
+// ranked by a ballot so that the row keeps the order of the segment (one thread per mate walked ~900 dependent
+// look-ups in a row: 350 us per pass at EuRoC size)
 template <bool FILL>
 __global__ __launch_bounds__(256) void temporal_candidates_kernel(const ebvo_edge *__restrict__ kfL,
                                                                   const ebvo_edge *__restrict__ kfR, int n_kf,
@@ -1437,44 +1440,51 @@ __global__ __launch_bounds__(256) void temporal_candidates_kernel(const ebvo_edg
                                                                   const int32_t *__restrict__ row_ptr,
                                                                   int32_t *__restrict__ col_idx, int64_t cap)
 {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_kf; i += gridDim.x * blockDim.x)
+    const int lane = threadIdx.x & 63, e = lane & 15, gshift = lane & 48;
+    const int groups = (gridDim.x * blockDim.x) >> 4;
+    // the four groups of a wave advance together (the ballots below are wave-wide): a group past the end idles
+    for (int w0 = ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) * 4; w0 < n_kf; w0 += groups)
     {
+        const int i0 = w0 + (lane >> 4);
+        const bool live = i0 < n_kf;
+        const int i = live ? i0 : 0;
         const ebvo_edge kl = kfL[i], kr = kfR[i];
         // the query cells are not clipped (include/Dataset.h:95-96); neighbour cells outside the grid hold nothing
         const int qlx = (int)kl.x / cell, qly = (int)kl.y / cell, qrx = (int)kr.x / cell, qry = (int)kr.y / cell;
         int c = 0;
-        int64_t o = FILL ? row_ptr[i] : 0;
+        int64_t o = (FILL && live) ? row_ptr[i] : 0;
         for (int dy = -sr; dy <= sr; ++dy)
-        {
-            const int ny = qly + dy;
-            if (ny < 0 || ny >= gh)
-                continue;
             for (int dx = -sr; dx <= sr; ++dx)
             {
-                const int nx = qlx + dx;
-                if (nx < 0 || nx >= gw)
-                    continue;
-                const int a = cell_start[ny * gw + nx], b = cell_start[ny * gw + nx + 1];
-                for (int k = a; k < b; ++k)
+                const int ny = qly + dy, nx = qlx + dx;
+                const bool in_grid = live && ny >= 0 && ny < gh && nx >= 0 && nx < gw;
+                const int a = in_grid ? cell_start[ny * gw + nx] : 0, b = in_grid ? cell_start[ny * gw + nx + 1] : 0;
+                for (int k0 = a; __any(k0 < b); k0 += 16)
                 {
-                    const int j = cell_list[k];
-                    const MateCells m = cells[j];
-                    // right_set.count(cf_idx): the mate's right edge is in a neighbour cell of the right query
-                    if (abs(m.rx - qrx) <= sr && abs(m.ry - qry) <= sr && orient_close(kl.theta, cfL[j].theta, orient_thr) &&
-                        orient_close(kr.theta, cfR[j].theta, orient_thr))
+                    const int k = k0 + e;
+                    bool ok = false;
+                    int j = 0;
+                    if (k < b)
                     {
-                        if (FILL)
-                        {
-                            if (o < cap)
-                                col_idx[o] = j;
-                            ++o;
-                        }
-                        ++c;
+                        j = cell_list[k];
+                        const MateCells m = cells[j];
+                        // right_set.count(cf_idx): the mate's right edge is in a neighbour cell of the right query
+                        ok = abs(m.rx - qrx) <= sr && abs(m.ry - qry) <= sr && orient_close(kl.theta, cfL[j].theta, orient_thr) &&
+                             orient_close(kr.theta, cfR[j].theta, orient_thr);
                     }
+                    const unsigned hits = (unsigned)((__ballot(ok) >> gshift) & 0xffffull);
+                    if (FILL && ok)
+                    {
+                        const int64_t pos = o + __popc(hits & ((1u << e) - 1u));
+                        if (pos < cap)
+                            col_idx[pos] = j;
+                    }
+                    const int nh = __popc(hits);
+                    c += nh;
+                    o += nh;
                 }
             }
-        }
-        if (!FILL)
+        if (!FILL && live && e == 0)
             cnt[i] = c;
     }
 }
@@ -2003,7 +2013,7 @@ int match_temporal_candidates_enqueue(ebvo_ctx *ctx, Slot &s, const ebvo_edge *d
         return EBVO_OK;
     ProfScope ps(ctx, s, d_row_ptr ? K_CAND_FILL : K_CAND_COUNT);
     const TemporalGrid g = temporal_grid(const_cast<void *>(d_grid), n_cf, gw * gh);
-    const unsigned nb = blocks_for(n_kf, 256, 4096);
+    const unsigned nb = blocks_for(n_kf, 16, 8192); // 16 mates per block of 256 threads
     if (d_row_ptr)
         hipLaunchKernelGGL(temporal_candidates_kernel<true>, dim3(nb), dim3(256), 0, s.stream, d_kfL, d_kfR, n_kf, d_cfL, d_cfR,
                            g.cells, g.start, g.sorted, cell, sr, gw, gh, orient_thr, d_cnt, d_row_ptr, d_col_idx, cap);
