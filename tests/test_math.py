@@ -52,3 +52,48 @@ def test_exp_agrees_with_libm_and_mpmath():
     for xv, av, bv in list(zip(x[diff], a[diff], b[diff]))[:200]:
         exact = mp.exp(mp.mpf(float(xv)))
         assert abs(mp.mpf(float(av)) - exact) <= abs(mp.mpf(float(bv)) - exact)
+
+
+def _is_nearest(mp, value, exact):
+    """`value` (a double) is the double closest to the arbitrary-precision `exact`"""
+    d = abs(mp.mpf(float(value)) - exact)
+    lo, hi = np.nextafter(value, -np.inf), np.nextafter(value, np.inf)
+    return d <= abs(mp.mpf(float(lo)) - exact) and d <= abs(mp.mpf(float(hi)) - exact)
+
+
+def test_atan2_sincos_are_correctly_rounded_against_mpmath():
+    """An anchor that does not go through csrc/ebvo_math.h: the oracle's portable mode and the kernels share that header,
+    so their agreement on theta / sin / cos says nothing about the routine itself.  Here every result is compared with the
+    200-bit value of mpmath: the shared routine returns the nearest double on all sampled inputs, including every input
+    on which glibc returns the other neighbour."""
+    import mpmath as mp
+    mp.mp.prec = 200
+    rng = np.random.default_rng(3)
+    # atan2 as the detector calls it: a unit vector (cpu_toed.cpp:226-229), plus general magnitudes
+    ang = rng.uniform(-np.pi, np.pi, 6000)
+    y = np.concatenate([np.sin(ang), rng.normal(0, 50, 2000), np.array([1e-8, -1e-8, 1.0, -1.0, 3.0])])
+    x = np.concatenate([np.cos(ang), rng.normal(0, 50, 2000), np.array([1.0, -1.0, 1e-8, -1e-8, -4.0])])
+    a, b = orc.atan2_v(y, x, orc.PORTABLE), orc.atan2_v(y, x, orc.LIBM)
+    for yv, xv, av in zip(y, x, a):
+        assert _is_nearest(mp, av, mp.atan2(mp.mpf(float(yv)), mp.mpf(float(xv)))), (yv, xv, av)
+    # the inputs on which glibc disagrees, from a larger sample: the shared routine is the nearest one there too
+    ang = rng.uniform(-np.pi, np.pi, 300_000)
+    y, x = np.sin(ang), np.cos(ang)
+    a, b = orc.atan2_v(y, x, orc.PORTABLE), orc.atan2_v(y, x, orc.LIBM)
+    dis = np.flatnonzero(a != b)
+    assert len(dis) > 20
+    for k in dis[:300]:
+        assert _is_nearest(mp, a[k], mp.atan2(mp.mpf(float(y[k])), mp.mpf(float(x[k]))))
+    # sin / cos on the orientation range and beyond
+    t = np.concatenate([rng.uniform(-np.pi, np.pi, 6000), rng.uniform(-50, 50, 1500), np.array([1e-9, -1e-9, np.pi / 2, np.pi])])
+    s, c = orc.sincos_v(t, orc.PORTABLE)
+    for tv, sv, cv in zip(t, s, c):
+        m = mp.mpf(float(tv))
+        assert _is_nearest(mp, sv, mp.sin(m)) and _is_nearest(mp, cv, mp.cos(m)), tv
+    t = rng.uniform(-np.pi, np.pi, 300_000)
+    s, c = orc.sincos_v(t, orc.PORTABLE)
+    sm, cm = orc.sincos_v(t, orc.LIBM)
+    for k in np.flatnonzero(s != sm)[:200]:
+        assert _is_nearest(mp, s[k], mp.sin(mp.mpf(float(t[k]))))
+    for k in np.flatnonzero(c != cm)[:200]:
+        assert _is_nearest(mp, c[k], mp.cos(mp.mpf(float(t[k]))))
