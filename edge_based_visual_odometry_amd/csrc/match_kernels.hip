@@ -11,7 +11,7 @@
 //
 // Candidate search.  The reference scans all N_R right edges for each of the N_L left edges
 // (O(N_L * N_R) fp64 predicates).  Here the right edges are summarised by bounding boxes over
-// consecutive index ranges (16 edges per chunk).  A block owns 256 consecutive left edges: it
+// consecutive index ranges (8 edges per chunk).  A block owns 64 consecutive left edges: it
 // selects, in index order, the chunks whose box can intersect the union of its lefts' search
 // regions ({epipolar band} ∩ {disparity square}), stages their edges in LDS, and then every lane
 // walks only the staged chunks that can intersect ITS region and evaluates the reference's exact
@@ -36,9 +36,9 @@
 namespace
 {
 
-constexpr int CHUNK = 16;        // edges per chunk box
-constexpr int GROUP = 64;        // chunks per group box (1024 edges)
-constexpr int BATCH = 64;        // chunks staged in LDS at a time (1024 edges, 24 KB)
+constexpr int CHUNK = 8;         // edges per chunk box = lanes per left edge in the candidate walk
+constexpr int GROUP = 64;        // chunks per group box (512 edges)
+constexpr int BATCH = 64;        // chunks staged in LDS at a time (512 edges, 12 KB)
 constexpr int TILE = 64;         // left edges per block of the candidate search
 constexpr int STAGE = 64;        // candidates per left edge kept by the counting pass (rows beyond it are refilled)
 constexpr double BOX_SLACK = 1e-6;
@@ -110,7 +110,7 @@ __device__ inline double wave_max(double v)
     return v;
 }
 
-// Bounding boxes of the index ranges: one thread per chunk (16 edges), one wave per group (64 chunks), so the group
+// Bounding boxes of the index ranges: one thread per chunk (CHUNK edges), one wave per group (64 chunks), so the group
 // box is a wave reduction of the chunk boxes it has just produced.
 __global__ __launch_bounds__(256) void boxes_kernel(const ebvo_edge *__restrict__ R, DevN nRd, Box *__restrict__ cb,
                                                     Box *__restrict__ gb)
@@ -291,7 +291,11 @@ __global__ __launch_bounds__(256) void candidates_kernel(const ebvo_edge *__rest
     __shared__ unsigned long long s_tot[4];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int gid = tid >> 4, e = tid & 15, gshift = lane & 48; // 16-lane group, lane in group, group's bit offset
+    // CHUNK lanes per left edge: group of the block, lane in group, bit offset of the group in a ballot
+    constexpr int LPE = CHUNK, GPB = 256 / LPE, ROUNDS = TILE / GPB;
+    constexpr unsigned long long GMASK = (1ull << LPE) - 1ull;
+    static_assert(TILE % GPB == 0 && BATCH % LPE == 0 && BATCH <= 64, "tile rounds / marked-chunk mask");
+    const int gid = tid / LPE, e = tid % LPE, gshift = lane & ~(LPE - 1);
     const int nL = devn(P.nL), nR = devn(P.nR);
     const int nchunks = (nR + CHUNK - 1) / CHUNK, ngroups = (nchunks + GROUP - 1) / GROUP;
     const double d2 = P.max_disp * P.max_disp;
@@ -352,15 +356,21 @@ __global__ __launch_bounds__(256) void candidates_kernel(const ebvo_edge *__rest
             return !(bx.x0 > U.x1 || bx.x1 < U.x0 || bx.y0 > U.y1 || bx.y1 < U.y0);
         };
 
-        // the four left edges of this 16-lane group (one per walk round): hit counts and output cursors
-        int n[4] = {0, 0, 0, 0};
-        int64_t o[4] = {0, 0, 0, 0};
+        // the left edges of this group of CHUNK lanes (one per walk round): hit counts and output cursors
+        int n[ROUNDS];
+        int64_t o[ROUNDS];
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r)
+        {
+            n[r] = 0;
+            o[r] = 0;
+        }
         if (FILL)
         {
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+            for (int r = 0; r < ROUNDS; ++r)
             {
-                const int i = tile * TILE + r * 16 + gid;
+                const int i = tile * TILE + r * GPB + gid;
                 o[r] = (int64_t)row_ptr[i < nL ? i : 0];
             }
         }
@@ -392,23 +402,23 @@ __global__ __launch_bounds__(256) void candidates_kernel(const ebvo_edge *__rest
                     __syncthreads();
                     // ---- 3. walk
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
+                    for (int r = 0; r < ROUNDS; ++r)
                     {
-                        const int li = r * 16 + gid;
+                        const int li = r * GPB + gid;
                         const int i = tile * TILE + li;
                         const bool live = i < nL; // uniform in the group
                         const LeftCtx l = s_left[li];
-                        // which staged chunks can meet this edge's region: lane e looks at boxes e, e+16, e+32, e+48
+                        // which staged chunks can meet this edge's region: lane e looks at boxes e, e + LPE, e + 2 LPE, ...
                         unsigned long long pm = 0;
 #pragma unroll
-                        for (int k = 0; k < BATCH / 16; ++k)
+                        for (int k = 0; k < BATCH / LPE; ++k)
                         {
-                            const int j = k * 16 + e;
+                            const int j = k * LPE + e;
                             const bool may = live && j < mb &&
                                              box_may_match(s_box[j < mb ? j : 0], l.lx, l.ly, l.ah, l.bh, l.ch, D, band,
                                                            P.mask);
                             const unsigned long long bal = __ballot(may);
-                            pm |= ((bal >> gshift) & 0xffffull) << (16 * k);
+                            pm |= ((bal >> gshift) & GMASK) << (LPE * k);
                         }
                         // marked chunks in ascending order, one pair test per lane
                         while (__any(pm != 0))
@@ -418,7 +428,7 @@ __global__ __launch_bounds__(256) void candidates_kernel(const ebvo_edge *__rest
                             pm &= pm - 1; // 0 stays 0
                             const int idx = j * CHUNK + e;
                             const bool ok = act && pair_passes(l, s_x[idx], s_y[idx], s_th[idx], P);
-                            const unsigned hits = (unsigned)((__ballot(ok) >> gshift) & 0xffffull);
+                            const unsigned hits = (unsigned)((__ballot(ok) >> gshift) & GMASK);
                             if (ok)
                             {
                                 const int rank = __popc(hits & ((1u << e) - 1u));
@@ -444,9 +454,9 @@ __global__ __launch_bounds__(256) void candidates_kernel(const ebvo_edge *__rest
         {
             unsigned long long tsum = 0;
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+            for (int r = 0; r < ROUNDS; ++r)
             {
-                const int i = tile * TILE + r * 16 + gid;
+                const int i = tile * TILE + r * GPB + gid;
                 if (e == 0 && i < nL)
                 {
                     cnt[i] = n[r];
