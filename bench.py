@@ -299,14 +299,16 @@ def sequence_bench(args, wl, H, W, F, device, rank, world, dist, reduce_device):
     for k, (l, r) in enumerate(frames):
         ctx.stereo_upload(l, r, slot=k)
 
-    def frame(k, first=False):
+    def frame(k, first=False, stages=0):
+        """stages = 0: temporal quads through the NCC filter, what BASELINE configs[2] names; 1: every stage of
+        get_Temporal_Edge_Pairs_from_Quads (SIFT filter, both Best-Nearly-Best tests, refinement of both cameras, clustering)"""
         ctx.stereo_submit(params, slot=k)
         c = ctx.stereo_wait(slot=k)
         fc, _ = ctx.stereo_finalize(calib, slot=k, use_sift=True)
         if first:
             ctx.temporal_set_keyframe(slot=k)
             return c, fc, None
-        tc, _ = ctx.temporal_match(slot=k, fetch=False)
+        tc, _ = ctx.temporal_match(slot=k, fetch=False, stages=stages)
         return c, fc, tc
 
     frame(0, first=True)                               # keyframe = frame 0 (src/Pipeline.cpp:133-138)
@@ -343,6 +345,13 @@ def sequence_bench(args, wl, H, W, F, device, rank, world, dist, reduce_device):
         kernels = {k: {"ms_per_step": v[0] / n_ser, "launches_per_step": v[1] / n_ser} for k, v in prof.items() if v[1]}
         dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
         c, fc, tc = frame(1)
+        # the same loop with every stage of the temporal chain (never `value`: the config names the NCC quads)
+        n_full = min(16, n_frames)
+        frame(1, stages=1)
+        t1 = time.perf_counter()
+        for k in range(n_full):
+            _, _, tcf = frame(k % n_frames, stages=1)
+        t_full = (time.perf_counter() - t1) / n_full
         alg_bytes = algorithmic_bytes_per_pair(H, W, c.n_left, c.n_right, c.n_pairs)
         dom_s = kernels[dom]["ms_per_step"] * 1e-3 / max(1.0, kernels[dom]["launches_per_step"])
         result = {
@@ -361,6 +370,10 @@ def sequence_bench(args, wl, H, W, F, device, rank, world, dist, reduce_device):
                          "note": "the stereo hot path's algorithmic bytes (SURVEY.md 8(d)) over the dominant kernel id's launch "
                                  "duration (HIP events, frames one at a time, after the timed region)"},
             "kernels": kernels,
+            "full_temporal_chain_frames_per_s": 1.0 / t_full,
+            "full_temporal_chain_note": "the same frame loop with the rest of get_Temporal_Edge_Pairs_from_Quads after the NCC "
+                                        "filter (SIFT filter, Best-Nearly-Best on NCC and SIFT scores, photometric refinement "
+                                        "of both cameras, edge clustering): %d final quads per frame" % tcf["n_final"],
         }
         print(json.dumps(result))
     ctx.close()

@@ -44,7 +44,7 @@ ABI_SYMBOLS = (
     "ebvo_stereo_fetch_refined", "ebvo_gn_refine_temporal", "ebvo_finalize_pairs", "ebvo_bnb_test", "ebvo_keep_best", "ebvo_epipolar_shift", "ebvo_cluster_rows", "ebvo_stereo_finalize", "ebvo_stereo_fetch_final",
     "ebvo_debug_set", "ebvo_stereo_fetch_begin", "ebvo_stereo_fetch_end",
     "ebvo_undistort", "ebvo_stereo_set_undistort", "ebvo_sift_descriptors", "ebvo_sift_min_distances",
-    "ebvo_temporal_default_params", "ebvo_temporal_set_keyframe", "ebvo_temporal_match", "ebvo_temporal_fetch",
+    "ebvo_temporal_default_params", "ebvo_temporal_set_keyframe", "ebvo_temporal_match", "ebvo_temporal_fetch", "ebvo_temporal_fetch_final",
 )
 
 
@@ -83,12 +83,15 @@ class UndistortParams(C.Structure):
 
 
 class TemporalParams(C.Structure):
-    _fields_ = [("cell_size", C.c_int), ("reserved", C.c_int), ("grid_radius", C.c_double), ("orient_thr_deg", C.c_double),
-                ("ncc_thr", C.c_double)]
+    _fields_ = [("cell_size", C.c_int), ("stages", C.c_int), ("grid_radius", C.c_double), ("orient_thr_deg", C.c_double),
+                ("ncc_thr", C.c_double), ("sift_thr", C.c_double), ("bnb_ncc", C.c_double), ("bnb_sift", C.c_double),
+                ("gn", GnParams)]
 
 
 class TemporalCounts(C.Structure):
-    _fields_ = [("n_kf", C.c_int32), ("n_cf", C.c_int32), ("n_candidates", C.c_int64), ("n_kept", C.c_int64)]
+    _fields_ = [("n_kf", C.c_int32), ("n_cf", C.c_int32), ("n_candidates", C.c_int64), ("n_kept", C.c_int64),
+                ("n_sift", C.c_int64), ("n_bnb_ncc", C.c_int64), ("n_bnb_sift", C.c_int64), ("n_refined_valid", C.c_int64),
+                ("n_final", C.c_int64)]
 
 
 class StereoView(C.Structure):
@@ -172,6 +175,8 @@ def load_library() -> C.CDLL:
     lib.ebvo_temporal_set_keyframe.argtypes = [vp, i32]
     lib.ebvo_temporal_match.argtypes = [vp, i32, C.POINTER(TemporalParams), C.POINTER(TemporalCounts)]
     lib.ebvo_temporal_fetch.argtypes = [vp, i32, vp, vp, vp, vp, vp]
+    lib.ebvo_temporal_fetch_final.restype = i32
+    lib.ebvo_temporal_fetch_final.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.ebvo_undistort.argtypes = [vp, vp, i32, i32, ssz, vp, vp, i32, vp, ssz]
     lib.ebvo_stereo_set_undistort.argtypes = [vp, C.POINTER(UndistortParams)]
     lib.ebvo_stereo_fetch_end.argtypes = [vp, i32, C.POINTER(StereoView)]

@@ -458,6 +458,9 @@ class Context:
         c = _lib.TemporalCounts()
         self._check(self.lib.ebvo_temporal_match(self._ctx, slot, C.byref(p), C.byref(c)), "ebvo_temporal_match")
         counts = dict(n_kf=c.n_kf, n_cf=c.n_cf, n_candidates=c.n_candidates, n_kept=c.n_kept)
+        if p.stages:
+            counts.update(n_sift=c.n_sift, n_bnb_ncc=c.n_bnb_ncc, n_bnb_sift=c.n_bnb_sift, n_refined_valid=c.n_refined_valid,
+                          n_final=c.n_final)
         if not fetch:
             return counts, None
         n = c.n_candidates
@@ -465,6 +468,15 @@ class Context:
                    sim_right=np.zeros(n), keep=np.zeros(n, dtype=np.uint8))
         self._check(self.lib.ebvo_temporal_fetch(self._ctx, slot, ptr(out["row_ptr"]), ptr(out["col_idx"]), ptr(out["sim_left"]),
                                                  ptr(out["sim_right"]), ptr(out["keep"])), "ebvo_temporal_fetch")
+        if p.stages:
+            m = c.n_final
+            fin = dict(row_ptr=np.zeros(c.n_kf + 1, dtype=np.int32), cf_index=np.zeros(m, dtype=np.int32),
+                       left=np.zeros(m, dtype=EDGE_DTYPE), right=np.zeros(m, dtype=EDGE_DTYPE), ncc_left=np.zeros(m),
+                       sift_left=np.zeros(m), score_left=np.zeros(m), score_right=np.zeros(m), valid=np.zeros(m, dtype=np.uint8))
+            self._check(self.lib.ebvo_temporal_fetch_final(self._ctx, slot, *(ptr(fin[k]) for k in (
+                "row_ptr", "cf_index", "left", "right", "ncc_left", "sift_left", "score_left", "score_right", "valid"))),
+                "ebvo_temporal_fetch_final")
+            out["final"] = fin
         return counts, out
 
     def stereo_fetch_begin(self, slot: int = 0, what: int = _lib.FETCH_DEFAULT):

@@ -139,7 +139,7 @@ static void slot_destroy(Slot *s)
         (void)hipFree(ws.cand_lists);
         (void)hipFree(ws.cand_lcount);
     }
-    GrowBuf *bufs[] = {&s->lines,        &s->boxes_chunk,  &s->boxes_group,    &s->cand_cnt,       &s->cand_stage, &s->cand_tileflag, &s->row_ptr, &s->grad_x, &s->grad_y, &s->gn_xy, &s->gn_out, &s->gn_valid, &s->gn_iters, &s->gn_state, &s->gn_lists, &s->gn_pack, &s->sift_img, &s->sift_desc, &s->sift_f32, &s->sift_dist, &s->tq_i32, &s->tq_cols, &s->tq_f64, &s->tq_u8, &s->tq_cells, &s->fin_i32, &s->fin_edges, &s->fin_f64, &s->fin_u8, &s->fin_out,
+    GrowBuf *bufs[] = {&s->lines,        &s->boxes_chunk,  &s->boxes_group,    &s->cand_cnt,       &s->cand_stage, &s->cand_tileflag, &s->row_ptr, &s->grad_x, &s->grad_y, &s->gn_xy, &s->gn_out, &s->gn_valid, &s->gn_iters, &s->gn_state, &s->gn_lists, &s->gn_pack, &s->sift_img, &s->sift_desc, &s->sift_f32, &s->sift_dist, &s->tq_i32, &s->tq_cols, &s->tq_f64, &s->tq_u8, &s->tq_cells, &s->tq_chain, &s->fin_i32, &s->fin_edges, &s->fin_f64, &s->fin_u8, &s->fin_out,
                        &s->scan_tmp,     &s->col_idx,      &s->rc_edges,       &s->sims,           &s->best,
                        &s->keep,         &s->patches_raw,  &s->patches_norm,   &s->patches_flag,   &s->patches_norm_r,
                        &s->patches_flag_r, &s->pair_left,  &s->sincos,         &s->scratch_b,      &s->scratch_c,
@@ -308,6 +308,10 @@ extern "C" void ebvo_ctx_destroy(ebvo_ctx *ctx)
     (void)hipFree(ctx->kf_Ln);
     (void)hipFree(ctx->kf_Rn);
     (void)hipFree(ctx->kf_Lf);
+    (void)hipFree(ctx->kf_Ld);
+    (void)hipFree(ctx->kf_Rd);
+    (void)hipFree(ctx->kf_imgL);
+    (void)hipFree(ctx->kf_imgR);
     (void)hipFree(ctx->kf_Rf);
     delete ctx;
 }
@@ -938,6 +942,7 @@ extern "C" int ebvo_stereo_upload_slot(ebvo_ctx *ctx, int slot, const uint8_t *i
         return EBVO_ERR_STATE;
     s.have_pair = s.have_run = s.have_refined = s.have_final = false; // results of the previous pair are gone
     s.tq_n = -1;
+    s.tq_final.n = -1;
     if (s.fetch_pending) // a result copy of the previous pair is still reading the buffers
         EBVO_HIP(ctx, hipEventSynchronize(s.ev_rebind));
     s.fetch_pending = false;
@@ -1489,6 +1494,7 @@ extern "C" int ebvo_stereo_finalize(ebvo_ctx *ctx, int slot, const ebvo_finalize
     memset(counts, 0, sizeof *counts);
     s.have_final = s.have_refined = false; // the refinement buffers are reused
     s.tq_n = -1;
+    s.tq_final.n = -1;
 
     s.n_final = 0;
     const int nL = s.result.n_left, h = s.cur_h, w = s.cur_w;
@@ -1852,6 +1858,11 @@ extern "C" void ebvo_temporal_default_params(ebvo_temporal_params *p)
     p->grid_radius = 30.0;
     p->orient_thr_deg = 10.0;
     p->ncc_thr = EBVO_NCC_THRESH_TEMPORAL;
+    p->stages = 0;
+    p->sift_thr = 200.0; // src/Temporal_Matches.cpp:196
+    p->bnb_ncc = 0.8;    // :200
+    p->bnb_sift = 0.8;   // :204
+    ebvo_gn_default_params(&p->gn); // 20, 1e-3, 3.0 (:612, :615)
 }
 
 // the final mates of a finalized slot: left edges, right centre edges (carved by ebvo_stereo_finalize)
@@ -1860,6 +1871,25 @@ static void final_mates(Slot &s, const ebvo_edge **fl, const ebvo_edge **fr)
     const size_t nz = (size_t)s.result.n_pairs, nLz = (size_t)s.result.n_left + 1;
     *fl = (const ebvo_edge *)s.fin_edges.p + 3 * nz;
     *fr = *fl + nLz;
+}
+
+// SIFT descriptors of n stereo mates of the slot's pair: left edges on the undistorted left image, right edges on the
+// undistorted right image (the octave base of each image is rebuilt here: one separable blur per image)
+static int mate_descriptors(ebvo_ctx *ctx, Slot &s, const ebvo_edge *d_L, const ebvo_edge *d_R, int n, uint8_t *d_descL,
+                            uint8_t *d_descR)
+{
+    const int h = s.cur_h, w = s.cur_w;
+    const size_t npx = (size_t)h * w;
+    int rc;
+    if ((rc = ebvo_grow(ctx, s, s.sift_img, sizeof(float) * 2 * npx)))
+        return rc;
+    float *tmp = (float *)s.sift_img.p, *base = tmp + npx;
+    if ((rc = sift_base_enqueue(ctx, s, s.im[0].img, h, w, w, tmp, base)) ||
+        (rc = sift_descriptors_enqueue(ctx, s, base, h, w, d_L, n, nullptr, d_descL)) ||
+        (rc = sift_base_enqueue(ctx, s, s.im[1].img, h, w, w, tmp, base)) ||
+        (rc = sift_descriptors_enqueue(ctx, s, base, h, w, d_R, n, nullptr, d_descR)))
+        return rc;
+    return EBVO_OK;
 }
 
 extern "C" int ebvo_temporal_set_keyframe(ebvo_ctx *ctx, int slot)
@@ -1877,16 +1907,19 @@ extern "C" int ebvo_temporal_set_keyframe(ebvo_ctx *ctx, int slot)
     if (n > ctx->kf_cap)
     {
         EBVO_HIP(ctx, hipDeviceSynchronize());
-        for (void *p : {(void *)ctx->kf_L, (void *)ctx->kf_R, (void *)ctx->kf_Ln, (void *)ctx->kf_Rn, (void *)ctx->kf_Lf, (void *)ctx->kf_Rf})
+        for (void *p : {(void *)ctx->kf_L, (void *)ctx->kf_R, (void *)ctx->kf_Ln, (void *)ctx->kf_Rn, (void *)ctx->kf_Lf, (void *)ctx->kf_Rf,
+                        (void *)ctx->kf_Ld, (void *)ctx->kf_Rd})
             (void)hipFree(p);
         ctx->kf_L = ctx->kf_R = nullptr;
         ctx->kf_Ln = ctx->kf_Rn = nullptr;
         ctx->kf_Lf = ctx->kf_Rf = nullptr;
+        ctx->kf_Ld = ctx->kf_Rd = nullptr;
         ctx->kf_cap = 0;
         const size_t cap = n + n / 4 + 64;
         if (hipMalloc(&ctx->kf_L, sizeof(ebvo_edge) * cap) != hipSuccess || hipMalloc(&ctx->kf_R, sizeof(ebvo_edge) * cap) != hipSuccess ||
             hipMalloc(&ctx->kf_Ln, sizeof(float) * 98 * cap) != hipSuccess || hipMalloc(&ctx->kf_Rn, sizeof(float) * 98 * cap) != hipSuccess ||
-            hipMalloc(&ctx->kf_Lf, 2 * cap) != hipSuccess || hipMalloc(&ctx->kf_Rf, 2 * cap) != hipSuccess)
+            hipMalloc(&ctx->kf_Lf, 2 * cap) != hipSuccess || hipMalloc(&ctx->kf_Rf, 2 * cap) != hipSuccess ||
+            hipMalloc(&ctx->kf_Ld, 256 * cap) != hipSuccess || hipMalloc(&ctx->kf_Rd, 256 * cap) != hipSuccess)
         {
             (void)hipGetLastError();
             ctx->last_error = "hipMalloc failed (keyframe store)";
@@ -1895,8 +1928,32 @@ extern "C" int ebvo_temporal_set_keyframe(ebvo_ctx *ctx, int slot)
         ctx->kf_cap = cap;
     }
     ctx->kf_n = (int)n;
+    {
+        // the keyframe's undistorted images stay with it: the photometric refinement of the quads samples them
+        const size_t bytes = (size_t)s.cur_h * s.cur_w;
+        if (bytes > ctx->kf_img_bytes)
+        {
+            EBVO_HIP(ctx, hipDeviceSynchronize());
+            (void)hipFree(ctx->kf_imgL);
+            (void)hipFree(ctx->kf_imgR);
+            ctx->kf_imgL = ctx->kf_imgR = nullptr;
+            ctx->kf_img_bytes = 0;
+            if (hipMalloc(&ctx->kf_imgL, bytes) != hipSuccess || hipMalloc(&ctx->kf_imgR, bytes) != hipSuccess)
+            {
+                (void)hipGetLastError();
+                ctx->last_error = "hipMalloc failed (keyframe images)";
+                return EBVO_ERR_NOMEM;
+            }
+            ctx->kf_img_bytes = bytes;
+        }
+        EBVO_HIP(ctx, hipMemcpyAsync(ctx->kf_imgL, s.im[0].img, bytes, hipMemcpyDeviceToDevice, s.stream));
+        EBVO_HIP(ctx, hipMemcpyAsync(ctx->kf_imgR, s.im[1].img, bytes, hipMemcpyDeviceToDevice, s.stream));
+    }
     if (n == 0)
+    {
+        EBVO_HIP(ctx, hipStreamSynchronize(s.stream));
         return EBVO_OK;
+    }
     const ebvo_edge *fl, *fr;
     final_mates(s, &fl, &fr);
     int rc;
@@ -1908,14 +1965,223 @@ extern "C" int ebvo_temporal_set_keyframe(ebvo_ctx *ctx, int slot)
         (rc = match_patches_enqueue(ctx, s, s.im[1].img, s.cur_h, s.cur_w, s.cur_w, ctx->kf_R, (int)n, nullptr, 0, nullptr, ctx->kf_Rn,
                                     ctx->kf_Rf)))
         return rc;
+    // left_edge_descriptors (augment_Edge_Data, src/Stereo_Matches.cpp:655-689: the left TOED edge on the undistorted left
+    // image) and right_edge_descriptors (finalize_stereo_edge_mates, :1627-1635: the final right edge on the undistorted
+    // right image) of every mate
+    if ((rc = mate_descriptors(ctx, s, ctx->kf_L, ctx->kf_R, (int)n, ctx->kf_Ld, ctx->kf_Rd)))
+        return rc;
     EBVO_HIP(ctx, hipStreamSynchronize(s.stream));
+    return EBVO_OK;
+}
+
+// get_Temporal_Edge_Pairs_from_Quads after the NCC filter (src/Temporal_Matches.cpp:196-215) on the candidate quads of the
+// slot's pair: rp / col / quad_kf / sim_l / keep are the CSR candidate lists, the current-frame mate and the keyframe mate
+// of every candidate, its left NCC maximum and the NCC keep flag, as ebvo_temporal_match left them on the device.
+static int temporal_chain(ebvo_ctx *ctx, Slot &s, const ebvo_temporal_params &P, const int32_t *rp, const int32_t *col,
+                          const int32_t *quad_kf, const double *sim_l, const uint8_t *keep, int n_kf, const ebvo_edge *cfL,
+                          const ebvo_edge *cfR, int n_cf, int64_t n_kept, ebvo_temporal_counts *counts)
+{
+    const int h = s.cur_h, w = s.cur_w;
+    const size_t nk1 = (size_t)n_kf + 1, nK = (size_t)(n_kept > 0 ? n_kept : 1), ncz = (size_t)n_cf;
+    hipStream_t st = s.stream;
+    int rc;
+    // one buffer, carved: two quad sets (ping-pong), row bookkeeping, refinement and clustering arrays, the final lists
+    struct QuadSet
+    {
+        int32_t *rp, *cf, *kf;
+        double *simL, *siftL, *siftR;
+    } A, B;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) {
+        const size_t o = off;
+        off += (bytes + 63) & ~(size_t)63;
+        return o;
+    };
+    size_t o_set[2][6];
+    for (int k = 0; k < 2; ++k)
+    {
+        o_set[k][0] = carve(sizeof(int32_t) * nk1);
+        o_set[k][1] = carve(sizeof(int32_t) * nK);
+        o_set[k][2] = carve(sizeof(int32_t) * nK);
+        o_set[k][3] = carve(sizeof(double) * nK);
+        o_set[k][4] = carve(sizeof(double) * nK);
+        o_set[k][5] = carve(sizeof(double) * nK);
+    }
+    // `order` is indexed like the INPUT list of a selection: the first one selects from all nq candidate quads
+    const size_t nq = (size_t)(s.tq_n > 0 ? s.tq_n : 1);
+    const size_t o_cnt = carve(sizeof(int32_t) * (nk1 + 1)), o_order = carve(sizeof(int32_t) * (nq > nK ? nq : nK)),
+                 o_idx = carve(sizeof(int32_t) * nK),
+                 o_ok = carve(3 * nK), o_desc = carve(512 * ncz), o_kfe = carve(sizeof(ebvo_edge) * 2 * nK),
+                 o_cfe = carve(sizeof(ebvo_edge) * 2 * nK), o_init = carve(sizeof(double) * 4 * nK),
+                 o_disp = carve(sizeof(double) * 4 * nK), o_score = carve(sizeof(double) * 2 * nK), o_valid = carve(3 * nK),
+                 o_iters = carve(sizeof(int32_t) * 2 * nK), o_cen = carve(sizeof(ebvo_edge) * 2 * nK),
+                 o_centres = carve(sizeof(ebvo_edge) * nK), o_clof = carve(sizeof(int32_t) * nK),
+                 o_frp = carve(sizeof(int32_t) * nk1), o_fsrc = carve(sizeof(int32_t) * nK), o_fcf = carve(sizeof(int32_t) * nK),
+                 o_fL = carve(sizeof(ebvo_edge) * nK), o_fR = carve(sizeof(ebvo_edge) * nK), o_fd = carve(sizeof(double) * 4 * nK),
+                 o_fvalid = carve(nK);
+    if ((rc = ebvo_grow(ctx, s, s.tq_chain, off + 64)))
+        return rc;
+    char *base = (char *)s.tq_chain.p;
+    QuadSet *sets[2] = {&A, &B};
+    for (int k = 0; k < 2; ++k)
+    {
+        sets[k]->rp = (int32_t *)(base + o_set[k][0]);
+        sets[k]->cf = (int32_t *)(base + o_set[k][1]);
+        sets[k]->kf = (int32_t *)(base + o_set[k][2]);
+        sets[k]->simL = (double *)(base + o_set[k][3]);
+        sets[k]->siftL = (double *)(base + o_set[k][4]);
+        sets[k]->siftR = (double *)(base + o_set[k][5]);
+    }
+    int32_t *cnt = (int32_t *)(base + o_cnt), *order = (int32_t *)(base + o_order), *idx = (int32_t *)(base + o_idx);
+    uint8_t *okL = (uint8_t *)(base + o_ok), *okR = okL + nK, *ok = okR + nK;
+    uint8_t *cf_Ld = (uint8_t *)(base + o_desc), *cf_Rd = cf_Ld + 256 * ncz;
+    auto scan_counts = [&](int32_t *rp_out, int32_t *total) -> int {
+        EBVO_HIP(ctx, hipMemsetAsync(cnt + n_kf, 0, sizeof(int32_t), st));
+        int r = ebvo_device_scan(ctx, s, cnt, rp_out, n_kf, nullptr, 1, n_kf + 1);
+        return r ? r : read_i32(ctx, s, rp_out + n_kf, total);
+    };
+    // select rows of `from` (counts / order just formed against from.rp) into `to`
+    auto compact = [&](const QuadSet &from, QuadSet &to, int32_t *total, bool with_sift) -> int {
+        int r;
+        if ((r = scan_counts(to.rp, total)) || *total == 0)
+            return r;
+        if ((r = glue_row_index_enqueue(ctx, s, from.rp, cnt, order, to.rp, n_kf, idx)))
+            return r;
+        GlueGather g;
+        g.i_src[0] = from.cf, g.i_dst[0] = to.cf;
+        g.i_src[1] = from.kf, g.i_dst[1] = to.kf;
+        g.d_src[0] = from.simL, g.d_dst[0] = to.simL;
+        if (with_sift)
+        {
+            g.d_src[1] = from.siftL, g.d_dst[1] = to.siftL;
+            g.d_src[2] = from.siftR, g.d_dst[2] = to.siftR;
+        }
+        return glue_gather_enqueue(ctx, s, idx, *total, g);
+    };
+    auto finish_empty = [&]() -> int { // nothing left: an empty final list
+        s.tq_final.rp = (int32_t *)(base + o_frp);
+        EBVO_HIP(ctx, hipMemsetAsync(s.tq_final.rp, 0, sizeof(int32_t) * nk1, st));
+        EBVO_HIP(ctx, hipStreamSynchronize(st));
+        s.tq_final.n = 0;
+        return EBVO_OK;
+    };
+    // 0. the quads that passed the NCC filter
+    int32_t n0 = 0;
+    {
+        QuadSet G0{const_cast<int32_t *>(rp), const_cast<int32_t *>(col), const_cast<int32_t *>(quad_kf), const_cast<double *>(sim_l),
+                   nullptr, nullptr};
+        if ((rc = glue_rows_from_flags_enqueue(ctx, s, rp, n_kf, keep, cnt, order)) || (rc = compact(G0, A, &n0, false)))
+            return rc;
+    }
+    if (n0 == 0)
+        return finish_empty();
+    // 1. apply_SIFT_filtering_quads (:471-515): the smaller of the four descriptor distances of the left edges AND of the right
+    // edges below the threshold; the distances become the quad's SIFT scores
+    if ((rc = mate_descriptors(ctx, s, cfL, cfR, n_cf, cf_Ld, cf_Rd)) ||
+        (rc = sift_distances_enqueue(ctx, s, ctx->kf_Ld, cf_Ld, A.kf, A.cf, n0, P.sift_thr, A.siftL, okL)) ||
+        (rc = sift_distances_enqueue(ctx, s, ctx->kf_Rd, cf_Rd, A.kf, A.cf, n0, P.sift_thr, A.siftR, okR)) ||
+        (rc = sift_and_flags_enqueue(ctx, s, okL, okR, n0, ok)) || (rc = glue_rows_from_flags_enqueue(ctx, s, A.rp, n_kf, ok, cnt, order)))
+        return rc;
+    int32_t n1 = 0;
+    if ((rc = compact(A, B, &n1, true)))
+        return rc;
+    counts->n_sift = n1;
+    if (n1 == 0)
+        return finish_empty();
+    // 2. apply_best_nearly_best_filtering_quads on the left NCC scores, then on the left SIFT scores (:517-570): rows of two or
+    // more quads come out sorted by the score
+    int32_t n2 = 0, n3 = 0;
+    if ((rc = glue_bnb_enqueue(ctx, s, B.rp, n_kf, B.simL, P.bnb_ncc, 1 | 2, cnt, order)) || (rc = compact(B, A, &n2, true)))
+        return rc;
+    counts->n_bnb_ncc = n2;
+    if ((rc = glue_bnb_enqueue(ctx, s, A.rp, n_kf, A.siftL, P.bnb_sift, 0 | 2, cnt, order)) || (rc = compact(A, B, &n3, true)))
+        return rc;
+    counts->n_bnb_sift = n3;
+    if (n3 == 0)
+        return finish_empty();
+    // 3. apply_photometric_refinement_quads (:572-634): both cameras of every quad, keyframe image against the current image
+    // (undistorted), gradients of the current image; the quad's centres move where the refinement is valid
+    const size_t n3z = (size_t)n3;
+    ebvo_edge *kfeL = (ebvo_edge *)(base + o_kfe), *kfeR = kfeL + n3z, *cfeL = (ebvo_edge *)(base + o_cfe), *cfeR = cfeL + n3z;
+    double *initL = (double *)(base + o_init), *initR = initL + 2 * n3z, *dispL = (double *)(base + o_disp), *dispR = dispL + 2 * n3z;
+    double *scoreL = (double *)(base + o_score), *scoreR = scoreL + n3z;
+    uint8_t *validL = (uint8_t *)(base + o_valid), *validR = validL + n3z, *valid = validR + n3z;
+    int32_t *itersL = (int32_t *)(base + o_iters), *itersR = itersL + n3z;
+    ebvo_edge *cenL = (ebvo_edge *)(base + o_cen), *cenR = cenL + n3z;
+    if ((rc = ebvo_grow(ctx, s, s.grad_x, 2 * sizeof(float) * (size_t)h * w + 64)) ||
+        (rc = ebvo_grow(ctx, s, s.grad_y, 2 * sizeof(float) * (size_t)h * w + 64)) ||
+        (rc = refine_sobel_enqueue(ctx, s, s.im[0].img, h, w, w, nullptr, nullptr, s.grad_x.p)) ||
+        (rc = refine_sobel_enqueue(ctx, s, s.im[1].img, h, w, w, nullptr, nullptr, s.grad_y.p)) ||
+        (rc = glue_quad_refine_inputs_enqueue(ctx, s, ctx->kf_L, B.kf, cfL, B.cf, n3, kfeL, cfeL, initL)) ||
+        (rc = glue_quad_refine_inputs_enqueue(ctx, s, ctx->kf_R, B.kf, cfR, B.cf, n3, kfeR, cfeR, initR)) ||
+        // both cameras in one batch: items 0 .. n3 - 1 the left images, n3 .. 2 n3 - 1 the right ones (the arrays are contiguous)
+        (rc = refine_gn_temporal_enqueue(ctx, s, ctx->kf_imgL, s.im[0].img, s.grad_x.p, h, w, kfeL, cfeL, initL, 2 * (int64_t)n3,
+                                         P.gn.max_iter, P.gn.tol, P.gn.huber_delta, dispL, scoreL, validL, itersL, n3, ctx->kf_imgR,
+                                         s.im[1].img, s.grad_y.p)) ||
+        (rc = glue_quad_apply_refine_enqueue(ctx, s, kfeL, cfeL, dispL, validL, kfeR, cfeR, dispR, validR, n3, cenL, cenR, valid)))
+        return rc;
+    unsigned long long *d_nvalid = (unsigned long long *)(base + o_ok); // (the SIFT flags are no longer needed)
+    EBVO_HIP(ctx, hipMemsetAsync(d_nvalid, 0, sizeof *d_nvalid, st));
+    if ((rc = match_count_flags_enqueue(ctx, s, valid, n3, d_nvalid)))
+        return rc;
+    // 4. apply_temporal_edge_clustering_quads (:636-733): EdgeClusterer by orientation on the refined left edges of every row of
+    // two or more quads, the right centre and the record of a merged quad from its members
+    ebvo_edge *centres = (ebvo_edge *)(base + o_centres);
+    int32_t *cluster_of = (int32_t *)(base + o_clof);
+    Slot::TqFinal F;
+    F.rp = (int32_t *)(base + o_frp);
+    int32_t *fsrc = (int32_t *)(base + o_fsrc);
+    F.cf = (int32_t *)(base + o_fcf);
+    F.L = (ebvo_edge *)(base + o_fL);
+    F.R = (ebvo_edge *)(base + o_fR);
+    F.ncc = (double *)(base + o_fd);
+    int32_t n4 = 0;
+    if ((rc = glue_cluster_enqueue(ctx, s, cenL, B.rp, n_kf, 1, 1, cnt, centres, cluster_of)) || (rc = scan_counts(F.rp, &n4)))
+        return rc;
+    const size_t n4z = (size_t)n4;
+    F.sift = F.ncc + n4z;
+    F.sL = F.sift + n4z;
+    F.sR = F.sL + n4z;
+    F.valid = (uint8_t *)(base + o_fvalid);
+    if ((rc = glue_quad_cluster_post_enqueue(ctx, s, B.rp, n_kf, cnt, cluster_of, centres, cenL, cenR, F.rp, F.L, F.R, fsrc)))
+        return rc;
+    {
+        GlueGather g;
+        g.i_src[0] = B.cf, g.i_dst[0] = F.cf;
+        g.d_src[0] = B.simL, g.d_dst[0] = F.ncc;
+        g.d_src[1] = B.siftL, g.d_dst[1] = F.sift;
+        g.d_src[2] = scoreL, g.d_dst[2] = F.sL;
+        g.d_src[3] = scoreR, g.d_dst[3] = F.sR;
+        g.b_src[0] = valid, g.b_dst[0] = F.valid;
+        if ((rc = glue_gather_enqueue(ctx, s, fsrc, n4, g)))
+            return rc;
+    }
+    unsigned long long nvalid = 0;
+    EBVO_HIP(ctx, hipMemcpyAsync(s.h_result, d_nvalid, sizeof nvalid, hipMemcpyDeviceToHost, st));
+    EBVO_HIP(ctx, hipStreamSynchronize(st));
+    memcpy(&nvalid, s.h_result, sizeof nvalid);
+    counts->n_refined_valid = (int64_t)nvalid;
+    counts->n_final = n4;
+    s.tq_final.rp = F.rp;
+    s.tq_final.cf = F.cf;
+    s.tq_final.L = F.L;
+    s.tq_final.R = F.R;
+    s.tq_final.ncc = F.ncc;
+    s.tq_final.sift = F.sift;
+    s.tq_final.sL = F.sL;
+    s.tq_final.sR = F.sR;
+    s.tq_final.valid = F.valid;
+    s.tq_final.n = n4;
     return EBVO_OK;
 }
 
 extern "C" int ebvo_temporal_match(ebvo_ctx *ctx, int slot, const ebvo_temporal_params *p, ebvo_temporal_counts *counts)
 {
     Slot *sp;
-    if (!p || !counts || p->cell_size < 1 || !(p->grid_radius >= 0) || !(p->orient_thr_deg >= 0) || get_slot(ctx, slot, &sp))
+    if (!p || !counts || p->cell_size < 1 || !(p->grid_radius >= 0) || !(p->orient_thr_deg >= 0) || (p->stages & ~1) ||
+        (p->stages && (!(p->sift_thr > 0) || !(p->bnb_ncc >= 0) || !(p->bnb_sift >= 0) || p->gn.max_iter < 1 || !(p->gn.tol >= 0) ||
+                       !(p->gn.huber_delta > 0))) ||
+        get_slot(ctx, slot, &sp))
         return EBVO_ERR_ARG;
     Slot &s = *sp;
     if (!s.have_final || s.in_flight || ctx->kf_n < 0)
@@ -1984,6 +2250,43 @@ extern "C" int ebvo_temporal_match(ebvo_ctx *ctx, int slot, const ebvo_temporal_
     EBVO_HIP(ctx, hipStreamSynchronize(s.stream));
     memcpy(&kept, s.h_result, sizeof kept);
     counts->n_kept = (int64_t)kept;
+    s.tq_final.n = -1;
+    if (p->stages == 0)
+        return EBVO_OK;
+    return temporal_chain(ctx, s, *p, rp, col, quad_kf, sim_l, keep, n_kf, cfL, cfR, n_cf, (int64_t)kept, counts);
+}
+
+extern "C" int ebvo_temporal_fetch_final(ebvo_ctx *ctx, int slot, int32_t *row_ptr, int32_t *cf_index, ebvo_edge *left,
+                                         ebvo_edge *right, double *ncc_left, double *sift_left, double *score_left,
+                                         double *score_right, uint8_t *valid)
+{
+    Slot *sp;
+    if (get_slot(ctx, slot, &sp))
+        return EBVO_ERR_ARG;
+    Slot &s = *sp;
+    if (s.tq_final.n < 0 || s.in_flight)
+        return EBVO_ERR_STATE;
+    EBVO_HIP(ctx, hipSetDevice(ctx->device));
+    const Slot::TqFinal &F = s.tq_final;
+    const size_t nk1 = (size_t)s.tq_n_kf + 1, n = (size_t)F.n;
+    hipStream_t st = s.stream;
+    if (row_ptr)
+        EBVO_HIP(ctx, hipMemcpyAsync(row_ptr, F.rp, sizeof(int32_t) * nk1, hipMemcpyDeviceToHost, st));
+    if (n)
+    {
+        const struct
+        {
+            void *dst;
+            const void *src;
+            size_t bytes;
+        } copies[] = {{cf_index, F.cf, sizeof(int32_t) * n}, {left, F.L, sizeof(ebvo_edge) * n}, {right, F.R, sizeof(ebvo_edge) * n},
+                      {ncc_left, F.ncc, sizeof(double) * n}, {sift_left, F.sift, sizeof(double) * n},
+                      {score_left, F.sL, sizeof(double) * n}, {score_right, F.sR, sizeof(double) * n}, {valid, F.valid, n}};
+        for (const auto &c : copies)
+            if (c.dst)
+                EBVO_HIP(ctx, hipMemcpyAsync(c.dst, c.src, c.bytes, hipMemcpyDeviceToHost, st));
+    }
+    EBVO_HIP(ctx, hipStreamSynchronize(st));
     return EBVO_OK;
 }
 

@@ -118,6 +118,15 @@ struct Slot
     // matching workspace
     GrowBuf grad_x, grad_y, gn_xy, gn_out, gn_valid, gn_iters, gn_state, gn_lists, gn_pack; // photometric refinement (refine_kernels.hip)
     GrowBuf tq_i32, tq_cols, tq_f64, tq_u8, tq_cells; // temporal quads of the slot's pair against the keyframe
+    GrowBuf tq_chain;                                  // ... and what the stages after the NCC filter need
+    struct TqFinal                                     // the quads that leave the chain (pointers into tq_chain)
+    {
+        int32_t *rp = nullptr, *cf = nullptr;
+        ebvo_edge *L = nullptr, *R = nullptr;
+        double *ncc = nullptr, *sift = nullptr, *sL = nullptr, *sR = nullptr;
+        uint8_t *valid = nullptr;
+        int64_t n = -1;
+    } tq_final;
     int tq_n_kf = 0;
     int64_t tq_n = -1;                       // -1: none
     GrowBuf sift_img, sift_desc, sift_f32, sift_dist; // SIFT: blurred levels, descriptor banks, per-pair distances (sift_kernels.hip)
@@ -164,6 +173,9 @@ struct ebvo_ctx
     ebvo_edge *kf_L = nullptr, *kf_R = nullptr;
     float *kf_Ln = nullptr, *kf_Rn = nullptr;   // [n][2][49] normalised patches (left image raw, right image undistorted)
     uint8_t *kf_Lf = nullptr, *kf_Rf = nullptr; // [n][2] sentinel flags
+    uint8_t *kf_Ld = nullptr, *kf_Rd = nullptr; // [n][2][128] SIFT descriptors of the mates (left TOED edge / final right edge)
+    uint8_t *kf_imgL = nullptr, *kf_imgR = nullptr; // the keyframe's undistorted images (photometric refinement of the quads)
+    size_t kf_img_bytes = 0;
     size_t kf_cap = 0;
     bool undist_on = false;    // ebvo_stereo_set_undistort
     ebvo_undistort_params undist{};
@@ -266,6 +278,32 @@ int ebvo_device_scan(ebvo_ctx *ctx, Slot &s, const int32_t *in, int32_t *out, in
 // glue_kernels.hip
 int glue_bnb_enqueue(ebvo_ctx *ctx, Slot &s, const int32_t *d_row_ptr, int nL, const double *d_scores, double thr,
                      int higher_is_better, int32_t *d_new_count, int32_t *d_order);
+// temporal quads after the NCC filter
+struct GlueGather // null-terminated lists of (source, destination) arrays gathered through one index list
+{
+    const int32_t *i_src[4] = {nullptr, nullptr, nullptr, nullptr};
+    int32_t *i_dst[4] = {nullptr, nullptr, nullptr, nullptr};
+    const double *d_src[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    double *d_dst[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    const uint8_t *b_src[2] = {nullptr, nullptr};
+    uint8_t *b_dst[2] = {nullptr, nullptr};
+    const ebvo_edge *e_src[2] = {nullptr, nullptr};
+    ebvo_edge *e_dst[2] = {nullptr, nullptr};
+};
+int glue_row_index_enqueue(ebvo_ctx *ctx, Slot &s, const int32_t *d_rp_in, const int32_t *d_cnt, const int32_t *d_order,
+                           const int32_t *d_rp_out, int nL, int32_t *d_idx);
+int glue_gather_enqueue(ebvo_ctx *ctx, Slot &s, const int32_t *d_idx, int64_t n, const GlueGather &g);
+int glue_quad_refine_inputs_enqueue(ebvo_ctx *ctx, Slot &s, const ebvo_edge *d_kfE, const int32_t *d_quad_kf,
+                                    const ebvo_edge *d_cfE, const int32_t *d_quad_cf, int64_t n, ebvo_edge *d_kf_out,
+                                    ebvo_edge *d_cf_out, double *d_init);
+int glue_quad_apply_refine_enqueue(ebvo_ctx *ctx, Slot &s, const ebvo_edge *d_kfL, const ebvo_edge *d_cfL, const double *d_dispL,
+                                   const uint8_t *d_validL, const ebvo_edge *d_kfR, const ebvo_edge *d_cfR,
+                                   const double *d_dispR, const uint8_t *d_validR, int64_t n, ebvo_edge *d_cenL,
+                                   ebvo_edge *d_cenR, uint8_t *d_valid);
+int glue_quad_cluster_post_enqueue(ebvo_ctx *ctx, Slot &s, const int32_t *d_rp_in, int nL, const int32_t *d_new_count,
+                                   const int32_t *d_cluster_of, const ebvo_edge *d_centres, const ebvo_edge *d_cenL,
+                                   const ebvo_edge *d_cenR, const int32_t *d_rp_out, ebvo_edge *d_outL, ebvo_edge *d_outR,
+                                   int32_t *d_src);
 int glue_keep_best_enqueue(ebvo_ctx *ctx, Slot &s, const int32_t *d_row_ptr, int nL, const double *d_scores,
                            int32_t *d_new_count, int32_t *d_order);
 int glue_shift_enqueue(ebvo_ctx *ctx, Slot &s, const ebvo_edge *d_cand, const double *d_lines, const int32_t *d_pair_left,
@@ -299,7 +337,8 @@ int refine_finalize_pairs_enqueue(ebvo_ctx *ctx, Slot &s, const double *K_left, 
 int refine_gn_temporal_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_imgK, const uint8_t *d_imgC, const void *d_gxy,
                                int h, int w, const ebvo_edge *d_kf, const ebvo_edge *d_cf, const double *d_init, int64_t n,
                                int max_iter, double tol, double huber, double *d_disp, double *d_score, uint8_t *d_valid,
-                               int32_t *d_iters);
+                               int32_t *d_iters, int64_t n_first = -1, const uint8_t *d_imgK2 = nullptr,
+                               const uint8_t *d_imgC2 = nullptr, const void *d_gxy2 = nullptr);
 // sift_kernels.hip
 int sift_base_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_img, int h, int w, int pitch, float *d_tmp, float *d_base);
 int sift_descriptors_enqueue(ebvo_ctx *ctx, Slot &s, const float *d_base, int h, int w, const ebvo_edge *d_edges, int n,

@@ -32,6 +32,11 @@ __device__ __noinline__ void sort_long_row(int32_t *ord, int n, const double *sc
 __global__ void bnb_kernel(const int32_t *__restrict__ row_ptr, int nL, const double *__restrict__ scores, double thr,
                            int higher, int32_t *__restrict__ new_count, int32_t *__restrict__ order)
 {
+    // bit 1 of `higher`: the temporal variant (Temporal_Matches::apply_best_nearly_best_filtering_quads,
+    // src/Temporal_Matches.cpp:517-570) rebuilds every row of two or more candidates in SORTED order, whether or not
+    // something was dropped; the stereo test leaves an unpruned row untouched (src/Stereo_Matches.cpp:840)
+    const bool always_sorted = (higher & 2) != 0;
+    higher &= 1;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nL; i += gridDim.x * blockDim.x)
     {
         const int b = row_ptr[i], n = row_ptr[i + 1] - b;
@@ -73,7 +78,7 @@ __global__ void bnb_kernel(const int32_t *__restrict__ row_ptr, int nL, const do
         }
         if (keep < n)
             new_count[i] = keep;
-        else
+        else if (!always_sorted)
             for (int k = 0; k < n; ++k) // nothing dropped: the reference leaves the row untouched (:840)
                 ord[k] = b + k;
     }
@@ -509,6 +514,235 @@ __global__ void final_pairs_kernel(const int32_t *__restrict__ rp_in, const int3
 inline unsigned grid_for(int64_t n) { return (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048); }
 
 } // namespace
+
+// ---- temporal quads after the NCC filter (Temporal_Matches::get_Temporal_Edge_Pairs_from_Quads, :196-215) ---------
+namespace
+{
+// source index of every surviving pair of a row selection: idx[rp_out[i] + k] = order[rp_in[i] + k], k < cnt[i]
+__global__ void row_index_kernel(const int32_t *__restrict__ rp_in, const int32_t *__restrict__ cnt,
+                                 const int32_t *__restrict__ order, const int32_t *__restrict__ rp_out, int nL,
+                                 int32_t *__restrict__ idx)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nL; i += gridDim.x * blockDim.x)
+        for (int k = 0; k < cnt[i]; ++k)
+            idx[rp_out[i] + k] = order[rp_in[i] + k];
+}
+
+struct GatherArgs
+{
+    const int32_t *i_src[4];
+    int32_t *i_dst[4];
+    const double *d_src[6];
+    double *d_dst[6];
+    const uint8_t *b_src[2];
+    uint8_t *b_dst[2];
+    const ebvo_edge *e_src[2];
+    ebvo_edge *e_dst[2];
+    int ni, nd, nb, ne;
+};
+__global__ void gather_kernel(GatherArgs G, const int32_t *__restrict__ idx, int64_t n)
+{
+    for (int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x)
+    {
+        const int32_t k = idx[j];
+        for (int a = 0; a < G.ni; ++a)
+            G.i_dst[a][j] = G.i_src[a][k];
+        for (int a = 0; a < G.nd; ++a)
+            G.d_dst[a][j] = G.d_src[a][k];
+        for (int a = 0; a < G.nb; ++a)
+            G.b_dst[a][j] = G.b_src[a][k];
+        for (int a = 0; a < G.ne; ++a)
+            G.e_dst[a][j] = G.e_src[a][k];
+    }
+}
+
+// apply_photometric_refinement_quads, the per-quad inputs of one camera (:600-603): keyframe edge, current-frame edge,
+// initial displacement = keyframe location - current-frame location
+__global__ void quad_refine_inputs_kernel(const ebvo_edge *__restrict__ kfE, const int32_t *__restrict__ quad_kf,
+                                          const ebvo_edge *__restrict__ cfE, const int32_t *__restrict__ quad_cf, int64_t n,
+                                          ebvo_edge *__restrict__ kf_out, ebvo_edge *__restrict__ cf_out,
+                                          double *__restrict__ init)
+{
+    for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x)
+    {
+        const ebvo_edge k = kfE[quad_kf[q]], c = cfE[quad_cf[q]];
+        kf_out[q] = k;
+        cf_out[q] = c;
+        init[2 * q] = k.x - c.x;
+        init[2 * q + 1] = k.y - c.y;
+    }
+}
+
+// (:620-631): the cluster centres of a quad move to keyframe location - refined displacement where the refinement of that
+// camera is valid; the orientation stays the current-frame mate's; the quad is valid if both cameras are
+__global__ void quad_apply_refine_kernel(const ebvo_edge *__restrict__ kfL, const ebvo_edge *__restrict__ cfL,
+                                         const double *__restrict__ dispL, const uint8_t *__restrict__ validL,
+                                         const ebvo_edge *__restrict__ kfR, const ebvo_edge *__restrict__ cfR,
+                                         const double *__restrict__ dispR, const uint8_t *__restrict__ validR, int64_t n,
+                                         ebvo_edge *__restrict__ cenL, ebvo_edge *__restrict__ cenR,
+                                         uint8_t *__restrict__ valid)
+{
+    for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x)
+    {
+        ebvo_edge l = cfL[q], r = cfR[q];
+        if (validL[q] == 1)
+        {
+            l.x = kfL[q].x - dispL[2 * q];
+            l.y = kfL[q].y - dispL[2 * q + 1];
+        }
+        if (validR[q] == 1)
+        {
+            r.x = kfR[q].x - dispR[2 * q];
+            r.y = kfR[q].y - dispR[2 * q + 1];
+        }
+        cenL[q] = l;
+        cenR[q] = r;
+        valid[q] = (validL[q] == 1 && validR[q] == 1) ? 1 : 0;
+    }
+}
+
+// apply_temporal_edge_clustering_quads after EdgeClusterer::performClustering (:660-722), one thread per keyframe mate.
+// Cluster c of the row: its members in index order; for every member the FIRST candidate of the row at the smallest
+// distance from it (the member itself unless an earlier candidate has the same location) supplies the right edge and the
+// record the merged quad is copied from (`best_idx` = the last member's); the right centre is that edge, or the plain
+// mean of the members' right edges (location and orientation).  Rows of fewer than two candidates stay as they are.
+__global__ void quad_cluster_post_kernel(const int32_t *__restrict__ rp_in, int nL, const int32_t *__restrict__ new_count,
+                                         const int32_t *__restrict__ cluster_of, const ebvo_edge *__restrict__ centres,
+                                         const ebvo_edge *__restrict__ cenL, const ebvo_edge *__restrict__ cenR,
+                                         const int32_t *__restrict__ rp_out, ebvo_edge *__restrict__ outL,
+                                         ebvo_edge *__restrict__ outR, int32_t *__restrict__ src)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nL; i += gridDim.x * blockDim.x)
+    {
+        const int b = rp_in[i], n = rp_in[i + 1] - b, o = rp_out[i];
+        if (n < 2)
+        {
+            if (n == 1)
+            {
+                outL[o] = cenL[b];
+                outR[o] = cenR[b];
+                src[o] = b;
+            }
+            continue;
+        }
+        for (int c = 0; c < new_count[i]; ++c)
+        {
+            double sx = 0, sy = 0, st = 0;
+            int members = 0, best = -1;
+            ebvo_edge only;
+            for (int m = 0; m < n; ++m)
+            {
+                if (cluster_of[b + m] != c)
+                    continue;
+                int closest = -1;
+                double dmin = 1.7976931348623157e308; // std::numeric_limits<double>::max()
+                for (int k = 0; k < n; ++k)
+                {
+                    const double dx = cenL[b + m].x - cenL[b + k].x, dy = cenL[b + m].y - cenL[b + k].y;
+                    const double d = sqrt(dx * dx + dy * dy); // cv::norm(Point2d)
+                    if (d < dmin)
+                    {
+                        dmin = d;
+                        closest = k;
+                    }
+                }
+                if (closest < 0)
+                    continue; // a NaN location: no candidate is "closer" (the member contributes nothing, :684)
+                const ebvo_edge r = cenR[b + closest];
+                sx += r.x;
+                sy += r.y;
+                st += r.theta;
+                only = r;
+                ++members;
+                best = closest;
+            }
+            ebvo_edge right = only;
+            if (members > 1)
+            {
+                right.x = sx / members;
+                right.y = sy / members;
+                right.theta = st / members;
+            }
+            // (a cluster none of whose members found a closest candidate is skipped by the reference; its slot is marked)
+            outL[o + c] = centres[b + c];
+            if (best >= 0)
+                outR[o + c] = right;
+            src[o + c] = best >= 0 ? b + best : -1;
+        }
+    }
+}
+} // namespace
+
+int glue_row_index_enqueue(ebvo_ctx *ctx, Slot &s, const int32_t *d_rp_in, const int32_t *d_cnt, const int32_t *d_order,
+                           const int32_t *d_rp_out, int nL, int32_t *d_idx)
+{
+    if (nL <= 0)
+        return EBVO_OK;
+    ProfScope ps(ctx, s, K_MISC);
+    hipLaunchKernelGGL(row_index_kernel, dim3(grid_for(nL)), dim3(256), 0, s.stream, d_rp_in, d_cnt, d_order, d_rp_out, nL, d_idx);
+    EBVO_HIP(ctx, hipGetLastError());
+    return EBVO_OK;
+}
+
+int glue_gather_enqueue(ebvo_ctx *ctx, Slot &s, const int32_t *d_idx, int64_t n, const GlueGather &g)
+{
+    if (n <= 0)
+        return EBVO_OK;
+    GatherArgs G = {};
+    for (int a = 0; a < 4 && g.i_src[a]; ++a, ++G.ni)
+        G.i_src[a] = g.i_src[a], G.i_dst[a] = g.i_dst[a];
+    for (int a = 0; a < 6 && g.d_src[a]; ++a, ++G.nd)
+        G.d_src[a] = g.d_src[a], G.d_dst[a] = g.d_dst[a];
+    for (int a = 0; a < 2 && g.b_src[a]; ++a, ++G.nb)
+        G.b_src[a] = g.b_src[a], G.b_dst[a] = g.b_dst[a];
+    for (int a = 0; a < 2 && g.e_src[a]; ++a, ++G.ne)
+        G.e_src[a] = g.e_src[a], G.e_dst[a] = g.e_dst[a];
+    ProfScope ps(ctx, s, K_MISC);
+    hipLaunchKernelGGL(gather_kernel, dim3(grid_for(n)), dim3(256), 0, s.stream, G, d_idx, n);
+    EBVO_HIP(ctx, hipGetLastError());
+    return EBVO_OK;
+}
+
+int glue_quad_refine_inputs_enqueue(ebvo_ctx *ctx, Slot &s, const ebvo_edge *d_kfE, const int32_t *d_quad_kf,
+                                    const ebvo_edge *d_cfE, const int32_t *d_quad_cf, int64_t n, ebvo_edge *d_kf_out,
+                                    ebvo_edge *d_cf_out, double *d_init)
+{
+    if (n <= 0)
+        return EBVO_OK;
+    ProfScope ps(ctx, s, K_MISC);
+    hipLaunchKernelGGL(quad_refine_inputs_kernel, dim3(grid_for(n)), dim3(256), 0, s.stream, d_kfE, d_quad_kf, d_cfE, d_quad_cf, n,
+                       d_kf_out, d_cf_out, d_init);
+    EBVO_HIP(ctx, hipGetLastError());
+    return EBVO_OK;
+}
+
+int glue_quad_apply_refine_enqueue(ebvo_ctx *ctx, Slot &s, const ebvo_edge *d_kfL, const ebvo_edge *d_cfL, const double *d_dispL,
+                                   const uint8_t *d_validL, const ebvo_edge *d_kfR, const ebvo_edge *d_cfR,
+                                   const double *d_dispR, const uint8_t *d_validR, int64_t n, ebvo_edge *d_cenL,
+                                   ebvo_edge *d_cenR, uint8_t *d_valid)
+{
+    if (n <= 0)
+        return EBVO_OK;
+    ProfScope ps(ctx, s, K_MISC);
+    hipLaunchKernelGGL(quad_apply_refine_kernel, dim3(grid_for(n)), dim3(256), 0, s.stream, d_kfL, d_cfL, d_dispL, d_validL, d_kfR,
+                       d_cfR, d_dispR, d_validR, n, d_cenL, d_cenR, d_valid);
+    EBVO_HIP(ctx, hipGetLastError());
+    return EBVO_OK;
+}
+
+int glue_quad_cluster_post_enqueue(ebvo_ctx *ctx, Slot &s, const int32_t *d_rp_in, int nL, const int32_t *d_new_count,
+                                   const int32_t *d_cluster_of, const ebvo_edge *d_centres, const ebvo_edge *d_cenL,
+                                   const ebvo_edge *d_cenR, const int32_t *d_rp_out, ebvo_edge *d_outL, ebvo_edge *d_outR,
+                                   int32_t *d_src)
+{
+    if (nL <= 0)
+        return EBVO_OK;
+    ProfScope ps(ctx, s, K_MISC);
+    hipLaunchKernelGGL(quad_cluster_post_kernel, dim3(grid_for(nL)), dim3(256), 0, s.stream, d_rp_in, nL, d_new_count,
+                       d_cluster_of, d_centres, d_cenL, d_cenR, d_rp_out, d_outL, d_outR, d_src);
+    EBVO_HIP(ctx, hipGetLastError());
+    return EBVO_OK;
+}
 
 int glue_bnb_enqueue(ebvo_ctx *ctx, Slot &s, const int32_t *d_row_ptr, int nL, const double *d_scores, double thr,
                      int higher_is_better, int32_t *d_new_count, int32_t *d_order)

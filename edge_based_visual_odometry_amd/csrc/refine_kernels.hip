@@ -516,6 +516,11 @@ struct Gn2Args
 {
     const uint8_t *imgK, *imgC;
     const float2 *gxy; // interleaved Sobel planes of the current-frame image
+    // items n_first .. n - 1 belong to a second camera (the right images of the quads): both cameras of a batch of quads
+    // run in the same launches (a launch of a few thousand items lasts ~100 us whatever their number)
+    const uint8_t *imgK2, *imgC2;
+    const float2 *gxy2;
+    int64_t n_first;
     int h, w;
     const ebvo_edge *kf, *cf;
     const double *init; // n x 2
@@ -568,6 +573,8 @@ __global__ __launch_bounds__(256) void gn2_init_kernel(Gn2Args A)
     for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < A.n; k += (int64_t)gridDim.x * blockDim.x)
     {
         const ebvo_edge ke = A.kf[k];
+        const bool second = k >= A.n_first;
+        const uint8_t *__restrict__ imgK = second ? A.imgK2 : A.imgK;
         double st, ct, stc, ctc;
         ebvo_sincos(ke.theta, &st, &ct);
         ebvo_sincos(A.cf[k].theta, &stc, &ctc);
@@ -581,7 +588,7 @@ __global__ __launch_bounds__(256) void gn2_init_kernel(Gn2Args A)
             for (int i = -3; i <= 3; ++i)
 #pragma unroll
                 for (int j = -3; j <= 3; ++j)
-                    sum += (double)sample_u8(A.imgK, w, w, h, cx + ct * i - st * j, cy + st * i + ct * j);
+                    sum += (double)sample_u8(imgK, w, w, h, cx + ct * i - st * j, cy + st * i + ct * j);
             A.mean_l[(size_t)sd * A.n + k] = sum / 49;
         }
         A.sc[k] = st;
@@ -613,6 +620,9 @@ __global__ __launch_bounds__(256) void gn2_iter_kernel(Gn2Args A, int it)
         {
             k = lin[idx];
             const ebvo_edge ke = A.kf[k];
+            const bool second = k >= A.n_first;
+            const uint8_t *__restrict__ imgK = second ? A.imgK2 : A.imgK, *__restrict__ imgC = second ? A.imgC2 : A.imgC;
+            const float2 *__restrict__ gxy = second ? A.gxy2 : A.gxy;
             const double st = A.sc[k], ct = A.sc[A.n + k], stc = A.sc[2 * A.n + k], ctc = A.sc[3 * A.n + k];
             const double nx = -st, ny = ct, ncx = -stc, ncy = ctc, side = (7 / 2.0) + 1.0;
             const double meanL[2] = {A.mean_l[k], A.mean_l[A.n + k]};
@@ -628,7 +638,7 @@ __global__ __launch_bounds__(256) void gn2_iter_kernel(Gn2Args A, int it)
                 for (int i = -3; i <= 3; ++i)
 #pragma unroll
                     for (int j = -3; j <= 3; ++j)
-                        sum += (double)sample_u8(A.imgC, w, w, h, cx + ctc * i - stc * j, cy + stc * i + ctc * j);
+                        sum += (double)sample_u8(imgC, w, w, h, cx + ctc * i - stc * j, cy + stc * i + ctc * j);
                 meanR[sd] = sum / 49;
             }
             double H00 = 0, H10 = 0, H11 = 0, b0 = 0, b1 = 0, cost = 0;
@@ -642,15 +652,15 @@ __global__ __launch_bounds__(256) void gn2_iter_kernel(Gn2Args A, int it)
 #pragma unroll 1
                     for (int j = -3; j <= 3; ++j)
                     {
-                        const double Lf = (double)sample_u8(A.imgK, w, w, h, lcx + ct * i - st * j, lcy + st * i + ct * j);
+                        const double Lf = (double)sample_u8(imgK, w, w, h, lcx + ct * i - st * j, lcy + st * i + ct * j);
                         int x0, x1, y0, y1;
                         double wa, wb;
                         tap_at(cx + ctc * i - stc * j, cy + stc * i + ctc * j, w, h, x0, x1, y0, y1, wa, wb);
                         const int xa = min(x0, w - 2);
                         const bool shifted = xa != x0;
-                        const Corners ci = corners_u8(A.imgC, w, w, x0, x1, y0, y1);
-                        const float4 g0 = *reinterpret_cast<const float4 *>(A.gxy + (size_t)y0 * w + xa);
-                        const float4 g1 = *reinterpret_cast<const float4 *>(A.gxy + (size_t)y1 * w + xa);
+                        const Corners ci = corners_u8(imgC, w, w, x0, x1, y0, y1);
+                        const float4 g0 = *reinterpret_cast<const float4 *>(gxy + (size_t)y0 * w + xa);
+                        const float4 g1 = *reinterpret_cast<const float4 *>(gxy + (size_t)y1 * w + xa);
                         const double Rf = (double)blend(wa, wb, ci.v00, ci.v10, ci.v01, ci.v11);
                         const double J0 = (double)blend(wa, wb, shifted ? g0.z : g0.x, g0.z, shifted ? g1.z : g1.x, g1.z);
                         const double J1 = (double)blend(wa, wb, shifted ? g0.w : g0.y, g0.w, shifted ? g1.w : g1.y, g1.w);
@@ -899,7 +909,8 @@ int refine_gn_stereo_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_imgL, cons
 int refine_gn_temporal_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_imgK, const uint8_t *d_imgC, const void *d_gxy,
                                int h, int w, const ebvo_edge *d_kf, const ebvo_edge *d_cf, const double *d_init, int64_t n,
                                int max_iter, double tol, double huber, double *d_disp, double *d_score, uint8_t *d_valid,
-                               int32_t *d_iters)
+                               int32_t *d_iters, int64_t n_first, const uint8_t *d_imgK2, const uint8_t *d_imgC2,
+                               const void *d_gxy2)
 {
     if (n <= 0)
         return EBVO_OK;
@@ -916,6 +927,10 @@ int refine_gn_temporal_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_imgK, co
     A.imgK = d_imgK;
     A.imgC = d_imgC;
     A.gxy = (const float2 *)d_gxy;
+    A.n_first = (n_first >= 0 && d_imgK2) ? n_first : n; // items n_first .. n - 1 use the second image set
+    A.imgK2 = d_imgK2 ? d_imgK2 : d_imgK;
+    A.imgC2 = d_imgC2 ? d_imgC2 : d_imgC;
+    A.gxy2 = d_gxy2 ? (const float2 *)d_gxy2 : (const float2 *)d_gxy;
     A.h = h;
     A.w = w;
     A.kf = d_kf;

@@ -31,8 +31,9 @@
 extern "C" {
 #endif
 
-#define EBVO_ABI_VERSION 3 /* 2: photometric refinement, stage glue, finalisation, resident chain; 3: pinned result views,
-                              undistortion, SIFT descriptors, SIFT stages of the chain */
+#define EBVO_ABI_VERSION 4 /* 2: photometric refinement, stage glue, finalisation, resident chain; 3: pinned result views,
+                              undistortion, SIFT descriptors, SIFT stages of the chain; 4: the temporal chain after the
+                              NCC filter (ebvo_temporal_params / _counts grew, ebvo_temporal_fetch_final) */
 
 typedef struct ebvo_ctx ebvo_ctx;
 
@@ -405,22 +406,37 @@ int ebvo_ncc_quads(ebvo_ctx *ctx, const float *kfL, const float *kfR, const floa
 typedef struct ebvo_temporal_params
 {
     int cell_size;         /* GRID_SIZE 15, include/definitions.h:45 */
-    int reserved;
+    int stages;            /* 0: through the NCC filter (src/Temporal_Matches.cpp:184-192);
+                              1: the rest of get_Temporal_Edge_Pairs_from_Quads as well (:196-215): SIFT filter, Best-Nearly-Best
+                                 on the NCC and on the SIFT scores, photometric refinement of both cameras, edge clustering */
     double grid_radius;    /* 30, src/Temporal_Matches.cpp:184 */
     double orient_thr_deg; /* 10, :188 */
     double ncc_thr;        /* EBVO_NCC_THRESH_TEMPORAL 0.8, :192 */
+    double sift_thr;       /* 200, :196: both min-of-four descriptor distances (left and right camera) below it */
+    double bnb_ncc;        /* 0.8, :200 */
+    double bnb_sift;       /* 0.8, :204 */
+    ebvo_gn_params gn;     /* 20 iterations, 1e-3, Huber 3.0, :612-617 */
 } ebvo_temporal_params;
 typedef struct ebvo_temporal_counts
 {
     int32_t n_kf, n_cf;   /* keyframe / current-frame mates */
     int64_t n_candidates; /* quads after the grid and orientation filters */
     int64_t n_kept;       /* quads with both NCC maxima above the threshold */
+    int64_t n_sift, n_bnb_ncc, n_bnb_sift; /* stages = 1: quads surviving each later filter */
+    int64_t n_refined_valid;               /* quads whose refinement is valid in both cameras (they all stay, :618) */
+    int64_t n_final;                       /* quads after the edge clustering */
 } ebvo_temporal_counts;
 void ebvo_temporal_default_params(ebvo_temporal_params *p);
 /* the final mates of `slot` (after ebvo_stereo_finalize) become the keyframe (src/Pipeline.cpp:133-138: frame 0) */
 int ebvo_temporal_set_keyframe(ebvo_ctx *ctx, int slot);
 /* quads of the keyframe against the final mates of `slot` */
 int ebvo_temporal_match(ebvo_ctx *ctx, int slot, const ebvo_temporal_params *p, ebvo_temporal_counts *counts);
+/* The quads that leave the whole chain (stages = 1), CSR over the keyframe mates: row_ptr n_kf + 1; per final quad the
+ * current-frame mate it is copied from (`best_idx` of :713), the left cluster centre (EdgeClusterer's weighted average, or
+ * the refined left edge of an unclustered quad), the right centre (the mean of the members' refined right edges), the left
+ * NCC and SIFT scores, the final residuals of both refinements and refine_validity.  Any pointer may be NULL. */
+int ebvo_temporal_fetch_final(ebvo_ctx *ctx, int slot, int32_t *row_ptr, int32_t *cf_index, ebvo_edge *left, ebvo_edge *right,
+                              double *ncc_left, double *sift_left, double *score_left, double *score_right, uint8_t *valid);
 /* row_ptr: n_kf + 1; col_idx / sim_left / sim_right / keep: n_candidates.  Any pointer may be NULL. */
 int ebvo_temporal_fetch(ebvo_ctx *ctx, int slot, int32_t *row_ptr, int32_t *col_idx, double *sim_left, double *sim_right,
                         uint8_t *keep);

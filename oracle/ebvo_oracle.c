@@ -1045,6 +1045,10 @@ void orc_finalize_pairs(const double *Kl, const double *Kr, const double *R21, c
 void orc_bnb_test(const int32_t *row_ptr, int nL, const double *scores, double thr, int higher_is_better,
                   int32_t *new_count, int32_t *order)
 {
+    /* bit 1: Temporal_Matches::apply_best_nearly_best_filtering_quads (src/Temporal_Matches.cpp:517-570) -- the same test,
+     * but every row of two or more candidates is rebuilt in sorted order whether or not something was dropped (:553-558) */
+    const int always_sorted = (higher_is_better & 2) != 0;
+    higher_is_better &= 1;
     for (int i = 0; i < nL; i++)
     {
         const int b = row_ptr[i], n = row_ptr[i + 1] - b;
@@ -1087,7 +1091,7 @@ void orc_bnb_test(const int32_t *row_ptr, int nL, const double *scores, double t
         }
         if (keep < n)
             new_count[i] = keep;
-        else
+        else if (!always_sorted)
             for (int k = 0; k < n; k++)
                 ord[k] = b + k; /* untouched row */
     }

@@ -167,12 +167,12 @@ def gn_refine_temporal(imgKF, imgCF, kf, cf, init_disp, max_iter=20, tol=1e-3, h
     return out
 
 
-def bnb_test(row_ptr, scores, ratio_thr, higher_is_better=True):
+def bnb_test(row_ptr, scores, ratio_thr, higher_is_better=True, always_sorted=False):
     row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int32)
     scores = np.ascontiguousarray(scores, dtype=np.float64)
     cnt = np.zeros(len(row_ptr) - 1, dtype=np.int32)
     order = np.full(len(scores), -1, dtype=np.int32)
-    lib().orc_bnb_test(_p(row_ptr), len(row_ptr) - 1, _p(scores), C.c_double(ratio_thr), int(higher_is_better), _p(cnt),
+    lib().orc_bnb_test(_p(row_ptr), len(row_ptr) - 1, _p(scores), C.c_double(ratio_thr), int(higher_is_better) | (2 if always_sorted else 0), _p(cnt),
                        _p(order))
     return cnt, order
 

@@ -114,3 +114,103 @@ def stereo_edge_pairs(left_img, right_img, F, calib=None, bnb_ratio=0.9, ncc_thr
     rows16 = orc.finalize_pairs(*calib, L[left_index], right) if calib is not None else None
     return dict(counts=counts, left_index=left_index, right=right, score=fscore, rows=rows16, left=L, right_edges=R,
                 lines=lines)
+
+
+def _select_rows(row_ptr, cnt, order):
+    """(row_ptr of the selection, source index of every selected pair): order[row_ptr[i] + k], k < cnt[i]"""
+    rp = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int32)
+    idx = np.concatenate([order[row_ptr[i]:row_ptr[i] + cnt[i]] for i in range(len(cnt))] or [np.zeros(0, np.int32)]).astype(np.int64)
+    return rp, idx
+
+
+def temporal_edge_pairs(kfL, kfR, cfL, cfR, kf_imgs, cf_imgs, rp, ci, sim_left, keep, sift_thr=200.0, bnb_ncc=0.8,
+                        bnb_sift=0.8, max_iter=20, tol=1e-3, huber=3.0):
+    """Temporal_Matches::get_Temporal_Edge_Pairs_from_Quads after the NCC filter (src/Temporal_Matches.cpp:196-215) as a chain
+    of oracle functions.  kfL / kfR / cfL / cfR: the stereo mates (left TOED edge, final right edge) of the keyframe and of
+    the current frame; kf_imgs / cf_imgs = (undistorted left, undistorted right); rp / ci: candidate quads per keyframe mate;
+    sim_left / keep: their left NCC maximum and the NCC keep flag."""
+    n_kf = len(kfL)
+    # SIFT descriptors of the mates: left edge on the undistorted left image, final right edge on the undistorted right one
+    dkL, dkR = orc.sift_descriptors(kf_imgs[0], kfL), orc.sift_descriptors(kf_imgs[1], kfR)
+    dcL, dcR = orc.sift_descriptors(cf_imgs[0], cfL), orc.sift_descriptors(cf_imgs[1], cfR)
+    # the quads that passed the NCC filter
+    cnt = np.array([int(keep[rp[i]:rp[i + 1]].sum()) for i in range(n_kf)], dtype=np.int32)
+    order = np.full(len(ci), -1, dtype=np.int32)
+    for i in range(n_kf):
+        k = np.flatnonzero(keep[rp[i]:rp[i + 1]]) + rp[i]
+        order[rp[i]:rp[i] + len(k)] = k
+    rp0, idx = _select_rows(rp, cnt, order)
+    cf, simL = ci[idx], sim_left[idx]
+    counts = {}
+    # apply_SIFT_filtering_quads (:471-515)
+    siftL, siftR = orc.sift_min_distances(dkL, dcL[cf], rp0), orc.sift_min_distances(dkR, dcR[cf], rp0)
+    ok = (siftL < sift_thr) & (siftR < sift_thr)
+    cnt = np.array([int(ok[rp0[i]:rp0[i + 1]].sum()) for i in range(n_kf)], dtype=np.int32)
+    order = np.full(len(cf), -1, dtype=np.int32)
+    for i in range(n_kf):
+        k = np.flatnonzero(ok[rp0[i]:rp0[i + 1]]) + rp0[i]
+        order[rp0[i]:rp0[i] + len(k)] = k
+    rp1, idx = _select_rows(rp0, cnt, order)
+    cf, simL, siftL, siftR = cf[idx], simL[idx], siftL[idx], siftR[idx]
+    counts["n_sift"] = len(cf)
+    # apply_best_nearly_best_filtering_quads on the NCC, then on the SIFT scores (:517-570)
+    for name, thr, scores_of, higher in (("n_bnb_ncc", bnb_ncc, lambda: simL, True), ("n_bnb_sift", bnb_sift, lambda: siftL, False)):
+        c, o = orc.bnb_test(rp1, scores_of(), thr, higher, always_sorted=True)
+        rp1, idx = _select_rows(rp1, c, o)
+        cf, simL, siftL, siftR = cf[idx], simL[idx], siftL[idx], siftR[idx]
+        counts[name] = len(cf)
+    kf = np.repeat(np.arange(n_kf), np.diff(rp1))
+    # apply_photometric_refinement_quads (:572-634)
+    out = {}
+    cen = {}
+    for cam, kE, cE, kimg, cimg in (("L", kfL, cfL, kf_imgs[0], cf_imgs[0]), ("R", kfR, cfR, kf_imgs[1], cf_imgs[1])):
+        ke, ce = kE[kf], cE[cf]
+        init = np.stack([ke["x"] - ce["x"], ke["y"] - ce["y"]], 1)
+        r = orc.gn_refine_temporal(kimg, cimg, ke, ce, init, max_iter, tol, huber)
+        c = ce.copy()
+        v = r["validity"] == 1
+        c["x"][v] = ke["x"][v] - r["disp"][v, 0]
+        c["y"][v] = ke["y"][v] - r["disp"][v, 1]
+        out[cam], cen[cam] = r, c
+    valid = ((out["L"]["validity"] == 1) & (out["R"]["validity"] == 1)).astype(np.uint8)
+    counts["n_refined_valid"] = int(valid.sum())
+    # apply_temporal_edge_clustering_quads (:636-733)
+    ncl, centres, cluster_of = orc.cluster_rows(cen["L"], rp1, True, True)
+    f_rows, f_src, f_L, f_R = [0], [], [], []
+    for i in range(n_kf):
+        b, n = rp1[i], rp1[i + 1] - rp1[i]
+        if n < 2:
+            for k in range(n):
+                f_src.append(b)
+                f_L.append(cen["L"][b])
+                f_R.append(cen["R"][b])
+            f_rows.append(len(f_src))
+            continue
+        loc = np.stack([cen["L"]["x"][b:b + n], cen["L"]["y"][b:b + n]], 1)
+        for c in range(ncl[i]):
+            members = [m for m in range(n) if cluster_of[b + m] == c]
+            rights, best = [], -1
+            for m in members:
+                d = np.sqrt((loc[m, 0] - loc[:, 0]) * (loc[m, 0] - loc[:, 0]) + (loc[m, 1] - loc[:, 1]) * (loc[m, 1] - loc[:, 1]))
+                closest = int(np.argmin(d))                              # the first smallest: `d < closest_dist`
+                rights.append(cen["R"][b + closest])
+                best = closest
+            right = rights[0].copy()
+            if len(rights) > 1:
+                sx = sy = st = 0.0
+                for e in rights:
+                    sx += float(e["x"])
+                    sy += float(e["y"])
+                    st += float(e["theta"])
+                right["x"], right["y"], right["theta"] = sx / len(rights), sy / len(rights), st / len(rights)
+            f_src.append(b + best)
+            f_L.append(centres[b + c])
+            f_R.append(right)
+        f_rows.append(len(f_src))
+    f_src = np.array(f_src, dtype=np.int64)
+    counts["n_final"] = len(f_src)
+    return dict(counts=counts, row_ptr=np.array(f_rows, dtype=np.int32), cf_index=cf[f_src].astype(np.int32),
+                left=np.array(f_L, dtype=orc.EDGE_DTYPE) if f_L else np.zeros(0, orc.EDGE_DTYPE),
+                right=np.array(f_R, dtype=orc.EDGE_DTYPE) if f_R else np.zeros(0, orc.EDGE_DTYPE), ncc_left=simL[f_src],
+                sift_left=siftL[f_src], score_left=out["L"]["score"][f_src], score_right=out["R"]["score"][f_src],
+                valid=valid[f_src])

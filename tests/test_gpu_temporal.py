@@ -70,6 +70,56 @@ def test_temporal_quads_equal_oracle(ctx, undist):
     assert abs(np.median(dx) - 3.0) < 1.0
 
 
+@pytest.mark.parametrize("undist", [False, True])
+def test_temporal_chain_equals_oracle_chain(ctx, undist):
+    """get_Temporal_Edge_Pairs_from_Quads stage for stage (src/Temporal_Matches.cpp:184-215): grid + orientation candidates,
+    NCC, SIFT filter, Best-Nearly-Best on the NCC and on the SIFT scores, photometric refinement of both cameras, edge
+    clustering -- the device chain against the chain of oracle functions (tests/oracle_chain.py), every final quad."""
+    from tests import oracle_chain
+    h, w = 240, 376
+    ce = synth.CALIB["euroc"]
+    K = tuple(v / 2 for v in ce["K"])
+    Kr = tuple(v / 2 for v in ce["K_right"])
+    F = synth.fundamental_21(K, Kr, ce["R21"], ce["T21"])
+    calib = ([K[0], 0, K[2], 0, K[1], K[3], 0, 0, 1], [Kr[0], 0, Kr[2], 0, Kr[1], Kr[3], 0, 0, 1], ce["R21"], ce["T21"])
+    if undist:
+        ctx.set_undistort(K, ce["dist"], Kr, ce["dist_right"])
+    try:
+        l0, r0, _ = _frame(ctx, h, w, 0, F, calib)
+        c0 = ctx.stereo_run(ctx.default_params(F))
+        left0 = ctx.stereo_fetch(c0)["left"]
+        _, kf = ctx.stereo_finalize(calib)
+        ctx.temporal_set_keyframe()
+        kfL, kfR = left0[kf["left_index"]], kf["right"]
+        l3, r3, _ = _frame(ctx, h, w, 2, F, calib)
+        c3 = ctx.stereo_run(ctx.default_params(F))
+        left3 = ctx.stereo_fetch(c3)["left"]
+        _, cf = ctx.stereo_finalize(calib)
+        cfL, cfR = left3[cf["left_index"]], cf["right"]
+        counts, q = ctx.temporal_match(stages=1)
+    finally:
+        if undist:
+            ctx.set_undistort()
+    und = (lambda img, k, d: orc.undistort(img, k, d)) if undist else (lambda img, k, d: img)
+    kf_imgs = (und(l0, K, ce["dist"]), und(r0, Kr, ce["dist_right"]))
+    cf_imgs = (und(l3, K, ce["dist"]), und(r3, Kr, ce["dist_right"]))
+    ref = oracle_chain.temporal_edge_pairs(kfL, kfR, cfL, cfR, kf_imgs, cf_imgs, q["row_ptr"], q["col_idx"], q["sim_left"],
+                                           q["keep"])
+    got = {k: counts[k] for k in ref["counts"]}
+    assert got == ref["counts"] and counts["n_final"] > 300 and counts["n_sift"] < counts["n_kept"]
+    fin = q["final"]
+    assert_bit_equal(fin["row_ptr"], ref["row_ptr"], "row_ptr")
+    assert_bit_equal(fin["cf_index"], ref["cf_index"], "cf_index")
+    assert_edges_equal(fin["left"], ref["left"], "left centres")
+    assert_edges_equal(fin["right"], ref["right"], "right centres")
+    for k in ("ncc_left", "sift_left", "score_left", "score_right", "valid"):
+        assert_bit_equal(fin[k], ref[k], k)
+    # the scene moved by 2 px between the keyframe and this frame
+    rows = np.repeat(np.arange(len(kfL)), np.diff(fin["row_ptr"]))
+    v = fin["valid"].astype(bool)
+    assert v.mean() > 0.5 and abs(np.median(fin["left"]["x"][v] - kfL["x"][rows[v]]) - 2.0) < 0.5
+
+
 def test_temporal_state_machine(ctx):
     from edge_based_visual_odometry_amd._lib import EbvoError, EBVO_ERR_STATE
     l, r = synth.stereo_pair("s2", 96, 160)
@@ -83,6 +133,16 @@ def test_temporal_state_machine(ctx):
     ctx.temporal_set_keyframe()
     counts, q = ctx.temporal_match()                    # a frame against itself
     assert counts["n_kf"] == counts["n_cf"] and counts["n_kept"] >= counts["n_kf"] * 0.9
+    with pytest.raises(EbvoError) as ei:                # the chain after the NCC filter was not run for this pair
+        ctx.lib.ebvo_temporal_fetch_final.restype = int
+        ctx._check(ctx.lib.ebvo_temporal_fetch_final(ctx._ctx, 0, None, None, None, None, None, None, None, None, None), "fetch_final")
+    assert ei.value.status == EBVO_ERR_STATE
+    counts, q = ctx.temporal_match(stages=1)            # ... now it was: a frame against itself keeps itself (the
+    assert counts["n_final"] >= counts["n_kf"] * 0.8    # refinement stops at once: "outlier", fewer than two iterations)
+    rows = np.repeat(np.arange(counts["n_kf"]), np.diff(q["final"]["row_ptr"]))
+    assert (q["final"]["cf_index"] == rows).mean() > 0.8
     ctx.stereo_upload(l, r)
     with pytest.raises(EbvoError):
         ctx.temporal_match()                            # the new pair has no final mates yet
+    with pytest.raises(EbvoError):
+        ctx._check(ctx.lib.ebvo_temporal_fetch_final(ctx._ctx, 0, None, None, None, None, None, None, None, None, None), "fetch_final")

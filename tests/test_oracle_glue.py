@@ -62,6 +62,33 @@ def test_bnb_matches_python_reading():
                 assert np.array_equal(order[b:rp[i + 1]], np.arange(b, rp[i + 1]))
 
 
+def test_temporal_bnb_variant_always_returns_sorted_rows():
+    """Temporal_Matches::apply_best_nearly_best_filtering_quads (src/Temporal_Matches.cpp:517-570): the same ratio test, but a
+    row of two or more quads is rebuilt from the sorted indices whether or not something was dropped."""
+    rng = np.random.default_rng(8)
+    rp, n = _rows(rng)
+    for higher, thr in ((True, 0.8), (False, 0.8)):
+        sc = rng.uniform(0.5, 1.0, n) if higher else rng.uniform(20, 200, n)
+        sc[7] = 0.0
+        cnt, order = orc.bnb_test(rp, sc, thr, higher, always_sorted=True)
+        pc, po = _bnb_python(rp, sc, thr, higher)                   # the stereo reading: same counts, same kept prefix
+        assert np.array_equal(cnt, pc)
+        untouched = 0
+        for i in range(len(rp) - 1):
+            b, m = rp[i], rp[i + 1] - rp[i]
+            kept = order[b:b + cnt[i]]
+            if m >= 2:                                              # :531-541 sorted, :553-558 rebuilt from indices[0 .. keep)
+                want = sorted(range(b, b + m), key=lambda k: (-sc[k] if higher else sc[k]))[:cnt[i]]
+                if m <= 16:
+                    assert list(kept) == want
+                else:
+                    assert np.array_equal(sc[kept], sc[want])
+                untouched += int(cnt[i] == m and list(kept) == list(range(b, b + m)))
+            else:
+                assert list(kept) == list(range(b, b + m))          # :524 `if (n < 2) continue`
+        assert untouched < (np.diff(rp) >= 2).sum()                 # rows that lost nothing were still reordered
+
+
 def test_std_sort_restatement_equals_libstdcxx(tmp_path):
     """csrc/ebvo_sort.h against the real std::sort of this toolchain (tests/cpp/sort_check.cpp): ties, both comparators,
     lengths up to 5000."""
