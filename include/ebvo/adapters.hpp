@@ -440,6 +440,66 @@ class StereoMatcherHIP
     Context::Ptr ctx_;
 };
 
+// Temporal_Matches::get_Temporal_Edge_Pairs_from_Quads (src/Temporal_Matches.cpp:168-218) on the FINAL stereo mates of
+// resident pairs: the keyframe's mates stay on the device (set_keyframe after StereoMatcherHIP::stereo_edge_pairs on that
+// slot), every later frame's mates are matched against them.  stages = 0 stops after the NCC filter (:192), 1 runs the
+// SIFT filter, both Best-Nearly-Best tests, the photometric refinement and the edge clustering as well.
+class TemporalMatcherHIP
+{
+  public:
+    explicit TemporalMatcherHIP(Context::Ptr ctx) : ctx_(std::move(ctx)) {}
+    int last_status = EBVO_OK;
+
+    bool set_keyframe(int slot = 0) // keyframe = frame 0 in the reference (src/Pipeline.cpp:133-138)
+    {
+        return report(*ctx_, last_status = ebvo_temporal_set_keyframe(ctx_->get(), slot), "ebvo_temporal_set_keyframe");
+    }
+
+    struct Quads
+    {
+        ebvo_temporal_counts counts{};
+        // per keyframe mate i: the quads row_ptr[i] .. row_ptr[i + 1] that left the chain
+        std::vector<int32_t> row_ptr, cf_index;
+        std::vector<ebvo_edge> left, right; // cluster centres (CF_left / CF_right center_edge)
+        std::vector<double> ncc_left, sift_left, refine_score_left, refine_score_right;
+        std::vector<uint8_t> refine_validity;
+    };
+    Quads match(int slot = 0, int stages = 1, const ebvo_temporal_params *params = nullptr)
+    {
+        Quads q;
+        ebvo_temporal_params p;
+        if (params)
+            p = *params;
+        else
+        {
+            ebvo_temporal_default_params(&p);
+            p.stages = stages;
+        }
+        if (!report(*ctx_, last_status = ebvo_temporal_match(ctx_->get(), slot, &p, &q.counts), "ebvo_temporal_match") || !p.stages)
+            return q;
+        const size_t n = (size_t)q.counts.n_final;
+        q.row_ptr.resize((size_t)q.counts.n_kf + 1);
+        q.cf_index.resize(n);
+        q.left.resize(n);
+        q.right.resize(n);
+        q.ncc_left.resize(n);
+        q.sift_left.resize(n);
+        q.refine_score_left.resize(n);
+        q.refine_score_right.resize(n);
+        q.refine_validity.resize(n);
+        report(*ctx_,
+               last_status = ebvo_temporal_fetch_final(ctx_->get(), slot, q.row_ptr.data(), q.cf_index.data(), q.left.data(),
+                                                       q.right.data(), q.ncc_left.data(), q.sift_left.data(),
+                                                       q.refine_score_left.data(), q.refine_score_right.data(),
+                                                       q.refine_validity.data()),
+               "ebvo_temporal_fetch_final");
+        return q;
+    }
+
+  private:
+    Context::Ptr ctx_;
+};
+
 // cv::undistort(src, dst, K, dist) of src/Pipeline.cpp:78-79 on a CV_8UC1 image (K = fx fy cx cy, dist = k1 k2 p1 p2 [k3])
 inline std::vector<uint8_t> undistort(const Context &c, const uint8_t *img, int rows, int cols, ptrdiff_t step, const double K[4],
                                       const std::vector<double> &dist)

@@ -146,6 +146,28 @@ int main(int argc, char **argv)
     std::fwrite(fp.right.data(), sizeof(ebvo_edge), fp.right.size(), o);
     std::fwrite(fp.ncc_score.data(), sizeof(double), fp.ncc_score.size(), o);
     std::fwrite(fp.out16.data(), sizeof(double), fp.out16.size(), o);
+    // temporal quads: this frame is the keyframe; the next frame is the same scene moved by two pixels
+    ebvo::TemporalMatcherHIP temporal(TOED->context());
+    if (!temporal.set_keyframe(0))
+        return 10;
+    std::vector<unsigned char> l2(bl.size()), r2(br.size());
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x)
+        {
+            l2[(size_t)y * w + x] = bl[(size_t)y * w + (x + w - 2) % w];
+            r2[(size_t)y * w + x] = br[(size_t)y * w + (x + w - 2) % w];
+        }
+    auto fp2 = matcher.stereo_edge_pairs(l2.data(), r2.data(), h, w, w, w, F, &calib, true);
+    auto tq = temporal.match(0, 1);
+    if (matcher.last_status != EBVO_OK || temporal.last_status != EBVO_OK)
+        return 11;
+    int64_t th[4] = {tq.counts.n_kf, tq.counts.n_kept, tq.counts.n_bnb_sift, tq.counts.n_final};
+    std::fwrite(th, sizeof th, 1, o);
+    std::fwrite(tq.row_ptr.data(), sizeof(int32_t), tq.row_ptr.size(), o);
+    std::fwrite(tq.cf_index.data(), sizeof(int32_t), tq.cf_index.size(), o);
+    std::fwrite(tq.left.data(), sizeof(ebvo_edge), tq.left.size(), o);
+    std::fwrite(tq.right.data(), sizeof(ebvo_edge), tq.right.size(), o);
+    std::fwrite(tq.refine_validity.data(), 1, tq.refine_validity.size(), o);
     std::fclose(o);
     std::printf("adapter_demo ok: %zu + %zu edges, %zu pairs\n", left_edges.size(), right_edges.size(), cand.size());
     return 0;
