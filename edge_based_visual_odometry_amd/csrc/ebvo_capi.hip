@@ -2202,9 +2202,18 @@ extern "C" int ebvo_temporal_match(ebvo_ctx *ctx, int slot, const ebvo_temporal_
     int32_t *cnt = (int32_t *)s.tq_i32.p, *rp = cnt + nk1;
     unsigned long long *d_kept = (unsigned long long *)(((uintptr_t)(rp + nk1) + 7) & ~(uintptr_t)7); // 8-byte aligned counter
     EBVO_HIP(ctx, hipMemsetAsync(cnt, 0, sizeof(int32_t) * 2 * nk1, s.stream));
+    s.tq_final = Slot::TqFinal();
+    auto empty_final = [&]() { // no quads at all: the chain's result is an empty list over the (zeroed) row offsets
+        if (p->stages)
+        {
+            s.tq_final.rp = rp;
+            s.tq_final.n = 0;
+        }
+    };
     if (n_kf == 0 || n_cf == 0)
     {
         EBVO_HIP(ctx, hipStreamSynchronize(s.stream));
+        empty_final();
         return EBVO_OK;
     }
     const ebvo_edge *cfL, *cfR;
@@ -2225,7 +2234,10 @@ extern "C" int ebvo_temporal_match(ebvo_ctx *ctx, int slot, const ebvo_temporal_
     counts->n_candidates = nq;
     s.tq_n = nq;
     if (nq == 0)
+    {
+        empty_final(); // (rp holds the scanned counts: all zero)
         return EBVO_OK;
+    }
     const size_t nqz = (size_t)nq, ncz = (size_t)n_cf;
     if ((rc = ebvo_grow(ctx, s, s.tq_cols, sizeof(int32_t) * 2 * nqz)) || (rc = ebvo_grow(ctx, s, s.tq_f64, sizeof(double) * 2 * nqz)) ||
         (rc = ebvo_grow(ctx, s, s.tq_u8, 2 * ncz + nqz + 64)) || (rc = ebvo_grow(ctx, s, s.patches_raw, sizeof(float) * 98 * ncz)) ||

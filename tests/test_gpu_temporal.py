@@ -146,3 +146,43 @@ def test_temporal_state_machine(ctx):
         ctx.temporal_match()                            # the new pair has no final mates yet
     with pytest.raises(EbvoError):
         ctx._check(ctx.lib.ebvo_temporal_fetch_final(ctx._ctx, 0, None, None, None, None, None, None, None, None, None), "fetch_final")
+
+
+def test_temporal_chain_with_nothing_to_match(ctx):
+    """Empty ends of the chain: a current frame without a single mate in reach of the keyframe's, and a keyframe without
+    mates -- counts of zero, an empty final list, no error."""
+    h, w = 96, 160
+    F = synth.fundamental_for("kitti")
+    l, r = synth.stereo_pair("s2", h, w)
+    ctx.stereo_upload(l, r)
+    ctx.stereo_run(ctx.default_params(F))
+    _, kf = ctx.stereo_finalize(None)
+    assert len(kf["left_index"]) > 100
+    ctx.temporal_set_keyframe()
+    flat = np.full((h, w), 128, dtype=np.uint8)           # no edges at all in the current frame
+    ctx.stereo_upload(flat, flat)
+    c = ctx.stereo_run(ctx.default_params(F))
+    assert c.n_left == 0
+    ctx.stereo_finalize(None)
+    counts, q = ctx.temporal_match(stages=1)
+    assert counts["n_cf"] == 0 and counts["n_final"] == 0 and len(q["final"]["cf_index"]) == 0
+    assert_bit_equal(q["final"]["row_ptr"], np.zeros(counts["n_kf"] + 1, dtype=np.int32))
+    # the mirrored scene: candidates exist by location, none survives orientation + NCC + SIFT all the way ... or some do; either
+    # way the lists are consistent
+    ctx.stereo_upload(l[:, ::-1].copy(), r[:, ::-1].copy())
+    ctx.stereo_run(ctx.default_params(F))
+    ctx.stereo_finalize(None)
+    counts, q = ctx.temporal_match(stages=1)
+    f = q["final"]
+    assert f["row_ptr"][-1] == counts["n_final"] == len(f["cf_index"]) and (np.diff(f["row_ptr"]) >= 0).all()
+    assert counts["n_final"] <= counts["n_bnb_sift"] <= counts["n_bnb_ncc"] <= counts["n_sift"] <= counts["n_kept"]
+    # a keyframe without mates
+    ctx.stereo_upload(flat, flat)
+    ctx.stereo_run(ctx.default_params(F))
+    ctx.stereo_finalize(None)
+    ctx.temporal_set_keyframe()
+    ctx.stereo_upload(l, r)
+    ctx.stereo_run(ctx.default_params(F))
+    ctx.stereo_finalize(None)
+    counts, q = ctx.temporal_match(stages=1)
+    assert counts["n_kf"] == 0 and counts["n_final"] == 0 and len(q["final"]["row_ptr"]) == 1
