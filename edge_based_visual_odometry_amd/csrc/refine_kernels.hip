@@ -507,6 +507,156 @@ __global__ __launch_bounds__(256) void gn_iter_kernel(GnArgs A, int it)
     }
 }
 
+// The same iteration with EIGHT LANES PER PAIR (lane r < 7 = patch row r of both sides, lane 7 idle), for SMALL problems.
+// A launch of the one-thread-per-pair kernel lasts at least ~90-110 us however few pairs it holds (one wave per SIMD
+// issues an instruction only every ~10 cycles and a thread walks 196 samples); with hundreds of thousands of pairs that
+// floor is irrelevant (KITTI: 314 us for 472,947 pairs, and this layout costs 2x there), with the 50-100 k pairs of a
+// 752 x 480 frame every one of the 20 launches sits on it.  Here a lane samples 7 + 7 points per side: eight times the
+// waves, an eighth of the chain.  The reference's sums are sequential over the 49 (98) samples and stay so: the running
+// sum visits the lanes in row order (lane r adds its seven terms to what lane r - 1 produced).  Bit-identical to
+// gn_iter_kernel (the refinement tests run both).
+__global__ __launch_bounds__(256) void gn_iter_rows_kernel(GnArgs A, int it)
+{
+    const int h = A.h, w = A.w;
+    const int n_in = A.counts[it];
+    const int32_t *__restrict__ lin = A.list[it & 1];
+    int32_t *__restrict__ lout = A.list[(it + 1) & 1];
+    const int lane = threadIdx.x & 63, row = lane & 7, gbase = lane & ~7;
+    const int groups_per_block = blockDim.x >> 3;
+    for (int base = blockIdx.x * groups_per_block; base < n_in; base += gridDim.x * groups_per_block)
+    {
+        const int idx = base + (threadIdx.x >> 3);
+        const bool live = idx < n_in; // uniform in the group; the cross-lane exchanges below run for every lane of the wave
+        const int64_t k = live ? lin[idx] : 0;
+        bool survives = false;
+        ebvo_edge le;
+        double ex, ey;
+        gn_geometry(A, k, le, ex, ey);
+        const int li = A.pair_left[k];
+        const double st = A.sc[li], ct = A.sc[A.nL + li];
+        const double nx = -st, ny = ct, side = (7 / 2.0) + 1.0;
+        double rx, ry;
+        gn_candidate(A, k, rx, ry);
+        const double meanL[2] = {A.mean_l[li], A.mean_l[A.nL + li]};
+        double alpha = A.alpha[k];
+        const double shx = ex * alpha, shy = ey * alpha;
+        const int i = min(row, 6) - 3; // this lane's patch row (lane 7 repeats row 6 and is never selected)
+        double meanR[2];
+#pragma unroll 1
+        for (int sd = 0; sd < 2; ++sd)
+        {
+            const double cx = (sd ? rx - nx * side : rx + nx * side) + shx; // :1204-1205
+            const double cy = (sd ? ry - ny * side : ry + ny * side) + shy;
+            float v[7];
+#pragma unroll
+            for (int j = -3; j <= 3; ++j)
+                v[j + 3] = sample_pix4(A.pix4R, w, h, cx + ct * i - st * j, cy + st * i + ct * j);
+            double sum = 0;
+#pragma unroll 1
+            for (int r = 0; r < 7; ++r)
+            {
+                double t = sum;
+#pragma unroll
+                for (int j = 0; j < 7; ++j)
+                    t += (double)v[j];
+                sum = __shfl(t, gbase | r); // the running sum after row r
+            }
+            meanR[sd] = sum / 49;
+        }
+        double H = 0.0, b = 0.0, cost = 0.0;
+#pragma unroll 1
+        for (int sd = 0; sd < 2; ++sd)
+        {
+            const float *__restrict__ lrec = A.left_rec + (size_t)li * 98 + sd * 49 + (i + 3) * 7;
+            const double cx = (sd ? rx - nx * side : rx + nx * side) + shx;
+            const double cy = (sd ? ry - ny * side : ry + ny * side) + shy;
+            double tH[7], tb[7], tc[7];
+#pragma unroll
+            for (int j = -3; j <= 3; ++j)
+            {
+                const double Lf = (double)lrec[j + 3]; // sampled once by gn_left_kernel
+                int x0, x1, y0, y1;
+                double wa, wb;
+                tap_at(cx + ct * i - st * j, cy + st * i + ct * j, w, h, x0, x1, y0, y1, wa, wb);
+                const uint4 q = A.recR[(size_t)y0 * w + x0]; // the four corners: intensity, 8 gx, 8 gy
+                const unsigned wd[4] = {q.x, q.y, q.z, q.w};
+                float iv[4], gxc[4], gyc[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                {
+                    iv[c] = (float)((wd[c] & 31u) | ((wd[c] >> 11) & 0xe0u));
+                    gxc[c] = (float)(((int)(wd[c] << 16)) >> 21) * 0.125f; // bits 5..15, sign-extended
+                    gyc[c] = (float)(((int)wd[c]) >> 21) * 0.125f;         // bits 21..31
+                }
+                const double Rf = (double)blend(wa, wb, iv[0], iv[1], iv[2], iv[3]);
+                const double gxv = (double)blend(wa, wb, gxc[0], gxc[1], gxc[2], gxc[3]);
+                const double gyv = (double)blend(wa, wb, gyc[0], gyc[1], gyc[2], gyc[3]);
+                const double r = (Lf - meanL[sd]) - (Rf - meanR[sd]);
+                const double g = -gxv * ex + gyv * ey; // :1237
+                const double absr = fabs(r);
+                const double wgt = (absr <= A.huber) ? 1.0 : A.huber / absr;
+                tH[j + 3] = wgt * g * g; // the addends of gn_iter_kernel's three sums, formed by the same operations
+                tb[j + 3] = wgt * g * r;
+                tc[j + 3] = wgt * r * r;
+            }
+#pragma unroll 1
+            for (int r = 0; r < 7; ++r)
+            {
+                double uH = H, ub = b, uc = cost;
+#pragma unroll
+                for (int j = 0; j < 7; ++j)
+                {
+                    uH += tH[j];
+                    ub += tb[j];
+                    uc += tc[j];
+                }
+                H = __shfl(uH, gbase | r);
+                b = __shfl(ub, gbase | r);
+                cost = __shfl(uc, gbase | r);
+            }
+        }
+        if (live && row == 0)
+        {
+            int done_iters = it; // stop on H < 1e-8: outputs stay unset (:1255)
+            bool finished = true;
+            if (!(H < 1e-8))
+            {
+                const double delta = -b / H;
+                alpha += delta;
+                const double rms = sqrt(cost / 98);
+                const bool is_outlier = (rms > A.huber * 2.0) || (it + 1 < 2); // residual_log.size() == it + 1
+                if (fabs(delta) < A.tol || it == A.max_iter - 1)
+                {
+                    A.valid[k] = is_outlier ? 0 : 1;
+                    A.score[k] = rms;
+                    A.conf[k] = ebvo_exp(-rms / A.huber);
+                    done_iters = it + 1;
+                }
+                else
+                    finished = false;
+            }
+            A.alpha[k] = alpha;
+            if (finished)
+            {
+                A.iters[k] = done_iters;
+                A.refined_xy[2 * k] = rx + ex * alpha; // :1349-1351
+                A.refined_xy[2 * k + 1] = ry + ey * alpha;
+            }
+            survives = !finished;
+        }
+        // append the survivors: one atomic per wave
+        const unsigned long long m = __ballot(survives);
+        int wbase = 0;
+        if (lane == 0 && m)
+            wbase = atomicAdd(&A.counts[it + 1], __popcll(m));
+        wbase = __shfl(wbase, 0);
+        if (survives)
+            lout[wbase + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)k;
+    }
+}
+
+constexpr int64_t GN_ROWS_MAX_PAIRS = 131072; // up to this many pairs every iteration runs eight lanes per pair
+
 // ------------------------------------------------------------------------------------------
 // Temporal 2-D refinement: Temporal_Matches::min_Edge_Photometric_Residual_by_Gauss_Newton,
 // src/Temporal_Matches.cpp:735-851.  Same launch-per-iteration scheme; differences from the stereo variant: the
@@ -901,7 +1051,14 @@ int refine_gn_stereo_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_imgL, cons
                        s.stream, A);
     hipLaunchKernelGGL(gn_init_kernel, dim3(blocks), dim3(256), 0, s.stream, A);
     for (int it = 0; it < max_iter; ++it)
-        hipLaunchKernelGGL(gn_iter_kernel, dim3(blocks), dim3(256), 0, s.stream, A, it);
+    {
+        const bool rows = n_pairs <= GN_ROWS_MAX_PAIRS && !getenv("EBVO_GN_NO_ROWS");
+        const unsigned rblocks = (unsigned)((n_pairs + 31) / 32 < 8192 ? (n_pairs + 31) / 32 : 8192);
+        if (rows)
+            hipLaunchKernelGGL(gn_iter_rows_kernel, dim3(rblocks), dim3(256), 0, s.stream, A, it);
+        else
+            hipLaunchKernelGGL(gn_iter_kernel, dim3(blocks), dim3(256), 0, s.stream, A, it);
+    }
     EBVO_HIP(ctx, hipGetLastError());
     return EBVO_OK;
 }
