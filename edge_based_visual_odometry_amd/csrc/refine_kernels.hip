@@ -857,6 +857,141 @@ __global__ __launch_bounds__(256) void gn2_iter_kernel(Gn2Args A, int it)
     }
 }
 
+// Eight lanes per item for small batches, as gn_iter_rows_kernel: lane r < 7 = patch row r of both sides; the nine
+// running sums (H gets its 1e-6 I after every sample, :809) visit the lanes in row order.  Bit-identical to gn2_iter_kernel.
+__global__ __launch_bounds__(256) void gn2_iter_rows_kernel(Gn2Args A, int it)
+{
+    const int h = A.h, w = A.w;
+    const int n_in = A.counts[it];
+    const int32_t *__restrict__ lin = A.list[it & 1];
+    int32_t *__restrict__ lout = A.list[(it + 1) & 1];
+    const int lane = threadIdx.x & 63, row = lane & 7, gbase = lane & ~7;
+    const int groups_per_block = blockDim.x >> 3;
+    for (int base = blockIdx.x * groups_per_block; base < n_in; base += gridDim.x * groups_per_block)
+    {
+        const int idx = base + (threadIdx.x >> 3);
+        const bool live = idx < n_in; // uniform in the group
+        const int64_t k = live ? lin[idx] : 0;
+        bool survives = false;
+        const ebvo_edge ke = A.kf[k];
+        const bool second = k >= A.n_first;
+        const uint8_t *__restrict__ imgK = second ? A.imgK2 : A.imgK, *__restrict__ imgC = second ? A.imgC2 : A.imgC;
+        const float2 *__restrict__ gxy = second ? A.gxy2 : A.gxy;
+        const double st = A.sc[k], ct = A.sc[A.n + k], stc = A.sc[2 * A.n + k], ctc = A.sc[3 * A.n + k];
+        const double nx = -st, ny = ct, ncx = -stc, ncy = ctc, side = (7 / 2.0) + 1.0;
+        const double meanL[2] = {A.mean_l[k], A.mean_l[A.n + k]};
+        double d0 = A.disp[2 * k], d1 = A.disp[2 * k + 1];
+        const double lx = ke.x - d0, ly = ke.y - d1; // :786
+        const int i = min(row, 6) - 3; // this lane's patch row (lane 7 repeats row 6 and is never selected)
+        double meanR[2];
+#pragma unroll 1
+        for (int sd = 0; sd < 2; ++sd)
+        {
+            const double cx = sd ? lx - ncx * side : lx + ncx * side, cy = sd ? ly - ncy * side : ly + ncy * side;
+            float v[7];
+#pragma unroll
+            for (int j = -3; j <= 3; ++j)
+                v[j + 3] = sample_u8(imgC, w, w, h, cx + ctc * i - stc * j, cy + stc * i + ctc * j);
+            double sum = 0;
+#pragma unroll 1
+            for (int r = 0; r < 7; ++r)
+            {
+                double t = sum;
+#pragma unroll
+                for (int j = 0; j < 7; ++j)
+                    t += (double)v[j];
+                sum = __shfl(t, gbase | r);
+            }
+            meanR[sd] = sum / 49;
+        }
+        double H00 = 0, H10 = 0, H11 = 0, b0 = 0, b1 = 0, cost = 0;
+#pragma unroll 1
+        for (int sd = 0; sd < 2; ++sd)
+        {
+            const double lcx = sd ? ke.x - nx * side : ke.x + nx * side, lcy = sd ? ke.y - ny * side : ke.y + ny * side;
+            const double cx = sd ? lx - ncx * side : lx + ncx * side, cy = sd ? ly - ncy * side : ly + ncy * side;
+            double t00[7], t10[7], t11[7], tb0[7], tb1[7], tc[7];
+#pragma unroll
+            for (int j = -3; j <= 3; ++j)
+            {
+                const double Lf = (double)sample_u8(imgK, w, w, h, lcx + ct * i - st * j, lcy + st * i + ct * j);
+                int x0, x1, y0, y1;
+                double wa, wb;
+                tap_at(cx + ctc * i - stc * j, cy + stc * i + ctc * j, w, h, x0, x1, y0, y1, wa, wb);
+                const int xa = min(x0, w - 2);
+                const bool shifted = xa != x0;
+                const Corners ci = corners_u8(imgC, w, w, x0, x1, y0, y1);
+                const float4 g0 = *reinterpret_cast<const float4 *>(gxy + (size_t)y0 * w + xa);
+                const float4 g1 = *reinterpret_cast<const float4 *>(gxy + (size_t)y1 * w + xa);
+                const double Rf = (double)blend(wa, wb, ci.v00, ci.v10, ci.v01, ci.v11);
+                const double J0 = (double)blend(wa, wb, shifted ? g0.z : g0.x, g0.z, shifted ? g1.z : g1.x, g1.z);
+                const double J1 = (double)blend(wa, wb, shifted ? g0.w : g0.y, g0.w, shifted ? g1.w : g1.y, g1.w);
+                const double r = (Lf - meanL[sd]) - (Rf - meanR[sd]);
+                const double absr = fabs(r);
+                const double wgt = (absr < A.huber) ? 1.0 : A.huber / absr; // strict, :806
+                const double wJ0 = wgt * J0, wJ1 = wgt * J1;
+                t00[j + 3] = wJ0 * J0; // the addends of gn2_iter_kernel's sums, formed by the same operations
+                t10[j + 3] = wJ1 * J0;
+                t11[j + 3] = wJ1 * J1;
+                tb0[j + 3] = wJ0 * r;
+                tb1[j + 3] = wJ1 * r;
+                tc[j + 3] = wgt * r * r;
+            }
+#pragma unroll 1
+            for (int r = 0; r < 7; ++r)
+            {
+                double u00 = H00, u10 = H10, u11 = H11, ub0 = b0, ub1 = b1, uc = cost;
+#pragma unroll
+                for (int j = 0; j < 7; ++j)
+                {
+                    u00 += t00[j];
+                    u10 += t10[j];
+                    u11 += t11[j];
+                    u00 += 1e-6; // H += 1e-6 * I (:809)
+                    u10 += 0.0;
+                    u11 += 1e-6;
+                    ub0 += tb0[j];
+                    ub1 += tb1[j];
+                    uc += tc[j];
+                }
+                H00 = __shfl(u00, gbase | r);
+                H10 = __shfl(u10, gbase | r);
+                H11 = __shfl(u11, gbase | r);
+                b0 = __shfl(ub0, gbase | r);
+                b1 = __shfl(ub1, gbase | r);
+                cost = __shfl(uc, gbase | r);
+            }
+        }
+        if (live && row == 0)
+        {
+            double s0, s1;
+            ldlt2_solve(H00, H10, H11, b0, b1, s0, s1);
+            const double delta0 = -s0, delta1 = -s1;
+            d0 += delta0;
+            d1 += delta1;
+            const double rms = sqrt(cost / 98);
+            const bool is_outlier = (rms > A.huber * 2.0) || (it + 1 < 2);
+            const bool finished = sqrt(delta0 * delta0 + delta1 * delta1) < A.tol || it == A.max_iter - 1;
+            A.disp[2 * k] = d0;
+            A.disp[2 * k + 1] = d1;
+            if (finished)
+            {
+                A.valid[k] = is_outlier ? 0 : 1;
+                A.score[k] = rms;
+                A.iters[k] = it + 1;
+            }
+            survives = !finished;
+        }
+        const unsigned long long m = __ballot(survives);
+        int wbase = 0;
+        if (lane == 0 && m)
+            wbase = atomicAdd(&A.counts[it + 1], __popcll(m));
+        wbase = __shfl(wbase, 0);
+        if (survives)
+            lout[wbase + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)k;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // Finalisation geometry: the 16 numbers write_finalized_stereo_edge_pairs_to_file prints per final pair
 // (src/Stereo_Matches.cpp:1656-1699; src/utility.cpp:95-119).  One thread per pair; the calibration inverses are
@@ -1110,8 +1245,13 @@ int refine_gn_temporal_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_imgK, co
     EBVO_HIP(ctx, hipMemsetAsync(A.counts, 0, sizeof(int32_t) * ((size_t)max_iter + 2), s.stream));
     const unsigned blocks = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
     hipLaunchKernelGGL(gn2_init_kernel, dim3(blocks), dim3(256), 0, s.stream, A);
+    const bool rows = n <= GN_ROWS_MAX_PAIRS && !getenv("EBVO_GN_NO_ROWS"); // small batch: eight lanes per item
+    const unsigned rblocks = (unsigned)((n + 31) / 32 < 8192 ? (n + 31) / 32 : 8192);
     for (int it = 0; it < max_iter; ++it)
-        hipLaunchKernelGGL(gn2_iter_kernel, dim3(blocks), dim3(256), 0, s.stream, A, it);
+        if (rows)
+            hipLaunchKernelGGL(gn2_iter_rows_kernel, dim3(rblocks), dim3(256), 0, s.stream, A, it);
+        else
+            hipLaunchKernelGGL(gn2_iter_kernel, dim3(blocks), dim3(256), 0, s.stream, A, it);
     EBVO_HIP(ctx, hipGetLastError());
     return EBVO_OK;
 }

@@ -22,6 +22,17 @@ def _compare(out, ref):
     assert_bit_equal(out["confidence"], ref["confidence"], "confidence")
 
 
+@pytest.fixture(params=["rows", "threads"])
+def gn_layout(request, monkeypatch):
+    """Both launch layouts of the Gauss-Newton iterations: eight lanes per pair (what the library picks for up to 131,072
+    pairs) and one thread per pair (EBVO_GN_NO_ROWS, what larger problems run).  Same bits either way."""
+    if request.param == "threads":
+        monkeypatch.setenv("EBVO_GN_NO_ROWS", "1")
+    else:
+        monkeypatch.delenv("EBVO_GN_NO_ROWS", raising=False)
+    return request.param
+
+
 @pytest.mark.parametrize("shape", [(48, 64), (96, 160), (120, 200)])
 def test_sobel_equals_oracle(ctx, shape):
     img = synth.s2_image(*shape)
@@ -31,7 +42,7 @@ def test_sobel_equals_oracle(ctx, shape):
     assert_bit_equal(gy, oy, "gy")
 
 
-def test_refine_pipeline_matches_small(ctx):
+def test_refine_pipeline_matches_small(ctx, gn_layout):
     """The reference's use: every kept NCC match of a pair, candidate = the right TOED edge."""
     l, r = synth.stereo_pair("s2", 96, 160)
     ctx.stereo_upload(l, r)
@@ -50,7 +61,7 @@ def test_refine_pipeline_matches_small(ctx):
 
 
 @pytest.mark.parametrize("cfg", ["euroc", "eth3d"])
-def test_refine_slanted_lines_borders_and_params(ctx, cfg):
+def test_refine_slanted_lines_borders_and_params(ctx, cfg, gn_layout):
     """Slanted epipolar lines (EuRoC calibration), candidates on and beyond the image border (clamped sampling),
     non-default parameters, empty rows."""
     F = synth.fundamental_for(cfg)
@@ -72,7 +83,7 @@ def test_refine_slanted_lines_borders_and_params(ctx, cfg):
         _compare(out, ref)
 
 
-def test_refine_degenerate(ctx):
+def test_refine_degenerate(ctx, gn_layout):
     flat = np.full((48, 64), 77, dtype=np.uint8)
     L = np.zeros(2, dtype=orc.EDGE_DTYPE)
     L["x"], L["y"], L["theta"] = [20.0, 30.0], [20.0, 25.0], [0.3, -1.2]
@@ -149,7 +160,7 @@ def _compare_temporal(out, ref):
 
 
 @pytest.mark.parametrize("shape", [(96, 160), (120, 200)])
-def test_temporal_refine_equals_oracle(ctx, shape):
+def test_temporal_refine_equals_oracle(ctx, shape, gn_layout):
     """ebvo_gn_refine_temporal vs the restatement of src/Temporal_Matches.cpp:735-851: bit-exact disparity, score,
     validity and iteration count, incl. items starting on / beyond the border and non-default parameters."""
     h, w = shape
@@ -173,7 +184,7 @@ def test_temporal_refine_equals_oracle(ctx, shape):
     assert len(empty["score"]) == 0
 
 
-def test_temporal_refine_flat_image(ctx):
+def test_temporal_refine_flat_image(ctx, gn_layout):
     """Zero gradients: H is only the accumulated 1e-6 regulariser, the update is exactly zero, one iteration."""
     flat = np.full((64, 96), 90, dtype=np.uint8)
     kf = np.zeros(3, dtype=orc.EDGE_DTYPE)
