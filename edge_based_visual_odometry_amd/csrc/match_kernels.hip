@@ -1109,17 +1109,17 @@ __global__ void expand_rows_kernel(const int32_t *__restrict__ row_ptr, DevN nLd
 // Every right TOED edge is a candidate of ~5 left edges spread over two or three interpolated rows, so its two patches are
 // sampled and normalised ONCE into a bank; every left edge's patches are needed by its own CSR row only, so they never
 // leave the workgroup that samples them.
-//   right bank : per edge 2 sides x 8 rows x 8 floats = 512 B.  A lane owns one 32-byte row: two aligned 16-byte
+//   right bank : per edge 2 sides x 7 rows x 8 floats = 448 B.  A lane owns one 32-byte row: two aligned 16-byte
 //                accesses instead of seven dwords (the gather is address-divergent: the texture path charges per load
 //                instruction and per 128-byte line touched).  Slot [7] of every row carries the side's sentinel flag
-//                (sum of squares < 1e-10, src/utility.cpp:170), row 7 is never touched.
+//                (sum of squares < 1e-10, src/utility.cpp:170).
 //   ncc_tile   : a WAVE owns NW consecutive left edges = a contiguous range of CSR pairs.  Phase 1 samples and
 //                normalises their patches into LDS (same layout as a bank entry, 7 rows), phase 2 walks the pairs of the
 //                tile, eight lanes per pair (lane r = row r of all four patches): four 16-byte loads of the right rows,
 //                four ds_read_b128 of the left rows, four 49-term dots in the canonical order (dot7 + butterfly8).  Arithmetic identical to
 //                ncc_pairs_kernel / the oracle: the normalised rows are the same floats, the reductions the same order.
-constexpr int BANK_SIDE = 64;   // floats per side of a bank entry
-constexpr int BANK_EDGE = 128;  // floats per edge
+constexpr int BANK_SIDE = 56;   // floats per side of a bank entry: 7 rows x 8 floats (224 B, 16-byte aligned rows)
+constexpr int BANK_EDGE = 112;  // floats per edge (448 B)
 constexpr int NCC_NW = 4;       // left edges per wave (one sampling round: four 16-lane groups)
 constexpr int NCC_WPE = 5;      // waves per SIMD the tile kernel is compiled for
 
