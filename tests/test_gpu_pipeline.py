@@ -144,6 +144,39 @@ def test_more_slots_than_lanes_agree_with_lone_runs():
                 assert_bit_equal(np.asarray(views["best"]), ref["best"], "pinned best")
 
 
+def test_resubmission_while_result_copies_are_pending():
+    """Resident replay with fetches: a slot is submitted again while the copies of its previous results (copy stream) are
+    still in flight; the new pair's kernels wait for them (event) and every later result is still right."""
+    from edge_based_visual_odometry_amd.api import Context
+    with Context(120, 200) as c, Context(120, 200) as lone:
+        c.set_slots(5)                                         # lanes in use
+        p = c.default_params(F_KITTI)
+        pairs = [synth.stereo_pair("s2", 120, 200, scene=11 + k, noise_base=3 * k) for k in range(5)]
+        refs = []
+        for k, (l, r) in enumerate(pairs):
+            c.stereo_upload(l, r, slot=k)
+            c.stereo_submit(p, slot=k)
+            lone.stereo_upload(l, r)
+            cr = lone.stereo_run(p)
+            refs.append(lone.stereo_fetch(cr))
+        for rnd in range(3):
+            for k in range(5):
+                c.stereo_wait(slot=k)
+                c.stereo_fetch_begin(slot=k)
+                c.stereo_submit(p, slot=k)                     # the copies of slot k are abandoned, but still in flight:
+            for k in range(5):                                 # the new kernels must not overwrite what they read
+                ck = c.stereo_wait(slot=k)
+                c.stereo_fetch_begin(slot=k)
+                v = c.stereo_fetch_end(slot=k)
+                assert ck.n_pairs == len(refs[k]["col_idx"])
+                for key in ("row_ptr", "col_idx", "best", "keep"):
+                    assert_bit_equal(np.asarray(v[key]), refs[k][key], f"round {rnd} slot {k} {key}")
+                assert_edges_equal(np.asarray(v["left"]), refs[k]["left"])
+                c.stereo_submit(p, slot=k)
+        for k in range(5):
+            c.stereo_wait(slot=k)
+
+
 def test_pipeline_grows_pair_buffers_on_overflow():
     """More candidates than the pair-indexed buffers hold: the library grows them and redoes the matching half."""
     from edge_based_visual_odometry_amd.api import Context
