@@ -101,7 +101,7 @@ struct ProfEvent
 
 constexpr int EBVO_CLEAR_MAX = 8;      // arrays one clear launch zeroes
 constexpr int EBVO_TOTAL_PARTS = 4096;  // most blocks the counting pass of the candidate search is launched with
-constexpr int EBVO_MATCH_PARTS = 4096; // most blocks ncc_banked_kernel is launched with
+constexpr int EBVO_MATCH_PARTS = 4096; // most blocks ncc_tile_kernel is launched with
 
 // Everything that belongs to one HIP stream: a stereo pair in flight (or the workspace of a host-buffer call).
 struct Slot
@@ -140,7 +140,7 @@ struct Slot
     int64_t pipe_cap = 0;                // capacity the device pipeline keeps between pairs
     unsigned long long *d_total = nullptr; // [0]: 64-bit candidate total; [1 ..]: per-block partial totals
     int n_total_part = 0;
-    int32_t *d_matches = nullptr; // [EBVO_MATCH_PARTS] per-block kept-pair counts of ncc_banked_kernel
+    int32_t *d_matches = nullptr; // [EBVO_MATCH_PARTS] per-block kept-pair counts of ncc_tile_kernel
     int n_match_part = 0;
     int32_t *d_sizes = nullptr;          // [4] host-provided sizes for the host-buffer entry points
     double *d_F = nullptr;               // 9 doubles
