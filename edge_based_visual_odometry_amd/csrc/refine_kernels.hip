@@ -391,10 +391,22 @@ __global__ __launch_bounds__(256) void gn_init_kernel(GnArgs A)
     }
 }
 
-__global__ __launch_bounds__(256) void gn_iter_kernel(GnArgs A, int it)
+// Which layout runs an iteration is decided on the device, from the number of pairs still active: one thread per pair
+// above GN_ROWS_BELOW active pairs (the launch is throughput-bound there and that layout is the cheaper one per pair),
+// eight lanes per pair below it (a small launch of the thread layout lasts ~100 us whatever it holds).  Large problems
+// launch BOTH kernels per iteration and one of them returns at once (mode 1 / 2); small ones only the row layout (mode 0).
+constexpr int GN_ROWS_BELOW = 65536;
+__device__ inline bool gn_other_layout(int mode, int n_active)
+{
+    return (mode == 1 && n_active <= GN_ROWS_BELOW) || (mode == 2 && n_active > GN_ROWS_BELOW);
+}
+
+__global__ __launch_bounds__(256) void gn_iter_kernel(GnArgs A, int it, int mode)
 {
     const int h = A.h, w = A.w;
     const int n_in = A.counts[it];
+    if (gn_other_layout(mode, n_in))
+        return;
     const int32_t *__restrict__ lin = A.list[it & 1];
     int32_t *__restrict__ lout = A.list[(it + 1) & 1];
     const int lane = threadIdx.x & 63;
@@ -515,10 +527,12 @@ __global__ __launch_bounds__(256) void gn_iter_kernel(GnArgs A, int it)
 // waves, an eighth of the chain.  The reference's sums are sequential over the 49 (98) samples and stay so: the running
 // sum visits the lanes in row order (lane r adds its seven terms to what lane r - 1 produced).  Bit-identical to
 // gn_iter_kernel (the refinement tests run both).
-__global__ __launch_bounds__(256) void gn_iter_rows_kernel(GnArgs A, int it)
+__global__ __launch_bounds__(256) void gn_iter_rows_kernel(GnArgs A, int it, int mode)
 {
     const int h = A.h, w = A.w;
     const int n_in = A.counts[it];
+    if (gn_other_layout(mode, n_in))
+        return;
     const int32_t *__restrict__ lin = A.list[it & 1];
     int32_t *__restrict__ lout = A.list[(it + 1) & 1];
     const int lane = threadIdx.x & 63, row = lane & 7, gbase = lane & ~7;
@@ -655,7 +669,7 @@ __global__ __launch_bounds__(256) void gn_iter_rows_kernel(GnArgs A, int it)
     }
 }
 
-constexpr int64_t GN_ROWS_MAX_PAIRS = 131072; // up to this many pairs every iteration runs eight lanes per pair
+constexpr int64_t GN_ROWS_MAX_PAIRS = 131072; // temporal batches of up to this many items run eight lanes per item
 
 // ------------------------------------------------------------------------------------------
 // Temporal 2-D refinement: Temporal_Matches::min_Edge_Photometric_Residual_by_Gauss_Newton,
@@ -1187,12 +1201,17 @@ int refine_gn_stereo_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_imgL, cons
     hipLaunchKernelGGL(gn_init_kernel, dim3(blocks), dim3(256), 0, s.stream, A);
     for (int it = 0; it < max_iter; ++it)
     {
-        const bool rows = n_pairs <= GN_ROWS_MAX_PAIRS && !getenv("EBVO_GN_NO_ROWS");
+        const bool no_rows = getenv("EBVO_GN_NO_ROWS") != nullptr;
         const unsigned rblocks = (unsigned)((n_pairs + 31) / 32 < 8192 ? (n_pairs + 31) / 32 : 8192);
-        if (rows)
-            hipLaunchKernelGGL(gn_iter_rows_kernel, dim3(rblocks), dim3(256), 0, s.stream, A, it);
+        if (no_rows)
+            hipLaunchKernelGGL(gn_iter_kernel, dim3(blocks), dim3(256), 0, s.stream, A, it, 0);
+        else if (n_pairs <= GN_ROWS_BELOW)
+            hipLaunchKernelGGL(gn_iter_rows_kernel, dim3(rblocks), dim3(256), 0, s.stream, A, it, 0);
         else
-            hipLaunchKernelGGL(gn_iter_kernel, dim3(blocks), dim3(256), 0, s.stream, A, it);
+        {
+            hipLaunchKernelGGL(gn_iter_kernel, dim3(blocks), dim3(256), 0, s.stream, A, it, 1);
+            hipLaunchKernelGGL(gn_iter_rows_kernel, dim3(rblocks), dim3(256), 0, s.stream, A, it, 2);
+        }
     }
     EBVO_HIP(ctx, hipGetLastError());
     return EBVO_OK;
