@@ -395,6 +395,7 @@ static int host_slot(ebvo_ctx *ctx, Slot **out)
         return rc;
     s.fetch_pending = false;
     s.have_pair = s.have_run = s.have_refined = s.have_final = false;
+    s.sift_left_valid = false;
     s.undist_pair = false;
     s.fetch_what = 0;
     *out = &s;
@@ -943,6 +944,7 @@ extern "C" int ebvo_stereo_upload_slot(ebvo_ctx *ctx, int slot, const uint8_t *i
     s.have_pair = s.have_run = s.have_refined = s.have_final = false; // results of the previous pair are gone
     s.tq_n = -1;
     s.tq_final.n = -1;
+    s.sift_left_valid = false;
     if (s.fetch_pending) // a result copy of the previous pair is still reading the buffers
         EBVO_HIP(ctx, hipEventSynchronize(s.ev_rebind));
     s.fetch_pending = false;
@@ -1495,6 +1497,7 @@ extern "C" int ebvo_stereo_finalize(ebvo_ctx *ctx, int slot, const ebvo_finalize
     s.have_final = s.have_refined = false; // the refinement buffers are reused
     s.tq_n = -1;
     s.tq_final.n = -1;
+    s.sift_left_valid = false;
 
     s.n_final = 0;
     const int nL = s.result.n_left, h = s.cur_h, w = s.cur_w;
@@ -1566,6 +1569,7 @@ extern "C" int ebvo_stereo_finalize(ebvo_ctx *ctx, int slot, const ebvo_finalize
         counts->n_sift = nS;
         keep1 = both;
         conf0 = dist;
+        s.sift_left_valid = true; // dL: the descriptors of every left TOED edge of this pair (ebvo_temporal_* reuse them)
     }
     // 1. the kept NCC matches as a CSR list of right TOED edges with their scores (apply_NCC_Filtering's output, :597-607)
     if ((rc = glue_rows_from_flags_enqueue(ctx, s, rp0, nL, keep1, cnt, order)) || (rc = scan_counts(rpA, &nA)) ||
@@ -1884,9 +1888,18 @@ static int mate_descriptors(ebvo_ctx *ctx, Slot &s, const ebvo_edge *d_L, const 
     if ((rc = ebvo_grow(ctx, s, s.sift_img, sizeof(float) * 2 * npx)))
         return rc;
     float *tmp = (float *)s.sift_img.p, *base = tmp + npx;
-    if ((rc = sift_base_enqueue(ctx, s, s.im[0].img, h, w, w, tmp, base)) ||
-        (rc = sift_descriptors_enqueue(ctx, s, base, h, w, d_L, n, nullptr, d_descL)) ||
-        (rc = sift_base_enqueue(ctx, s, s.im[1].img, h, w, w, tmp, base)) ||
+    // a mate's left edge IS its left TOED edge: if ebvo_stereo_finalize ran the SIFT stages on this pair, the descriptors of
+    // every left TOED edge are still there and the mates' are picked from them
+    const size_t nLz = (size_t)s.result.n_left + 1;
+    if (s.sift_left_valid && s.have_final && d_L == (const ebvo_edge *)s.fin_edges.p + 3 * (size_t)s.result.n_pairs)
+    {
+        if ((rc = sift_gather_enqueue(ctx, s, (const uint8_t *)s.sift_desc.p, (const int32_t *)s.fin_i32.p + 3 * nLz, n, d_descL)))
+            return rc;
+    }
+    else if ((rc = sift_base_enqueue(ctx, s, s.im[0].img, h, w, w, tmp, base)) ||
+             (rc = sift_descriptors_enqueue(ctx, s, base, h, w, d_L, n, nullptr, d_descL)))
+        return rc;
+    if ((rc = sift_base_enqueue(ctx, s, s.im[1].img, h, w, w, tmp, base)) ||
         (rc = sift_descriptors_enqueue(ctx, s, base, h, w, d_R, n, nullptr, d_descR)))
         return rc;
     return EBVO_OK;
@@ -1968,7 +1981,7 @@ extern "C" int ebvo_temporal_set_keyframe(ebvo_ctx *ctx, int slot)
     // left_edge_descriptors (augment_Edge_Data, src/Stereo_Matches.cpp:655-689: the left TOED edge on the undistorted left
     // image) and right_edge_descriptors (finalize_stereo_edge_mates, :1627-1635: the final right edge on the undistorted
     // right image) of every mate
-    if ((rc = mate_descriptors(ctx, s, ctx->kf_L, ctx->kf_R, (int)n, ctx->kf_Ld, ctx->kf_Rd)))
+    if ((rc = mate_descriptors(ctx, s, fl, fr, (int)n, ctx->kf_Ld, ctx->kf_Rd)))
         return rc;
     EBVO_HIP(ctx, hipStreamSynchronize(s.stream));
     return EBVO_OK;

@@ -119,6 +119,7 @@ struct Slot
     GrowBuf grad_x, grad_y, gn_xy, gn_out, gn_valid, gn_iters, gn_state, gn_lists, gn_pack; // photometric refinement (refine_kernels.hip)
     GrowBuf tq_i32, tq_cols, tq_f64, tq_u8, tq_cells; // temporal quads of the slot's pair against the keyframe
     GrowBuf tq_chain;                                  // ... and what the stages after the NCC filter need
+    bool sift_left_valid = false;                      // sift_desc holds the descriptors of every left TOED edge of this pair
     struct TqFinal                                     // the quads that leave the chain (pointers into tq_chain)
     {
         int32_t *rp = nullptr, *cf = nullptr;
@@ -343,6 +344,7 @@ int refine_gn_temporal_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_imgK, co
 int sift_base_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_img, int h, int w, int pitch, float *d_tmp, float *d_base);
 int sift_descriptors_enqueue(ebvo_ctx *ctx, Slot &s, const float *d_base, int h, int w, const ebvo_edge *d_edges, int n,
                              float *d_desc_f, uint8_t *d_desc_u8);
+int sift_gather_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_src, const int32_t *d_index, int n, uint8_t *d_dst);
 int sift_to_u8_enqueue(ebvo_ctx *ctx, Slot &s, const float *d_f, int64_t n, uint8_t *d_u8);
 int sift_distances_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_left, const uint8_t *d_cand, const int32_t *d_pair_left,
                            const int32_t *d_cand_index, int64_t n_pairs, double thr, double *d_dist, uint8_t *d_ok);

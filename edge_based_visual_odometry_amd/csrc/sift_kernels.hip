@@ -368,6 +368,27 @@ int sift_to_u8_enqueue(ebvo_ctx *ctx, Slot &s, const float *d_f, int64_t n, uint
     return EBVO_OK;
 }
 
+// descriptor pairs (256 bytes each) of selected edges: dst[k] = src[index[k]], sixteen lanes per entry
+__global__ __launch_bounds__(256) void sift_gather_kernel(const uint8_t *__restrict__ src, const int32_t *__restrict__ index, int n,
+                                                          uint8_t *__restrict__ dst)
+{
+    const int64_t groups = ((int64_t)gridDim.x * blockDim.x) >> 4;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int g = (int)(t & 15);
+    for (int64_t k = t >> 4; k < n; k += groups)
+        reinterpret_cast<uint4 *>(dst + (size_t)k * 256)[g] = reinterpret_cast<const uint4 *>(src + (size_t)index[k] * 256)[g];
+}
+
+int sift_gather_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_src, const int32_t *d_index, int n, uint8_t *d_dst)
+{
+    if (n <= 0)
+        return EBVO_OK;
+    ProfScope ps(ctx, s, K_SIFT);
+    hipLaunchKernelGGL(sift_gather_kernel, dim3(grid1d((int64_t)n * 16, 256, 4096)), dim3(256), 0, s.stream, d_src, d_index, n, d_dst);
+    EBVO_HIP(ctx, hipGetLastError());
+    return EBVO_OK;
+}
+
 int sift_distances_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_left, const uint8_t *d_cand, const int32_t *d_pair_left,
                            const int32_t *d_cand_index, int64_t n_pairs, double thr, double *d_dist, uint8_t *d_ok)
 {

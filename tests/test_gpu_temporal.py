@@ -88,13 +88,13 @@ def test_temporal_chain_equals_oracle_chain(ctx, undist):
         l0, r0, _ = _frame(ctx, h, w, 0, F, calib)
         c0 = ctx.stereo_run(ctx.default_params(F))
         left0 = ctx.stereo_fetch(c0)["left"]
-        _, kf = ctx.stereo_finalize(calib)
-        ctx.temporal_set_keyframe()
+        _, kf = ctx.stereo_finalize(calib, use_sift=not undist)   # with the SIFT stages the mates' left descriptors are
+        ctx.temporal_set_keyframe()                               # picked from the chain's, otherwise computed: same bits
         kfL, kfR = left0[kf["left_index"]], kf["right"]
         l3, r3, _ = _frame(ctx, h, w, 2, F, calib)
         c3 = ctx.stereo_run(ctx.default_params(F))
         left3 = ctx.stereo_fetch(c3)["left"]
-        _, cf = ctx.stereo_finalize(calib)
+        _, cf = ctx.stereo_finalize(calib, use_sift=not undist)
         cfL, cfR = left3[cf["left_index"]], cf["right"]
         counts, q = ctx.temporal_match(stages=1)
     finally:
