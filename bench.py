@@ -384,7 +384,7 @@ def sequence_bench(args, wl, H, W, F, device, rank, world, dist, reduce_device):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="kitti", choices=sorted(WORKLOADS),
                     help="kitti = the headline (BASELINE.json configs[1]); euroc / eth3d = the other reference shapes")
