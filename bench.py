@@ -525,7 +525,11 @@ def main():
             bl, br = pool[k % len(pool)]
             eL, eR, _ = ctx.toed_pair(bl, br)
             lines_b = ctx.epipolar_lines(F, eL)
-            rp_b, ci_b = ctx.epi_candidates(eL, eR, lines_b)
+            rp2, ci2, ok_b = ctx.epi_candidates_staged(eL, eR, lines_b)           # stages 1 + 2 as a list, stage 3 as flags
+            keep_b = ok_b.astype(bool)
+            rows_b = np.repeat(np.arange(len(eL)), np.diff(rp2))[keep_b]
+            rp_b = np.concatenate([[0], np.cumsum(np.bincount(rows_b, minlength=len(eL)))]).astype(np.int32)
+            ci_b = ci2[keep_b]
             ctx.ncc_pairs(bl, br, eL, eR[ci_b], rp_b, want_left_patches=True)
         t_b = (time.perf_counter() - tb) / n_b
         legs = {"dropin_final_pairs_per_s": n_drop / t_drop, "dropin_final_pairs_per_frame": final_per_pair,
@@ -535,7 +539,7 @@ def main():
                                "copied back; the stereo pairs of up to three frames in flight",
                 "boundary_pairs_per_s": 1.0 / t_b,
                 "boundary_note": "the stage-wise drop-in sequence through the host-buffer C entry points (ebvo_toed_pair, "
-                                 "ebvo_epipolar_lines, ebvo_epi_candidates with all three stages, ebvo_ncc_pairs with left "
+                                 "ebvo_epipolar_lines, ebvo_epi_candidates_staged = one search for the three stages, ebvo_ncc_pairs with left "
                                  "patches), every input and output in pageable host arrays, no overlap between calls",
                 "with_h2d": n_leg / t_up, "with_h2d_d2h": n_leg / t_def, "d2h_bytes_per_pair": mb_def,
                 "with_h2d_d2h_all_scores": n_leg / t_all, "d2h_bytes_per_pair_all_scores": mb_all,

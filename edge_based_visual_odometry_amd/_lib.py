@@ -35,7 +35,7 @@ TOED_STRICT, TOED_HYBRID = 0, 1
 ABI_SYMBOLS = (
     "ebvo_strerror", "ebvo_last_error", "ebvo_abi_version", "ebvo_ctx_create", "ebvo_ctx_destroy",
     "ebvo_set_toed_mode", "ebvo_get_toed_mode", "ebvo_toed_stats",
-    "ebvo_toed", "ebvo_toed_pair", "ebvo_epipolar_lines", "ebvo_epi_candidates", "ebvo_ncc_pairs",
+    "ebvo_toed", "ebvo_toed_pair", "ebvo_epipolar_lines", "ebvo_epi_candidates", "ebvo_epi_candidates_staged", "ebvo_ncc_pairs",
     "ebvo_edge_patches", "ebvo_ncc_patches", "ebvo_ncc_quads", "ebvo_stereo_default_params", "ebvo_finalize_default_params",
     "ebvo_stereo_upload", "ebvo_stereo_run", "ebvo_stereo_fetch", "ebvo_stereo_set_slots",
     "ebvo_stereo_upload_slot", "ebvo_stereo_submit", "ebvo_stereo_wait", "ebvo_stereo_fetch_slot", "ebvo_profile_enable",
@@ -146,6 +146,8 @@ def load_library() -> C.CDLL:
     lib.ebvo_epipolar_lines.argtypes = [vp, vp, i32, vp]
     lib.ebvo_epi_candidates.argtypes = [vp, vp, i32, vp, i32, vp, dbl, dbl, dbl, i32, vp, vp, i64,
                                         C.POINTER(i64)]
+    lib.ebvo_epi_candidates_staged.restype = i32
+    lib.ebvo_epi_candidates_staged.argtypes = [vp, vp, i32, vp, i32, vp, dbl, dbl, dbl, vp, vp, vp, i64, C.POINTER(i64)]
     lib.ebvo_ncc_pairs.argtypes = [vp, vp, vp, i32, i32, ssz, ssz, vp, i32, vp, vp, dbl, vp, vp, vp, vp]
     lib.ebvo_edge_patches.argtypes = [vp, vp, i32, i32, ssz, vp, i32, vp]
     lib.ebvo_ncc_patches.argtypes = [vp, vp, vp, i32, vp]

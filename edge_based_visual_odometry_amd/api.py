@@ -141,6 +141,25 @@ class Context:
         self._check(rc, "ebvo_epi_candidates")
         return row_ptr, col[: n.value].copy()
 
+    def epi_candidates_staged(self, L, R, lines, epi_thr=0.5, max_disp=25.0, orient_thr_deg=10.0):
+        """One search for the three geometric stages: the (epipolar AND disparity) list + the orientation flag of every
+        listed pair.  One call: the list is sized generously first and fetched again only if it did not fit."""
+        L, R = _edges(L), _edges(R)
+        lines = np.ascontiguousarray(lines, dtype=np.float64).reshape(-1, 3)
+        assert len(lines) == len(L)
+        row_ptr = np.zeros(len(L) + 1, dtype=np.int32)
+        n = C.c_int64()
+        cap = max(1024, 24 * len(L))
+        for _ in range(2):
+            col, ok = np.zeros(cap, dtype=np.int32), np.zeros(cap, dtype=np.uint8)
+            rc = self.lib.ebvo_epi_candidates_staged(self._ctx, ptr(L), len(L), ptr(R), len(R), ptr(lines), epi_thr, max_disp,
+                                                     orient_thr_deg, ptr(row_ptr), ptr(col), ptr(ok), cap, C.byref(n))
+            if rc != _lib.EBVO_ERR_CAPACITY:
+                break
+            cap = int(n.value)
+        self._check(rc, "ebvo_epi_candidates_staged")
+        return row_ptr, col[: n.value].copy(), ok[: n.value].copy()
+
     # -- Stereo_Matches::apply_NCC_Filtering --------------------------------------------------
     def ncc_pairs(self, imgL, imgR, L, Rc, row_ptr, thr=0.6, want_left_patches=False):
         imgL, imgR = _u8(imgL), _u8(imgR)

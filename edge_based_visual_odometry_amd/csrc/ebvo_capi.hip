@@ -542,10 +542,33 @@ extern "C" int ebvo_epipolar_lines(const double F[9], const ebvo_edge *edges, in
     return EBVO_OK;
 }
 
+static int epi_candidates_impl(ebvo_ctx *ctx, const ebvo_edge *L, int nL, const ebvo_edge *R, int nR, const double *lines,
+                               double epi_thr, double max_disp, double orient_thr_deg, int stage_mask, int32_t *row_ptr,
+                               int32_t *col_idx, uint8_t *orient_ok, int64_t cap, int64_t *n_pairs);
+
 extern "C" int ebvo_epi_candidates(ebvo_ctx *ctx, const ebvo_edge *L, int nL, const ebvo_edge *R, int nR,
                                    const double *lines, double epi_thr, double max_disp, double orient_thr_deg,
                                    int stage_mask, int32_t *row_ptr, int32_t *col_idx, int64_t cap,
                                    int64_t *n_pairs)
+{
+    return epi_candidates_impl(ctx, L, nL, R, nR, lines, epi_thr, max_disp, orient_thr_deg, stage_mask, row_ptr, col_idx, nullptr,
+                               cap, n_pairs);
+}
+
+extern "C" int ebvo_epi_candidates_staged(ebvo_ctx *ctx, const ebvo_edge *L, int nL, const ebvo_edge *R, int nR,
+                                          const double *lines, double epi_thr, double max_disp, double orient_thr_deg,
+                                          int32_t *row_ptr, int32_t *col_idx, uint8_t *orient_ok, int64_t cap,
+                                          int64_t *n_pairs)
+{
+    if (cap > 0 && !orient_ok)
+        return EBVO_ERR_ARG;
+    return epi_candidates_impl(ctx, L, nL, R, nR, lines, epi_thr, max_disp, orient_thr_deg,
+                               EBVO_STAGE_EPIPOLAR | EBVO_STAGE_DISPARITY, row_ptr, col_idx, orient_ok, cap, n_pairs);
+}
+
+static int epi_candidates_impl(ebvo_ctx *ctx, const ebvo_edge *L, int nL, const ebvo_edge *R, int nR, const double *lines,
+                               double epi_thr, double max_disp, double orient_thr_deg, int stage_mask, int32_t *row_ptr,
+                               int32_t *col_idx, uint8_t *orient_ok, int64_t cap, int64_t *n_pairs)
 {
     if (!ctx || nL < 0 || nR < 0 || !row_ptr || !n_pairs || cap < 0 || (cap > 0 && !col_idx) ||
         (nL > 0 && (!L || !lines)) || (nR > 0 && !R) || (stage_mask & ~EBVO_STAGE_ALL) || stage_mask == 0)
@@ -607,6 +630,15 @@ extern "C" int ebvo_epi_candidates(ebvo_ctx *ctx, const ebvo_edge *L, int nL, co
                                             epi_thr, max_disp, orient_thr_deg, stage_mask)))
         return rc;
     EBVO_HIP(ctx, hipMemcpyAsync(col_idx, s.col_idx.p, sizeof(int32_t) * (size_t)np, hipMemcpyDeviceToHost, s.stream));
+    if (orient_ok)
+    {
+        // the third reference stage (apply_orientation_filter, src/Stereo_Matches.cpp:863-915) as one flag per listed pair
+        if ((rc = ebvo_grow(ctx, s, s.keep, (size_t)np)) ||
+            (rc = match_orient_flags_enqueue(ctx, s, dL, nL, dR, (const int32_t *)s.row_ptr.p, (const int32_t *)s.col_idx.p, np,
+                                             orient_thr_deg, (uint8_t *)s.keep.p)))
+            return rc;
+        EBVO_HIP(ctx, hipMemcpyAsync(orient_ok, s.keep.p, (size_t)np, hipMemcpyDeviceToHost, s.stream));
+    }
     EBVO_HIP(ctx, hipStreamSynchronize(s.stream));
     s.cap_pairs = 0; // the pipeline re-establishes its own capacity
     return EBVO_OK;

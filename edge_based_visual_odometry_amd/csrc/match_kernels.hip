@@ -1573,6 +1573,26 @@ __global__ void count_flags_kernel(const uint8_t *__restrict__ f, int64_t n, uns
         atomicAdd(out, c); // integer sum: order-independent
 }
 
+// apply_orientation_filter (src/Stereo_Matches.cpp:863-915) as a flag per listed pair: sixteen lanes per left edge
+__global__ __launch_bounds__(256) void orient_flags_kernel(const ebvo_edge *__restrict__ L, int nL, const ebvo_edge *__restrict__ R,
+                                                           const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ col_idx,
+                                                           double thr, uint8_t *__restrict__ ok)
+{
+    const int e = threadIdx.x & 15;
+    const int rows = (gridDim.x * blockDim.x) >> 4;
+    for (int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 4; i < nL; i += rows)
+    {
+        const double lth = L[i].theta;
+        for (int k = row_ptr[i] + e; k < row_ptr[i + 1]; k += 16)
+        {
+            double od = fabs((lth - R[col_idx[k]].theta) * 0x1.ca5dc1a63c1f8p+5 /* 180.0 / M_PI */);
+            if (od > 180.0)
+                od = 360.0 - od;
+            ok[k] = (od < thr || fabs(od - 180.0) < thr) ? 1 : 0; // :897
+        }
+    }
+}
+
 // Last kernel of a device-resident pair: gathers every count the host wants into one record (PairResult,
 // ebvo_internal.h).
 __global__ void pair_result_kernel(const int32_t *__restrict__ cntL, const int32_t *__restrict__ cntR,
@@ -1963,6 +1983,18 @@ int match_ncc_resident_enqueue(ebvo_ctx *ctx, Slot &s, int h, int w, int cap_edg
                            nLd, (const int32_t *)s.row_ptr.p, (const int32_t *)s.col_idx.p, (const float *)s.patches_norm_r.p,
                            s.cap_pairs, thr, (double *)s.sims.p, (double *)s.best.p, (uint8_t *)s.keep.p, s.d_matches);
     }
+    EBVO_HIP(ctx, hipGetLastError());
+    return EBVO_OK;
+}
+
+int match_orient_flags_enqueue(ebvo_ctx *ctx, Slot &s, const ebvo_edge *d_L, int nL, const ebvo_edge *d_R, const int32_t *d_row_ptr,
+                               const int32_t *d_col_idx, int64_t n_pairs, double orient_thr_deg, uint8_t *d_ok)
+{
+    if (nL <= 0 || n_pairs <= 0)
+        return EBVO_OK;
+    ProfScope ps(ctx, s, K_CAND_FILL);
+    hipLaunchKernelGGL(orient_flags_kernel, dim3(blocks_for((int64_t)nL * 16, 256, 4096)), dim3(256), 0, s.stream, d_L, nL, d_R,
+                       d_row_ptr, d_col_idx, orient_thr_deg, d_ok);
     EBVO_HIP(ctx, hipGetLastError());
     return EBVO_OK;
 }

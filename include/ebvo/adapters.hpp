@@ -211,18 +211,60 @@ class StereoMatcherHIP
         out.row_ptr.assign(left.size() + 1, 0);
         int64_t n = 0;
         const double *ln = lines.empty() ? nullptr : lines[0].data();
-        last_status = ebvo_epi_candidates(ctx_->get(), L.data(), (int)L.size(), R.data(), (int)R.size(), ln, epi_thr,
-                                          max_disp, orient_thr_deg, stage_mask, out.row_ptr.data(), nullptr, 0, &n);
-        if (!report(*ctx_, last_status, "ebvo_epi_candidates"))
-            return out;
-        out.col_idx.resize((size_t)n);
-        if (n)
+        // one search when the list fits a first guess of 24 candidates per edge (the reported size is exact otherwise)
+        int64_t cap = stage_mask == EBVO_STAGE_EPIPOLAR ? 0 : (int64_t)(24 * left.size() + 1024);
+        for (int attempt = 0; attempt < 2; ++attempt)
         {
-            last_status =
-                ebvo_epi_candidates(ctx_->get(), L.data(), (int)L.size(), R.data(), (int)R.size(), ln, epi_thr, max_disp,
-                                    orient_thr_deg, stage_mask, out.row_ptr.data(), out.col_idx.data(), n, &n);
-            report(*ctx_, last_status, "ebvo_epi_candidates");
+            out.col_idx.resize((size_t)cap);
+            last_status = ebvo_epi_candidates(ctx_->get(), L.data(), (int)L.size(), R.data(), (int)R.size(), ln, epi_thr, max_disp,
+                                              orient_thr_deg, stage_mask, out.row_ptr.data(), cap ? out.col_idx.data() : nullptr,
+                                              cap, &n);
+            if (last_status != EBVO_ERR_CAPACITY && !(cap == 0 && last_status == EBVO_OK && n > 0))
+                break;
+            cap = n;
         }
+        out.col_idx.resize(last_status == EBVO_OK ? (size_t)n : 0);
+        report(*ctx_, last_status, "ebvo_epi_candidates");
+        return out;
+    }
+
+    // The three geometric stages of get_Stereo_Edge_Pairs (:1374, :1387, :1399) from ONE device search: the list under the
+    // epipolar and disparity predicates + orient_ok[k] = pair k also passes apply_orientation_filter.  A stage-wise caller
+    // fills matching_edge_clusters from the list at the first stage (the epipolar-only list, hundreds of candidates per
+    // edge, is never formed), has nothing to do at the second and keeps the flagged pairs at the third.
+    struct StagedCandidates
+    {
+        CandidateLists lists;
+        std::vector<uint8_t> orient_ok;
+    };
+    StagedCandidates candidates_staged(const std::vector<EdgeT> &left, const std::vector<EdgeT> &right,
+                                       const std::vector<std::array<double, 3>> &lines,
+                                       double epi_thr = EBVO_EPIPOLAR_LINE_DIST_THRESH, double max_disp = EBVO_MAX_DISPARITY,
+                                       double orient_thr_deg = EBVO_ORIENT_THRESH_DEG)
+    {
+        StagedCandidates out;
+        std::vector<ebvo_edge> L(left.size()), R(right.size());
+        for (size_t k = 0; k < left.size(); ++k)
+            L[k] = to_abi(left[k]);
+        for (size_t k = 0; k < right.size(); ++k)
+            R[k] = to_abi(right[k]);
+        out.lists.row_ptr.assign(left.size() + 1, 0);
+        int64_t n = 0, cap = (int64_t)(24 * left.size() + 1024);
+        const double *ln = lines.empty() ? nullptr : lines[0].data();
+        for (int attempt = 0; attempt < 2; ++attempt)
+        {
+            out.lists.col_idx.resize((size_t)cap);
+            out.orient_ok.resize((size_t)cap);
+            last_status = ebvo_epi_candidates_staged(ctx_->get(), L.data(), (int)L.size(), R.data(), (int)R.size(), ln, epi_thr,
+                                                     max_disp, orient_thr_deg, out.lists.row_ptr.data(), out.lists.col_idx.data(),
+                                                     out.orient_ok.data(), cap, &n);
+            if (last_status != EBVO_ERR_CAPACITY)
+                break;
+            cap = n;
+        }
+        out.lists.col_idx.resize(last_status == EBVO_OK ? (size_t)n : 0);
+        out.orient_ok.resize(out.lists.col_idx.size());
+        report(*ctx_, last_status, "ebvo_epi_candidates_staged");
         return out;
     }
 

@@ -140,6 +140,15 @@ int ebvo_epi_candidates(ebvo_ctx *ctx, const ebvo_edge *L, int nL, const ebvo_ed
                         const double *lines, double epi_thr, double max_disp, double orient_thr_deg,
                         int stage_mask, int32_t *row_ptr, int32_t *col_idx, int64_t cap, int64_t *n_pairs);
 
+/* The three geometric stages for a stage-wise caller from ONE device search: the list under the epipolar AND disparity
+ * predicates (apply_Epipolar_Line_Distance_Filtering + apply_Disparity_Filtering, :381-419, :534-553) plus one flag per
+ * listed pair, orient_ok[k] = the pair passes apply_orientation_filter (:863-915).  The pairs with the flag, in order, are
+ * exactly the list ebvo_epi_candidates returns for EBVO_STAGE_ALL; the epipolar-only list (hundreds of candidates per
+ * edge) is never formed.  Same calling convention as ebvo_epi_candidates (cap = 0 sizes the list). */
+int ebvo_epi_candidates_staged(ebvo_ctx *ctx, const ebvo_edge *L, int nL, const ebvo_edge *R, int nR, const double *lines,
+                               double epi_thr, double max_disp, double orient_thr_deg, int32_t *row_ptr, int32_t *col_idx,
+                               uint8_t *orient_ok, int64_t cap, int64_t *n_pairs);
+
 /*
  * Replaces Stereo_Matches::apply_NCC_Filtering (src/Stereo_Matches.cpp:555-616) and under it
  * Utility::get_edge_patches / get_patch_similarity (src/utility.cpp:182-212, :163-180).

@@ -38,6 +38,15 @@ void keep_listed(Stereo_Edge_Pairs &p, const ebvo::CandidateLists &c)
         cl = std::move(out);
     }
 }
+// orientation flags of the staged search, for the frame they were computed on (one Pipeline per thread, as in the reference)
+struct StagedFlags
+{
+    const Stereo_Edge_Pairs *owner = nullptr;
+    double orient_thr = 0;
+    std::vector<int32_t> row_ptr;
+    std::vector<uint8_t> orient_ok;
+};
+thread_local StagedFlags g_staged;
 } // namespace
 
 void Stereo_Matches::apply_Epipolar_Line_Distance_Filtering(Stereo_Edge_Pairs &p, Dataset::Ptr dataset,
@@ -54,7 +63,22 @@ void Stereo_Matches::apply_Epipolar_Line_Distance_Filtering(Stereo_Edge_Pairs &p
         ln[i] = {lines[i](0), lines[i](1), lines[i](2)};
     const std::vector<Edge> &cand = is_left ? p.stereo_frame->right_edges : p.stereo_frame->left_edges;
     auto m = matcher();
+#ifdef EBVO_STAGEWISE_EXACT_INTERMEDIATES
+    // the epipolar-only list exactly as the reference leaves it after this stage: hundreds of candidates per edge, one
+    // device search per stage (the two filters below search again)
     ebvo::CandidateLists c = m.candidates(p.get_focused_edges(), cand, ln, EBVO_STAGE_EPIPOLAR, EPIPOLAR_LINE_DIST_THRESH);
+#else
+    // ONE device search for the three geometric stages: the (epipolar AND disparity) list now, the orientation flags kept for
+    // apply_orientation_filter.  What differs from the reference is only what an observer sees BETWEEN the stages: the
+    // candidates the disparity filter would drop are already gone here.
+    auto st = m.candidates_staged(p.get_focused_edges(), cand, ln, EPIPOLAR_LINE_DIST_THRESH, MAX_DISPARITY,
+                                  EBVO_ORIENT_THRESH_DEG);
+    const ebvo::CandidateLists &c = st.lists;
+    g_staged.owner = &p;
+    g_staged.orient_thr = EBVO_ORIENT_THRESH_DEG;
+    g_staged.row_ptr = st.lists.row_ptr;
+    g_staged.orient_ok = st.orient_ok;
+#endif
     for (size_t i = 0; i < c.rows(); ++i)
     {
         std::vector<EdgeCluster> clusters;
@@ -88,11 +112,36 @@ static void filter_stage(Stereo_Edge_Pairs &p, int stage, double max_disp, doubl
 
 void Stereo_Matches::apply_Disparity_Filtering(Stereo_Edge_Pairs &p, const std::string &, size_t)
 {
+    if (g_staged.owner == &p) // the staged search applied the disparity predicate already
+        return;
     filter_stage(p, EBVO_STAGE_DISPARITY, MAX_DISPARITY, EBVO_ORIENT_THRESH_DEG);
 }
 
 void Stereo_Matches::apply_orientation_filter(Stereo_Edge_Pairs &p, double orientation_threshold, const std::string &, size_t)
 {
+    if (g_staged.owner == &p && g_staged.orient_thr == orientation_threshold &&
+        g_staged.row_ptr.size() == p.matching_edge_clusters.size() + 1)
+    {
+        // keep the flagged candidates of every row: no device call, no list crosses the boundary again
+        for (size_t i = 0; i + 1 < g_staged.row_ptr.size(); ++i)
+        {
+            auto &cl = p.matching_edge_clusters[i].edge_clusters;
+            const int32_t b = g_staged.row_ptr[i], n = g_staged.row_ptr[i + 1] - b;
+            if ((size_t)n != cl.size())
+                break; // the lists were changed behind our back: fall through to the device search below
+            std::vector<EdgeCluster> out;
+            for (int32_t k = 0; k < n; ++k)
+                if (g_staged.orient_ok[(size_t)(b + k)])
+                    out.push_back(std::move(cl[(size_t)k]));
+            cl = std::move(out);
+            if (i + 2 == g_staged.row_ptr.size())
+            {
+                g_staged.owner = nullptr;
+                return;
+            }
+        }
+    }
+    g_staged.owner = nullptr;
     filter_stage(p, EBVO_STAGE_DISPARITY | EBVO_STAGE_ORIENTATION, MAX_DISPARITY, orientation_threshold);
 }
 

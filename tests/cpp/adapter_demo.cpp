@@ -69,6 +69,16 @@ int main(int argc, char **argv)
     ebvo::StereoMatcherHIP<Edge> matcher(TOED->context());
     auto lines = ebvo::StereoMatcherHIP<Edge>::CalculateEpipolarLine(F, left_edges);
     ebvo::CandidateLists c = matcher.candidates(left_edges, right_edges, lines);
+    {
+        // the staged call: flagged pairs of the (epipolar + disparity) list == the list of all three stages
+        auto st = matcher.candidates_staged(left_edges, right_edges, lines);
+        std::vector<int32_t> flagged;
+        for (size_t k = 0; k < st.lists.col_idx.size(); ++k)
+            if (st.orient_ok[k])
+                flagged.push_back(st.lists.col_idx[k]);
+        if (matcher.last_status != EBVO_OK || flagged != c.col_idx || st.lists.col_idx.size() <= c.col_idx.size())
+            return 12;
+    }
     std::vector<Edge> cand(c.col_idx.size());
     for (size_t k = 0; k < cand.size(); ++k)
         cand[k] = right_edges[(size_t)c.col_idx[k]];

@@ -118,3 +118,27 @@ def test_candidates_rows_longer_than_the_staging_area(ctx):
             assert n.min() > 64                              # every row is refilled
         if mask == 3:
             assert n.max() > 64 and n.min() <= 64            # staged and refilled rows side by side
+
+
+@pytest.mark.parametrize("cfg", ["kitti", "euroc"])
+def test_staged_candidates_give_all_three_stages_from_one_search(ctx, cfg):
+    """ebvo_epi_candidates_staged: the (epipolar AND disparity) list of the oracle, and the pairs flagged orient_ok are, in
+    order, the oracle's list for all three stages."""
+    l, r = synth.stereo_pair("s2", 120, 200)
+    L, R = orc.toed(l)["edges"], orc.toed(r)["edges"]
+    lines = orc.epipolar_lines(synth.fundamental_for(cfg), L)
+    for thr in ((0.5, 25.0, 10.0), (1.5, 12.0, 30.0)):
+        rp, ci, ok = ctx.epi_candidates_staged(L, R, lines, *thr)
+        rp2, ci2 = orc.epi_candidates(L, R, lines, *thr, stage_mask=3)
+        assert_bit_equal(rp, rp2, "row_ptr (epipolar + disparity)")
+        assert_bit_equal(ci, ci2, "col_idx (epipolar + disparity)")
+        rp3, ci3 = orc.epi_candidates(L, R, lines, *thr, stage_mask=7)
+        rows = np.repeat(np.arange(len(L)), np.diff(rp))
+        keep = ok.astype(bool)
+        assert_bit_equal(ci[keep], ci3, "flagged pairs == the list of all three stages")
+        assert_bit_equal(np.bincount(rows[keep], minlength=len(L)).astype(np.int32), np.diff(rp3).astype(np.int32), "rows")
+        if cfg == "kitti":   # the euroc F leaves this small synthetic pair without candidates: parity of the empty lists only
+            assert 0 < keep.sum() < len(keep)
+    # empty inputs
+    rp, ci, ok = ctx.epi_candidates_staged(L[:0], R, lines[:0])
+    assert len(rp) == 1 and len(ci) == 0 and len(ok) == 0
