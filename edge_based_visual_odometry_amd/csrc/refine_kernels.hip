@@ -146,15 +146,17 @@ __global__ __launch_bounds__(256) void undistort_kernel(const uint8_t *__restric
 // one point
 __device__ inline void tap_at(double x, double y, int w, int h, int &x0, int &x1, int &y0, int &y1, double &a, double &b)
 {
-    x = x < 0.0 ? 0.0 : (((double)w - 1.0) < x ? ((double)w - 1.0) : x); // std::clamp
-    y = y < 0.0 ? 0.0 : (((double)h - 1.0) < y ? ((double)h - 1.0) : y);
+    // std::clamp(x, 0, w - 1) as max / min: the same value for every non-NaN x (a NaN coordinate is undefined behaviour
+    // in the reference: it converts floor(NaN) to int); two instructions instead of two compares and four selects
+    x = fmin(fmax(x, 0.0), (double)w - 1.0);
+    y = fmin(fmax(y, 0.0), (double)h - 1.0);
     const double fx = floor(x), fy = floor(y);
     x0 = (int)fx;
     y0 = (int)fy;
     x1 = min(x0 + 1, w - 1);
     y1 = min(y0 + 1, h - 1);
-    a = x - x0;
-    b = y - y0;
+    a = x - fx; // == x - (double)x0: fx is an integer in [0, w - 1]
+    b = y - fy;
 }
 
 __device__ inline float blend(double a, double b, float v00, float v10, float v01, float v11)
@@ -259,6 +261,40 @@ __device__ inline float sample_pix4(const uint32_t *__restrict__ pix4, int w, in
     return blend(a, b, (float)(q & 0xffu), (float)((q >> 8) & 0xffu), (float)((q >> 16) & 0xffu), (float)(q >> 24));
 }
 
+// One bilinear tap of the three right-image planes from the packed corner record: the floats util_bilinear_Sample_F
+// returns for the intensity, Sobel gx and Sobel gy at (x, y) -- ONE 16-byte load.
+struct GnTap
+{
+    float v, gx, gy;
+};
+
+__device__ inline GnTap gn_tap(const uint4 *__restrict__ rec, int w, int h, double x, double y)
+{
+    int x0, x1, y0, y1;
+    double wa, wb;
+    tap_at(x, y, w, h, x0, x1, y0, y1, wa, wb);
+    const uint4 q = rec[(size_t)y0 * w + x0]; // the four corners: intensity, 8 gx, 8 gy
+    const unsigned wd[4] = {q.x, q.y, q.z, q.w};
+    double iv[4], gxc[4], gyc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+    {
+        iv[c] = (double)((wd[c] & 31u) | ((wd[c] >> 11) & 0xe0u));
+        gxc[c] = (double)(((int)(wd[c] << 16)) >> 21); // 8 gx: bits 5..15, sign-extended
+        gyc[c] = (double)(((int)wd[c]) >> 21);         // 8 gy: bits 21..31
+    }
+    // blend()'s sums with the corner weights formed once.  The gradient planes hold (float)(8 g) * 0.125f; the factor
+    // 1/8 goes into the weights instead -- a power of two, so every product and every sum is the same double.
+    const double oma = 1 - wa, omb = 1 - wb;
+    const double w00 = oma * omb, w10 = wa * omb, w01 = oma * wb, w11 = wa * wb;
+    const double s00 = w00 * 0.125, s10 = w10 * 0.125, s01 = w01 * 0.125, s11 = w11 * 0.125;
+    GnTap t;
+    t.v = (float)(w00 * iv[0] + w10 * iv[1] + w01 * iv[2] + w11 * iv[3]);
+    t.gx = (float)(s00 * gxc[0] + s10 * gxc[1] + s01 * gxc[2] + s11 * gxc[3]);
+    t.gy = (float)(s00 * gyc[0] + s10 * gyc[1] + s01 * gyc[2] + s11 * gyc[3]);
+    return t;
+}
+
 struct GnArgs
 {
     const uint8_t *imgL, *imgR;
@@ -287,6 +323,7 @@ struct GnArgs
     double *sc;       // [2][nL] sin, cos of the left orientation
     int32_t *list[2]; // active pairs, ping-pong
     int32_t *counts;  // [max_iter + 1] active pairs entering iteration it
+    int rows_below;   // an iteration entering with at most this many active pairs runs eight lanes per pair
 };
 
 // The pairs need 1 .. max_iter iterations each (mean ~8, an eighth run all 20): one thread looping to its own
@@ -395,20 +432,24 @@ __global__ __launch_bounds__(256) void gn_init_kernel(GnArgs A)
 // above GN_ROWS_BELOW active pairs (the launch is throughput-bound there and that layout is the cheaper one per pair),
 // eight lanes per pair below it (a small launch of the thread layout lasts ~100 us whatever it holds).  Large problems
 // launch BOTH kernels per iteration and one of them returns at once (mode 1 / 2); small ones only the row layout (mode 0).
+#ifndef GN_TAP_ROWS
+#define GN_TAP_ROWS 1
+#endif
 constexpr int GN_ROWS_BELOW = 65536;
-__device__ inline bool gn_other_layout(int mode, int n_active)
+__device__ inline bool gn_other_layout(int mode, int n_active, int rows_below)
 {
-    return (mode == 1 && n_active <= GN_ROWS_BELOW) || (mode == 2 && n_active > GN_ROWS_BELOW);
+    return (mode == 1 && n_active <= rows_below) || (mode == 2 && n_active > rows_below);
 }
 
-__global__ __launch_bounds__(256) void gn_iter_kernel(GnArgs A, int it, int mode)
+__global__ __launch_bounds__(256, 2) void gn_iter_kernel(GnArgs A, int it, int mode)
 {
     const int h = A.h, w = A.w;
     const int n_in = A.counts[it];
-    if (gn_other_layout(mode, n_in))
+    if (gn_other_layout(mode, n_in, A.rows_below))
         return;
     const int32_t *__restrict__ lin = A.list[it & 1];
     int32_t *__restrict__ lout = A.list[(it + 1) & 1];
+    __shared__ float s_tv[49][256]; // the intensity taps of one side, private to each thread (its gradient taps stay in registers)
     const int lane = threadIdx.x & 63;
     for (int base = blockIdx.x * blockDim.x; base < n_in; base += gridDim.x * blockDim.x)
     {
@@ -429,57 +470,50 @@ __global__ __launch_bounds__(256) void gn_iter_kernel(GnArgs A, int it, int mode
             const double meanL[2] = {A.mean_l[li], A.mean_l[A.nL + li]};
             double alpha = A.alpha[k];
             const double shx = ex * alpha, shy = ey * alpha;
-            double meanR[2];
-#pragma unroll 1
-            for (int sd = 0; sd < 2; ++sd)
-            {
-                const double cx = (sd ? rx - nx * side : rx + nx * side) + shx; // :1204-1205
-                const double cy = (sd ? ry - ny * side : ry + ny * side) + shy;
-                double sum = 0;
-#pragma unroll 1
-                for (int i = -3; i <= 3; ++i)
-#pragma unroll
-                    for (int j = -3; j <= 3; ++j)
-                        sum += (double)sample_pix4(A.pix4R, w, h, cx + ct * i - st * j, cy + st * i + ct * j);
-                meanR[sd] = sum / 49;
-            }
+            // One pass over the right image per side: every sample point is tapped ONCE (intensity and both gradients from
+            // one 16-byte record) and its three floats stay in registers while the mean of the side forms; the residual
+            // terms follow from the registers.  (The reference samples the patch twice, :1204-1247; the values are the same.)
             double H = 0.0, b = 0.0, cost = 0.0;
 #pragma unroll 1
             for (int sd = 0; sd < 2; ++sd)
             {
                 const float *__restrict__ lrec = A.left_rec + (size_t)li * 98 + sd * 49;
-                const double cx = (sd ? rx - nx * side : rx + nx * side) + shx;
+                const double cx = (sd ? rx - nx * side : rx + nx * side) + shx; // :1204-1205
                 const double cy = (sd ? ry - ny * side : ry + ny * side) + shy;
-#pragma unroll 1
+                float tgx[49], tgy[49];
+                double sum = 0;
+#pragma unroll
                 for (int i = -3; i <= 3; ++i)
+                {
 #pragma unroll // the seven 16-byte loads of a patch row are independent: all in flight together
                     for (int j = -3; j <= 3; ++j)
                     {
-                        const double Lf = (double)lrec[(i + 3) * 7 + (j + 3)]; // sampled once by gn_left_kernel
-                        int x0, x1, y0, y1;
-                        double wa, wb;
-                        tap_at(cx + ct * i - st * j, cy + st * i + ct * j, w, h, x0, x1, y0, y1, wa, wb);
-                        const uint4 q = A.recR[(size_t)y0 * w + x0]; // the four corners: intensity, 8 gx, 8 gy
-                        const unsigned wd[4] = {q.x, q.y, q.z, q.w};
-                        float iv[4], gxc[4], gyc[4];
-#pragma unroll
-                        for (int c = 0; c < 4; ++c)
-                        {
-                            iv[c] = (float)((wd[c] & 31u) | ((wd[c] >> 11) & 0xe0u));
-                            gxc[c] = (float)(((int)(wd[c] << 16)) >> 21) * 0.125f; // bits 5..15, sign-extended
-                            gyc[c] = (float)(((int)wd[c]) >> 21) * 0.125f;         // bits 21..31
-                        }
-                        const double Rf = (double)blend(wa, wb, iv[0], iv[1], iv[2], iv[3]);
-                        const double gxv = (double)blend(wa, wb, gxc[0], gxc[1], gxc[2], gxc[3]);
-                        const double gyv = (double)blend(wa, wb, gyc[0], gyc[1], gyc[2], gyc[3]);
-                        const double r = (Lf - meanL[sd]) - (Rf - meanR[sd]);
-                        const double g = -gxv * ex + gyv * ey; // :1237
-                        const double absr = fabs(r);
-                        const double wgt = (absr <= A.huber) ? 1.0 : A.huber / absr;
-                        H += wgt * g * g;
-                        b += wgt * g * r;
-                        cost += wgt * r * r;
+                        const GnTap t = gn_tap(A.recR, w, h, cx + ct * i - st * j, cy + st * i + ct * j);
+                        const int o = (i + 3) * 7 + (j + 3);
+                        s_tv[o][threadIdx.x] = t.v;
+                        tgx[o] = t.gx;
+                        tgy[o] = t.gy;
+                        sum += (double)t.v;
                     }
+                    if ((i + 3) % GN_TAP_ROWS == GN_TAP_ROWS - 1) // GN_TAP_ROWS rows of records in flight, not all forty-nine
+                        __builtin_amdgcn_sched_barrier(0);
+                }
+                const double meanR = sum / 49;
+#pragma unroll
+                for (int o = 0; o < 49; ++o)
+                {
+                    if (o % 7 == 0)
+                        __builtin_amdgcn_sched_barrier(0);
+                    const double Lf = (double)lrec[o]; // sampled once by gn_left_kernel
+                    const double Rf = (double)s_tv[o][threadIdx.x], gxv = (double)tgx[o], gyv = (double)tgy[o];
+                    const double r = (Lf - meanL[sd]) - (Rf - meanR);
+                    const double g = -gxv * ex + gyv * ey; // :1237
+                    const double absr = fabs(r);
+                    const double wgt = (absr <= A.huber) ? 1.0 : A.huber / absr;
+                    H += wgt * g * g;
+                    b += wgt * g * r;
+                    cost += wgt * r * r;
+                }
             }
             int done_iters = it; // stop on H < 1e-8: outputs stay unset (:1255)
             bool finished = true;
@@ -527,11 +561,11 @@ __global__ __launch_bounds__(256) void gn_iter_kernel(GnArgs A, int it, int mode
 // waves, an eighth of the chain.  The reference's sums are sequential over the 49 (98) samples and stay so: the running
 // sum visits the lanes in row order (lane r adds its seven terms to what lane r - 1 produced).  Bit-identical to
 // gn_iter_kernel (the refinement tests run both).
-__global__ __launch_bounds__(256) void gn_iter_rows_kernel(GnArgs A, int it, int mode)
+__global__ __launch_bounds__(256, 3) void gn_iter_rows_kernel(GnArgs A, int it, int mode)
 {
     const int h = A.h, w = A.w;
     const int n_in = A.counts[it];
-    if (gn_other_layout(mode, n_in))
+    if (gn_other_layout(mode, n_in, A.rows_below))
         return;
     const int32_t *__restrict__ lin = A.list[it & 1];
     int32_t *__restrict__ lout = A.list[(it + 1) & 1];
@@ -555,16 +589,17 @@ __global__ __launch_bounds__(256) void gn_iter_rows_kernel(GnArgs A, int it, int
         double alpha = A.alpha[k];
         const double shx = ex * alpha, shy = ey * alpha;
         const int i = min(row, 6) - 3; // this lane's patch row (lane 7 repeats row 6 and is never selected)
-        double meanR[2];
+        double H = 0.0, b = 0.0, cost = 0.0;
 #pragma unroll 1
         for (int sd = 0; sd < 2; ++sd)
         {
+            const float *__restrict__ lrec = A.left_rec + (size_t)li * 98 + sd * 49 + (i + 3) * 7;
             const double cx = (sd ? rx - nx * side : rx + nx * side) + shx; // :1204-1205
             const double cy = (sd ? ry - ny * side : ry + ny * side) + shy;
-            float v[7];
+            GnTap tp[7]; // this lane's row of the side: tapped once, intensity and both gradients
 #pragma unroll
             for (int j = -3; j <= 3; ++j)
-                v[j + 3] = sample_pix4(A.pix4R, w, h, cx + ct * i - st * j, cy + st * i + ct * j);
+                tp[j + 3] = gn_tap(A.recR, w, h, cx + ct * i - st * j, cy + st * i + ct * j);
             double sum = 0;
 #pragma unroll 1
             for (int r = 0; r < 7; ++r)
@@ -572,46 +607,23 @@ __global__ __launch_bounds__(256) void gn_iter_rows_kernel(GnArgs A, int it, int
                 double t = sum;
 #pragma unroll
                 for (int j = 0; j < 7; ++j)
-                    t += (double)v[j];
+                    t += (double)tp[j].v;
                 sum = __shfl(t, gbase | r); // the running sum after row r
             }
-            meanR[sd] = sum / 49;
-        }
-        double H = 0.0, b = 0.0, cost = 0.0;
-#pragma unroll 1
-        for (int sd = 0; sd < 2; ++sd)
-        {
-            const float *__restrict__ lrec = A.left_rec + (size_t)li * 98 + sd * 49 + (i + 3) * 7;
-            const double cx = (sd ? rx - nx * side : rx + nx * side) + shx;
-            const double cy = (sd ? ry - ny * side : ry + ny * side) + shy;
+            const double meanR = sum / 49;
             double tH[7], tb[7], tc[7];
 #pragma unroll
-            for (int j = -3; j <= 3; ++j)
+            for (int j = 0; j < 7; ++j)
             {
-                const double Lf = (double)lrec[j + 3]; // sampled once by gn_left_kernel
-                int x0, x1, y0, y1;
-                double wa, wb;
-                tap_at(cx + ct * i - st * j, cy + st * i + ct * j, w, h, x0, x1, y0, y1, wa, wb);
-                const uint4 q = A.recR[(size_t)y0 * w + x0]; // the four corners: intensity, 8 gx, 8 gy
-                const unsigned wd[4] = {q.x, q.y, q.z, q.w};
-                float iv[4], gxc[4], gyc[4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-                {
-                    iv[c] = (float)((wd[c] & 31u) | ((wd[c] >> 11) & 0xe0u));
-                    gxc[c] = (float)(((int)(wd[c] << 16)) >> 21) * 0.125f; // bits 5..15, sign-extended
-                    gyc[c] = (float)(((int)wd[c]) >> 21) * 0.125f;         // bits 21..31
-                }
-                const double Rf = (double)blend(wa, wb, iv[0], iv[1], iv[2], iv[3]);
-                const double gxv = (double)blend(wa, wb, gxc[0], gxc[1], gxc[2], gxc[3]);
-                const double gyv = (double)blend(wa, wb, gyc[0], gyc[1], gyc[2], gyc[3]);
-                const double r = (Lf - meanL[sd]) - (Rf - meanR[sd]);
+                const double Lf = (double)lrec[j]; // sampled once by gn_left_kernel
+                const double Rf = (double)tp[j].v, gxv = (double)tp[j].gx, gyv = (double)tp[j].gy;
+                const double r = (Lf - meanL[sd]) - (Rf - meanR);
                 const double g = -gxv * ex + gyv * ey; // :1237
                 const double absr = fabs(r);
                 const double wgt = (absr <= A.huber) ? 1.0 : A.huber / absr;
-                tH[j + 3] = wgt * g * g; // the addends of gn_iter_kernel's three sums, formed by the same operations
-                tb[j + 3] = wgt * g * r;
-                tc[j + 3] = wgt * r * r;
+                tH[j] = wgt * g * g; // the addends of gn_iter_kernel's three sums, formed by the same operations
+                tb[j] = wgt * g * r;
+                tc[j] = wgt * r * r;
             }
 #pragma unroll 1
             for (int r = 0; r < 7; ++r)
@@ -873,7 +885,7 @@ __global__ __launch_bounds__(256) void gn2_iter_kernel(Gn2Args A, int it)
 
 // Eight lanes per item for small batches, as gn_iter_rows_kernel: lane r < 7 = patch row r of both sides; the nine
 // running sums (H gets its 1e-6 I after every sample, :809) visit the lanes in row order.  Bit-identical to gn2_iter_kernel.
-__global__ __launch_bounds__(256) void gn2_iter_rows_kernel(Gn2Args A, int it)
+__global__ __launch_bounds__(256, 2) void gn2_iter_rows_kernel(Gn2Args A, int it)
 {
     const int h = A.h, w = A.w;
     const int n_in = A.counts[it];
@@ -1199,13 +1211,15 @@ int refine_gn_stereo_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_imgL, cons
     hipLaunchKernelGGL(gn_left_kernel, dim3((unsigned)((nL + 255) / 256 < 2048 ? (nL + 255) / 256 : 2048)), dim3(256), 0,
                        s.stream, A);
     hipLaunchKernelGGL(gn_init_kernel, dim3(blocks), dim3(256), 0, s.stream, A);
+    const bool no_rows = getenv("EBVO_GN_NO_ROWS") != nullptr;
+    const char *rows_env = getenv("EBVO_GN_ROWS_BELOW"); // developer knob (tools/gpu_stereo_refine_time.py sweeps it)
+    A.rows_below = rows_env ? atoi(rows_env) : GN_ROWS_BELOW;
     for (int it = 0; it < max_iter; ++it)
     {
-        const bool no_rows = getenv("EBVO_GN_NO_ROWS") != nullptr;
         const unsigned rblocks = (unsigned)((n_pairs + 31) / 32 < 8192 ? (n_pairs + 31) / 32 : 8192);
         if (no_rows)
             hipLaunchKernelGGL(gn_iter_kernel, dim3(blocks), dim3(256), 0, s.stream, A, it, 0);
-        else if (n_pairs <= GN_ROWS_BELOW)
+        else if (n_pairs <= A.rows_below)
             hipLaunchKernelGGL(gn_iter_rows_kernel, dim3(rblocks), dim3(256), 0, s.stream, A, it, 0);
         else
         {

@@ -10,7 +10,7 @@ python3 - "$CSV" <<'PY'
 import csv, sys
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if "gn_" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-last = rows[-22:]          # the last refine call: init kernels + 20 iterations
+last = rows[-44:]          # the last refine call: init kernels + 20 iterations x two layouts
 for r in last:
     print("%-40s %8.1f us  grid %s" % (r["Kernel_Name"][:40], (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, r.get("Grid_Size", "?")))
 PY
