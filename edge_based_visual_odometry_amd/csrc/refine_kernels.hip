@@ -211,9 +211,10 @@ __device__ inline float sample_u8(const uint8_t *__restrict__ img, int pitch, in
 // image, everything a bilinear tap at floor = (x0, y0) reads, with util_bilinear_Sample_F's clamps x1 = min(x0 + 1, w - 1),
 // y1 = min(y0 + 1, h - 1) (include/utility.h:166-167) baked in:
 //   pix4[y0 * w + x0] = I(x0,y0) | I(x1,y0) << 8 | I(x0,y1) << 16 | I(x1,y1) << 24                 (4 bytes)
-//   rec [y0 * w + x0] = eight 16-bit words: (8 gx) << 5 | I low 5 bits, (8 gy) << 5 | I high 3 bits per corner  (16 bytes)
+//   rec [y0 * w + x0] = one word per corner: I | (8 gx) << 8 | (8 gy) << 19  (two 11-bit signed fields)             (16 bytes)
 // (8 x Sobel / 8 is an integer in [-1020, 1020]: 11 bits; the float the reference reads is that integer times 0.125,
-// exactly).  One 4-byte load per point in the mean pass, one 16-byte load in the residual pass: 2 instead of 6.
+// exactly).  The iterations read ONE 16-byte record per sample point (gn_tap) and keep its three floats while the mean
+// of the patch forms; pix4 serves the left image, whose patches are sampled once per left edge (gn_left_kernel).
 __device__ inline void sobel_at(const uint8_t *__restrict__ img, int h, int w, int pitch, int x, int y, int &sx, int &sy)
 {
     const uint8_t *r0 = img + (size_t)reflect101(y - 1, h) * pitch, *r1 = img + (size_t)y * pitch,
@@ -235,7 +236,8 @@ __global__ __launch_bounds__(256) void gn_pack_kernel(const uint8_t *__restrict_
 #pragma unroll
     for (int c = 0; c < 4; ++c)
         I[c] = img[(size_t)cy[c] * pitch + cx[c]];
-    pix4[(size_t)y0 * w + x0] = I[0] | (I[1] << 8) | (I[2] << 16) | (I[3] << 24);
+    if (pix4)
+        pix4[(size_t)y0 * w + x0] = I[0] | (I[1] << 8) | (I[2] << 16) | (I[3] << 24);
     if (!rec)
         return;
     unsigned wd[4];
@@ -244,9 +246,7 @@ __global__ __launch_bounds__(256) void gn_pack_kernel(const uint8_t *__restrict_
     {
         int sx, sy;
         sobel_at(img, h, w, pitch, cx[c], cy[c], sx, sy);
-        const unsigned wx = (((unsigned)sx << 5) & 0xffe0u) | (I[c] & 31u);
-        const unsigned wy = (((unsigned)sy << 5) & 0xffe0u) | (I[c] >> 5);
-        wd[c] = wx | (wy << 16);
+        wd[c] = I[c] | (((unsigned)sx & 0x7ffu) << 8) | (((unsigned)sy & 0x7ffu) << 19);
     }
     rec[(size_t)y0 * w + x0] = make_uint4(wd[0], wd[1], wd[2], wd[3]);
 }
@@ -279,9 +279,9 @@ __device__ inline GnTap gn_tap(const uint4 *__restrict__ rec, int w, int h, doub
 #pragma unroll
     for (int c = 0; c < 4; ++c)
     {
-        iv[c] = (double)((wd[c] & 31u) | ((wd[c] >> 11) & 0xe0u));
-        gxc[c] = (double)(((int)(wd[c] << 16)) >> 21); // 8 gx: bits 5..15, sign-extended
-        gyc[c] = (double)(((int)wd[c]) >> 21);         // 8 gy: bits 21..31
+        iv[c] = (double)(wd[c] & 0xffu);
+        gxc[c] = (double)(((int)(wd[c] << 13)) >> 21); // 8 gx: bits 8..18, sign-extended
+        gyc[c] = (double)(((int)(wd[c] << 2)) >> 21);  // 8 gy: bits 19..29
     }
     // blend()'s sums with the corner weights formed once.  The gradient planes hold (float)(8 g) * 0.125f; the factor
     // 1/8 goes into the weights instead -- a power of two, so every product and every sum is the same double.
@@ -325,6 +325,30 @@ struct GnArgs
     int32_t *counts;  // [max_iter + 1] active pairs entering iteration it
     int rows_below;   // an iteration entering with at most this many active pairs runs eight lanes per pair
 };
+
+// Append to a device list from a block of 256 threads: ONE atomic per block (one per wave made gn_init_kernel last 107 us
+// for 581,657 pairs -- 9,088 returning atomics on one address).  Every thread of the block must call it; `turn` is the
+// caller's loop count (the scratch words alternate so that a fast wave cannot overwrite what a slow one still reads).
+// Returns the slot of this thread's item (meaningful where `put`).
+__device__ inline int block_append_slot(bool put, int32_t *counter, int turn)
+{
+    __shared__ int s_cnt[2][4], s_base[2];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, t = turn & 1;
+    const unsigned long long m = __ballot(put);
+    if (lane == 0)
+        s_cnt[t][wv] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        const int total = s_cnt[t][0] + s_cnt[t][1] + s_cnt[t][2] + s_cnt[t][3];
+        s_base[t] = total ? atomicAdd(counter, total) : 0;
+    }
+    __syncthreads();
+    int slot = s_base[t] + __popcll(m & ((1ull << lane) - 1ull));
+    for (int v = 0; v < wv; ++v)
+        slot += s_cnt[t][v];
+    return slot;
+}
 
 // The pairs need 1 .. max_iter iterations each (mean ~8, an eighth run all 20): one thread looping to its own
 // convergence keeps a wave busy until its slowest lane is done (2.6x the work at 64 lanes).  So the iteration is a
@@ -391,21 +415,17 @@ __global__ __launch_bounds__(256) void gn_left_kernel(GnArgs A)
 
 __global__ __launch_bounds__(256) void gn_init_kernel(GnArgs A)
 {
-    const int lane = threadIdx.x & 63;
+    int turn = 0;
     const int64_t span = (int64_t)gridDim.x * blockDim.x;
     for (int64_t k0 = (int64_t)blockIdx.x * blockDim.x; k0 < A.n_pairs; k0 += span)
     {
         const int64_t k = k0 + threadIdx.x;
         const bool inside = k < A.n_pairs;
         const bool active = inside && (!A.keep || A.keep[k]);
-        // the first active list, one atomic per wave (its order does not influence any result)
-        const unsigned long long m = __ballot(active);
-        int wbase = 0;
-        if (lane == 0 && m)
-            wbase = atomicAdd(&A.counts[0], __popcll(m));
-        wbase = __shfl(wbase, 0);
+        // the first active list (its order does not influence any result)
+        const int slot = block_append_slot(active, &A.counts[0], turn++);
         if (active)
-            A.list[0][wbase + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)k;
+            A.list[0][slot] = (int32_t)k;
         if (inside && !active)
         {
             double rx, ry;
@@ -433,7 +453,7 @@ __global__ __launch_bounds__(256) void gn_init_kernel(GnArgs A)
 // eight lanes per pair below it (a small launch of the thread layout lasts ~100 us whatever it holds).  Large problems
 // launch BOTH kernels per iteration and one of them returns at once (mode 1 / 2); small ones only the row layout (mode 0).
 #ifndef GN_TAP_ROWS
-#define GN_TAP_ROWS 1
+#define GN_TAP_ROWS 2 // patch rows whose records are in flight together (2.79 -> 2.72 ms against 1)
 #endif
 constexpr int GN_ROWS_BELOW = 65536;
 __device__ inline bool gn_other_layout(int mode, int n_active, int rows_below)
@@ -450,7 +470,7 @@ __global__ __launch_bounds__(256, 2) void gn_iter_kernel(GnArgs A, int it, int m
     const int32_t *__restrict__ lin = A.list[it & 1];
     int32_t *__restrict__ lout = A.list[(it + 1) & 1];
     __shared__ float s_tv[49][256]; // the intensity taps of one side, private to each thread (its gradient taps stay in registers)
-    const int lane = threadIdx.x & 63;
+    int turn = 0;
     for (int base = blockIdx.x * blockDim.x; base < n_in; base += gridDim.x * blockDim.x)
     {
         const int idx = base + threadIdx.x;
@@ -542,14 +562,10 @@ __global__ __launch_bounds__(256, 2) void gn_iter_kernel(GnArgs A, int it, int m
             }
             survives = !finished;
         }
-        // append the survivors: one atomic per wave
-        const unsigned long long m = __ballot(survives);
-        int wbase = 0;
-        if (lane == 0 && m)
-            wbase = atomicAdd(&A.counts[it + 1], __popcll(m));
-        wbase = __shfl(wbase, 0);
+        // append the survivors: one atomic per block
+        const int slot = block_append_slot(survives, &A.counts[it + 1], turn++);
         if (survives)
-            lout[wbase + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)k;
+            lout[slot] = (int32_t)k;
     }
 }
 
@@ -1206,7 +1222,7 @@ int refine_gn_stereo_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_imgL, cons
     {
         const dim3 pg((w + 63) / 64, (h + 3) / 4);
         hipLaunchKernelGGL(gn_pack_kernel, pg, dim3(256), 0, s.stream, d_imgL, h, w, w, pix4L, (uint4 *)nullptr);
-        hipLaunchKernelGGL(gn_pack_kernel, pg, dim3(256), 0, s.stream, d_imgR, h, w, w, pix4R, recR);
+        hipLaunchKernelGGL(gn_pack_kernel, pg, dim3(256), 0, s.stream, d_imgR, h, w, w, (uint32_t *)nullptr, recR);
     }
     hipLaunchKernelGGL(gn_left_kernel, dim3((unsigned)((nL + 255) / 256 < 2048 ? (nL + 255) / 256 : 2048)), dim3(256), 0,
                        s.stream, A);
