@@ -29,58 +29,160 @@ __device__ __noinline__ void sort_long_row(int32_t *ord, int n, const double *sc
     ebvo_std_sort(ord, n, &c);
 }
 
-__global__ void bnb_kernel(const int32_t *__restrict__ row_ptr, int nL, const double *__restrict__ scores, double thr,
-                           int higher, int32_t *__restrict__ new_count, int32_t *__restrict__ order)
+// the keep count of a sorted row: candidates whose ratio against the BEST (not the previous one, :829) reaches thr
+template <class ScoreAt>
+__device__ inline int bnb_keep_count(int n, double thr, int higher, ScoreAt score_at)
+{
+    int keep = 1;
+    const double best = score_at(0);
+    for (int j = 0; j < n - 1; ++j)
+    {
+        const double next = score_at(j + 1);
+        if (best == 0)
+            break;
+        const double ratio = higher ? next / best : best / next;
+        if (ratio >= thr)
+            ++keep;
+        else
+            break;
+    }
+    return keep;
+}
+
+constexpr int BNB_LONG_CAP = 256; // longest row the cooperative path stages in LDS
+constexpr int BNB_QUEUE = 512;    // long rows one block can queue (the rest take the serial path in global memory)
+
+__global__ __launch_bounds__(256) void bnb_kernel(const int32_t *__restrict__ row_ptr, int nL, const double *__restrict__ scores,
+                                                  double thr, int higher, int32_t *__restrict__ new_count,
+                                                  int32_t *__restrict__ order)
 {
     // bit 1 of `higher`: the temporal variant (Temporal_Matches::apply_best_nearly_best_filtering_quads,
     // src/Temporal_Matches.cpp:517-570) rebuilds every row of two or more candidates in SORTED order, whether or not
     // something was dropped; the stereo test leaves an unpruned row untouched (src/Stereo_Matches.cpp:840)
     const bool always_sorted = (higher & 2) != 0;
     higher &= 1;
+    // Phase 1, one thread per row: rows of up to 16 candidates (all but a handful) are sorted in LDS -- the scores are
+    // fetched once, all loads in flight together; sorting in place in global memory made every step of the insertion
+    // sort two dependent round trips (order[j - 1], then its score).  std::sort(indices, comp) (:809-813) runs ONE
+    // insertion sort up to 16 entries, which leaves equal scores in their original order.
+    __shared__ double s_sc[16][256];
+    __shared__ int32_t s_ix[16][256];
+    __shared__ int32_t s_queue[BNB_QUEUE];
+    __shared__ int s_nq;
+    const int t = threadIdx.x;
+    if (t == 0)
+        s_nq = 0;
+    __syncthreads();
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nL; i += gridDim.x * blockDim.x)
     {
         const int b = row_ptr[i], n = row_ptr[i + 1] - b;
         int32_t *ord = order + b;
+        if (n >= 2 && n <= 16)
+        {
+            for (int k = 0; k < n; ++k)
+            {
+                s_sc[k][t] = scores[b + k];
+                s_ix[k][t] = k;
+            }
+            for (int k = 1; k < n; ++k)
+            {
+                const double sv = s_sc[k][t];
+                const int32_t v = s_ix[k][t];
+                int j = k;
+                while (j > 0 && (higher ? sv > s_sc[j - 1][t] : sv < s_sc[j - 1][t]))
+                {
+                    s_sc[j][t] = s_sc[j - 1][t];
+                    s_ix[j][t] = s_ix[j - 1][t];
+                    --j;
+                }
+                s_sc[j][t] = sv;
+                s_ix[j][t] = v;
+            }
+            const int keep = bnb_keep_count(n, thr, higher, [&](int j) { return s_sc[j][t]; });
+            const bool sorted_out = keep < n || always_sorted; // nothing dropped: the reference leaves the row untouched (:840)
+            new_count[i] = keep < n ? keep : n;
+            for (int k = 0; k < n; ++k)
+                ord[k] = b + (sorted_out ? s_ix[k][t] : k);
+            continue;
+        }
+        if (n < 2)
+        {
+            if (n == 1)
+                ord[0] = b;
+            new_count[i] = n;
+            continue;
+        }
+        // a long row: queued for phase 2; when the queue is full (or the row longer than its staging area), here and now
+        const int q = n <= BNB_LONG_CAP ? atomicAdd(&s_nq, 1) : BNB_QUEUE;
+        if (q < BNB_QUEUE)
+        {
+            s_queue[q] = i;
+            continue;
+        }
         for (int k = 0; k < n; ++k)
             ord[k] = b + k;
-        new_count[i] = n;
-        if (n < 2)
-            continue;
-        // std::sort(indices, comp) (:809-813).  Up to 16 entries libstdc++ runs one insertion sort, which leaves equal
-        // scores in their original order; longer rows go through its introsort, where ties land wherever the partitioning
-        // puts them -- reproduced move for move by sort_long_row
-        if (n > 16)
-            sort_long_row(ord, n, scores, higher);
-        for (int k = 1; k < n && n <= 16; ++k)
-        {
-            const int32_t v = ord[k];
-            const double sv = scores[v];
-            int j = k;
-            while (j > 0 && (higher ? sv > scores[ord[j - 1]] : sv < scores[ord[j - 1]]))
-            {
-                ord[j] = ord[j - 1];
-                --j;
-            }
-            ord[j] = v;
-        }
-        int keep = 1;
-        const double best = scores[ord[0]];
-        for (int j = 0; j < n - 1; ++j)
-        {
-            const double next = scores[ord[j + 1]];
-            if (best == 0)
-                break;
-            const double ratio = higher ? next / best : best / next; // against the BEST, not the previous one (:829)
-            if (ratio >= thr)
-                ++keep;
-            else
-                break;
-        }
-        if (keep < n)
-            new_count[i] = keep;
-        else if (!always_sorted)
-            for (int k = 0; k < n; ++k) // nothing dropped: the reference leaves the row untouched (:840)
+        sort_long_row(ord, n, scores, higher);
+        const int keep = bnb_keep_count(n, thr, higher, [&](int j) { return scores[ord[j]]; });
+        new_count[i] = keep < n ? keep : n;
+        if (keep == n && !always_sorted)
+            for (int k = 0; k < n; ++k)
                 ord[k] = b + k;
+    }
+    __syncthreads();
+    // Phase 2, one WAVE per long row (one thread sorting 30-60 entries in global memory set the kernel's duration: 187 us
+    // whatever phase 1 did).  Longer rows go through libstdc++'s introsort, where ties land wherever the partitioning
+    // puts them (reproduced move for move by sort_long_row) -- but without equal (or NaN) scores in the row every correct
+    // sort returns the same permutation, so the wave ranks the entries in parallel and only a row WITH ties is sorted by
+    // lane 0 alone, in LDS.
+    __shared__ double s_ls[4][BNB_LONG_CAP];
+    __shared__ int32_t s_lo[4][BNB_LONG_CAP];
+    const int lane = t & 63, wv = t >> 6;
+    const int nq = s_nq < BNB_QUEUE ? s_nq : BNB_QUEUE;
+    for (int q = wv; q < nq; q += 4)
+    {
+        const int i = s_queue[q];
+        const int b = row_ptr[i], n = row_ptr[i + 1] - b;
+        double *ls = s_ls[wv];
+        int32_t *lo = s_lo[wv];
+        for (int k = lane; k < n; k += 64)
+            ls[k] = scores[b + k];
+        __builtin_amdgcn_wave_barrier();
+        bool tie = false;
+        for (int k = lane; k < n; k += 64)
+        {
+            const double sk = ls[k];
+            int rank = 0;
+            tie = tie || sk != sk;
+            for (int m = 0; m < n; ++m)
+            {
+                const double sm = ls[m];
+                rank += higher ? sm > sk : sm < sk;
+                tie = tie || (m != k && sm == sk);
+            }
+            if (!tie)
+                lo[rank] = k;
+        }
+        const bool any_tie = __any(tie);
+        __builtin_amdgcn_wave_barrier();
+        if (any_tie)
+        {
+            for (int k = lane; k < n; k += 64)
+                lo[k] = k;
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0)
+                sort_long_row(lo, n, ls, higher);
+            __builtin_amdgcn_wave_barrier();
+        }
+        int keep = 0;
+        if (lane == 0)
+            keep = bnb_keep_count(n, thr, higher, [&](int j) { return ls[lo[j]]; });
+        keep = __shfl(keep, 0);
+        const bool sorted_out = keep < n || always_sorted;
+        if (lane == 0)
+            new_count[i] = keep < n ? keep : n;
+        for (int k = lane; k < n; k += 64)
+            order[b + k] = b + (sorted_out ? lo[k] : k);
+        __builtin_amdgcn_wave_barrier(); // the staging area is reused by this wave's next row
     }
 }
 
@@ -174,7 +276,13 @@ __global__ void shift_kernel(const ebvo_edge *__restrict__ cand, const double *_
 // consolidate_redundant_edge_hypothesis :1006-1034).  Merging decisions use sqrt / compare only and equal the
 // restatement exactly; the Gaussian weights use csrc/ebvo_math.h's exp, the routine the oracle's portable mode calls, so the
 // centres are bit-identical to it (glibc's exp differs by 1 ulp on a fraction of inputs: <= 1e-12 px on a centre).
-__device__ inline void gaussian_average(const ebvo_edge *__restrict__ E, const int32_t *lab, int n, int label, double &gx,
+struct RowPoint
+{
+    double x, y, theta;
+};
+
+template <class EdgeT> // ebvo_edge (global memory) or RowPoint (the row staged in LDS)
+__device__ inline void gaussian_average(const EdgeT *__restrict__ E, const int32_t *lab, int n, int label, double &gx,
                                         double &gy, double &gt)
 {
     double sx = 0, sy = 0;
@@ -300,6 +408,9 @@ __global__ __launch_bounds__(256) void cluster_kernel(const ebvo_edge *__restric
     // labels of the parallel path live in LDS (64 per group): lanes of a group read what other lanes wrote in the step
     // before, which LDS orders within a wave
     __shared__ int32_t s_lab[16][64];
+    // ... and so does the row itself (x, y, theta of up to 64 candidates per group): the merging loops read every point
+    // of the row again and again, from global memory that was a chain of L1 / L2 round trips
+    __shared__ RowPoint s_pt[16][64];
     const double orient_thr = 20.0 * 0x1.921fb54442d18p+1 / 180.0; // deg_to_rad(CLUSTER_ORIENT_THRESH): 20 * M_PI / 180
     const int e = threadIdx.x & 15;                                 // lane in the 16-lane group
     const int groups = (gridDim.x * blockDim.x) >> 4;
@@ -310,7 +421,8 @@ __global__ __launch_bounds__(256) void cluster_kernel(const ebvo_edge *__restric
         const int r = it * groups + ((blockIdx.x * blockDim.x + threadIdx.x) >> 4);
         const bool row_ok = r < nL;
         const int b = row_ok ? row_ptr[r] : 0, n = row_ok ? row_ptr[r + 1] - b : 0;
-        const ebvo_edge *E = cand + b;
+        const ebvo_edge *Eg = cand + b;
+        const RowPoint *E = s_pt[threadIdx.x >> 4];
         int32_t *glab = cluster_of + b;
         int32_t *lab = s_lab[threadIdx.x >> 4];
         if (row_ok && e == 0)
@@ -318,7 +430,7 @@ __global__ __launch_bounds__(256) void cluster_kernel(const ebvo_edge *__restric
         const bool simple = n == 0 || (n == 1 && skip_single);
         if (row_ok && simple && n == 1 && e == 0)
         {
-            centres[b] = E[0];
+            centres[b] = Eg[0];
             glab[0] = 0;
         }
         const bool serial = !simple && n > 64;
@@ -326,12 +438,20 @@ __global__ __launch_bounds__(256) void cluster_kernel(const ebvo_edge *__restric
         {
             for (int i = 0; i < n; ++i)
                 glab[i] = i;
-            cluster_row_serial(E, glab, n, by_orientation, orient_thr, centres + b, &new_count[r]);
+            cluster_row_serial(Eg, glab, n, by_orientation, orient_thr, centres + b, &new_count[r]);
         }
         const bool par = !simple && !serial; // uniform within the group
         if (par)
             for (int i = e; i < n; i += 16)
+            {
                 lab[i] = i;
+                const ebvo_edge g = Eg[i];
+                RowPoint q;
+                q.x = g.x;
+                q.y = g.y;
+                q.theta = g.theta;
+                s_pt[threadIdx.x >> 4][i] = q;
+            }
         __builtin_amdgcn_wave_barrier();
         // ---- merging: wave-uniform loop, each group on its own row
         bool merged = par;

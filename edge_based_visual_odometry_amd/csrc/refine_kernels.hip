@@ -455,7 +455,7 @@ __global__ __launch_bounds__(256) void gn_init_kernel(GnArgs A)
 #ifndef GN_TAP_ROWS
 #define GN_TAP_ROWS 2 // patch rows whose records are in flight together (2.79 -> 2.72 ms against 1)
 #endif
-constexpr int GN_ROWS_BELOW = 65536;
+constexpr int GN_ROWS_BELOW = 49152; // tools/gpu_gn_sweep.sh: KITTI 2.33 ms (2.41 at 65536, 2.35 at 0), EuRoC sequence 320 frames/s (314, 293)
 __device__ inline bool gn_other_layout(int mode, int n_active, int rows_below)
 {
     return (mode == 1 && n_active <= rows_below) || (mode == 2 && n_active > rows_below);

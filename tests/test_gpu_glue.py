@@ -33,6 +33,28 @@ def test_bnb_equals_oracle(ctx, higher, thr):
     assert_bit_equal(order, oo, "order")
 
 
+@pytest.mark.parametrize("higher", [True, False])
+def test_bnb_long_rows(ctx, higher):
+    """Rows of 17 .. 400 candidates: the wave-cooperative path (parallel ranking without ties, introsort in LDS with
+    ties) and, beyond its 256-entry staging area, the serial path -- all three against std::sort's permutation."""
+    rng = np.random.default_rng(11)
+    lens = np.concatenate([rng.integers(17, 64, 300), rng.integers(200, 400, 40), rng.integers(0, 5, 200)])
+    rng.shuffle(lens)
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    n = int(rp[-1])
+    sc = rng.uniform(0.2, 1.0, n) if higher else rng.uniform(50, 400, n)
+    for i in range(0, len(lens), 3):                              # ties in every third row, several per row
+        b, e = rp[i], rp[i + 1]
+        if e - b >= 4:
+            sc[b + 1] = sc[b + 3]
+            sc[e - 1] = sc[b]
+    sc[rp[7]:rp[8]][::5] = np.nan
+    cnt, order = ctx.bnb_test(rp, sc, 0.8 if higher else 0.5, higher)
+    oc, oo = orc.bnb_test(rp, sc, 0.8 if higher else 0.5, higher)
+    assert_bit_equal(cnt, oc, "new_count")
+    assert_bit_equal(order, oo, "order")
+
+
 def test_keep_best_equals_oracle_and_edge_cases(ctx):
     rng = np.random.default_rng(8)
     rp, n = _rows(rng, 3000, 12)
