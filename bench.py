@@ -608,7 +608,8 @@ def main():
                          "note": "achieved = the whole pair's algorithmic bytes (SURVEY.md 8(d)) / the dominant kernel's "
                                  "launch duration: the contract's formula, not a bandwidth this kernel moves.  The path is "
                                  "FP64-VALU-bound, not HBM-bound; see roofline_fp64.  Durations: HIP events, pairs one at a "
-                                 "time, after the timed region."},
+                                 "time, after the timed region; the dominant kernel's pair of events is stamped by its own "
+                                 "dispatch (hipExtLaunchKernelGGL), which is what rocprofv3's kernel trace reports."},
             "kernels": kernels,
             "kernel_groups": KERNEL_GROUPS[args.toed_mode],
         }

@@ -67,6 +67,30 @@ void ebvo_prof_begin(ebvo_ctx *ctx, Slot &s, int kid)
     s.prof_pending.push_back(pe);
 }
 
+// Events for ONE kernel launch timed by its own dispatch (hipExtLaunchKernelGGL stamps them with the kernel's begin and
+// end, the timestamps a kernel trace reports) instead of a pair recorded around the launch.  False when profiling is off.
+bool ebvo_prof_kernel(ebvo_ctx *ctx, Slot &s, int kid, hipEvent_t *a, hipEvent_t *b)
+{
+    if (!ctx->prof || !s.prof_now)
+        return false;
+    ProfEvent pe;
+    if (!ctx->prof_free.empty())
+    {
+        pe = ctx->prof_free.back();
+        ctx->prof_free.pop_back();
+    }
+    else
+    {
+        if (hipEventCreate(&pe.a) != hipSuccess || hipEventCreate(&pe.b) != hipSuccess)
+            return false;
+    }
+    pe.kid = kid;
+    s.prof_pending.push_back(pe);
+    *a = pe.a;
+    *b = pe.b;
+    return true;
+}
+
 void ebvo_prof_end(ebvo_ctx *ctx, Slot &s)
 {
     if (!ctx->prof || !s.prof_now || s.prof_pending.empty())
@@ -2151,7 +2175,7 @@ static int temporal_chain(ebvo_ctx *ctx, Slot &s, const ebvo_temporal_params &P,
     double *initL = (double *)(base + o_init), *initR = initL + 2 * n3z, *dispL = (double *)(base + o_disp), *dispR = dispL + 2 * n3z;
     double *scoreL = (double *)(base + o_score), *scoreR = scoreL + n3z;
     uint8_t *validL = (uint8_t *)(base + o_valid), *validR = validL + n3z, *valid = validR + n3z;
-    int32_t *itersL = (int32_t *)(base + o_iters), *itersR = itersL + n3z;
+    int32_t *itersL = (int32_t *)(base + o_iters); // the second camera's counts follow at + n3z (one batch, refine_gn_temporal_enqueue)
     ebvo_edge *cenL = (ebvo_edge *)(base + o_cen), *cenR = cenL + n3z;
     if ((rc = ebvo_grow(ctx, s, s.grad_x, 2 * sizeof(float) * (size_t)h * w + 64)) ||
         (rc = ebvo_grow(ctx, s, s.grad_y, 2 * sizeof(float) * (size_t)h * w + 64)) ||

@@ -213,6 +213,8 @@ int ebvo_grow(ebvo_ctx *ctx, Slot &s, GrowBuf &b, size_t bytes);
 void ebvo_prof_begin(ebvo_ctx *ctx, Slot &s, int kid);
 void ebvo_prof_end(ebvo_ctx *ctx, Slot &s);
 
+bool ebvo_prof_kernel(ebvo_ctx *ctx, Slot &s, int kid, hipEvent_t *a, hipEvent_t *b);
+
 struct ProfScope
 {
     ebvo_ctx *c;

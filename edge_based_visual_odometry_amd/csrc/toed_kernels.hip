@@ -32,6 +32,8 @@
 //   toed_exact_decide_kernel   S3d: exact NMS + sub-pixel fit;  toed_cand_scatter_kernel S4: edge records
 #include <cstring>
 
+#include <hip/hip_ext.h>
+
 #include "ebvo_internal.h"
 #include "ebvo_math.h"
 
@@ -1654,9 +1656,13 @@ int toed_enqueue(ebvo_ctx *ctx, Slot &s, int n_img, int h, int w, hipEvent_t ev_
             }
             const ToedTables *T = (const ToedTables *)g_tables_dev[ctx->device];
             {
-                ProfScope ps(ctx, s, K_EXACT_CENTRE);
-                hipLaunchKernelGGL(toed_exact_centre_kernel, dim3(resident_blocks(ctx, 0)), dim3(256), 0, s.stream, E, T,
-                                   h, w, cap, n_img);
+                hipEvent_t k_begin, k_end; // the dominant kernel: timed by its own dispatch when the profiler is on
+                if (ebvo_prof_kernel(ctx, s, K_EXACT_CENTRE, &k_begin, &k_end))
+                    hipExtLaunchKernelGGL(toed_exact_centre_kernel, dim3(resident_blocks(ctx, 0)), dim3(256), 0, s.stream,
+                                          k_begin, k_end, 0, E, T, h, w, cap, n_img);
+                else
+                    hipLaunchKernelGGL(toed_exact_centre_kernel, dim3(resident_blocks(ctx, 0)), dim3(256), 0, s.stream, E,
+                                       T, h, w, cap, n_img);
             }
             {
                 ProfScope ps(ctx, s, K_COMPACT); // the lists of the distinct neighbour points
