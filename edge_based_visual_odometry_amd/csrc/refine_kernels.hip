@@ -461,9 +461,96 @@ __device__ inline bool gn_other_layout(int mode, int n_active, int rows_below)
     return (mode == 1 && n_active <= rows_below) || (mode == 2 && n_active > rows_below);
 }
 
-__global__ __launch_bounds__(256, 2) void gn_iter_kernel(GnArgs A, int it, int mode)
+// One Gauss-Newton iteration `it` of pair k in the one-thread-per-pair layout; `alpha` is the iteration state (in and out).
+// Returns true when the pair is finished (its outputs are written then).  s_tv: the block's tap staging, [49][256].
+__device__ inline bool gn_thread_iteration(const GnArgs &A, int64_t k, int it, double &alpha, float (*s_tv)[256])
 {
     const int h = A.h, w = A.w;
+    ebvo_edge le;
+    double ex, ey;
+    gn_geometry(A, k, le, ex, ey);
+    const int li = A.pair_left[k];
+    const double st = A.sc[li], ct = A.sc[A.nL + li];
+    const double nx = -st, ny = ct, side = (7 / 2.0) + 1.0;
+    double rx, ry;
+    gn_candidate(A, k, rx, ry);
+    const double meanL[2] = {A.mean_l[li], A.mean_l[A.nL + li]};
+    const double shx = ex * alpha, shy = ey * alpha;
+    // One pass over the right image per side: every sample point is tapped ONCE (intensity and both gradients from
+    // one 16-byte record) and its three floats stay in registers while the mean of the side forms; the residual
+    // terms follow from the registers.  (The reference samples the patch twice, :1204-1247; the values are the same.)
+    double H = 0.0, b = 0.0, cost = 0.0;
+#pragma unroll 1
+    for (int sd = 0; sd < 2; ++sd)
+    {
+        const float *__restrict__ lrec = A.left_rec + (size_t)li * 98 + sd * 49;
+        const double cx = (sd ? rx - nx * side : rx + nx * side) + shx; // :1204-1205
+        const double cy = (sd ? ry - ny * side : ry + ny * side) + shy;
+        float tgx[49], tgy[49];
+        double sum = 0;
+#pragma unroll
+        for (int i = -3; i <= 3; ++i)
+        {
+#pragma unroll // the seven 16-byte loads of a patch row are independent: all in flight together
+            for (int j = -3; j <= 3; ++j)
+            {
+                const GnTap t = gn_tap(A.recR, w, h, cx + ct * i - st * j, cy + st * i + ct * j);
+                const int o = (i + 3) * 7 + (j + 3);
+                s_tv[o][threadIdx.x] = t.v;
+                tgx[o] = t.gx;
+                tgy[o] = t.gy;
+                sum += (double)t.v;
+            }
+            if ((i + 3) % GN_TAP_ROWS == GN_TAP_ROWS - 1) // GN_TAP_ROWS rows of records in flight, not all forty-nine
+                __builtin_amdgcn_sched_barrier(0);
+        }
+        const double meanR = sum / 49;
+#pragma unroll
+        for (int o = 0; o < 49; ++o)
+        {
+            if (o % 7 == 0)
+                __builtin_amdgcn_sched_barrier(0);
+            const double Lf = (double)lrec[o]; // sampled once by gn_left_kernel
+            const double Rf = (double)s_tv[o][threadIdx.x], gxv = (double)tgx[o], gyv = (double)tgy[o];
+            const double r = (Lf - meanL[sd]) - (Rf - meanR);
+            const double g = -gxv * ex + gyv * ey; // :1237
+            const double absr = fabs(r);
+            const double wgt = (absr <= A.huber) ? 1.0 : A.huber / absr;
+            H += wgt * g * g;
+            b += wgt * g * r;
+            cost += wgt * r * r;
+        }
+    }
+    int done_iters = it; // stop on H < 1e-8: outputs stay unset (:1255)
+    bool finished = true;
+    if (!(H < 1e-8))
+    {
+        const double delta = -b / H;
+        alpha += delta;
+        const double rms = sqrt(cost / 98);
+        const bool is_outlier = (rms > A.huber * 2.0) || (it + 1 < 2); // residual_log.size() == it + 1
+        if (fabs(delta) < A.tol || it == A.max_iter - 1)
+        {
+            A.valid[k] = is_outlier ? 0 : 1;
+            A.score[k] = rms;
+            A.conf[k] = ebvo_exp(-rms / A.huber);
+            done_iters = it + 1;
+        }
+        else
+            finished = false;
+    }
+    A.alpha[k] = alpha;
+    if (finished)
+    {
+        A.iters[k] = done_iters;
+        A.refined_xy[2 * k] = rx + ex * alpha; // :1349-1351
+        A.refined_xy[2 * k + 1] = ry + ey * alpha;
+    }
+    return finished;
+}
+
+__global__ __launch_bounds__(256, 2) void gn_iter_kernel(GnArgs A, int it, int mode)
+{
     const int n_in = A.counts[it];
     if (gn_other_layout(mode, n_in, A.rows_below))
         return;
@@ -479,88 +566,8 @@ __global__ __launch_bounds__(256, 2) void gn_iter_kernel(GnArgs A, int it, int m
         if (idx < n_in)
         {
             k = lin[idx];
-            ebvo_edge le;
-            double ex, ey;
-            gn_geometry(A, k, le, ex, ey);
-            const int li = A.pair_left[k];
-            const double st = A.sc[li], ct = A.sc[A.nL + li];
-            const double nx = -st, ny = ct, side = (7 / 2.0) + 1.0;
-            double rx, ry;
-            gn_candidate(A, k, rx, ry);
-            const double meanL[2] = {A.mean_l[li], A.mean_l[A.nL + li]};
             double alpha = A.alpha[k];
-            const double shx = ex * alpha, shy = ey * alpha;
-            // One pass over the right image per side: every sample point is tapped ONCE (intensity and both gradients from
-            // one 16-byte record) and its three floats stay in registers while the mean of the side forms; the residual
-            // terms follow from the registers.  (The reference samples the patch twice, :1204-1247; the values are the same.)
-            double H = 0.0, b = 0.0, cost = 0.0;
-#pragma unroll 1
-            for (int sd = 0; sd < 2; ++sd)
-            {
-                const float *__restrict__ lrec = A.left_rec + (size_t)li * 98 + sd * 49;
-                const double cx = (sd ? rx - nx * side : rx + nx * side) + shx; // :1204-1205
-                const double cy = (sd ? ry - ny * side : ry + ny * side) + shy;
-                float tgx[49], tgy[49];
-                double sum = 0;
-#pragma unroll
-                for (int i = -3; i <= 3; ++i)
-                {
-#pragma unroll // the seven 16-byte loads of a patch row are independent: all in flight together
-                    for (int j = -3; j <= 3; ++j)
-                    {
-                        const GnTap t = gn_tap(A.recR, w, h, cx + ct * i - st * j, cy + st * i + ct * j);
-                        const int o = (i + 3) * 7 + (j + 3);
-                        s_tv[o][threadIdx.x] = t.v;
-                        tgx[o] = t.gx;
-                        tgy[o] = t.gy;
-                        sum += (double)t.v;
-                    }
-                    if ((i + 3) % GN_TAP_ROWS == GN_TAP_ROWS - 1) // GN_TAP_ROWS rows of records in flight, not all forty-nine
-                        __builtin_amdgcn_sched_barrier(0);
-                }
-                const double meanR = sum / 49;
-#pragma unroll
-                for (int o = 0; o < 49; ++o)
-                {
-                    if (o % 7 == 0)
-                        __builtin_amdgcn_sched_barrier(0);
-                    const double Lf = (double)lrec[o]; // sampled once by gn_left_kernel
-                    const double Rf = (double)s_tv[o][threadIdx.x], gxv = (double)tgx[o], gyv = (double)tgy[o];
-                    const double r = (Lf - meanL[sd]) - (Rf - meanR);
-                    const double g = -gxv * ex + gyv * ey; // :1237
-                    const double absr = fabs(r);
-                    const double wgt = (absr <= A.huber) ? 1.0 : A.huber / absr;
-                    H += wgt * g * g;
-                    b += wgt * g * r;
-                    cost += wgt * r * r;
-                }
-            }
-            int done_iters = it; // stop on H < 1e-8: outputs stay unset (:1255)
-            bool finished = true;
-            if (!(H < 1e-8))
-            {
-                const double delta = -b / H;
-                alpha += delta;
-                const double rms = sqrt(cost / 98);
-                const bool is_outlier = (rms > A.huber * 2.0) || (it + 1 < 2); // residual_log.size() == it + 1
-                if (fabs(delta) < A.tol || it == A.max_iter - 1)
-                {
-                    A.valid[k] = is_outlier ? 0 : 1;
-                    A.score[k] = rms;
-                    A.conf[k] = ebvo_exp(-rms / A.huber);
-                    done_iters = it + 1;
-                }
-                else
-                    finished = false;
-            }
-            A.alpha[k] = alpha;
-            if (finished)
-            {
-                A.iters[k] = done_iters;
-                A.refined_xy[2 * k] = rx + ex * alpha; // :1349-1351
-                A.refined_xy[2 * k + 1] = ry + ey * alpha;
-            }
-            survives = !finished;
+            survives = !gn_thread_iteration(A, k, it, alpha, s_tv);
         }
         // append the survivors: one atomic per block
         const int slot = block_append_slot(survives, &A.counts[it + 1], turn++);
@@ -577,7 +584,10 @@ __global__ __launch_bounds__(256, 2) void gn_iter_kernel(GnArgs A, int it, int m
 // waves, an eighth of the chain.  The reference's sums are sequential over the 49 (98) samples and stay so: the running
 // sum visits the lanes in row order (lane r adds its seven terms to what lane r - 1 produced).  Bit-identical to
 // gn_iter_kernel (the refinement tests run both).
-__global__ __launch_bounds__(256, 3) void gn_iter_rows_kernel(GnArgs A, int it, int mode)
+#ifndef GN_ROWS_WAVES
+#define GN_ROWS_WAVES 3 // waves per SIMD the row layout is compiled for (166 VGPRs; 4 -> 128 with spills, measured slower)
+#endif
+__global__ __launch_bounds__(256, GN_ROWS_WAVES) void gn_iter_rows_kernel(GnArgs A, int it, int mode)
 {
     const int h = A.h, w = A.w;
     const int n_in = A.counts[it];
