@@ -47,10 +47,10 @@ int ebvo_grow(ebvo_ctx *ctx, Slot &s, GrowBuf &b, size_t bytes)
     return EBVO_OK;
 }
 
-void ebvo_prof_begin(ebvo_ctx *ctx, Slot &s, int kid)
+bool ebvo_prof_begin(ebvo_ctx *ctx, Slot &s, int kid)
 {
-    if (!ctx->prof || !s.prof_now)
-        return;
+    if (!ctx->prof || !s.prof_now || (ctx->prof_only >= 0 && kid != ctx->prof_only))
+        return false;
     ProfEvent pe;
     if (!ctx->prof_free.empty())
     {
@@ -60,18 +60,19 @@ void ebvo_prof_begin(ebvo_ctx *ctx, Slot &s, int kid)
     else
     {
         if (hipEventCreate(&pe.a) != hipSuccess || hipEventCreate(&pe.b) != hipSuccess)
-            return;
+            return false;
     }
     pe.kid = kid;
     (void)hipEventRecord(pe.a, s.stream);
     s.prof_pending.push_back(pe);
+    return true;
 }
 
 // Events for ONE kernel launch timed by its own dispatch (hipExtLaunchKernelGGL stamps them with the kernel's begin and
 // end, the timestamps a kernel trace reports) instead of a pair recorded around the launch.  False when profiling is off.
 bool ebvo_prof_kernel(ebvo_ctx *ctx, Slot &s, int kid, hipEvent_t *a, hipEvent_t *b)
 {
-    if (!ctx->prof || !s.prof_now)
+    if (!ctx->prof || !s.prof_now || (ctx->prof_only >= 0 && kid != ctx->prof_only))
         return false;
     ProfEvent pe;
     if (!ctx->prof_free.empty())
@@ -2550,6 +2551,8 @@ extern "C" int ebvo_debug_set(ebvo_ctx *ctx, int key, int value)
         ctx->force_overflow = value;
     else if (key == 2)
         ctx->lanes = value; // 0 = one stream per slot whatever their number
+    else if (key == 3)
+        ctx->prof_only = value - 1; // 0 = every stage; id + 1 = that stage alone: no event markers between the other kernels
     else
         return EBVO_ERR_ARG;
     return EBVO_OK;

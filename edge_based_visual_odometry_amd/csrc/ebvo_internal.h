@@ -181,6 +181,7 @@ struct ebvo_ctx
     bool undist_on = false;    // ebvo_stereo_set_undistort
     ebvo_undistort_params undist{};
     int lanes = 4;             // streams the kernels of submitted pairs are dealt to from four slots on (ebvo_stereo_submit)
+    int prof_only = -1; // >= 0: the profiler instruments this stage id alone (ebvo_debug_set key 3 = id + 1)
     uint64_t submit_seq = 0;
     std::vector<hipStream_t> lane_streams; // created on first use, owned by the context
     hipStream_t copy_stream = nullptr;     // result copies of ebvo_stereo_fetch_begin (all slots), created on first use
@@ -210,7 +211,7 @@ int ebvo_fail_hip(ebvo_ctx *ctx, hipError_t e, const char *what, const char *fil
 int ebvo_grow(ebvo_ctx *ctx, Slot &s, GrowBuf &b, size_t bytes);
 
 // profiling brackets around kernel launches on a slot's stream
-void ebvo_prof_begin(ebvo_ctx *ctx, Slot &s, int kid);
+bool ebvo_prof_begin(ebvo_ctx *ctx, Slot &s, int kid); // false: nothing was recorded (profiler off, or another stage selected)
 void ebvo_prof_end(ebvo_ctx *ctx, Slot &s);
 
 bool ebvo_prof_kernel(ebvo_ctx *ctx, Slot &s, int kid, hipEvent_t *a, hipEvent_t *b);
@@ -219,8 +220,13 @@ struct ProfScope
 {
     ebvo_ctx *c;
     Slot &s;
-    ProfScope(ebvo_ctx *ctx, Slot &slot, int kid) : c(ctx), s(slot) { ebvo_prof_begin(c, s, kid); }
-    ~ProfScope() { ebvo_prof_end(c, s); }
+    bool on;
+    ProfScope(ebvo_ctx *ctx, Slot &slot, int kid) : c(ctx), s(slot), on(ebvo_prof_begin(ctx, slot, kid)) {}
+    ~ProfScope()
+    {
+        if (on)
+            ebvo_prof_end(c, s);
+    }
 };
 
 // ---- device-level stages (device pointers; asynchronous on the slot's stream; NO host synchronisation) ----

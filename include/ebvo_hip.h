@@ -542,7 +542,9 @@ int ebvo_profile_get(ebvo_ctx *ctx, ebvo_kernel_time *out /* EBVO_MAX_KERNELS */
  * key 1: treat the next `value` pair results as "candidate buffers overflowed" (exercises the regrow / give-up path);
  * key 2: lanes -- from four slots on, ebvo_stereo_submit deals the kernels of the pairs round-robin to
  *        min(lanes, slots - 1) streams of the context instead of one stream per slot (default 4, the measured optimum
- *        on MI355X; 0 = one stream per slot whatever their number). */
+ *        on MI355X; 0 = one stream per slot whatever their number).
+ * key 3: the profiler instruments ONE stage (value = its index in ebvo_profile_get's order + 1; 0 = every stage): no
+ *        event markers between the other kernels, so the stage is timed as it runs in the unprofiled pipeline. */
 int ebvo_debug_set(ebvo_ctx *ctx, int key, int value);
 
 /* Raw FP64 vector-ALU microbenchmark (mul + add, no FMA) used to anchor the compute roofline:
