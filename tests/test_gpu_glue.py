@@ -38,7 +38,8 @@ def test_bnb_long_rows(ctx, higher):
     """Rows of 17 .. 400 candidates: the wave-cooperative path (parallel ranking without ties, introsort in LDS with
     ties) and, beyond its 256-entry staging area, the serial path -- all three against std::sort's permutation."""
     rng = np.random.default_rng(11)
-    lens = np.concatenate([rng.integers(17, 64, 300), rng.integers(200, 400, 40), rng.integers(0, 5, 200)])
+    lens = np.concatenate([rng.integers(17, 64, 300), rng.integers(200, 400, 40), rng.integers(0, 5, 200),
+                           [16, 17, 255, 256, 257, 16, 17, 256, 257]])   # both sides of the insertion-sort and staging limits
     rng.shuffle(lens)
     rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
     n = int(rp[-1])
@@ -49,6 +50,8 @@ def test_bnb_long_rows(ctx, higher):
             sc[b + 1] = sc[b + 3]
             sc[e - 1] = sc[b]
     sc[rp[7]:rp[8]][::5] = np.nan
+    j = int(np.argmax(lens == 257))
+    sc[rp[j]:rp[j + 1]] = sc[rp[j]]                                # a long row of equal scores
     cnt, order = ctx.bnb_test(rp, sc, 0.8 if higher else 0.5, higher)
     oc, oo = orc.bnb_test(rp, sc, 0.8 if higher else 0.5, higher)
     assert_bit_equal(cnt, oc, "new_count")
