@@ -278,6 +278,101 @@ def frame_loop(ctx, params, pool, nslots, steps, upload, fetch):
     return time.perf_counter() - t0, nbytes / max(1, steps)
 
 
+def host_threads(args):
+    """--host-threads "2,4": the thread counts of the optional multi-context legs (none by default)"""
+    return [int(x) for x in args.host_threads.split(",") if x.strip()]
+
+
+def threaded_dropin(T, args, H, W, F, device, pool, calib, steps):
+    """frames/s of dropin_loop run by T host threads, each on its own context (three slots each)."""
+    import threading
+    ctxs = []
+    for t in range(T):
+        c = Context(H, W, device=device, toed_mode=args.toed_mode)
+        c.set_slots(3)
+        p = c.default_params(F)
+        dropin_loop(c, p, pool, calib, 3, 3)     # untimed: sizes the buffers, one context after the other
+        ctxs.append((c, p))
+    start = threading.Barrier(T + 1)
+    per = [steps // T + (1 if t < steps % T else 0) for t in range(T)]
+
+    def work(t):
+        c, p = ctxs[t]
+        start.wait()
+        dropin_loop(c, p, pool, calib, 3, per[t])
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(T)]
+    old_switch = sys.getswitchinterval()
+    sys.setswitchinterval(1e-4)                  # a thread back from a C call should not wait 5 ms for the interpreter lock
+    for x in th:
+        x.start()
+    start.wait()
+    t0 = time.perf_counter()
+    for x in th:
+        x.join()
+    dt = time.perf_counter() - t0
+    sys.setswitchinterval(old_switch)
+    for c, _ in ctxs:
+        c.close()
+    return steps / dt
+
+
+def threaded_sequence(T, args, H, W, F, device, frames, calib, cal, steps):
+    """frames/s of the EuRoC frame loop with T contexts, each driven by its own host thread: context t holds the keyframe
+    (frame 0) and the frames k = t (mod T); ctypes calls release the interpreter lock, so the chains run concurrently."""
+    import threading
+    ctxs, slots_of = [], []
+    for t in range(T):
+        mine = [k for k in range(len(frames)) if k % T == t]
+        c = Context(H, W, device=device, toed_mode=args.toed_mode)
+        c.set_slots(len(mine) + 1)
+        if "dist" in cal:
+            c.set_undistort(cal["K"], cal["dist"], cal["K_right"], cal["dist_right"])
+        p = c.default_params(F)
+        c.stereo_upload(*frames[0], slot=0)
+        c.stereo_submit(p, slot=0)
+        c.stereo_wait(slot=0)
+        c.stereo_finalize(calib, slot=0, use_sift=True)
+        c.temporal_set_keyframe(slot=0)
+        for j, k in enumerate(mine):
+            c.stereo_upload(*frames[k], slot=j + 1)
+        ctxs.append((c, p))
+        slots_of.append(list(range(1, len(mine) + 1)))
+
+    def one(c, p, slot):
+        c.stereo_submit(p, slot=slot)
+        c.stereo_wait(slot=slot)
+        c.stereo_finalize(calib, slot=slot, use_sift=True)
+        c.temporal_match(slot=slot, fetch=False, stages=0)
+
+    for (c, p), sl in zip(ctxs, slots_of):       # untimed: sizes every buffer, one context after the other
+        for slot in sl[:2]:
+            one(c, p, slot)
+    start = threading.Barrier(T + 1)
+    per = [steps // T + (1 if t < steps % T else 0) for t in range(T)]
+
+    def work(t):
+        c, p = ctxs[t]
+        start.wait()
+        for i in range(per[t]):
+            one(c, p, slots_of[t][i % len(slots_of[t])])
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(T)]
+    old_switch = sys.getswitchinterval()
+    sys.setswitchinterval(1e-4)                  # a thread back from a C call should not wait 5 ms for the interpreter lock
+    for x in th:
+        x.start()
+    start.wait()
+    t0 = time.perf_counter()
+    for x in th:
+        x.join()
+    dt = time.perf_counter() - t0
+    sys.setswitchinterval(old_switch)
+    for c, _ in ctxs:
+        c.close()
+    return steps / dt
+
+
 def sequence_bench(args, wl, H, W, F, device, rank, world, dist, reduce_device):
     """configs[2]: a sequence with a keyframe.  A step = one frame through the whole per-frame path; the frames are resident
     (one slot each), so the timed region holds no host-to-device image traffic, like the headline workload."""
@@ -352,6 +447,11 @@ def sequence_bench(args, wl, H, W, F, device, rank, world, dist, reduce_device):
         for k in range(n_full):
             _, _, tcf = frame(k % n_frames, stages=1)
         t_full = (time.perf_counter() - t1) / n_full
+        # the same frames through T contexts driven by T host threads (the library's model: one ebvo_ctx per host thread):
+        # a frame is a host-sequenced chain of ~180 short launches, so several chains share the device well
+        threaded = {}
+        for T in host_threads(args):
+            threaded[str(T)] = threaded_sequence(T, args, H, W, F, device, frames, calib, cal, min(args.steps, 64))
         alg_bytes = algorithmic_bytes_per_pair(H, W, c.n_left, c.n_right, c.n_pairs)
         dom_s = kernels[dom]["ms_per_step"] * 1e-3 / max(1.0, kernels[dom]["launches_per_step"])
         result = {
@@ -370,6 +470,7 @@ def sequence_bench(args, wl, H, W, F, device, rank, world, dist, reduce_device):
                          "note": "the stereo hot path's algorithmic bytes (SURVEY.md 8(d)) over the dominant kernel id's launch "
                                  "duration (HIP events, frames one at a time, after the timed region)"},
             "kernels": kernels,
+            "frames_per_s_by_host_threads": threaded,
             "full_temporal_chain_frames_per_s": 1.0 / t_full,
             "full_temporal_chain_note": "the same frame loop with the rest of get_Temporal_Edge_Pairs_from_Quads after the NCC "
                                         "filter (SIFT filter, Best-Nearly-Best on NCC and SIFT scores, photometric refinement "
@@ -398,6 +499,9 @@ def main():
     ap.add_argument("--streams", type=int, default=6,
                     help="stereo pairs kept in flight per GPU (slots; one HIP stream each up to 3, from 4 on their kernels are "
                          "dealt to min(4, slots - 1) streams of the context)")
+    ap.add_argument("--host-threads", default="",
+                    help="e.g. 2,4,8: also run the frame loops (euroc: the sequence; kitti / eth3d: the one-pass drop-in) in that "
+                         "many host threads, one context each -- extra keys of the JSON line, never `value`")
     args = ap.parse_args()
 
     info = sharding.rank_info()
@@ -529,6 +633,7 @@ def main():
         n_drop = max(nslots, min(args.steps, 24))
         dropin_loop(ctx, params, pool, calib, min(nslots, 3), min(nslots, 3))                 # untimed: sizes the chain's buffers
         t_drop, final_per_pair = dropin_loop(ctx, params, pool, calib, min(nslots, 3), n_drop)
+        drop_threads = {str(T): threaded_dropin(T, args, H, W, F, device, pool, calib, 2 * n_drop) for T in host_threads(args)}
         # the drop-in path: what main_VO executes through integration/*.cpp -- host-buffer entry points, results in host
         # arrays, one call after the other (src/Pipeline.cpp:24-29, :109-145): TOED of both images, epipolar lines,
         # candidate search (the three geometric stages in one call), NCC with left patches
@@ -550,6 +655,10 @@ def main():
                                "memory per frame, TOED + candidates + NCC, SIFT filter, both Best-Nearly-Best tests, shift, "
                                "photometric refinement, clustering, second NCC pass, best per row; final pairs + output rows "
                                "copied back; the stereo pairs of up to three frames in flight",
+                "dropin_final_pairs_per_s_by_host_threads": drop_threads,
+                "dropin_threads_note": "the same loop in T host threads, each with its own context (the library's model: one "
+                                       "ebvo_ctx per host thread): the later stages are a host-sequenced chain of short launches, "
+                                       "several chains share the device",
                 "boundary_pairs_per_s": 1.0 / t_b,
                 "boundary_note": "the stage-wise drop-in sequence through the host-buffer C entry points (ebvo_toed_pair, "
                                  "ebvo_epipolar_lines, ebvo_epi_candidates_staged = one search for the three stages, ebvo_ncc_pairs with left "

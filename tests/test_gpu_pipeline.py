@@ -376,3 +376,55 @@ def test_fresh_contexts_are_deterministic(mode):
             ref[it % 2] = sig
         else:
             assert sig == ref[it % 2], f"context #{it} differs: " + ", ".join(k for k in sig if sig[k] != ref[it % 2][k])
+
+
+def test_one_context_per_host_thread():
+    """The library's threading model: one ebvo_ctx per host thread.  Three threads, each with its own context, run the
+    pipeline and the resident chain on their own pairs at the same time; every result equals a lone run's."""
+    import hashlib
+    import threading
+    from edge_based_visual_odometry_amd.api import Context
+    cal = synth.CALIB["kitti"]
+    calib = ([cal["K"][0], 0, cal["K"][2], 0, cal["K"][1], cal["K"][3], 0, 0, 1],
+             [cal["K_right"][0], 0, cal["K_right"][2], 0, cal["K_right"][1], cal["K_right"][3], 0, 0, 1], cal["R21"], cal["T21"])
+    pairs = [synth.stereo_pair("s2", 120, 200, scene=11 + t, noise_base=3 * t) for t in range(3)]
+
+    def signature(c, pair, rounds):
+        sigs = []
+        p = c.default_params(F_KITTI)
+        for _ in range(rounds):
+            c.stereo_upload(*pair)
+            cnt = c.stereo_run(p)
+            out = c.stereo_fetch(cnt)
+            fc, fin = c.stereo_finalize(calib, use_sift=True)
+            h = hashlib.sha1()
+            for k in ("row_ptr", "col_idx", "sims", "best", "keep"):
+                h.update(np.ascontiguousarray(out[k]).view(np.uint8).tobytes())
+            for k in sorted(fin):
+                if isinstance(fin[k], np.ndarray):
+                    h.update(np.ascontiguousarray(fin[k]).view(np.uint8).tobytes())
+            sigs.append((cnt.n_pairs, cnt.n_matches, fc["n_final"], h.hexdigest()))
+        return sigs
+
+    with Context(120, 200) as lone:
+        want = [signature(lone, pr, 1)[0] for pr in pairs]
+    ctxs = [Context(120, 200) for _ in pairs]
+    got, errors = [None] * len(pairs), []
+
+    def work(t):
+        try:
+            got[t] = signature(ctxs[t], pairs[t], 6)
+        except Exception as e:  # noqa: BLE001 - reported by the assertion below
+            errors.append(repr(e))
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(len(pairs))]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join(timeout=120)
+    for c in ctxs:
+        c.close()
+    assert not errors, errors
+    for t in range(len(pairs)):
+        assert got[t] is not None and all(s == want[t] for s in got[t]), f"thread {t}: {got[t]} != {want[t]}"
+        assert want[t][2] > 0

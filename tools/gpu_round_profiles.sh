@@ -18,11 +18,12 @@ echo "== trace_hybrid: rocprofv3 --kernel-trace --stats -- python3 bench.py --wo
 sum ${TAG}_euroc hybrid; rm -rf gpurun_out/prof_${TAG}_euroc
 bash tools/gpu_timeline.sh ${TAG} > /dev/null 2>&1; cp gpurun_out/timeline_${TAG}/summary.txt "$EBVO_PROFILES_DST/${TAG}_timeline_slots.txt"; rm -rf gpurun_out/timeline_${TAG}
 # bench lines of the round (untraced)
-python3 bench.py > "$EBVO_PROFILES_DST/${TAG}_bench_kitti.json" 2> /dev/null
+python3 bench.py --no-cpu-baseline --no-transfer-legs > /dev/null 2>&1   # the first run on a fresh box reads low (clocks)
+python3 bench.py --host-threads 2,4 > "$EBVO_PROFILES_DST/${TAG}_bench_kitti.json" 2> /dev/null
 python3 bench.py --streams 1 --no-cpu-baseline --no-transfer-legs > "$EBVO_PROFILES_DST/${TAG}_bench_kitti_1slot.json" 2> /dev/null
 python3 bench.py --toed-mode strict --no-cpu-baseline --no-transfer-legs > "$EBVO_PROFILES_DST/${TAG}_bench_kitti_strict.json" 2> /dev/null
 python3 bench.py --workload eth3d --no-cpu-baseline > "$EBVO_PROFILES_DST/${TAG}_bench_eth3d.json" 2> /dev/null
-python3 bench.py --workload euroc --steps 64 --warmup 4 > "$EBVO_PROFILES_DST/${TAG}_bench_euroc.json" 2> /dev/null
+python3 bench.py --workload euroc --steps 64 --warmup 4 --host-threads 2,4,8 > "$EBVO_PROFILES_DST/${TAG}_bench_euroc.json" 2> /dev/null
 python3 tools/gpu_chain_time.py > "$EBVO_PROFILES_DST/${TAG}_chain_time.txt" 2>&1
 python3 tools/gpu_streams_sweep.py > "$EBVO_PROFILES_DST/${TAG}_slots_sweep.txt" 2>&1
 ls -la "$EBVO_PROFILES_DST"
