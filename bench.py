@@ -708,7 +708,7 @@ def main():
         else:
             ops, executed, ops_note = None, None, "not an fp64-ALU kernel"
         result = {
-            "metric": "stereo pairs/sec (TOED+NCC match) on KITTI 1241x376; achieved HBM GB/s",
+            "metric": "stereo pairs/sec (TOED+NCC match) on KITTI 1241\u00d7376; achieved HBM GB/s",   # BASELINE.json's string
             "value": sharding.job_throughput(world, args.steps, dt),
             "unit": "stereo pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
