@@ -734,6 +734,8 @@ struct Gn2Args
     int32_t *iters;
     double *mean_l; // [2][n]
     double *sc;     // [4][n]: sin, cos of the keyframe edge, sin, cos of the current-frame edge
+    float *lrec;    // [n][98] the keyframe-side samples of every item (they do not change with the iterations): gn2_init_kernel
+    const uint4 *recC, *recC2; // packed corner records (intensity + Sobel gradients, gn_pack_kernel) of the current-frame images
     int32_t *list[2];
     int32_t *counts;
 };
@@ -790,7 +792,11 @@ __global__ __launch_bounds__(256) void gn2_init_kernel(Gn2Args A)
             for (int i = -3; i <= 3; ++i)
 #pragma unroll
                 for (int j = -3; j <= 3; ++j)
-                    sum += (double)sample_u8(imgK, w, w, h, cx + ct * i - st * j, cy + st * i + ct * j);
+                {
+                    const float v = sample_u8(imgK, w, w, h, cx + ct * i - st * j, cy + st * i + ct * j);
+                    A.lrec[(size_t)k * 98 + sd * 49 + (i + 3) * 7 + (j + 3)] = v; // read back by every iteration
+                    sum += (double)v;
+                }
             A.mean_l[(size_t)sd * A.n + k] = sum / 49;
         }
         A.sc[k] = st;
@@ -823,10 +829,10 @@ __global__ __launch_bounds__(256) void gn2_iter_kernel(Gn2Args A, int it)
             k = lin[idx];
             const ebvo_edge ke = A.kf[k];
             const bool second = k >= A.n_first;
-            const uint8_t *__restrict__ imgK = second ? A.imgK2 : A.imgK, *__restrict__ imgC = second ? A.imgC2 : A.imgC;
-            const float2 *__restrict__ gxy = second ? A.gxy2 : A.gxy;
-            const double st = A.sc[k], ct = A.sc[A.n + k], stc = A.sc[2 * A.n + k], ctc = A.sc[3 * A.n + k];
-            const double nx = -st, ny = ct, ncx = -stc, ncy = ctc, side = (7 / 2.0) + 1.0;
+            const uint8_t *__restrict__ imgC = second ? A.imgC2 : A.imgC;
+            const uint4 *__restrict__ recC = second ? A.recC2 : A.recC;
+            const double stc = A.sc[2 * A.n + k], ctc = A.sc[3 * A.n + k];
+            const double ncx = -stc, ncy = ctc, side = (7 / 2.0) + 1.0;
             const double meanL[2] = {A.mean_l[k], A.mean_l[A.n + k]};
             double d0 = A.disp[2 * k], d1 = A.disp[2 * k + 1];
             const double lx = ke.x - d0, ly = ke.y - d1; // :786
@@ -847,25 +853,16 @@ __global__ __launch_bounds__(256) void gn2_iter_kernel(Gn2Args A, int it)
 #pragma unroll 1
             for (int sd = 0; sd < 2; ++sd)
             {
-                const double lcx = sd ? ke.x - nx * side : ke.x + nx * side, lcy = sd ? ke.y - ny * side : ke.y + ny * side;
+                const float *__restrict__ lrec = A.lrec + (size_t)k * 98 + sd * 49;
                 const double cx = sd ? lx - ncx * side : lx + ncx * side, cy = sd ? ly - ncy * side : ly + ncy * side;
 #pragma unroll 1
                 for (int i = -3; i <= 3; ++i)
 #pragma unroll 1
                     for (int j = -3; j <= 3; ++j)
                     {
-                        const double Lf = (double)sample_u8(imgK, w, w, h, lcx + ct * i - st * j, lcy + st * i + ct * j);
-                        int x0, x1, y0, y1;
-                        double wa, wb;
-                        tap_at(cx + ctc * i - stc * j, cy + stc * i + ctc * j, w, h, x0, x1, y0, y1, wa, wb);
-                        const int xa = min(x0, w - 2);
-                        const bool shifted = xa != x0;
-                        const Corners ci = corners_u8(imgC, w, w, x0, x1, y0, y1);
-                        const float4 g0 = *reinterpret_cast<const float4 *>(gxy + (size_t)y0 * w + xa);
-                        const float4 g1 = *reinterpret_cast<const float4 *>(gxy + (size_t)y1 * w + xa);
-                        const double Rf = (double)blend(wa, wb, ci.v00, ci.v10, ci.v01, ci.v11);
-                        const double J0 = (double)blend(wa, wb, shifted ? g0.z : g0.x, g0.z, shifted ? g1.z : g1.x, g1.z);
-                        const double J1 = (double)blend(wa, wb, shifted ? g0.w : g0.y, g0.w, shifted ? g1.w : g1.y, g1.w);
+                        const double Lf = (double)lrec[(i + 3) * 7 + (j + 3)]; // sampled once by gn2_init_kernel
+                        const GnTap tp = gn_tap(recC, w, h, cx + ctc * i - stc * j, cy + stc * i + ctc * j);
+                        const double Rf = (double)tp.v, J0 = (double)tp.gx, J1 = (double)tp.gy;
                         const double r = (Lf - meanL[sd]) - (Rf - meanR[sd]);
                         const double absr = fabs(r);
                         const double wgt = (absr < A.huber) ? 1.0 : A.huber / absr; // strict, :806
@@ -927,23 +924,23 @@ __global__ __launch_bounds__(256, 2) void gn2_iter_rows_kernel(Gn2Args A, int it
         bool survives = false;
         const ebvo_edge ke = A.kf[k];
         const bool second = k >= A.n_first;
-        const uint8_t *__restrict__ imgK = second ? A.imgK2 : A.imgK, *__restrict__ imgC = second ? A.imgC2 : A.imgC;
-        const float2 *__restrict__ gxy = second ? A.gxy2 : A.gxy;
-        const double st = A.sc[k], ct = A.sc[A.n + k], stc = A.sc[2 * A.n + k], ctc = A.sc[3 * A.n + k];
-        const double nx = -st, ny = ct, ncx = -stc, ncy = ctc, side = (7 / 2.0) + 1.0;
+        const uint4 *__restrict__ recC = second ? A.recC2 : A.recC;
+        const double stc = A.sc[2 * A.n + k], ctc = A.sc[3 * A.n + k];
+        const double ncx = -stc, ncy = ctc, side = (7 / 2.0) + 1.0;
         const double meanL[2] = {A.mean_l[k], A.mean_l[A.n + k]};
         double d0 = A.disp[2 * k], d1 = A.disp[2 * k + 1];
         const double lx = ke.x - d0, ly = ke.y - d1; // :786
         const int i = min(row, 6) - 3; // this lane's patch row (lane 7 repeats row 6 and is never selected)
-        double meanR[2];
+        double H00 = 0, H10 = 0, H11 = 0, b0 = 0, b1 = 0, cost = 0;
 #pragma unroll 1
         for (int sd = 0; sd < 2; ++sd)
         {
+            const float *__restrict__ lrec = A.lrec + (size_t)k * 98 + sd * 49 + (i + 3) * 7;
             const double cx = sd ? lx - ncx * side : lx + ncx * side, cy = sd ? ly - ncy * side : ly + ncy * side;
-            float v[7];
+            GnTap tp[7]; // this lane's row of the side: every point tapped once (intensity and both gradients)
 #pragma unroll
             for (int j = -3; j <= 3; ++j)
-                v[j + 3] = sample_u8(imgC, w, w, h, cx + ctc * i - stc * j, cy + stc * i + ctc * j);
+                tp[j + 3] = gn_tap(recC, w, h, cx + ctc * i - stc * j, cy + stc * i + ctc * j);
             double sum = 0;
 #pragma unroll 1
             for (int r = 0; r < 7; ++r)
@@ -951,43 +948,26 @@ __global__ __launch_bounds__(256, 2) void gn2_iter_rows_kernel(Gn2Args A, int it
                 double t = sum;
 #pragma unroll
                 for (int j = 0; j < 7; ++j)
-                    t += (double)v[j];
+                    t += (double)tp[j].v;
                 sum = __shfl(t, gbase | r);
             }
-            meanR[sd] = sum / 49;
-        }
-        double H00 = 0, H10 = 0, H11 = 0, b0 = 0, b1 = 0, cost = 0;
-#pragma unroll 1
-        for (int sd = 0; sd < 2; ++sd)
-        {
-            const double lcx = sd ? ke.x - nx * side : ke.x + nx * side, lcy = sd ? ke.y - ny * side : ke.y + ny * side;
-            const double cx = sd ? lx - ncx * side : lx + ncx * side, cy = sd ? ly - ncy * side : ly + ncy * side;
+            const double meanR = sum / 49;
             double t00[7], t10[7], t11[7], tb0[7], tb1[7], tc[7];
 #pragma unroll
-            for (int j = -3; j <= 3; ++j)
+            for (int j = 0; j < 7; ++j)
             {
-                const double Lf = (double)sample_u8(imgK, w, w, h, lcx + ct * i - st * j, lcy + st * i + ct * j);
-                int x0, x1, y0, y1;
-                double wa, wb;
-                tap_at(cx + ctc * i - stc * j, cy + stc * i + ctc * j, w, h, x0, x1, y0, y1, wa, wb);
-                const int xa = min(x0, w - 2);
-                const bool shifted = xa != x0;
-                const Corners ci = corners_u8(imgC, w, w, x0, x1, y0, y1);
-                const float4 g0 = *reinterpret_cast<const float4 *>(gxy + (size_t)y0 * w + xa);
-                const float4 g1 = *reinterpret_cast<const float4 *>(gxy + (size_t)y1 * w + xa);
-                const double Rf = (double)blend(wa, wb, ci.v00, ci.v10, ci.v01, ci.v11);
-                const double J0 = (double)blend(wa, wb, shifted ? g0.z : g0.x, g0.z, shifted ? g1.z : g1.x, g1.z);
-                const double J1 = (double)blend(wa, wb, shifted ? g0.w : g0.y, g0.w, shifted ? g1.w : g1.y, g1.w);
-                const double r = (Lf - meanL[sd]) - (Rf - meanR[sd]);
+                const double Lf = (double)lrec[j]; // sampled once by gn2_init_kernel
+                const double Rf = (double)tp[j].v, J0 = (double)tp[j].gx, J1 = (double)tp[j].gy;
+                const double r = (Lf - meanL[sd]) - (Rf - meanR);
                 const double absr = fabs(r);
                 const double wgt = (absr < A.huber) ? 1.0 : A.huber / absr; // strict, :806
                 const double wJ0 = wgt * J0, wJ1 = wgt * J1;
-                t00[j + 3] = wJ0 * J0; // the addends of gn2_iter_kernel's sums, formed by the same operations
-                t10[j + 3] = wJ1 * J0;
-                t11[j + 3] = wJ1 * J1;
-                tb0[j + 3] = wJ0 * r;
-                tb1[j + 3] = wJ1 * r;
-                tc[j + 3] = wgt * r * r;
+                t00[j] = wJ0 * J0; // the addends of gn2_iter_kernel's sums, formed by the same operations
+                t10[j] = wJ1 * J0;
+                t11[j] = wJ1 * J1;
+                tb0[j] = wJ0 * r;
+                tb1[j] = wJ1 * r;
+                tc[j] = wgt * r * r;
             }
 #pragma unroll 1
             for (int r = 0; r < 7; ++r)
@@ -1271,8 +1251,11 @@ int refine_gn_temporal_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_imgK, co
         return EBVO_ERR_ARG;
     int rc;
     const size_t np = (size_t)n;
-    if ((rc = ebvo_grow(ctx, s, s.gn_state, sizeof(double) * 6 * np)) ||
-        (rc = ebvo_grow(ctx, s, s.gn_lists, sizeof(int32_t) * (2 * np + (size_t)max_iter + 2))))
+    const size_t npx = (size_t)h * w;
+    const bool two = d_imgC2 && d_imgC2 != d_imgC;
+    if ((rc = ebvo_grow(ctx, s, s.gn_state, sizeof(double) * 6 * np + sizeof(float) * 98 * np)) ||
+        (rc = ebvo_grow(ctx, s, s.gn_lists, sizeof(int32_t) * (2 * np + (size_t)max_iter + 2))) ||
+        (rc = ebvo_grow(ctx, s, s.gn_pack, sizeof(uint4) * npx * (two ? 2 : 1))))
         return rc;
     Gn2Args A{};
     A.imgK = d_imgK;
@@ -1297,12 +1280,23 @@ int refine_gn_temporal_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_imgK, co
     A.iters = d_iters;
     A.mean_l = (double *)s.gn_state.p;
     A.sc = A.mean_l + 2 * np;
+    A.lrec = (float *)(A.sc + 4 * np);
+    uint4 *rec = (uint4 *)s.gn_pack.p;
+    A.recC = rec;
+    A.recC2 = two ? rec + npx : rec;
     A.list[0] = (int32_t *)s.gn_lists.p;
     A.list[1] = A.list[0] + np;
     A.counts = A.list[1] + np;
     ProfScope ps(ctx, s, K_GN_REFINE);
     EBVO_HIP(ctx, hipMemsetAsync(A.counts, 0, sizeof(int32_t) * ((size_t)max_iter + 2), s.stream));
     const unsigned blocks = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    {
+        // the current-frame images as packed corner records (intensity + Sobel gradients): one load per sample point
+        const dim3 pg((w + 63) / 64, (h + 3) / 4);
+        hipLaunchKernelGGL(gn_pack_kernel, pg, dim3(256), 0, s.stream, d_imgC, h, w, w, (uint32_t *)nullptr, rec);
+        if (two)
+            hipLaunchKernelGGL(gn_pack_kernel, pg, dim3(256), 0, s.stream, d_imgC2, h, w, w, (uint32_t *)nullptr, rec + npx);
+    }
     hipLaunchKernelGGL(gn2_init_kernel, dim3(blocks), dim3(256), 0, s.stream, A);
     const bool rows = n <= GN_ROWS_MAX_PAIRS && !getenv("EBVO_GN_NO_ROWS"); // small batch: eight lanes per item
     const unsigned rblocks = (unsigned)((n + 31) / 32 < 8192 ? (n + 31) / 32 : 8192);
