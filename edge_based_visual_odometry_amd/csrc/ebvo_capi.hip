@@ -1264,9 +1264,9 @@ extern "C" int ebvo_gn_refine_temporal(ebvo_ctx *ctx, const uint8_t *imgKF, cons
         return EBVO_OK;
     if (!kf || !cf || !init_disp || !disp || !score || !validity || !iters)
         return EBVO_ERR_ARG;
-    const size_t nz = (size_t)n, img_bytes = sizeof(float) * (size_t)h * w;
+    const size_t nz = (size_t)n;
     if ((rc = upload_image(ctx, s, 0, imgKF, h, w, strideKF)) || (rc = upload_image(ctx, s, 1, imgCF, h, w, strideCF)) ||
-        (rc = ebvo_grow(ctx, s, s.grad_x, 2 * img_bytes + 64)) || (rc = ebvo_grow(ctx, s, s.scratch_b, sizeof(ebvo_edge) * nz)) ||
+        (rc = ebvo_grow(ctx, s, s.scratch_b, sizeof(ebvo_edge) * nz)) ||
         (rc = ebvo_grow(ctx, s, s.scratch_c, sizeof(ebvo_edge) * nz)) || (rc = ebvo_grow(ctx, s, s.gn_xy, sizeof(double) * 2 * nz)) ||
         (rc = ebvo_grow(ctx, s, s.gn_out, sizeof(double) * 3 * nz)) || (rc = ebvo_grow(ctx, s, s.gn_valid, nz)) ||
         (rc = ebvo_grow(ctx, s, s.gn_iters, sizeof(int32_t) * nz)))
@@ -1276,8 +1276,8 @@ extern "C" int ebvo_gn_refine_temporal(ebvo_ctx *ctx, const uint8_t *imgKF, cons
     EBVO_HIP(ctx, hipMemcpyAsync(s.scratch_c.p, cf, sizeof(ebvo_edge) * nz, hipMemcpyHostToDevice, st));
     EBVO_HIP(ctx, hipMemcpyAsync(s.gn_xy.p, init_disp, sizeof(double) * 2 * nz, hipMemcpyHostToDevice, st));
     double *out = (double *)s.gn_out.p;
-    if ((rc = refine_sobel_enqueue(ctx, s, s.im[1].img, h, w, w, nullptr, nullptr, s.grad_x.p)) ||
-        (rc = refine_gn_temporal_enqueue(ctx, s, s.im[0].img, s.im[1].img, s.grad_x.p, h, w,
+    // (the refinement packs the current-frame image itself: intensity + Sobel gradients per bilinear cell)
+    if ((rc = refine_gn_temporal_enqueue(ctx, s, s.im[0].img, s.im[1].img, nullptr, h, w,
                                          (const ebvo_edge *)s.scratch_b.p, (const ebvo_edge *)s.scratch_c.p,
                                          (const double *)s.gn_xy.p, n, params->max_iter, params->tol, params->huber_delta,
                                          out, out + 2 * nz, (uint8_t *)s.gn_valid.p, (int32_t *)s.gn_iters.p)))
@@ -2178,16 +2178,12 @@ static int temporal_chain(ebvo_ctx *ctx, Slot &s, const ebvo_temporal_params &P,
     uint8_t *validL = (uint8_t *)(base + o_valid), *validR = validL + n3z, *valid = validR + n3z;
     int32_t *itersL = (int32_t *)(base + o_iters); // the second camera's counts follow at + n3z (one batch, refine_gn_temporal_enqueue)
     ebvo_edge *cenL = (ebvo_edge *)(base + o_cen), *cenR = cenL + n3z;
-    if ((rc = ebvo_grow(ctx, s, s.grad_x, 2 * sizeof(float) * (size_t)h * w + 64)) ||
-        (rc = ebvo_grow(ctx, s, s.grad_y, 2 * sizeof(float) * (size_t)h * w + 64)) ||
-        (rc = refine_sobel_enqueue(ctx, s, s.im[0].img, h, w, w, nullptr, nullptr, s.grad_x.p)) ||
-        (rc = refine_sobel_enqueue(ctx, s, s.im[1].img, h, w, w, nullptr, nullptr, s.grad_y.p)) ||
-        (rc = glue_quad_refine_inputs_enqueue(ctx, s, ctx->kf_L, B.kf, cfL, B.cf, n3, kfeL, cfeL, initL)) ||
+    if ((rc = glue_quad_refine_inputs_enqueue(ctx, s, ctx->kf_L, B.kf, cfL, B.cf, n3, kfeL, cfeL, initL)) ||
         (rc = glue_quad_refine_inputs_enqueue(ctx, s, ctx->kf_R, B.kf, cfR, B.cf, n3, kfeR, cfeR, initR)) ||
         // both cameras in one batch: items 0 .. n3 - 1 the left images, n3 .. 2 n3 - 1 the right ones (the arrays are contiguous)
-        (rc = refine_gn_temporal_enqueue(ctx, s, ctx->kf_imgL, s.im[0].img, s.grad_x.p, h, w, kfeL, cfeL, initL, 2 * (int64_t)n3,
+        (rc = refine_gn_temporal_enqueue(ctx, s, ctx->kf_imgL, s.im[0].img, nullptr, h, w, kfeL, cfeL, initL, 2 * (int64_t)n3,
                                          P.gn.max_iter, P.gn.tol, P.gn.huber_delta, dispL, scoreL, validL, itersL, n3, ctx->kf_imgR,
-                                         s.im[1].img, s.grad_y.p)) ||
+                                         s.im[1].img, nullptr)) ||
         (rc = glue_quad_apply_refine_enqueue(ctx, s, kfeL, cfeL, dispL, validL, kfeR, cfeR, dispR, validR, n3, cenL, cenR, valid)))
         return rc;
     unsigned long long *d_nvalid = (unsigned long long *)(base + o_ok); // (the SIFT flags are no longer needed)

@@ -717,7 +717,7 @@ constexpr int64_t GN_ROWS_MAX_PAIRS = 131072; // temporal batches of up to this 
 struct Gn2Args
 {
     const uint8_t *imgK, *imgC;
-    const float2 *gxy; // interleaved Sobel planes of the current-frame image
+    const float2 *gxy; // (unused since the packed records: interleaved Sobel planes of the current-frame image)
     // items n_first .. n - 1 belong to a second camera (the right images of the quads): both cameras of a batch of quads
     // run in the same launches (a launch of a few thousand items lasts ~100 us whatever their number)
     const uint8_t *imgK2, *imgC2;
