@@ -726,9 +726,8 @@ extern "C" int ebvo_gn_refine_stereo(ebvo_ctx *ctx, const uint8_t *imgL, const u
         return EBVO_OK;
     if (!cand_xy || !alpha || !score || !confidence || !validity || !iters || !refined_xy)
         return EBVO_ERR_ARG;
-    const size_t img_bytes = sizeof(float) * (size_t)h * w, npz = (size_t)np;
+    const size_t npz = (size_t)np;
     if ((rc = upload_image(ctx, s, 0, imgL, h, w, strideL)) || (rc = upload_image(ctx, s, 1, imgR, h, w, strideR)) ||
-        (rc = ebvo_grow(ctx, s, s.grad_x, 2 * img_bytes + 64)) || /* interleaved (gx, gy) plane + slack for the 16-byte corner loads */
         (rc = ebvo_grow(ctx, s, s.scratch_b, sizeof(ebvo_edge) * (size_t)nL)) ||
         (rc = ebvo_grow(ctx, s, s.lines, sizeof(double) * 3 * (size_t)nL)) ||
         (rc = ebvo_grow(ctx, s, s.row_ptr, sizeof(int32_t) * ((size_t)nL + 1))) ||
@@ -742,9 +741,8 @@ extern "C" int ebvo_gn_refine_stereo(ebvo_ctx *ctx, const uint8_t *imgL, const u
     EBVO_HIP(ctx, hipMemcpyAsync(s.row_ptr.p, row_ptr, sizeof(int32_t) * ((size_t)nL + 1), hipMemcpyHostToDevice, st));
     EBVO_HIP(ctx, hipMemcpyAsync(s.gn_xy.p, cand_xy, sizeof(double) * 2 * npz, hipMemcpyHostToDevice, st));
     double *out = (double *)s.gn_out.p;
-    if ((rc = refine_sobel_enqueue(ctx, s, s.im[1].img, h, w, w, nullptr, nullptr, s.grad_x.p)) ||
-        (rc = match_expand_rows_enqueue(ctx, s, (const int32_t *)s.row_ptr.p, nL, np, (int32_t *)s.pair_left.p)) ||
-        (rc = refine_gn_stereo_enqueue(ctx, s, s.im[0].img, s.im[1].img, s.grad_x.p, h, w, (const ebvo_edge *)s.scratch_b.p, nL,
+    if ((rc = match_expand_rows_enqueue(ctx, s, (const int32_t *)s.row_ptr.p, nL, np, (int32_t *)s.pair_left.p)) ||
+        (rc = refine_gn_stereo_enqueue(ctx, s, s.im[0].img, s.im[1].img, nullptr, h, w, (const ebvo_edge *)s.scratch_b.p, nL,
                                        (const double *)s.lines.p, (const int32_t *)s.pair_left.p,
                                        (const double *)s.gn_xy.p, nullptr, nullptr, nullptr, np, params->max_iter,
                                        params->tol, params->huber_delta,
@@ -1475,8 +1473,7 @@ extern "C" int ebvo_stereo_refine(ebvo_ctx *ctx, int slot, const ebvo_gn_params 
     const int h = s.cur_h, w = s.cur_w;
     const size_t npz = (size_t)np;
     int rc;
-    if ((rc = ebvo_grow(ctx, s, s.grad_x, 2 * sizeof(float) * (size_t)h * w + 64)) ||
-        (rc = ebvo_grow(ctx, s, s.gn_out, sizeof(double) * 5 * npz)) || (rc = ebvo_grow(ctx, s, s.gn_valid, npz)) ||
+    if ((rc = ebvo_grow(ctx, s, s.gn_out, sizeof(double) * 5 * npz)) || (rc = ebvo_grow(ctx, s, s.gn_valid, npz)) ||
         (rc = ebvo_grow(ctx, s, s.gn_iters, sizeof(int32_t) * npz)))
         return rc;
     double *out = (double *)s.gn_out.p;
@@ -1484,8 +1481,7 @@ extern "C" int ebvo_stereo_refine(ebvo_ctx *ctx, int slot, const ebvo_gn_params 
     // expansion of the CSR is formed here (the matching kernels themselves work per tile of rows)
     if ((rc = ebvo_grow(ctx, s, s.pair_left, sizeof(int32_t) * npz)) ||
         (rc = match_expand_rows_enqueue(ctx, s, (const int32_t *)s.row_ptr.p, s.result.n_left, np, (int32_t *)s.pair_left.p)) ||
-        (rc = refine_sobel_enqueue(ctx, s, s.im[1].img, h, w, w, nullptr, nullptr, s.grad_x.p)) ||
-        (rc = refine_gn_stereo_enqueue(ctx, s, s.im[0].img, s.im[1].img, s.grad_x.p, h, w, s.im[0].edges, s.result.n_left,
+        (rc = refine_gn_stereo_enqueue(ctx, s, s.im[0].img, s.im[1].img, nullptr, h, w, s.im[0].edges, s.result.n_left,
                                        (const double *)s.lines.p, (const int32_t *)s.pair_left.p, nullptr, s.im[1].edges,
                                        (const int32_t *)s.col_idx.p, (const uint8_t *)s.keep.p, np, params->max_iter,
                                        params->tol, params->huber_delta, out, out + npz, out + 2 * npz,
@@ -1571,7 +1567,6 @@ extern "C" int ebvo_stereo_finalize(ebvo_ctx *ctx, int slot, const ebvo_finalize
         (rc = ebvo_grow(ctx, s, s.fin_edges, sizeof(ebvo_edge) * (3 * nz + 2 * nLz))) ||
         (rc = ebvo_grow(ctx, s, s.fin_f64, sizeof(double) * (5 * nz + nLz) + 16 * nz)) ||
         (rc = ebvo_grow(ctx, s, s.fin_u8, nz)) || (rc = ebvo_grow(ctx, s, s.fin_out, sizeof(double) * 16 * nLz)) ||
-        (rc = ebvo_grow(ctx, s, s.grad_x, 2 * sizeof(float) * (size_t)h * w + 64)) ||
         (rc = ebvo_grow(ctx, s, s.gn_xy, sizeof(double) * 2 * nz)) || (rc = ebvo_grow(ctx, s, s.gn_out, sizeof(double) * 5 * nz)) ||
         (rc = ebvo_grow(ctx, s, s.gn_valid, nz)) || (rc = ebvo_grow(ctx, s, s.gn_iters, sizeof(int32_t) * nz)))
         return rc;
@@ -1661,8 +1656,7 @@ extern "C" int ebvo_stereo_finalize(ebvo_ctx *ctx, int slot, const ebvo_finalize
         if ((rc = match_expand_rows_enqueue(ctx, s, rpB, nL, nB, left_of)) ||
             (rc = glue_shift_enqueue(ctx, s, candB, (const double *)s.lines.p, left_of, nB, candC)) ||
             (rc = glue_xy_enqueue(ctx, s, candC, (double *)s.gn_xy.p, nB, false)) ||
-            (rc = refine_sobel_enqueue(ctx, s, s.im[1].img, h, w, w, nullptr, nullptr, s.grad_x.p)) ||
-            (rc = refine_gn_stereo_enqueue(ctx, s, s.im[0].img, s.im[1].img, s.grad_x.p, h, w, s.im[0].edges, nL,
+            (rc = refine_gn_stereo_enqueue(ctx, s, s.im[0].img, s.im[1].img, nullptr, h, w, s.im[0].edges, nL,
                                            (const double *)s.lines.p, left_of, (const double *)s.gn_xy.p, nullptr, nullptr,
                                            nullptr, nB, p->gn.max_iter, p->gn.tol, p->gn.huber_delta, out, out + nz,
                                            out + 2 * nz, (uint8_t *)s.gn_valid.p, (int32_t *)s.gn_iters.p, out + 3 * nz)) ||
