@@ -453,76 +453,87 @@ __global__ __launch_bounds__(256) void cluster_kernel(const ebvo_edge *__restric
                 s_pt[threadIdx.x >> 4][i] = q;
             }
         __builtin_amdgcn_wave_barrier();
-        // ---- merging: wave-uniform loop, each group on its own row
-        bool merged = par;
-        while (__any(merged))
+        // ---- merging: wave-uniform loop, each group on its own row.  The reference restarts its scan at point 0 after
+        // every merge and takes the first point (ascending) whose nearest foreign point can be merged.  A point that was
+        // examined and could not merge stays that way until ITS OWN cluster changes: the set of points foreign to it is
+        // the same, so is its nearest one, and the two cluster sizes of the size test only grow.  So only the members of the
+        // cluster a merge has just formed need another look (`dirty`, a bit per point, the same in every lane of the group),
+        // and the next point to examine is the lowest dirty one -- the same merges in the same order as the restarting
+        // scan, without walking the settled head of the row again after each of them.
+        unsigned long long dirty = par ? (n >= 64 ? ~0ull : (1ull << n) - 1ull) : 0ull;
+        while (__any(dirty != 0ull))
         {
-            const bool active = merged;
-            merged = false;
-            // the first i (ascending) whose nearest foreign point can be merged: groups scan i in lock step
-            int i = 0;
-            bool searching = active;
-            while (__any(searching))
+            const bool searching = dirty != 0ull;
+            const int i = searching ? __ffsll((long long)dirty) - 1 : 0;
+            double best = 1.7976931348623157e308;
+            int nearest = -1, li = 0;
+            if (searching)
             {
-                double best = 1.7976931348623157e308;
-                int nearest = -1, li = 0;
-                if (searching)
-                {
-                    li = lab[i];
-                    const double xi = E[i].x, yi = E[i].y, ti = E[i].theta;
-                    for (int j = e; j < n; j += 16)
-                        if (lab[j] != li)
-                        {
-                            const double dx = xi - E[j].x, dy = yi - E[j].y;
-                            const double dist = sqrt(dx * dx + dy * dy);
-                            if (dist < best && dist < 1 && (!by_orientation || fabs(ti - E[j].theta) < orient_thr))
-                            {
-                                best = dist;
-                                nearest = j;
-                            }
-                        }
-                }
-                // minimum over the group; ties -> the lowest j, as the serial scan finds it
-#pragma unroll
-                for (int d = 8; d > 0; d >>= 1)
-                {
-                    const double ob = __shfl_xor(best, d);
-                    const int on = __shfl_xor(nearest, d);
-                    const bool take = on >= 0 && (nearest < 0 || ob < best || (ob == best && on < nearest));
-                    best = take ? ob : best;
-                    nearest = take ? on : nearest;
-                }
-                int so = 0, sn = 0, old_label = -1;
-                if (searching && nearest >= 0)
-                {
-                    old_label = lab[nearest];
-                    for (int k = e; k < n; k += 16)
+                li = lab[i];
+                const double xi = E[i].x, yi = E[i].y, ti = E[i].theta;
+                for (int j = e; j < n; j += 16)
+                    if (lab[j] != li)
                     {
-                        so += lab[k] == old_label;
-                        sn += lab[k] == li;
+                        const double dx = xi - E[j].x, dy = yi - E[j].y;
+                        const double dist = sqrt(dx * dx + dy * dy);
+                        if (dist < best && dist < 1 && (!by_orientation || fabs(ti - E[j].theta) < orient_thr))
+                        {
+                            best = dist;
+                            nearest = j;
+                        }
+                    }
+            }
+            // minimum over the group; ties -> the lowest j, as the serial scan finds it
+#pragma unroll
+            for (int d = 8; d > 0; d >>= 1)
+            {
+                const double ob = __shfl_xor(best, d);
+                const int on = __shfl_xor(nearest, d);
+                const bool take = on >= 0 && (nearest < 0 || ob < best || (ob == best && on < nearest));
+                best = take ? ob : best;
+                nearest = take ? on : nearest;
+            }
+            int so = 0, sn = 0, old_label = -1;
+            if (searching && nearest >= 0)
+            {
+                old_label = lab[nearest];
+                for (int k = e; k < n; k += 16)
+                {
+                    so += lab[k] == old_label;
+                    sn += lab[k] == li;
+                }
+            }
+#pragma unroll
+            for (int d = 8; d > 0; d >>= 1)
+            {
+                so += __shfl_xor(so, d);
+                sn += __shfl_xor(sn, d);
+            }
+            const bool merge = searching && nearest >= 0 && so + sn <= 10; // MAX_CLUSTER_SIZE
+            unsigned lo = 0, hi = 0; // the members of the merged cluster among this lane's points
+            if (merge)
+                for (int k = e; k < n; k += 16)
+                {
+                    const int lk = lab[k];
+                    if (lk == old_label)
+                        lab[k] = li;
+                    if (lk == old_label || lk == li)
+                    {
+                        lo |= k < 32 ? 1u << k : 0u;
+                        hi |= k >= 32 ? 1u << (k - 32) : 0u;
                     }
                 }
 #pragma unroll
-                for (int d = 8; d > 0; d >>= 1)
-                {
-                    so += __shfl_xor(so, d);
-                    sn += __shfl_xor(sn, d);
-                }
-                if (searching && nearest >= 0 && so + sn <= 10) // MAX_CLUSTER_SIZE
-                {
-                    for (int k = e; k < n; k += 16)
-                        if (lab[k] == old_label)
-                            lab[k] = li;
-                    merged = true;
-                    searching = false;
-                }
-                else if (searching)
-                {
-                    ++i;
-                    searching = i < n;
-                }
-                __builtin_amdgcn_wave_barrier();
+            for (int d = 8; d > 0; d >>= 1)
+            {
+                lo |= (unsigned)__shfl_xor((int)lo, d);
+                hi |= (unsigned)__shfl_xor((int)hi, d);
             }
+            if (merge)
+                dirty |= ((unsigned long long)hi << 32) | lo;
+            else if (searching)
+                dirty &= ~(1ull << i);
+            __builtin_amdgcn_wave_barrier();
         }
         // ---- one Gaussian-weighted average per cluster, clusters in ascending label order; labels renumbered
         unsigned long long present = 0;
