@@ -278,6 +278,29 @@ def frame_loop(ctx, params, pool, nslots, steps, upload, fetch):
     return time.perf_counter() - t0, nbytes / max(1, steps)
 
 
+def boundary_bench_cpp(left, right, H, W, iters=6):
+    """Builds and runs tools/boundary_bench.cpp (g++ against include/ebvo/adapters.hpp and the in-tree library) as a child
+    process; returns its JSON object, or None when there is no compiler / the build or the run fails."""
+    import subprocess
+    import tempfile
+    from edge_based_visual_odometry_amd import _lib
+    try:
+        libdir = os.path.dirname(_lib.LIB_PATH)
+        with tempfile.TemporaryDirectory() as tmp:
+            exe = os.path.join(tmp, "boundary_bench")
+            subprocess.check_call(["g++", "-std=c++17", "-O2", "-I", os.path.join(ROOT, "include"),
+                                   os.path.join(ROOT, "tools", "boundary_bench.cpp"), "-o", exe, "-L", libdir, "-lebvo_hip",
+                                   f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"], stdout=subprocess.DEVNULL,
+                                  stderr=subprocess.DEVNULL, timeout=120)
+            lp, rp_ = os.path.join(tmp, "l.raw"), os.path.join(tmp, "r.raw")
+            np.ascontiguousarray(left).tofile(lp)
+            np.ascontiguousarray(right).tofile(rp_)
+            out = subprocess.run([exe, lp, rp_, str(H), str(W), str(iters)], capture_output=True, timeout=120, check=True)
+            return json.loads(out.stdout.decode().strip().splitlines()[-1])
+    except Exception:  # noqa: BLE001 - the Python leg stands in
+        return None
+
+
 def host_threads(args):
     """--host-threads "2,4": the thread counts of the optional multi-context legs (none by default)"""
     return [int(x) for x in args.host_threads.split(",") if x.strip()]
@@ -637,19 +660,30 @@ def main():
         # the drop-in path: what main_VO executes through integration/*.cpp -- host-buffer entry points, results in host
         # arrays, one call after the other (src/Pipeline.cpp:24-29, :109-145): TOED of both images, epipolar lines,
         # candidate search (the three geometric stages in one call), NCC with left patches
-        n_b = 5
-        tb = time.perf_counter()
-        for k in range(n_b):
+        n_b = 6
+        split = np.zeros(5)
+        for k in range(n_b + 1):                                                  # the first turn is untimed (sizes the buffers)
             bl, br = pool[k % len(pool)]
+            tk = [time.perf_counter()]
             eL, eR, _ = ctx.toed_pair(bl, br)
+            tk.append(time.perf_counter())
             lines_b = ctx.epipolar_lines(F, eL)
+            tk.append(time.perf_counter())
             rp2, ci2, ok_b = ctx.epi_candidates_staged(eL, eR, lines_b)           # stages 1 + 2 as a list, stage 3 as flags
-            keep_b = ok_b.astype(bool)
-            rows_b = np.repeat(np.arange(len(eL)), np.diff(rp2))[keep_b]
-            rp_b = np.concatenate([[0], np.cumsum(np.bincount(rows_b, minlength=len(eL)))]).astype(np.int32)
-            ci_b = ci2[keep_b]
-            ctx.ncc_pairs(bl, br, eL, eR[ci_b], rp_b, want_left_patches=True)
-        t_b = (time.perf_counter() - tb) / n_b
+            tk.append(time.perf_counter())
+            # what the binding does on the host between the calls (integration/stereo_matches_hip.cpp: drop the unflagged
+            # candidates of every row): new row starts = kept candidates before each old row start
+            kept_before = np.concatenate([[0], np.cumsum(ok_b, dtype=np.int64)])
+            rp_b = kept_before[rp2].astype(np.int32)
+            cand_b = eR[ci2[ok_b.view(np.bool_)]]
+            tk.append(time.perf_counter())
+            ctx.ncc_pairs(bl, br, eL, cand_b, rp_b, want_left_patches=True)
+            tk.append(time.perf_counter())
+            if k:
+                split += np.diff(tk)
+        split /= n_b
+        t_b = float(split.sum())
+        boundary_cpp = boundary_bench_cpp(pool[0][0], pool[0][1], H, W)        # the same sequence through the C++ adapters
         legs = {"dropin_final_pairs_per_s": n_drop / t_drop, "dropin_final_pairs_per_frame": final_per_pair,
                 "dropin_note": "get_Stereo_Edge_Pairs in one pass (StereoMatcherHIP::stereo_edge_pairs): a new pair from host "
                                "memory per frame, TOED + candidates + NCC, SIFT filter, both Best-Nearly-Best tests, shift, "
@@ -659,8 +693,17 @@ def main():
                 "dropin_threads_note": "the same loop in T host threads, each with its own context (the library's model: one "
                                        "ebvo_ctx per host thread): the later stages are a host-sequenced chain of short launches, "
                                        "several chains share the device",
-                "boundary_pairs_per_s": 1.0 / t_b,
-                "boundary_note": "the stage-wise drop-in sequence through the host-buffer C entry points (ebvo_toed_pair, "
+                "boundary_pairs_per_s": boundary_cpp["pairs_per_s"] if boundary_cpp else 1.0 / t_b,
+                "boundary_cpp": boundary_cpp,
+                "boundary_pairs_per_s_python_harness": 1.0 / t_b,
+                "boundary_ms": dict(zip(("toed_pair", "epipolar_lines", "epi_candidates_staged", "host_row_filter", "ncc_pairs_with_left_patches"),
+                                        (float(x) * 1e3 for x in split))),
+                "boundary_note": "boundary_pairs_per_s: tools/boundary_bench.cpp, the stage-wise sequence as main_VO runs it through "
+                                 "include/ebvo/adapters.hpp (ProcessEdges x 2, CalculateEpipolarLine, one staged candidate search + the "
+                                 "host-side drop of unflagged pairs, NCC with left patches; std::vector results, no overlap).  "
+                                 "_python_harness / boundary_ms: the same calls from numpy, where the host step (a cumulative sum over "
+                                 "2.2 M flags and a gather of 0.58 M edge records) costs more than all device calls together.  "
+                                 "Python leg: the stage-wise drop-in sequence through the host-buffer C entry points (ebvo_toed_pair, "
                                  "ebvo_epipolar_lines, ebvo_epi_candidates_staged = one search for the three stages, ebvo_ncc_pairs with left "
                                  "patches), every input and output in pageable host arrays, no overlap between calls",
                 "with_h2d": n_leg / t_up, "with_h2d_d2h": n_leg / t_def, "d2h_bytes_per_pair": mb_def,

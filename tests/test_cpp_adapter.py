@@ -28,6 +28,16 @@ def test_adapter_builds_with_plain_gxx():
     assert os.path.exists(EXE)
 
 
+def test_boundary_bench_builds_with_plain_gxx(tmp_path):
+    """tools/boundary_bench.cpp (bench.py's boundary_pairs_per_s: the stage-wise sequence through the adapters)."""
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    exe = str(tmp_path / "boundary_bench")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tools", "boundary_bench.cpp"), "-o", exe, "-L", libdir, "-lebvo_hip",
+                           f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"])
+    assert os.path.exists(exe)
+
+
 @pytest.mark.gpu
 def test_adapter_matches_oracle(tmp_path):
     build_demo()
