@@ -76,6 +76,45 @@ constexpr float FLT_EPS = 1.1920928955078125e-07f;
 
 __device__ inline int cv_round_f(float v) { return (int)rintf(v); }
 
+// ebvo_expf / ebvo_fast_atan2_deg (ebvo_math.h) with their case distinctions as selects: the same operations on the path
+// the original takes, no branches -- the three dependent chains of a sample (orientation, magnitude, weight) then sit in
+// one basic block and overlap (one wave per SIMD: nothing else hides their latency)
+__device__ inline float sift_expf_sel(float x)
+{
+    const float fk = x * 1.44269504088896341f;
+    const int k = (int)(fk + (fk >= 0.0f ? 0.5f : -0.5f));
+    const float dk = (float)k;
+    const float r = (x - dk * 0.693359375f) - dk * -2.12194440e-4f;
+    float p = 1.0f / 720.0f;
+    p = p * r + 1.0f / 120.0f;
+    p = p * r + 1.0f / 24.0f;
+    p = p * r + 1.0f / 6.0f;
+    p = p * r + 0.5f;
+    p = p * r + 1.0f;
+    p = p * r + 1.0f;
+    float v = __builtin_ldexpf(p, k);
+    v = x < -87.0f ? 0.0f : v;
+    v = x > 88.0f ? 3.4028234663852886e38f * 2.0f : v;
+    return x != x ? x : v;
+}
+
+__device__ inline float sift_fast_atan2_sel(float y, float x)
+{
+    const float p1 = 0.9997878412794807f * (float)(180 / 3.14159265358979323846);
+    const float p3 = -0.3258083974640975f * (float)(180 / 3.14159265358979323846);
+    const float p5 = 0.1555786518463281f * (float)(180 / 3.14159265358979323846);
+    const float p7 = -0.04432655554792128f * (float)(180 / 3.14159265358979323846);
+    const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
+    const bool xs = ax >= ay;
+    const float c = (xs ? ay : ax) / ((xs ? ax : ay) + (float)2.2204460492503131e-16);
+    const float c2 = c * c;
+    const float t = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    float a = xs ? t : 90.f - t;
+    a = x < 0 ? 180.f - a : a;
+    a = y < 0 ? 360.f - a : a;
+    return a;
+}
+
 // calcSIFTDescriptor (modules/features2d/src/sift.simd.hpp), one thread per keypoint (edge e, side sd)
 __global__ __launch_bounds__(64) void sift_desc_kernel(const float *__restrict__ base, int rows, int cols,
                                                        const ebvo_edge *__restrict__ edges, int n_edges,
@@ -130,9 +169,9 @@ __global__ __launch_bounds__(64) void sift_desc_kernel(const float *__restrict__
                     const float dx = base[(size_t)r * cols + c + 1] - base[(size_t)r * cols + c - 1];
                     const float dy = base[(size_t)(r - 1) * cols + c] - base[(size_t)(r + 1) * cols + c];
                     const float wexp = (c_rot * c_rot + r_rot * r_rot) * exp_scale;
-                    const float Ori = ebvo_fast_atan2_deg(dy, dx);
+                    const float Ori = sift_fast_atan2_sel(dy, dx);
                     const float Mag = sqrtf(dx * dx + dy * dy);
-                    const float W = ebvo_expf(wexp);
+                    const float W = sift_expf_sel(wexp);
                     float obin = (Ori - ori) * bins_per_rad;
                     const float mag = Mag * W;
                     const int r0 = (int)floorf(rbin), c0 = (int)floorf(cbin);
