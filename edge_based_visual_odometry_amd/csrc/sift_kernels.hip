@@ -216,14 +216,38 @@ __global__ __launch_bounds__(64) void sift_desc_kernel(const float *__restrict__
         if ((unsigned)rr_ < (unsigned)SD && (unsigned)cc_ < (unsigned)SD)                                     \
             H[((rr_ * SD + cc_) * (SN + 2) + oo_) * 64] += (val);                                             \
     }
-                    EBVO_SIFT_VOTE(0, 0, 0, v_rco000)
-                    EBVO_SIFT_VOTE(0, 0, 1, v_rco001)
-                    EBVO_SIFT_VOTE(0, 1, 0, v_rco010)
-                    EBVO_SIFT_VOTE(0, 1, 1, v_rco011)
-                    EBVO_SIFT_VOTE(1, 0, 0, v_rco100)
-                    EBVO_SIFT_VOTE(1, 0, 1, v_rco101)
-                    EBVO_SIFT_VOTE(1, 1, 0, v_rco110)
-                    EBVO_SIFT_VOTE(1, 1, 1, v_rco111)
+                    {
+                        // all eight votes without branches: cells by the rules of the macro above as selects; a vote outside the
+                        // 4 x 4 interior adds +0 to a bin none of the eight can be (cell 0, three bins past the sample's first:
+                        // its votes use two adjacent bins; bins are sums of non-negative terms, x + 0 == x).  The eight cells
+                        // are distinct, so they are read together, updated and written together.
+                        const float add[8] = {v_rco000, v_rco001, v_rco010, v_rco011, v_rco100, v_rco101, v_rco110, v_rco111};
+                        const int first = o0 < 0 ? o0 + SN + 2 : o0;
+                        const int scratch = (first + 3 < SN + 2 ? first + 3 : first + 3 - (SN + 2)) * 64;
+                        int idx[8];
+                        float val[8], cur[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q)
+                        {
+                            const int dr = q >> 2, dc = (q >> 1) & 1, dob = q & 1;
+                            int rr = r0 + dr, cq = c0 + dc, oo = o0 + dob;
+                            const bool neg = oo < 0;
+                            oo = neg ? oo + SN + 2 : oo;
+                            cq = neg ? cq - 1 : cq;
+                            const bool wrap = cq < -1;
+                            cq = wrap ? SD : cq;
+                            rr = wrap ? rr - 1 : rr;
+                            const bool valid = (unsigned)rr < (unsigned)SD && (unsigned)cq < (unsigned)SD;
+                            idx[q] = valid ? ((rr * SD + cq) * (SN + 2) + oo) * 64 : scratch;
+                            val[q] = valid ? add[q] : 0.f;
+                        }
+#pragma unroll
+                        for (int q = 0; q < 8; ++q)
+                            cur[q] = H[idx[q]];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q)
+                            H[idx[q]] = cur[q] + val[q];
+                    }
 #undef EBVO_SIFT_VOTE
                 }
             }
