@@ -156,101 +156,131 @@ __global__ __launch_bounds__(64) void sift_desc_kernel(const float *__restrict__
         float *H = hist + lane;
         for (int b = 0; b < SHIST; ++b)
             H[b * 64] = 0.f;
-        for (int i = -radius; i <= radius; ++i)
-            for (int j = -radius; j <= radius; ++j)
-            {
-                const float c_rot = j * cos_t - i * sin_t;
-                const float r_rot = j * sin_t + i * cos_t;
-                float rbin = r_rot + SD / 2 - 0.5f;
-                float cbin = c_rot + SD / 2 - 0.5f;
-                const int r = py + i, c = px + j;
-                if (rbin > -1 && rbin < SD && cbin > -1 && cbin < SD && r > 0 && r < rows - 1 && c > 0 && c < cols - 1)
-                {
-                    const float dx = base[(size_t)r * cols + c + 1] - base[(size_t)r * cols + c - 1];
-                    const float dy = base[(size_t)(r - 1) * cols + c] - base[(size_t)(r + 1) * cols + c];
-                    const float wexp = (c_rot * c_rot + r_rot * r_rot) * exp_scale;
-                    const float Ori = sift_fast_atan2_sel(dy, dx);
-                    const float Mag = sqrtf(dx * dx + dy * dy);
-                    const float W = sift_expf_sel(wexp);
-                    float obin = (Ori - ori) * bins_per_rad;
-                    const float mag = Mag * W;
-                    const int r0 = (int)floorf(rbin), c0 = (int)floorf(cbin);
-                    int o0 = (int)floorf(obin);
-                    rbin -= r0;
-                    cbin -= c0;
-                    obin -= o0;
-                    if (o0 < 0)
-                        o0 += SN;
-                    if (o0 >= SN)
-                        o0 -= SN;
-                    const float v_r1 = mag * rbin, v_r0 = mag - v_r1;
-                    const float v_rc11 = v_r1 * cbin, v_rc10 = v_r1 - v_rc11;
-                    const float v_rc01 = v_r0 * cbin, v_rc00 = v_r0 - v_rc01;
-                    const float v_rco111 = v_rc11 * obin, v_rco110 = v_rc11 - v_rco111;
-                    const float v_rco101 = v_rc10 * obin, v_rco100 = v_rc10 - v_rco101;
-                    const float v_rco011 = v_rc01 * obin, v_rco010 = v_rc01 - v_rco011;
-                    const float v_rco001 = v_rc00 * obin, v_rco000 = v_rc00 - v_rco001;
-                    // The eight cells of the tri-linear vote, in the order of calcSIFTDescriptor.  Two things shape the
-                    // indexing.  (1) The border rows and columns of OpenCV's (d + 2) x (d + 2) histogram only collect what
-                    // falls outside the descriptor and are dropped at the end: they are not stored here (every kept cell
-                    // still receives its own addends in sample order), which leaves 4 x 4 x (8 + 2) floats per keypoint,
-                    // 40 KB per workgroup instead of 90.  (2) The reference passes orientations of -180 .. 180 degrees
-                    // where OpenCV expects 0 .. 360, so o0 can stay negative (down to -4) after the single "+= n": in
-                    // OpenCV's FLAT array such a vote lands in the upper bins of the previous cell (column - 1, or the
-                    // last column of the row above).  That aliasing is part of the reference's result and is reproduced
-                    // by the carry below; a vote in front of the array (undefined behaviour in OpenCV) is dropped, as
-                    // in the restatement (oracle/ebvo_oracle.c: calc_sift_descriptor).
+        // one sample that lies in the rotated window: its gradient (dx, dy) and rotated position -> the tri-linear vote
+        auto vote_sample = [&](float dx, float dy, float c_rot, float r_rot, float rbin, float cbin) {
+            const float wexp = (c_rot * c_rot + r_rot * r_rot) * exp_scale;
+            const float Ori = sift_fast_atan2_sel(dy, dx);
+            const float Mag = sqrtf(dx * dx + dy * dy);
+            const float W = sift_expf_sel(wexp);
+            float obin = (Ori - ori) * bins_per_rad;
+            const float mag = Mag * W;
+            const int r0 = (int)floorf(rbin), c0 = (int)floorf(cbin);
+            int o0 = (int)floorf(obin);
+            rbin -= r0;
+            cbin -= c0;
+            obin -= o0;
+            if (o0 < 0)
+                o0 += SN;
+            if (o0 >= SN)
+                o0 -= SN;
+            const float v_r1 = mag * rbin, v_r0 = mag - v_r1;
+            const float v_rc11 = v_r1 * cbin, v_rc10 = v_r1 - v_rc11;
+            const float v_rc01 = v_r0 * cbin, v_rc00 = v_r0 - v_rc01;
+            const float v_rco111 = v_rc11 * obin, v_rco110 = v_rc11 - v_rco111;
+            const float v_rco101 = v_rc10 * obin, v_rco100 = v_rc10 - v_rco101;
+            const float v_rco011 = v_rc01 * obin, v_rco010 = v_rc01 - v_rco011;
+            const float v_rco001 = v_rc00 * obin, v_rco000 = v_rc00 - v_rco001;
+            // The eight cells of the tri-linear vote, in the order of calcSIFTDescriptor.  Two things shape the
+            // indexing.  (1) The border rows and columns of OpenCV's (d + 2) x (d + 2) histogram only collect what
+            // falls outside the descriptor and are dropped at the end: they are not stored here (every kept cell
+            // still receives its own addends in sample order), which leaves 4 x 4 x (8 + 2) floats per keypoint,
+            // 40 KB per workgroup instead of 90.  (2) The reference passes orientations of -180 .. 180 degrees
+            // where OpenCV expects 0 .. 360, so o0 can stay negative (down to -4) after the single "+= n": in
+            // OpenCV's FLAT array such a vote lands in the upper bins of the previous cell (column - 1, or the
+            // last column of the row above).  That aliasing is part of the reference's result and is reproduced
+            // by the carry below; a vote in front of the array (undefined behaviour in OpenCV) is dropped, as
+            // in the restatement (oracle/ebvo_oracle.c: calc_sift_descriptor).
 #define EBVO_SIFT_VOTE(dr, dc, dob, val)                                                                      \
     {                                                                                                         \
-        int rr_ = r0 + dr, cc_ = c0 + dc, oo_ = o0 + dob; /* interior coordinates: -1 .. SD */                \
-        if (oo_ < 0)                                                                                          \
-        {                                                                                                     \
-            oo_ += SN + 2;                                                                                    \
-            cc_ -= 1;                                                                                         \
-            if (cc_ < -1)                                                                                     \
-            {                                                                                                 \
-                cc_ = SD;                                                                                     \
-                rr_ -= 1;                                                                                     \
-            }                                                                                                 \
-        }                                                                                                     \
-        if ((unsigned)rr_ < (unsigned)SD && (unsigned)cc_ < (unsigned)SD)                                     \
-            H[((rr_ * SD + cc_) * (SN + 2) + oo_) * 64] += (val);                                             \
+int rr_ = r0 + dr, cc_ = c0 + dc, oo_ = o0 + dob; /* interior coordinates: -1 .. SD */                \
+if (oo_ < 0)                                                                                          \
+{                                                                                                     \
+    oo_ += SN + 2;                                                                                    \
+    cc_ -= 1;                                                                                         \
+    if (cc_ < -1)                                                                                     \
+    {                                                                                                 \
+        cc_ = SD;                                                                                     \
+        rr_ -= 1;                                                                                     \
+    }                                                                                                 \
+}                                                                                                     \
+if ((unsigned)rr_ < (unsigned)SD && (unsigned)cc_ < (unsigned)SD)                                     \
+    H[((rr_ * SD + cc_) * (SN + 2) + oo_) * 64] += (val);                                             \
     }
-                    {
-                        // all eight votes without branches: cells by the rules of the macro above as selects; a vote outside the
-                        // 4 x 4 interior adds +0 to a bin none of the eight can be (cell 0, three bins past the sample's first:
-                        // its votes use two adjacent bins; bins are sums of non-negative terms, x + 0 == x).  The eight cells
-                        // are distinct, so they are read together, updated and written together.
-                        const float add[8] = {v_rco000, v_rco001, v_rco010, v_rco011, v_rco100, v_rco101, v_rco110, v_rco111};
-                        const int first = o0 < 0 ? o0 + SN + 2 : o0;
-                        const int scratch = (first + 3 < SN + 2 ? first + 3 : first + 3 - (SN + 2)) * 64;
-                        int idx[8];
-                        float val[8], cur[8];
+            {
+                // all eight votes without branches: cells by the rules of the macro above as selects; a vote outside the
+                // 4 x 4 interior adds +0 to a bin none of the eight can be (cell 0, three bins past the sample's first:
+                // its votes use two adjacent bins; bins are sums of non-negative terms, x + 0 == x).  The eight cells
+                // are distinct, so they are read together, updated and written together.
+                const float add[8] = {v_rco000, v_rco001, v_rco010, v_rco011, v_rco100, v_rco101, v_rco110, v_rco111};
+                const int first = o0 < 0 ? o0 + SN + 2 : o0;
+                const int scratch = (first + 3 < SN + 2 ? first + 3 : first + 3 - (SN + 2)) * 64;
+                int idx[8];
+                float val[8], cur[8];
 #pragma unroll
-                        for (int q = 0; q < 8; ++q)
-                        {
-                            const int dr = q >> 2, dc = (q >> 1) & 1, dob = q & 1;
-                            int rr = r0 + dr, cq = c0 + dc, oo = o0 + dob;
-                            const bool neg = oo < 0;
-                            oo = neg ? oo + SN + 2 : oo;
-                            cq = neg ? cq - 1 : cq;
-                            const bool wrap = cq < -1;
-                            cq = wrap ? SD : cq;
-                            rr = wrap ? rr - 1 : rr;
-                            const bool valid = (unsigned)rr < (unsigned)SD && (unsigned)cq < (unsigned)SD;
-                            idx[q] = valid ? ((rr * SD + cq) * (SN + 2) + oo) * 64 : scratch;
-                            val[q] = valid ? add[q] : 0.f;
-                        }
-#pragma unroll
-                        for (int q = 0; q < 8; ++q)
-                            cur[q] = H[idx[q]];
-#pragma unroll
-                        for (int q = 0; q < 8; ++q)
-                            H[idx[q]] = cur[q] + val[q];
-                    }
-#undef EBVO_SIFT_VOTE
+                for (int q = 0; q < 8; ++q)
+                {
+                    const int dr = q >> 2, dc = (q >> 1) & 1, dob = q & 1;
+                    int rr = r0 + dr, cq = c0 + dc, oo = o0 + dob;
+                    const bool neg = oo < 0;
+                    oo = neg ? oo + SN + 2 : oo;
+                    cq = neg ? cq - 1 : cq;
+                    const bool wrap = cq < -1;
+                    cq = wrap ? SD : cq;
+                    rr = wrap ? rr - 1 : rr;
+                    const bool valid = (unsigned)rr < (unsigned)SD && (unsigned)cq < (unsigned)SD;
+                    idx[q] = valid ? ((rr * SD + cq) * (SN + 2) + oo) * 64 : scratch;
+                    val[q] = valid ? add[q] : 0.f;
                 }
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    cur[q] = H[idx[q]];
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    H[idx[q]] = cur[q] + val[q];
             }
+#undef EBVO_SIFT_VOTE
+        };
+        // A wave whose keypoints all have their 13 x 13 neighbourhood inside the image (all but the waves at the border) needs
+        // no image tests, and fetches the four pixels of a sample one sample ahead, whether the sample will count or not:
+        // their latency runs under the previous sample's arithmetic.
+        const bool inside = radius == 5 && px >= 6 && px + 6 <= cols - 1 && py >= 6 && py + 6 <= rows - 1;
+        if (__all(inside))
+        {
+            const float *ctr = base + (size_t)(py - 5) * cols + (px - 5); // the pixel of sample (i, j) = (-5, -5)
+            float n0 = ctr[1], n1 = ctr[-1], n2 = ctr[-cols], n3 = ctr[cols];
+#pragma unroll 1
+            for (int i = -5; i <= 5; ++i)
+#pragma unroll 1
+                for (int j = -5; j <= 5; ++j)
+                {
+                    const float dx = n0 - n1, dy = n2 - n3;
+                    const bool last = i == 5 && j == 5;
+                    ctr += last ? 0 : (j == 5 ? cols - 10 : 1); // the next sample's pixel
+                    n0 = ctr[1];
+                    n1 = ctr[-1];
+                    n2 = ctr[-cols];
+                    n3 = ctr[cols];
+                    const float c_rot = j * cos_t - i * sin_t;
+                    const float r_rot = j * sin_t + i * cos_t;
+                    const float rbin = r_rot + SD / 2 - 0.5f;
+                    const float cbin = c_rot + SD / 2 - 0.5f;
+                    if (rbin > -1 && rbin < SD && cbin > -1 && cbin < SD)
+                        vote_sample(dx, dy, c_rot, r_rot, rbin, cbin);
+                }
+        }
+        else
+            for (int i = -radius; i <= radius; ++i)
+                for (int j = -radius; j <= radius; ++j)
+                {
+                    const float c_rot = j * cos_t - i * sin_t;
+                    const float r_rot = j * sin_t + i * cos_t;
+                    const float rbin = r_rot + SD / 2 - 0.5f;
+                    const float cbin = c_rot + SD / 2 - 0.5f;
+                    const int r = py + i, c = px + j;
+                    if (rbin > -1 && rbin < SD && cbin > -1 && cbin < SD && r > 0 && r < rows - 1 && c > 0 && c < cols - 1)
+                        vote_sample(base[(size_t)r * cols + c + 1] - base[(size_t)r * cols + c - 1],
+                                    base[(size_t)(r - 1) * cols + c] - base[(size_t)(r + 1) * cols + c], c_rot, r_rot, rbin, cbin);
+                }
         // the orientation histograms are circular; the 4 x 4 x 8 interior is the raw descriptor (kept in place)
         float nrm2 = 0;
         for (int i = 0; i < SD; ++i)
