@@ -290,38 +290,61 @@ if ((unsigned)rr_ < (unsigned)SD && (unsigned)cc_ < (unsigned)SD)               
                 H[idx * 64] += H[(idx + SN) * 64];
                 H[(idx + 1) * 64] += H[(idx + SN + 1) * 64];
             }
-        for (int i = 0; i < SD; ++i)
-            for (int j = 0; j < SD; ++j)
-                for (int k = 0; k < SN; ++k)
-                {
-                    const float v = H[((i * SD + j) * (SN + 2) + k) * 64];
-                    nrm2 += v * v;
-                }
+        // (the eight bins of a cell are read together; the sums still take their terms one by one, in bin order)
+        for (int cell = 0; cell < SD * SD; ++cell)
+        {
+            float v[SN];
+#pragma unroll
+            for (int k = 0; k < SN; ++k)
+                v[k] = H[(cell * (SN + 2) + k) * 64];
+#pragma unroll
+            for (int k = 0; k < SN; ++k)
+                nrm2 += v[k] * v[k];
+        }
         const float thr = sqrtf(nrm2) * 0.2f;
         nrm2 = 0;
-        for (int i = 0; i < SD; ++i)
-            for (int j = 0; j < SD; ++j)
-                for (int k = 0; k < SN; ++k)
-                {
-                    float *p = &H[((i * SD + j) * (SN + 2) + k) * 64];
-                    const float val = *p < thr ? *p : thr;
-                    *p = val;
-                    nrm2 += val * val;
-                }
+        for (int cell = 0; cell < SD * SD; ++cell)
+        {
+            float v[SN];
+#pragma unroll
+            for (int k = 0; k < SN; ++k)
+                v[k] = H[(cell * (SN + 2) + k) * 64];
+#pragma unroll
+            for (int k = 0; k < SN; ++k)
+            {
+                const float val = v[k] < thr ? v[k] : thr;
+                H[(cell * (SN + 2) + k) * 64] = val;
+                nrm2 += val * val;
+            }
+        }
         const float sq = sqrtf(nrm2);
         nrm2 = 512.f / (sq > FLT_EPS ? sq : FLT_EPS);
-        for (int i = 0; i < SD; ++i)
-            for (int j = 0; j < SD; ++j)
-                for (int k = 0; k < SN; ++k)
-                {
-                    int v = cv_round_f(H[((i * SD + j) * (SN + 2) + k) * 64] * nrm2);
-                    v = v < 0 ? 0 : (v > 255 ? 255 : v);
-                    const size_t o = (size_t)kp * 128 + (i * SD + j) * SN + k;
-                    if (desc_f)
-                        desc_f[o] = (float)v;
-                    if (desc_u8)
-                        desc_u8[o] = (uint8_t)v;
-                }
+        for (int cell = 0; cell < SD * SD; ++cell)
+        {
+            // a cell's eight values leave as one 8-byte (u8) / two 16-byte (float) stores: a store per value was 128 (+ 128)
+            // scattered store instructions per keypoint
+            int q[SN];
+#pragma unroll
+            for (int k = 0; k < SN; ++k)
+            {
+                const int t = cv_round_f(H[(cell * (SN + 2) + k) * 64] * nrm2);
+                q[k] = t < 0 ? 0 : (t > 255 ? 255 : t);
+            }
+            const size_t o = (size_t)kp * 128 + cell * SN;
+            if (desc_f)
+            {
+                float4 *d = reinterpret_cast<float4 *>(desc_f + o);
+                d[0] = make_float4((float)q[0], (float)q[1], (float)q[2], (float)q[3]);
+                d[1] = make_float4((float)q[4], (float)q[5], (float)q[6], (float)q[7]);
+            }
+            if (desc_u8)
+            {
+                uint2 w;
+                w.x = (unsigned)q[0] | ((unsigned)q[1] << 8) | ((unsigned)q[2] << 16) | ((unsigned)q[3] << 24);
+                w.y = (unsigned)q[4] | ((unsigned)q[5] << 8) | ((unsigned)q[6] << 16) | ((unsigned)q[7] << 24);
+                *reinterpret_cast<uint2 *>(desc_u8 + o) = w;
+            }
+        }
     }
 }
 
