@@ -382,34 +382,58 @@ __device__ inline void gn_candidate(const GnArgs &A, int64_t k, double &rx, doub
 }
 
 // the left side of every pair depends on the left edge only: sin / cos, the 2 x 49 samples and their means, once per edge
+// Eight lanes per left edge (lane r < 7 = patch row r of both sides; lane 7 repeats row 6 and writes nothing): the 98
+// samples of an edge are stored by neighbouring lanes as one contiguous run, and a lane walks 14 samples instead of 98 (a
+// thread per edge issued 98 scattered 4-byte stores and was one long dependent walk: 64 us at KITTI size).  The mean's
+// sum visits the lanes in row order, as in gn_iter_rows_kernel: the same additions in the same order.
 __global__ __launch_bounds__(256) void gn_left_kernel(GnArgs A)
 {
     const int h = A.h, w = A.w;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < A.nL; i += gridDim.x * blockDim.x)
+    const int lane = threadIdx.x & 63, row = lane & 7, gbase = lane & ~7;
+    const int groups_per_block = blockDim.x >> 3;
+    for (int base = blockIdx.x * groups_per_block; base < A.nL; base += gridDim.x * groups_per_block)
     {
-        const ebvo_edge le = A.L[i];
+        const int i = base + (threadIdx.x >> 3);
+        const bool live = i < A.nL; // uniform in the group; the exchanges below run for every lane of the wave
+        const ebvo_edge le = A.L[live ? i : 0];
         double st, ct;
         ebvo_sincos(le.theta, &st, &ct);
         const double nx = -st, ny = ct;      // n(-t.y, t.x), :1172
         const double side = (7 / 2.0) + 1.0; // :1173
+        const int a = min(row, 6) - 3;       // this lane's patch row
 #pragma unroll 1
         for (int sd = 0; sd < 2; ++sd)
         {
             const double cx = sd ? le.x - nx * side : le.x + nx * side, cy = sd ? le.y - ny * side : le.y + ny * side;
+            float v[7];
+#pragma unroll
+            for (int b = -3; b <= 3; ++b)
+                v[b + 3] = sample_pix4(A.pix4L, w, h, cx + ct * a - st * b, cy + st * a + ct * b);
+            if (live && row < 7)
+            {
+                float *dst = A.left_rec + (size_t)i * 98 + sd * 49 + row * 7;
+#pragma unroll
+                for (int b = 0; b < 7; ++b)
+                    dst[b] = v[b];
+            }
             double sum = 0;
 #pragma unroll 1
-            for (int a = -3; a <= 3; ++a)
+            for (int r = 0; r < 7; ++r)
+            {
+                double t = sum;
 #pragma unroll
-                for (int b = -3; b <= 3; ++b)
-                {
-                    const float v = sample_pix4(A.pix4L, w, h, cx + ct * a - st * b, cy + st * a + ct * b);
-                    A.left_rec[(size_t)i * 98 + sd * 49 + (a + 3) * 7 + (b + 3)] = v;
-                    sum += (double)v;
-                }
-            A.mean_l[(size_t)sd * A.nL + i] = sum / 49; // :1183-1190
+                for (int b = 0; b < 7; ++b)
+                    t += (double)v[b];
+                sum = __shfl(t, gbase | r); // the running sum after row r
+            }
+            if (live && row == 0)
+                A.mean_l[(size_t)sd * A.nL + i] = sum / 49; // :1183-1190
         }
-        A.sc[i] = st;
-        A.sc[A.nL + i] = ct;
+        if (live && row == 0)
+        {
+            A.sc[i] = st;
+            A.sc[A.nL + i] = ct;
+        }
     }
 }
 
@@ -769,46 +793,68 @@ __device__ inline void ldlt2_solve(double h00, double h10, double h11, double b0
     x1 = swap ? y0 : y1;
 }
 
+// (eight lanes per item, as gn_left_kernel: the keyframe-side samples leave as one contiguous run per item)
 __global__ __launch_bounds__(256) void gn2_init_kernel(Gn2Args A)
 {
     if (blockIdx.x == 0 && threadIdx.x == 0)
         A.counts[0] = (int32_t)A.n;
     const int h = A.h, w = A.w;
-    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < A.n; k += (int64_t)gridDim.x * blockDim.x)
+    const int lane = threadIdx.x & 63, row = lane & 7, gbase = lane & ~7;
+    const int64_t groups_per_block = blockDim.x >> 3;
+    for (int64_t base = (int64_t)blockIdx.x * groups_per_block; base < A.n; base += (int64_t)gridDim.x * groups_per_block)
     {
-        const ebvo_edge ke = A.kf[k];
-        const bool second = k >= A.n_first;
+        const int64_t k = base + (threadIdx.x >> 3);
+        const bool live = k < A.n; // uniform in the group
+        const int64_t kk = live ? k : 0;
+        const ebvo_edge ke = A.kf[kk];
+        const bool second = kk >= A.n_first;
         const uint8_t *__restrict__ imgK = second ? A.imgK2 : A.imgK;
         double st, ct, stc, ctc;
         ebvo_sincos(ke.theta, &st, &ct);
-        ebvo_sincos(A.cf[k].theta, &stc, &ctc);
+        ebvo_sincos(A.cf[kk].theta, &stc, &ctc);
         const double nx = -st, ny = ct, side = (7 / 2.0) + 1.0;
+        const int i = min(row, 6) - 3; // this lane's patch row (lane 7 repeats row 6 and writes nothing)
 #pragma unroll 1
         for (int sd = 0; sd < 2; ++sd)
         {
             const double cx = sd ? ke.x - nx * side : ke.x + nx * side, cy = sd ? ke.y - ny * side : ke.y + ny * side;
+            float v[7];
+#pragma unroll
+            for (int j = -3; j <= 3; ++j)
+                v[j + 3] = sample_u8(imgK, w, w, h, cx + ct * i - st * j, cy + st * i + ct * j);
+            if (live && row < 7)
+            {
+                float *dst = A.lrec + (size_t)k * 98 + sd * 49 + row * 7; // read back by every iteration
+#pragma unroll
+                for (int j = 0; j < 7; ++j)
+                    dst[j] = v[j];
+            }
             double sum = 0;
 #pragma unroll 1
-            for (int i = -3; i <= 3; ++i)
+            for (int r = 0; r < 7; ++r)
+            {
+                double t = sum;
 #pragma unroll
-                for (int j = -3; j <= 3; ++j)
-                {
-                    const float v = sample_u8(imgK, w, w, h, cx + ct * i - st * j, cy + st * i + ct * j);
-                    A.lrec[(size_t)k * 98 + sd * 49 + (i + 3) * 7 + (j + 3)] = v; // read back by every iteration
-                    sum += (double)v;
-                }
-            A.mean_l[(size_t)sd * A.n + k] = sum / 49;
+                for (int j = 0; j < 7; ++j)
+                    t += (double)v[j];
+                sum = __shfl(t, gbase | r);
+            }
+            if (live && row == 0)
+                A.mean_l[(size_t)sd * A.n + k] = sum / 49;
         }
-        A.sc[k] = st;
-        A.sc[A.n + k] = ct;
-        A.sc[2 * A.n + k] = stc;
-        A.sc[3 * A.n + k] = ctc;
-        A.disp[2 * k] = A.init[2 * k];
-        A.disp[2 * k + 1] = A.init[2 * k + 1];
-        A.score[k] = __builtin_nan("");
-        A.valid[k] = 2;
-        A.iters[k] = 0;
-        A.list[0][k] = (int32_t)k;
+        if (live && row == 0)
+        {
+            A.sc[k] = st;
+            A.sc[A.n + k] = ct;
+            A.sc[2 * A.n + k] = stc;
+            A.sc[3 * A.n + k] = ctc;
+            A.disp[2 * k] = A.init[2 * k];
+            A.disp[2 * k + 1] = A.init[2 * k + 1];
+            A.score[k] = __builtin_nan("");
+            A.valid[k] = 2;
+            A.iters[k] = 0;
+            A.list[0][k] = (int32_t)k;
+        }
     }
 }
 
@@ -1214,7 +1260,7 @@ int refine_gn_stereo_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_imgL, cons
         hipLaunchKernelGGL(gn_pack_kernel, pg, dim3(256), 0, s.stream, d_imgL, h, w, w, pix4L, (uint4 *)nullptr);
         hipLaunchKernelGGL(gn_pack_kernel, pg, dim3(256), 0, s.stream, d_imgR, h, w, w, (uint32_t *)nullptr, recR);
     }
-    hipLaunchKernelGGL(gn_left_kernel, dim3((unsigned)((nL + 255) / 256 < 2048 ? (nL + 255) / 256 : 2048)), dim3(256), 0,
+    hipLaunchKernelGGL(gn_left_kernel, dim3((unsigned)((nL + 31) / 32 < 8192 ? (nL + 31) / 32 : 8192)), dim3(256), 0,
                        s.stream, A);
     hipLaunchKernelGGL(gn_init_kernel, dim3(blocks), dim3(256), 0, s.stream, A);
     const bool no_rows = getenv("EBVO_GN_NO_ROWS") != nullptr;
@@ -1297,7 +1343,7 @@ int refine_gn_temporal_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_imgK, co
         if (two)
             hipLaunchKernelGGL(gn_pack_kernel, pg, dim3(256), 0, s.stream, d_imgC2, h, w, w, (uint32_t *)nullptr, rec + npx);
     }
-    hipLaunchKernelGGL(gn2_init_kernel, dim3(blocks), dim3(256), 0, s.stream, A);
+    hipLaunchKernelGGL(gn2_init_kernel, dim3((unsigned)((n + 31) / 32 < 8192 ? (n + 31) / 32 : 8192)), dim3(256), 0, s.stream, A);
     const bool rows = n <= GN_ROWS_MAX_PAIRS && !getenv("EBVO_GN_NO_ROWS"); // small batch: eight lanes per item
     const unsigned rblocks = (unsigned)((n + 31) / 32 < 8192 ? (n + 31) / 32 : 8192);
     for (int it = 0; it < max_iter; ++it)
