@@ -33,8 +33,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-from edge_based_visual_odometry_amd import sharding, synth  # noqa: E402
-from edge_based_visual_odometry_amd.api import Context  # noqa: E402
+from edge_based_visual_odometry_amd import sharding, synth  # noqa: E402  (numpy only: no GPU library is loaded here)
+
+
+def Context(*a, **k):
+    """edge_based_visual_odometry_amd.api.Context, imported on first use: the launcher branch of main() must start its
+    ranks before this process has loaded the HIP library."""
+    from edge_based_visual_odometry_amd.api import Context as C_
+    return C_(*a, **k)
 
 TOED_FLOPS_PER_PX = 37044            # SURVEY.md 8(d): 1,372 taps x 9 responses x 3 flops, as written in the reference
 HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: HBM3E spec
@@ -265,6 +271,11 @@ def frame_loop(ctx, params, pool, nslots, steps, upload, fetch):
             out = ctx.stereo_fetch(cnt, slot=k)
             nbytes += sum(v.nbytes for v in out.values() if v is not None)
             launch(k)
+        elif fetch and nslots < 2:
+            # one slot: nothing to overlap the copy with, and the slot cannot be waited on again before it is resubmitted
+            ctx.stereo_fetch_begin(slot=k, what=fetch)
+            consume(k)
+            launch(k)
         elif fetch:
             ctx.stereo_fetch_begin(slot=k, what=fetch)
             if pending is not None:
@@ -450,7 +461,9 @@ def sequence_bench(args, wl, H, W, F, device, rank, world, dist, reduce_device):
         totals["quads"] += tc["n_candidates"]
         totals["kept"] += tc["n_kept"]
     barrier()
-    dt = sharding.max_over_ranks(time.perf_counter() - t0, dist, reduce_device)
+    dt = time.perf_counter() - t0
+    per_rank = sharding.gather_over_ranks(args.steps / dt, dist, reduce_device)
+    dt = sharding.max_over_ranks(dt, dist, reduce_device)
     prof = None
     if rank == 0:
         ctx.profile_reset()
@@ -482,6 +495,7 @@ def sequence_bench(args, wl, H, W, F, device, rank, world, dist, reduce_device):
             "value": sharding.job_throughput(world, args.steps, dt), "unit": "stereo frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "per_rank_frames_per_s": per_rank,
             "config": {"workload": wl["label"], "shape": f"{W}x{H}", "toed_mode": args.toed_mode,
                        "edges_left": c.n_left, "edges_right": c.n_right, "candidate_pairs": c.n_pairs, "ncc_matches": c.n_matches,
                        "final_stereo_mates": fc["n_final"], "temporal_candidate_quads": tc["n_candidates"],
@@ -507,7 +521,9 @@ def sequence_bench(args, wl, H, W, F, device, rank, world, dist, reduce_device):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=1,
+                    help="ranks = GPUs of this node, one sequence each.  N > 1 with no WORLD_SIZE in the environment: bench.py "
+                         "starts the N ranks itself; under torch.distributed.run it must equal WORLD_SIZE")
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="kitti", choices=sorted(WORKLOADS),
@@ -518,7 +534,11 @@ def main():
     ap.add_argument("--toed-mode", default="hybrid", choices=["strict", "hybrid"],
                     help="strict: direct-form convolution at every pixel; hybrid: separable screen + exact "
                          "re-evaluation of the candidates (bit-identical edges, ~3x less work)")
-    ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for the barrier / max (nccl = RCCL)")
+    ap.add_argument("--dist-backend", default="auto",
+                    help="torch.distributed backend for the barrier / max: nccl (= RCCL), gloo, or auto = nccl when every rank "
+                         "has its own GPU, gloo when N ranks rehearse on fewer GPUs")
+    ap.add_argument("--selftest-launch", action="store_true",
+                    help="run only the multi-rank plumbing (launcher, rendezvous, barrier, reductions) and stop before any GPU call")
     ap.add_argument("--streams", type=int, default=6,
                     help="stereo pairs kept in flight per GPU (slots; one HIP stream each up to 3, from 4 on their kernels are "
                          "dealt to min(4, slots - 1) streams of the context)")
@@ -527,20 +547,48 @@ def main():
                          "many host threads, one context each -- extra keys of the JSON line, never `value`")
     args = ap.parse_args()
 
+    # ---- N > 1 without a launcher: this process becomes the launcher (before it has touched the GPU or loaded the HIP
+    # library) -- N fresh child processes, one per GPU, each re-entering main() with RANK / WORLD_SIZE set ---------------
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(sharding.launch_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
+
     info = sharding.rank_info()
     rank, local_rank, world = info.rank, info.local_rank, info.world
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the launcher must start exactly --gpus ranks", file=sys.stderr)
+        sys.exit(2)
     dist = None
     import torch
-    ndev = torch.cuda.device_count()
+    ndev = torch.cuda.device_count()             # counting devices does not initialise the GPU
     device = local_rank % max(1, ndev)           # one rank per GPU on a full node; wraps only when rehearsing N > #GPUs
+    backend = args.dist_backend
+    if backend == "auto":                        # RCCL needs one device per rank; a rehearsal of N ranks on fewer GPUs uses gloo
+        backend = "nccl" if 0 < world <= ndev else "gloo"
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(device)
-        if args.dist_backend == "nccl":
+        if backend == "nccl":
+            torch.cuda.set_device(device)
             dist.init_process_group("nccl", device_id=torch.device("cuda", device))
         else:
-            dist.init_process_group(args.dist_backend)
-    reduce_device = f"cuda:{device}" if args.dist_backend == "nccl" else "cpu"
+            dist.init_process_group(backend)
+    reduce_device = f"cuda:{device}" if backend == "nccl" else "cpu"
+
+    if args.selftest_launch:
+        # the N > 1 plumbing only (launcher, rendezvous, barrier, MAX / gather over ranks), no GPU call: what
+        # tests/test_bench_launch.py drives with two gloo ranks on a machine without a GPU
+        if dist is not None:
+            dist.barrier()
+        mine = 0.25 * (rank + 1)
+        per_rank = sharding.gather_over_ranks(mine, dist, reduce_device)
+        dt = sharding.max_over_ranks(mine, dist, reduce_device)
+        if rank == 0:
+            print(json.dumps({"selftest_launch": True, "n_gpus": world, "backend": backend if world > 1 else None,
+                              "per_rank_seconds": per_rank, "max_seconds": dt,
+                              "value": sharding.job_throughput(world, args.steps, dt),
+                              "sequences": [sharding.rank_workload(r) for r in range(world)]}))
+        if dist is not None:
+            dist.destroy_process_group()
+        return
 
     wl = WORKLOADS[args.workload]
     H, W = synth.SHAPES[wl["cfg"]]
@@ -595,6 +643,7 @@ def main():
             submitted += 1
     barrier()
     dt = time.perf_counter() - t0
+    per_rank = sharding.gather_over_ranks(args.steps / dt, dist, reduce_device)
     dt = sharding.max_over_ranks(dt, dist, reduce_device)
 
     # ---- what the timed region produced (every rank checks its own sequence) ---------------------------------
@@ -758,6 +807,7 @@ def main():
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
+            "per_rank_pairs_per_s": per_rank,
             "config": {"workload": wl["label"], "shape": f"{W}x{H}",
                        "toed_mode": args.toed_mode,
                        "edges_left": counts.n_left, "edges_right": counts.n_right,

@@ -523,7 +523,8 @@ class Context:
     def debug_set(self, key: int, value: int):
         """Test hooks (ebvo_debug_set): 0 = attempts of the regrow loop, 1 = force N overflowed results, 2 = number of
         lanes (streams the submitted pairs are dealt to when more slots are in use; 0 = one stream per slot), 3 = the
-        profiler instruments one stage alone (index in profile_get()'s order + 1; 0 = every stage)."""
+        profiler instruments one stage alone (index in profile_get()'s order + 1; 0 = every stage), 4 / 5 = launch layout
+        of the refinements (1 = one thread per pair always / threshold of the eight-lanes layout)."""
         self._check(self.lib.ebvo_debug_set(self._ctx, key, value), "ebvo_debug_set")
 
     # -- profiling -----------------------------------------------------------------------------

@@ -654,15 +654,26 @@ static int epi_candidates_impl(ebvo_ctx *ctx, const ebvo_edge *L, int nL, const 
     if ((rc = match_candidates_fill_enqueue(ctx, s, dL, nL, nullptr, dR, nR, nullptr, 0, (const double *)s.lines.p,
                                             epi_thr, max_disp, orient_thr_deg, stage_mask)))
         return rc;
-    EBVO_HIP(ctx, hipMemcpyAsync(col_idx, s.col_idx.p, sizeof(int32_t) * (size_t)np, hipMemcpyDeviceToHost, s.stream));
-    if (orient_ok)
+    // from here on copies into caller-owned memory are in flight: whatever fails, the stream is drained before returning
+    rc = [&]() -> int {
+        int r;
+        if (orient_ok)
+        {
+            // the third reference stage (apply_orientation_filter, src/Stereo_Matches.cpp:863-915) as one flag per listed pair
+            if ((r = ebvo_grow(ctx, s, s.keep, (size_t)np)) ||
+                (r = match_orient_flags_enqueue(ctx, s, dL, nL, dR, (const int32_t *)s.row_ptr.p, (const int32_t *)s.col_idx.p,
+                                                np, orient_thr_deg, (uint8_t *)s.keep.p)))
+                return r;
+        }
+        EBVO_HIP(ctx, hipMemcpyAsync(col_idx, s.col_idx.p, sizeof(int32_t) * (size_t)np, hipMemcpyDeviceToHost, s.stream));
+        if (orient_ok)
+            EBVO_HIP(ctx, hipMemcpyAsync(orient_ok, s.keep.p, (size_t)np, hipMemcpyDeviceToHost, s.stream));
+        return EBVO_OK;
+    }();
+    if (rc)
     {
-        // the third reference stage (apply_orientation_filter, src/Stereo_Matches.cpp:863-915) as one flag per listed pair
-        if ((rc = ebvo_grow(ctx, s, s.keep, (size_t)np)) ||
-            (rc = match_orient_flags_enqueue(ctx, s, dL, nL, dR, (const int32_t *)s.row_ptr.p, (const int32_t *)s.col_idx.p, np,
-                                             orient_thr_deg, (uint8_t *)s.keep.p)))
-            return rc;
-        EBVO_HIP(ctx, hipMemcpyAsync(orient_ok, s.keep.p, (size_t)np, hipMemcpyDeviceToHost, s.stream));
+        (void)hipStreamSynchronize(s.stream);
+        return rc;
     }
     EBVO_HIP(ctx, hipStreamSynchronize(s.stream));
     s.cap_pairs = 0; // the pipeline re-establishes its own capacity
@@ -2543,6 +2554,10 @@ extern "C" int ebvo_debug_set(ebvo_ctx *ctx, int key, int value)
         ctx->lanes = value; // 0 = one stream per slot whatever their number
     else if (key == 3)
         ctx->prof_only = value - 1; // 0 = every stage; id + 1 = that stage alone: no event markers between the other kernels
+    else if (key == 4 && value <= 1)
+        ctx->gn_no_rows = value; // refinement launch layout (same bits either way, tests/test_gpu_refine.py)
+    else if (key == 5)
+        ctx->gn_rows_below = value;
     else
         return EBVO_ERR_ARG;
     return EBVO_OK;

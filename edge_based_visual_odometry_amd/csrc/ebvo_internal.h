@@ -185,6 +185,8 @@ struct ebvo_ctx
     uint64_t submit_seq = 0;
     std::vector<hipStream_t> lane_streams; // created on first use, owned by the context
     hipStream_t copy_stream = nullptr;     // result copies of ebvo_stereo_fetch_begin (all slots), created on first use
+    int gn_no_rows = 0;        // developer key (ebvo_debug_set 4): 1 = the refinements never use the eight-lanes-per-pair layout
+    int gn_rows_below = 0;     // developer key (ebvo_debug_set 5): active-pair count below which an iteration uses it, 0 = default
     int wait_attempts = 0;     // test hook (ebvo_debug_set): attempts of ebvo_stereo_wait's regrow loop, 0 = default (4)
     int force_overflow = 0;    // test hook: treat the next N results as overflowed
 

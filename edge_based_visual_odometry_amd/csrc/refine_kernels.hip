@@ -1263,9 +1263,8 @@ int refine_gn_stereo_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_imgL, cons
     hipLaunchKernelGGL(gn_left_kernel, dim3((unsigned)((nL + 31) / 32 < 8192 ? (nL + 31) / 32 : 8192)), dim3(256), 0,
                        s.stream, A);
     hipLaunchKernelGGL(gn_init_kernel, dim3(blocks), dim3(256), 0, s.stream, A);
-    const bool no_rows = getenv("EBVO_GN_NO_ROWS") != nullptr;
-    const char *rows_env = getenv("EBVO_GN_ROWS_BELOW"); // developer knob (tools/gpu_stereo_refine_time.py sweeps it)
-    A.rows_below = rows_env ? atoi(rows_env) : GN_ROWS_BELOW;
+    const bool no_rows = ctx->gn_no_rows != 0;                                  // developer keys (ebvo_debug_set 4 / 5)
+    A.rows_below = ctx->gn_rows_below > 0 ? ctx->gn_rows_below : GN_ROWS_BELOW; // tools/gpu_gn_sweep.sh sweeps it
     for (int it = 0; it < max_iter; ++it)
     {
         const unsigned rblocks = (unsigned)((n_pairs + 31) / 32 < 8192 ? (n_pairs + 31) / 32 : 8192);
@@ -1344,7 +1343,7 @@ int refine_gn_temporal_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_imgK, co
             hipLaunchKernelGGL(gn_pack_kernel, pg, dim3(256), 0, s.stream, d_imgC2, h, w, w, (uint32_t *)nullptr, rec + npx);
     }
     hipLaunchKernelGGL(gn2_init_kernel, dim3((unsigned)((n + 31) / 32 < 8192 ? (n + 31) / 32 : 8192)), dim3(256), 0, s.stream, A);
-    const bool rows = n <= GN_ROWS_MAX_PAIRS && !getenv("EBVO_GN_NO_ROWS"); // small batch: eight lanes per item
+    const bool rows = n <= GN_ROWS_MAX_PAIRS && !ctx->gn_no_rows; // small batch: eight lanes per item
     const unsigned rblocks = (unsigned)((n + 31) / 32 < 8192 ? (n + 31) / 32 : 8192);
     for (int it = 0; it < max_iter; ++it)
         if (rows)

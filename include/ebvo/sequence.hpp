@@ -264,6 +264,7 @@ class BatchedStereoFeeder
         status_ = ebvo_stereo_set_slots(ctx_, slots_);
     }
     int status() const { return status_; }
+    size_t skipped() const { return skipped_; } // pairs whose two images differ in size (reported, not processed)
 
     // runs the whole sequence (or max_frames of it); returns the number of pairs processed
     size_t run(StereoSequence &seq, const ebvo_stereo_params &params, const Callback &done, size_t max_frames = (size_t)-1)
@@ -309,8 +310,20 @@ class BatchedStereoFeeder
         size_t submitted = 0, completed = 0;
         auto launch = [&](int k) {
             StereoImages f;
-            if (!take(f))
-                return false;
+            // left and right must share one size (the TOED object is built once from the left image); a pair
+            // that does not is reported and skipped, as the reference does for frames that fail to load
+            for (;;)
+            {
+                if (!take(f))
+                    return false;
+                if (f.left.width == f.right.width && f.left.height == f.right.height &&
+                    f.left.pixels.size() == (size_t)f.left.width * f.left.height &&
+                    f.right.pixels.size() == (size_t)f.right.width * f.right.height)
+                    break;
+                std::fprintf(stderr, "[ebvo] pair %zu skipped: left %dx%d, right %dx%d\n", f.index, f.left.width, f.left.height,
+                             f.right.width, f.right.height);
+                ++skipped_;
+            }
             int rc = ebvo_stereo_upload_slot(ctx_, k, f.left.pixels.data(), f.right.pixels.data(), f.left.height, f.left.width,
                                              f.left.width, f.right.width);
             if (rc == EBVO_OK)
@@ -359,6 +372,7 @@ class BatchedStereoFeeder
   private:
     ebvo_ctx *ctx_;
     int slots_, ahead_, status_ = EBVO_OK;
+    size_t skipped_ = 0;
 };
 
 } // namespace ebvo

@@ -544,7 +544,9 @@ int ebvo_profile_get(ebvo_ctx *ctx, ebvo_kernel_time *out /* EBVO_MAX_KERNELS */
  *        min(lanes, slots - 1) streams of the context instead of one stream per slot (default 4, the measured optimum
  *        on MI355X; 0 = one stream per slot whatever their number).
  * key 3: the profiler instruments ONE stage (value = its index in ebvo_profile_get's order + 1; 0 = every stage): no
- *        event markers between the other kernels, so the stage is timed as it runs in the unprofiled pipeline. */
+ *        event markers between the other kernels, so the stage is timed as it runs in the unprofiled pipeline.
+ * key 4: 1 = the photometric refinements never use their eight-lanes-per-pair launch layout (0 = default: chosen per
+ *        iteration from the number of active pairs); key 5: that threshold (0 = built-in).  Same bits either way. */
 int ebvo_debug_set(ebvo_ctx *ctx, int key, int value);
 
 /* Raw FP64 vector-ALU microbenchmark (mul + add, no FMA) used to anchor the compute roofline:

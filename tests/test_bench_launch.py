@@ -1,0 +1,98 @@
+"""bench.py --gpus N is its own launcher: N fresh ranks started before any GPU call, one sequence each, the job's one
+JSON line from rank 0 (BASELINE.json configs[4]; the split follows src/Pipeline.cpp:133-138: the keyframe is fixed at
+frame 0, so sequences are independent).  The CPU tests drive bench.py's real entry with --selftest-launch (stops before the
+first GPU call); the GPU test runs the whole bench with two ranks sharing the one GPU of the box."""
+import json
+import os
+import subprocess
+import sys
+import time
+
+import pytest
+
+from edge_based_visual_odometry_amd import sharding
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _clean_env():
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return env
+
+
+def _json_lines(text):
+    return [json.loads(l) for l in text.splitlines() if l.startswith("{")]
+
+
+def test_bench_gpus_2_starts_two_ranks_by_itself():
+    out = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--selftest-launch", "--dist-backend", "gloo", "--steps", "10"],
+                         env=_clean_env(), capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = _json_lines(out.stdout)
+    assert len(lines) == 1                                   # rank 0 prints the job's ONE line
+    r = lines[0]
+    assert r["n_gpus"] == 2 and r["backend"] == "gloo"
+    assert r["per_rank_seconds"] == [0.25, 0.5] and r["max_seconds"] == 0.5     # MAX over ranks
+    assert r["value"] == 2 * 10 / 0.5                        # whole-job throughput: every rank's steps over the max
+    assert r["sequences"][0] != r["sequences"][1]            # one sequence per rank
+
+
+def test_bench_under_an_external_launcher_uses_its_ranks():
+    """what the driver does: torch.distributed.run sets RANK / WORLD_SIZE; bench.py must not launch again"""
+    env = _clean_env()
+    port = sharding.free_port()
+    procs = []
+    for r in range(2):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, BENCH, "--gpus", "2", "--selftest-launch", "--dist-backend", "gloo"],
+                                      env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert [p.returncode for p in procs] == [0, 0], outs
+    assert _json_lines(outs[0][0])[0]["n_gpus"] == 2 and _json_lines(outs[1][0]) == []
+
+
+def test_gpus_must_match_world_size():
+    env = dict(_clean_env(), RANK="0", LOCAL_RANK="0", WORLD_SIZE="3", MASTER_ADDR="127.0.0.1", MASTER_PORT="1")
+    out = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--selftest-launch"], env=env, capture_output=True, text=True,
+                         timeout=120)
+    assert out.returncode == 2 and "WORLD_SIZE=3" in out.stderr
+
+
+def test_a_failing_rank_fails_the_job_and_ends_the_others(tmp_path):
+    prog = tmp_path / "rank.py"
+    prog.write_text("import os, sys, time\n"
+                    "assert os.environ['WORLD_SIZE'] == '3' and os.environ['MASTER_ADDR'] == '127.0.0.1'\n"
+                    "assert os.environ['LOCAL_RANK'] == os.environ['RANK']\n"
+                    "if os.environ['RANK'] == '1':\n    sys.exit(7)\n"
+                    "time.sleep(120)\n")
+    t0 = time.monotonic()
+    rc = sharding.launch_ranks(3, [sys.executable, str(prog)], env=_clean_env())
+    assert rc == 7 and time.monotonic() - t0 < 60            # the sleeping ranks were ended, not waited for
+
+
+def test_all_ranks_ok_returns_zero(tmp_path):
+    prog = tmp_path / "ok.py"
+    prog.write_text("import os\nopen(os.environ['OUT'] + os.environ['RANK'], 'w').write(os.environ['MASTER_PORT'])\n")
+    assert sharding.launch_ranks(4, [sys.executable, str(prog)], env=dict(_clean_env(), OUT=str(tmp_path / "r"))) == 0
+    ports = {(tmp_path / f"r{r}").read_text() for r in range(4)}
+    assert len(ports) == 1                                   # one rendezvous for the job
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_on_one_gpu_runs_the_hot_path_on_both_ranks():
+    """Two ranks share the box's one GPU (gloo for the barrier: RCCL wants a device per rank); each owns its own sequence,
+    rank 0 checks its pair's known answers and prints the job's line."""
+    out = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "5", "--warmup", "1", "--streams", "2",
+                          "--no-cpu-baseline", "--no-transfer-legs"], env=_clean_env(), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = _json_lines(out.stdout)
+    assert len(lines) == 1
+    r = lines[0]
+    assert r["n_gpus"] == 2 and r["steps"] == 5 and r["scaling"] == "weak"
+    assert len(r["per_rank_pairs_per_s"]) == 2 and all(v > 0 for v in r["per_rank_pairs_per_s"])
+    assert r["verified"] is True
+    assert abs(r["value"] - 2 * 5 / (r["ms_per_step"] * 5e-3)) < 1e-6 * r["value"]
+    assert r["value"] <= sum(r["per_rank_pairs_per_s"]) * (1 + 1e-9)

@@ -23,14 +23,12 @@ def _compare(out, ref):
 
 
 @pytest.fixture(params=["rows", "threads"])
-def gn_layout(request, monkeypatch):
+def gn_layout(request, ctx):
     """Both launch layouts of the Gauss-Newton iterations: eight lanes per pair (what the library picks for up to 131,072
-    pairs) and one thread per pair (EBVO_GN_NO_ROWS, what larger problems run).  Same bits either way."""
-    if request.param == "threads":
-        monkeypatch.setenv("EBVO_GN_NO_ROWS", "1")
-    else:
-        monkeypatch.delenv("EBVO_GN_NO_ROWS", raising=False)
-    return request.param
+    pairs) and one thread per pair (developer key 4 of ebvo_debug_set, what larger problems run).  Same bits either way."""
+    ctx.debug_set(4, 1 if request.param == "threads" else 0)
+    yield request.param
+    ctx.debug_set(4, 0)
 
 
 @pytest.mark.parametrize("shape", [(48, 64), (96, 160), (120, 200)])

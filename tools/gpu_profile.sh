@@ -13,13 +13,16 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-COMMON="--no-cpu-baseline --no-verify --toed-mode $MODE --streams 1 $*"
+# --no-transfer-legs: the trace covers the resident loop only (the boundary leg would start g++ and a GPU child under the
+# profiler's preload)
+COMMON="--no-cpu-baseline --no-verify --no-transfer-legs --toed-mode $MODE --streams 1 $*"
+FAILED=0
 pass() { # name, bench steps, rocprofv3 options ...
     local name=$1 steps=$2
     shift 2
     echo "== $name: rocprofv3 $* -- python3 bench.py --steps $steps --warmup 2 $COMMON" | tee -a "$OUT/log.txt"
     rocprofv3 "$@" -d "$OUT/$name" -o out -- python3 "$ROOT/bench.py" --steps "$steps" --warmup 2 $COMMON >> "$OUT/log.txt" 2>&1 ||
-        echo "   FAILED: $name" | tee -a "$OUT/log.txt"
+        { echo "   FAILED: $name" | tee -a "$OUT/log.txt"; FAILED=1; }
 }
 pass trace_$MODE 40 --kernel-trace --stats
 pass pmc_fetch_$MODE 8 --kernel-trace --pmc FETCH_SIZE
@@ -29,3 +32,4 @@ pass pmc_sq2_$MODE 8 --kernel-trace --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU
 pass pmc_sq3_$MODE 8 --kernel-trace --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32 SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS
 pass pmc_grbm_$MODE 8 --kernel-trace --pmc GRBM_GUI_ACTIVE GRBM_TA_BUSY
 ls "$OUT"
+if [ $FAILED -ne 0 ]; then echo "gpu_profile.sh: at least one pass failed (see $OUT/log.txt)"; tail -30 "$OUT/log.txt"; exit 1; fi

@@ -26,7 +26,10 @@ os.makedirs(dst, exist_ok=True)
 
 
 def db(name):
-    f = glob.glob(os.path.join(src, name, "**", "*_results.db"), recursive=True)
+    f = sorted(glob.glob(os.path.join(src, name, "**", "*_results.db"), recursive=True))
+    if len(f) > 1:  # a child process of the profiled program wrote its own database: which one is bench.py's is a guess
+        sys.exit(f"rocprof_summary: {len(f)} databases under {os.path.join(src, name)}: {f}; profile a run without child "
+                 "GPU processes (bench.py --no-transfer-legs)")
     return sqlite3.connect(f[0]) if f else None
 
 
