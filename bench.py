@@ -407,6 +407,42 @@ def threaded_sequence(T, args, H, W, F, device, frames, calib, cal, steps):
     return steps / dt
 
 
+def verify_sequence_frame(ctx, frames, k, params, calib, cal, H, W):
+    """After the timed region of the sequence workload: frame k once more, its results fetched and compared with the CPU oracle
+    -- both TOED edge lists (on the undistorted images), every candidate quad against the keyframe, both NCC maxima and the
+    keep flag of every quad, and every final quad of the whole temporal chain (tests/oracle_chain.py: temporal_reference).
+    Returns the list of differences (empty = verified)."""
+    from tests import oracle as orc
+    from tests import oracle_chain
+
+    def triple(imgs):
+        if "dist" not in cal:
+            return imgs[0], imgs[0], imgs[1]
+        return imgs[0], orc.undistort(imgs[0], cal["K"], cal["dist"]), orc.undistort(imgs[1], cal["K_right"], cal["dist_right"])
+
+    def mates(slot):
+        ctx.stereo_submit(params, slot=slot)
+        c = ctx.stereo_wait(slot=slot)
+        out = ctx.stereo_fetch(c, slot=slot)
+        _, fin = ctx.stereo_finalize(calib, slot=slot, use_sift=True)
+        return out, out["left"][fin["left_index"]], fin["right"]
+
+    problems = []
+    _, kfL, kfR = mates(0)                          # the keyframe's mates (slot 0 still holds frame 0)
+    out, cfL, cfR = mates(k)
+    counts, q = ctx.temporal_match(slot=k, fetch=True, stages=1)
+    t0, tk = triple(frames[0]), triple(frames[k])
+    for side, img in (("left", tk[1]), ("right", tk[2])):
+        ref = orc.toed(img)["edges"]
+        got = out[side]
+        if len(ref) != len(got) or any((ref[f].view(np.uint64) != got[f].view(np.uint64)).any() for f in ("x", "y", "theta")):
+            problems.append(f"frame {k}: {side} edge list differs from the oracle")
+    ref = oracle_chain.temporal_reference(kfL, kfR, cfL, cfR, t0, tk, W, H)
+    problems += [f"frame {k}: {p}" for p in oracle_chain.temporal_problems(counts, q, ref)]
+    return problems, dict(frame=k, n_kf=counts["n_kf"], n_cf=counts["n_cf"], candidate_quads=counts["n_candidates"],
+                          quads_kept=counts["n_kept"], final_quads=counts["n_final"])
+
+
 def sequence_bench(args, wl, H, W, F, device, rank, world, dist, reduce_device):
     """configs[2]: a sequence with a keyframe.  A step = one frame through the whole per-frame path; the frames are resident
     (one slot each), so the timed region holds no host-to-device image traffic, like the headline workload."""
@@ -513,7 +549,18 @@ def sequence_bench(args, wl, H, W, F, device, rank, world, dist, reduce_device):
                                         "filter (SIFT filter, Best-Nearly-Best on NCC and SIFT scores, photometric refinement "
                                         "of both cameras, edge clustering): %d final quads per frame" % tcf["n_final"],
         }
+        if not args.no_verify:
+            problems, what = verify_sequence_frame(ctx, frames, min(3, n_frames - 1), params, calib, cal, H, W)
+            result["verified"] = not problems
+            result["verified_what"] = dict(what, note="both edge lists, every candidate quad (row_ptr / col_idx), both NCC maxima "
+                                                      "and the keep flag of every quad, every final quad of the temporal chain: bit "
+                                                      "for bit against the CPU oracle (tests/oracle_chain.py)")
+            if problems:
+                result["verification_failures"] = problems
         print(json.dumps(result))
+        if result.get("verified") is False:
+            ctx.close()
+            sys.exit(3)
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()

@@ -214,3 +214,58 @@ def temporal_edge_pairs(kfL, kfR, cfL, cfR, kf_imgs, cf_imgs, rp, ci, sim_left, 
                 right=np.array(f_R, dtype=orc.EDGE_DTYPE) if f_R else np.zeros(0, orc.EDGE_DTYPE), ncc_left=simL[f_src],
                 sift_left=siftL[f_src], score_left=out["L"]["score"][f_src], score_right=out["R"]["score"][f_src],
                 valid=valid[f_src])
+
+
+def temporal_reference(kfL, kfR, cfL, cfR, kf_imgs, cf_imgs, w, h, chain=True, ncc_thr=0.8):
+    """One frame of Temporal_Matches::get_Temporal_Edge_Pairs_from_Quads on the oracle, from the stereo mates of the keyframe
+    and of the current frame (src/Temporal_Matches.cpp:168-218): grid + orientation candidates (:335-414), NCC on the
+    stored patches (:416-469), and with chain=True every later stage (temporal_edge_pairs above).
+    kf_imgs / cf_imgs = (RAW left, undistorted left, undistorted right): the left patches of a mate are sampled from the raw
+    left image (src/Stereo_Matches.cpp:562), the right ones from the undistorted right image (:1580-1582)."""
+    rp, ci = orc.temporal_candidates(kfL, kfR, cfL, cfR, w, h)
+    pkL, pkR = orc.edge_patches(kf_imgs[0], kfL), orc.edge_patches(kf_imgs[2], kfR)
+    pcL, pcR = orc.edge_patches(cf_imgs[0], cfL), orc.edge_patches(cf_imgs[2], cfR)
+    rows = rows_of(rp)
+    sl, sr, keep = orc.ncc_quads(pkL[rows], pkR[rows], pcL[ci], pcR[ci], ncc_thr)
+    ref = dict(row_ptr=rp, col_idx=ci, sim_left=sl, sim_right=sr, keep=keep,
+               counts=dict(n_kf=len(kfL), n_cf=len(cfL), n_candidates=len(ci), n_kept=int(keep.sum())))
+    if chain:
+        ref["final"] = temporal_edge_pairs(kfL, kfR, cfL, cfR, kf_imgs[1:], cf_imgs[1:], rp, ci, sl, keep)
+        ref["counts"].update(ref["final"]["counts"])
+    return ref
+
+
+def _same(a, b):
+    a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+    if a.shape != b.shape:
+        return False
+    if a.dtype.kind == "f":
+        ua = a.view(np.uint64 if a.dtype == np.float64 else np.uint32)
+        ub = b.view(np.uint64 if b.dtype == np.float64 else np.uint32)
+        return bool(((ua == ub) | (np.isnan(a) & np.isnan(b))).all())
+    return bool((a == b).all())
+
+
+def _same_edges(a, b):
+    return len(a) == len(b) and all(_same(a[f].copy(), b[f].copy()) for f in ("x", "y", "theta")) and bool((a["index"] == b["index"]).all())
+
+
+def temporal_problems(counts, q, ref):
+    """What of ebvo_temporal_match's results (counts, the arrays of ebvo_temporal_fetch / _fetch_final as api.temporal_match
+    returns them) differs from temporal_reference's -- every quad, bit for bit.  Empty list = parity."""
+    bad = []
+    for k, v in ref["counts"].items():
+        if counts.get(k) != v:
+            bad.append(f"count {k}: {counts.get(k)} != oracle {v}")
+    for k in ("row_ptr", "col_idx", "sim_left", "sim_right", "keep"):
+        if not _same(q[k], ref[k]):
+            bad.append(f"{k} differs from the oracle")
+    if "final" in ref:
+        fin, rf = q["final"], ref["final"]
+        for k in ("row_ptr", "cf_index", "ncc_left", "sift_left", "score_left", "score_right", "valid"):
+            if not _same(fin[k], rf[k]):
+                bad.append(f"final.{k} differs from the oracle")
+        for k in ("left", "right"):
+            if not _same_edges(fin[k], rf[k]):
+                bad.append(f"final.{k} centres differ from the oracle")
+    return bad
