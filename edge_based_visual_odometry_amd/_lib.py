@@ -44,6 +44,7 @@ ABI_SYMBOLS = (
     "ebvo_stereo_fetch_refined", "ebvo_gn_refine_temporal", "ebvo_finalize_pairs", "ebvo_bnb_test", "ebvo_keep_best", "ebvo_epipolar_shift", "ebvo_cluster_rows", "ebvo_stereo_finalize", "ebvo_stereo_fetch_final",
     "ebvo_debug_set", "ebvo_stereo_fetch_begin", "ebvo_stereo_fetch_end",
     "ebvo_undistort", "ebvo_stereo_set_undistort", "ebvo_sift_descriptors", "ebvo_sift_min_distances",
+    "ebvo_toed_resident", "ebvo_epi_candidates_resident", "ebvo_ncc_pairs_resident",
     "ebvo_temporal_default_params", "ebvo_temporal_set_keyframe", "ebvo_temporal_match", "ebvo_temporal_fetch", "ebvo_temporal_fetch_final",
 )
 
@@ -99,6 +100,23 @@ class StereoView(C.Structure):
                 ("sims", C.c_void_p), ("best", C.c_void_p), ("keep", C.c_void_p), ("n_left", C.c_int32),
                 ("n_right", C.c_int32), ("n_pairs", C.c_int64)]
 
+
+class ToedView(C.Structure):
+    _fields_ = [("edges", C.c_void_p), ("all4", C.c_void_p), ("n_kept", C.c_int32), ("n_total", C.c_int32),
+                ("tag", C.c_uint64), ("t_conv", C.c_double), ("t_nms", C.c_double)]
+
+
+class CandidatesView(C.Structure):
+    _fields_ = [("row_ptr", C.c_void_p), ("col_idx", C.c_void_p), ("orient_ok", C.c_void_p), ("n_pairs", C.c_int64),
+                ("row_ptr_final", C.c_void_p), ("col_idx_final", C.c_void_p), ("n_final", C.c_int64)]
+
+
+class NccView(C.Structure):
+    _fields_ = [("left_patches", C.c_void_p), ("sims", C.c_void_p), ("best", C.c_void_p), ("keep", C.c_void_p),
+                ("n_left", C.c_int32), ("n_pairs", C.c_int64)]
+
+
+NCC_WANT_LEFT_PATCHES, NCC_WANT_SIMS = 1, 2
 
 FETCH_EDGES, FETCH_CSR, FETCH_BEST, FETCH_KEEP, FETCH_SIMS, FETCH_DEFAULT, FETCH_ALL = 1, 2, 4, 8, 16, 15, 31
 
@@ -157,6 +175,10 @@ def load_library() -> C.CDLL:
     lib.ebvo_finalize_default_params.argtypes = [C.c_void_p]
     lib.ebvo_stereo_default_params.argtypes = [C.POINTER(StereoParams)]
     lib.ebvo_stereo_upload.argtypes = [vp, vp, vp, i32, i32, ssz, ssz]
+    lib.ebvo_toed_resident.argtypes = [vp, i32, vp, i32, i32, ssz, i32, C.POINTER(ToedView)]
+    lib.ebvo_epi_candidates_resident.argtypes = [vp, C.c_uint64, C.c_uint64, vp, dbl, dbl, dbl, i32, i32, C.POINTER(CandidatesView)]
+    lib.ebvo_ncc_pairs_resident.argtypes = [vp, C.c_uint64, C.c_uint64, vp, vp, i32, i32, ssz, ssz, vp, vp, dbl, i32,
+                                            C.POINTER(NccView)]
     lib.ebvo_stereo_run.argtypes = [vp, C.POINTER(StereoParams), C.POINTER(StereoCounts)]
     lib.ebvo_stereo_fetch.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.ebvo_stereo_set_slots.argtypes = [vp, i32]

@@ -177,6 +177,58 @@ class Context:
         self._check(rc, "ebvo_ncc_pairs")
         return sims, best, keep, lp
 
+    # -- the resident stage-wise calls (what a stage produced stays on the device under a tag) ------------------------
+    @staticmethod
+    def _view(ptr_, count, dtype):
+        """copy of `count` items of `dtype` at a page-locked address the library returned"""
+        if not ptr_ or count == 0:
+            return np.zeros(0, dtype=dtype)
+        buf = (C.c_ubyte * (int(count) * np.dtype(dtype).itemsize)).from_address(ptr_)
+        return np.frombuffer(buf, dtype=dtype, count=int(count)).copy()
+
+    def toed_resident(self, img: np.ndarray, which: int, want_all: bool = False):
+        """ebvo_toed_resident: (edges, n_total, all4 or None, tag)"""
+        img = _u8(img)
+        h, w = img.shape
+        v = _lib.ToedView()
+        self._check(self.lib.ebvo_toed_resident(self._ctx, which, ptr(img), h, w, img.strides[0], int(want_all), C.byref(v)),
+                    "ebvo_toed_resident")
+        all4 = self._view(v.all4, v.n_total * 4, np.float64).reshape(-1, 4) if want_all else None
+        return self._view(v.edges, v.n_kept, EDGE_DTYPE), v.n_total, all4, int(v.tag)
+
+    def epi_candidates_resident(self, tag_left, tag_right, lines, epi_thr=0.5, max_disp=25.0, orient_thr_deg=10.0,
+                                stage_mask=_lib.STAGE_ALL, staged=False):
+        """ebvo_epi_candidates_resident: (row_ptr, col_idx[, orient_ok]); staged = the (epipolar AND disparity) list + flags"""
+        lines = np.ascontiguousarray(lines, dtype=np.float64).reshape(-1, 3)
+        v = _lib.CandidatesView()
+        mask = (_lib.STAGE_EPIPOLAR | _lib.STAGE_DISPARITY) if staged else stage_mask
+        self._check(self.lib.ebvo_epi_candidates_resident(self._ctx, tag_left, tag_right, ptr(lines), epi_thr, max_disp,
+                                                          orient_thr_deg, mask, int(staged), C.byref(v)),
+                    "ebvo_epi_candidates_resident")
+        rp = self._view(v.row_ptr, len(lines) + 1, np.int32)
+        ci = self._view(v.col_idx, v.n_pairs, np.int32)
+        if not staged:
+            return rp, ci
+        # the list the flags select (after apply_orientation_filter), formed on the device as well
+        self.last_final_lists = (self._view(v.row_ptr_final, len(lines) + 1, np.int32), self._view(v.col_idx_final, v.n_final, np.int32))
+        return rp, ci, self._view(v.orient_ok, v.n_pairs, np.uint8)
+
+    def ncc_pairs_resident(self, tag_left, tag_right, imgL, imgR, row_ptr, col_idx, thr=0.6, want_left_patches=False,
+                           want_sims=True):
+        """ebvo_ncc_pairs_resident: (sims or None, best, keep, left_patches or None)"""
+        imgL, imgR = _u8(imgL), _u8(imgR)
+        h, w = imgL.shape
+        row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int32)
+        col_idx = np.ascontiguousarray(col_idx, dtype=np.int32)
+        want = (_lib.NCC_WANT_LEFT_PATCHES if want_left_patches else 0) | (_lib.NCC_WANT_SIMS if want_sims else 0)
+        v = _lib.NccView()
+        self._check(self.lib.ebvo_ncc_pairs_resident(self._ctx, tag_left, tag_right, ptr(imgL), ptr(imgR), h, w, imgL.strides[0],
+                                                     imgR.strides[0], ptr(row_ptr), ptr(col_idx), thr, want, C.byref(v)),
+                    "ebvo_ncc_pairs_resident")
+        sims = self._view(v.sims, v.n_pairs * 4, np.float64).reshape(-1, 4) if want_sims else None
+        lp = self._view(v.left_patches, v.n_left * 98, np.float32).reshape(-1, 2, 49) if want_left_patches else None
+        return sims, self._view(v.best, v.n_pairs, np.float64), self._view(v.keep, v.n_pairs, np.uint8), lp
+
     # -- cv::undistort (src/Pipeline.cpp:78-79) ---------------------------------------------------------
     def undistort(self, img, K, dist):
         img = _u8(img)

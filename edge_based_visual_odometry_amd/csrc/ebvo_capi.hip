@@ -1,10 +1,12 @@
 // ebvo_capi.hip -- the C ABI of include/ebvo_hip.h: context and slots, host-buffer entry points,
 // the sync-free device-resident stereo pipeline, profiling.
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <utility>
 
 #include "ebvo_internal.h"
 
@@ -338,6 +340,9 @@ extern "C" void ebvo_ctx_destroy(ebvo_ctx *ctx)
     (void)hipFree(ctx->kf_imgL);
     (void)hipFree(ctx->kf_imgR);
     (void)hipFree(ctx->kf_Rf);
+    for (PinnedBuf *b : {&ctx->sw_toed[0], &ctx->sw_toed[1], &ctx->sw_cand, &ctx->sw_ncc, &ctx->sw_up})
+        if (b->p)
+            (void)hipHostFree(b->p);
     delete ctx;
 }
 
@@ -490,6 +495,7 @@ extern "C" int ebvo_toed(ebvo_ctx *ctx, const uint8_t *img, int h, int w, ptrdif
     if ((rc = check_size(ctx, h, w)) || (rc = host_slot(ctx, &sp)))
         return rc;
     Slot &s = *sp;
+    ctx->sw_tag[0] = ctx->sw_tag[1] = 0; // the edge lists of the resident stage-wise calls live in these workspaces
     if ((rc = upload_image(ctx, s, 0, img, h, w, stride)))
         return rc;
     float ms_c = 0, ms_n = 0;
@@ -530,6 +536,7 @@ extern "C" int ebvo_toed_pair(ebvo_ctx *ctx, const uint8_t *img_left, const uint
     if ((rc = check_size(ctx, h, w)) || (rc = host_slot(ctx, &sp)))
         return rc;
     Slot &s = *sp;
+    ctx->sw_tag[0] = ctx->sw_tag[1] = 0;
     if ((rc = upload_image(ctx, s, 0, img_left, h, w, stride_left)))
         return rc;
     if ((rc = upload_image(ctx, s, 1, img_right, h, w, stride_right)))
@@ -1008,6 +1015,8 @@ extern "C" int ebvo_stereo_upload_slot(ebvo_ctx *ctx, int slot, const uint8_t *i
     if (s.in_flight)
         return EBVO_ERR_STATE;
     s.have_pair = s.have_run = s.have_refined = s.have_final = false; // results of the previous pair are gone
+    if (slot == 0)
+        ctx->sw_tag[0] = ctx->sw_tag[1] = 0; // ... and so are the TOED results of the resident stage-wise calls
     s.tq_n = -1;
     s.tq_final.n = -1;
     s.sift_left_valid = false;
@@ -1253,6 +1262,449 @@ extern "C" int ebvo_stereo_run(ebvo_ctx *ctx, const ebvo_stereo_params *p, ebvo_
     if (rc)
         return rc;
     return ebvo_stereo_wait(ctx, 0, counts);
+}
+
+// ------------------------------------------------------------------------------------------
+// Resident stage-wise path.  main_VO calls the stages one after the other (src/Pipeline.cpp:24-29, :93-97,
+// src/Stereo_Matches.cpp:1374-1427) and hands every stage the vectors the previous one returned.  The calls below keep
+// what a stage produced on the device (slot 0's two image workspaces: edges, counts) under a TAG, take tags instead of
+// edge arrays, and return their results as pointers into page-locked memory of the context: nothing that the device
+// already holds is uploaded again, no result passes through pageable memory.  A tag dies when its workspace gets another
+// edge list: the next ebvo_toed_resident on it, ebvo_toed / ebvo_toed_pair, a pair uploaded into slot 0.  The other
+// host-buffer entry points (SIFT, Best-Nearly-Best, refinement, ... -- what get_Stereo_Edge_Pairs calls between the stages)
+// use slot 0's scratch buffers and image planes only and leave the tags valid.  A caller that cannot present valid tags
+// gets EBVO_ERR_STATE and uses the host-buffer calls.
+static int pinned_grow(ebvo_ctx *ctx, PinnedBuf &b, size_t bytes)
+{
+    if (bytes <= b.bytes)
+        return EBVO_OK;
+    if (b.p)
+        EBVO_HIP(ctx, hipHostFree(b.p));
+    b.p = nullptr;
+    b.bytes = 0;
+    const size_t want = bytes + bytes / 4 + 4096;
+    hipError_t e = hipHostMalloc(&b.p, want);
+    if (e != hipSuccess)
+    {
+        b.p = nullptr;
+        ebvo_fail_hip(ctx, e, "hipHostMalloc (stage-wise result arena)", __FILE__, __LINE__);
+        return e == hipErrorOutOfMemory ? EBVO_ERR_NOMEM : EBVO_ERR_HIP;
+    }
+    b.bytes = want;
+    return EBVO_OK;
+}
+
+static size_t align64(size_t v) { return (v + 63) & ~(size_t)63; }
+
+// Host-to-device copy of caller memory through the context's page-locked staging (`off` bytes into sw_up, which the caller
+// has sized).  The caller's buffers are ordinary pageable memory (a cv::Mat, a std::vector) that it frees or reuses right
+// after the call: copying out of them directly makes the runtime lock their pages for the transfer, and unmapping locked
+// pages later stalls the next submission (measured: ~1 ms on the first call of the next frame).
+static int upload_staged(ebvo_ctx *ctx, Slot &s, void *d_dst, const void *src, size_t bytes, size_t off)
+{
+    if (!bytes)
+        return EBVO_OK;
+    char *stage = (char *)ctx->sw_up.p + off;
+    memcpy(stage, src, bytes);
+    EBVO_HIP(ctx, hipMemcpyAsync(d_dst, stage, bytes, hipMemcpyHostToDevice, s.stream));
+    return EBVO_OK;
+}
+static int upload_image_staged(ebvo_ctx *ctx, Slot &s, int k, const uint8_t *img, int h, int w, ptrdiff_t stride, size_t off)
+{
+    if (stride < w)
+        return EBVO_ERR_ARG;
+    uint8_t *stage = (uint8_t *)ctx->sw_up.p + off;
+    if (stride == (ptrdiff_t)w)
+        memcpy(stage, img, (size_t)w * h);
+    else
+        for (int y = 0; y < h; ++y)
+            memcpy(stage + (size_t)y * w, img + (size_t)y * stride, (size_t)w);
+    EBVO_HIP(ctx, hipMemcpyAsync(s.im[k].img, stage, (size_t)w * h, hipMemcpyHostToDevice, s.stream));
+    return EBVO_OK;
+}
+
+extern "C" int ebvo_toed_resident(ebvo_ctx *ctx, int which, const uint8_t *img, int h, int w, ptrdiff_t stride,
+                                  int want_all4, ebvo_toed_view *view)
+{
+    if (!ctx || !img || !view || which < 0 || which > 1)
+        return EBVO_ERR_ARG;
+    memset(view, 0, sizeof *view);
+    EBVO_HIP(ctx, hipSetDevice(ctx->device));
+    int rc;
+    Slot *sp;
+    if ((rc = check_size(ctx, h, w)) || (rc = host_slot(ctx, &sp)))
+        return rc;
+    Slot &s = *sp;
+    if (ctx->sw_h != h || ctx->sw_w != w) // the two workspaces of a slot hold images of ONE size
+        ctx->sw_tag[0] = ctx->sw_tag[1] = 0;
+    ctx->sw_h = h;
+    ctx->sw_w = w;
+    ctx->sw_tag[which] = 0;
+    static const bool trace = getenv("EBVO_TRACE_STAGEWISE") != nullptr;
+    auto tnow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tt[6] = {0};
+    if (trace)
+        tt[0] = tnow();
+    if ((rc = pinned_grow(ctx, ctx->sw_up, (size_t)h * w + 64)) || (rc = upload_image_staged(ctx, s, which, img, h, w, stride, 0)))
+        return rc;
+    if (trace)
+    {
+        tt[1] = tnow();
+        (void)hipStreamSynchronize(s.stream);
+        tt[2] = tnow();
+    }
+    float ms_c = 0, ms_n = 0;
+    {
+        // TOED of ONE image, in place in workspace `which`: the enqueue walks workspaces 0 .. n - 1, so the two are swapped
+        // around it (plain pointer records; the kernels hold their own copies of the pointers)
+        struct Swap
+        {
+            Slot &s;
+            bool on;
+            Swap(Slot &s_, bool on_) : s(s_), on(on_)
+            {
+                if (on)
+                    std::swap(s.im[0], s.im[1]);
+            }
+            ~Swap()
+            {
+                if (on)
+                    std::swap(s.im[0], s.im[1]);
+            }
+        } swap_ws(s, which == 1);
+        if ((rc = toed_sync(ctx, s, 1, h, w, &ms_c, &ms_n)))
+            return rc;
+    }
+    if (trace)
+        tt[3] = tnow();
+    const ImageWS &ws = s.im[which];
+    view->n_kept = ws.n_kept;
+    view->n_total = ws.n_total;
+    view->t_conv = ms_c * 1e-3;
+    view->t_nms = ms_n * 1e-3;
+    if (ws.n_total > ctx->cap_edges)
+    {
+        ctx->last_error = "internal edge capacity exceeded";
+        return EBVO_ERR_CAPACITY;
+    }
+    const size_t eb = align64(sizeof(ebvo_edge) * (size_t)ws.n_kept), ab = want_all4 ? sizeof(double) * 4 * (size_t)ws.n_total : 0;
+    PinnedBuf &pb = ctx->sw_toed[which];
+    if ((rc = pinned_grow(ctx, pb, eb + ab + 64)))
+        return rc;
+    if (ws.n_kept)
+        EBVO_HIP(ctx, hipMemcpyAsync(pb.p, ws.edges, sizeof(ebvo_edge) * (size_t)ws.n_kept, hipMemcpyDeviceToHost, s.stream));
+    if (ab)
+        EBVO_HIP(ctx, hipMemcpyAsync((char *)pb.p + eb, ws.all4, ab, hipMemcpyDeviceToHost, s.stream));
+    EBVO_HIP(ctx, hipStreamSynchronize(s.stream));
+    if (trace)
+    {
+        tt[4] = tnow();
+        fprintf(stderr, "[ebvo] toed_resident(%d): upload call %.3f, upload done %.3f, toed + counts %.3f, result copies %.3f ms (device %.3f)\n",
+                which, (tt[1] - tt[0]) * 1e3, (tt[2] - tt[1]) * 1e3, (tt[3] - tt[2]) * 1e3, (tt[4] - tt[3]) * 1e3, ms_c + ms_n);
+    }
+    view->edges = (const ebvo_edge *)pb.p;
+    view->all4 = want_all4 ? (const double *)((char *)pb.p + eb) : nullptr;
+    view->tag = ctx->sw_tag[which] = ++ctx->sw_seq;
+    return EBVO_OK;
+}
+
+// which workspace holds `tag` (0 / 1), -1 if neither does
+static int resident_ws(const ebvo_ctx *ctx, uint64_t tag)
+{
+    if (tag != 0 && ctx->sw_tag[0] == tag)
+        return 0;
+    if (tag != 0 && ctx->sw_tag[1] == tag)
+        return 1;
+    return -1;
+}
+
+extern "C" int ebvo_epi_candidates_resident(ebvo_ctx *ctx, uint64_t tag_left, uint64_t tag_right, const double *lines,
+                                            double epi_thr, double max_disp, double orient_thr_deg, int stage_mask,
+                                            int want_orient_flags, ebvo_candidates_view *view)
+{
+    if (!ctx || !view || (stage_mask & ~EBVO_STAGE_ALL) || stage_mask == 0)
+        return EBVO_ERR_ARG;
+    memset(view, 0, sizeof *view);
+    const int iL = resident_ws(ctx, tag_left), iR = resident_ws(ctx, tag_right);
+    if (iL < 0 || iR < 0 || iL == iR)
+    {
+        ctx->last_error = "the edge lists named by the tags are no longer resident";
+        return EBVO_ERR_STATE;
+    }
+    EBVO_HIP(ctx, hipSetDevice(ctx->device));
+    int rc;
+    Slot *sp;
+    if ((rc = host_slot(ctx, &sp)))
+        return rc;
+    Slot &s = *sp;
+    const int nL = s.im[iL].n_kept, nR = s.im[iR].n_kept;
+    if (nL > 0 && !lines)
+        return EBVO_ERR_ARG;
+    const size_t rb = align64(sizeof(int32_t) * ((size_t)nL + 1));
+    if ((rc = pinned_grow(ctx, ctx->sw_cand, rb + 64)))
+        return rc;
+    view->row_ptr = (const int32_t *)ctx->sw_cand.p;
+    if (nL == 0 || nR == 0)
+    {
+        memset(ctx->sw_cand.p, 0, rb);
+        if (want_orient_flags)
+            view->row_ptr_final = view->row_ptr; // all zeros
+        return EBVO_OK;
+    }
+    if ((rc = ebvo_grow(ctx, s, s.lines, sizeof(double) * 3 * (size_t)nL)))
+        return rc;
+    if ((rc = pinned_grow(ctx, ctx->sw_up, sizeof(double) * 3 * (size_t)nL + 64)) ||
+        (rc = upload_staged(ctx, s, s.lines.p, lines, sizeof(double) * 3 * (size_t)nL, 0)))
+        return rc;
+    const ebvo_edge *dL = s.im[iL].edges, *dR = s.im[iR].edges;
+    s.cap_pairs = 0;
+    if ((rc = match_candidates_enqueue(ctx, s, dL, nL, nullptr, dR, nR, nullptr, 0, (const double *)s.lines.p, epi_thr,
+                                       max_disp, orient_thr_deg, stage_mask, false)))
+    {
+        (void)hipStreamSynchronize(s.stream); // the copy out of the caller's `lines` may still be in flight
+        return rc;
+    }
+    unsigned long long *h_total_p = reinterpret_cast<unsigned long long *>(s.h_result);
+    {
+        hipError_t e1 = hipMemcpyAsync(h_total_p, s.d_total, sizeof(*h_total_p), hipMemcpyDeviceToHost, s.stream);
+        hipError_t e2 = e1 == hipSuccess ? hipMemcpyAsync(ctx->sw_cand.p, s.row_ptr.p, sizeof(int32_t) * ((size_t)nL + 1),
+                                                          hipMemcpyDeviceToHost, s.stream)
+                                         : hipSuccess;
+        hipError_t e3 = hipStreamSynchronize(s.stream);
+        if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess)
+            return ebvo_fail_hip(ctx, e1 != hipSuccess ? e1 : (e2 != hipSuccess ? e2 : e3), "candidate total read-back",
+                                 __FILE__, __LINE__);
+    }
+    const unsigned long long h_total = *h_total_p;
+    if (h_total > 0x7fffffffull)
+    {
+        ctx->last_error = "candidate list exceeds 2^31-1 pairs";
+        return EBVO_ERR_CAPACITY;
+    }
+    const int64_t np = (int64_t)h_total;
+    view->n_pairs = np;
+    if (np == 0)
+    {
+        if (want_orient_flags)
+            view->row_ptr_final = view->row_ptr; // all zeros
+        return EBVO_OK;
+    }
+    // arena: row_ptr | col_idx | flags | row_ptr_final | col_idx_final (the final list is a sub-list: np bounds it)
+    const bool staged = want_orient_flags != 0;
+    const size_t cb = align64(sizeof(int32_t) * (size_t)np), fb = staged ? align64((size_t)np) : 0;
+    const size_t rb2 = staged ? rb : 0, cb2 = staged ? cb : 0;
+    {
+        // growing the arena moves it: the row offsets already copied are kept
+        PinnedBuf &pb = ctx->sw_cand;
+        const size_t need = rb + cb + fb + rb2 + cb2 + 64;
+        if (pb.bytes < need)
+        {
+            PinnedBuf fresh;
+            if ((rc = pinned_grow(ctx, fresh, need)))
+                return rc;
+            memcpy(fresh.p, pb.p, rb);
+            (void)hipHostFree(pb.p);
+            pb = fresh;
+        }
+        view->row_ptr = (const int32_t *)pb.p;
+    }
+    if ((rc = ebvo_grow(ctx, s, s.col_idx, sizeof(int32_t) * (size_t)np)))
+        return rc;
+    s.cap_pairs = np;
+    char *base = (char *)ctx->sw_cand.p;
+    unsigned long long *h_final_p = h_total_p + 1; // second word of the slot's pinned record
+    static_assert(sizeof(PairResult) >= 2 * sizeof(unsigned long long), "pinned record too small for two totals");
+    rc = [&]() -> int {
+        int r;
+        if ((r = match_candidates_fill_enqueue(ctx, s, dL, nL, nullptr, dR, nR, nullptr, 0, (const double *)s.lines.p, epi_thr,
+                                               max_disp, orient_thr_deg, stage_mask)))
+            return r;
+        if (staged)
+        {
+            if ((r = ebvo_grow(ctx, s, s.keep, (size_t)np)) ||
+                (r = match_orient_flags_enqueue(ctx, s, dL, nL, dR, (const int32_t *)s.row_ptr.p, (const int32_t *)s.col_idx.p,
+                                                np, orient_thr_deg, (uint8_t *)s.keep.p)))
+                return r;
+        }
+        EBVO_HIP(ctx, hipMemcpyAsync(base + rb, s.col_idx.p, sizeof(int32_t) * (size_t)np, hipMemcpyDeviceToHost, s.stream));
+        if (staged)
+        {
+            EBVO_HIP(ctx, hipMemcpyAsync(base + rb + cb, s.keep.p, (size_t)np, hipMemcpyDeviceToHost, s.stream));
+            // the list the flags select = the search under all three predicates (stream order: the copies above have read
+            // row_ptr / col_idx before these kernels overwrite them); it fits the buffers of the longer list
+            if ((r = match_candidates_enqueue(ctx, s, dL, nL, nullptr, dR, nR, nullptr, 0, (const double *)s.lines.p, epi_thr,
+                                              max_disp, orient_thr_deg, stage_mask | EBVO_STAGE_ORIENTATION, false)) ||
+                (r = match_candidates_fill_enqueue(ctx, s, dL, nL, nullptr, dR, nR, nullptr, 0, (const double *)s.lines.p, epi_thr,
+                                                   max_disp, orient_thr_deg, stage_mask | EBVO_STAGE_ORIENTATION)))
+                return r;
+            EBVO_HIP(ctx, hipMemcpyAsync(h_final_p, s.d_total, sizeof(*h_final_p), hipMemcpyDeviceToHost, s.stream));
+            EBVO_HIP(ctx, hipMemcpyAsync(base + rb + cb + fb, s.row_ptr.p, sizeof(int32_t) * ((size_t)nL + 1),
+                                         hipMemcpyDeviceToHost, s.stream));
+        }
+        return EBVO_OK;
+    }();
+    hipError_t es = hipStreamSynchronize(s.stream);
+    int64_t nf = 0;
+    if (!rc && es == hipSuccess && staged)
+    {
+        nf = (int64_t)*h_final_p;
+        if (nf > np) // cannot happen: a sub-list
+        {
+            ctx->last_error = "internal: the orientation-filtered list is longer than the list it filters";
+            rc = EBVO_ERR_HIP;
+        }
+        else if (nf > 0)
+        {
+            hipError_t e = hipMemcpyAsync(base + rb + cb + fb + rb2, s.col_idx.p, sizeof(int32_t) * (size_t)nf, hipMemcpyDeviceToHost,
+                                          s.stream);
+            es = hipStreamSynchronize(s.stream);
+            if (e != hipSuccess)
+                es = e;
+        }
+    }
+    s.cap_pairs = 0; // the pipeline re-establishes its own capacity
+    if (rc)
+        return rc;
+    EBVO_HIP(ctx, es);
+    view->col_idx = (const int32_t *)(base + rb);
+    view->orient_ok = staged ? (const uint8_t *)(base + rb + cb) : nullptr;
+    if (staged)
+    {
+        view->row_ptr_final = (const int32_t *)(base + rb + cb + fb);
+        view->col_idx_final = (const int32_t *)(base + rb + cb + fb + rb2);
+        view->n_final = nf;
+    }
+    return EBVO_OK;
+}
+
+extern "C" int ebvo_ncc_pairs_resident(ebvo_ctx *ctx, uint64_t tag_left, uint64_t tag_right, const uint8_t *imgL,
+                                       const uint8_t *imgR, int h, int w, ptrdiff_t strideL, ptrdiff_t strideR,
+                                       const int32_t *row_ptr, const int32_t *col_idx, double thr, int want,
+                                       ebvo_ncc_view *view)
+{
+    if (!ctx || !view || !imgL || !imgR || !row_ptr || (want & ~(EBVO_NCC_WANT_LEFT_PATCHES | EBVO_NCC_WANT_SIMS)))
+        return EBVO_ERR_ARG;
+    memset(view, 0, sizeof *view);
+    const int iL = resident_ws(ctx, tag_left), iR = resident_ws(ctx, tag_right);
+    if (iL < 0 || iR < 0 || iL == iR)
+    {
+        ctx->last_error = "the edge lists named by the tags are no longer resident";
+        return EBVO_ERR_STATE;
+    }
+    EBVO_HIP(ctx, hipSetDevice(ctx->device));
+    int rc;
+    Slot *sp;
+    if ((rc = check_size(ctx, h, w)) || (rc = host_slot(ctx, &sp)))
+        return rc;
+    Slot &s = *sp;
+    if (h != ctx->sw_h || w != ctx->sw_w)
+    {
+        ctx->last_error = "image size differs from the size the resident edges were detected on";
+        return EBVO_ERR_ARG;
+    }
+    const int nL = s.im[iL].n_kept, nR = s.im[iR].n_kept;
+    if (row_ptr[0] != 0)
+        return EBVO_ERR_ARG;
+    const int64_t np = nL > 0 ? row_ptr[nL] : 0;
+    if (np < 0 || (np > 0 && !col_idx))
+        return EBVO_ERR_ARG;
+    if (nL == 0)
+        return EBVO_OK;
+    // the lists go through page-locked staging and are validated on the way: the kernels index the right patch bank with
+    // col_idx and walk the pair arrays with row_ptr
+    const size_t rb = align64(sizeof(int32_t) * ((size_t)nL + 1)), cb = align64(sizeof(int32_t) * (size_t)np);
+    const size_t ib = align64((size_t)h * w);
+    if ((rc = pinned_grow(ctx, ctx->sw_up, rb + cb + 2 * ib + 64)))
+        return rc;
+    int32_t *h_rp = (int32_t *)ctx->sw_up.p, *h_ci = (int32_t *)((char *)ctx->sw_up.p + rb);
+    {
+        int32_t prev = 0, bad = 0;
+        for (int i = 0; i <= nL; ++i)
+        {
+            const int32_t v = row_ptr[i];
+            bad |= (v < prev);
+            prev = v;
+            h_rp[i] = v;
+        }
+        uint32_t over = 0;
+        for (int64_t k = 0; k < np; ++k)
+        {
+            const int32_t v = col_idx[k];
+            over |= ((uint32_t)v >= (uint32_t)nR);
+            h_ci[k] = v;
+        }
+        if (bad || over)
+        {
+            ctx->last_error = bad ? "row_ptr is not non-decreasing" : "col_idx holds an index outside the resident right edge list";
+            return EBVO_ERR_ARG;
+        }
+    }
+    int64_t want_cap = s.pipe_cap > np ? s.pipe_cap : np + np / 4 + 1024;
+    if (want_cap < 4096)
+        want_cap = 4096;
+    if ((rc = ensure_pipeline_buffers(ctx, s, want_cap)))
+        return rc;
+    if ((rc = ebvo_grow(ctx, s, s.row_ptr, sizeof(int32_t) * ((size_t)ctx->cap_edges + 1))))
+        return rc;
+    const size_t lb = (want & EBVO_NCC_WANT_LEFT_PATCHES) ? align64(sizeof(float) * 98 * (size_t)nL) : 0;
+    const size_t sb = (want & EBVO_NCC_WANT_SIMS) ? align64(sizeof(double) * 4 * (size_t)np) : 0;
+    const size_t bb = align64(sizeof(double) * (size_t)np), kb = align64((size_t)np);
+    if ((rc = pinned_grow(ctx, ctx->sw_ncc, lb + sb + bb + kb + 64)))
+        return rc;
+    // the images the NCC samples are the RAW ones the caller passes (src/Stereo_Matches.cpp:562-563); they replace the
+    // images in the workspaces, the edges stay
+    if ((rc = upload_image_staged(ctx, s, iL, imgL, h, w, strideL, rb + cb)) ||
+        (rc = upload_image_staged(ctx, s, iR, imgR, h, w, strideR, rb + cb + ib)))
+    {
+        (void)hipStreamSynchronize(s.stream);
+        return rc;
+    }
+    bool patches_on_copy_stream = false;
+    rc = [&]() -> int {
+        int r;
+        EBVO_HIP(ctx, hipMemcpyAsync(s.row_ptr.p, h_rp, sizeof(int32_t) * ((size_t)nL + 1), hipMemcpyHostToDevice, s.stream));
+        if (np)
+            EBVO_HIP(ctx, hipMemcpyAsync(s.col_idx.p, h_ci, sizeof(int32_t) * (size_t)np, hipMemcpyHostToDevice, s.stream));
+        if (lb && (r = match_patches_enqueue(ctx, s, s.im[iL].img, h, w, w, s.im[iL].edges, nL, nullptr, 0,
+                                             (float *)s.patches_raw.p, (float *)s.patches_norm.p, (uint8_t *)s.patches_flag.p)))
+            return r;
+        char *base = (char *)ctx->sw_ncc.p;
+        if (lb)
+        {
+            // the left patches (the largest result: 392 bytes per left edge) travel on the copy stream while the pairs are scored
+            if (!ctx->copy_stream)
+                EBVO_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+            EBVO_HIP(ctx, hipEventRecord(s.ev_done, s.stream));
+            EBVO_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, s.ev_done, 0));
+            EBVO_HIP(ctx, hipMemcpyAsync(base, s.patches_raw.p, sizeof(float) * 98 * (size_t)nL, hipMemcpyDeviceToHost,
+                                         ctx->copy_stream));
+            patches_on_copy_stream = true;
+        }
+        if (np)
+        {
+            if ((r = match_ncc_resident_enqueue(ctx, s, h, w, ctx->cap_edges, thr, iL)))
+                return r;
+            if (sb)
+                EBVO_HIP(ctx, hipMemcpyAsync(base + lb, s.sims.p, sizeof(double) * 4 * (size_t)np, hipMemcpyDeviceToHost, s.stream));
+            EBVO_HIP(ctx, hipMemcpyAsync(base + lb + sb, s.best.p, sizeof(double) * (size_t)np, hipMemcpyDeviceToHost, s.stream));
+            EBVO_HIP(ctx, hipMemcpyAsync(base + lb + sb + bb, s.keep.p, (size_t)np, hipMemcpyDeviceToHost, s.stream));
+        }
+        return EBVO_OK;
+    }();
+    const hipError_t es = hipStreamSynchronize(s.stream);
+    const hipError_t ec = patches_on_copy_stream ? hipStreamSynchronize(ctx->copy_stream) : hipSuccess;
+    if (rc)
+        return rc;
+    EBVO_HIP(ctx, es);
+    EBVO_HIP(ctx, ec);
+    char *base = (char *)ctx->sw_ncc.p;
+    view->n_left = nL;
+    view->n_pairs = np;
+    view->left_patches = lb ? (const float *)base : nullptr;
+    view->sims = sb ? (const double *)(base + lb) : nullptr;
+    view->best = np ? (const double *)(base + lb + sb) : nullptr;
+    view->keep = np ? (const uint8_t *)(base + lb + sb + bb) : nullptr;
+    return EBVO_OK;
 }
 
 extern "C" int ebvo_gn_refine_temporal(ebvo_ctx *ctx, const uint8_t *imgKF, const uint8_t *imgCF, int h, int w,

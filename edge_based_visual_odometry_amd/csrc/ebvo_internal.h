@@ -161,6 +161,13 @@ struct Slot
 // the image the NCC passes sample: the RAW one (src/Stereo_Matches.cpp:562-563)
 inline const uint8_t *ncc_img(const Slot &s, int k) { return s.undist_pair ? s.im[k].raw : s.im[k].img; }
 
+// page-locked host memory owned by the context (results of the resident stage-wise calls), grown on demand
+struct PinnedBuf
+{
+    void *p = nullptr;
+    size_t bytes = 0;
+};
+
 struct ebvo_ctx
 {
     int device = 0;
@@ -185,6 +192,12 @@ struct ebvo_ctx
     uint64_t submit_seq = 0;
     std::vector<hipStream_t> lane_streams; // created on first use, owned by the context
     hipStream_t copy_stream = nullptr;     // result copies of ebvo_stereo_fetch_begin (all slots), created on first use
+    // resident stage-wise path (ebvo_toed_resident / ebvo_epi_candidates_resident / ebvo_ncc_pairs_resident): the TOED results
+    // of the last two images stay in slot 0's image workspaces; tag 0 = that workspace holds nothing a caller may refer to
+    uint64_t sw_seq = 0;
+    uint64_t sw_tag[2] = {0, 0};
+    int sw_h = 0, sw_w = 0;
+    PinnedBuf sw_toed[2], sw_cand, sw_ncc, sw_up;
     int gn_no_rows = 0;        // developer key (ebvo_debug_set 4): 1 = the refinements never use the eight-lanes-per-pair layout
     int gn_rows_below = 0;     // developer key (ebvo_debug_set 5): active-pair count below which an iteration uses it, 0 = default
     int wait_attempts = 0;     // test hook (ebvo_debug_set): attempts of ebvo_stereo_wait's regrow loop, 0 = default (4)
@@ -262,7 +275,8 @@ int match_ncc_pairs_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_imgR, int h
                             double *d_best, uint8_t *d_keep, int32_t *d_pair_left_scratch = nullptr,
                             void *d_sincos_scratch = nullptr /* n_pairs double2; NULL: the slot's own buffers */);
 // resident pipeline: sin/cos, right patch bank, LDS-tiled NCC of every CSR pair (sizes read on the device)
-int match_ncc_resident_enqueue(ebvo_ctx *ctx, Slot &s, int h, int w, int cap_edges, double thr);
+// left = index of the slot's image workspace that holds the LEFT image and edges (the right one is the other)
+int match_ncc_resident_enqueue(ebvo_ctx *ctx, Slot &s, int h, int w, int cap_edges, double thr, int left = 0);
 size_t match_right_bank_bytes(int cap_edges);
 int match_pair_result_enqueue(ebvo_ctx *ctx, Slot &s);
 int match_orient_flags_enqueue(ebvo_ctx *ctx, Slot &s, const ebvo_edge *d_L, int nL, const ebvo_edge *d_R, const int32_t *d_row_ptr,

@@ -1948,11 +1948,12 @@ int match_ncc_pairs_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_imgR, int h
 
 // NCC of the CSR pairs in s.row_ptr / s.col_idx of the resident pair: sin/cos of both edge lists, the right bank, the
 // tile kernel.  s.patches_norm_r holds the right bank (BANK_EDGE floats per edge).
-int match_ncc_resident_enqueue(ebvo_ctx *ctx, Slot &s, int h, int w, int cap_edges, double thr)
+int match_ncc_resident_enqueue(ebvo_ctx *ctx, Slot &s, int h, int w, int cap_edges, double thr, int left)
 {
     int rc;
     if ((rc = ebvo_grow(ctx, s, s.sincos, sizeof(double2) * 2 * (size_t)cap_edges)))
         return rc;
+    const int iL = left ? 1 : 0, iR = 1 - iL; // workspace of the left / of the right image
     PatchBatch B{};
     for (int k = 0; k < 2; ++k)
     {
@@ -1961,15 +1962,15 @@ int match_ncc_resident_enqueue(ebvo_ctx *ctx, Slot &s, int h, int w, int cap_edg
         B.n[k] = DevN{0, s.im[k].counts + 1};
         B.sc[k] = (double2 *)s.sincos.p + (size_t)k * cap_edges;
     }
-    const DevN nLd{0, s.im[0].counts + 1}, nRd{0, s.im[1].counts + 1};
+    const DevN nLd{0, s.im[iL].counts + 1}, nRd{0, s.im[iR].counts + 1};
     {
         ProfScope ps(ctx, s, K_PATCHES);
         hipLaunchKernelGGL(row_pairs_kernel, dim3(blocks_for(((int64_t)h * w + 3) / 4, 256, 512), 2), dim3(256), 0, s.stream,
                            ncc_img(s, 0), ncc_img(s, 1), s.im[0].pix2, s.im[1].pix2, h, w);
         hipLaunchKernelGGL(sincos_batch_kernel, dim3(blocks_for(cap_edges, 256, 512), 2), dim3(256), 0, s.stream, B);
         hipLaunchKernelGGL(right_bank_kernel, dim3(blocks_for((int64_t)cap_edges * 16, 256, 1024)), dim3(256), 0, s.stream,
-                           ncc_img(s, 1), (const uint16_t *)s.im[1].pix2, h, w, w, (const ebvo_edge *)s.im[1].edges, (const double2 *)B.sc[1],
-                           nRd, (float *)s.patches_norm_r.p);
+                           ncc_img(s, iR), (const uint16_t *)s.im[iR].pix2, h, w, w, (const ebvo_edge *)s.im[iR].edges,
+                           (const double2 *)B.sc[iR], nRd, (float *)s.patches_norm_r.p);
     }
     {
         ProfScope ps(ctx, s, K_NCC_PAIRS);
@@ -1978,8 +1979,8 @@ int match_ncc_resident_enqueue(ebvo_ctx *ctx, Slot &s, int h, int w, int cap_edg
         s.n_match_part = nblk;
         // NW = 4 left edges per wave, at most 5 waves per SIMD: measured best of {4, 8, 16} x {4, 5, 6, 8} (a bigger tile
         // serialises more sampling rounds in one wave; a higher occupancy target spills)
-        hipLaunchKernelGGL((ncc_tile_kernel<NCC_NW, NCC_WPE>), dim3(nblk), dim3(256), 0, s.stream, ncc_img(s, 0),
-                           (const uint16_t *)s.im[0].pix2, h, w, w, (const ebvo_edge *)s.im[0].edges, (const double2 *)B.sc[0],
+        hipLaunchKernelGGL((ncc_tile_kernel<NCC_NW, NCC_WPE>), dim3(nblk), dim3(256), 0, s.stream, ncc_img(s, iL),
+                           (const uint16_t *)s.im[iL].pix2, h, w, w, (const ebvo_edge *)s.im[iL].edges, (const double2 *)B.sc[iL],
                            nLd, (const int32_t *)s.row_ptr.p, (const int32_t *)s.col_idx.p, (const float *)s.patches_norm_r.p,
                            s.cap_pairs, thr, (double *)s.sims.p, (double *)s.best.p, (uint8_t *)s.keep.p, s.d_matches);
     }

@@ -59,6 +59,19 @@ class Context
     int max_w() const { return w_; }
     typedef std::shared_ptr<Context> Ptr;
 
+    // Resident stage-wise path: what the last two get_Third_Order_Edges calls produced is still on the device (one result
+    // per image workspace of the library, used alternately: main_VO detects left, then right, src/Pipeline.cpp:93-97) and
+    // in page-locked memory (`edges`).  A later stage that is handed a vector with exactly these edges names the device copy
+    // by its tag instead of uploading the vector.
+    struct ResidentEdges
+    {
+        uint64_t tag = 0; // 0: nothing
+        const ebvo_edge *edges = nullptr;
+        int n = 0;
+    };
+    ResidentEdges resident[2];
+    int next_workspace = 0;
+
   private:
     ebvo_ctx *ctx_ = nullptr;
     int status_ = EBVO_OK, h_, w_;
@@ -85,6 +98,49 @@ inline ebvo_edge to_abi(const EdgeT &e)
     return o;
 }
 
+// read-only view of an array the library or a result object owns
+template <class T>
+struct Span
+{
+    const T *p = nullptr;
+    size_t n = 0;
+    Span() = default;
+    Span(const T *p_, size_t n_) : p(p_), n(n_) {}
+    Span(const std::vector<T> &v) : p(v.data()), n(v.size()) {}
+    const T *data() const { return p; }
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+    const T &operator[](size_t k) const { return p[k]; }
+    const T *begin() const { return p; }
+    const T *end() const { return p + n; }
+};
+
+inline bool same_bits(double a, double b) { return std::memcmp(&a, &b, sizeof a) == 0; }
+
+// the workspace whose resident edge list is EXACTLY `edges` (every x, y, orientation bit for bit, every index), or -1
+template <class EdgeT>
+inline int resident_workspace(const Context &c, const std::vector<EdgeT> &edges)
+{
+    for (int ws = 0; ws < 2; ++ws)
+    {
+        const Context::ResidentEdges &r = c.resident[ws];
+        if (!r.tag || (size_t)r.n != edges.size())
+            continue;
+        size_t k = 0;
+        for (; k < edges.size(); ++k)
+        {
+            const ebvo_edge &a = r.edges[k];
+            const EdgeT &e = edges[k];
+            if (!(same_bits(a.x, e.location.x) && same_bits(a.y, e.location.y) && same_bits(a.theta, e.orientation) &&
+                  a.index == (int32_t)e.index))
+                break;
+        }
+        if (k == edges.size())
+            return ws;
+    }
+    return -1;
+}
+
 // ---------------------------------------------------------------------------------------------
 template <class EdgeT>
 class ThirdOrderEdgeDetectionHIP
@@ -104,8 +160,7 @@ class ThirdOrderEdgeDetectionHIP
     ThirdOrderEdgeDetectionHIP(int H, int W, int device = 0)
         : img_height(H), img_width(W), ctx_(std::make_shared<Context>(H, W, device))
     {
-        all4_.resize((size_t)H * W * 4);
-        abi_.resize((size_t)H * W);
+        all4_.resize(4); // subpix_edge_pts_final of an image without a single maximum
         subpix_edge_pts_final = all4_.data();
         last_status = ctx_->status();
     }
@@ -129,20 +184,33 @@ class ThirdOrderEdgeDetectionHIP
             last_status = EBVO_ERR_ARG;
             return;
         }
-        int n_kept = 0, n_total = 0;
-        last_status = ebvo_toed(ctx_->get(), data, rows, cols, step, abi_.data(), (int)abi_.size(), &n_kept, &n_total,
-                                all4_.data(), (int)(all4_.size() / 4), &time_conv, &time_nms);
-        if (!report(*ctx_, last_status, "ebvo_toed"))
+        // the result stays on the device (workspace `ws`) and arrives in page-locked memory: toed_edges is built straight
+        // from it, subpix_edge_pts_final points at it (valid until the next call but one, like the reference's member buffer
+        // is valid until the next call)
+        const int ws = ctx_->next_workspace;
+        ctx_->next_workspace ^= 1;
+        ctx_->resident[ws] = Context::ResidentEdges();
+        ebvo_toed_view v;
+        last_status = ebvo_toed_resident(ctx_->get(), ws, data, rows, cols, step, 1, &v);
+        if (!report(*ctx_, last_status, "ebvo_toed_resident"))
             return;
-        toed_edges.resize((size_t)n_kept); // default-constructed: b_isEmpty = true, frame_source = -1
+        time_conv = v.t_conv;
+        time_nms = v.t_nms;
+        const int n_kept = v.n_kept, n_total = v.n_total;
+        toed_edges.reserve((size_t)n_kept);
+        EdgeT e{}; // default-constructed: b_isEmpty = true, frame_source = -1
         for (int k = 0; k < n_kept; ++k)
         {
-            EdgeT &e = toed_edges[(size_t)k];
-            e.location.x = abi_[(size_t)k].x;
-            e.location.y = abi_[(size_t)k].y;
-            e.orientation = abi_[(size_t)k].theta;
-            e.index = abi_[(size_t)k].index;
+            e.location.x = v.edges[k].x;
+            e.location.y = v.edges[k].y;
+            e.orientation = v.edges[k].theta;
+            e.index = v.edges[k].index;
+            toed_edges.push_back(e);
         }
+        subpix_edge_pts_final = n_total ? const_cast<double *>(v.all4) : all4_.data();
+        ctx_->resident[ws].tag = v.tag;
+        ctx_->resident[ws].edges = v.edges;
+        ctx_->resident[ws].n = n_kept;
         Total_Num_Of_TOED = n_total;
         edge_pt_list_idx = n_total;
     }
@@ -153,7 +221,6 @@ class ThirdOrderEdgeDetectionHIP
     int img_height, img_width;
     Context::Ptr ctx_;
     std::vector<double> all4_;
-    std::vector<ebvo_edge> abi_;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -185,7 +252,8 @@ class StereoMatcherHIP
     static std::vector<std::array<double, 3>> CalculateEpipolarLine(const double F[9], const std::vector<EdgeT> &edges)
     {
         std::vector<std::array<double, 3>> lines(edges.size());
-        std::vector<ebvo_edge> abi(edges.size());
+        static thread_local std::vector<ebvo_edge> abi; // reused: a fresh 4 MB vector per frame costs more than the lines
+        abi.resize(edges.size());
         for (size_t k = 0; k < edges.size(); ++k)
             abi[k] = to_abi(edges[k]);
         ebvo_epipolar_lines(F, abi.data(), (int)abi.size(), lines.empty() ? nullptr : lines[0].data());
@@ -289,6 +357,149 @@ class StereoMatcherHIP
                                      s.best.data(), s.keep.data());
         report(*ctx_, last_status, "ebvo_ncc_pairs");
         return s;
+    }
+
+    // ---- the same stages for a caller that hands back the vectors get_Third_Order_Edges gave it (main_VO as it is) ----
+    // If `left` and `right` are exactly the edge lists still resident on the device (Context::resident), the stage runs on
+    // the device copies and its results are views of page-locked memory of the context -- no edge list is uploaded, no result
+    // vector is allocated; they stay valid until the next call of the same stage.  Otherwise (edges edited, other edges, a
+    // call in between that used the library's slot 0) the host-buffer path above runs and the views point into `own`.
+    // Same bits either way (tests/test_cpp_adapter.py).
+    struct StagedView
+    {
+        Span<int32_t> row_ptr, col_idx;             // the lists after the epipolar and disparity stages
+        Span<uint8_t> orient_ok;                    // per listed pair: passes the orientation stage
+        Span<int32_t> row_ptr_final, col_idx_final; // the lists after the orientation stage (the flagged pairs, in order)
+        bool resident = false;
+        StagedCandidates own;
+        CandidateLists own_final;
+        StagedView() = default;
+        StagedView(StagedView &&) = default;
+        StagedView &operator=(StagedView &&) = default;
+        StagedView(const StagedView &) = delete;
+        size_t rows() const { return row_ptr.empty() ? 0 : row_ptr.size() - 1; }
+    };
+    StagedView candidates_staged_view(const std::vector<EdgeT> &left, const std::vector<EdgeT> &right,
+                                      const std::vector<std::array<double, 3>> &lines,
+                                      double epi_thr = EBVO_EPIPOLAR_LINE_DIST_THRESH, double max_disp = EBVO_MAX_DISPARITY,
+                                      double orient_thr_deg = EBVO_ORIENT_THRESH_DEG)
+    {
+        StagedView out;
+        const int wl = resident_workspace(*ctx_, left), wr = resident_workspace(*ctx_, right);
+        if (wl >= 0 && wr >= 0 && wl != wr && lines.size() == left.size())
+        {
+            ebvo_candidates_view v;
+            last_status = ebvo_epi_candidates_resident(ctx_->get(), ctx_->resident[wl].tag, ctx_->resident[wr].tag,
+                                                       lines.empty() ? nullptr : lines[0].data(), epi_thr, max_disp, orient_thr_deg,
+                                                       EBVO_STAGE_EPIPOLAR | EBVO_STAGE_DISPARITY, 1, &v);
+            if (last_status == EBVO_OK)
+            {
+                out.resident = true;
+                out.row_ptr = Span<int32_t>(v.row_ptr, left.size() + 1);
+                out.col_idx = Span<int32_t>(v.col_idx, (size_t)v.n_pairs);
+                out.orient_ok = Span<uint8_t>(v.orient_ok, (size_t)v.n_pairs);
+                out.row_ptr_final = Span<int32_t>(v.row_ptr_final, left.size() + 1);
+                out.col_idx_final = Span<int32_t>(v.col_idx_final, (size_t)v.n_final);
+                return out;
+            }
+            if (last_status != EBVO_ERR_STATE) // a stale tag is not an error: the host-buffer path takes over
+            {
+                report(*ctx_, last_status, "ebvo_epi_candidates_resident");
+                return out;
+            }
+            ctx_->resident[0] = ctx_->resident[1] = Context::ResidentEdges();
+        }
+        out.own = candidates_staged(left, right, lines, epi_thr, max_disp, orient_thr_deg);
+        out.row_ptr = out.own.lists.row_ptr;
+        out.col_idx = out.own.lists.col_idx;
+        out.orient_ok = out.own.orient_ok;
+        // the flagged pairs of every row, in order (branch-free: a slot is overwritten unless its pair is flagged)
+        out.own_final.row_ptr.assign(out.row_ptr.size(), 0);
+        out.own_final.col_idx.resize(out.col_idx.size());
+        size_t n = 0;
+        for (size_t i = 0; i + 1 < out.row_ptr.size(); ++i)
+        {
+            for (int32_t k = out.row_ptr[i]; k < out.row_ptr[i + 1]; ++k)
+            {
+                out.own_final.col_idx[n] = out.col_idx[(size_t)k];
+                n += out.orient_ok[(size_t)k];
+            }
+            out.own_final.row_ptr[i + 1] = (int32_t)n;
+        }
+        out.own_final.col_idx.resize(n);
+        out.row_ptr_final = out.own_final.row_ptr;
+        out.col_idx_final = out.own_final.col_idx;
+        return out;
+    }
+
+    // apply_NCC_Filtering in its first pass (:1427): candidate k of the lists is right[col_idx[k]] (a TOED edge,
+    // contributing_edges_toed_indices[0], :413).  The four scores per pair only if asked for.
+    struct NccView
+    {
+        Span<float> left_patches;     // nL x 2 x 49 (left_edge_patches, :578)
+        Span<double> pp_nn_pn_np;     // 4 per pair, empty unless want_sims
+        Span<double> best;            // final_SIM_score (:596)
+        Span<uint8_t> keep;           // best > NCC_THRESH (:597)
+        bool resident = false;
+        NccScores own;
+        NccView() = default;
+        NccView(NccView &&) = default;
+        NccView &operator=(NccView &&) = default;
+        NccView(const NccView &) = delete;
+    };
+    NccView ncc_indexed(const uint8_t *imgL, const uint8_t *imgR, int rows, int cols, ptrdiff_t stepL, ptrdiff_t stepR,
+                        const std::vector<EdgeT> &left, const std::vector<EdgeT> &right, Span<int32_t> row_ptr,
+                        Span<int32_t> col_idx, double thr = EBVO_NCC_THRESH, bool want_sims = false)
+    {
+        NccView out;
+        if (row_ptr.size() != left.size() + 1 || (left.size() && (size_t)row_ptr[left.size()] != col_idx.size()))
+        {
+            last_status = EBVO_ERR_ARG;
+            report(*ctx_, last_status, "ncc_indexed: row_ptr / col_idx do not describe one list per left edge");
+            return out;
+        }
+        const int wl = resident_workspace(*ctx_, left), wr = resident_workspace(*ctx_, right);
+        if (wl >= 0 && wr >= 0 && wl != wr)
+        {
+            ebvo_ncc_view v;
+            last_status = ebvo_ncc_pairs_resident(ctx_->get(), ctx_->resident[wl].tag, ctx_->resident[wr].tag, imgL, imgR, rows, cols,
+                                                  stepL, stepR, row_ptr.data(), col_idx.data(), thr,
+                                                  EBVO_NCC_WANT_LEFT_PATCHES | (want_sims ? EBVO_NCC_WANT_SIMS : 0), &v);
+            if (last_status == EBVO_OK)
+            {
+                out.resident = true;
+                out.left_patches = Span<float>(v.left_patches, (size_t)v.n_left * 98);
+                out.pp_nn_pn_np = Span<double>(v.sims, v.sims ? (size_t)v.n_pairs * 4 : 0);
+                out.best = Span<double>(v.best, (size_t)v.n_pairs);
+                out.keep = Span<uint8_t>(v.keep, (size_t)v.n_pairs);
+                return out;
+            }
+            if (last_status != EBVO_ERR_STATE)
+            {
+                report(*ctx_, last_status, "ebvo_ncc_pairs_resident");
+                return out;
+            }
+            ctx_->resident[0] = ctx_->resident[1] = Context::ResidentEdges();
+        }
+        std::vector<EdgeT> cand(col_idx.size());
+        for (size_t k = 0; k < cand.size(); ++k)
+        {
+            if ((size_t)col_idx[k] >= right.size())
+            {
+                last_status = EBVO_ERR_ARG;
+                report(*ctx_, last_status, "ncc_indexed: candidate index outside the right edge list");
+                return out;
+            }
+            cand[k] = right[(size_t)col_idx[k]];
+        }
+        std::vector<int32_t> rp(row_ptr.begin(), row_ptr.end());
+        out.own = ncc(imgL, imgR, rows, cols, stepL, stepR, left, rp, cand, thr);
+        out.left_patches = out.own.left_patches;
+        if (want_sims)
+            out.pp_nn_pn_np = out.own.pp_nn_pn_np;
+        out.best = out.own.best;
+        out.keep = out.own.keep;
+        return out;
     }
 
     // refine_edge_disparity (:1290-1358): photometric Gauss-Newton of every (left edge, candidate centre) pair along

@@ -31,9 +31,10 @@
 extern "C" {
 #endif
 
-#define EBVO_ABI_VERSION 4 /* 2: photometric refinement, stage glue, finalisation, resident chain; 3: pinned result views,
+#define EBVO_ABI_VERSION 5 /* 2: photometric refinement, stage glue, finalisation, resident chain; 3: pinned result views,
                               undistortion, SIFT descriptors, SIFT stages of the chain; 4: the temporal chain after the
-                              NCC filter (ebvo_temporal_params / _counts grew, ebvo_temporal_fetch_final) */
+                              NCC filter (ebvo_temporal_params / _counts grew, ebvo_temporal_fetch_final); 5: the resident
+                              stage-wise calls (ebvo_toed_resident, ebvo_epi_candidates_resident, ebvo_ncc_pairs_resident) */
 
 typedef struct ebvo_ctx ebvo_ctx;
 
@@ -148,6 +149,71 @@ int ebvo_epi_candidates(ebvo_ctx *ctx, const ebvo_edge *L, int nL, const ebvo_ed
 int ebvo_epi_candidates_staged(ebvo_ctx *ctx, const ebvo_edge *L, int nL, const ebvo_edge *R, int nR, const double *lines,
                                double epi_thr, double max_disp, double orient_thr_deg, int32_t *row_ptr, int32_t *col_idx,
                                uint8_t *orient_ok, int64_t cap, int64_t *n_pairs);
+
+/*
+ * The same three stages for a caller that runs them ONE AFTER THE OTHER on what the previous stage returned -- main_VO as it
+ * is: Pipeline::ProcessEdges x 2 (src/Pipeline.cpp:24-29, :93-97), then apply_Epipolar_Line_Distance_Filtering /
+ * apply_Disparity_Filtering / apply_orientation_filter (src/Stereo_Matches.cpp:1374-1399), then apply_NCC_Filtering (:1427).
+ * What a stage produced STAYS on the device under a tag; the next stage names it by tag instead of uploading it again, and
+ * every result is returned as pointers into page-locked memory owned by the context (valid until the next call of the
+ * same function on this context; nothing to free).  The tags of the two most recent ebvo_toed_resident results (one per
+ * `which`) are valid until that workspace receives another edge list (ebvo_toed_resident on it, ebvo_toed, ebvo_toed_pair,
+ * a pair uploaded into slot 0); the other host-buffer entry points leave them valid, so the SIFT / Best-Nearly-Best /
+ * refinement calls get_Stereo_Edge_Pairs makes between the stages do not cost the residency.  A stale tag gives
+ * EBVO_ERR_STATE and the caller falls back to the host-buffer entry points above (include/ebvo/adapters.hpp does).
+ * Results are bit-identical to ebvo_toed / ebvo_epi_candidates(_staged) / ebvo_ncc_pairs on the same inputs.
+ */
+typedef struct ebvo_toed_view
+{
+    const ebvo_edge *edges; /* toed_edges: n_kept records */
+    const double *all4;     /* subpix_edge_pts_final: n_total x 4, NULL unless asked for */
+    int32_t n_kept, n_total;
+    uint64_t tag;           /* names this result in the calls below; never 0 */
+    double t_conv, t_nms;   /* seconds of device time */
+} ebvo_toed_view;
+/* ThirdOrderEdgeDetectionCPU::get_Third_Order_Edges (src/toed/cpu_toed.cpp:66-77) into workspace `which` (0 or 1): the
+ * image is uploaded, the edges are detected, copied to page-locked memory AND kept on the device. */
+int ebvo_toed_resident(ebvo_ctx *ctx, int which, const uint8_t *img, int h, int w, ptrdiff_t stride, int want_all4,
+                       ebvo_toed_view *view);
+
+typedef struct ebvo_candidates_view
+{
+    const int32_t *row_ptr;   /* n_left + 1 */
+    const int32_t *col_idx;   /* n_pairs right-edge indices, ascending per row */
+    const uint8_t *orient_ok; /* n_pairs flags (see ebvo_epi_candidates_staged), NULL unless asked for */
+    int64_t n_pairs;
+    /* with the flags also the list they select, i.e. the lists after apply_orientation_filter (= ebvo_epi_candidates with
+     * EBVO_STAGE_ALL): what the next stage takes as its row_ptr / col_idx */
+    const int32_t *row_ptr_final; /* n_left + 1 */
+    const int32_t *col_idx_final; /* n_final */
+    int64_t n_final;
+} ebvo_candidates_view;
+/* ebvo_epi_candidates / ebvo_epi_candidates_staged on two resident edge lists (left and right may sit in either
+ * workspace); only the nL x 3 line coefficients travel to the device. */
+int ebvo_epi_candidates_resident(ebvo_ctx *ctx, uint64_t tag_left, uint64_t tag_right, const double *lines, double epi_thr,
+                                 double max_disp, double orient_thr_deg, int stage_mask, int want_orient_flags,
+                                 ebvo_candidates_view *view);
+
+enum
+{
+    EBVO_NCC_WANT_LEFT_PATCHES = 1, /* left_edge_patches (src/Stereo_Matches.cpp:578): n_left x 2 x 49 floats */
+    EBVO_NCC_WANT_SIMS = 2          /* the four scores of every pair (:592-595) */
+};
+typedef struct ebvo_ncc_view
+{
+    const float *left_patches; /* n_left x 98 */
+    const double *sims;        /* n_pairs x 4 */
+    const double *best;        /* n_pairs: final_SIM_score (:596) */
+    const uint8_t *keep;       /* n_pairs: best > thr (:597) */
+    int32_t n_left;
+    int64_t n_pairs;
+} ebvo_ncc_view;
+/* apply_NCC_Filtering in its FIRST pass (:1427), where every candidate is a right TOED edge: the pairs are given as CSR
+ * indices into the resident right edge list (contributing_edges_toed_indices[0], :413) instead of 32-byte edge records.
+ * imgL / imgR are the RAW images (:562-563); they are uploaded (0.5 MB each), the edges are not. */
+int ebvo_ncc_pairs_resident(ebvo_ctx *ctx, uint64_t tag_left, uint64_t tag_right, const uint8_t *imgL, const uint8_t *imgR,
+                            int h, int w, ptrdiff_t strideL, ptrdiff_t strideR, const int32_t *row_ptr,
+                            const int32_t *col_idx, double thr, int want, ebvo_ncc_view *view);
 
 /*
  * Replaces Stereo_Matches::apply_NCC_Filtering (src/Stereo_Matches.cpp:555-616) and under it

@@ -57,6 +57,7 @@ void ThirdOrderEdgeDetectionCPU::get_Third_Order_Edges(cv::Mat img)
     auto &d = impl(this);
     d.get_Third_Order_Edges(img); // cv::Mat has .data/.rows/.cols/.step
     toed_edges = d.toed_edges;    // Edge{location, orientation, index}; b_isEmpty = true, frame_source = -1
+    subpix_edge_pts_final = d.subpix_edge_pts_final; // N x 4 rows in page-locked memory of the adapter's context
     Total_Num_Of_TOED = d.Total_Num_Of_TOED;
     edge_pt_list_idx = d.edge_pt_list_idx;
     time_conv = d.time_conv;

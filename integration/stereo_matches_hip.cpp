@@ -71,13 +71,16 @@ void Stereo_Matches::apply_Epipolar_Line_Distance_Filtering(Stereo_Edge_Pairs &p
     // ONE device search for the three geometric stages: the (epipolar AND disparity) list now, the orientation flags kept for
     // apply_orientation_filter.  What differs from the reference is only what an observer sees BETWEEN the stages: the
     // candidates the disparity filter would drop are already gone here.
-    auto st = m.candidates_staged(p.get_focused_edges(), cand, ln, EPIPOLAR_LINE_DIST_THRESH, MAX_DISPARITY,
-                                  EBVO_ORIENT_THRESH_DEG);
-    const ebvo::CandidateLists &c = st.lists;
+    // The focused and candidate edges are the vectors Pipeline::ProcessEdges got from the detector (src/Pipeline.cpp:93-97):
+    // the adapter recognises them as the lists still resident on the device and searches there (nothing but the line
+    // coefficients is uploaded); edited or foreign edge lists take the host-buffer path, same result.
+    auto st = m.candidates_staged_view(p.get_focused_edges(), cand, ln, EPIPOLAR_LINE_DIST_THRESH, MAX_DISPARITY,
+                                       EBVO_ORIENT_THRESH_DEG);
+    const auto &c = st;
     g_staged.owner = &p;
     g_staged.orient_thr = EBVO_ORIENT_THRESH_DEG;
-    g_staged.row_ptr = st.lists.row_ptr;
-    g_staged.orient_ok = st.orient_ok;
+    g_staged.row_ptr.assign(st.row_ptr.begin(), st.row_ptr.end());
+    g_staged.orient_ok.assign(st.orient_ok.begin(), st.orient_ok.end());
 #endif
     for (size_t i = 0; i < c.rows(); ++i)
     {
@@ -150,21 +153,53 @@ void Stereo_Matches::apply_NCC_Filtering(Stereo_Edge_Pairs &p, const std::string
     const cv::Mat &imgL = is_left ? p.stereo_frame->left_image : p.stereo_frame->right_image; // RAW images, :562-568
     const cv::Mat &imgR = is_left ? p.stereo_frame->right_image : p.stereo_frame->left_image;
     const std::vector<Edge> left = p.get_focused_edges();
-    std::vector<int32_t> row_ptr(left.size() + 1, 0);
-    std::vector<Edge> cand;
-    for (size_t i = 0; i < left.size(); ++i)
+    const std::vector<Edge> &right = is_left ? p.stereo_frame->right_edges : p.stereo_frame->left_edges;
+    std::vector<int32_t> row_ptr(left.size() + 1, 0), col_idx;
+    // First pass (:1427): every candidate is still a right TOED edge, named by contributing_edges_toed_indices[0] (:413) --
+    // the pairs go to the device as indices into the resident right edge list.  Second pass (:1500): cluster centres,
+    // explicit edges (the consolidate step leaves contributing_edges_toed_indices empty).
+    bool indexed = true;
+    for (size_t i = 0; i < left.size() && indexed; ++i)
     {
         for (const EdgeCluster &ec : p.matching_edge_clusters[i].edge_clusters)
-            cand.push_back(ec.center_edge); // :588 -- a TOED edge (1st pass) or a cluster centre (2nd pass)
-        row_ptr[i + 1] = (int32_t)cand.size();
+        {
+            const int idx = ec.contributing_edges_toed_indices.size() == 1 ? ec.contributing_edges_toed_indices[0] : -1;
+            if (idx < 0 || (size_t)idx >= right.size() || !(right[(size_t)idx].location == ec.center_edge.location) ||
+                right[(size_t)idx].orientation != ec.center_edge.orientation)
+            {
+                indexed = false;
+                break;
+            }
+            col_idx.push_back(idx);
+        }
+        row_ptr[i + 1] = (int32_t)col_idx.size();
     }
     auto m = matcher();
-    ebvo::NccScores s = m.ncc(imgL.data, imgR.data, imgL.rows, imgL.cols, (ptrdiff_t)imgL.step, (ptrdiff_t)imgR.step,
-                              left, row_ptr, cand, NCC_THRESH);
+    ebvo::StereoMatcherHIP<Edge>::NccView s;
+    if (indexed)
+        s = m.ncc_indexed(imgL.data, imgR.data, imgL.rows, imgL.cols, (ptrdiff_t)imgL.step, (ptrdiff_t)imgR.step, left, right,
+                          row_ptr, col_idx, NCC_THRESH);
+    else
+    {
+        std::vector<Edge> cand;
+        for (size_t i = 0; i < left.size(); ++i)
+        {
+            for (const EdgeCluster &ec : p.matching_edge_clusters[i].edge_clusters)
+                cand.push_back(ec.center_edge); // :588 -- a cluster centre
+            row_ptr[i + 1] = (int32_t)cand.size();
+        }
+        s.own = m.ncc(imgL.data, imgR.data, imgL.rows, imgL.cols, (ptrdiff_t)imgL.step, (ptrdiff_t)imgR.step, left, row_ptr,
+                      cand, NCC_THRESH);
+        s.left_patches = s.own.left_patches;
+        s.best = s.own.best;
+        s.keep = s.own.keep;
+    }
+    if (s.keep.size() != (size_t)row_ptr[left.size()] || s.left_patches.size() != 98 * left.size())
+        return; // the call failed and was reported; the lists stay as they are
     p.left_edge_patches.resize(left.size());
     for (size_t i = 0; i < left.size(); ++i)
     {
-        cv::Mat plus(7, 7, CV_32F, s.left_patches.data() + i * 98), minus(7, 7, CV_32F, s.left_patches.data() + i * 98 + 49);
+        cv::Mat plus(7, 7, CV_32F, (void *)(s.left_patches.data() + i * 98)), minus(7, 7, CV_32F, (void *)(s.left_patches.data() + i * 98 + 49));
         p.left_edge_patches[i] = {plus.clone(), minus.clone()}; // :578
         auto &mc = p.matching_edge_clusters[i];
         std::vector<EdgeCluster> keep;

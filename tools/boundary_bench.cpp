@@ -1,8 +1,9 @@
 // boundary_bench.cpp -- wall time of the stage-wise drop-in sequence as main_VO runs it through the adapters
 // (src/Pipeline.cpp:24-29, :93-97; src/Stereo_Matches.cpp:1374-1427): ProcessEdges(left), ProcessEdges(right),
-// CalculateEpipolarLine, the three geometric candidate stages (one device search: candidates_staged + the host-side drop
-// of the unflagged pairs), apply_NCC_Filtering with the left patches -- every input and output in ordinary host memory,
-// one call after the other.  Plain local types stand where cv::Mat / struct Edge stand in the reference tree.
+// CalculateEpipolarLine, the three geometric candidate stages (one device search: candidates_staged_view + the host-side
+// drop of the unflagged pairs), apply_NCC_Filtering with the left patches -- one call after the other, every stage handed
+// the std::vectors the previous one returned.  The adapters recognise those vectors as the edge lists still resident on the
+// device (bit-for-bit comparison) and run the stage there; results are read from page-locked memory of the context.  Plain local types stand where cv::Mat / struct Edge stand in the reference tree.
 // usage: boundary_bench <left.raw> <right.raw> <h> <w> <iterations>      prints one JSON object
 #include <chrono>
 #include <cstdio>
@@ -63,47 +64,49 @@ int main(int argc, char **argv)
     ebvo::StereoMatcherHIP<Edge> matcher(TOED->context());
     double split[5] = {0, 0, 0, 0, 0};
     size_t n_left = 0, n_listed = 0, n_pairs = 0, n_kept = 0;
+    int resident_calls = 0;
+    std::vector<int32_t> row_ptr, col; // the caller's lists, reused from frame to frame
     for (int it = 0; it <= iters; ++it) // the first turn is untimed: it sizes the library's buffers
     {
         double tk[6];
         tk[0] = now();
         TOED->get_Third_Order_Edges(left);
-        std::vector<Edge> left_edges = TOED->toed_edges;
+        std::vector<Edge> left_edges = TOED->toed_edges; // Pipeline::ProcessEdges copies the result out (src/Pipeline.cpp:28)
         TOED->get_Third_Order_Edges(right);
         std::vector<Edge> right_edges = TOED->toed_edges;
         tk[1] = now();
         auto lines = ebvo::StereoMatcherHIP<Edge>::CalculateEpipolarLine(F, left_edges);
         tk[2] = now();
-        auto st = matcher.candidates_staged(left_edges, right_edges, lines);
+        // the vectors handed back are the ones the detector produced: the search runs on the device copies
+        auto st = matcher.candidates_staged_view(left_edges, right_edges, lines);
         if (matcher.last_status != EBVO_OK)
             return 4;
         tk[3] = now();
-        // the host step of the binding: the orientation stage keeps the flagged candidates of every row
-        std::vector<int32_t> row_ptr(left_edges.size() + 1, 0);
-        std::vector<Edge> cand;
-        cand.reserve(st.lists.col_idx.size() / 3);
-        for (size_t i = 0; i < left_edges.size(); ++i)
-        {
-            for (int32_t k = st.lists.row_ptr[i]; k < st.lists.row_ptr[i + 1]; ++k)
-                if (st.orient_ok[(size_t)k])
-                    cand.push_back(right_edges[(size_t)st.lists.col_idx[(size_t)k]]);
-            row_ptr[i + 1] = (int32_t)cand.size();
-        }
+        // the host step of the binding: after apply_orientation_filter the caller's lists are the flagged pairs of every
+        // row (the staged search returns that list as well, formed on the device); the NCC stage names each survivor by its
+        // right TOED index
+        row_ptr.assign(st.row_ptr_final.begin(), st.row_ptr_final.end());
+        col.assign(st.col_idx_final.begin(), st.col_idx_final.end());
         tk[4] = now();
-        ebvo::NccScores s = matcher.ncc(left.data, right.data, h, w, (ptrdiff_t)left.step, (ptrdiff_t)right.step, left_edges,
-                                        row_ptr, cand);
+        auto s = matcher.ncc_indexed(left.data, right.data, h, w, (ptrdiff_t)left.step, (ptrdiff_t)right.step, left_edges,
+                                     right_edges, row_ptr, col);
         if (matcher.last_status != EBVO_OK)
             return 5;
         tk[5] = now();
         if (it)
+        {
             for (int q = 0; q < 5; ++q)
                 split[q] += tk[q + 1] - tk[q];
+            resident_calls += (st.resident ? 1 : 0) + (s.resident ? 1 : 0);
+        }
         n_left = left_edges.size();
-        n_listed = st.lists.col_idx.size();
-        n_pairs = cand.size();
+        n_listed = st.col_idx.size();
+        n_pairs = col.size();
         n_kept = 0;
         for (uint8_t kf : s.keep)
             n_kept += kf;
+        if (s.left_patches.size() != 98 * n_left || s.best.size() != n_pairs)
+            return 6;
     }
     double total = 0;
     for (double &v : split)
@@ -113,8 +116,8 @@ int main(int argc, char **argv)
     }
     std::printf("{\"pairs_per_s\": %.3f, \"ms\": {\"toed_both_images\": %.3f, \"epipolar_lines\": %.3f, \"candidates_staged\": %.3f, "
                 "\"host_row_filter\": %.3f, \"ncc_with_left_patches\": %.3f}, \"left_edges\": %zu, \"listed_pairs\": %zu, "
-                "\"candidate_pairs\": %zu, \"ncc_matches\": %zu}\n",
+                "\"candidate_pairs\": %zu, \"ncc_matches\": %zu, \"resident_stage_calls\": %d, \"stage_calls\": %d}\n",
                 1.0 / total, split[0] * 1e3, split[1] * 1e3, split[2] * 1e3, split[3] * 1e3, split[4] * 1e3, n_left, n_listed,
-                n_pairs, n_kept);
+                n_pairs, n_kept, resident_calls, 2 * iters);
     return 0;
 }
