@@ -208,14 +208,16 @@ KERNEL_GROUPS = {
 }
 
 
-def dropin_loop(ctx, params, pool, calib, nslots, steps):
-    """What StereoMatcherHIP::stereo_edge_pairs does per frame (include/ebvo/adapters.hpp; the one-pass body of
-    get_Stereo_Edge_Pairs, integration/stereo_matches_hip.cpp): a NEW pair uploaded from host memory, TOED + candidates +
-    NCC, then the later stages on the device with the SIFT filter (ebvo_stereo_finalize) and the final pairs + output rows
-    copied back.  `nslots` frames in flight: the stereo pair of frame k + 1 .. is submitted before frame k is finalized."""
+def dropin_loop(ctx, params, pool, calib, nslots, steps, chains=2):
+    """What a frame loop over StereoMatcherHIP::stereo_edge_pairs_begin / _end does per frame (include/ebvo/adapters.hpp; the
+    one-pass body of get_Stereo_Edge_Pairs, integration/stereo_matches_hip.cpp): a NEW pair uploaded from host memory, TOED +
+    candidates + NCC, then the later stages on the device with the SIFT filter (ebvo_stereo_finalize_submit / _wait) and the
+    final pairs + output rows copied back.  `nslots` frames in flight, up to `chains` of them in their later stages: the
+    chain of a frame is enqueued without a host synchronisation, so the chains of different slots overlap on the device."""
     t0 = time.perf_counter()
     sub = done = 0
     n_final = 0
+    in_chain = []                                   # slots whose chain is enqueued, oldest first
 
     def launch(k):
         nonlocal sub
@@ -224,15 +226,27 @@ def dropin_loop(ctx, params, pool, calib, nslots, steps):
             ctx.stereo_submit(params, slot=k)
             sub += 1
 
-    for k in range(min(nslots, steps)):
-        launch(k)
-    while done < steps:
-        k = done % nslots
-        ctx.stereo_wait(slot=k)
-        fc, fin = ctx.stereo_finalize(calib, slot=k, use_sift=True)
+    def retire():
+        nonlocal done, n_final
+        k = in_chain.pop(0)
+        fc, fin = ctx.stereo_finalize_wait(slot=k)
         n_final += fc["n_final"]
         done += 1
         launch(k)
+
+    for k in range(min(nslots, steps)):
+        launch(k)
+    entered = 0
+    while entered < steps:
+        k = entered % nslots
+        ctx.stereo_wait(slot=k)
+        ctx.stereo_finalize_submit(calib, slot=k, use_sift=True)
+        in_chain.append(k)
+        entered += 1
+        while len(in_chain) >= max(1, min(chains, nslots)):
+            retire()
+    while in_chain:
+        retire()
     return time.perf_counter() - t0, n_final / max(1, steps)
 
 

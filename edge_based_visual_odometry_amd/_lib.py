@@ -41,7 +41,7 @@ ABI_SYMBOLS = (
     "ebvo_stereo_upload_slot", "ebvo_stereo_submit", "ebvo_stereo_wait", "ebvo_stereo_fetch_slot", "ebvo_profile_enable",
     "ebvo_profile_reset", "ebvo_profile_get", "ebvo_fp64_peak",
     "ebvo_gn_default_params", "ebvo_sobel_gradients", "ebvo_gn_refine_stereo", "ebvo_stereo_refine",
-    "ebvo_stereo_fetch_refined", "ebvo_gn_refine_temporal", "ebvo_finalize_pairs", "ebvo_bnb_test", "ebvo_keep_best", "ebvo_epipolar_shift", "ebvo_cluster_rows", "ebvo_stereo_finalize", "ebvo_stereo_fetch_final",
+    "ebvo_stereo_fetch_refined", "ebvo_gn_refine_temporal", "ebvo_finalize_pairs", "ebvo_bnb_test", "ebvo_keep_best", "ebvo_epipolar_shift", "ebvo_cluster_rows", "ebvo_stereo_finalize", "ebvo_stereo_finalize_submit", "ebvo_stereo_finalize_wait", "ebvo_stereo_fetch_final",
     "ebvo_debug_set", "ebvo_stereo_fetch_begin", "ebvo_stereo_fetch_end",
     "ebvo_undistort", "ebvo_stereo_set_undistort", "ebvo_sift_descriptors", "ebvo_sift_min_distances",
     "ebvo_toed_resident", "ebvo_epi_candidates_resident", "ebvo_ncc_pairs_resident",
@@ -214,6 +214,8 @@ def load_library() -> C.CDLL:
     lib.ebvo_epipolar_shift.argtypes = [vp, vp, vp, vp, i32, vp]
     lib.ebvo_cluster_rows.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, vp]
     lib.ebvo_stereo_finalize.argtypes = [vp, i32, C.POINTER(FinalizeParams), C.POINTER(StereoCalib), C.POINTER(FinalizeCounts)]
+    lib.ebvo_stereo_finalize_submit.argtypes = [vp, i32, C.POINTER(FinalizeParams), C.POINTER(StereoCalib)]
+    lib.ebvo_stereo_finalize_wait.argtypes = [vp, i32, C.POINTER(FinalizeCounts)]
     lib.ebvo_stereo_fetch_final.argtypes = [vp, i32, vp, vp, vp, vp]
     lib.ebvo_finalize_pairs.argtypes = [vp, C.POINTER(StereoCalib), vp, vp, i32, vp]
     lib.ebvo_stereo_refine.argtypes = [vp, i32, C.POINTER(GnParams)]

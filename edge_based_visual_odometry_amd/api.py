@@ -401,11 +401,8 @@ class Context:
                                                      ptr(out)), "ebvo_sift_min_distances")
         return out
 
-    def stereo_finalize(self, calib=None, slot=0, bnb_ratio=0.9, ncc_thr=0.6, use_sift=False, sift_thr=500.0, bnb_sift=0.4,
-                        **gn):
-        """BNB -> shift -> refine -> cluster -> NCC -> best on the resident pair.  calib = (K_left, K_right, R21, T21) adds the
-        output-file rows.  Returns (counts dict, dict(left_index, right, score[, rows]))."""
-        from ._lib import FinalizeCounts, FinalizeParams, StereoCalib
+    def _finalize_args(self, calib, bnb_ratio, ncc_thr, use_sift, sift_thr, bnb_sift, gn):
+        from ._lib import FinalizeParams, StereoCalib
         p = FinalizeParams()
         p.bnb_ratio, p.ncc_thr, p.gn = bnb_ratio, ncc_thr, self._gn_params(**gn)
         p.use_sift, p.sift_thr, p.bnb_sift = int(bool(use_sift)), sift_thr, bnb_sift
@@ -414,18 +411,42 @@ class Context:
             cal = StereoCalib()
             for name, v, n in zip(("K_left", "K_right", "R21", "T21"), calib, (9, 9, 9, 3)):
                 getattr(cal, name)[:] = np.ascontiguousarray(v, dtype=np.float64).reshape(n).tolist()
+        return p, cal
+
+    def stereo_finalize_submit(self, calib=None, slot=0, bnb_ratio=0.9, ncc_thr=0.6, use_sift=False, sift_thr=500.0,
+                               bnb_sift=0.4, **gn):
+        """Enqueue the chain after the first NCC pass on the slot's stream and return (ebvo_stereo_finalize_submit)."""
+        p, cal = self._finalize_args(calib, bnb_ratio, ncc_thr, use_sift, sift_thr, bnb_sift, gn)
+        self._check(self.lib.ebvo_stereo_finalize_submit(self._ctx, slot, C.byref(p), C.byref(cal) if cal is not None else None),
+                    "ebvo_stereo_finalize_submit")
+        self._fin_opts = getattr(self, "_fin_opts", {})
+        self._fin_opts[slot] = (calib is not None, bool(use_sift))
+
+    def stereo_finalize_wait(self, slot=0, fetch=True):
+        """Wait for the chain of `slot`; returns (counts dict, dict(left_index, right, score[, rows]) or None)."""
+        from ._lib import FinalizeCounts
         cnt = FinalizeCounts()
-        self._check(self.lib.ebvo_stereo_finalize(self._ctx, slot, C.byref(p), C.byref(cal) if cal is not None else None,
-                                                  C.byref(cnt)), "ebvo_stereo_finalize")
+        self._check(self.lib.ebvo_stereo_finalize_wait(self._ctx, slot, C.byref(cnt)), "ebvo_stereo_finalize_wait")
+        has_rows, use_sift = self._fin_opts.get(slot, (False, False))
+        keys = ("n_sift",) * use_sift + ("n_ncc", "n_bnb", "n_clusters", "n_ncc2", "n_final")
+        counts = {k: getattr(cnt, k) for k in keys}
+        if not fetch:
+            return counts, None
         n = cnt.n_final
         out = dict(left_index=np.zeros(n, dtype=np.int32), right=np.zeros(n, dtype=EDGE_DTYPE), score=np.zeros(n))
-        rows = np.zeros((n, 16)) if calib is not None else None
+        rows = np.zeros((n, 16)) if has_rows else None
         self._check(self.lib.ebvo_stereo_fetch_final(self._ctx, slot, ptr(out["left_index"]), ptr(out["right"]),
                                                      ptr(out["score"]), ptr(rows)), "ebvo_stereo_fetch_final")
         if rows is not None:
             out["rows"] = rows
-        keys = ("n_sift",) * bool(use_sift) + ("n_ncc", "n_bnb", "n_clusters", "n_ncc2", "n_final")
-        return {k: getattr(cnt, k) for k in keys}, out
+        return counts, out
+
+    def stereo_finalize(self, calib=None, slot=0, bnb_ratio=0.9, ncc_thr=0.6, use_sift=False, sift_thr=500.0, bnb_sift=0.4,
+                        **gn):
+        """BNB -> shift -> refine -> cluster -> NCC -> best on the resident pair.  calib = (K_left, K_right, R21, T21) adds the
+        output-file rows.  Returns (counts dict, dict(left_index, right, score[, rows]))."""
+        self.stereo_finalize_submit(calib, slot, bnb_ratio, ncc_thr, use_sift, sift_thr, bnb_sift, **gn)
+        return self.stereo_finalize_wait(slot)
 
     def stereo_refine(self, counts, slot=0, **kw):
         """Refine every kept match of the resident pair on the device; returns the per-pair outputs (n_pairs entries,

@@ -186,6 +186,11 @@ static void slot_destroy(Slot *s)
         (void)hipEventDestroy(s->ev_done);
     if (s->ev_rebind)
         (void)hipEventDestroy(s->ev_rebind);
+    (void)hipFree(s->d_fin_tot);
+    if (s->h_fin_tot)
+        (void)hipHostFree(s->h_fin_tot);
+    if (s->ev_fin)
+        (void)hipEventDestroy(s->ev_fin);
     if (s->own_stream)
         (void)hipStreamDestroy(s->own_stream);
     delete s;
@@ -261,6 +266,9 @@ static int slot_create(ebvo_ctx *ctx, Slot **out)
     CK(hipMalloc(&s->d_F, sizeof(double) * 9));
     CK(hipMalloc(&s->d_result, sizeof(PairResult)));
     CK(hipHostMalloc(&s->h_result, sizeof(PairResult)));
+    CK(hipMalloc(&s->d_fin_tot, sizeof(int32_t) * 8));
+    CK(hipHostMalloc(&s->h_fin_tot, sizeof(int32_t) * 8));
+    CK(hipEventCreateWithFlags(&s->ev_fin, hipEventDisableTiming));
     CK(hipStreamSynchronize(s->stream));
 #undef CK
     *out = s;
@@ -416,9 +424,9 @@ static int upload_image(ebvo_ctx *ctx, Slot &s, int k, const uint8_t *img, int h
 static int host_slot(ebvo_ctx *ctx, Slot **out)
 {
     Slot &s = *ctx->slots[0];
-    if (s.in_flight)
+    if (s.in_flight || s.fin_in_flight)
     {
-        ctx->last_error = "slot 0 has a submitted pair in flight; call ebvo_stereo_wait first";
+        ctx->last_error = "slot 0 has a submitted pair in flight; call ebvo_stereo_wait / ebvo_stereo_finalize_wait first";
         return EBVO_ERR_STATE;
     }
     if (int rc = drain_fetch(ctx, s)) // result copies of the previous pair (copy stream) still read the slot's buffers
@@ -1012,7 +1020,7 @@ extern "C" int ebvo_stereo_upload_slot(ebvo_ctx *ctx, int slot, const uint8_t *i
     if ((rc = check_size(ctx, h, w)))
         return rc;
     Slot &s = *sp;
-    if (s.in_flight)
+    if (s.in_flight || s.fin_in_flight)
         return EBVO_ERR_STATE;
     s.have_pair = s.have_run = s.have_refined = s.have_final = false; // results of the previous pair are gone
     if (slot == 0)
@@ -1102,7 +1110,7 @@ extern "C" int ebvo_stereo_submit(ebvo_ctx *ctx, int slot, const ebvo_stereo_par
     if (!p || (p->stage_mask & ~EBVO_STAGE_ALL) || p->stage_mask == 0 || get_slot(ctx, slot, &sp))
         return EBVO_ERR_ARG;
     Slot &s = *sp;
-    if (!s.have_pair || s.in_flight)
+    if (!s.have_pair || s.in_flight || s.fin_in_flight)
         return EBVO_ERR_STATE;
     EBVO_HIP(ctx, hipSetDevice(ctx->device));
     int rc;
@@ -1986,9 +1994,12 @@ extern "C" int ebvo_stereo_fetch_refined(ebvo_ctx *ctx, int slot, double *alpha,
     return EBVO_OK;
 }
 
-// ---- the stages after the NCC pass, on the resident pair (no SIFT): BNB -> shift -> refine -> cluster -> NCC -> best
+// ---- the stages after the NCC pass, on the resident pair: [SIFT filter ->] BNB -> shift -> refine -> cluster -> NCC -> best
 // Every stage is the kernel behind the corresponding host-buffer entry point; only the CSR bookkeeping between them is
-// new (glue_kernels.hip).  The host reads one count per stage to size the next launches; no candidate data leaves HBM.
+// new (glue_kernels.hip).  The chain is ENQUEUED: a stage's survivor count stays on the device (the last entry of the
+// scanned row offsets), the next stage's kernels are launched for the upper bound (the pair count of the run: every stage
+// only shrinks the lists) and read the count there.  The six stage totals travel to page-locked memory in one copy behind
+// the last kernel; ebvo_stereo_finalize_wait is the only host synchronisation.  No candidate data leaves HBM.
 static int read_i32(ebvo_ctx *ctx, Slot &s, const int32_t *d, int32_t *h)
 {
     EBVO_HIP(ctx, hipMemcpyAsync(h, d, sizeof(int32_t), hipMemcpyDeviceToHost, s.stream));
@@ -1996,33 +2007,10 @@ static int read_i32(ebvo_ctx *ctx, Slot &s, const int32_t *d, int32_t *h)
     return EBVO_OK;
 }
 
-extern "C" int ebvo_stereo_finalize(ebvo_ctx *ctx, int slot, const ebvo_finalize_params *p, const ebvo_stereo_calib *calib,
-                                    ebvo_finalize_counts *counts)
+static int finalize_enqueue(ebvo_ctx *ctx, Slot &s, const ebvo_finalize_params *p, const ebvo_stereo_calib *calib)
 {
-    Slot *sp;
-    if (!p || !counts || !(p->bnb_ratio >= 0) || !(p->ncc_thr == p->ncc_thr) || p->gn.max_iter < 1 || !(p->gn.tol >= 0) ||
-        !(p->gn.huber_delta > 0) || (p->use_sift && (!(p->sift_thr > 0) || !(p->bnb_sift >= 0))) || get_slot(ctx, slot, &sp))
-        return EBVO_ERR_ARG;
-    Slot &s = *sp;
-    if (!s.have_run || s.in_flight)
-        return EBVO_ERR_STATE;
-    EBVO_HIP(ctx, hipSetDevice(ctx->device));
-    if (int rc_f = drain_fetch(ctx, s))
-        return rc_f;
-    memset(counts, 0, sizeof *counts);
-    s.have_final = s.have_refined = false; // the refinement buffers are reused
-    s.tq_n = -1;
-    s.tq_final.n = -1;
-    s.sift_left_valid = false;
-
-    s.n_final = 0;
     const int nL = s.result.n_left, h = s.cur_h, w = s.cur_w;
     const int64_t n0 = s.result.n_pairs;
-    if (nL == 0 || n0 == 0)
-    {
-        s.have_final = true;
-        return EBVO_OK;
-    }
     const size_t nz = (size_t)n0, nLz = (size_t)nL + 1;
     int rc;
     // carve the work buffers: everything is bounded by the pair count of the run (each stage only shrinks the lists)
@@ -2033,6 +2021,8 @@ extern "C" int ebvo_stereo_finalize(ebvo_ctx *ctx, int slot, const ebvo_finalize
         (rc = ebvo_grow(ctx, s, s.gn_xy, sizeof(double) * 2 * nz)) || (rc = ebvo_grow(ctx, s, s.gn_out, sizeof(double) * 5 * nz)) ||
         (rc = ebvo_grow(ctx, s, s.gn_valid, nz)) || (rc = ebvo_grow(ctx, s, s.gn_iters, sizeof(int32_t) * nz)))
         return rc;
+    // (the final lists keep their places: ebvo_stereo_fetch_final and the temporal stage read final_left, fin_l / fin_r and
+    // fin_score at these offsets)
     int32_t *cnt = (int32_t *)s.fin_i32.p, *rpA = cnt + nLz, *rpB = rpA + nLz, *final_left = rpB + nLz;
     int32_t *order = final_left + nLz, *left_of = order + nz, *cluster_of = left_of + nz, *ncc_left = cluster_of + nz;
     ebvo_edge *candA = (ebvo_edge *)s.fin_edges.p, *candB = candA + nz, *candC = candB + nz, *fin_l = candC + nz,
@@ -2043,13 +2033,18 @@ extern "C" int ebvo_stereo_finalize(ebvo_ctx *ctx, int slot, const ebvo_finalize
     uint8_t *keep2 = (uint8_t *)s.fin_u8.p;
     const int32_t *rp0 = (const int32_t *)s.row_ptr.p;
     hipStream_t st = s.stream;
-    auto scan_counts = [&](int32_t *rp_out, int32_t *total) -> int {
-        // exclusive scan of cnt[0 .. nL) with the total at rp_out[nL]
+    int32_t *tot = s.d_fin_tot;
+    EBVO_HIP(ctx, hipMemsetAsync(tot, 0, sizeof(int32_t) * 8, st));
+    auto scan_counts = [&](int32_t *rp_out, int which) -> int {
+        // exclusive scan of cnt[0 .. nL) with the total at rp_out[nL]; the total is also kept as stage total `which`
         EBVO_HIP(ctx, hipMemsetAsync(cnt + nL, 0, sizeof(int32_t), st));
         int r = ebvo_device_scan(ctx, s, cnt, rp_out, nL, nullptr, 1, nL + 1);
-        return r ? r : read_i32(ctx, s, rp_out + nL, total);
+        if (r)
+            return r;
+        EBVO_HIP(ctx, hipMemcpyAsync(tot + which, rp_out + nL, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+        return EBVO_OK;
     };
-    int32_t nA = 0, nB = 0, nE = 0, nF = 0, nG = 0;
+    enum { T_SIFT = 0, T_NCC, T_BNB, T_CLUSTERS, T_NCC2, T_FINAL };
     const uint8_t *keep1 = (const uint8_t *)s.keep.p;
     const double *conf0 = nullptr; // SIFT distance per pair of the run (refine_confidences, :757)
     if (p->use_sift)
@@ -2078,93 +2073,149 @@ extern "C" int ebvo_stereo_finalize(ebvo_ctx *ctx, int slot, const ebvo_finalize
                                          p->sift_thr, dist, ok)) ||
             (rc = sift_and_flags_enqueue(ctx, s, ok, (const uint8_t *)s.keep.p, n0, both)))
             return rc;
-        int32_t nS = 0;
-        if ((rc = glue_rows_from_flags_enqueue(ctx, s, rp0, nL, ok, cnt, order)) || (rc = scan_counts(rpA, &nS)))
+        if ((rc = glue_rows_from_flags_enqueue(ctx, s, rp0, nL, ok, cnt, order)) || (rc = scan_counts(rpA, T_SIFT)))
             return rc;
-        counts->n_sift = nS;
         keep1 = both;
         conf0 = dist;
         s.sift_left_valid = true; // dL: the descriptors of every left TOED edge of this pair (ebvo_temporal_* reuse them)
     }
     // 1. the kept NCC matches as a CSR list of right TOED edges with their scores (apply_NCC_Filtering's output, :597-607)
-    if ((rc = glue_rows_from_flags_enqueue(ctx, s, rp0, nL, keep1, cnt, order)) || (rc = scan_counts(rpA, &nA)) ||
+    if ((rc = glue_rows_from_flags_enqueue(ctx, s, rp0, nL, keep1, cnt, order)) || (rc = scan_counts(rpA, T_NCC)) ||
         (rc = glue_gather_rows_enqueue(ctx, s, rp0, cnt, order, rpA, nL, s.im[1].edges, (const int32_t *)s.col_idx.p, candA,
                                        (const double *)s.best.p, scoreA)) ||
         (conf0 && (rc = glue_gather_rows_enqueue(ctx, s, rp0, cnt, order, rpA, nL, nullptr, nullptr, nullptr, conf0, confA))))
         return rc;
-    counts->n_ncc = nA;
     // 2. Best-Nearly-Best test on the NCC scores (:1440) ...
-    if (nA && ((rc = glue_bnb_enqueue(ctx, s, rpA, nL, scoreA, p->bnb_ratio, 1, cnt, order)) || (rc = scan_counts(rpB, &nB)) ||
-               (rc = glue_gather_rows_enqueue(ctx, s, rpA, cnt, order, rpB, nL, candA, nullptr, candB, scoreA, scoreB)) ||
-               (conf0 && (rc = glue_gather_rows_enqueue(ctx, s, rpA, cnt, order, rpB, nL, nullptr, nullptr, nullptr, confA, confB)))))
+    if ((rc = glue_bnb_enqueue(ctx, s, rpA, nL, scoreA, p->bnb_ratio, 1, cnt, order)) || (rc = scan_counts(rpB, T_BNB)) ||
+        (rc = glue_gather_rows_enqueue(ctx, s, rpA, cnt, order, rpB, nL, candA, nullptr, candB, scoreA, scoreB)) ||
+        (conf0 && (rc = glue_gather_rows_enqueue(ctx, s, rpA, cnt, order, rpB, nL, nullptr, nullptr, nullptr, confA, confB))))
         return rc;
-    if (conf0 && nB)
+    if (conf0)
     {
-        // ... and on the SIFT distances, lower is better (:1452).  The survivors return to candB / rpB.
-        int32_t nB2 = 0;
-        if ((rc = glue_bnb_enqueue(ctx, s, rpB, nL, confB, p->bnb_sift, 0, cnt, order)) || (rc = scan_counts(rpA, &nB2)) ||
-            (rc = glue_gather_rows_enqueue(ctx, s, rpB, cnt, order, rpA, nL, candB, nullptr, candA, scoreB, scoreA)) ||
-            (rc = hipMemcpyAsync(rpB, rpA, sizeof(int32_t) * nLz, hipMemcpyDeviceToDevice, st) == hipSuccess ? EBVO_OK : EBVO_ERR_HIP) ||
-            (nB2 && (rc = hipMemcpyAsync(candB, candA, sizeof(ebvo_edge) * (size_t)nB2, hipMemcpyDeviceToDevice, st) == hipSuccess
-                              ? EBVO_OK
-                              : EBVO_ERR_HIP)))
+        // ... and on the SIFT distances, lower is better (:1452).  The survivors land in candA / rpA; the two sets of buffers
+        // swap their roles instead of being copied back.
+        if ((rc = glue_bnb_enqueue(ctx, s, rpB, nL, confB, p->bnb_sift, 0, cnt, order)) || (rc = scan_counts(rpA, T_BNB)) ||
+            (rc = glue_gather_rows_enqueue(ctx, s, rpB, cnt, order, rpA, nL, candB, nullptr, candA, scoreB, scoreA)))
             return rc;
-        nB = nB2;
+        std::swap(rpA, rpB);
+        std::swap(candA, candB);
+        std::swap(scoreA, scoreB);
     }
-    counts->n_bnb = nB;
-    if (nB)
+    const int32_t *d_nB = rpB + nL; // pairs that enter the refinement
     {
         // 3. epipolar shift (:1436) and 4. photometric refinement along the epipolar line (:1438)
         double *out = (double *)s.gn_out.p;
-        if ((rc = match_expand_rows_enqueue(ctx, s, rpB, nL, nB, left_of)) ||
-            (rc = glue_shift_enqueue(ctx, s, candB, (const double *)s.lines.p, left_of, nB, candC)) ||
-            (rc = glue_xy_enqueue(ctx, s, candC, (double *)s.gn_xy.p, nB, false)) ||
+        if ((rc = match_expand_rows_enqueue(ctx, s, rpB, nL, n0, left_of)) ||
+            (rc = glue_shift_enqueue(ctx, s, candB, (const double *)s.lines.p, left_of, n0, candC, d_nB)) ||
+            (rc = glue_xy_enqueue(ctx, s, candC, (double *)s.gn_xy.p, n0, false, d_nB)) ||
             (rc = refine_gn_stereo_enqueue(ctx, s, s.im[0].img, s.im[1].img, nullptr, h, w, s.im[0].edges, nL,
                                            (const double *)s.lines.p, left_of, (const double *)s.gn_xy.p, nullptr, nullptr,
-                                           nullptr, nB, p->gn.max_iter, p->gn.tol, p->gn.huber_delta, out, out + nz,
-                                           out + 2 * nz, (uint8_t *)s.gn_valid.p, (int32_t *)s.gn_iters.p, out + 3 * nz)) ||
-            (rc = glue_xy_enqueue(ctx, s, candC, out + 3 * nz, nB, true)))
+                                           nullptr, n0, p->gn.max_iter, p->gn.tol, p->gn.huber_delta, out, out + nz,
+                                           out + 2 * nz, (uint8_t *)s.gn_valid.p, (int32_t *)s.gn_iters.p, out + 3 * nz, d_nB)) ||
+            (rc = glue_xy_enqueue(ctx, s, candC, out + 3 * nz, n0, true, d_nB)))
             return rc;
         // 5. consolidate_redundant_edge_hypothesis(pairs, false, true) (:1483).  Against the signature (pairs, frame_idx,
         // b_do_epipolar_shift = true, b_do_clustering = true) this binds frame_idx = 0, shift = true, cluster = true: the
         // refined centres are shifted to the epipolar line AGAIN (:981-998) and clustered with b_cluster_by_orientation =
         // b_do_epipolar_shift = true (:1031); rows with one candidate are not skipped on the shift branch (:1001 is the
         // else branch only).  -> candA in the rows of rpA
-        if ((rc = glue_shift_enqueue(ctx, s, candC, (const double *)s.lines.p, left_of, nB, candA)) ||
-            (rc = glue_cluster_enqueue(ctx, s, candA, rpB, nL, 1, 0, cnt, candB, cluster_of)) || (rc = scan_counts(rpA, &nE)) ||
+        if ((rc = glue_shift_enqueue(ctx, s, candC, (const double *)s.lines.p, left_of, n0, candA, d_nB)) ||
+            (rc = glue_cluster_enqueue(ctx, s, candA, rpB, nL, 1, 0, cnt, candB, cluster_of)) ||
+            (rc = scan_counts(rpA, T_CLUSTERS)) ||
             (rc = glue_gather_rows_enqueue(ctx, s, rpB, cnt, nullptr, rpA, nL, candB, nullptr, candA, nullptr, nullptr)))
             return rc;
     }
-    counts->n_clusters = nE;
-    if (nE)
     {
         // 6. second NCC pass on the cluster centres (:1500) -> keep2 / best2, 7. the best survivor of every row (:1513).
         // The normalised left patches (left_edge_patches, :578) are sampled here: the first pass keeps them in LDS only.
         if ((rc = match_patches_enqueue(ctx, s, ncc_img(s, 0), h, w, w, s.im[0].edges, nL, nullptr, 0, nullptr,
                                         (float *)s.patches_norm.p, (uint8_t *)s.patches_flag.p)) ||
-            (rc = match_ncc_pairs_enqueue(ctx, s, ncc_img(s, 1), h, w, w, candA, rpA, nL, nE, (const float *)s.patches_norm.p,
+            (rc = match_ncc_pairs_enqueue(ctx, s, ncc_img(s, 1), h, w, w, candA, rpA, nL, n0, (const float *)s.patches_norm.p,
                                           (const uint8_t *)s.patches_flag.p, p->ncc_thr, nullptr, best2, keep2, ncc_left,
-                                          sincos2)) ||
-            (rc = glue_rows_from_flags_enqueue(ctx, s, rpA, nL, keep2, cnt, order)) || (rc = scan_counts(rpB, &nF)) ||
+                                          sincos2, rpA + nL)) ||
+            (rc = glue_rows_from_flags_enqueue(ctx, s, rpA, nL, keep2, cnt, order)) || (rc = scan_counts(rpB, T_NCC2)) ||
             (rc = glue_gather_rows_enqueue(ctx, s, rpA, cnt, order, rpB, nL, candA, nullptr, candC, best2, scoreB)))
             return rc;
-        counts->n_ncc2 = nF;
-        if (nF && ((rc = glue_keep_best_enqueue(ctx, s, rpB, nL, scoreB, cnt, order)) || (rc = scan_counts(rpA, &nG)) ||
-                   (rc = glue_final_pairs_enqueue(ctx, s, rpB, cnt, order, rpA, nL, s.im[0].edges, candC, scoreB, final_left,
-                                                  fin_l, fin_r, fin_score))))
+        if ((rc = glue_keep_best_enqueue(ctx, s, rpB, nL, scoreB, cnt, order)) || (rc = scan_counts(rpA, T_FINAL)) ||
+            (rc = glue_final_pairs_enqueue(ctx, s, rpB, cnt, order, rpA, nL, s.im[0].edges, candC, scoreB, final_left,
+                                           fin_l, fin_r, fin_score)))
             return rc;
     }
-    counts->n_final = nG;
-    // 8. the rows of the output file
-    if (nG && calib &&
-        (rc = refine_finalize_pairs_enqueue(ctx, s, calib->K_left, calib->K_right, calib->R21, calib->T21, fin_l, fin_r, nG,
-                                            (double *)s.fin_out.p)))
+    // 8. the rows of the output file (at most one final pair per left edge)
+    if (calib && (rc = refine_finalize_pairs_enqueue(ctx, s, calib->K_left, calib->K_right, calib->R21, calib->T21, fin_l, fin_r,
+                                                     nL, (double *)s.fin_out.p, tot + T_FINAL)))
         return rc;
-    EBVO_HIP(ctx, hipStreamSynchronize(st));
-    s.n_final = nG;
-    s.have_final = true;
-    s.final_has_rows = calib != nullptr;
+    EBVO_HIP(ctx, hipMemcpyAsync(s.h_fin_tot, tot, sizeof(int32_t) * 8, hipMemcpyDeviceToHost, st));
+    EBVO_HIP(ctx, hipEventRecord(s.ev_fin, st));
     return EBVO_OK;
+}
+
+extern "C" int ebvo_stereo_finalize_submit(ebvo_ctx *ctx, int slot, const ebvo_finalize_params *p, const ebvo_stereo_calib *calib)
+{
+    Slot *sp;
+    if (!p || !(p->bnb_ratio >= 0) || !(p->ncc_thr == p->ncc_thr) || p->gn.max_iter < 1 || !(p->gn.tol >= 0) ||
+        !(p->gn.huber_delta > 0) || (p->use_sift && (!(p->sift_thr > 0) || !(p->bnb_sift >= 0))) || get_slot(ctx, slot, &sp))
+        return EBVO_ERR_ARG;
+    Slot &s = *sp;
+    if (!s.have_run || s.in_flight || s.fin_in_flight)
+        return EBVO_ERR_STATE;
+    EBVO_HIP(ctx, hipSetDevice(ctx->device));
+    if (int rc_f = drain_fetch(ctx, s))
+        return rc_f;
+    s.have_final = s.have_refined = false; // the refinement buffers are reused
+    s.tq_n = -1;
+    s.tq_final.n = -1;
+    s.sift_left_valid = false;
+    s.n_final = 0;
+    s.final_has_rows = calib != nullptr;
+    memset(s.h_fin_tot, 0, sizeof(int32_t) * 8);
+    if (s.result.n_left == 0 || s.result.n_pairs == 0)
+    {
+        EBVO_HIP(ctx, hipEventRecord(s.ev_fin, s.stream)); // nothing to do: the wait returns zero counts
+        s.fin_in_flight = true;
+        return EBVO_OK;
+    }
+    int rc = finalize_enqueue(ctx, s, p, calib);
+    if (rc)
+    {
+        (void)hipStreamSynchronize(s.stream); // part of the chain may be enqueued
+        return rc;
+    }
+    s.fin_in_flight = true;
+    return EBVO_OK;
+}
+
+extern "C" int ebvo_stereo_finalize_wait(ebvo_ctx *ctx, int slot, ebvo_finalize_counts *counts)
+{
+    Slot *sp;
+    if (!counts || get_slot(ctx, slot, &sp))
+        return EBVO_ERR_ARG;
+    Slot &s = *sp;
+    if (!s.fin_in_flight)
+        return EBVO_ERR_STATE;
+    EBVO_HIP(ctx, hipSetDevice(ctx->device));
+    s.fin_in_flight = false;
+    EBVO_HIP(ctx, hipEventSynchronize(s.ev_fin));
+    const int32_t *t = s.h_fin_tot;
+    memset(counts, 0, sizeof *counts);
+    counts->n_sift = t[0];
+    counts->n_ncc = t[1];
+    counts->n_bnb = t[2];
+    counts->n_clusters = t[3];
+    counts->n_ncc2 = t[4];
+    counts->n_final = t[5];
+    s.n_final = t[5];
+    s.have_final = true;
+    return EBVO_OK;
+}
+
+extern "C" int ebvo_stereo_finalize(ebvo_ctx *ctx, int slot, const ebvo_finalize_params *p, const ebvo_stereo_calib *calib,
+                                    ebvo_finalize_counts *counts)
+{
+    if (!counts)
+        return EBVO_ERR_ARG;
+    int rc = ebvo_stereo_finalize_submit(ctx, slot, p, calib);
+    return rc ? rc : ebvo_stereo_finalize_wait(ctx, slot, counts);
 }
 
 extern "C" int ebvo_stereo_fetch_final(ebvo_ctx *ctx, int slot, int32_t *left_index, ebvo_edge *right_edge, double *ncc_score,

@@ -134,6 +134,11 @@ struct Slot
     GrowBuf fin_i32, fin_edges, fin_f64, fin_u8, fin_out; // ebvo_stereo_finalize: CSRs, candidate lists, scores, final rows
     int n_final = 0;
     bool have_final = false, final_has_rows = false;
+    // ebvo_stereo_finalize_submit / _wait: the chain is enqueued without reading a count back; the stage totals travel in
+    // one copy behind its last kernel
+    int32_t *d_fin_tot = nullptr, *h_fin_tot = nullptr; // [8] device / page-locked: n_sift, n_ncc, n_bnb, n_clusters, n_ncc2, n_final
+    hipEvent_t ev_fin = nullptr;
+    bool fin_in_flight = false;
     GrowBuf lines, boxes_chunk, boxes_group, cand_cnt, cand_stage, cand_tileflag, row_ptr, scan_tmp, col_idx, rc_edges, sims, best, keep,
         patches_raw, patches_norm, patches_flag, patches_norm_r, patches_flag_r, pair_left, sincos, scratch_b, scratch_c,
         scratch_d;
@@ -214,6 +219,24 @@ struct ebvo_ctx
 
 int ebvo_fail_hip(ebvo_ctx *ctx, hipError_t e, const char *what, const char *file, int line);
 
+// A pair / item count that is either known on the host (dev == nullptr) or lives in device memory (an int32: the last
+// entry of a CSR row_ptr, a stage total).  With a device pointer `host` is the UPPER BOUND the launch and the buffers are
+// sized for: the chains after the first NCC pass enqueue every stage without reading a count back.
+struct DevCount
+{
+    int64_t host;
+    const int32_t *dev;
+};
+#ifdef __HIPCC__
+__device__ inline int64_t devcount(const DevCount &c)
+{
+    if (!c.dev)
+        return c.host;
+    const int64_t v = *c.dev;
+    return v < c.host ? v : c.host;
+}
+#endif
+
 #define EBVO_HIP(ctx, call)                                              \
     do                                                                   \
     {                                                                    \
@@ -273,7 +296,8 @@ int match_ncc_pairs_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_imgR, int h
                             const ebvo_edge *d_Rc, const int32_t *d_row_ptr, int nL, int64_t n_pairs,
                             const float *d_left_norm, const uint8_t *d_left_flag, double thr, double *d_sims,
                             double *d_best, uint8_t *d_keep, int32_t *d_pair_left_scratch = nullptr,
-                            void *d_sincos_scratch = nullptr /* n_pairs double2; NULL: the slot's own buffers */);
+                            void *d_sincos_scratch = nullptr /* n_pairs double2; NULL: the slot's own buffers */,
+                            const int32_t *d_n_pairs = nullptr /* the count on the device; n_pairs is then its bound */);
 // resident pipeline: sin/cos, right patch bank, LDS-tiled NCC of every CSR pair (sizes read on the device)
 // left = index of the slot's image workspace that holds the LEFT image and edges (the right one is the other)
 int match_ncc_resident_enqueue(ebvo_ctx *ctx, Slot &s, int h, int w, int cap_edges, double thr, int left = 0);
@@ -333,8 +357,9 @@ int glue_quad_cluster_post_enqueue(ebvo_ctx *ctx, Slot &s, const int32_t *d_rp_i
                                    int32_t *d_src);
 int glue_keep_best_enqueue(ebvo_ctx *ctx, Slot &s, const int32_t *d_row_ptr, int nL, const double *d_scores,
                            int32_t *d_new_count, int32_t *d_order);
+// n / d_n: item count on the host, or (d_n != nullptr) its upper bound and where the device holds the count
 int glue_shift_enqueue(ebvo_ctx *ctx, Slot &s, const ebvo_edge *d_cand, const double *d_lines, const int32_t *d_pair_left,
-                       int64_t n, ebvo_edge *d_out);
+                       int64_t n, ebvo_edge *d_out, const int32_t *d_n = nullptr);
 int glue_cluster_enqueue(ebvo_ctx *ctx, Slot &s, const ebvo_edge *d_cand, const int32_t *d_row_ptr, int nL,
                          int by_orientation, int skip_single, int32_t *d_new_count, ebvo_edge *d_centres,
                          int32_t *d_cluster_of);
@@ -343,7 +368,7 @@ int glue_rows_from_flags_enqueue(ebvo_ctx *ctx, Slot &s, const int32_t *d_row_pt
 int glue_gather_rows_enqueue(ebvo_ctx *ctx, Slot &s, const int32_t *d_rp_in, const int32_t *d_cnt, const int32_t *d_order,
                              const int32_t *d_rp_out, int nL, const ebvo_edge *d_E_src, const int32_t *d_emap,
                              ebvo_edge *d_E_dst, const double *d_D_src, double *d_D_dst);
-int glue_xy_enqueue(ebvo_ctx *ctx, Slot &s, ebvo_edge *d_edges, double *d_xy, int64_t n, bool to_edges);
+int glue_xy_enqueue(ebvo_ctx *ctx, Slot &s, ebvo_edge *d_edges, double *d_xy, int64_t n, bool to_edges, const int32_t *d_n = nullptr);
 int glue_final_pairs_enqueue(ebvo_ctx *ctx, Slot &s, const int32_t *d_rp_in, const int32_t *d_cnt, const int32_t *d_order,
                              const int32_t *d_rp_out, int nL, const ebvo_edge *d_L, const ebvo_edge *d_cand,
                              const double *d_score, int32_t *d_left_index, ebvo_edge *d_left_edge, ebvo_edge *d_right_edge,
@@ -358,9 +383,11 @@ int refine_gn_stereo_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_imgL, cons
                              const int32_t *d_pair_left, const double *d_cand_xy /* or NULL with R + col_idx */,
                              const ebvo_edge *d_R, const int32_t *d_col_idx, const uint8_t *d_keep /* optional */,
                              int64_t n_pairs, int max_iter, double tol, double huber, double *d_alpha, double *d_score,
-                             double *d_conf, uint8_t *d_valid, int32_t *d_iters, double *d_refined_xy);
+                             double *d_conf, uint8_t *d_valid, int32_t *d_iters, double *d_refined_xy,
+                             const int32_t *d_n_pairs = nullptr /* the count on the device; n_pairs is then its bound */);
 int refine_finalize_pairs_enqueue(ebvo_ctx *ctx, Slot &s, const double *K_left, const double *K_right, const double *R21,
-                                  const double *T21, const ebvo_edge *d_L, const ebvo_edge *d_R, int n, double *d_out);
+                                  const double *T21, const ebvo_edge *d_L, const ebvo_edge *d_R, int n, double *d_out,
+                                  const int32_t *d_n = nullptr);
 int refine_gn_temporal_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_imgK, const uint8_t *d_imgC, const void *d_gxy,
                                int h, int w, const ebvo_edge *d_kf, const ebvo_edge *d_cf, const double *d_init, int64_t n,
                                int max_iter, double tol, double huber, double *d_disp, double *d_score, uint8_t *d_valid,

@@ -222,8 +222,9 @@ __device__ inline double tangential_dist(double a1, double b1, double c1, double
 }
 
 __global__ void shift_kernel(const ebvo_edge *__restrict__ cand, const double *__restrict__ lines,
-                             const int32_t *__restrict__ pair_left, int64_t n, ebvo_edge *__restrict__ out)
+                             const int32_t *__restrict__ pair_left, DevCount nd, ebvo_edge *__restrict__ out)
 {
+    const int64_t n = devcount(nd);
     for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x)
     {
         const int i = pair_left[k];
@@ -605,8 +606,9 @@ __global__ void gather_rows_kernel(const int32_t *__restrict__ rp_in, const int3
         }
 }
 
-__global__ void edges_to_xy_kernel(const ebvo_edge *__restrict__ e, int64_t n, double *__restrict__ xy)
+__global__ void edges_to_xy_kernel(const ebvo_edge *__restrict__ e, DevCount nd, double *__restrict__ xy)
 {
+    const int64_t n = devcount(nd);
     for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x)
     {
         xy[2 * k] = e[k].x;
@@ -614,8 +616,9 @@ __global__ void edges_to_xy_kernel(const ebvo_edge *__restrict__ e, int64_t n, d
     }
 }
 
-__global__ void xy_to_edges_kernel(const double *__restrict__ xy, int64_t n, ebvo_edge *__restrict__ e)
+__global__ void xy_to_edges_kernel(const double *__restrict__ xy, DevCount nd, ebvo_edge *__restrict__ e)
 {
+    const int64_t n = devcount(nd);
     for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x)
     {
         e[k].x = xy[2 * k];
@@ -900,12 +903,13 @@ int glue_keep_best_enqueue(ebvo_ctx *ctx, Slot &s, const int32_t *d_row_ptr, int
 }
 
 int glue_shift_enqueue(ebvo_ctx *ctx, Slot &s, const ebvo_edge *d_cand, const double *d_lines, const int32_t *d_pair_left,
-                       int64_t n, ebvo_edge *d_out)
+                       int64_t n, ebvo_edge *d_out, const int32_t *d_n)
 {
     if (n <= 0)
         return EBVO_OK;
     ProfScope ps(ctx, s, K_MISC);
-    hipLaunchKernelGGL(shift_kernel, dim3(grid_for(n)), dim3(256), 0, s.stream, d_cand, d_lines, d_pair_left, n, d_out);
+    hipLaunchKernelGGL(shift_kernel, dim3(grid_for(n)), dim3(256), 0, s.stream, d_cand, d_lines, d_pair_left, DevCount{n, d_n},
+                       d_out);
     EBVO_HIP(ctx, hipGetLastError());
     return EBVO_OK;
 }
@@ -946,14 +950,16 @@ int glue_gather_rows_enqueue(ebvo_ctx *ctx, Slot &s, const int32_t *d_rp_in, con
     return EBVO_OK;
 }
 
-int glue_xy_enqueue(ebvo_ctx *ctx, Slot &s, ebvo_edge *d_edges, double *d_xy, int64_t n, bool to_edges)
+int glue_xy_enqueue(ebvo_ctx *ctx, Slot &s, ebvo_edge *d_edges, double *d_xy, int64_t n, bool to_edges, const int32_t *d_n)
 {
     if (n <= 0)
         return EBVO_OK;
     if (to_edges)
-        hipLaunchKernelGGL(xy_to_edges_kernel, dim3(grid_for(n)), dim3(256), 0, s.stream, (const double *)d_xy, n, d_edges);
+        hipLaunchKernelGGL(xy_to_edges_kernel, dim3(grid_for(n)), dim3(256), 0, s.stream, (const double *)d_xy, DevCount{n, d_n},
+                           d_edges);
     else
-        hipLaunchKernelGGL(edges_to_xy_kernel, dim3(grid_for(n)), dim3(256), 0, s.stream, (const ebvo_edge *)d_edges, n, d_xy);
+        hipLaunchKernelGGL(edges_to_xy_kernel, dim3(grid_for(n)), dim3(256), 0, s.stream, (const ebvo_edge *)d_edges,
+                           DevCount{n, d_n}, d_xy);
     EBVO_HIP(ctx, hipGetLastError());
     return EBVO_OK;
 }

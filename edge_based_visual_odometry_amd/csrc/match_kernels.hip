@@ -1019,12 +1019,15 @@ __global__ __launch_bounds__(256) void patches_kernel(PatchBatch B, int h, int w
 __global__ __launch_bounds__(256) void ncc_pairs_kernel(const uint8_t *__restrict__ imgR, int h, int w,
                                                         int pitch, const ebvo_edge *__restrict__ Rc,
                                                         const double2 *__restrict__ sc,
-                                                        const int32_t *__restrict__ pair_left, int64_t n_pairs,
+                                                        const int32_t *__restrict__ pair_left, DevCount npd,
                                                         const float *__restrict__ left_norm,
                                                         const uint8_t *__restrict__ left_flag, double thr,
                                                         double *__restrict__ sims, double *__restrict__ best,
                                                         uint8_t *__restrict__ keep, int32_t *__restrict__ match_cnt)
 {
+    const int64_t n_pairs = devcount(npd);
+    if ((int64_t)blockIdx.x * 16 >= n_pairs) // a block scores 16 pairs; the grid may be sized for an upper bound
+        return;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t k = t >> 4;
     const int g = (int)(t & 15), side = g >> 3, row = g & 7;
@@ -1917,7 +1920,8 @@ int match_patches_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_img, int h, i
 int match_ncc_pairs_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_imgR, int h, int w, int pitchR,
                             const ebvo_edge *d_Rc, const int32_t *d_row_ptr, int nL, int64_t n_pairs,
                             const float *d_left_norm, const uint8_t *d_left_flag, double thr, double *d_sims,
-                            double *d_best, uint8_t *d_keep, int32_t *d_pair_left_scratch, void *d_sincos_scratch)
+                            double *d_best, uint8_t *d_keep, int32_t *d_pair_left_scratch, void *d_sincos_scratch,
+                            const int32_t *d_n_pairs)
 {
     if (n_pairs <= 0 || nL <= 0)
         return EBVO_OK;
@@ -1933,14 +1937,14 @@ int match_ncc_pairs_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_imgR, int h
         hipLaunchKernelGGL(expand_rows_kernel, dim3(blocks_for(nL, 256, 512)), dim3(256), 0, s.stream, d_row_ptr,
                            DevN{nL, nullptr}, pair_left, n_pairs);
         hipLaunchKernelGGL(sincos_edges_kernel, dim3(blocks_for(n_pairs, 256, 1024)), dim3(256), 0, s.stream, d_Rc,
-                           DevN{(int)n_pairs, nullptr}, sc);
+                           DevN{(int)n_pairs, d_n_pairs}, sc);
     }
     {
         ProfScope ps(ctx, s, K_NCC_PAIRS);
         const int64_t threads = n_pairs * 16;
         hipLaunchKernelGGL(ncc_pairs_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s.stream, d_imgR, h,
-                           w, pitchR, d_Rc, (const double2 *)sc, (const int32_t *)pair_left, n_pairs, d_left_norm,
-                           d_left_flag, thr, d_sims, d_best, d_keep, (int32_t *)nullptr);
+                           w, pitchR, d_Rc, (const double2 *)sc, (const int32_t *)pair_left, DevCount{n_pairs, d_n_pairs},
+                           d_left_norm, d_left_flag, thr, d_sims, d_best, d_keep, (int32_t *)nullptr);
     }
     EBVO_HIP(ctx, hipGetLastError());
     return EBVO_OK;

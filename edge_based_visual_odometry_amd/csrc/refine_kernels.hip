@@ -310,6 +310,7 @@ struct GnArgs
     const int32_t *col_idx;
     const uint8_t *keep;      // optional: only pairs with keep[k] != 0 are refined, the others get validity 255
     int64_t n_pairs;
+    const int32_t *n_pairs_dev; // non-null: the number of pairs lives here, n_pairs is its upper bound
     int max_iter;
     double tol, huber;
     double *alpha, *score, *conf, *refined_xy; // outputs; alpha doubles as the iteration state
@@ -441,10 +442,11 @@ __global__ __launch_bounds__(256) void gn_init_kernel(GnArgs A)
 {
     int turn = 0;
     const int64_t span = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t k0 = (int64_t)blockIdx.x * blockDim.x; k0 < A.n_pairs; k0 += span)
+    const int64_t n_pairs = devcount(DevCount{A.n_pairs, A.n_pairs_dev});
+    for (int64_t k0 = (int64_t)blockIdx.x * blockDim.x; k0 < n_pairs; k0 += span)
     {
         const int64_t k = k0 + threadIdx.x;
-        const bool inside = k < A.n_pairs;
+        const bool inside = k < n_pairs;
         const bool active = inside && (!A.keep || A.keep[k]);
         // the first active list (its order does not influence any result)
         const int slot = block_append_slot(active, &A.counts[0], turn++);
@@ -1110,9 +1112,10 @@ __device__ inline void normalize3(double *v)
     }
 }
 
-__global__ void finalize_pairs_kernel(FinalCalib C, const ebvo_edge *__restrict__ L, const ebvo_edge *__restrict__ R, int n,
+__global__ void finalize_pairs_kernel(FinalCalib C, const ebvo_edge *__restrict__ L, const ebvo_edge *__restrict__ R, DevCount nd,
                                       double *__restrict__ out)
 {
+    const int n = (int)devcount(nd);
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x)
     {
         const ebvo_edge l = L[k], r = R[k];
@@ -1199,7 +1202,7 @@ int refine_gn_stereo_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_imgL, cons
                              const int32_t *d_pair_left, const double *d_cand_xy, const ebvo_edge *d_R,
                              const int32_t *d_col_idx, const uint8_t *d_keep, int64_t n_pairs, int max_iter,
                              double tol, double huber, double *d_alpha, double *d_score, double *d_conf,
-                             uint8_t *d_valid, int32_t *d_iters, double *d_refined_xy)
+                             uint8_t *d_valid, int32_t *d_iters, double *d_refined_xy, const int32_t *d_n_pairs)
 {
     if (n_pairs <= 0)
         return EBVO_OK;
@@ -1237,6 +1240,7 @@ int refine_gn_stereo_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_imgL, cons
     A.col_idx = d_col_idx;
     A.keep = d_keep;
     A.n_pairs = n_pairs;
+    A.n_pairs_dev = d_n_pairs;
     A.max_iter = max_iter;
     A.tol = tol;
     A.huber = huber;
@@ -1375,7 +1379,8 @@ static void inverse3_host(const double *m, double *inv)
 }
 
 int refine_finalize_pairs_enqueue(ebvo_ctx *ctx, Slot &s, const double *K_left, const double *K_right, const double *R21,
-                                  const double *T21, const ebvo_edge *d_L, const ebvo_edge *d_R, int n, double *d_out)
+                                  const double *T21, const ebvo_edge *d_L, const ebvo_edge *d_R, int n, double *d_out,
+                                  const int32_t *d_n)
 {
     if (n <= 0)
         return EBVO_OK;
@@ -1388,7 +1393,7 @@ int refine_finalize_pairs_enqueue(ebvo_ctx *ctx, Slot &s, const double *K_left, 
         C.T21[i] = T21[i];
     ProfScope ps(ctx, s, K_MISC);
     const unsigned blocks = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
-    hipLaunchKernelGGL(finalize_pairs_kernel, dim3(blocks), dim3(256), 0, s.stream, C, d_L, d_R, n, d_out);
+    hipLaunchKernelGGL(finalize_pairs_kernel, dim3(blocks), dim3(256), 0, s.stream, C, d_L, d_R, DevCount{n, d_n}, d_out);
     EBVO_HIP(ctx, hipGetLastError());
     return EBVO_OK;
 }

@@ -445,6 +445,12 @@ typedef struct
 void ebvo_finalize_default_params(ebvo_finalize_params *p); /* the reference's constants, use_sift = 0 */
 int ebvo_stereo_finalize(ebvo_ctx *ctx, int slot, const ebvo_finalize_params *params, const ebvo_stereo_calib *calib,
                          ebvo_finalize_counts *counts);
+/* The same chain without blocking the caller: _submit ENQUEUES every stage on the slot's stream (the stage totals stay on
+ * the device; no count is read back in between) and returns; _wait blocks until the chain has run and returns the
+ * counts.  A frame loop keeps several slots in flight: the chains of different slots run concurrently on the device.
+ * Between the two calls the slot accepts no other call (EBVO_ERR_STATE). */
+int ebvo_stereo_finalize_submit(ebvo_ctx *ctx, int slot, const ebvo_finalize_params *p, const ebvo_stereo_calib *calib);
+int ebvo_stereo_finalize_wait(ebvo_ctx *ctx, int slot, ebvo_finalize_counts *counts);
 /* n_final entries each: index of the left TOED edge, the matched right centre edge, its NCC score, and (if calib was
  * given) the 16 numbers of the output row.  Any pointer may be NULL. */
 int ebvo_stereo_fetch_final(ebvo_ctx *ctx, int slot, int32_t *left_index, ebvo_edge *right_edge, double *ncc_score,
