@@ -303,7 +303,7 @@ def frame_loop(ctx, params, pool, nslots, steps, upload, fetch):
     return time.perf_counter() - t0, nbytes / max(1, steps)
 
 
-def boundary_bench_cpp(left, right, H, W, iters=6):
+def boundary_bench_cpp(left, right, H, W, iters=10, toed_mode="hybrid"):
     """Builds and runs tools/boundary_bench.cpp (g++ against include/ebvo/adapters.hpp and the in-tree library) as a child
     process; returns its JSON object, or None when there is no compiler / the build or the run fails."""
     import subprocess
@@ -320,7 +320,8 @@ def boundary_bench_cpp(left, right, H, W, iters=6):
             lp, rp_ = os.path.join(tmp, "l.raw"), os.path.join(tmp, "r.raw")
             np.ascontiguousarray(left).tofile(lp)
             np.ascontiguousarray(right).tofile(rp_)
-            out = subprocess.run([exe, lp, rp_, str(H), str(W), str(iters)], capture_output=True, timeout=120, check=True)
+            out = subprocess.run([exe, lp, rp_, str(H), str(W), str(iters)], capture_output=True, timeout=120, check=True,
+                                 env=dict(os.environ, EBVO_TOED_MODE=toed_mode))
             return json.loads(out.stdout.decode().strip().splitlines()[-1])
     except Exception:  # noqa: BLE001 - the Python leg stands in
         return None
@@ -793,7 +794,7 @@ def main():
                 split += np.diff(tk)
         split /= n_b
         t_b = float(split.sum())
-        boundary_cpp = boundary_bench_cpp(pool[0][0], pool[0][1], H, W)        # the same sequence through the C++ adapters
+        boundary_cpp = boundary_bench_cpp(pool[0][0], pool[0][1], H, W, toed_mode=args.toed_mode)  # the same sequence through the C++ adapters
         legs = {"dropin_final_pairs_per_s": n_drop / t_drop, "dropin_final_pairs_per_frame": final_per_pair,
                 "dropin_note": "get_Stereo_Edge_Pairs in one pass (StereoMatcherHIP::stereo_edge_pairs): a new pair from host "
                                "memory per frame, TOED + candidates + NCC, SIFT filter, both Best-Nearly-Best tests, shift, "

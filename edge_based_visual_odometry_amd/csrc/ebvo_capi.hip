@@ -374,8 +374,9 @@ extern "C" int ebvo_ctx_create(int device, int max_h, int max_w, ebvo_ctx **out)
     ctx->max_w = max_w;
     ctx->cap_edges = max_h * max_w;
     {
+        // both modes return the same bits (every TOED parity test runs in both); hybrid does a third of the work
         const char *m = getenv("EBVO_TOED_MODE");
-        ctx->toed_mode = (m && strcmp(m, "hybrid") == 0) ? EBVO_TOED_HYBRID : EBVO_TOED_STRICT;
+        ctx->toed_mode = (m && strcmp(m, "strict") == 0) ? EBVO_TOED_STRICT : EBVO_TOED_HYBRID;
     }
     int rc;
     auto fail = [&](int code) {

@@ -90,7 +90,7 @@ void ebvo_ctx_destroy(ebvo_ctx *ctx);
  *   EBVO_TOED_HYBRID  a separable fp64 screen selects a superset of the NMS maxima (tolerance 1e-6, five orders of
  *                     magnitude above the screen's error), and only those pixels are evaluated in the reference's
  *                     exact arithmetic.  Same bits out, ~3x less work; see toed_kernels.hip.
- * The default is EBVO_TOED_STRICT unless the environment variable EBVO_TOED_MODE is "hybrid". */
+ * The default is EBVO_TOED_HYBRID unless the environment variable EBVO_TOED_MODE is "strict". */
 enum
 {
     EBVO_TOED_STRICT = 0,

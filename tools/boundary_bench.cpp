@@ -65,16 +65,27 @@ int main(int argc, char **argv)
     double split[5] = {0, 0, 0, 0, 0};
     size_t n_left = 0, n_listed = 0, n_pairs = 0, n_kept = 0;
     int resident_calls = 0;
+    double toed_split[4] = {0, 0, 0, 0}; // detector call (left), copy of its result, detector call (right), copy
     std::vector<int32_t> row_ptr, col; // the caller's lists, reused from frame to frame
     for (int it = 0; it <= iters; ++it) // the first turn is untimed: it sizes the library's buffers
     {
         double tk[6];
         tk[0] = now();
         TOED->get_Third_Order_Edges(left);
+        const double t_a = now();
         std::vector<Edge> left_edges = TOED->toed_edges; // Pipeline::ProcessEdges copies the result out (src/Pipeline.cpp:28)
+        const double t_b = now();
         TOED->get_Third_Order_Edges(right);
+        const double t_c = now();
         std::vector<Edge> right_edges = TOED->toed_edges;
         tk[1] = now();
+        if (it)
+        {
+            toed_split[0] += t_a - tk[0];
+            toed_split[1] += t_b - t_a;
+            toed_split[2] += t_c - t_b;
+            toed_split[3] += tk[1] - t_c;
+        }
         auto lines = ebvo::StereoMatcherHIP<Edge>::CalculateEpipolarLine(F, left_edges);
         tk[2] = now();
         // the vectors handed back are the ones the detector produced: the search runs on the device copies
@@ -116,8 +127,10 @@ int main(int argc, char **argv)
     }
     std::printf("{\"pairs_per_s\": %.3f, \"ms\": {\"toed_both_images\": %.3f, \"epipolar_lines\": %.3f, \"candidates_staged\": %.3f, "
                 "\"host_row_filter\": %.3f, \"ncc_with_left_patches\": %.3f}, \"left_edges\": %zu, \"listed_pairs\": %zu, "
-                "\"candidate_pairs\": %zu, \"ncc_matches\": %zu, \"resident_stage_calls\": %d, \"stage_calls\": %d}\n",
+                "\"candidate_pairs\": %zu, \"ncc_matches\": %zu, \"resident_stage_calls\": %d, \"stage_calls\": %d, \"toed_ms\": {\"get_Third_Order_Edges_left\": %.3f, "
+                "\"copy_left\": %.3f, \"get_Third_Order_Edges_right\": %.3f, \"copy_right\": %.3f}}\n",
                 1.0 / total, split[0] * 1e3, split[1] * 1e3, split[2] * 1e3, split[3] * 1e3, split[4] * 1e3, n_left, n_listed,
-                n_pairs, n_kept, resident_calls, 2 * iters);
+                n_pairs, n_kept, resident_calls, 2 * iters, toed_split[0] / iters * 1e3, toed_split[1] / iters * 1e3,
+                toed_split[2] / iters * 1e3, toed_split[3] / iters * 1e3);
     return 0;
 }
