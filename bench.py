@@ -480,8 +480,9 @@ def sequence_bench(args, wl, H, W, F, device, rank, world, dist, reduce_device):
         ctx.stereo_upload(l, r, slot=k)
 
     def frame(k, first=False, stages=0):
-        """stages = 0: temporal quads through the NCC filter, what BASELINE configs[2] names; 1: every stage of
-        get_Temporal_Edge_Pairs_from_Quads (SIFT filter, both Best-Nearly-Best tests, refinement of both cameras, clustering)"""
+        """one frame, every stage waited for before the next is enqueued.  stages = 0: temporal quads through the NCC filter, what
+        BASELINE configs[2] names; 1: every stage of get_Temporal_Edge_Pairs_from_Quads (SIFT filter, both Best-Nearly-Best
+        tests, refinement of both cameras, clustering)"""
         ctx.stereo_submit(params, slot=k)
         c = ctx.stereo_wait(slot=k)
         fc, _ = ctx.stereo_finalize(calib, slot=k, use_sift=True)
@@ -491,9 +492,27 @@ def sequence_bench(args, wl, H, W, F, device, rank, world, dist, reduce_device):
         tc, _ = ctx.temporal_match(slot=k, fetch=False, stages=stages)
         return c, fc, tc
 
-    frame(0, first=True)                               # keyframe = frame 0 (src/Pipeline.cpp:133-138)
-    for k in range(min(args.warmup, n_frames)):
-        frame(k)
+    def frame_pipeline(slots, stages=0):
+        """The frames `slots` (one per step, each resident in its slot) as a software pipeline over four enqueue-only steps --
+        A: TOED + candidates + NCC submitted; B: its counts read, the stereo chain enqueued (ebvo_stereo_finalize_submit); C: the
+        chain's counts read, the temporal stages enqueued (ebvo_temporal_match_submit); D: their counts read -- so the host
+        never waits for the frame it has just enqueued and the chains of up to four frames overlap on the device.  Returns the
+        per-frame (stereo counts, chain counts, temporal counts), in order."""
+        n = len(slots)
+        res = [[None, None, None] for _ in range(n)]
+        for i in range(n + 3):
+            if i < n:
+                assert slots[i] not in slots[max(0, i - 3):i], "a slot re-enters the pipeline before it has left it"
+                ctx.stereo_submit(params, slot=slots[i])                                      # A
+            if 0 <= i - 1 < n:
+                res[i - 1][0] = ctx.stereo_wait(slot=slots[i - 1])                            # B
+                ctx.stereo_finalize_submit(calib, slot=slots[i - 1], use_sift=True)
+            if 0 <= i - 2 < n:
+                res[i - 2][1] = ctx.stereo_finalize_wait(slot=slots[i - 2], fetch=False)[0]   # C
+                ctx.temporal_match_submit(slot=slots[i - 2], stages=stages)
+            if 0 <= i - 3 < n:
+                res[i - 3][2] = ctx.temporal_match_wait(slot=slots[i - 3], fetch=False)[0]    # D
+        return [tuple(r) for r in res]
 
     def barrier():
         torch.cuda.synchronize()
@@ -504,8 +523,7 @@ def sequence_bench(args, wl, H, W, F, device, rank, world, dist, reduce_device):
     barrier()
     t0 = time.perf_counter()
     totals = dict(pairs=0, matches=0, final=0, quads=0, kept=0)
-    for step in range(args.steps):
-        c, fc, tc = frame(step % n_frames)
+    for c, fc, tc in frame_pipeline([step % n_frames for step in range(args.steps)]):
         totals["pairs"] += c.n_pairs
         totals["matches"] += c.n_matches
         totals["final"] += fc["n_final"]
@@ -531,9 +549,13 @@ def sequence_bench(args, wl, H, W, F, device, rank, world, dist, reduce_device):
         n_full = min(16, n_frames)
         frame(1, stages=1)
         t1 = time.perf_counter()
-        for k in range(n_full):
-            _, _, tcf = frame(k % n_frames, stages=1)
+        tcf = frame_pipeline([k % n_frames for k in range(n_full)], stages=1)[-1][2]
         t_full = (time.perf_counter() - t1) / n_full
+        # ... and frame after frame, every stage waited for (what the loop was before the enqueue-only chains)
+        t1 = time.perf_counter()
+        for k in range(n_full):
+            frame(k % n_frames)
+        t_serial = (time.perf_counter() - t1) / n_full
         # the same frames through T contexts driven by T host threads (the library's model: one ebvo_ctx per host thread):
         # a frame is a host-sequenced chain of ~180 short launches, so several chains share the device well
         threaded = {}
@@ -560,6 +582,10 @@ def sequence_bench(args, wl, H, W, F, device, rank, world, dist, reduce_device):
             "kernels": kernels,
             "frames_per_s_by_host_threads": threaded,
             "full_temporal_chain_frames_per_s": 1.0 / t_full,
+            "one_frame_at_a_time_frames_per_s": 1.0 / t_serial,
+            "pipeline_note": "value: the frame loop as a software pipeline of enqueue-only steps (TOED + matching | stereo chain | "
+                             "temporal stages | counts), up to four frames in flight in their own slots from one host thread and "
+                             "one context; one_frame_at_a_time: every stage waited for before the next is enqueued",
             "full_temporal_chain_note": "the same frame loop with the rest of get_Temporal_Edge_Pairs_from_Quads after the NCC "
                                         "filter (SIFT filter, Best-Nearly-Best on NCC and SIFT scores, photometric refinement "
                                         "of both cameras, edge clustering): %d final quads per frame" % tcf["n_final"],

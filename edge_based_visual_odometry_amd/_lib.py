@@ -45,7 +45,7 @@ ABI_SYMBOLS = (
     "ebvo_debug_set", "ebvo_stereo_fetch_begin", "ebvo_stereo_fetch_end",
     "ebvo_undistort", "ebvo_stereo_set_undistort", "ebvo_sift_descriptors", "ebvo_sift_min_distances",
     "ebvo_toed_resident", "ebvo_epi_candidates_resident", "ebvo_ncc_pairs_resident",
-    "ebvo_temporal_default_params", "ebvo_temporal_set_keyframe", "ebvo_temporal_match", "ebvo_temporal_fetch", "ebvo_temporal_fetch_final",
+    "ebvo_temporal_default_params", "ebvo_temporal_set_keyframe", "ebvo_temporal_match", "ebvo_temporal_match_submit", "ebvo_temporal_match_wait", "ebvo_temporal_fetch", "ebvo_temporal_fetch_final",
 )
 
 
@@ -198,6 +198,8 @@ def load_library() -> C.CDLL:
     lib.ebvo_temporal_default_params.argtypes = [C.POINTER(TemporalParams)]
     lib.ebvo_temporal_set_keyframe.argtypes = [vp, i32]
     lib.ebvo_temporal_match.argtypes = [vp, i32, C.POINTER(TemporalParams), C.POINTER(TemporalCounts)]
+    lib.ebvo_temporal_match_submit.argtypes = [vp, i32, C.POINTER(TemporalParams)]
+    lib.ebvo_temporal_match_wait.argtypes = [vp, i32, C.POINTER(TemporalCounts)]
     lib.ebvo_temporal_fetch.argtypes = [vp, i32, vp, vp, vp, vp, vp]
     lib.ebvo_temporal_fetch_final.restype = i32
     lib.ebvo_temporal_fetch_final.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]

@@ -542,15 +542,28 @@ class Context:
     def temporal_set_keyframe(self, slot: int = 0):
         self._check(self.lib.ebvo_temporal_set_keyframe(self._ctx, slot), "ebvo_temporal_set_keyframe")
 
-    def temporal_match(self, slot: int = 0, fetch: bool = True, **kw):
+    def temporal_match_submit(self, slot: int = 0, **kw):
+        """Enqueue the candidate + NCC stages of the slot's final mates against the keyframe (ebvo_temporal_match_submit)."""
         p = _lib.TemporalParams()
         self.lib.ebvo_temporal_default_params(C.byref(p))
         for k, v in kw.items():
             setattr(p, k, v)
+        self._check(self.lib.ebvo_temporal_match_submit(self._ctx, slot, C.byref(p)), "ebvo_temporal_match_submit")
+        self._tq_stages = getattr(self, "_tq_stages", {})
+        self._tq_stages[slot] = int(p.stages)
+
+    def temporal_match_wait(self, slot: int = 0, fetch: bool = True):
         c = _lib.TemporalCounts()
-        self._check(self.lib.ebvo_temporal_match(self._ctx, slot, C.byref(p), C.byref(c)), "ebvo_temporal_match")
+        self._check(self.lib.ebvo_temporal_match_wait(self._ctx, slot, C.byref(c)), "ebvo_temporal_match_wait")
+        return self._temporal_results(slot, c, self._tq_stages.get(slot, 0), fetch)
+
+    def temporal_match(self, slot: int = 0, fetch: bool = True, **kw):
+        self.temporal_match_submit(slot, **kw)
+        return self.temporal_match_wait(slot, fetch)
+
+    def _temporal_results(self, slot, c, stages, fetch):
         counts = dict(n_kf=c.n_kf, n_cf=c.n_cf, n_candidates=c.n_candidates, n_kept=c.n_kept)
-        if p.stages:
+        if stages:
             counts.update(n_sift=c.n_sift, n_bnb_ncc=c.n_bnb_ncc, n_bnb_sift=c.n_bnb_sift, n_refined_valid=c.n_refined_valid,
                           n_final=c.n_final)
         if not fetch:
@@ -560,7 +573,7 @@ class Context:
                    sim_right=np.zeros(n), keep=np.zeros(n, dtype=np.uint8))
         self._check(self.lib.ebvo_temporal_fetch(self._ctx, slot, ptr(out["row_ptr"]), ptr(out["col_idx"]), ptr(out["sim_left"]),
                                                  ptr(out["sim_right"]), ptr(out["keep"])), "ebvo_temporal_fetch")
-        if p.stages:
+        if stages:
             m = c.n_final
             fin = dict(row_ptr=np.zeros(c.n_kf + 1, dtype=np.int32), cf_index=np.zeros(m, dtype=np.int32),
                        left=np.zeros(m, dtype=EDGE_DTYPE), right=np.zeros(m, dtype=EDGE_DTYPE), ncc_left=np.zeros(m),

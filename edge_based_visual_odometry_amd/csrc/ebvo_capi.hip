@@ -191,6 +191,11 @@ static void slot_destroy(Slot *s)
         (void)hipHostFree(s->h_fin_tot);
     if (s->ev_fin)
         (void)hipEventDestroy(s->ev_fin);
+    (void)hipFree(s->d_tq_tot);
+    if (s->h_tq_tot)
+        (void)hipHostFree(s->h_tq_tot);
+    if (s->ev_tq)
+        (void)hipEventDestroy(s->ev_tq);
     if (s->own_stream)
         (void)hipStreamDestroy(s->own_stream);
     delete s;
@@ -269,6 +274,9 @@ static int slot_create(ebvo_ctx *ctx, Slot **out)
     CK(hipMalloc(&s->d_fin_tot, sizeof(int32_t) * 8));
     CK(hipHostMalloc(&s->h_fin_tot, sizeof(int32_t) * 8));
     CK(hipEventCreateWithFlags(&s->ev_fin, hipEventDisableTiming));
+    CK(hipMalloc(&s->d_tq_tot, sizeof(unsigned long long) * 2));
+    CK(hipHostMalloc(&s->h_tq_tot, sizeof(unsigned long long) * 2));
+    CK(hipEventCreateWithFlags(&s->ev_tq, hipEventDisableTiming));
     CK(hipStreamSynchronize(s->stream));
 #undef CK
     *out = s;
@@ -425,9 +433,9 @@ static int upload_image(ebvo_ctx *ctx, Slot &s, int k, const uint8_t *img, int h
 static int host_slot(ebvo_ctx *ctx, Slot **out)
 {
     Slot &s = *ctx->slots[0];
-    if (s.in_flight || s.fin_in_flight)
+    if (s.in_flight || s.fin_in_flight || s.tq_in_flight)
     {
-        ctx->last_error = "slot 0 has a submitted pair in flight; call ebvo_stereo_wait / ebvo_stereo_finalize_wait first";
+        ctx->last_error = "slot 0 has submitted work in flight; call ebvo_stereo_wait / ebvo_stereo_finalize_wait / ebvo_temporal_match_wait first";
         return EBVO_ERR_STATE;
     }
     if (int rc = drain_fetch(ctx, s)) // result copies of the previous pair (copy stream) still read the slot's buffers
@@ -1021,7 +1029,7 @@ extern "C" int ebvo_stereo_upload_slot(ebvo_ctx *ctx, int slot, const uint8_t *i
     if ((rc = check_size(ctx, h, w)))
         return rc;
     Slot &s = *sp;
-    if (s.in_flight || s.fin_in_flight)
+    if (s.in_flight || s.fin_in_flight || s.tq_in_flight)
         return EBVO_ERR_STATE;
     s.have_pair = s.have_run = s.have_refined = s.have_final = false; // results of the previous pair are gone
     if (slot == 0)
@@ -1111,7 +1119,7 @@ extern "C" int ebvo_stereo_submit(ebvo_ctx *ctx, int slot, const ebvo_stereo_par
     if (!p || (p->stage_mask & ~EBVO_STAGE_ALL) || p->stage_mask == 0 || get_slot(ctx, slot, &sp))
         return EBVO_ERR_ARG;
     Slot &s = *sp;
-    if (!s.have_pair || s.in_flight || s.fin_in_flight)
+    if (!s.have_pair || s.in_flight || s.fin_in_flight || s.tq_in_flight)
         return EBVO_ERR_STATE;
     EBVO_HIP(ctx, hipSetDevice(ctx->device));
     int rc;
@@ -2158,7 +2166,7 @@ extern "C" int ebvo_stereo_finalize_submit(ebvo_ctx *ctx, int slot, const ebvo_f
         !(p->gn.huber_delta > 0) || (p->use_sift && (!(p->sift_thr > 0) || !(p->bnb_sift >= 0))) || get_slot(ctx, slot, &sp))
         return EBVO_ERR_ARG;
     Slot &s = *sp;
-    if (!s.have_run || s.in_flight || s.fin_in_flight)
+    if (!s.have_run || s.in_flight || s.fin_in_flight || s.tq_in_flight)
         return EBVO_ERR_STATE;
     EBVO_HIP(ctx, hipSetDevice(ctx->device));
     if (int rc_f = drain_fetch(ctx, s))
@@ -2477,7 +2485,7 @@ extern "C" int ebvo_temporal_set_keyframe(ebvo_ctx *ctx, int slot)
     if (get_slot(ctx, slot, &sp))
         return EBVO_ERR_ARG;
     Slot &s = *sp;
-    if (!s.have_final || s.in_flight)
+    if (!s.have_final || s.in_flight || s.tq_in_flight)
         return EBVO_ERR_STATE;
     EBVO_HIP(ctx, hipSetDevice(ctx->device));
     if (int rc_f = drain_fetch(ctx, s))
@@ -2750,47 +2758,20 @@ static int temporal_chain(ebvo_ctx *ctx, Slot &s, const ebvo_temporal_params &P,
     return EBVO_OK;
 }
 
-extern "C" int ebvo_temporal_match(ebvo_ctx *ctx, int slot, const ebvo_temporal_params *p, ebvo_temporal_counts *counts)
+// Candidate quads + NCC of the slot's final mates against the keyframe's.  The buffers indexed by candidate quad are sized
+// for a CAPACITY (s.tq_cap: what the last frame needed, with headroom), every kernel takes the number of quads from the
+// device (the last entry of the scanned row offsets), and the two counts -- candidates, kept -- travel to page-locked memory
+// behind the last kernel: no host synchronisation between the stages.  Only a first frame (no capacity yet) or a frame
+// with more candidates than the capacity reads the count back first.
+static int temporal_stage0_enqueue(ebvo_ctx *ctx, Slot &s, const ebvo_temporal_params *p, bool size_first)
 {
-    Slot *sp;
-    if (!p || !counts || p->cell_size < 1 || !(p->grid_radius >= 0) || !(p->orient_thr_deg >= 0) || (p->stages & ~1) ||
-        (p->stages && (!(p->sift_thr > 0) || !(p->bnb_ncc >= 0) || !(p->bnb_sift >= 0) || p->gn.max_iter < 1 || !(p->gn.tol >= 0) ||
-                       !(p->gn.huber_delta > 0))) ||
-        get_slot(ctx, slot, &sp))
-        return EBVO_ERR_ARG;
-    Slot &s = *sp;
-    if (!s.have_final || s.in_flight || ctx->kf_n < 0)
-        return EBVO_ERR_STATE;
-    EBVO_HIP(ctx, hipSetDevice(ctx->device));
-    if (int rc_f = drain_fetch(ctx, s))
-        return rc_f;
-    memset(counts, 0, sizeof *counts);
     const int n_kf = ctx->kf_n, n_cf = s.n_final, h = s.cur_h, w = s.cur_w;
-    counts->n_kf = n_kf;
-    counts->n_cf = n_cf;
-    s.tq_n = 0;
-    s.tq_n_kf = n_kf;
     int rc;
     const size_t nk1 = (size_t)n_kf + 1;
     if ((rc = ebvo_grow(ctx, s, s.tq_i32, sizeof(int32_t) * (2 * nk1 + 2) + 16)))
         return rc;
     int32_t *cnt = (int32_t *)s.tq_i32.p, *rp = cnt + nk1;
-    unsigned long long *d_kept = (unsigned long long *)(((uintptr_t)(rp + nk1) + 7) & ~(uintptr_t)7); // 8-byte aligned counter
     EBVO_HIP(ctx, hipMemsetAsync(cnt, 0, sizeof(int32_t) * 2 * nk1, s.stream));
-    s.tq_final = Slot::TqFinal();
-    auto empty_final = [&]() { // no quads at all: the chain's result is an empty list over the (zeroed) row offsets
-        if (p->stages)
-        {
-            s.tq_final.rp = rp;
-            s.tq_final.n = 0;
-        }
-    };
-    if (n_kf == 0 || n_cf == 0)
-    {
-        EBVO_HIP(ctx, hipStreamSynchronize(s.stream));
-        empty_final();
-        return EBVO_OK;
-    }
     const ebvo_edge *cfL, *cfR;
     final_mates(s, &cfL, &cfR);
     const int cell = p->cell_size, gw = (w + cell - 1) / cell, gh = (h + cell - 1) / cell;
@@ -2803,44 +2784,156 @@ extern "C" int ebvo_temporal_match(ebvo_ctx *ctx, int slot, const ebvo_temporal_
                                                 p->orient_thr_deg, cnt, nullptr, nullptr, 0)) ||
         (rc = ebvo_device_scan(ctx, s, cnt, rp, n_kf, nullptr, 1, n_kf + 1)))
         return rc;
-    int32_t nq = 0;
-    if ((rc = read_i32(ctx, s, rp + n_kf, &nq)))
-        return rc;
-    counts->n_candidates = nq;
-    s.tq_n = nq;
-    if (nq == 0)
+    if (size_first)
     {
-        empty_final(); // (rp holds the scanned counts: all zero)
-        return EBVO_OK;
+        int32_t nq = 0;
+        if ((rc = read_i32(ctx, s, rp + n_kf, &nq)))
+            return rc;
+        s.tq_cap = (int64_t)nq + nq / 4 + 1024;
     }
-    const size_t nqz = (size_t)nq, ncz = (size_t)n_cf;
-    if ((rc = ebvo_grow(ctx, s, s.tq_cols, sizeof(int32_t) * 2 * nqz)) || (rc = ebvo_grow(ctx, s, s.tq_f64, sizeof(double) * 2 * nqz)) ||
-        (rc = ebvo_grow(ctx, s, s.tq_u8, 2 * ncz + nqz + 64)) || (rc = ebvo_grow(ctx, s, s.patches_raw, sizeof(float) * 98 * ncz)) ||
+    const size_t capz = (size_t)s.tq_cap, ncz = (size_t)n_cf;
+    if ((rc = ebvo_grow(ctx, s, s.tq_cols, sizeof(int32_t) * 2 * capz)) || (rc = ebvo_grow(ctx, s, s.tq_f64, sizeof(double) * 2 * capz)) ||
+        (rc = ebvo_grow(ctx, s, s.tq_u8, 2 * ncz + capz + 64)) || (rc = ebvo_grow(ctx, s, s.patches_raw, sizeof(float) * 98 * ncz)) ||
         (rc = ebvo_grow(ctx, s, s.patches_norm, sizeof(float) * 98 * ncz)) || (rc = ebvo_grow(ctx, s, s.patches_flag, 2 * ncz)))
         return rc;
-    int32_t *col = (int32_t *)s.tq_cols.p, *quad_kf = col + nqz;
-    double *sim_l = (double *)s.tq_f64.p, *sim_r = sim_l + nqz;
+    int32_t *col = (int32_t *)s.tq_cols.p, *quad_kf = col + capz;
+    double *sim_l = (double *)s.tq_f64.p, *sim_r = sim_l + capz;
     uint8_t *flagR = (uint8_t *)s.tq_u8.p, *keep = flagR + ((2 * ncz + 63) & ~(size_t)63);
     float *cfLn = (float *)s.patches_norm.p, *cfRn = (float *)s.patches_raw.p;
     uint8_t *cfLf = (uint8_t *)s.patches_flag.p;
+    const int32_t *d_nq = rp + n_kf;
     if ((rc = match_temporal_candidates_enqueue(ctx, s, ctx->kf_L, ctx->kf_R, n_kf, cfL, cfR, grid, n_cf, cell, sr, gw, gh,
-                                                p->orient_thr_deg, nullptr, rp, col, nq)) ||
-        (rc = match_expand_rows_enqueue(ctx, s, rp, n_kf, nq, quad_kf)) ||
+                                                p->orient_thr_deg, nullptr, rp, col, s.tq_cap)) ||
+        (rc = match_expand_rows_enqueue(ctx, s, rp, n_kf, s.tq_cap, quad_kf)) ||
         (rc = match_patches_enqueue(ctx, s, ncc_img(s, 0), h, w, w, cfL, n_cf, nullptr, 0, nullptr, cfLn, cfLf)) ||
         (rc = match_patches_enqueue(ctx, s, s.im[1].img, h, w, w, cfR, n_cf, nullptr, 0, nullptr, cfRn, flagR)) ||
         (rc = match_ncc_quads_indexed_enqueue(ctx, s, ctx->kf_Ln, ctx->kf_Lf, ctx->kf_Rn, ctx->kf_Rf, cfLn, cfLf, cfRn, flagR, quad_kf,
-                                              col, nq, p->ncc_thr, sim_l, sim_r, keep)) ||
-        (rc = match_count_flags_enqueue(ctx, s, keep, nq, d_kept)))
+                                              col, s.tq_cap, p->ncc_thr, sim_l, sim_r, keep, d_nq)) ||
+        (rc = match_count_flags_enqueue(ctx, s, keep, s.tq_cap, s.d_tq_tot + 1, d_nq)))
         return rc;
-    unsigned long long kept = 0;
-    EBVO_HIP(ctx, hipMemcpyAsync(s.h_result, d_kept, sizeof kept, hipMemcpyDeviceToHost, s.stream));
-    EBVO_HIP(ctx, hipStreamSynchronize(s.stream));
-    memcpy(&kept, s.h_result, sizeof kept);
-    counts->n_kept = (int64_t)kept;
-    s.tq_final.n = -1;
-    if (p->stages == 0)
+    // candidate count (an int32 of the row offsets) widened into the first word on the device side of the copy below
+    EBVO_HIP(ctx, hipMemsetAsync(s.d_tq_tot, 0, sizeof(unsigned long long), s.stream));
+    EBVO_HIP(ctx, hipMemcpyAsync(s.d_tq_tot, d_nq, sizeof(int32_t), hipMemcpyDeviceToDevice, s.stream)); // little-endian low word
+    EBVO_HIP(ctx, hipMemcpyAsync(s.h_tq_tot, s.d_tq_tot, sizeof(unsigned long long) * 2, hipMemcpyDeviceToHost, s.stream));
+    EBVO_HIP(ctx, hipEventRecord(s.ev_tq, s.stream));
+    return EBVO_OK;
+}
+
+extern "C" int ebvo_temporal_match_submit(ebvo_ctx *ctx, int slot, const ebvo_temporal_params *p)
+{
+    Slot *sp;
+    if (!p || p->cell_size < 1 || !(p->grid_radius >= 0) || !(p->orient_thr_deg >= 0) || (p->stages & ~1) ||
+        (p->stages && (!(p->sift_thr > 0) || !(p->bnb_ncc >= 0) || !(p->bnb_sift >= 0) || p->gn.max_iter < 1 || !(p->gn.tol >= 0) ||
+                       !(p->gn.huber_delta > 0))) ||
+        get_slot(ctx, slot, &sp))
+        return EBVO_ERR_ARG;
+    Slot &s = *sp;
+    if (!s.have_final || s.in_flight || s.fin_in_flight || s.tq_in_flight || ctx->kf_n < 0)
+        return EBVO_ERR_STATE;
+    EBVO_HIP(ctx, hipSetDevice(ctx->device));
+    if (int rc_f = drain_fetch(ctx, s))
+        return rc_f;
+    s.tq_n = -1;
+    s.tq_n_kf = ctx->kf_n;
+    s.tq_final = Slot::TqFinal();
+    s.tq_params = *p;
+    s.tq_empty = ctx->kf_n == 0 || s.n_final == 0;
+    s.h_tq_tot[0] = s.h_tq_tot[1] = 0;
+    if (s.tq_empty)
+    {
+        // no quads at all: zeroed row offsets, nothing else to run
+        const size_t nk1 = (size_t)ctx->kf_n + 1;
+        int rc = ebvo_grow(ctx, s, s.tq_i32, sizeof(int32_t) * (2 * nk1 + 2) + 16);
+        if (rc)
+            return rc;
+        EBVO_HIP(ctx, hipMemsetAsync(s.tq_i32.p, 0, sizeof(int32_t) * 2 * nk1, s.stream));
+        EBVO_HIP(ctx, hipEventRecord(s.ev_tq, s.stream));
+        s.tq_in_flight = true;
         return EBVO_OK;
-    return temporal_chain(ctx, s, *p, rp, col, quad_kf, sim_l, keep, n_kf, cfL, cfR, n_cf, (int64_t)kept, counts);
+    }
+    int rc = temporal_stage0_enqueue(ctx, s, p, s.tq_cap == 0);
+    if (rc)
+    {
+        (void)hipStreamSynchronize(s.stream);
+        return rc;
+    }
+    s.tq_in_flight = true;
+    return EBVO_OK;
+}
+
+extern "C" int ebvo_temporal_match_wait(ebvo_ctx *ctx, int slot, ebvo_temporal_counts *counts)
+{
+    Slot *sp;
+    if (!counts || get_slot(ctx, slot, &sp))
+        return EBVO_ERR_ARG;
+    Slot &s = *sp;
+    if (!s.tq_in_flight)
+        return EBVO_ERR_STATE;
+    EBVO_HIP(ctx, hipSetDevice(ctx->device));
+    s.tq_in_flight = false;
+    memset(counts, 0, sizeof *counts);
+    const ebvo_temporal_params &P = s.tq_params;
+    const int n_kf = s.tq_n_kf, n_cf = s.n_final;
+    counts->n_kf = n_kf;
+    counts->n_cf = n_cf;
+    EBVO_HIP(ctx, hipEventSynchronize(s.ev_tq));
+    const size_t nk1 = (size_t)n_kf + 1;
+    int32_t *rp = (int32_t *)s.tq_i32.p + nk1;
+    if (s.tq_empty)
+    {
+        s.tq_n = 0;
+        if (P.stages)
+        {
+            s.tq_final.rp = rp;
+            s.tq_final.n = 0;
+        }
+        return EBVO_OK;
+    }
+    int64_t nq = (int64_t)s.h_tq_tot[0];
+    if (nq > s.tq_cap)
+    {
+        // more candidate quads than the buffers were sized for: size them for this frame and run the stages again
+        s.tq_cap = 0;
+        int rc = temporal_stage0_enqueue(ctx, s, &P, true);
+        if (rc)
+        {
+            (void)hipStreamSynchronize(s.stream);
+            return rc;
+        }
+        EBVO_HIP(ctx, hipEventSynchronize(s.ev_tq));
+        nq = (int64_t)s.h_tq_tot[0];
+    }
+    const int64_t kept = (int64_t)s.h_tq_tot[1];
+    counts->n_candidates = nq;
+    counts->n_kept = kept;
+    s.tq_n = nq;
+    s.tq_final.n = -1;
+    if (nq == 0)
+    {
+        if (P.stages)
+        {
+            s.tq_final.rp = rp; // the scanned counts: all zero
+            s.tq_final.n = 0;
+        }
+        return EBVO_OK;
+    }
+    if (P.stages == 0)
+        return EBVO_OK;
+    const size_t capz = (size_t)s.tq_cap, ncz = (size_t)n_cf;
+    const ebvo_edge *cfL, *cfR;
+    final_mates(s, &cfL, &cfR);
+    const int32_t *col = (const int32_t *)s.tq_cols.p, *quad_kf = col + capz;
+    const double *sim_l = (const double *)s.tq_f64.p;
+    const uint8_t *keep = (const uint8_t *)s.tq_u8.p + ((2 * ncz + 63) & ~(size_t)63);
+    return temporal_chain(ctx, s, P, rp, col, quad_kf, sim_l, keep, n_kf, cfL, cfR, n_cf, kept, counts);
+}
+
+extern "C" int ebvo_temporal_match(ebvo_ctx *ctx, int slot, const ebvo_temporal_params *p, ebvo_temporal_counts *counts)
+{
+    if (!counts)
+        return EBVO_ERR_ARG;
+    int rc = ebvo_temporal_match_submit(ctx, slot, p);
+    return rc ? rc : ebvo_temporal_match_wait(ctx, slot, counts);
 }
 
 extern "C" int ebvo_temporal_fetch_final(ebvo_ctx *ctx, int slot, int32_t *row_ptr, int32_t *cf_index, ebvo_edge *left,
@@ -2851,7 +2944,7 @@ extern "C" int ebvo_temporal_fetch_final(ebvo_ctx *ctx, int slot, int32_t *row_p
     if (get_slot(ctx, slot, &sp))
         return EBVO_ERR_ARG;
     Slot &s = *sp;
-    if (s.tq_final.n < 0 || s.in_flight)
+    if (s.tq_final.n < 0 || s.in_flight || s.tq_in_flight)
         return EBVO_ERR_STATE;
     EBVO_HIP(ctx, hipSetDevice(ctx->device));
     const Slot::TqFinal &F = s.tq_final;
@@ -2884,10 +2977,10 @@ extern "C" int ebvo_temporal_fetch(ebvo_ctx *ctx, int slot, int32_t *row_ptr, in
     if (get_slot(ctx, slot, &sp))
         return EBVO_ERR_ARG;
     Slot &s = *sp;
-    if (s.tq_n < 0 || s.in_flight)
+    if (s.tq_n < 0 || s.in_flight || s.tq_in_flight)
         return EBVO_ERR_STATE;
     EBVO_HIP(ctx, hipSetDevice(ctx->device));
-    const size_t nk1 = (size_t)s.tq_n_kf + 1, nq = (size_t)s.tq_n, ncz = (size_t)s.n_final;
+    const size_t nk1 = (size_t)s.tq_n_kf + 1, nq = (size_t)s.tq_n, ncz = (size_t)s.n_final, capz = (size_t)s.tq_cap;
     hipStream_t st = s.stream;
     if (row_ptr)
         EBVO_HIP(ctx, hipMemcpyAsync(row_ptr, (const int32_t *)s.tq_i32.p + nk1, sizeof(int32_t) * nk1, hipMemcpyDeviceToHost, st));
@@ -2898,7 +2991,7 @@ extern "C" int ebvo_temporal_fetch(ebvo_ctx *ctx, int slot, int32_t *row_ptr, in
         if (sim_left)
             EBVO_HIP(ctx, hipMemcpyAsync(sim_left, s.tq_f64.p, sizeof(double) * nq, hipMemcpyDeviceToHost, st));
         if (sim_right)
-            EBVO_HIP(ctx, hipMemcpyAsync(sim_right, (const double *)s.tq_f64.p + nq, sizeof(double) * nq, hipMemcpyDeviceToHost, st));
+            EBVO_HIP(ctx, hipMemcpyAsync(sim_right, (const double *)s.tq_f64.p + capz, sizeof(double) * nq, hipMemcpyDeviceToHost, st));
         if (keep)
             EBVO_HIP(ctx, hipMemcpyAsync(keep, (const uint8_t *)s.tq_u8.p + ((2 * ncz + 63) & ~(size_t)63), nq, hipMemcpyDeviceToHost, st));
     }
@@ -3062,6 +3155,12 @@ extern "C" int ebvo_debug_set(ebvo_ctx *ctx, int key, int value)
         ctx->gn_no_rows = value; // refinement launch layout (same bits either way, tests/test_gpu_refine.py)
     else if (key == 5)
         ctx->gn_rows_below = value;
+    else if (key == 6 && value >= 1)
+    {
+        for (Slot *sl : ctx->slots) // test hook: the next temporal match of every slot finds its quad buffers too small
+            if (sl->tq_cap > 0 && !sl->tq_in_flight)
+                sl->tq_cap = value;
+    }
     else
         return EBVO_ERR_ARG;
     return EBVO_OK;

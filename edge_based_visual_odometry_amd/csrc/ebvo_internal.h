@@ -130,6 +130,13 @@ struct Slot
     } tq_final;
     int tq_n_kf = 0;
     int64_t tq_n = -1;                       // -1: none
+    // ebvo_temporal_match_submit / _wait: the candidate and NCC stages are enqueued for a capacity of quads (what the last
+    // frame needed, with headroom); the two counts travel behind the last kernel
+    int64_t tq_cap = 0;
+    unsigned long long *d_tq_tot = nullptr, *h_tq_tot = nullptr; // [2] device / page-locked: candidate quads, kept quads
+    hipEvent_t ev_tq = nullptr;
+    bool tq_in_flight = false, tq_empty = false;
+    ebvo_temporal_params tq_params{};
     GrowBuf sift_img, sift_desc, sift_f32, sift_dist; // SIFT: blurred levels, descriptor banks, per-pair distances (sift_kernels.hip)
     GrowBuf fin_i32, fin_edges, fin_f64, fin_u8, fin_out; // ebvo_stereo_finalize: CSRs, candidate lists, scores, final rows
     int n_final = 0;
@@ -313,11 +320,13 @@ int match_temporal_candidates_enqueue(ebvo_ctx *ctx, Slot &s, const ebvo_edge *d
                                       const ebvo_edge *d_cfL, const ebvo_edge *d_cfR, const void *d_grid, int n_cf, int cell,
                                       int sr, int gw, int gh, double orient_thr, int32_t *d_cnt, const int32_t *d_row_ptr,
                                       int32_t *d_col_idx, int64_t cap);
-int match_count_flags_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_flags, int64_t n, unsigned long long *d_out);
+int match_count_flags_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_flags, int64_t n, unsigned long long *d_out,
+                              const int32_t *d_n = nullptr);
 int match_ncc_quads_indexed_enqueue(ebvo_ctx *ctx, Slot &s, const float *kfLn, const uint8_t *kfLf, const float *kfRn,
                                     const uint8_t *kfRf, const float *cfLn, const uint8_t *cfLf, const float *cfRn,
                                     const uint8_t *cfRf, const int32_t *d_quad_kf, const int32_t *d_quad_cf, int64_t n_quads,
-                                    double thr, double *d_sim_left, double *d_sim_right, uint8_t *d_keep);
+                                    double thr, double *d_sim_left, double *d_sim_right, uint8_t *d_keep,
+                                    const int32_t *d_n_quads = nullptr);
 // exclusive scan of n (+ n_add) int32 on the slot's stream; n_dev != nullptr: the count lives on the device, cap_n bounds it
 // zero n (<= EBVO_CLEAR_MAX) int32 arrays with one launch
 int ebvo_clear_enqueue(ebvo_ctx *ctx, Slot &s, int32_t *const ptrs[], const int counts[], int n);

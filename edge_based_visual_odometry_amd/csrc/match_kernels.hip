@@ -1510,10 +1510,11 @@ __global__ __launch_bounds__(256) void ncc_quads_indexed_kernel(const float *__r
                                                                 const float *__restrict__ cfLn, const uint8_t *__restrict__ cfLf,
                                                                 const float *__restrict__ cfRn, const uint8_t *__restrict__ cfRf,
                                                                 const int32_t *__restrict__ quad_kf,
-                                                                const int32_t *__restrict__ quad_cf, int64_t n_quads, double thr,
+                                                                const int32_t *__restrict__ quad_cf, DevCount nqd, double thr,
                                                                 double *__restrict__ sim_left, double *__restrict__ sim_right,
                                                                 uint8_t *__restrict__ keep)
 {
+    const int64_t n_quads = devcount(nqd);
     const int64_t groups = ((int64_t)gridDim.x * blockDim.x) >> 4;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int g = (int)(t & 15), img = g >> 3, row = g & 7;
@@ -1565,8 +1566,9 @@ __global__ __launch_bounds__(256) void ncc_quads_indexed_kernel(const float *__r
     }
 }
 
-__global__ void count_flags_kernel(const uint8_t *__restrict__ f, int64_t n, unsigned long long *__restrict__ out)
+__global__ void count_flags_kernel(const uint8_t *__restrict__ f, DevCount nd, unsigned long long *__restrict__ out)
 {
+    const int64_t n = devcount(nd);
     unsigned long long c = 0;
     for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x)
         c += f[k] ? 1 : 0;
@@ -2071,11 +2073,13 @@ int match_temporal_candidates_enqueue(ebvo_ctx *ctx, Slot &s, const ebvo_edge *d
     return EBVO_OK;
 }
 
-int match_count_flags_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_flags, int64_t n, unsigned long long *d_out)
+int match_count_flags_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_flags, int64_t n, unsigned long long *d_out,
+                              const int32_t *d_n)
 {
     EBVO_HIP(ctx, hipMemsetAsync(d_out, 0, sizeof(unsigned long long), s.stream));
     if (n > 0)
-        hipLaunchKernelGGL(count_flags_kernel, dim3(blocks_for(n, 256, 1024)), dim3(256), 0, s.stream, d_flags, n, d_out);
+        hipLaunchKernelGGL(count_flags_kernel, dim3(blocks_for(n, 256, 1024)), dim3(256), 0, s.stream, d_flags, DevCount{n, d_n},
+                           d_out);
     EBVO_HIP(ctx, hipGetLastError());
     return EBVO_OK;
 }
@@ -2083,13 +2087,14 @@ int match_count_flags_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_flags, in
 int match_ncc_quads_indexed_enqueue(ebvo_ctx *ctx, Slot &s, const float *kfLn, const uint8_t *kfLf, const float *kfRn,
                                     const uint8_t *kfRf, const float *cfLn, const uint8_t *cfLf, const float *cfRn,
                                     const uint8_t *cfRf, const int32_t *d_quad_kf, const int32_t *d_quad_cf, int64_t n_quads,
-                                    double thr, double *d_sim_left, double *d_sim_right, uint8_t *d_keep)
+                                    double thr, double *d_sim_left, double *d_sim_right, uint8_t *d_keep, const int32_t *d_n_quads)
 {
     if (n_quads <= 0)
         return EBVO_OK;
     ProfScope ps(ctx, s, K_NCC_STORED);
     hipLaunchKernelGGL(ncc_quads_indexed_kernel, dim3(blocks_for(n_quads * 16, 256, 8192)), dim3(256), 0, s.stream, kfLn, kfLf, kfRn,
-                       kfRf, cfLn, cfLf, cfRn, cfRf, d_quad_kf, d_quad_cf, n_quads, thr, d_sim_left, d_sim_right, d_keep);
+                       kfRf, cfLn, cfLf, cfRn, cfRf, d_quad_kf, d_quad_cf, DevCount{n_quads, d_n_quads}, thr, d_sim_left, d_sim_right,
+                       d_keep);
     EBVO_HIP(ctx, hipGetLastError());
     return EBVO_OK;
 }

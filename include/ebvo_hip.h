@@ -512,6 +512,11 @@ void ebvo_temporal_default_params(ebvo_temporal_params *p);
 int ebvo_temporal_set_keyframe(ebvo_ctx *ctx, int slot);
 /* quads of the keyframe against the final mates of `slot` */
 int ebvo_temporal_match(ebvo_ctx *ctx, int slot, const ebvo_temporal_params *p, ebvo_temporal_counts *counts);
+/* The same without blocking the caller (see ebvo_stereo_finalize_submit): _submit enqueues the candidate search and the NCC
+ * of the stored patches on the slot's stream and returns, _wait returns the counts (and, for stages = 1, runs the rest of
+ * the chain).  Frames in different slots overlap on the device. */
+int ebvo_temporal_match_submit(ebvo_ctx *ctx, int slot, const ebvo_temporal_params *p);
+int ebvo_temporal_match_wait(ebvo_ctx *ctx, int slot, ebvo_temporal_counts *counts);
 /* The quads that leave the whole chain (stages = 1), CSR over the keyframe mates: row_ptr n_kf + 1; per final quad the
  * current-frame mate it is copied from (`best_idx` of :713), the left cluster centre (EdgeClusterer's weighted average, or
  * the refined left edge of an unclustered quad), the right centre (the mean of the members' refined right edges), the left
@@ -618,7 +623,9 @@ int ebvo_profile_get(ebvo_ctx *ctx, ebvo_kernel_time *out /* EBVO_MAX_KERNELS */
  * key 3: the profiler instruments ONE stage (value = its index in ebvo_profile_get's order + 1; 0 = every stage): no
  *        event markers between the other kernels, so the stage is timed as it runs in the unprofiled pipeline.
  * key 4: 1 = the photometric refinements never use their eight-lanes-per-pair launch layout (0 = default: chosen per
- *        iteration from the number of active pairs); key 5: that threshold (0 = built-in).  Same bits either way. */
+ *        iteration from the number of active pairs); key 5: that threshold (0 = built-in).  Same bits either way.
+ * key 6: set the candidate-quad capacity of every slot's temporal stage to `value` (>= 1): the next ebvo_temporal_match
+ *        finds more quads than its buffers hold and takes the regrow path. */
 int ebvo_debug_set(ebvo_ctx *ctx, int key, int value);
 
 /* Raw FP64 vector-ALU microbenchmark (mul + add, no FMA) used to anchor the compute roofline:
