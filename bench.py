@@ -514,6 +514,11 @@ def sequence_bench(args, wl, H, W, F, device, rank, world, dist, reduce_device):
                 res[i - 3][2] = ctx.temporal_match_wait(slot=slots[i - 3], fetch=False)[0]    # D
         return [tuple(r) for r in res]
 
+    frame(0, first=True)                               # keyframe = frame 0 (src/Pipeline.cpp:133-138)
+    for k in range(min(args.warmup, n_frames)):
+        frame(k)
+    frame_pipeline(list(range(min(8, n_frames))))      # untimed: sizes the quad buffers of these slots, warms the pipeline
+
     def barrier():
         torch.cuda.synchronize()
         if dist is not None:

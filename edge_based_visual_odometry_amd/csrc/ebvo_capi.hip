@@ -2829,7 +2829,12 @@ extern "C" int ebvo_temporal_match_submit(ebvo_ctx *ctx, int slot, const ebvo_te
         return EBVO_ERR_ARG;
     Slot &s = *sp;
     if (!s.have_final || s.in_flight || s.fin_in_flight || s.tq_in_flight || ctx->kf_n < 0)
+    {
+        ctx->last_error = !s.have_final ? "the slot holds no final stereo mates (ebvo_stereo_finalize first)"
+                          : ctx->kf_n < 0 ? "no keyframe (ebvo_temporal_set_keyframe first)"
+                                          : "the slot has work in flight (wait for it first)";
         return EBVO_ERR_STATE;
+    }
     EBVO_HIP(ctx, hipSetDevice(ctx->device));
     if (int rc_f = drain_fetch(ctx, s))
         return rc_f;
