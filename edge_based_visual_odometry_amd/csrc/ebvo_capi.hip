@@ -3160,6 +3160,10 @@ extern "C" int ebvo_debug_set(ebvo_ctx *ctx, int key, int value)
         ctx->gn_no_rows = value; // refinement launch layout (same bits either way, tests/test_gpu_refine.py)
     else if (key == 5)
         ctx->gn_rows_below = value;
+    else if (key == 8 && (value == 2 || value == 3))
+        ctx->gn_persist_waves = value;
+    else if (key == 7 && value <= 1)
+        ctx->gn_per_iteration_rows = value; // the stereo refinement's row layout as a launch per iteration (A/B and parity tests)
     else if (key == 6 && value >= 1)
     {
         for (Slot *sl : ctx->slots) // test hook: the next temporal match of every slot finds its quad buffers too small

@@ -613,9 +613,123 @@ __global__ __launch_bounds__(256, 2) void gn_iter_kernel(GnArgs A, int it, int m
 #ifndef GN_ROWS_WAVES
 #define GN_ROWS_WAVES 3 // waves per SIMD the row layout is compiled for (166 VGPRs; 4 -> 128 with spills, measured slower)
 #endif
-__global__ __launch_bounds__(256, GN_ROWS_WAVES) void gn_iter_rows_kernel(GnArgs A, int it, int mode)
+// what an eight-lane group keeps of its pair between iterations (the persistent kernel below loads it once per pair)
+struct GnRowsState
+{
+    double ex, ey, st, ct, rx, ry, meanL0, meanL1, alpha;
+    int li;
+};
+__device__ inline void gn_rows_load(const GnArgs &A, int64_t k, GnRowsState &S)
+{
+    ebvo_edge le;
+    gn_geometry(A, k, le, S.ex, S.ey);
+    S.li = A.pair_left[k];
+    S.st = A.sc[S.li];
+    S.ct = A.sc[A.nL + S.li];
+    gn_candidate(A, k, S.rx, S.ry);
+    S.meanL0 = A.mean_l[S.li];
+    S.meanL1 = A.mean_l[A.nL + S.li];
+    S.alpha = A.alpha[k];
+}
+// One iteration `it` of pair k by the eight lanes of a group (every lane of the wave runs it: the exchanges are wave-wide;
+// `live` false = the group holds no pair, nothing is written).  Returns, on the group's lane 0, whether the pair is finished
+// (its outputs are written then); S.alpha advances on that lane.
+__device__ inline bool gn_rows_iteration(const GnArgs &A, int64_t k, GnRowsState &S, int it, bool live, int row, int gbase)
 {
     const int h = A.h, w = A.w;
+    const double ex = S.ex, ey = S.ey, st = S.st, ct = S.ct, rx = S.rx, ry = S.ry;
+    const int li = S.li;
+    const double nx = -st, ny = ct, side = (7 / 2.0) + 1.0;
+    const double meanL[2] = {S.meanL0, S.meanL1};
+    double alpha = S.alpha;
+    const double shx = ex * alpha, shy = ey * alpha;
+    const int i = min(row, 6) - 3; // this lane's patch row (lane 7 repeats row 6 and is never selected)
+    double H = 0.0, b = 0.0, cost = 0.0;
+#pragma unroll 1
+    for (int sd = 0; sd < 2; ++sd)
+    {
+        const float *__restrict__ lrec = A.left_rec + (size_t)li * 98 + sd * 49 + (i + 3) * 7;
+        const double cx = (sd ? rx - nx * side : rx + nx * side) + shx; // :1204-1205
+        const double cy = (sd ? ry - ny * side : ry + ny * side) + shy;
+        GnTap tp[7]; // this lane's row of the side: tapped once, intensity and both gradients
+#pragma unroll
+        for (int j = -3; j <= 3; ++j)
+            tp[j + 3] = gn_tap(A.recR, w, h, cx + ct * i - st * j, cy + st * i + ct * j);
+        double sum = 0;
+#pragma unroll 1
+        for (int r = 0; r < 7; ++r)
+        {
+            double t = sum;
+#pragma unroll
+            for (int j = 0; j < 7; ++j)
+                t += (double)tp[j].v;
+            sum = __shfl(t, gbase | r); // the running sum after row r
+        }
+        const double meanR = sum / 49;
+        double tH[7], tb[7], tc[7];
+#pragma unroll
+        for (int j = 0; j < 7; ++j)
+        {
+            const double Lf = (double)lrec[j]; // sampled once by gn_left_kernel
+            const double Rf = (double)tp[j].v, gxv = (double)tp[j].gx, gyv = (double)tp[j].gy;
+            const double r = (Lf - meanL[sd]) - (Rf - meanR);
+            const double g = -gxv * ex + gyv * ey; // :1237
+            const double absr = fabs(r);
+            const double wgt = (absr <= A.huber) ? 1.0 : A.huber / absr;
+            tH[j] = wgt * g * g; // the addends of gn_iter_kernel's three sums, formed by the same operations
+            tb[j] = wgt * g * r;
+            tc[j] = wgt * r * r;
+        }
+#pragma unroll 1
+        for (int r = 0; r < 7; ++r)
+        {
+            double uH = H, ub = b, uc = cost;
+#pragma unroll
+            for (int j = 0; j < 7; ++j)
+            {
+                uH += tH[j];
+                ub += tb[j];
+                uc += tc[j];
+            }
+            H = __shfl(uH, gbase | r);
+            b = __shfl(ub, gbase | r);
+            cost = __shfl(uc, gbase | r);
+        }
+    }
+    bool finished = true;
+    if (live && row == 0)
+    {
+        int done_iters = it; // stop on H < 1e-8: outputs stay unset (:1255)
+        if (!(H < 1e-8))
+        {
+            const double delta = -b / H;
+            alpha += delta;
+            const double rms = sqrt(cost / 98);
+            const bool is_outlier = (rms > A.huber * 2.0) || (it + 1 < 2); // residual_log.size() == it + 1
+            if (fabs(delta) < A.tol || it == A.max_iter - 1)
+            {
+                A.valid[k] = is_outlier ? 0 : 1;
+                A.score[k] = rms;
+                A.conf[k] = ebvo_exp(-rms / A.huber);
+                done_iters = it + 1;
+            }
+            else
+                finished = false;
+        }
+        A.alpha[k] = alpha;
+        S.alpha = alpha;
+        if (finished)
+        {
+            A.iters[k] = done_iters;
+            A.refined_xy[2 * k] = rx + ex * alpha; // :1349-1351
+            A.refined_xy[2 * k + 1] = ry + ey * alpha;
+        }
+    }
+    return finished;
+}
+
+__global__ __launch_bounds__(256, GN_ROWS_WAVES) void gn_iter_rows_kernel(GnArgs A, int it, int mode)
+{
     const int n_in = A.counts[it];
     if (gn_other_layout(mode, n_in, A.rows_below))
         return;
@@ -628,100 +742,10 @@ __global__ __launch_bounds__(256, GN_ROWS_WAVES) void gn_iter_rows_kernel(GnArgs
         const int idx = base + (threadIdx.x >> 3);
         const bool live = idx < n_in; // uniform in the group; the cross-lane exchanges below run for every lane of the wave
         const int64_t k = live ? lin[idx] : 0;
-        bool survives = false;
-        ebvo_edge le;
-        double ex, ey;
-        gn_geometry(A, k, le, ex, ey);
-        const int li = A.pair_left[k];
-        const double st = A.sc[li], ct = A.sc[A.nL + li];
-        const double nx = -st, ny = ct, side = (7 / 2.0) + 1.0;
-        double rx, ry;
-        gn_candidate(A, k, rx, ry);
-        const double meanL[2] = {A.mean_l[li], A.mean_l[A.nL + li]};
-        double alpha = A.alpha[k];
-        const double shx = ex * alpha, shy = ey * alpha;
-        const int i = min(row, 6) - 3; // this lane's patch row (lane 7 repeats row 6 and is never selected)
-        double H = 0.0, b = 0.0, cost = 0.0;
-#pragma unroll 1
-        for (int sd = 0; sd < 2; ++sd)
-        {
-            const float *__restrict__ lrec = A.left_rec + (size_t)li * 98 + sd * 49 + (i + 3) * 7;
-            const double cx = (sd ? rx - nx * side : rx + nx * side) + shx; // :1204-1205
-            const double cy = (sd ? ry - ny * side : ry + ny * side) + shy;
-            GnTap tp[7]; // this lane's row of the side: tapped once, intensity and both gradients
-#pragma unroll
-            for (int j = -3; j <= 3; ++j)
-                tp[j + 3] = gn_tap(A.recR, w, h, cx + ct * i - st * j, cy + st * i + ct * j);
-            double sum = 0;
-#pragma unroll 1
-            for (int r = 0; r < 7; ++r)
-            {
-                double t = sum;
-#pragma unroll
-                for (int j = 0; j < 7; ++j)
-                    t += (double)tp[j].v;
-                sum = __shfl(t, gbase | r); // the running sum after row r
-            }
-            const double meanR = sum / 49;
-            double tH[7], tb[7], tc[7];
-#pragma unroll
-            for (int j = 0; j < 7; ++j)
-            {
-                const double Lf = (double)lrec[j]; // sampled once by gn_left_kernel
-                const double Rf = (double)tp[j].v, gxv = (double)tp[j].gx, gyv = (double)tp[j].gy;
-                const double r = (Lf - meanL[sd]) - (Rf - meanR);
-                const double g = -gxv * ex + gyv * ey; // :1237
-                const double absr = fabs(r);
-                const double wgt = (absr <= A.huber) ? 1.0 : A.huber / absr;
-                tH[j] = wgt * g * g; // the addends of gn_iter_kernel's three sums, formed by the same operations
-                tb[j] = wgt * g * r;
-                tc[j] = wgt * r * r;
-            }
-#pragma unroll 1
-            for (int r = 0; r < 7; ++r)
-            {
-                double uH = H, ub = b, uc = cost;
-#pragma unroll
-                for (int j = 0; j < 7; ++j)
-                {
-                    uH += tH[j];
-                    ub += tb[j];
-                    uc += tc[j];
-                }
-                H = __shfl(uH, gbase | r);
-                b = __shfl(ub, gbase | r);
-                cost = __shfl(uc, gbase | r);
-            }
-        }
-        if (live && row == 0)
-        {
-            int done_iters = it; // stop on H < 1e-8: outputs stay unset (:1255)
-            bool finished = true;
-            if (!(H < 1e-8))
-            {
-                const double delta = -b / H;
-                alpha += delta;
-                const double rms = sqrt(cost / 98);
-                const bool is_outlier = (rms > A.huber * 2.0) || (it + 1 < 2); // residual_log.size() == it + 1
-                if (fabs(delta) < A.tol || it == A.max_iter - 1)
-                {
-                    A.valid[k] = is_outlier ? 0 : 1;
-                    A.score[k] = rms;
-                    A.conf[k] = ebvo_exp(-rms / A.huber);
-                    done_iters = it + 1;
-                }
-                else
-                    finished = false;
-            }
-            A.alpha[k] = alpha;
-            if (finished)
-            {
-                A.iters[k] = done_iters;
-                A.refined_xy[2 * k] = rx + ex * alpha; // :1349-1351
-                A.refined_xy[2 * k + 1] = ry + ey * alpha;
-            }
-            survives = !finished;
-        }
+        GnRowsState S;
+        gn_rows_load(A, k, S);
+        const bool finished = gn_rows_iteration(A, k, S, it, live, row, gbase);
+        const bool survives = live && row == 0 && !finished;
         // append the survivors: one atomic per wave
         const unsigned long long m = __ballot(survives);
         int wbase = 0;
@@ -730,6 +754,68 @@ __global__ __launch_bounds__(256, GN_ROWS_WAVES) void gn_iter_rows_kernel(GnArgs
         wbase = __shfl(wbase, 0);
         if (survives)
             lout[wbase + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)k;
+    }
+}
+
+// The remaining iterations of every pair still active in ONE launch, eight lanes per pair: a group draws a pair from the
+// list, runs its iterations back to back (the pair's geometry, left-edge record address and means stay in registers: a
+// launch per iteration reloads them twenty times through a chain of dependent loads) and draws the next one when the pair
+// has converged -- no launch between two iterations of a pair, no list to compact, and a wave is never idle while the list
+// holds work.  The groups of a wave are at different iterations of different pairs; the iteration body does not depend on
+// the iteration number except through two wave-uniform-per-group scalars, so they run in lock step without divergence.
+// Which list: the last one the per-iteration launches of the one-thread-per-pair layout left non-empty (they stop as soon
+// as at most rows_below pairs are active, see gn_iter_kernel), or list 0 when no such launch was made.  Same arithmetic per
+// pair and iteration as gn_iter_rows_kernel (one device function), hence the same bits.
+template <int WAVES>
+__global__ __launch_bounds__(256, WAVES) void gn_rows_persistent_kernel(GnArgs A)
+{
+    int it0 = -1;
+    for (int it = A.max_iter - 1; it >= 0; --it) // wave-uniform: the last list that holds pairs
+        if (A.counts[it] > 0)
+        {
+            it0 = it;
+            break;
+        }
+    if (it0 < 0)
+        return;
+    const int n_in = A.counts[it0];
+    if (n_in > A.rows_below) // the one-thread-per-pair launches ran this list (and it was the last iteration, or nothing survived)
+        return;
+    const int32_t *__restrict__ lin = A.list[it0 & 1];
+    int32_t *head = &A.counts[A.max_iter + 1]; // next list entry to hand out (zeroed with the counts)
+    const int lane = threadIdx.x & 63, row = lane & 7, gbase = lane & ~7;
+    bool have = false;
+    int it = it0;
+    int64_t k = lin[0]; // a group without a pair computes on pair lin[0] and writes nothing
+    GnRowsState S;
+    gn_rows_load(A, k, S);
+    for (;;)
+    {
+        // groups without a pair draw the next list entries: one atomic per wave
+        const unsigned long long need = __ballot(!have && row == 0);
+        int base = 0;
+        if (lane == 0 && need)
+            base = atomicAdd(head, __popcll(need));
+        base = __shfl(base, 0);
+        if (!have)
+        {
+            const int idx = base + __popcll(need & ((1ull << gbase) - 1ull)); // rank of this group among the drawing ones
+            if (idx < n_in)
+            {
+                k = lin[idx];
+                gn_rows_load(A, k, S);
+                it = it0;
+                have = true;
+            }
+        }
+        if (!__ballot(have))
+            break; // the list is drained and every pair of this wave has converged
+        const bool finished = gn_rows_iteration(A, k, S, it, have, row, gbase);
+        const bool fin_g = __shfl((int)finished, gbase) != 0; // the group's verdict (formed on its lane 0)
+        S.alpha = __shfl(S.alpha, gbase);
+        if (have && fin_g)
+            have = false;
+        ++it;
     }
 }
 
@@ -1269,18 +1355,26 @@ int refine_gn_stereo_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_imgL, cons
     hipLaunchKernelGGL(gn_init_kernel, dim3(blocks), dim3(256), 0, s.stream, A);
     const bool no_rows = ctx->gn_no_rows != 0;                                  // developer keys (ebvo_debug_set 4 / 5)
     A.rows_below = ctx->gn_rows_below > 0 ? ctx->gn_rows_below : GN_ROWS_BELOW; // tools/gpu_gn_sweep.sh sweeps it
-    for (int it = 0; it < max_iter; ++it)
-    {
-        const unsigned rblocks = (unsigned)((n_pairs + 31) / 32 < 8192 ? (n_pairs + 31) / 32 : 8192);
-        if (no_rows)
+    // Iterations: the one-thread-per-pair layout, a launch per iteration, while more than rows_below pairs are active (each
+    // of these launches returns at once when it finds fewer); then ONE launch of the eight-lanes-per-pair layout runs every
+    // remaining pair to its convergence.  A problem that cannot hold more than rows_below pairs gets that launch only.
+    if (no_rows)
+        for (int it = 0; it < max_iter; ++it)
             hipLaunchKernelGGL(gn_iter_kernel, dim3(blocks), dim3(256), 0, s.stream, A, it, 0);
-        else if (n_pairs <= A.rows_below)
-            hipLaunchKernelGGL(gn_iter_rows_kernel, dim3(rblocks), dim3(256), 0, s.stream, A, it, 0);
+    else
+    {
+        if (n_pairs > A.rows_below)
+            for (int it = 0; it < max_iter; ++it)
+                hipLaunchKernelGGL(gn_iter_kernel, dim3(blocks), dim3(256), 0, s.stream, A, it, 1);
+        const int64_t most = n_pairs < A.rows_below ? n_pairs : A.rows_below; // pairs the persistent launch can be handed
+        const unsigned pblocks = (unsigned)((most + 31) / 32 < 8192 ? (most + 31) / 32 : 8192);
+        if (ctx->gn_per_iteration_rows) // developer key: the row layout as a launch per iteration (the form before the persistent kernel)
+            for (int it = 0; it < max_iter; ++it)
+                hipLaunchKernelGGL(gn_iter_rows_kernel, dim3(pblocks), dim3(256), 0, s.stream, A, it, n_pairs > A.rows_below ? 2 : 0);
+        else if (ctx->gn_persist_waves == 3)
+            hipLaunchKernelGGL((gn_rows_persistent_kernel<3>), dim3(pblocks), dim3(256), 0, s.stream, A);
         else
-        {
-            hipLaunchKernelGGL(gn_iter_kernel, dim3(blocks), dim3(256), 0, s.stream, A, it, 1);
-            hipLaunchKernelGGL(gn_iter_rows_kernel, dim3(rblocks), dim3(256), 0, s.stream, A, it, 2);
-        }
+            hipLaunchKernelGGL((gn_rows_persistent_kernel<2>), dim3(pblocks), dim3(256), 0, s.stream, A);
     }
     EBVO_HIP(ctx, hipGetLastError());
     return EBVO_OK;

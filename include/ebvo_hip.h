@@ -624,6 +624,8 @@ int ebvo_profile_get(ebvo_ctx *ctx, ebvo_kernel_time *out /* EBVO_MAX_KERNELS */
  *        event markers between the other kernels, so the stage is timed as it runs in the unprofiled pipeline.
  * key 4: 1 = the photometric refinements never use their eight-lanes-per-pair launch layout (0 = default: chosen per
  *        iteration from the number of active pairs); key 5: that threshold (0 = built-in).  Same bits either way.
+ * key 7: 1 = the stereo refinement's eight-lanes layout as a launch per iteration instead of one persistent launch;
+ * key 8: waves per SIMD the persistent launch is built for (2 or 3).  Same bits either way.
  * key 6: set the candidate-quad capacity of every slot's temporal stage to `value` (>= 1): the next ebvo_temporal_match
  *        finds more quads than its buffers hold and takes the regrow path. */
 int ebvo_debug_set(ebvo_ctx *ctx, int key, int value);

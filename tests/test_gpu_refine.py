@@ -22,13 +22,17 @@ def _compare(out, ref):
     assert_bit_equal(out["confidence"], ref["confidence"], "confidence")
 
 
-@pytest.fixture(params=["rows", "threads"])
+@pytest.fixture(params=["rows", "threads", "rows_per_iteration", "rows_three_waves"])
 def gn_layout(request, ctx):
-    """Both launch layouts of the Gauss-Newton iterations: eight lanes per pair (what the library picks for up to 131,072
-    pairs) and one thread per pair (developer key 4 of ebvo_debug_set, what larger problems run).  Same bits either way."""
-    ctx.debug_set(4, 1 if request.param == "threads" else 0)
+    """The launch layouts of the stereo Gauss-Newton iterations (developer keys of ebvo_debug_set): eight lanes per pair in one
+    persistent launch (what the library picks below ~49 k active pairs; built for two or three waves per SIMD), the same
+    layout as a launch per iteration, and one thread per pair (what larger problems run).  Same bits every way."""
+    key, value = {"rows": (4, 0), "threads": (4, 1), "rows_per_iteration": (7, 1), "rows_three_waves": (8, 3)}[request.param]
+    ctx.debug_set(key, value)
     yield request.param
     ctx.debug_set(4, 0)
+    ctx.debug_set(7, 0)
+    ctx.debug_set(8, 2)
 
 
 @pytest.mark.parametrize("shape", [(48, 64), (96, 160), (120, 200)])
