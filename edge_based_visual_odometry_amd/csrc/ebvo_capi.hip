@@ -2110,7 +2110,8 @@ static int finalize_enqueue(ebvo_ctx *ctx, Slot &s, const ebvo_finalize_params *
         std::swap(candA, candB);
         std::swap(scoreA, scoreB);
     }
-    const int32_t *d_nB = rpB + nL; // pairs that enter the refinement
+    const int32_t *d_nB = rpB + nL; // pairs that enter the refinement: a subset of the run's kept NCC matches
+    const int64_t n_ref = s.result.n_matches < n0 ? (s.result.n_matches > 0 ? s.result.n_matches : 1) : n0;
     {
         // 3. epipolar shift (:1436) and 4. photometric refinement along the epipolar line (:1438)
         double *out = (double *)s.gn_out.p;
@@ -2119,7 +2120,7 @@ static int finalize_enqueue(ebvo_ctx *ctx, Slot &s, const ebvo_finalize_params *
             (rc = glue_xy_enqueue(ctx, s, candC, (double *)s.gn_xy.p, n0, false, d_nB)) ||
             (rc = refine_gn_stereo_enqueue(ctx, s, s.im[0].img, s.im[1].img, nullptr, h, w, s.im[0].edges, nL,
                                            (const double *)s.lines.p, left_of, (const double *)s.gn_xy.p, nullptr, nullptr,
-                                           nullptr, n0, p->gn.max_iter, p->gn.tol, p->gn.huber_delta, out, out + nz,
+                                           nullptr, n_ref, p->gn.max_iter, p->gn.tol, p->gn.huber_delta, out, out + nz,
                                            out + 2 * nz, (uint8_t *)s.gn_valid.p, (int32_t *)s.gn_iters.p, out + 3 * nz, d_nB)) ||
             (rc = glue_xy_enqueue(ctx, s, candC, out + 3 * nz, n0, true, d_nB)))
             return rc;
@@ -3160,6 +3161,8 @@ extern "C" int ebvo_debug_set(ebvo_ctx *ctx, int key, int value)
         ctx->gn_no_rows = value; // refinement launch layout (same bits either way, tests/test_gpu_refine.py)
     else if (key == 5)
         ctx->gn_rows_below = value;
+    else if (key == 9)
+        ctx->gn_persist_blocks = value;
     else if (key == 8 && (value == 2 || value == 3))
         ctx->gn_persist_waves = value;
     else if (key == 7 && value <= 1)

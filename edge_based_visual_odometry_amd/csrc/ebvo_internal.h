@@ -212,6 +212,7 @@ struct ebvo_ctx
     PinnedBuf sw_toed[2], sw_cand, sw_ncc, sw_up;
     int gn_no_rows = 0;        // developer key (ebvo_debug_set 4): 1 = the refinements never use the eight-lanes-per-pair layout
     int gn_persist_waves = 2;      // developer key (ebvo_debug_set 8): waves per SIMD the persistent refinement kernel is built for (2 | 3)
+    int gn_persist_blocks = 0;     // developer key (ebvo_debug_set 9): most workgroups of the persistent refinement launch, 0 = default
     int gn_per_iteration_rows = 0; // developer key (ebvo_debug_set 7): 1 = the eight-lanes layout as a launch per iteration
     int gn_rows_below = 0;     // developer key (ebvo_debug_set 5): active-pair count below which an iteration uses it, 0 = default
     int wait_attempts = 0;     // test hook (ebvo_debug_set): attempts of ebvo_stereo_wait's regrow loop, 0 = default (4)

@@ -481,7 +481,9 @@ __global__ __launch_bounds__(256) void gn_init_kernel(GnArgs A)
 #ifndef GN_TAP_ROWS
 #define GN_TAP_ROWS 2 // patch rows whose records are in flight together (2.79 -> 2.72 ms against 1)
 #endif
-constexpr int GN_ROWS_BELOW = 49152; // tools/gpu_gn_sweep.sh: KITTI 2.33 ms (2.41 at 65536, 2.35 at 0), EuRoC sequence 320 frames/s (314, 293)
+constexpr int GN_ROWS_BELOW = 65536; // tools/gpu_gn_ab.py (persistent eight-lanes launch below it): KITTI chain refinement 0.98 / 0.99 / 1.01 /
+                                     // 1.04 / 1.13 / 1.41 ms at 32768 / 49152 / 65536 / 98304 / 131072 / 262144; a 752 x 480 frame (25 k pairs, at
+                                     // most 50 k kept matches) is below it from the start: one launch, 0.51 ms (0.94 as a launch per iteration)
 __device__ inline bool gn_other_layout(int mode, int n_active, int rows_below)
 {
     return (mode == 1 && n_active <= rows_below) || (mode == 2 && n_active > rows_below);
@@ -1367,7 +1369,10 @@ int refine_gn_stereo_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_imgL, cons
             for (int it = 0; it < max_iter; ++it)
                 hipLaunchKernelGGL(gn_iter_kernel, dim3(blocks), dim3(256), 0, s.stream, A, it, 1);
         const int64_t most = n_pairs < A.rows_below ? n_pairs : A.rows_below; // pairs the persistent launch can be handed
-        const unsigned pblocks = (unsigned)((most + 31) / 32 < 8192 ? (most + 31) / 32 : 8192);
+        // at most gn_persist_blocks workgroups (4 waves each; 256 = one wave per SIMD): with fewer groups than pairs a group
+        // draws several pairs one after the other, which evens out the 1 .. max_iter iterations the pairs need
+        const int64_t bcap = ctx->gn_persist_blocks > 0 ? ctx->gn_persist_blocks : 256; // tools/gpu_gn_ab.py: 256 < 512 < 768 ... at both sizes
+        const unsigned pblocks = (unsigned)((most + 31) / 32 < bcap ? (most + 31) / 32 : bcap);
         if (ctx->gn_per_iteration_rows) // developer key: the row layout as a launch per iteration (the form before the persistent kernel)
             for (int it = 0; it < max_iter; ++it)
                 hipLaunchKernelGGL(gn_iter_rows_kernel, dim3(pblocks), dim3(256), 0, s.stream, A, it, n_pairs > A.rows_below ? 2 : 0);
