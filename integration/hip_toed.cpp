@@ -2,8 +2,10 @@
 // src/CMakeLists.txt.  The header include/toed/cpu_toed.hpp stays untouched, so Pipeline.h:96,193 and
 // Pipeline::ProcessEdges (src/Pipeline.cpp:24-29) compile and behave as before.
 //
-// NOT compiled in this repository (needs the reference tree + OpenCV); the same marshalling is
-// compiled and parity-tested here through include/ebvo/adapters.hpp (tests/test_cpp_adapter.py).
+// Not BUILT in this repository (needs the reference tree + OpenCV).  Where the reference tree is present it is checked with
+// g++ -fsyntax-only against the reference's real headers (tests/test_integration_syntax.py: signatures and member names
+// agree); the same marshalling is compiled and parity-tested here through include/ebvo/adapters.hpp
+// (tests/test_cpp_adapter.py, tests/test_cpp_stagewise.py).
 #include <mutex>
 #include <unordered_map>
 

@@ -4,8 +4,10 @@
 // this file to src/CMakeLists.txt; headers, get_Stereo_Edge_Pairs (src/Stereo_Matches.cpp:1360-1540), the SIFT /
 // BNB / refinement stages between them and main_VO stay as they are.
 //
-// NOT compiled in this repository (needs the reference tree + OpenCV + Eigen); the marshalling below is the
-// one compiled and parity-tested through include/ebvo/adapters.hpp (tests/test_cpp_adapter.py).
+// Not BUILT in this repository (needs the reference tree + OpenCV + Eigen).  Where the reference tree is present it is
+// checked with g++ -fsyntax-only against the reference's real headers (tests/test_integration_syntax.py: signatures and member
+// names agree); the marshalling below is the one compiled and parity-tested through include/ebvo/adapters.hpp
+// (tests/test_cpp_adapter.py, tests/test_cpp_stagewise.py).
 #include "Stereo_Matches.h"
 #include "Temporal_Matches.h"
 #include <cstring>
