@@ -119,76 +119,100 @@ def xyi_hash(edges) -> str:
 
 
 def cpu_baseline(left, right, F):
-    """The CPU oracle (a port of the reference's path) on this box's host cores; bounded sample (~10-30 s).  Returns the
-    timing record and what it computed (edges, the sampled rows) so that the GPU's results can be checked against it."""
+    """The CPU oracle (a port of the reference's path) on this box's host cores, SURVEY.md 8(d) protocol: TOED = 1 warm-up + 5
+    timed repetitions, median; the candidate search and the NCC pass UNSAMPLED, stage by stage as get_Stereo_Edge_Pairs runs
+    them (src/Stereo_Matches.cpp:1374-1427): brute-force epipolar stage (OpenMP as written), disparity stage (its `#pragma omp
+    for` is orphaned, :536: serial as written), orientation stage (parallel as written), NCC (orphaned pragma again, :573:
+    serial as written) -- the two orphaned-pragma loops are timed both ways.  ~20-25 s on 16 cores.  Returns the timing record
+    and everything it computed so that the GPU's results can be checked against it, pair by pair."""
     from tests import oracle as orc
     # a one-GPU box's CPU share is 16 cores; EBVO_CPU_THREADS overrides
     cores = int(os.environ.get("EBVO_CPU_THREADS", min(16, len(os.sched_getaffinity(0)))))
-    t0 = time.perf_counter()
-    rl = orc.toed(left, math_mode=orc.LIBM, nthreads=cores)
-    rr = orc.toed(right, math_mode=orc.LIBM, nthreads=cores)
-    t_toed = time.perf_counter() - t0
+
+    def wall(fn, *a, **k):
+        t0 = time.perf_counter()
+        out = fn(*a, **k)
+        return out, time.perf_counter() - t0
+
+    # TOED of both images: warm-up + 5 repetitions
+    reps = []
+    for rep in range(6):
+        (rl, rr), dt = wall(lambda: (orc.toed(left, math_mode=orc.LIBM, nthreads=cores), orc.toed(right, math_mode=orc.LIBM, nthreads=cores)))
+        if rep:
+            reps.append(dt)
+    t_toed = float(np.median(reps))
     L, R = rl["edges"], rr["edges"]
-    stride = 16                                      # brute force is O(NL*NR): 1/16 of the left edges, scaled
-    Ls = L[::stride]
-    lines = orc.epipolar_lines(F, Ls)
-    t0 = time.perf_counter()
-    rp, ci = orc.epi_candidates(Ls, R, lines, nthreads=cores)
-    t_cand = (time.perf_counter() - t0) * stride
-    t0 = time.perf_counter()
-    orc.ncc_pairs(left, right, Ls, R[ci], rp, math_mode=orc.LIBM, nthreads=cores)
-    t_ncc = (time.perf_counter() - t0) * stride
-    total = t_toed + t_cand + t_ncc
-    # one thread, as SURVEY 8(d) also asks: TOED of one image timed, the matching scaled from a 1/128 sample of the left edges
-    t0 = time.perf_counter()
-    orc.toed(left, math_mode=orc.LIBM, nthreads=1)
-    t_toed1 = 2.0 * (time.perf_counter() - t0)
-    s1 = 128
-    L1 = L[::s1]
-    lines1 = orc.epipolar_lines(F, L1)
-    t0 = time.perf_counter()
-    rp1, ci1 = orc.epi_candidates(L1, R, lines1, nthreads=1)
-    orc.ncc_pairs(left, right, L1, R[ci1], rp1, math_mode=orc.LIBM, nthreads=1)
-    t_match1 = (time.perf_counter() - t0) * s1
-    # checker leg (not timed): the scores of the sampled rows in the arithmetic the GPU path uses (shared sin / cos)
+    lines = orc.epipolar_lines(F, L)
+    # stage 1: every left edge against every right edge (:91-109, :381-419) -- hundreds of candidates per edge
+    (rp1, ci1), t_epi = wall(orc.epi_candidates, L, R, lines, stage_mask=orc.STAGE_EPIPOLAR, nthreads=cores)
+    # stage 2 on those lists, serial as written and parallel as intended (:534-553)
+    k_disp, t_disp_serial = wall(orc.filter_pairs, L, R, rp1, ci1, stage_mask=orc.STAGE_DISPARITY, nthreads=1)
+    _, t_disp_par = wall(orc.filter_pairs, L, R, rp1, ci1, stage_mask=orc.STAGE_DISPARITY, nthreads=cores)
+    rows1 = np.repeat(np.arange(len(L)), np.diff(rp1.astype(np.int64)))
+    sel = k_disp.astype(bool)
+    rp2 = np.concatenate([[0], np.cumsum(np.bincount(rows1[sel], minlength=len(L)))]).astype(np.int32)
+    ci2 = ci1[sel]
+    # stage 3 on the survivors (:863-915, a parallel region as written)
+    k_or, t_orient = wall(orc.filter_pairs, L, R, rp2, ci2, stage_mask=orc.STAGE_ORIENTATION, nthreads=cores)
+    rows2 = rows1[sel]
+    sel3 = k_or.astype(bool)
+    rp3 = np.concatenate([[0], np.cumsum(np.bincount(rows2[sel3], minlength=len(L)))]).astype(np.int32)
+    ci3 = ci2[sel3]
+    # NCC of every surviving pair with the left patches (:555-616), serial as written and parallel as intended
+    cand = R[ci3]
+    _, t_ncc_serial = wall(orc.ncc_pairs, left, right, L, cand, rp3, math_mode=orc.LIBM, nthreads=1)
+    _, t_ncc_par = wall(orc.ncc_pairs, left, right, L, cand, rp3, math_mode=orc.LIBM, nthreads=cores)
+    # one thread throughout: TOED of one image timed once (x 2); the brute-force stage scaled from every 64th left edge
+    _, t1 = wall(orc.toed, left, math_mode=orc.LIBM, nthreads=1)
+    s1 = 64
+    _, te1 = wall(orc.epi_candidates, L[::s1], R, lines[::s1], stage_mask=orc.STAGE_EPIPOLAR, nthreads=1)
+    t_one = 2.0 * t1 + te1 * s1 + t_disp_serial + t_orient * cores + t_ncc_serial      # (orientation stage: scaled from the parallel run)
+    as_written = t_toed + t_epi + t_disp_serial + t_orient + t_ncc_serial
+    parallel = t_toed + t_epi + t_disp_par + t_orient + t_ncc_par
+    # checker leg (not timed): the same lists in the arithmetic the GPU path uses (shared sin / cos / atan2)
     Lp, Rp = orc.toed(left, nthreads=cores)["edges"], orc.toed(right, nthreads=cores)["edges"]
-    rp, ci = orc.epi_candidates(Lp[::stride], Rp, orc.epipolar_lines(F, Lp[::stride]), nthreads=cores)
-    sims, _, keep, _ = orc.ncc_pairs(left, right, Lp[::stride], Rp[ci], rp, nthreads=cores)
+    same_xy = len(Lp) == len(L) and len(Rp) == len(R) and all(
+        np.array_equal(a[f], b[f]) for a, b in ((Lp, L), (Rp, R)) for f in ("x", "y", "index"))
+    sims, _, keep, _ = orc.ncc_pairs(left, right, Lp, Rp[ci3], rp3, nthreads=cores)
     record = {
-        "value_1_thread": 1.0 / (t_toed1 + t_match1),
-        "seconds_per_pair_1_thread": t_toed1 + t_match1,
-        "value": 1.0 / total, "unit": "stereo pairs/s", "cores": cores, "kind": "port",
-        "sample": (f"oracle/ (C + OpenMP restatement of the reference path, gcc -O2, no FMA, {cores} threads) on the same "
-                   f"S2 pair: TOED of both images {t_toed:.2f}s; candidate search (brute force as the reference) "
-                   f"+ NCC on every {stride}th left edge, scaled x{stride}: {t_cand:.2f}s + {t_ncc:.2f}s (the reference "
-                   f"runs its NCC and disparity loops serially; the port runs them on all {cores} threads)"),
-        "seconds_per_pair": total,
+        "value": 1.0 / parallel, "unit": "stereo pairs/s", "cores": cores, "kind": "port",
+        "value_as_written": 1.0 / as_written,
+        "value_1_thread": 1.0 / t_one,
+        "seconds_per_pair": parallel, "seconds_per_pair_as_written": as_written, "seconds_per_pair_1_thread": t_one,
+        "seconds": {"toed_both_images_median_of_5": t_toed, "toed_repetitions": reps, "epipolar_stage_brute_force": t_epi,
+                    "disparity_stage_serial_as_written": t_disp_serial, "disparity_stage_parallel": t_disp_par,
+                    "orientation_stage": t_orient, "ncc_serial_as_written": t_ncc_serial, "ncc_parallel": t_ncc_par},
+        "pairs": {"after_epipolar_stage": int(len(ci1)), "after_disparity_stage": int(len(ci2)), "after_orientation_stage": int(len(ci3))},
+        "sample": (f"oracle/ (C + OpenMP restatement of the reference path, gcc -O2, no FMA, {cores} threads) on the same S2 pair, "
+                   "UNSAMPLED: TOED of both images (1 warm-up + 5 repetitions, median), then the stages of get_Stereo_Edge_Pairs one "
+                   "after the other on every left edge: brute-force epipolar stage, disparity stage, orientation stage, NCC with the "
+                   "left patches.  `value` counts the disparity and NCC loops in parallel (what their pragmas intend); "
+                   "`value_as_written` counts them serially (what the reference executes: both pragmas are orphaned, "
+                   "src/Stereo_Matches.cpp:536, :573)"),
     }
-    return record, dict(left=Lp, right=Rp, stride=stride, row_ptr=rp, col_idx=ci, sims=sims, keep=keep)
+    return record, dict(left=Lp, right=Rp, stride=1, row_ptr=rp3, col_idx=ci3, sims=sims, keep=keep, xy_equal_libm=bool(same_xy))
 
 
 def check_against_oracle(out, chk):
-    """Every edge of both images bit for bit, and the CSR rows / NCC scores of every `stride`-th left edge."""
+    """Every edge of both images, the WHOLE candidate CSR, all four NCC scores and the keep flag of every pair, bit for bit."""
     def same(a, b):
         return a.shape == b.shape and bool(((a.view(np.uint64) == b.view(np.uint64)) | (np.isnan(a) & np.isnan(b))).all())
+    if not chk.get("xy_equal_libm", True):
+        return "the oracle's edge positions differ between its libm and shared-math modes"
     for side in ("left", "right"):
         for f in ("x", "y", "theta"):
             if not same(out[side][f].copy(), chk[side][f].copy()):
                 return f"{side}.{f} differs from the oracle"
         if not (out[side]["index"] == chk[side]["index"]).all():
             return f"{side}.index differs from the oracle"
-    rp = out["row_ptr"].astype(np.int64)
-    rows = np.arange(0, len(out["left"]), chk["stride"])
-    beg, end = rp[rows], rp[rows + 1]
-    if not np.array_equal(np.concatenate([[0], np.cumsum(end - beg)]), chk["row_ptr"].astype(np.int64)):
-        return "candidate counts of the sampled rows differ from the oracle"
-    idx = np.concatenate([np.arange(b, e) for b, e in zip(beg, end)]) if len(rows) else np.zeros(0, np.int64)
-    if not np.array_equal(out["col_idx"][idx], chk["col_idx"]):
-        return "candidate indices of the sampled rows differ from the oracle"
-    if not same(np.ascontiguousarray(out["sims"][idx]), np.ascontiguousarray(chk["sims"])):
-        return "NCC scores of the sampled rows differ from the oracle"
-    if not np.array_equal(out["keep"][idx], chk["keep"]):
-        return "NCC keep flags of the sampled rows differ from the oracle"
+    if not np.array_equal(out["row_ptr"], chk["row_ptr"]):
+        return "candidate row offsets differ from the oracle"
+    if not np.array_equal(out["col_idx"], chk["col_idx"]):
+        return "candidate indices differ from the oracle"
+    if not same(np.ascontiguousarray(out["sims"]), np.ascontiguousarray(chk["sims"])):
+        return "NCC scores differ from the oracle"
+    if not np.array_equal(out["keep"], chk["keep"]):
+        return "NCC keep flags differ from the oracle"
     return None
 
 
@@ -807,19 +831,16 @@ def main():
         for k in range(n_b + 1):                                                  # the first turn is untimed (sizes the buffers)
             bl, br = pool[k % len(pool)]
             tk = [time.perf_counter()]
-            eL, eR, _ = ctx.toed_pair(bl, br)
+            eL, _, _, tagL = ctx.toed_resident(bl, 0, want_all=True)
+            eR, _, _, tagR = ctx.toed_resident(br, 1, want_all=True)
             tk.append(time.perf_counter())
             lines_b = ctx.epipolar_lines(F, eL)
             tk.append(time.perf_counter())
-            rp2, ci2, ok_b = ctx.epi_candidates_staged(eL, eR, lines_b)           # stages 1 + 2 as a list, stage 3 as flags
+            ctx.epi_candidates_resident(tagL, tagR, lines_b, staged=True)         # stages 1 + 2 as a list, stage 3 as flags + list
             tk.append(time.perf_counter())
-            # what the binding does on the host between the calls (integration/stereo_matches_hip.cpp: drop the unflagged
-            # candidates of every row): new row starts = kept candidates before each old row start
-            kept_before = np.concatenate([[0], np.cumsum(ok_b, dtype=np.int64)])
-            rp_b = kept_before[rp2].astype(np.int32)
-            cand_b = eR[ci2[ok_b.view(np.bool_)]]
+            rp_b, ci_b = ctx.last_final_lists                                     # the caller's lists after the orientation stage
             tk.append(time.perf_counter())
-            ctx.ncc_pairs(bl, br, eL, cand_b, rp_b, want_left_patches=True)
+            ctx.ncc_pairs_resident(tagL, tagR, bl, br, rp_b, ci_b, want_left_patches=True, want_sims=False)
             tk.append(time.perf_counter())
             if k:
                 split += np.diff(tk)
@@ -838,16 +859,16 @@ def main():
                 "boundary_pairs_per_s": boundary_cpp["pairs_per_s"] if boundary_cpp else 1.0 / t_b,
                 "boundary_cpp": boundary_cpp,
                 "boundary_pairs_per_s_python_harness": 1.0 / t_b,
-                "boundary_ms": dict(zip(("toed_pair", "epipolar_lines", "epi_candidates_staged", "host_row_filter", "ncc_pairs_with_left_patches"),
+                "boundary_ms": dict(zip(("toed_resident_x2", "epipolar_lines", "epi_candidates_resident_staged", "host_lists", "ncc_pairs_resident_with_left_patches"),
                                         (float(x) * 1e3 for x in split))),
                 "boundary_note": "boundary_pairs_per_s: tools/boundary_bench.cpp, the stage-wise sequence as main_VO runs it through "
-                                 "include/ebvo/adapters.hpp (ProcessEdges x 2, CalculateEpipolarLine, one staged candidate search + the "
-                                 "host-side drop of unflagged pairs, NCC with left patches; std::vector results, no overlap).  "
-                                 "_python_harness / boundary_ms: the same calls from numpy, where the host step (a cumulative sum over "
-                                 "2.2 M flags and a gather of 0.58 M edge records) costs more than all device calls together.  "
-                                 "Python leg: the stage-wise drop-in sequence through the host-buffer C entry points (ebvo_toed_pair, "
-                                 "ebvo_epipolar_lines, ebvo_epi_candidates_staged = one search for the three stages, ebvo_ncc_pairs with left "
-                                 "patches), every input and output in pageable host arrays, no overlap between calls",
+                                 "include/ebvo/adapters.hpp (ProcessEdges x 2 with the by-value copies of src/Pipeline.cpp:28, "
+                                 "CalculateEpipolarLine, one staged candidate search, the lists after the orientation stage, NCC with the "
+                                 "left patches); every stage is handed the std::vectors the previous one returned, the adapters recognise "
+                                 "them (bit-for-bit comparison) as the edge lists still resident on the device and run the stage there "
+                                 "(ebvo_toed_resident / ebvo_epi_candidates_resident / ebvo_ncc_pairs_resident), results are read from "
+                                 "page-locked memory; no overlap between calls.  _python_harness / boundary_ms: the same C entry points "
+                                 "from numpy (every returned view copied into a fresh array)",
                 "with_h2d": n_leg / t_up, "with_h2d_d2h": n_leg / t_def, "d2h_bytes_per_pair": mb_def,
                 "with_h2d_d2h_all_scores": n_leg / t_all, "d2h_bytes_per_pair_all_scores": mb_all,
                 "with_h2d_d2h_pageable_copies": max(nslots, n_leg // 3) / t_pg, "transfer_leg_pairs": n_leg,

@@ -337,6 +337,26 @@ static int pair_passes(const orc_edge *l, const orc_edge *r, const double *ln, d
     return 1;
 }
 
+/* One of the LATER geometric stages applied to candidate lists that already exist, as the reference runs them:
+ * apply_Disparity_Filtering (src/Stereo_Matches.cpp:534-553) walks every row's list on the calling thread (its
+ * `#pragma omp for` has no enclosing parallel region: serial as written, nthreads = 1; nthreads > 1 = the obviously intended
+ * parallel form), apply_orientation_filter (:863-915) is a parallel region.  keep[k] = pair k passes the stage(s) in mask
+ * (ORC_STAGE_DISPARITY and / or ORC_STAGE_ORIENTATION). */
+int orc_filter_pairs(const orc_edge *L, int nL, const orc_edge *R, const int32_t *row_ptr, const int32_t *col_idx,
+                     double max_disp, double orient_thr_deg, int mask, int nthreads, uint8_t *keep)
+{
+    if (mask & ~(ORC_STAGE_DISPARITY | ORC_STAGE_ORIENTATION))
+        return -1;
+    if (nthreads <= 0)
+        nthreads = omp_get_num_procs();
+    const double no_line[3] = {0, 0, 0};
+#pragma omp parallel for schedule(dynamic) num_threads(nthreads)
+    for (int i = 0; i < nL; i++)
+        for (int32_t k = row_ptr[i]; k < row_ptr[i + 1]; k++)
+            keep[k] = (uint8_t)pair_passes(&L[i], &R[col_idx[k]], no_line, 0.0, max_disp, orient_thr_deg, mask);
+    return 0;
+}
+
 int orc_epi_candidates(const orc_edge *L, int nL, const orc_edge *R, int nR, const double *lines,
                        double epi_thr, double max_disp, double orient_thr_deg, int stage_mask,
                        int nthreads, int32_t *row_ptr, int32_t *col_idx, int64_t cap, int64_t *n_pairs)

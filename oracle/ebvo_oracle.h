@@ -64,6 +64,9 @@ void orc_epipolar_lines(const double *F, const orc_edge *edges, int n, double *l
  * row_ptr has nL + 1 entries; col_idx receives right indices in ascending order per row.
  * Returns 0, or -1 if cap is too small (*n_pairs = required size).
  */
+/* a later geometric stage (disparity and / or orientation) on existing candidate lists: keep[k] per listed pair */
+int orc_filter_pairs(const orc_edge *L, int nL, const orc_edge *R, const int32_t *row_ptr, const int32_t *col_idx,
+                     double max_disp, double orient_thr_deg, int mask, int nthreads, uint8_t *keep);
 int orc_epi_candidates(const orc_edge *L, int nL, const orc_edge *R, int nR, const double *lines,
                        double epi_thr, double max_disp, double orient_thr_deg, int stage_mask,
                        int nthreads, int32_t *row_ptr, int32_t *col_idx, int64_t cap, int64_t *n_pairs);

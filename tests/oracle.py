@@ -64,6 +64,19 @@ def epipolar_lines(F, edges):
     return out
 
 
+def filter_pairs(L, R, row_ptr, col_idx, max_disp=25.0, orient_thr_deg=10.0, stage_mask=2, nthreads=0):
+    """a later geometric stage (2 = disparity, 4 = orientation) applied to existing lists: keep flag per listed pair"""
+    L = np.ascontiguousarray(L, dtype=EDGE_DTYPE)
+    R = np.ascontiguousarray(R, dtype=EDGE_DTYPE)
+    row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int32)
+    col_idx = np.ascontiguousarray(col_idx, dtype=np.int32)
+    keep = np.zeros(len(col_idx), dtype=np.uint8)
+    rc = lib().orc_filter_pairs(_p(L), len(L), _p(R), _p(row_ptr), _p(col_idx), C.c_double(max_disp), C.c_double(orient_thr_deg),
+                                stage_mask, nthreads, _p(keep))
+    assert rc == 0
+    return keep
+
+
 def epi_candidates(L, R, lines, epi_thr=0.5, max_disp=25.0, orient_thr_deg=10.0, stage_mask=STAGE_ALL, nthreads=0):
     L = np.ascontiguousarray(L, dtype=EDGE_DTYPE)
     R = np.ascontiguousarray(R, dtype=EDGE_DTYPE)
