@@ -819,8 +819,8 @@ def main():
         cal = synth.CALIB[wl["cfg"]]
         calib = ([cal["K"][0], 0, cal["K"][2], 0, cal["K"][1], cal["K"][3], 0, 0, 1],
                  [cal["K_right"][0], 0, cal["K_right"][2], 0, cal["K_right"][1], cal["K_right"][3], 0, 0, 1], cal["R21"], cal["T21"])
-        n_drop = max(nslots, min(args.steps, 24))
-        dropin_loop(ctx, params, pool, calib, min(nslots, 3), min(nslots, 3))                 # untimed: sizes the chain's buffers
+        n_drop = 48                                                                           # (a fixed count: ~0.15 s)
+        dropin_loop(ctx, params, pool, calib, min(nslots, 3), 3 * len(pool))                  # untimed: every slot sees every pair of the pool (sizes the chain's buffers)
         t_drop, final_per_pair = dropin_loop(ctx, params, pool, calib, min(nslots, 3), n_drop)
         drop_threads = {str(T): threaded_dropin(T, args, H, W, F, device, pool, calib, 2 * n_drop) for T in host_threads(args)}
         # the drop-in path: what main_VO executes through integration/*.cpp -- host-buffer entry points, results in host

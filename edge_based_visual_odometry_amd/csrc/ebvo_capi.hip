@@ -162,7 +162,6 @@ static void slot_destroy(Slot *s)
         (void)hipFree(ws.cand_flag);
         (void)hipFree(ws.cand_off);
         (void)hipFree(ws.cand_data);
-        (void)hipFree(ws.cand_sector);
         (void)hipFree(ws.cand_lists);
         (void)hipFree(ws.cand_lcount);
     }
@@ -257,8 +256,7 @@ static int slot_create(ebvo_ctx *ctx, Slot **out)
         CK(hipMalloc(&ws.cand_rec, 40 * (size_t)ctx->cap_edges));
         CK(hipMalloc(&ws.cand_flag, sizeof(int32_t) * 2 * (size_t)ctx->cap_edges));
         CK(hipMalloc(&ws.cand_off, sizeof(int32_t) * 2 * ((size_t)ctx->cap_edges + 1)));
-        CK(hipMalloc(&ws.cand_data, sizeof(double) * 9 * (size_t)ctx->cap_edges));
-        CK(hipMalloc(&ws.cand_sector, sizeof(int32_t) * (size_t)ctx->cap_edges));
+        CK(hipMalloc(&ws.cand_data, 64 * (size_t)ctx->cap_edges));
         CK(hipMalloc(&ws.cand_lists, sizeof(int32_t) * 12 * (size_t)ctx->cap_edges));
         CK(hipMalloc(&ws.cand_lcount, sizeof(int32_t) * 12));
         CK(hipMalloc(&ws.src, sizeof(int32_t) * 2 * (size_t)ctx->cap_edges));

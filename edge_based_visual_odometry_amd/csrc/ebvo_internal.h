@@ -76,8 +76,7 @@ struct ImageWS
     void *cand_rec = nullptr;       // hybrid TOED: [cap] exact records of the screened candidates
     int32_t *cand_flag = nullptr;   // [2][cap]   is-maximum / is-kept flags per candidate
     int32_t *cand_off = nullptr;    // [2][cap+1] exclusive scans of the flags
-    double *cand_data = nullptr;    // [9][cap] exact gx, gy, |g|, TOx, TOy and the four neighbour magnitudes
-    int32_t *cand_sector = nullptr; // [cap] packed NMS sector, -1 if rejected early
+    double *cand_data = nullptr;    // [cap] 64-byte records: exact gx, gy, |g|, TOx, TOy and the packed NMS sector of a candidate
     int32_t *cand_lists = nullptr;  // [12][cap] candidate indices by phase (4) and by (phase, axis) (8)
     int32_t *cand_lcount = nullptr; // [12]
     int n_total = 0, n_kept = 0; // host copies, valid after a synchronising call

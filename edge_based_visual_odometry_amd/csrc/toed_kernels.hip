@@ -581,6 +581,7 @@ constexpr int FT_H = 12, FT_W = 30;           // pixels screened per block
 constexpr int FE_H = FT_H + 2, FE_W = FT_W + 2; // ext tile
 constexpr int FI_H = FE_H + 2 * HALO, FI_W = FE_W + 2 * HALO; // image tile 32 x 50
 static_assert(FI_W + 6 == 56 && FI_H * (FE_W / 4) == 256 && FE_W * 4 * (FE_H / 7) == 256, "one work item per thread in both passes");
+static_assert(FE_W == 32 && FE_H == 14, "the rotated LDS layout of the row planes assumes 32 columns and the row groups 0-6 / 7-13");
 
 constexpr int FI_P = 56; // image-tile row pitch in bytes (>= FI_W + 2, multiple of 4)
 struct FusedLds
@@ -661,16 +662,23 @@ __global__ __launch_bounds__(256) void toed_screen_fused_kernel(ImgBatch B, cons
                 ah[c][1] = __builtin_fma(x, hgx, ah[c][1]);
             }
         }
+        // Column c of row r lives at [r][(c + (r & 3)) & 31].  A wave holds 8 rows x 8 column groups; with the plain layout
+        // its 64 eight-byte stores of one instruction fell on FOUR bank pairs (rows are 256 bytes apart, the column groups 32
+        // bytes: 16 lanes per bank pair -- the 29 % LDS_BANK_CONFLICT of the round-2 counters).  The rotation spreads them over
+        // all sixteen (four lanes each: what a 512-byte store costs anyway); the column pass reads 32 consecutive columns of
+        // one row, which a rotation keeps conflict-free.
+        const int rot = r & 3;
 #pragma unroll
         for (int c = 0; c < 4; ++c)
         {
             const double xl = v[c + HALO + 9], xr = v[c + HALO - 9]; // taps q = -9 and q = +9
-            L.R[0][r][c0 + c] = a17[c][0];
-            L.R[1][r][c0 + c] = a17[c][1];
-            L.R[2][r][c0 + c] = __builtin_fma(xr, L.tap[0][18][0], __builtin_fma(xl, L.tap[0][0][0], a17[c][0]));
-            L.R[3][r][c0 + c] = __builtin_fma(xr, L.tap[0][18][1], __builtin_fma(xl, L.tap[0][0][1], a17[c][1]));
-            L.R[4][r][c0 + c] = __builtin_fma(xr, L.tap[1][18][0], __builtin_fma(xl, L.tap[1][0][0], ah[c][0]));
-            L.R[5][r][c0 + c] = __builtin_fma(xr, L.tap[1][18][1], __builtin_fma(xl, L.tap[1][0][1], ah[c][1]));
+            const int cc = (c0 + c + rot) & (FE_W - 1);
+            L.R[0][r][cc] = a17[c][0];
+            L.R[1][r][cc] = a17[c][1];
+            L.R[2][r][cc] = __builtin_fma(xr, L.tap[0][18][0], __builtin_fma(xl, L.tap[0][0][0], a17[c][0]));
+            L.R[3][r][cc] = __builtin_fma(xr, L.tap[0][18][1], __builtin_fma(xl, L.tap[0][0][1], a17[c][1]));
+            L.R[4][r][cc] = __builtin_fma(xr, L.tap[1][18][0], __builtin_fma(xl, L.tap[1][0][0], ah[c][0]));
+            L.R[5][r][cc] = __builtin_fma(xr, L.tap[1][18][1], __builtin_fma(xl, L.tap[1][0][1], ah[c][1]));
         }
     }
     __syncthreads();
@@ -682,11 +690,26 @@ __global__ __launch_bounds__(256) void toed_screen_fused_kernel(ImgBatch B, cons
         const int base = sx ? 4 : (sy ? 2 : 0);
         const int pm = (ph == 0) ? 8 : 9;
         double rg[25], rgx[25]; // R filtered with G / Gx along x, image-tile rows e0 .. e0 + 24
-#pragma unroll
-        for (int k = 0; k < 25; ++k)
+        // rotated columns (see the row pass): row e0 + k holds column c at (c + ((e0 + k) & 3)) & 31; e0 is 0 or 7 for the whole
+        // wave, so the rotation of row k is a compile-time pick among four precomputed columns
+        const int crot[4] = {c, (c + 1) & (FE_W - 1), (c + 2) & (FE_W - 1), (c + 3) & (FE_W - 1)};
+        if (e0 == 0)
         {
-            rg[k] = L.R[base][e0 + k][c];
-            rgx[k] = L.R[base + 1][e0 + k][c];
+#pragma unroll
+            for (int k = 0; k < 25; ++k)
+            {
+                rg[k] = L.R[base][k][crot[k & 3]];
+                rgx[k] = L.R[base + 1][k][crot[k & 3]];
+            }
+        }
+        else
+        {
+#pragma unroll
+            for (int k = 0; k < 25; ++k)
+            {
+                rg[k] = L.R[base][7 + k][crot[(7 + k) & 3]];
+                rgx[k] = L.R[base + 1][7 + k][crot[(7 + k) & 3]];
+            }
         }
 #pragma unroll
         for (int e = 0; e < 7; ++e)
@@ -912,11 +935,17 @@ __global__ __launch_bounds__(256) void toed_compact_phase_kernel(ImgBatch B, int
 // Candidates are bucketed by sub-pixel phase so that every wave works on ONE phase: the taps are scalar
 // operands again (no per-lane table look-ups, no divergence between the integer phase and the others), and
 // the 19 pixels of a tap row are fetched together (19 independent byte loads in flight per lane).
-struct CandData // structure of arrays, one entry per candidate, [cap] each
+// What the centre kernel hands the decision kernel, one 64-byte record (one cache line) per candidate.  As six arrays
+// indexed by candidate rank the stores of a wave (64 candidates of ONE phase: ranks scattered over the raster order) each
+// dirtied a 64-byte line for 8 bytes -- 46.6 MB written per pair for 12.5 MB of results in the round-2 counters.
+struct __attribute__((aligned(64))) CandExact
 {
-    double *gx, *gy, *m, *tox, *toy, *mag; // mag: [4][cap] neighbour magnitudes (p1, p2, m1, m2)
-    int32_t *sector;                       // packed (a1+1) | (b1+1)<<2 | (a2+1)<<4 | (b2+1)<<6, or -1 if rejected early
+    double gx, gy, m, tox, toy;
+    int32_t sector; // packed (a1+1) | (b1+1)<<2 | (a2+1)<<4 | (b2+1)<<6, or -1 if rejected early
+    int32_t pad0;
+    double pad1[2];
 };
+static_assert(sizeof(CandExact) == 64, "one cache line per candidate");
 
 struct ExactBatch
 {
@@ -925,7 +954,7 @@ struct ExactBatch
     const int32_t *counts[MAX_BATCH];
     int32_t *lists[MAX_BATCH];   // [12][cap]: 0-3 candidates by phase; 4-11 candidates by (phase, axis)
     int32_t *lcount[MAX_BATCH];  // [12]
-    CandData cd[MAX_BATCH];
+    CandExact *cd[MAX_BATCH]; // [cap]
     CandRec *rec[MAX_BATCH];
     int32_t *cand_flag[MAX_BATCH];
     // neighbour magnitudes, every distinct grid point once
@@ -1210,7 +1239,7 @@ __device__ inline void centre_run(const ExactBatch &E, const ExactTaps &L, int h
     const int W2 = 2 * w, H2 = 2 * h, wpr = (W2 + 31) >> 5;
     constexpr int PH = (SY << 1) | SX;
     const int32_t *__restrict__ list = E.lists[im] + (size_t)PH * cap;
-    const CandData &cd = E.cd[im];
+    CandExact *__restrict__ cd = E.cd[im];
     const uint8_t *__restrict__ flag = E.flag[im];
     if (k < n)
     {
@@ -1239,11 +1268,15 @@ __device__ inline void centre_run(const ExactBatch &E, const ExactTaps &L, int h
                     atomicOr(&E.needbits[im][(size_t)nI * wpr + (nJ >> 5)], 1u << (nJ & 31));
             }
         }
-        cd.gx[t] = gx;
-        cd.gy[t] = gy;
-        cd.m[t] = m;
-        third_order_dir(f, cd.tox[t], cd.toy[t]);
-        cd.sector[t] = packed;
+        CandExact r;
+        r.gx = gx;
+        r.gy = gy;
+        r.m = m;
+        third_order_dir(f, r.tox, r.toy);
+        r.sector = packed;
+        r.pad0 = 0;
+        r.pad1[0] = r.pad1[1] = 0.0;
+        cd[t] = r; // the whole line
         E.magmap[im][o] = m;
     }
 }
@@ -1434,7 +1467,7 @@ __global__ __launch_bounds__(256) void toed_exact_mags_kernel(ExactBatch E, cons
 __global__ __launch_bounds__(256) void toed_exact_decide_kernel(ExactBatch E, int h, int w, int cap)
 {
     const int im = blockIdx.y, W2 = 2 * w;
-    const CandData &cd = E.cd[im];
+    const CandExact *__restrict__ cd = E.cd[im];
     CandRec *__restrict__ rec = E.rec[im];
     int32_t *__restrict__ ft = E.cand_flag[im], *__restrict__ fk = ft + cap;
     const int n = min(E.counts[im][2], cap);
@@ -1442,11 +1475,12 @@ __global__ __launch_bounds__(256) void toed_exact_decide_kernel(ExactBatch E, in
     {
         const int o = E.src[im][2 * t];
         const int I = o / W2, J = o - I * W2;
-        const double gx = cd.gx[t], gy = cd.gy[t], m = cd.m[t];
+        const CandExact ce = cd[t];
+        const double gx = ce.gx, gy = ce.gy, m = ce.m;
         NmsSector S;
         bool is_max = false;
         double px = 0, py = 0, sm = 0;
-        if (cd.sector[t] >= 0 && nms_sector(m, gx, gy, S))
+        if (ce.sector >= 0 && nms_sector(m, gx, gy, S))
         {
             const double *__restrict__ mm = E.magmap[im];
             is_max = nms_finish(m, S, I, J, mm[(I + S.a1) * W2 + (J + S.b1)], mm[(I + S.a2) * W2 + (J + S.b2)],
@@ -1455,8 +1489,8 @@ __global__ __launch_bounds__(256) void toed_exact_decide_kernel(ExactBatch E, in
         int kept = 0;
         CandRec r;
         r.x = r.y = r.smag = 0.0;
-        r.tox = cd.tox[t];
-        r.toy = cd.toy[t];
+        r.tox = ce.tox;
+        r.toy = ce.toy;
         if (is_max)
         {
             r.x = (px - 1) / 2; // :538,542
@@ -1638,13 +1672,7 @@ int toed_enqueue(ebvo_ctx *ctx, Slot &s, int n_img, int h, int w, hipEvent_t ev_
                 E.counts[k] = ws.counts;
                 E.lists[k] = ws.cand_lists;
                 E.lcount[k] = ws.cand_lcount;
-                double *d = ws.cand_data;
-                E.cd[k].gx = d;
-                E.cd[k].gy = d + (size_t)cap;
-                E.cd[k].m = d + (size_t)2 * cap;
-                E.cd[k].tox = d + (size_t)3 * cap;
-                E.cd[k].toy = d + (size_t)4 * cap;
-                E.cd[k].sector = ws.cand_sector;
+                E.cd[k] = (CandExact *)ws.cand_data; // 64 of the buffer's 72 bytes per candidate
                 E.rec[k] = (CandRec *)ws.cand_rec;
                 E.cand_flag[k] = ws.cand_flag;
                 // the planes of the strict path are free in hybrid mode: |g| map, need bitmap, per-row counters
