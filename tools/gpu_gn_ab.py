@@ -18,10 +18,13 @@ for cfg, disp in (("kitti", 12), ("euroc", 9)):
         c.stereo_upload(l, r)
         c.stereo_run(c.default_params(F))
         c.stereo_finalize(calib, use_sift=True)
-        variants = [("launch per iteration", ((7, 1), (8, 2), (9, 0), (5, 0)))]
-        for below in (0, 32768, 65536, 98304, 131072, 262144):
-            for blocks in (256, 512):
-                variants.append((f"persistent, <= {blocks} blocks, rows layout below {below or 49152}", ((7, 0), (8, 2), (9, blocks), (5, below))))
+        variants = [("eight-lanes layout as a launch per iteration (round 2)", ((7, 1), (8, 2), (9, 0), (5, 49152))),
+                    ("persistent launch (default: <= 256 blocks, below 65536)", ((7, 0), (8, 2), (9, 0), (5, 0))),
+                    ("persistent, built for 3 waves / SIMD", ((7, 0), (8, 3), (9, 0), (5, 0)))]
+        for blocks in (512, 1024, 8192):
+            variants.append((f"persistent, <= {blocks} blocks", ((7, 0), (8, 2), (9, blocks), (5, 0))))
+        for below in (32768, 131072, 262144):
+            variants.append((f"persistent, eight-lanes layout below {below}", ((7, 0), (8, 2), (9, 0), (5, below))))
         for name, keys in variants:
             for k, v in keys:
                 c.debug_set(k, v)
