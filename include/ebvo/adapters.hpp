@@ -689,6 +689,69 @@ class StereoMatcherHIP
         return r;
     }
 
+    // The same in three enqueue-only steps for a frame loop that keeps several frames in flight (one slot each,
+    // ebvo_stereo_set_slots): _begin uploads the pair and submits TOED + candidates + NCC; _chain reads their counts and
+    // enqueues every later stage (no host synchronisation between the stages: their totals stay on the device); _end waits
+    // for the chain and copies the final pairs back.  While the chain of frame k runs, the caller begins frame k + 1 and
+    // ends frame k - 1: the chains of different slots overlap on the device (bench.py: dropin_final_pairs_per_s).
+    bool stereo_edge_pairs_begin(const uint8_t *imgL, const uint8_t *imgR, int rows, int cols, ptrdiff_t stepL, ptrdiff_t stepR,
+                                 const double F21[9], int slot, const ebvo_stereo_params *stereo = nullptr)
+    {
+        ebvo_stereo_params sp;
+        if (stereo)
+            sp = *stereo;
+        else
+        {
+            ebvo_stereo_default_params(&sp);
+            std::memcpy(sp.F21, F21, sizeof sp.F21);
+        }
+        ebvo_ctx *c = ctx_->get();
+        return report(*ctx_, last_status = ebvo_stereo_upload_slot(c, slot, imgL, imgR, rows, cols, stepL, stepR),
+                      "ebvo_stereo_upload_slot") &&
+               report(*ctx_, last_status = ebvo_stereo_submit(c, slot, &sp), "ebvo_stereo_submit");
+    }
+    bool stereo_edge_pairs_chain(int slot, const ebvo_stereo_calib *calib, bool use_sift = true, ebvo_stereo_counts *stage1 = nullptr,
+                                 const ebvo_finalize_params *fin = nullptr)
+    {
+        ebvo_finalize_params fp;
+        if (fin)
+            fp = *fin;
+        else
+        {
+            ebvo_finalize_default_params(&fp);
+            fp.use_sift = use_sift ? 1 : 0;
+        }
+        ebvo_stereo_counts tmp{};
+        ebvo_ctx *c = ctx_->get();
+        return report(*ctx_, last_status = ebvo_stereo_wait(c, slot, stage1 ? stage1 : &tmp), "ebvo_stereo_wait") &&
+               report(*ctx_, last_status = ebvo_stereo_finalize_submit(c, slot, &fp, calib), "ebvo_stereo_finalize_submit");
+    }
+    FinalPairs stereo_edge_pairs_end(int slot, bool with_rows, int n_left_edges = -1)
+    {
+        FinalPairs r;
+        ebvo_ctx *c = ctx_->get();
+        if (!report(*ctx_, last_status = ebvo_stereo_finalize_wait(c, slot, &r.stages), "ebvo_stereo_finalize_wait"))
+            return r;
+        const size_t n = (size_t)r.stages.n_final;
+        r.left_index.resize(n);
+        r.right.resize(n);
+        r.ncc_score.resize(n);
+        if (with_rows)
+            r.out16.resize(16 * n);
+        if (n_left_edges >= 0)
+        {
+            r.left_edges.resize((size_t)n_left_edges);
+            if (!report(*ctx_, last_status = ebvo_stereo_fetch_slot(c, slot, r.left_edges.data(), nullptr, nullptr, nullptr, nullptr,
+                                                                    nullptr, nullptr, nullptr),
+                        "ebvo_stereo_fetch_slot"))
+                return r;
+        }
+        report(*ctx_, last_status = ebvo_stereo_fetch_final(c, slot, r.left_index.data(), r.right.data(), r.ncc_score.data(),
+                                                            with_rows ? r.out16.data() : nullptr),
+               "ebvo_stereo_fetch_final");
+        return r;
+    }
+
   private:
     Context::Ptr ctx_;
 };

@@ -271,77 +271,14 @@ class BatchedStereoFeeder
     {
         if (status_ != EBVO_OK)
             return 0;
-        std::deque<StereoImages> ready;
-        std::mutex m;
-        std::condition_variable cv_space, cv_item;
-        bool eof = false;
-        std::atomic<bool> stop{false};
-        std::thread decoder([&] {
-            size_t produced = 0;
-            while (produced < max_frames && !stop.load())
-            {
-                StereoImages f;
-                if (!seq.getNext(f))
-                    break;
-                std::unique_lock<std::mutex> lk(m);
-                cv_space.wait(lk, [&] { return (int)ready.size() < ahead_ || stop.load(); });
-                if (stop.load())
-                    break;
-                ready.push_back(std::move(f));
-                ++produced;
-                cv_item.notify_one();
-            }
-            std::lock_guard<std::mutex> lk(m);
-            eof = true;
-            cv_item.notify_one();
-        });
-        auto take = [&](StereoImages &f) {
-            std::unique_lock<std::mutex> lk(m);
-            cv_item.wait(lk, [&] { return !ready.empty() || eof; });
-            if (ready.empty())
-                return false;
-            f = std::move(ready.front());
-            ready.pop_front();
-            cv_space.notify_one();
-            return true;
-        };
+        Reader reader(seq, ahead_, max_frames);
         std::vector<StereoImages> in_slot((size_t)slots_);
-        std::vector<bool> busy((size_t)slots_, false);
         size_t submitted = 0, completed = 0;
-        auto launch = [&](int k) {
-            StereoImages f;
-            // left and right must share one size (the TOED object is built once from the left image); a pair
-            // that does not is reported and skipped, as the reference does for frames that fail to load
-            for (;;)
-            {
-                if (!take(f))
-                    return false;
-                if (f.left.width == f.right.width && f.left.height == f.right.height &&
-                    f.left.pixels.size() == (size_t)f.left.width * f.left.height &&
-                    f.right.pixels.size() == (size_t)f.right.width * f.right.height)
-                    break;
-                std::fprintf(stderr, "[ebvo] pair %zu skipped: left %dx%d, right %dx%d\n", f.index, f.left.width, f.left.height,
-                             f.right.width, f.right.height);
-                ++skipped_;
-            }
-            int rc = ebvo_stereo_upload_slot(ctx_, k, f.left.pixels.data(), f.right.pixels.data(), f.left.height, f.left.width,
-                                             f.left.width, f.right.width);
-            if (rc == EBVO_OK)
-                rc = ebvo_stereo_submit(ctx_, k, &params);
-            if (rc != EBVO_OK)
-            {
-                std::fprintf(stderr, "[ebvo] pair %zu: %s (%s)\n", f.index, ebvo_strerror(rc), ebvo_last_error(ctx_));
-                status_ = rc;
-                return false;
-            }
-            in_slot[(size_t)k] = std::move(f);
-            busy[(size_t)k] = true;
-            ++submitted;
-            return true;
-        };
         for (int k = 0; k < slots_; ++k)
-            if (!launch(k))
+            if (!launch(reader, params, k, in_slot))
                 break;
+            else
+                ++submitted;
         while (completed < submitted)
         {
             const int k = (int)(completed % (size_t)slots_);
@@ -354,19 +291,178 @@ class BatchedStereoFeeder
                 break;
             }
             done(in_slot[(size_t)k], k, c);
-            busy[(size_t)k] = false;
             ++completed;
-            if (status_ == EBVO_OK)
-                launch(k);
+            if (status_ == EBVO_OK && launch(reader, params, k, in_slot))
+                ++submitted;
         }
-        {
-            std::lock_guard<std::mutex> lk(m);
-            stop.store(true); // unblock a decoder that still waits for space
-            ready.clear();
-            cv_space.notify_all();
-        }
-        decoder.join();
         return completed;
+    }
+
+    // The same loop with the stages after the first NCC pass as well (ebvo_stereo_finalize_submit / _wait): when the counts
+    // of a pair have arrived its chain is enqueued at once, without a host synchronisation between its stages, and the pair
+    // stays in its slot until the chain has run; up to `chains` chains are in flight next to the pairs still in their first
+    // stage, and a slot receives its next pair when its chain has been retired.  `done` runs on the calling thread, in
+    // sequence order, with the final pairs of the frame still resident in its slot (ebvo_stereo_fetch_final, or
+    // ebvo_temporal_* against a keyframe).
+    using ChainCallback = std::function<void(const StereoImages &frame, int slot, const ebvo_stereo_counts &counts,
+                                             const ebvo_finalize_counts &final_counts)>;
+    size_t run_chain(StereoSequence &seq, const ebvo_stereo_params &params, const ebvo_finalize_params &fin,
+                     const ebvo_stereo_calib *calib, const ChainCallback &done, int chains = 2, size_t max_frames = (size_t)-1)
+    {
+        if (status_ != EBVO_OK)
+            return 0;
+        if (chains < 1)
+            chains = 1;
+        if (chains > slots_)
+            chains = slots_;
+        Reader reader(seq, ahead_, max_frames);
+        std::vector<StereoImages> in_slot((size_t)slots_);
+        std::deque<std::pair<int, ebvo_stereo_counts>> in_chain; // slots whose chain is enqueued, oldest first
+        std::deque<int> stage1;                                  // slots whose first stage is submitted, oldest first
+        size_t finished = 0;
+        auto retire = [&]() {
+            const int k = in_chain.front().first;
+            const ebvo_stereo_counts c = in_chain.front().second;
+            in_chain.pop_front();
+            ebvo_finalize_counts fc;
+            const int rc = ebvo_stereo_finalize_wait(ctx_, k, &fc);
+            if (rc != EBVO_OK)
+            {
+                std::fprintf(stderr, "[ebvo] finalize_wait: %s (%s)\n", ebvo_strerror(rc), ebvo_last_error(ctx_));
+                status_ = rc;
+                return;
+            }
+            done(in_slot[(size_t)k], k, c, fc);
+            ++finished;
+            if (launch(reader, params, k, in_slot)) // the slot is free again
+                stage1.push_back(k);
+        };
+        for (int k = 0; k < slots_; ++k)
+            if (launch(reader, params, k, in_slot))
+                stage1.push_back(k);
+            else
+                break;
+        while (status_ == EBVO_OK && (!stage1.empty() || !in_chain.empty()))
+        {
+            if (!stage1.empty())
+            {
+                const int k = stage1.front();
+                stage1.pop_front();
+                ebvo_stereo_counts c;
+                int rc = ebvo_stereo_wait(ctx_, k, &c);
+                if (rc == EBVO_OK)
+                    rc = ebvo_stereo_finalize_submit(ctx_, k, &fin, calib);
+                if (rc != EBVO_OK)
+                {
+                    std::fprintf(stderr, "[ebvo] pair %zu: %s (%s)\n", in_slot[(size_t)k].index, ebvo_strerror(rc), ebvo_last_error(ctx_));
+                    status_ = rc;
+                    break;
+                }
+                in_chain.emplace_back(k, c);
+            }
+            while (status_ == EBVO_OK && !in_chain.empty() && ((int)in_chain.size() >= chains || stage1.empty()))
+                retire();
+        }
+        if (status_ != EBVO_OK) // leave nothing in flight behind an error
+        {
+            ebvo_finalize_counts fc;
+            ebvo_stereo_counts c;
+            for (auto &pr : in_chain)
+                (void)ebvo_stereo_finalize_wait(ctx_, pr.first, &fc);
+            for (int k : stage1)
+                (void)ebvo_stereo_wait(ctx_, k, &c);
+        }
+        return finished;
+    }
+
+  private:
+    // decode on a background thread, `ahead` pairs in front of the consumer
+    class Reader
+    {
+      public:
+        Reader(StereoSequence &seq, int ahead, size_t max_frames)
+            : decoder_([this, &seq, ahead, max_frames] {
+                  size_t produced = 0;
+                  while (produced < max_frames && !stop_.load())
+                  {
+                      StereoImages f;
+                      if (!seq.getNext(f))
+                          break;
+                      std::unique_lock<std::mutex> lk(m_);
+                      cv_space_.wait(lk, [&] { return (int)ready_.size() < ahead || stop_.load(); });
+                      if (stop_.load())
+                          break;
+                      ready_.push_back(std::move(f));
+                      ++produced;
+                      cv_item_.notify_one();
+                  }
+                  std::lock_guard<std::mutex> lk(m_);
+                  eof_ = true;
+                  cv_item_.notify_one();
+              })
+        {
+        }
+        ~Reader()
+        {
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                stop_.store(true); // unblock a decoder that still waits for space
+                ready_.clear();
+                cv_space_.notify_all();
+            }
+            decoder_.join();
+        }
+        bool take(StereoImages &f)
+        {
+            std::unique_lock<std::mutex> lk(m_);
+            cv_item_.wait(lk, [&] { return !ready_.empty() || eof_; });
+            if (ready_.empty())
+                return false;
+            f = std::move(ready_.front());
+            ready_.pop_front();
+            cv_space_.notify_one();
+            return true;
+        }
+
+      private:
+        std::deque<StereoImages> ready_;
+        std::mutex m_;
+        std::condition_variable cv_space_, cv_item_;
+        bool eof_ = false;
+        std::atomic<bool> stop_{false};
+        std::thread decoder_; // last member: starts when everything above exists
+    };
+
+    // next pair of the sequence into slot k: upload + submit; false = the sequence has ended or a call failed (status_)
+    bool launch(Reader &reader, const ebvo_stereo_params &params, int k, std::vector<StereoImages> &in_slot)
+    {
+        StereoImages f;
+        // left and right must share one size (the TOED object is built once from the left image); a pair
+        // that does not is reported and skipped, as the reference does for frames that fail to load
+        for (;;)
+        {
+            if (!reader.take(f))
+                return false;
+            if (f.left.width == f.right.width && f.left.height == f.right.height &&
+                f.left.pixels.size() == (size_t)f.left.width * f.left.height &&
+                f.right.pixels.size() == (size_t)f.right.width * f.right.height)
+                break;
+            std::fprintf(stderr, "[ebvo] pair %zu skipped: left %dx%d, right %dx%d\n", f.index, f.left.width, f.left.height,
+                         f.right.width, f.right.height);
+            ++skipped_;
+        }
+        int rc = ebvo_stereo_upload_slot(ctx_, k, f.left.pixels.data(), f.right.pixels.data(), f.left.height, f.left.width,
+                                         f.left.width, f.right.width);
+        if (rc == EBVO_OK)
+            rc = ebvo_stereo_submit(ctx_, k, &params);
+        if (rc != EBVO_OK)
+        {
+            std::fprintf(stderr, "[ebvo] pair %zu: %s (%s)\n", f.index, ebvo_strerror(rc), ebvo_last_error(ctx_));
+            status_ = rc;
+            return false;
+        }
+        in_slot[(size_t)k] = std::move(f);
+        return true;
     }
 
   private:

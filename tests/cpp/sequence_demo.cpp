@@ -34,7 +34,14 @@ int main(int argc, char **argv)
     }
     std::unique_ptr<ebvo::StereoSequence> seq;
     int slots = 3;
-    if (argc >= 4 && !std::strcmp(argv[1], "kitti"))
+    bool chain = false;
+    if (argc >= 4 && !std::strcmp(argv[1], "kitti-chain")) // the same walk with the stages after the first NCC pass
+    {
+        seq.reset(new ebvo::KittiSequence(argv[2]));
+        slots = std::atoi(argv[3]);
+        chain = true;
+    }
+    else if (argc >= 4 && !std::strcmp(argv[1], "kitti"))
     {
         seq.reset(new ebvo::KittiSequence(argv[2]));
         slots = std::atoi(argv[3]);
@@ -68,6 +75,20 @@ int main(int argc, char **argv)
     const double fx = 718.856, T = 0.54;
     const double F[9] = {0, 0, 0, 0, 0, -T / fx, 0, T / fx, 0};
     std::memcpy(p.F21, F, sizeof F);
+    if (chain)
+    {
+        ebvo_finalize_params fp;
+        ebvo_finalize_default_params(&fp);
+        fp.use_sift = 1;
+        ebvo::BatchedStereoFeeder feeder(ctx, slots);
+        const size_t n = feeder.run_chain(*seq, p, fp, nullptr,
+                                          [](const ebvo::StereoImages &f, int, const ebvo_stereo_counts &c, const ebvo_finalize_counts &fc) {
+                                              std::printf("%zu %d %lld %d %d %d %d\n", f.index, c.n_left, (long long)c.n_matches, fc.n_sift,
+                                                          fc.n_bnb, fc.n_clusters, fc.n_final);
+                                          });
+        std::printf("pairs %zu status %d\n", n, feeder.status());
+    }
+    else
     {
         ebvo::BatchedStereoFeeder feeder(ctx, slots);
         const size_t n = feeder.run(*seq, p, [](const ebvo::StereoImages &f, int, const ebvo_stereo_counts &c) {

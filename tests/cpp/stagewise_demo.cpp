@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <utility>
 #include <vector>
 
 #include "ebvo/adapters.hpp"
@@ -184,6 +185,36 @@ int main(int argc, char **argv)
         bad[bad.size() / 3] = (int32_t)right_b.size();
         auto s6 = matcher.ncc_indexed(left.data, right.data, h, w, sl, sr, left_b, right_b, row_ptr, bad);
         CHECK(matcher.last_status == EBVO_ERR_ARG && s6.best.empty(), 21);
+    }
+
+    // ---- get_Stereo_Edge_Pairs in one pass, two frames in flight: begin / chain / end equal the one-call form ---------------
+    {
+        ebvo_stereo_calib calib = {{f, 0, 607.1928, 0, f, 185.2157, 0, 0, 1}, {f, 0, 607.1928, 0, f, 185.2157, 0, 0, 1},
+                                   {1, 0, 0, 0, 1, 0, 0, 0, 1}, {t, 0, 0}};
+        CHECK(ebvo_stereo_set_slots(TOED->context()->get(), 2) == EBVO_OK, 30);
+        auto ref0 = matcher.stereo_edge_pairs(left.data, right.data, h, w, sl, sr, F, &calib, true, 0);
+        auto ref1 = matcher.stereo_edge_pairs(right.data, left.data, h, w, sr, sl, F, &calib, true, 1); // another pair: the images swapped
+        CHECK(matcher.last_status == EBVO_OK && ref0.stages.n_final > 100, 31);
+        CHECK(matcher.stereo_edge_pairs_begin(left.data, right.data, h, w, sl, sr, F, 0) &&
+                  matcher.stereo_edge_pairs_begin(right.data, left.data, h, w, sr, sl, F, 1),
+              32);
+        ebvo_stereo_counts c0{}, c1{};
+        CHECK(matcher.stereo_edge_pairs_chain(0, &calib, true, &c0) && matcher.stereo_edge_pairs_chain(1, &calib, true, &c1), 33);
+        auto got1 = matcher.stereo_edge_pairs_end(1, true, c1.n_left);
+        auto got0 = matcher.stereo_edge_pairs_end(0, true, c0.n_left);
+        CHECK(matcher.last_status == EBVO_OK, 34);
+        for (auto pr : {std::make_pair(&got0, &ref0), std::make_pair(&got1, &ref1)})
+        {
+            const auto &g = *pr.first, &r = *pr.second;
+            CHECK(std::memcmp(&g.stages, &r.stages, sizeof g.stages) == 0 && g.left_index == r.left_index && g.ncc_score == r.ncc_score &&
+                      g.out16.size() == r.out16.size() &&
+                      std::memcmp(g.out16.data(), r.out16.data(), sizeof(double) * g.out16.size()) == 0 &&
+                      g.right.size() == r.right.size() &&
+                      std::memcmp(g.right.data(), r.right.data(), sizeof(ebvo_edge) * g.right.size()) == 0 &&
+                      g.left_edges.size() == r.left_edges.size() &&
+                      std::memcmp(g.left_edges.data(), r.left_edges.data(), sizeof(ebvo_edge) * g.left_edges.size()) == 0,
+                  35);
+        }
     }
 
     FILE *o = std::fopen(argv[5], "wb");

@@ -87,6 +87,33 @@ def test_kitti_feeder_equals_python_driver(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("slots", [1, 2, 4])
+def test_kitti_feeder_with_the_chain_equals_python_driver(tmp_path, slots):
+    """BatchedStereoFeeder::run_chain: the chains of several frames in flight, results in sequence order"""
+    from PIL import Image
+    from edge_based_visual_odometry_amd.api import Context
+    build_demo()
+    h, w, n = 120, 200, 9
+    os.makedirs(tmp_path / "image_0")
+    os.makedirs(tmp_path / "image_1")
+    pairs = [synth.stereo_pair("s2", h, w, noise_base=10 * k) for k in range(n)]
+    for k, (l, r) in enumerate(pairs):
+        Image.fromarray(l, "L").save(tmp_path / "image_0" / f"{k:06d}.png")
+        Image.fromarray(r, "L").save(tmp_path / "image_1" / f"{k:06d}.png")
+    out = subprocess.run([EXE, "kitti-chain", str(tmp_path), str(slots)], capture_output=True, text=True, check=True).stdout.split("\n")
+    assert out[n].startswith(f"pairs {n} status 0")
+    fx, T = 718.856, 0.54
+    F = np.array([[0, 0, 0], [0, 0, -T / fx], [0, T / fx, 0]])
+    with Context(h, w, toed_mode="hybrid") as c:
+        for k, (l, r) in enumerate(pairs):
+            c.stereo_upload(l, r)
+            cnt = c.stereo_run(c.default_params(F))
+            fc, _ = c.stereo_finalize(None, use_sift=True)
+            assert out[k] == f"{k} {cnt.n_left} {cnt.n_matches} {fc['n_sift']} {fc['n_bnb']} {fc['n_clusters']} {fc['n_final']}"
+            assert fc["n_final"] > 100
+
+
+@pytest.mark.gpu
 def test_euroc_feeder_reads_the_csv(tmp_path):
     from PIL import Image
     build_demo()
