@@ -947,6 +947,17 @@ struct __attribute__((aligned(64))) CandExact
 };
 static_assert(sizeof(CandExact) == 64, "one cache line per candidate");
 
+// The exact-|g| map holds a value at every candidate and at every marked neighbour point, i.e. along the edges: 8-byte
+// accesses scattered over a 2H x 2W array.  Stored in 2 x 4 tiles of grid points (one 64-byte line each) a candidate and the
+// points one grid step around it share at most four lines whatever the direction of the edge (row-major: three rows, a line
+// or two each, and a vertical edge dirties a line per point).
+__host__ __device__ inline size_t mag_tiles_per_row(int W2) { return (size_t)((W2 + 3) >> 2); }
+__host__ __device__ inline size_t mag_map_doubles(int H2, int W2) { return (size_t)((H2 + 1) >> 1) * mag_tiles_per_row(W2) * 8; }
+__host__ __device__ inline size_t mag_index(int I, int J, int W2)
+{
+    return ((size_t)(I >> 1) * mag_tiles_per_row(W2) + (size_t)(J >> 2)) * 8 + (size_t)(((I & 1) << 2) | (J & 3));
+}
+
 struct ExactBatch
 {
     const uint8_t *img[MAX_BATCH];
@@ -962,7 +973,7 @@ struct ExactBatch
     uint32_t *needbits[MAX_BATCH];  // [2H][ceil(2W / 32)] bit J of row I: the exact |g| of grid point (I, J) is needed
     int32_t *need_cnt[MAX_BATCH];   // [2][2H] marked points per grid row, even / odd columns
     int32_t *need_off[MAX_BATCH];   // [2][2H] their offsets in the phase lists (lists 4..7, lengths lcount[4..7])
-    double *magmap[MAX_BATCH];      // [2H x 2W] exact |g| at candidates and at marked points
+    double *magmap[MAX_BATCH];      // exact |g| at candidates and at marked points, 2 x 4 tiles (mag_index)
 };
 
 // append `value` to list `which` for the lanes with `put`, one atomic per block; returns nothing.
@@ -1277,7 +1288,7 @@ __device__ inline void centre_run(const ExactBatch &E, const ExactTaps &L, int h
         r.pad0 = 0;
         r.pad1[0] = r.pad1[1] = 0.0;
         cd[t] = r; // the whole line
-        E.magmap[im][o] = m;
+        E.magmap[im][mag_index(I, J, W2)] = m;
     }
 }
 
@@ -1436,7 +1447,7 @@ __device__ inline void mags_run(const ExactBatch &E, const ExactTaps &L, int h, 
     {
         const int o = list[k];
         const int I = o / W2, J = o - I * W2;
-        E.magmap[im][o] = exact_mag<SY, SX>(E.img[im], h, w, L, I, J);
+        E.magmap[im][mag_index(I, J, W2)] = exact_mag<SY, SX>(E.img[im], h, w, L, I, J);
     }
 }
 
@@ -1483,8 +1494,8 @@ __global__ __launch_bounds__(256) void toed_exact_decide_kernel(ExactBatch E, in
         if (ce.sector >= 0 && nms_sector(m, gx, gy, S))
         {
             const double *__restrict__ mm = E.magmap[im];
-            is_max = nms_finish(m, S, I, J, mm[(I + S.a1) * W2 + (J + S.b1)], mm[(I + S.a2) * W2 + (J + S.b2)],
-                                mm[(I - S.a1) * W2 + (J - S.b1)], mm[(I - S.a2) * W2 + (J - S.b2)], px, py, sm);
+            is_max = nms_finish(m, S, I, J, mm[mag_index(I + S.a1, J + S.b1, W2)], mm[mag_index(I + S.a2, J + S.b2, W2)],
+                                mm[mag_index(I - S.a1, J - S.b1, W2)], mm[mag_index(I - S.a2, J - S.b2, W2)], px, py, sm);
         }
         int kept = 0;
         CandRec r;
@@ -1635,7 +1646,7 @@ int toed_enqueue(ebvo_ctx *ctx, Slot &s, int n_img, int h, int w, hipEvent_t ev_
             if (ctx->toed_mode == EBVO_TOED_HYBRID)
             {
                 // need bitmap + its per-row counters live behind the |g| map in the (otherwise unused) plane buffer
-                ptrs[nc] = (int32_t *)(s.im[k].maps + (size_t)H2 * W2);
+                ptrs[nc] = (int32_t *)(s.im[k].maps + mag_map_doubles(H2, W2));
                 counts[nc++] = need_words; // the per-row counters behind it are written by toed_need_count_kernel
             }
         }
@@ -1678,7 +1689,7 @@ int toed_enqueue(ebvo_ctx *ctx, Slot &s, int n_img, int h, int w, hipEvent_t ev_
                 // the planes of the strict path are free in hybrid mode: |g| map, need bitmap, per-row counters
                 E.flag[k] = ws.flag;
                 E.magmap[k] = ws.maps;
-                E.needbits[k] = (uint32_t *)(ws.maps + (size_t)H2 * W2);
+                E.needbits[k] = (uint32_t *)(ws.maps + mag_map_doubles(H2, W2));
                 E.need_cnt[k] = (int32_t *)(E.needbits[k] + need_words);
                 E.need_off[k] = E.need_cnt[k] + 2 * H2;
             }
