@@ -146,3 +146,40 @@ def test_a_slot_with_a_chain_in_flight_accepts_nothing_else():
         ctx.temporal_match_submit(stages=1)
         tc, q = ctx.temporal_match_wait()
         assert tc["n_cf"] == 0 and tc["n_final"] == 0 and len(q["final"]["row_ptr"]) == tc["n_kf"] + 1
+
+
+def test_pipelined_frames_with_undistortion_equal_one_call_forms():
+    """the raw / undistorted split of the resident pipeline through the enqueue-only chains"""
+    F, calib, frames = _setup()
+    ce = synth.CALIB["euroc"]
+    K = tuple(v / 2 for v in ce["K"])
+    Kr = tuple(v / 2 for v in ce["K_right"])
+    with Context(H, W, device=0) as ctx:
+        ctx.set_slots(3)
+        ctx.set_undistort(K, ce["dist"], Kr, ce["dist_right"])
+        params = ctx.default_params(F)
+        ref = []
+        for k in range(3):
+            ctx.stereo_upload(*frames[k], slot=k)
+            ctx.stereo_submit(params, slot=k)
+            ctx.stereo_wait(slot=k)
+            fc, fin = ctx.stereo_finalize(calib, slot=k, use_sift=True)
+            if k == 0:
+                ctx.temporal_set_keyframe(slot=0)
+                ref.append((fc, fin, None, None))
+            else:
+                ref.append((fc, fin) + ctx.temporal_match(slot=k, stages=1))
+        for k in (1, 2):
+            ctx.stereo_submit(params, slot=k)
+        for k in (1, 2):
+            ctx.stereo_wait(slot=k)
+            ctx.stereo_finalize_submit(calib, slot=k, use_sift=True)
+        fins = {k: ctx.stereo_finalize_wait(slot=k) for k in (2, 1)}
+        for k in (1, 2):
+            ctx.temporal_match_submit(slot=k, stages=1)
+        for k in (1, 2):
+            tc, q = ctx.temporal_match_wait(slot=k)
+            assert fins[k][0] == ref[k][0] and tc == ref[k][2]
+            _same_final(fins[k][1], ref[k][1])
+            _same_quads(q, ref[k][3], True)
+        assert ref[1][2]["n_final"] > 300

@@ -159,3 +159,33 @@ def test_images_without_edges(ctx):
     assert len(best) == 0 and lp.shape == (len(eL), 2, 49)
     rp, ci = ctx.epi_candidates_resident(tagR, tagL, np.zeros((0, 3)))       # no left edges
     assert len(rp) == 1 and len(ci) == 0
+
+
+@pytest.mark.parametrize("cfg", ["euroc", "eth3d"])
+def test_stagewise_resident_with_strided_images_and_slanted_lines(ctx, cfg):
+    """non-rectified calibration (slanted epipolar lines) and images that are views into wider buffers (cv::Mat ROI: step > cols)"""
+    h, w = 200, 312
+    l, r = _pair(h, w, disparity=9)
+    wide_l = np.zeros((h, w + 24), dtype=np.uint8)
+    wide_r = np.full((h, w + 40), 255, dtype=np.uint8)
+    wide_l[:, 8:8 + w] = l
+    wide_r[:, 16:16 + w] = r
+    vl, vr = wide_l[:, 8:8 + w], wide_r[:, 16:16 + w]          # strides w + 24 / w + 40
+    assert not vl.flags["C_CONTIGUOUS"]
+    F = synth.fundamental_for(cfg)
+    eL, _, _, tagL = ctx.toed_resident(vl, 0)
+    eR, _, _, tagR = ctx.toed_resident(vr, 1)
+    oL, oR = orc.toed(l)["edges"], orc.toed(r)["edges"]
+    assert_edges_equal(eL, oL, "left")
+    assert_edges_equal(eR, oR, "right")
+    lines = ctx.epipolar_lines(F, eL)
+    rp, ci = ctx.epi_candidates_resident(tagL, tagR, lines)
+    orp, oci = orc.epi_candidates(oL, oR, lines)
+    assert_bit_equal(rp, orp, "row_ptr")
+    assert_bit_equal(ci, oci, "col_idx")
+    assert len(ci) > len(eL)
+    sims, best, keep, lp = ctx.ncc_pairs_resident(tagL, tagR, vl, vr, rp, ci, want_left_patches=True)
+    osims, obest, okeep, _ = orc.ncc_pairs(l, r, oL, oR[oci], orp)
+    assert_bit_equal(sims, osims, "sims")
+    assert_bit_equal(keep, okeep, "keep")
+    assert_bit_equal(lp, orc.edge_patches(l, oL), "left patches")
