@@ -726,9 +726,16 @@ def main():
     params = ctx.default_params(F)
     for k in range(nslots):
         ctx.stereo_upload(left, right, slot=k)
-        for _ in range(args.warmup):
-            ctx.stereo_submit(params, slot=k)
-            counts = ctx.stereo_wait(slot=k)
+    # warm-up: --warmup pairs per slot through the same pipelined submit / wait pattern as the timed region (lane streams, page-
+    # locked records and the capacity-sized buffers are all in their steady state afterwards)
+    n_warm = max(1, args.warmup) * nslots
+    sub = done = 0
+    while done < n_warm:
+        while sub < n_warm and sub - done < nslots:
+            ctx.stereo_submit(params, slot=sub % nslots)
+            sub += 1
+        counts = ctx.stereo_wait(slot=done % nslots)
+        done += 1
 
     def barrier():
         torch.cuda.synchronize()
