@@ -647,16 +647,23 @@ __device__ inline bool gn_rows_iteration(const GnArgs &A, int64_t k, GnRowsState
     const double shx = ex * alpha, shy = ey * alpha;
     const int i = min(row, 6) - 3; // this lane's patch row (lane 7 repeats row 6 and is never selected)
     double H = 0.0, b = 0.0, cost = 0.0;
-#pragma unroll 1
+    // this lane's row of BOTH sides, tapped once (intensity and both gradients): the fourteen record loads are in flight
+    // together, the second side's arrive while the first side's sums form
+    GnTap tps[2][7];
+#pragma unroll
+    for (int sd = 0; sd < 2; ++sd)
+    {
+        const double cx = (sd ? rx - nx * side : rx + nx * side) + shx; // :1204-1205
+        const double cy = (sd ? ry - ny * side : ry + ny * side) + shy;
+#pragma unroll
+        for (int j = -3; j <= 3; ++j)
+            tps[sd][j + 3] = gn_tap(A.recR, w, h, cx + ct * i - st * j, cy + st * i + ct * j);
+    }
+#pragma unroll
     for (int sd = 0; sd < 2; ++sd)
     {
         const float *__restrict__ lrec = A.left_rec + (size_t)li * 98 + sd * 49 + (i + 3) * 7;
-        const double cx = (sd ? rx - nx * side : rx + nx * side) + shx; // :1204-1205
-        const double cy = (sd ? ry - ny * side : ry + ny * side) + shy;
-        GnTap tp[7]; // this lane's row of the side: tapped once, intensity and both gradients
-#pragma unroll
-        for (int j = -3; j <= 3; ++j)
-            tp[j + 3] = gn_tap(A.recR, w, h, cx + ct * i - st * j, cy + st * i + ct * j);
+        const GnTap *tp = tps[sd];
         double sum = 0;
 #pragma unroll 1
         for (int r = 0; r < 7; ++r)
@@ -730,7 +737,7 @@ __device__ inline bool gn_rows_iteration(const GnArgs &A, int64_t k, GnRowsState
     return finished;
 }
 
-__global__ __launch_bounds__(256, GN_ROWS_WAVES) void gn_iter_rows_kernel(GnArgs A, int it, int mode)
+__global__ __launch_bounds__(256, 2) void gn_iter_rows_kernel(GnArgs A, int it, int mode) // (two waves per SIMD: both sides' taps are live)
 {
     const int n_in = A.counts[it];
     if (gn_other_layout(mode, n_in, A.rows_below))
