@@ -615,6 +615,15 @@ __global__ __launch_bounds__(256, 2) void gn_iter_kernel(GnArgs A, int it, int m
 #ifndef GN_ROWS_WAVES
 #define GN_ROWS_WAVES 3 // waves per SIMD the row layout is compiled for (166 VGPRs; 4 -> 128 with spills, measured slower)
 #endif
+// lane i receives lane i - 1's value (rows of 16 lanes; the first lane of a row receives 0): two DPP register moves
+__device__ inline double row_shr1(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x111, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
 // what an eight-lane group keeps of its pair between iterations (the persistent kernel below loads it once per pair)
 struct GnRowsState
 {
@@ -664,16 +673,21 @@ __device__ inline bool gn_rows_iteration(const GnArgs &A, int64_t k, GnRowsState
     {
         const float *__restrict__ lrec = A.left_rec + (size_t)li * 98 + sd * 49 + (i + 3) * 7;
         const GnTap *tp = tps[sd];
-        double sum = 0;
+        // The reference's sum runs over the 49 samples in order, i.e. through the lanes in row order.  In round r lane r adds
+        // its seven terms to what lane r - 1 handed it in round r - 1 (a DPP shift by one lane: a register move, where a
+        // ds_bpermute per round put 28 LDS round trips per side on the critical path); what the other lanes compute in that
+        // round is discarded.  After round 6 lane 6 holds the sum.
+        double run = 0.0, t = 0.0;
 #pragma unroll 1
         for (int r = 0; r < 7; ++r)
         {
-            double t = sum;
+            t = run;
 #pragma unroll
             for (int j = 0; j < 7; ++j)
                 t += (double)tp[j].v;
-            sum = __shfl(t, gbase | r); // the running sum after row r
+            run = row_shr1(t);
         }
+        const double sum = __shfl(t, gbase | 6);
         const double meanR = sum / 49;
         double tH[7], tb[7], tc[7];
 #pragma unroll
@@ -689,10 +703,12 @@ __device__ inline bool gn_rows_iteration(const GnArgs &A, int64_t k, GnRowsState
             tb[j] = wgt * g * r;
             tc[j] = wgt * r * r;
         }
+        // (H, b, cost enter the side on lane 0: every lane holds the totals of the previous side)
+        double rH = H, rb = b, rc = cost, uH = 0.0, ub = 0.0, uc = 0.0;
 #pragma unroll 1
         for (int r = 0; r < 7; ++r)
         {
-            double uH = H, ub = b, uc = cost;
+            uH = rH, ub = rb, uc = rc;
 #pragma unroll
             for (int j = 0; j < 7; ++j)
             {
@@ -700,10 +716,13 @@ __device__ inline bool gn_rows_iteration(const GnArgs &A, int64_t k, GnRowsState
                 ub += tb[j];
                 uc += tc[j];
             }
-            H = __shfl(uH, gbase | r);
-            b = __shfl(ub, gbase | r);
-            cost = __shfl(uc, gbase | r);
+            rH = row_shr1(uH);
+            rb = row_shr1(ub);
+            rc = row_shr1(uc);
         }
+        H = __shfl(uH, gbase | 6);
+        b = __shfl(ub, gbase | 6);
+        cost = __shfl(uc, gbase | 6);
     }
     bool finished = true;
     if (live && row == 0)
