@@ -96,3 +96,31 @@ def test_bench_gpus_2_on_one_gpu_runs_the_hot_path_on_both_ranks():
     assert r["verified"] is True
     assert abs(r["value"] - 2 * 5 / (r["ms_per_step"] * 5e-3)) < 1e-6 * r["value"]
     assert r["value"] <= sum(r["per_rank_pairs_per_s"]) * (1 + 1e-9)
+
+
+@pytest.mark.gpu
+def test_rccl_reductions_of_the_bench_on_the_gpu(tmp_path):
+    """The collectives bench.py issues on a full node -- barrier, MAX all-reduce and all-gather of one double on the rank's own
+    device through RCCL (backend "nccl") -- with the one rank this box can give them: the device-tensor path of
+    sharding.max_over_ranks / gather_over_ranks, in a process of its own."""
+    prog = tmp_path / "rccl.py"
+    prog.write_text(
+        "import os, sys\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "import torch, torch.distributed as dist\n"
+        "from edge_based_visual_odometry_amd import sharding\n"
+        "os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(sharding.free_port()), RANK='0', WORLD_SIZE='1')\n"
+        "torch.cuda.set_device(0)\n"
+        "dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))\n"
+        "dist.barrier()\n"
+        "t = torch.tensor([1.5], dtype=torch.float64, device='cuda:0')\n"
+        "dist.all_reduce(t, op=dist.ReduceOp.MAX)\n"
+        "out = [torch.zeros_like(t)]\n"
+        "dist.all_gather(out, t)\n"
+        "assert float(t.item()) == 1.5 and float(out[0].item()) == 1.5\n"
+        "assert sharding.max_over_ranks(2.5, dist, 'cuda:0') == 2.5\n"
+        "assert sharding.gather_over_ranks(3.5, dist, 'cuda:0') == [3.5]\n"
+        "dist.destroy_process_group()\n"
+        "print('rccl ok')\n")
+    out = subprocess.run([sys.executable, str(prog)], env=_clean_env(), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "rccl ok" in out.stdout, out.stderr[-3000:]
