@@ -827,7 +827,11 @@ def main():
         calib = ([cal["K"][0], 0, cal["K"][2], 0, cal["K"][1], cal["K"][3], 0, 0, 1],
                  [cal["K_right"][0], 0, cal["K_right"][2], 0, cal["K_right"][1], cal["K_right"][3], 0, 0, 1], cal["R21"], cal["T21"])
         n_drop = 48                                                                           # (a fixed count: ~0.15 s)
-        dropin_loop(ctx, params, pool, calib, min(nslots, 3), 3 * len(pool))                  # untimed: every slot sees every pair of the pool (sizes the chain's buffers)
+        # untimed: 96 frames (~0.25 s).  Every slot sees every pair of the pool (sizes the chain's buffers) and the loop reaches
+        # its steady state: behind a short timed region (--steps 20) a 12-frame warm-up left the 48 timed frames at 290-310
+        # frames/s where 96 give the 400-420 every longer run shows (the chain is a sequence of short launches: the device
+        # clocks follow the load with a delay)
+        dropin_loop(ctx, params, pool, calib, min(nslots, 3), 96)
         t_drop, final_per_pair = dropin_loop(ctx, params, pool, calib, min(nslots, 3), n_drop)
         drop_threads = {str(T): threaded_dropin(T, args, H, W, F, device, pool, calib, 2 * n_drop) for T in host_threads(args)}
         # the drop-in path: what main_VO executes through integration/*.cpp -- host-buffer entry points, results in host
@@ -855,10 +859,11 @@ def main():
         t_b = float(split.sum())
         boundary_cpp = boundary_bench_cpp(pool[0][0], pool[0][1], H, W, toed_mode=args.toed_mode)  # the same sequence through the C++ adapters
         legs = {"dropin_final_pairs_per_s": n_drop / t_drop, "dropin_final_pairs_per_frame": final_per_pair,
-                "dropin_note": "get_Stereo_Edge_Pairs in one pass (StereoMatcherHIP::stereo_edge_pairs): a new pair from host "
-                               "memory per frame, TOED + candidates + NCC, SIFT filter, both Best-Nearly-Best tests, shift, "
-                               "photometric refinement, clustering, second NCC pass, best per row; final pairs + output rows "
-                               "copied back; the stereo pairs of up to three frames in flight",
+                "dropin_note": "get_Stereo_Edge_Pairs in one pass (StereoMatcherHIP::stereo_edge_pairs_begin / _chain / _end): a new pair "
+                               "from host memory per frame, TOED + candidates + NCC, then the enqueue-only chain (SIFT filter, both "
+                               "Best-Nearly-Best tests, shift, photometric refinement, clustering, second NCC pass, best per row); "
+                               "final pairs + output rows copied back; three frames in flight, two of them in their chains; 48 "
+                               "timed frames after 96 untimed ones",
                 "dropin_final_pairs_per_s_by_host_threads": drop_threads,
                 "dropin_threads_note": "the same loop in T host threads, each with its own context (the library's model: one "
                                        "ebvo_ctx per host thread): the later stages are a host-sequenced chain of short launches, "
