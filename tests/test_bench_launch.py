@@ -54,6 +54,16 @@ def test_bench_under_an_external_launcher_uses_its_ranks():
     assert _json_lines(outs[0][0])[0]["n_gpus"] == 2 and _json_lines(outs[1][0]) == []
 
 
+def test_bench_under_torch_distributed_run():
+    """the driver's own command line for N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N"""
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(sharding.free_port()), BENCH, "--gpus", "2", "--steps", "7", "--warmup", "1",
+                          "--selftest-launch", "--dist-backend", "gloo"], env=_clean_env(), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = _json_lines(out.stdout)
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["value"] == 2 * 7 / 0.5
+
+
 def test_gpus_must_match_world_size():
     env = dict(_clean_env(), RANK="0", LOCAL_RANK="0", WORLD_SIZE="3", MASTER_ADDR="127.0.0.1", MASTER_PORT="1")
     out = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--selftest-launch"], env=env, capture_output=True, text=True,
