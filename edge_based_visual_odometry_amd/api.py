@@ -62,6 +62,11 @@ class Context:
                               n_neighbour_points=int(out[7]))}
 
     @property
+    def toed_fallbacks(self) -> int:
+        """Hybrid TOED runs the library repeated on the strict path (screened candidates > max_h * max_w)."""
+        return int(self.lib.ebvo_toed_fallbacks(self._ctx))
+
+    @property
     def toed_mode(self) -> str:
         return "hybrid" if self.lib.ebvo_get_toed_mode(self._ctx) == _lib.TOED_HYBRID else "strict"
 

@@ -251,8 +251,8 @@ static int slot_create(ebvo_ctx *ctx, Slot **out)
         CK(hipMalloc(&ws.flag, np2));
         CK(hipMalloc(&ws.row_cnt, sizeof(int32_t) * 2 * H2));
         CK(hipMalloc(&ws.row_off, sizeof(int32_t) * 3 * (H2 + 1)));
-        CK(hipMalloc(&ws.counts, sizeof(int32_t) * 4));
-        CK(hipMemsetAsync(ws.counts, 0, sizeof(int32_t) * 4, s->stream));
+        CK(hipMalloc(&ws.counts, sizeof(int32_t) * 8));
+        CK(hipMemsetAsync(ws.counts, 0, sizeof(int32_t) * 8, s->stream));
         CK(hipMalloc(&ws.cand_rec, 40 * (size_t)ctx->cap_edges));
         CK(hipMalloc(&ws.cand_flag, sizeof(int32_t) * 2 * (size_t)ctx->cap_edges));
         CK(hipMalloc(&ws.cand_off, sizeof(int32_t) * 2 * ((size_t)ctx->cap_edges + 1)));
@@ -309,6 +309,8 @@ extern "C" int ebvo_set_toed_mode(ebvo_ctx *ctx, int mode)
 }
 
 extern "C" int ebvo_get_toed_mode(const ebvo_ctx *ctx) { return ctx ? ctx->toed_mode : EBVO_ERR_ARG; }
+
+extern "C" int64_t ebvo_toed_fallbacks(const ebvo_ctx *ctx) { return ctx ? ctx->toed_fallbacks : -1; }
 
 extern "C" int ebvo_toed_stats(ebvo_ctx *ctx, int slot, int32_t out[8])
 {
@@ -469,23 +471,40 @@ static int toed_sync(ebvo_ctx *ctx, Slot &s, int n_img, int h, int w, float *ms_
     if (timed)
         for (hipEvent_t &e : ev.e)
             EBVO_HIP(ctx, hipEventCreate(&e));
-    int rc = toed_enqueue(ctx, s, n_img, h, w, ev.e[0], ev.e[1], ev.e[2]);
-    if (rc)
-        return rc;
     // the counts travel through the slot's pinned record, never through this stack frame: a failure between the
     // enqueue of a copy and the synchronisation cannot leave a DMA pointing at dead memory
     int32_t *hc = reinterpret_cast<int32_t *>(s.h_result);
-    static_assert(sizeof(PairResult) >= 4 * sizeof(int32_t), "pinned record too small for the TOED counts");
-    hipError_t e = hipSuccess;
-    for (int k = 0; k < n_img && e == hipSuccess; ++k)
-        e = hipMemcpyAsync(hc + 2 * k, s.im[k].counts, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s.stream);
-    const hipError_t es = hipStreamSynchronize(s.stream); // also on failure: nothing may stay in flight
-    if (e != hipSuccess || es != hipSuccess)
-        return ebvo_fail_hip(ctx, e != hipSuccess ? e : es, "TOED count read-back", __FILE__, __LINE__);
-    for (int k = 0; k < n_img; ++k)
+    static_assert(sizeof(PairResult) >= 6 * sizeof(int32_t), "pinned record too small for the TOED counts");
+    int mode = ctx->toed_mode;
+    for (int attempt = 0; attempt < 2; ++attempt)
     {
-        s.im[k].n_total = hc[2 * k];
-        s.im[k].n_kept = hc[2 * k + 1];
+        int rc = toed_enqueue(ctx, s, n_img, h, w, ev.e[0], ev.e[1], ev.e[2], mode);
+        if (rc)
+            return rc;
+        hipError_t e = hipSuccess;
+        for (int k = 0; k < n_img && e == hipSuccess; ++k)
+        {
+            e = hipMemcpyAsync(hc + 3 * k, s.im[k].counts, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s.stream);
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(hc + 3 * k + 2, s.im[k].counts + 4, sizeof(int32_t), hipMemcpyDeviceToHost, s.stream);
+        }
+        const hipError_t es = hipStreamSynchronize(s.stream); // also on failure: nothing may stay in flight
+        if (e != hipSuccess || es != hipSuccess)
+            return ebvo_fail_hip(ctx, e != hipSuccess ? e : es, "TOED count read-back", __FILE__, __LINE__);
+        bool fits = true;
+        for (int k = 0; k < n_img; ++k)
+        {
+            s.im[k].n_total = hc[3 * k];
+            s.im[k].n_kept = hc[3 * k + 1];
+            if (mode == EBVO_TOED_HYBRID && hc[3 * k + 2] > ctx->cap_edges)
+                fits = false;
+        }
+        if (fits)
+            break;
+        // the screen flagged more grid points than the candidate buffers hold (an image of ties): the strict path has no
+        // candidate lists and handles any image
+        mode = EBVO_TOED_STRICT;
+        ++ctx->toed_fallbacks;
     }
     if (timed)
     {
@@ -1091,7 +1110,7 @@ static int ensure_pipeline_buffers(ebvo_ctx *ctx, Slot &s, int64_t cap_pairs)
 }
 
 // lines -> candidates (count, scan, fill) -> right patch bank -> LDS-tiled NCC -> result record; no host synchronisation
-static int enqueue_matching(ebvo_ctx *ctx, Slot &s)
+static int enqueue_matching(ebvo_ctx *ctx, Slot &s, int toed_mode = -1)
 {
     const ebvo_stereo_params &p = s.params;
     const int h = s.cur_h, w = s.cur_w, ce = ctx->cap_edges;
@@ -1105,7 +1124,8 @@ static int enqueue_matching(ebvo_ctx *ctx, Slot &s)
         return rc;
     if ((rc = match_ncc_resident_enqueue(ctx, s, h, w, ce, p.ncc_thr)))
         return rc;
-    if ((rc = match_pair_result_enqueue(ctx, s)))
+    // a hybrid TOED run reports candidate lists that did not fit through the result record (bit 2 of `overflow`)
+    if ((rc = match_pair_result_enqueue(ctx, s, (toed_mode < 0 ? ctx->toed_mode : toed_mode) == EBVO_TOED_HYBRID ? ce : 0)))
         return rc;
     EBVO_HIP(ctx, hipEventRecord(s.ev_done, s.stream));
     return EBVO_OK;
@@ -1219,6 +1239,18 @@ extern "C" int ebvo_stereo_wait(ebvo_ctx *ctx, int slot, ebvo_stereo_counts *cou
             return ebvo_fail_hip(ctx, e, "hipEventSynchronize", __FILE__, __LINE__);
         }
         const PairResult r = *s.h_result;
+        if (r.overflow & 2)
+        {
+            // the hybrid screen flagged more candidates than fit (toed_rowscan_phase_kernel): the whole pair again, strict
+            ++ctx->toed_fallbacks;
+            if ((rc = toed_enqueue(ctx, s, 2, s.cur_h, s.cur_w, nullptr, nullptr, nullptr, EBVO_TOED_STRICT)) ||
+                (rc = enqueue_matching(ctx, s, EBVO_TOED_STRICT)))
+            {
+                s.in_flight = false;
+                return rc;
+            }
+            continue;
+        }
         if (r.n_total_left > ctx->cap_edges || r.n_total_right > ctx->cap_edges)
         {
             s.in_flight = false;

@@ -69,7 +69,8 @@ struct ImageWS
     uint8_t *flag = nullptr;    // 2H x 2W: 0 none, 1 NMS maximum, 3 maximum inside the 10-px border
     int32_t *row_cnt = nullptr; // [2][H2]   per interpolated row: all maxima, kept maxima (hybrid: even / odd column candidates)
     int32_t *row_off = nullptr; // [3][H2+1] exclusive prefix of row_cnt (hybrid: all, even-column, odd-column per row parity)
-    int32_t *counts = nullptr;  // [4] n_total, n_kept (device-side sizes of everything downstream), n_candidates, -
+    int32_t *counts = nullptr;  // [8] n_total, n_kept (device-side sizes of everything downstream), n_candidates (0 when they
+                                // did not fit), neighbour points, screened candidates before the capacity check
     int32_t *src = nullptr;     // [cap][2] (pixel offset, kept rank or -1) per maximum, raster order
     ebvo_edge *edges = nullptr; // [cap] kept edges
     double *all4 = nullptr;     // [cap][4] every maximum (x, y, theta, mag)
@@ -88,7 +89,7 @@ struct PairResult
     int32_t n_left, n_right, n_total_left, n_total_right;
     int64_t n_pairs;
     int64_t n_matches;
-    int32_t overflow;
+    int32_t overflow; // bit 0: more candidate pairs than the buffers hold; bit 1: the hybrid TOED screen overflowed
     int32_t pad;
 };
 
@@ -216,6 +217,7 @@ struct ebvo_ctx
     int gn_rows_below = 0;     // developer key (ebvo_debug_set 5): active-pair count below which an iteration uses it, 0 = default
     int wait_attempts = 0;     // test hook (ebvo_debug_set): attempts of ebvo_stereo_wait's regrow loop, 0 = default (4)
     int force_overflow = 0;    // test hook: treat the next N results as overflowed
+    int64_t toed_fallbacks = 0; // hybrid TOED runs repeated on the strict path (more screened candidates than cap_edges)
 
     // profiling (accumulated over all slots)
     bool prof = false;
@@ -282,9 +284,11 @@ struct ProfScope
 
 // toed_kernels.hip
 int toed_init_constants(ebvo_ctx *ctx);
-// conv + NMS + compaction of n_img (1 or 2) resident images of slot s; counts stay in s.im[k].counts
+// conv + NMS + compaction of n_img (1 or 2) resident images of slot s; counts stay in s.im[k].counts.  mode < 0: the
+// context's mode.  A hybrid run whose screen flags more candidates than the buffers hold leaves counts[4] > cap_edges and
+// empty results: the caller re-runs with EBVO_TOED_STRICT.
 int toed_enqueue(ebvo_ctx *ctx, Slot &s, int n_img, int h, int w, hipEvent_t ev_conv_begin, hipEvent_t ev_conv_end,
-                 hipEvent_t ev_end);
+                 hipEvent_t ev_end, int mode = -1);
 
 // match_kernels.hip
 int match_lines_enqueue(ebvo_ctx *ctx, Slot &s, const double *d_F, const ebvo_edge *d_edges, int n,
@@ -311,7 +315,7 @@ int match_ncc_pairs_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_imgR, int h
 // left = index of the slot's image workspace that holds the LEFT image and edges (the right one is the other)
 int match_ncc_resident_enqueue(ebvo_ctx *ctx, Slot &s, int h, int w, int cap_edges, double thr, int left = 0);
 size_t match_right_bank_bytes(int cap_edges);
-int match_pair_result_enqueue(ebvo_ctx *ctx, Slot &s);
+int match_pair_result_enqueue(ebvo_ctx *ctx, Slot &s, int cand_cap); // cand_cap > 0: hybrid TOED, report candidates > cand_cap
 int match_orient_flags_enqueue(ebvo_ctx *ctx, Slot &s, const ebvo_edge *d_L, int nL, const ebvo_edge *d_R, const int32_t *d_row_ptr,
                                const int32_t *d_col_idx, int64_t n_pairs, double orient_thr_deg, uint8_t *d_ok);
 // temporal quads (Temporal_Matches): cells + chunk boxes of the current-frame mates, candidate count / fill, indexed NCC

@@ -1602,7 +1602,7 @@ __global__ __launch_bounds__(256) void orient_flags_kernel(const ebvo_edge *__re
 // ebvo_internal.h).
 __global__ void pair_result_kernel(const int32_t *__restrict__ cntL, const int32_t *__restrict__ cntR,
                                    const unsigned long long *__restrict__ total_part, int n_total_part,
-                                   const int32_t *__restrict__ match_part, int n_part, int64_t cap,
+                                   const int32_t *__restrict__ match_part, int n_part, int64_t cap, int cand_cap,
                                    PairResult *__restrict__ out)
 {
     // one block of 1024 threads: the per-block candidate totals and match counts are summed here
@@ -1645,6 +1645,8 @@ __global__ void pair_result_kernel(const int32_t *__restrict__ cntL, const int32
     r.n_pairs = (int64_t)tot;
     r.n_matches = m;
     r.overflow = (r.n_pairs > cap || r.n_pairs > 0x7fffffffll) ? 1 : 0;
+    if (cand_cap > 0 && (cntL[4] > cand_cap || cntR[4] > cand_cap))
+        r.overflow |= 2;
     r.pad = 0;
     *out = r;
 }
@@ -2099,11 +2101,11 @@ int match_ncc_quads_indexed_enqueue(ebvo_ctx *ctx, Slot &s, const float *kfLn, c
     return EBVO_OK;
 }
 
-int match_pair_result_enqueue(ebvo_ctx *ctx, Slot &s)
+int match_pair_result_enqueue(ebvo_ctx *ctx, Slot &s, int cand_cap)
 {
     hipLaunchKernelGGL(pair_result_kernel, dim3(1), dim3(1024), 0, s.stream, (const int32_t *)s.im[0].counts,
                        (const int32_t *)s.im[1].counts, (const unsigned long long *)(s.d_total + 1), s.n_total_part,
-                       (const int32_t *)s.d_matches, s.n_match_part, s.cap_pairs, s.d_result);
+                       (const int32_t *)s.d_matches, s.n_match_part, s.cap_pairs, cand_cap, s.d_result);
     EBVO_HIP(ctx, hipGetLastError());
     EBVO_HIP(ctx, hipMemcpyAsync(s.h_result, s.d_result, sizeof(PairResult), hipMemcpyDeviceToHost, s.stream));
     return EBVO_OK;

@@ -22,7 +22,7 @@
 //   toed_compact_kernel  K3b: ordered (raster) stream compaction of the flagged pixels
 //   toed_finalize_kernel K3c: dense per-edge epilogue (sub-pixel position, atan2, records)
 // Hybrid mode (second half of the file; same bits out):
-//   toed_screen_fused_kernel   S1+S2: separable fp64 screen and relaxed NMS of a 12 x 30-pixel tile, all in LDS
+//   toed_screen_fused_kernel   S1+S2: separable fp32 screen and relaxed NMS of a 12 x 30-pixel tile, all in LDS
 //   toed_rowscan_phase_kernel / toed_compact_phase_kernel
 //                              S2b/c: candidate ranks and the four phase lists, ordered, no atomics
 //   toed_exact_centre_kernel   S3b: the nine exact responses of every candidate; marks its NMS neighbours
@@ -552,63 +552,79 @@ __global__ __launch_bounds__(256) void toed_finalize_kernel(ImgBatch B, int h, i
 // Hybrid TOED: separable screening + exact re-evaluation.  Bit-identical results, ~3x less work.
 //
 // The direct-form convolution above spends 27.6 k fp64 operations on every pixel, but only ~7 % of the
-// interpolated pixels become edges.  Here a cheap SEPARABLE fp64 convolution (FMA allowed: it is only a
-// screen) produces gx, gy, |g| with an absolute error below E = 1e-11 (bound: 2 * (361+2) * 2^-53 *
-// sum|v||Kq||Kp| <= 8e-12 for 8-bit pixels and these taps), a RELAXED non-maximum test with tolerance
-// 1e-6 >> E selects a superset of the pixels the reference accepts, and every selected pixel is then
-// evaluated in the reference's exact arithmetic (same taps, same order, no FMA): its nine responses and
-// the two-response magnitude of its four NMS neighbours (each distinct neighbour grid point once).  The exact NMS decision, sub-pixel position,
-// magnitude and orientation are computed from those exact values only, so the edge list equals the
-// strict path's bit for bit; a pixel that the relaxed screen rejects is rejected by the exact test too.
-//   relaxed screen: |g| > 2 - 1e-6, and either the gradient sector is ambiguous within 1e-6
-//   (|gx|, |gy| or ||gx|-|gy|| below it) or |g| >= fm - 1e-6 and |g| >= fp - 1e-6 with the screen's
-//   own neighbours; the |s*| <= sqrt(2) test is left to the exact stage.
+// interpolated pixels become edges.  Here a cheap SEPARABLE convolution (it is only a screen) produces gx, gy, |g|,
+// a RELAXED non-maximum test with a tolerance well above the screen's error selects a superset of the pixels the
+// reference accepts, and every selected pixel is then evaluated in the reference's exact arithmetic (same taps, same
+// order, no FMA): its nine responses and the two-response magnitude of its four NMS neighbours (each distinct
+// neighbour grid point once).  The exact NMS decision, sub-pixel position, magnitude and orientation are computed
+// from those exact values only, so the edge list equals the strict path's bit for bit; a pixel that the relaxed
+// screen rejects is rejected by the exact test too.
+//
+// Round 3: the screen runs in FP32 (it was fp64 with a tolerance of 1e-6).  Error budget, 8-bit pixels, these taps
+// (sum |G| <= 1.000, sum |Gx| <= 0.404 for the integer and the half-pixel tables), u = 2^-24:
+//   row pass     R_G, R_Gx = sums of <= 19 products v * K, v exact, K rounded to float, accumulated by FMA:
+//                |err| <= 20 u * 255 * sum|K|  ->  3.1e-4 on R_G (|R_G| <= 255), 1.3e-4 on R_Gx (|R_Gx| <= 103)
+//   column pass  gx = sum R_Gx * G, gy = sum R_G * Gx:  |err| <= sum|K| * err_R + 20 u * max|R| * sum|K|
+//                ->  1.3e-4 + 1.3e-4 and 0.404 * 3.1e-4 + 1.3e-4:  |d gx|, |d gy| <= 2.6e-4          (E_G)
+//   |g|          sqrt is 1-Lipschitz in (gx, gy): |d m| <= sqrt(2) E_G + u * 361 <= 4.0e-4                 (E_M)
+//   slope        minor / major with |major| >= |g| / sqrt(2) >= 1.41: |d s| <= 2 E_G / 1.41 <= 3.7e-4   (E_S)
+//   neighbours   fp = p1 (1 - s) + p2 s: |d fp| <= E_M + |p2 - p1| E_S (+ 3 u * 361 for the float arithmetic)
+// These are worst-case bounds (every rounding error aligned); on images the screen's |g| is within ~2e-6 of the exact one.
+// A comparison of two screened quantities needs twice the bound.  The relaxed test uses  TOL_M = 1e-3 (2.5 x E_M,
+// 3.8 x E_G)  wherever a magnitude or a gradient component is compared with a constant or with another component, and
+// TOL_M + TOL_S |p2 - p1|,  TOL_S = 5e-4 (1.35 x E_S),  where it is compared with an interpolated neighbour:
+//   |g| > 2 - TOL_M, and either the gradient sector is ambiguous (|gx|, |gy| or ||gx| - |gy|| below TOL_M: the exact
+//   sector could differ from the screen's) or |g| >= fm - tol and |g| >= fp - tol with the screen's own neighbours; the
+//   |s*| <= sqrt(2) test is left to the exact stage.
+// A wider tolerance only adds candidates (KITTI S2 pair: 130,5xx per image for 130,489 / 130,734 maxima, see
+// ebvo_toed_stats), never removes one; every TOED parity test runs in this mode.
 // ==========================================================================================
-constexpr double SCREEN_TOL = 1e-6;
+constexpr float SCREEN_TOL_M = 1e-3f;
+constexpr float SCREEN_TOL_S = 5e-4f;
 
 // S1+S2 fused -------------------------------------------------------------------------------
-// The screen in one kernel: the separable planes never leave LDS (the two-kernel form wrote 98 MB of fp64 planes per
-// pair and read 138 MB back, and its passes issued one ds_read_b64 per FMA).  One block screens the four phases of a
+// The screen in one kernel: the separable planes never leave LDS.  One block screens the four phases of a
 // 12 x 30-pixel tile; it needs |g| one grid step around it, i.e. a 14 x 32 "ext" tile, i.e. a 32 x 50 image tile.
-//   row pass     thread = (image-tile row, 4 adjacent ext columns): 22 pixels in registers feed 24 accumulators
-//                (G and Gx taps; integer positions with 17 and 19 taps, half-pixel positions) -> six R planes in LDS
+//   row pass     thread = (image-tile row, 4 adjacent ext columns): 22 pixels in registers feed 16 accumulators
+//                (G and Gx taps; integer positions with 17 and 19 taps, half-pixel positions) -> six R planes in LDS,
+//                a thread's four columns of a plane as ONE 16-byte store
 //   column pass  thread = (ext column, phase, 7 adjacent ext rows): 25 + 25 R values feed 14 accumulators; gx, gy stay
 //                in registers, |g| goes to LDS (aliasing the R planes once every thread is past them)
 //   relaxed NMS  every thread decides its own <= 7 grid points; flags and per-row candidate counts as before
-// The screen only has to be within SCREEN_TOL of the exact values, so sums may be re-associated: the 19-tap integer
-// row sum is the 17-tap one plus its two end taps.
+// In FP32 the block needs 26.6 KB of LDS (52 KB as doubles: three blocks per CU, and the kernel spent 54 % of its wave
+// time waiting at its barriers) and ~half the registers: six blocks per CU hide each other's barriers.
 constexpr int FT_H = 12, FT_W = 30;           // pixels screened per block
 constexpr int FE_H = FT_H + 2, FE_W = FT_W + 2; // ext tile
 constexpr int FI_H = FE_H + 2 * HALO, FI_W = FE_W + 2 * HALO; // image tile 32 x 50
 static_assert(FI_W + 6 == 56 && FI_H * (FE_W / 4) == 256 && FE_W * 4 * (FE_H / 7) == 256, "one work item per thread in both passes");
-static_assert(FE_W == 32 && FE_H == 14, "the rotated LDS layout of the row planes assumes 32 columns and the row groups 0-6 / 7-13");
+static_assert(FE_W == 32 && FE_H == 14, "32 ext columns per wave half, row groups 0-6 / 7-13");
 
 constexpr int FI_P = 56; // image-tile row pitch in bytes (>= FI_W + 2, multiple of 4)
 struct FusedLds
 {
-    uint32_t img[FI_H][FI_P / 4]; // the image tile as bytes: 1.8 KB instead of 12.8 KB as doubles -> three blocks per CU
+    uint32_t img[FI_H][FI_P / 4]; // the image tile as bytes
     union
     {
-        double R[6][FI_H][FE_W]; // [0,1] 17-tap integer (G, Gx); [2,3] 19-tap integer; [4,5] half-pixel
-        double M[4][FE_H][FE_W]; // |g| of the ext tile per phase ((sy << 1) | sx)
+        float R[6][FI_H][FE_W]; // [0,1] 17-tap integer (G, Gx); [2,3] 19-tap integer; [4,5] half-pixel
+        float M[4][FE_H][FE_W]; // |g| of the ext tile per phase ((sy << 1) | sx)
     };
-    double tap[2][19][4];        // [half][tap][derivative order], as ExactTaps
+    float tap[2][19][2];        // [half][tap][G, Gx]
 };
+static_assert(sizeof(FusedLds) <= 27306, "six blocks per CU (160 KB of LDS)");
 
 __global__ __launch_bounds__(256) void toed_screen_fused_kernel(ImgBatch B, const ToedTables *__restrict__ T, int h, int w)
 {
-    __shared__ FusedLds L;
+    __shared__ __attribute__((aligned(16))) FusedLds L;
     const uint8_t *__restrict__ img = B.img[blockIdx.z];
     const int W2 = 2 * w, H2 = 2 * h;
     const int j0 = blockIdx.x * FT_W - 1, i0 = blockIdx.y * FT_H - 1; // pixel of ext (0, 0)
     const int tid = threadIdx.x;
-    for (int t = tid; t < 2 * 19 * 4; t += 256)
+    if (tid < 2 * 19 * 2)
     {
-        const int half = t / 76, k = (t % 76) / 4, d = t & 3;
-        L.tap[half][k][d] = half ? T->tap_half[d][k] : T->tap_int[d][k];
+        const int half = tid / 38, k = (tid % 38) >> 1, d = tid & 1;
+        L.tap[half][k][d] = (float)(half ? T->tap_half[d][k] : T->tap_int[d][k]);
     }
-    // image tile: ONE 8-byte load per thread (32 rows x 7 chunks = 56 bytes cover the 50 columns; a per-pixel loop was seven
-    // dependent byte loads per thread and, at two waves per SIMD, most of the kernel's time).  The image buffer has 64
+    // image tile: ONE 8-byte load per thread (32 rows x 7 chunks = 56 bytes cover the 50 columns).  The image buffer has 64
     // readable bytes either side, rows are clamped and masked, columns masked per byte.
     if (tid < FI_H * 7)
     {
@@ -633,7 +649,7 @@ __global__ __launch_bounds__(256) void toed_screen_fused_kernel(ImgBatch B, cons
     // ---- row pass: R[.][r][c] = sum_q img[r][c + HALO - q] * tap[q]
     {
         const int r = tid >> 3, c0 = (tid & 7) * 4;
-        double v[22];
+        float v[22];
 #pragma unroll
         for (int q = 0; q < 6; ++q) // c0 is a multiple of 4: six aligned words hold the 22 pixels
         {
@@ -641,95 +657,77 @@ __global__ __launch_bounds__(256) void toed_screen_fused_kernel(ImgBatch B, cons
 #pragma unroll
             for (int b = 0; b < 4; ++b)
                 if (4 * q + b < 22)
-                    v[4 * q + b] = (double)((wq >> (8 * b)) & 0xffu);
+                    v[4 * q + b] = (float)((wq >> (8 * b)) & 0xffu);
         }
-        double a17[4][2], ah[4][2];
+        float a17[4][2], ah[4][2];
 #pragma unroll
         for (int c = 0; c < 4; ++c)
-            a17[c][0] = a17[c][1] = ah[c][0] = ah[c][1] = 0.0;
+            a17[c][0] = a17[c][1] = ah[c][0] = ah[c][1] = 0.0f;
 #pragma unroll
         for (int q = -8; q <= 8; ++q)
         {
-            const double g = L.tap[0][q + 9][0], gx = L.tap[0][q + 9][1];
-            const double hg = L.tap[1][q + 9][0], hgx = L.tap[1][q + 9][1];
+            const float g = L.tap[0][q + 9][0], gx = L.tap[0][q + 9][1];
+            const float hg = L.tap[1][q + 9][0], hgx = L.tap[1][q + 9][1];
 #pragma unroll
             for (int c = 0; c < 4; ++c)
             {
-                const double x = v[c + HALO - q];
-                a17[c][0] = __builtin_fma(x, g, a17[c][0]);
-                a17[c][1] = __builtin_fma(x, gx, a17[c][1]);
-                ah[c][0] = __builtin_fma(x, hg, ah[c][0]);
-                ah[c][1] = __builtin_fma(x, hgx, ah[c][1]);
+                const float x = v[c + HALO - q];
+                a17[c][0] = __builtin_fmaf(x, g, a17[c][0]);
+                a17[c][1] = __builtin_fmaf(x, gx, a17[c][1]);
+                ah[c][0] = __builtin_fmaf(x, hg, ah[c][0]);
+                ah[c][1] = __builtin_fmaf(x, hgx, ah[c][1]);
             }
         }
-        // Column c of row r lives at [r][(c + (r & 3)) & 31].  A wave holds 8 rows x 8 column groups; with the plain layout
-        // its 64 eight-byte stores of one instruction fell on FOUR bank pairs (rows are 256 bytes apart, the column groups 32
-        // bytes: 16 lanes per bank pair -- the 29 % LDS_BANK_CONFLICT of the round-2 counters).  The rotation spreads them over
-        // all sixteen (four lanes each: what a 512-byte store costs anyway); the column pass reads 32 consecutive columns of
-        // one row, which a rotation keeps conflict-free.
-        const int rot = r & 3;
+        float o[6][4];
 #pragma unroll
         for (int c = 0; c < 4; ++c)
         {
-            const double xl = v[c + HALO + 9], xr = v[c + HALO - 9]; // taps q = -9 and q = +9
-            const int cc = (c0 + c + rot) & (FE_W - 1);
-            L.R[0][r][cc] = a17[c][0];
-            L.R[1][r][cc] = a17[c][1];
-            L.R[2][r][cc] = __builtin_fma(xr, L.tap[0][18][0], __builtin_fma(xl, L.tap[0][0][0], a17[c][0]));
-            L.R[3][r][cc] = __builtin_fma(xr, L.tap[0][18][1], __builtin_fma(xl, L.tap[0][0][1], a17[c][1]));
-            L.R[4][r][cc] = __builtin_fma(xr, L.tap[1][18][0], __builtin_fma(xl, L.tap[1][0][0], ah[c][0]));
-            L.R[5][r][cc] = __builtin_fma(xr, L.tap[1][18][1], __builtin_fma(xl, L.tap[1][0][1], ah[c][1]));
+            const float xl = v[c + HALO + 9], xr = v[c + HALO - 9]; // taps q = -9 and q = +9
+            o[0][c] = a17[c][0];
+            o[1][c] = a17[c][1];
+            o[2][c] = __builtin_fmaf(xr, L.tap[0][18][0], __builtin_fmaf(xl, L.tap[0][0][0], a17[c][0]));
+            o[3][c] = __builtin_fmaf(xr, L.tap[0][18][1], __builtin_fmaf(xl, L.tap[0][0][1], a17[c][1]));
+            o[4][c] = __builtin_fmaf(xr, L.tap[1][18][0], __builtin_fmaf(xl, L.tap[1][0][0], ah[c][0]));
+            o[5][c] = __builtin_fmaf(xr, L.tap[1][18][1], __builtin_fmaf(xl, L.tap[1][0][1], ah[c][1]));
         }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) // one 16-byte store per plane (a wave: 8 rows x 8 column groups = 1 KB, eight bank passes)
+            *reinterpret_cast<float4 *>(&L.R[k][r][c0]) = make_float4(o[k][0], o[k][1], o[k][2], o[k][3]);
     }
     __syncthreads();
     // ---- column pass: thread = (ext column, phase, 7 ext rows)
     const int c = tid & 31, ph = (tid >> 5) & 3, sy = ph >> 1, sx = ph & 1, e0 = (tid >> 7) * 7;
-    double fx[7], fy[7], mg[7];
+    float fx[7], fy[7], mg[7];
     {
         // x kernel: sx ? half : integer (17 taps for phase (0,0), 19 otherwise); y kernel: sy ? half : integer
         const int base = sx ? 4 : (sy ? 2 : 0);
         const int pm = (ph == 0) ? 8 : 9;
-        double rg[25], rgx[25]; // R filtered with G / Gx along x, image-tile rows e0 .. e0 + 24
-        // rotated columns (see the row pass): row e0 + k holds column c at (c + ((e0 + k) & 3)) & 31; e0 is 0 or 7 for the whole
-        // wave, so the rotation of row k is a compile-time pick among four precomputed columns
-        const int crot[4] = {c, (c + 1) & (FE_W - 1), (c + 2) & (FE_W - 1), (c + 3) & (FE_W - 1)};
-        if (e0 == 0)
-        {
+        float rg[25], rgx[25]; // R filtered with G / Gx along x, image-tile rows e0 .. e0 + 24
 #pragma unroll
-            for (int k = 0; k < 25; ++k)
-            {
-                rg[k] = L.R[base][k][crot[k & 3]];
-                rgx[k] = L.R[base + 1][k][crot[k & 3]];
-            }
-        }
-        else
+        for (int k = 0; k < 25; ++k)
         {
-#pragma unroll
-            for (int k = 0; k < 25; ++k)
-            {
-                rg[k] = L.R[base][7 + k][crot[(7 + k) & 3]];
-                rgx[k] = L.R[base + 1][7 + k][crot[(7 + k) & 3]];
-            }
+            rg[k] = L.R[base][e0 + k][c];
+            rgx[k] = L.R[base + 1][e0 + k][c];
         }
 #pragma unroll
         for (int e = 0; e < 7; ++e)
-            fx[e] = fy[e] = 0.0;
+            fx[e] = fy[e] = 0.0f;
 #pragma unroll
         for (int p = -9; p <= 9; ++p)
         {
             if (p < -pm || p > pm) // uniform per wave half: phase (0,0) has no +-9 taps
                 continue;
-            const double kg = L.tap[sy][p + 9][0], kgx = L.tap[sy][p + 9][1];
+            const float kg = L.tap[sy][p + 9][0], kgx = L.tap[sy][p + 9][1];
 #pragma unroll
             for (int e = 0; e < 7; ++e)
             {
-                fx[e] = __builtin_fma(rgx[e + HALO - p], kg, fx[e]);  // Gx along x, G along y
-                fy[e] = __builtin_fma(rg[e + HALO - p], kgx, fy[e]);  // G along x, Gx along y
+                fx[e] = __builtin_fmaf(rgx[e + HALO - p], kg, fx[e]);  // Gx along x, G along y
+                fy[e] = __builtin_fmaf(rg[e + HALO - p], kgx, fy[e]);  // G along x, Gx along y
             }
         }
 #pragma unroll
         for (int e = 0; e < 7; ++e)
-            mg[e] = sqrt(fx[e] * fx[e] + fy[e] * fy[e]);
+            mg[e] = __builtin_sqrtf(__builtin_fmaf(fx[e], fx[e], fy[e] * fy[e]));
     }
     __syncthreads(); // every thread is done with R: M may overwrite it
 #pragma unroll
@@ -739,7 +737,7 @@ __global__ __launch_bounds__(256) void toed_screen_fused_kernel(ImgBatch B, cons
     // ---- relaxed NMS of this thread's grid points
     // |g| of the grid neighbours one step along the rows / columns: the thread's phase is fixed, so the LDS offsets
     // (plane, ext row, ext column) of "one grid step up / down / left / right" are three constants per axis
-    const double *Mflat = &L.M[0][0][0];
+    const float *Mflat = &L.M[0][0][0];
     auto row_step = [&](int da) { return ((((sy + da) & 1) - sy) * 2 * FE_H + ((sy + da) >> 1)) * FE_W; };
     auto col_step = [&](int db) { return (((sx + db) & 1) - sx) * FE_H * FE_W + ((sx + db) >> 1); };
     const int rdn = row_step(-1), rup = row_step(1), cdn = col_step(-1), cup = col_step(1);
@@ -754,33 +752,34 @@ __global__ __launch_bounds__(256) void toed_screen_fused_kernel(ImgBatch B, cons
         const bool mine = er >= 1 && er <= FT_H && c >= 1 && c <= FT_W && I >= 10 && I < H2 - 10 && J >= 10 && J < W2 - 10;
         if (mine)
         {
-            const double m = mg[e];
-            if (m > 2.0 - SCREEN_TOL)
+            const float m = mg[e];
+            if (m > 2.0f - SCREEN_TOL_M)
             {
-                const double gx = fx[e], gy = fy[e], ax = fabs(gx), ay = fabs(gy);
-                if (ax < SCREEN_TOL || ay < SCREEN_TOL || fabs(ax - ay) < SCREEN_TOL)
+                const float gx = fx[e], gy = fy[e], ax = fabsf(gx), ay = fabsf(gy);
+                if (ax < SCREEN_TOL_M || ay < SCREEN_TOL_M || fabsf(ax - ay) < SCREEN_TOL_M)
                     f = 1; // the exact sector could differ from the screen's: let the exact stage decide
                 else
                 {
-                    // the sector table of nms_core, by selects: eight divergent branches each carried their own fp64
-                    // division (a wave executed most of them); here one division per grid point.
+                    // the sector table of nms_core, by selects:
                     //   quadrant (sign of gx, gy) x (which of |gx|, |gy| dominates) -> axis step (a1, b1), diagonal
                     //   step (a2, b2), slope = minor / major with the quadrant's sign convention
                     const bool px = gx >= 0, py = gy >= 0;
                     // "x dominates" exactly as the reference compares in each quadrant
                     const bool xdom = px ? (py ? gx >= gy : !(gx < ay)) : (py ? !(ax < gy) : ax >= ay);
-                    const double num = xdom ? ((px == py) ? gy : -gy) : ((px == py) ? gx : -gx);
-                    const double den = xdom ? gx : gy;
-                    const double slope = num / den;
+                    const float num = xdom ? ((px == py) ? gy : -gy) : ((px == py) ? gx : -gx);
+                    const float den = xdom ? gx : gy;
+                    const float slope = num / den;
                     // diagonal step: sign of gy along rows, sign of gx along columns; axis step: the dominant axis only
                     // (a2, b2) = (sign gy, sign gx); (a1, b1) = (0, b2) if x dominates, (a2, 0) otherwise
                     const int ctr = (ph * FE_H + er) * FE_W + c;
                     const int rP = py ? rup : rdn, rM = py ? rdn : rup, cP = px ? cup : cdn, cM = px ? cdn : cup;
-                    const double p1 = Mflat[ctr + (xdom ? cP : rP)], p2 = Mflat[ctr + rP + cP];
-                    const double m1 = Mflat[ctr + (xdom ? cM : rM)], m2 = Mflat[ctr + rM + cM];
-                    const double fp = p1 * (1 - slope) + p2 * slope;
-                    const double fm = m1 * (1 - slope) + m2 * slope;
-                    if (m >= fm - SCREEN_TOL && m >= fp - SCREEN_TOL)
+                    const float p1 = Mflat[ctr + (xdom ? cP : rP)], p2 = Mflat[ctr + rP + cP];
+                    const float m1 = Mflat[ctr + (xdom ? cM : rM)], m2 = Mflat[ctr + rM + cM];
+                    const float fp = p1 * (1 - slope) + p2 * slope;
+                    const float fm = m1 * (1 - slope) + m2 * slope;
+                    const float tp = SCREEN_TOL_M + SCREEN_TOL_S * fabsf(p2 - p1);
+                    const float tm = SCREEN_TOL_M + SCREEN_TOL_S * fabsf(m2 - m1);
+                    if (m >= fm - tm && m >= fp - tp)
                         f = 1;
                 }
             }
@@ -804,8 +803,13 @@ __global__ __launch_bounds__(256) void toed_screen_fused_kernel(ImgBatch B, cons
 // t); waves 1, 2: candidates in even / odd columns, scanned separately over the even and the odd rows, which gives
 // every row its offset in the list of its phase.  Totals -> counts[2] and lcount[0..3]; lcount[4..11] are zeroed for
 // the (phase, axis) lists appended by the centre kernel.
-__global__ __launch_bounds__(192) void toed_rowscan_phase_kernel(ImgBatch B, int H2)
+// The candidate arrays hold `cap` (= max_h * max_w) entries; the screen can flag up to four times that on an image made of
+// ties (a fine checkerboard).  Then counts[4] keeps the real total and every list length is published as zero: the exact
+// stage runs empty, nothing is written past a buffer, and the host re-runs the image on the strict path (toed_sync,
+// ebvo_stereo_wait).
+__global__ __launch_bounds__(192) void toed_rowscan_phase_kernel(ImgBatch B, int H2, int cap)
 {
+    __shared__ int s_over;
     const int32_t *cnt = B.row_cnt[blockIdx.x];
     int32_t *off = B.row_off[blockIdx.x];
     int32_t *lcount = B.lcount[blockIdx.x];
@@ -833,11 +837,14 @@ __global__ __launch_bounds__(192) void toed_rowscan_phase_kernel(ImgBatch B, int
         if (lane == 63)
         {
             off[H2] = incl;
-            B.counts[blockIdx.x][2] = incl;
+            s_over = incl > cap;
+            B.counts[blockIdx.x][2] = incl > cap ? 0 : incl;
             B.counts[blockIdx.x][3] = 0;
+            B.counts[blockIdx.x][4] = incl;
         }
         if (lane >= 4 && lane < 12)
             lcount[lane] = 0;
+        __syncthreads();
         return;
     }
     const int sx = which - 1;
@@ -862,10 +869,11 @@ __global__ __launch_bounds__(192) void toed_rowscan_phase_kernel(ImgBatch B, int
         o[r] = run[r & 1];
         run[r & 1] += c[r];
     }
+    __syncthreads();
     if (lane == 63)
     {
-        lcount[sx] = incl[0];     // phase (SY 0, SX sx)
-        lcount[2 + sx] = incl[1]; // phase (SY 1, SX sx)
+        lcount[sx] = s_over ? 0 : incl[0];     // phase (SY 0, SX sx)
+        lcount[2 + sx] = s_over ? 0 : incl[1]; // phase (SY 1, SX sx)
     }
 }
 
@@ -1609,10 +1617,12 @@ static int resident_blocks(ebvo_ctx *ctx, int which)
 }
 
 int toed_enqueue(ebvo_ctx *ctx, Slot &s, int n_img, int h, int w, hipEvent_t ev_conv_begin, hipEvent_t ev_conv_end,
-                 hipEvent_t ev_end)
+                 hipEvent_t ev_end, int mode)
 {
     if (n_img < 1 || n_img > MAX_BATCH)
         return EBVO_ERR_ARG;
+    if (mode < 0)
+        mode = ctx->toed_mode;
     const int H2 = 2 * h, W2 = 2 * w;
     const int need_words = H2 * ((W2 + 31) / 32); // one bitmap row per grid row
     ImgBatch B{};
@@ -1643,7 +1653,7 @@ int toed_enqueue(ebvo_ctx *ctx, Slot &s, int n_img, int h, int w, hipEvent_t ev_
         {
             ptrs[nc] = s.im[k].row_cnt;
             counts[nc++] = 2 * H2;
-            if (ctx->toed_mode == EBVO_TOED_HYBRID)
+            if (mode == EBVO_TOED_HYBRID)
             {
                 // need bitmap + its per-row counters live behind the |g| map in the (otherwise unused) plane buffer
                 ptrs[nc] = (int32_t *)(s.im[k].maps + mag_map_doubles(H2, W2));
@@ -1654,7 +1664,7 @@ int toed_enqueue(ebvo_ctx *ctx, Slot &s, int n_img, int h, int w, hipEvent_t ev_
         if (rc)
             return rc;
     }
-    if (ctx->toed_mode == EBVO_TOED_HYBRID)
+    if (mode == EBVO_TOED_HYBRID)
     {
         const int cap = ctx->cap_edges;
         if (ev_conv_begin)
@@ -1667,7 +1677,7 @@ int toed_enqueue(ebvo_ctx *ctx, Slot &s, int n_img, int h, int w, hipEvent_t ev_
         }
         {
             ProfScope ps(ctx, s, K_ROWSCAN);
-            hipLaunchKernelGGL(toed_rowscan_phase_kernel, dim3(n_img), dim3(192), 0, s.stream, B, H2);
+            hipLaunchKernelGGL(toed_rowscan_phase_kernel, dim3(n_img), dim3(192), 0, s.stream, B, H2, cap);
         }
         {
             ProfScope ps(ctx, s, K_COMPACT);

@@ -87,9 +87,12 @@ void ebvo_ctx_destroy(ebvo_ctx *ctx);
 
 /* How the third-order detector reaches its (identical) result:
  *   EBVO_TOED_STRICT  the reference's direct-form convolution at every pixel (27.6 k fp64 operations per pixel);
- *   EBVO_TOED_HYBRID  a separable fp64 screen selects a superset of the NMS maxima (tolerance 1e-6, five orders of
- *                     magnitude above the screen's error), and only those pixels are evaluated in the reference's
- *                     exact arithmetic.  Same bits out, ~3x less work; see toed_kernels.hip.
+ *   EBVO_TOED_HYBRID  a separable fp32 screen selects a superset of the NMS maxima (tolerances two orders of
+ *                     magnitude above the screen's error bound), and only those pixels are evaluated in the
+ *                     reference's exact arithmetic.  Same bits out, ~3x less work; see toed_kernels.hip.  An image on
+ *                     which the screen flags more grid points than the context's max_h * max_w (possible only when
+ *                     most of the image is exact ties, e.g. a one-pixel checkerboard) is re-run on the strict path by
+ *                     the library; ebvo_toed_fallbacks counts those.
  * The default is EBVO_TOED_HYBRID unless the environment variable EBVO_TOED_MODE is "strict". */
 enum
 {
@@ -98,6 +101,7 @@ enum
 };
 int ebvo_set_toed_mode(ebvo_ctx *ctx, int mode);
 int ebvo_get_toed_mode(const ebvo_ctx *ctx);
+int64_t ebvo_toed_fallbacks(const ebvo_ctx *ctx); /* hybrid runs the library repeated on the strict path so far */
 /* diagnostics of the last TOED run on a slot: per image {all NMS maxima, kept edges, screened candidates (hybrid),
  * distinct neighbour grid points whose exact magnitude was evaluated (hybrid)} */
 int ebvo_toed_stats(ebvo_ctx *ctx, int slot, int32_t out[8]);

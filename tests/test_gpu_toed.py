@@ -124,3 +124,50 @@ def test_hybrid_equals_strict_on_adversarial_images(name):
     assert_edges_equal(a.edges, ref["edges"], "strict")
     assert_edges_equal(b.edges, a.edges, "hybrid")
     assert_bit_equal(b.all4, a.all4, "subpix_edge_pts_final")
+
+
+@pytest.mark.parametrize("name", ["checker4", "checker1", "uniform_noise"])
+def test_hybrid_screen_overflow_falls_back_to_strict(name):
+    """The candidate buffers of the hybrid detector hold max_h * max_w entries; on an image of ties the screen can flag
+    more grid points than that.  The library must notice and repeat the image on the strict path -- in a context sized
+    exactly to the image -- instead of dropping candidates."""
+    from edge_based_visual_odometry_amd.api import Context
+    img = _stress_images()[name]
+    h, w = img.shape
+    ref = orc.toed(img, math_mode=orc.PORTABLE, want_all=True)
+    with Context(h, w, toed_mode="hybrid") as ch:
+        b = ch.toed(img, want_all=True)
+        st = ch.toed_stats()["left"]
+        fell_back = ch.toed_fallbacks
+        lb, rb, _ = ch.toed_pair(img, img[:, ::-1].copy())
+    assert b.n_total == ref["n_total"]
+    assert_edges_equal(b.edges, ref["edges"], "hybrid, tight context")
+    assert_bit_equal(b.all4, ref["all4"], "subpix_edge_pts_final")
+    assert_edges_equal(lb, ref["edges"], "pair call, left")
+    if name == "checker4":
+        assert fell_back >= 1, (fell_back, st)  # 27 k screened candidates for 12 k entries
+
+
+def test_pipeline_falls_back_to_strict_when_the_screen_overflows():
+    """Same on the enqueue-only pair pipeline: the result record carries the overflow and ebvo_stereo_wait repeats the
+    pair with the strict detector."""
+    from edge_based_visual_odometry_amd.api import Context
+    img = _stress_images()["checker4"]
+    right = np.roll(img, -3, axis=1)
+    h, w = img.shape
+    out = {}
+    for mode in ("strict", "hybrid"):
+        with Context(h, w, toed_mode=mode) as c:
+            p = c.default_params()
+            c.stereo_upload(img, right)
+            c.stereo_submit(p)
+            counts = c.stereo_wait()
+            res = c.stereo_fetch(counts)
+            out[mode] = (counts, res, c.toed_fallbacks)
+    cs, rs, _ = out["strict"]
+    ch, rh, fb = out["hybrid"]
+    assert fb == 1
+    assert (cs.n_left, cs.n_right, cs.n_pairs, cs.n_matches) == (ch.n_left, ch.n_right, ch.n_pairs, ch.n_matches)
+    assert cs.n_left > 0
+    for k in ("left", "right", "row_ptr", "col_idx", "sims", "best", "keep"):
+        assert_bit_equal(rh[k], rs[k], k)
