@@ -34,7 +34,7 @@ TOED_STRICT, TOED_HYBRID = 0, 1
 # every symbol include/ebvo_hip.h declares (checked by tests/test_abi_symbols.py)
 ABI_SYMBOLS = (
     "ebvo_strerror", "ebvo_last_error", "ebvo_abi_version", "ebvo_ctx_create", "ebvo_ctx_destroy",
-    "ebvo_set_toed_mode", "ebvo_get_toed_mode", "ebvo_toed_fallbacks", "ebvo_toed_stats",
+    "ebvo_set_toed_mode", "ebvo_get_toed_mode", "ebvo_toed_fallbacks", "ebvo_graph_launches", "ebvo_toed_stats",
     "ebvo_toed", "ebvo_toed_pair", "ebvo_epipolar_lines", "ebvo_epi_candidates", "ebvo_epi_candidates_staged", "ebvo_ncc_pairs",
     "ebvo_edge_patches", "ebvo_ncc_patches", "ebvo_ncc_quads", "ebvo_stereo_default_params", "ebvo_finalize_default_params",
     "ebvo_stereo_upload", "ebvo_stereo_run", "ebvo_stereo_fetch", "ebvo_stereo_set_slots",
@@ -159,6 +159,8 @@ def load_library() -> C.CDLL:
     lib.ebvo_get_toed_mode.argtypes = [vp]
     lib.ebvo_toed_fallbacks.argtypes = [vp]
     lib.ebvo_toed_fallbacks.restype = i64
+    lib.ebvo_graph_launches.argtypes = [vp]
+    lib.ebvo_graph_launches.restype = i64
     lib.ebvo_toed_stats.argtypes = [vp, i32, vp]
     lib.ebvo_toed.argtypes = [vp, vp, i32, i32, ssz, vp, i32, C.POINTER(i32), C.POINTER(i32), vp, i32,
                               C.POINTER(dbl), C.POINTER(dbl)]

@@ -67,6 +67,11 @@ class Context:
         return int(self.lib.ebvo_toed_fallbacks(self._ctx))
 
     @property
+    def graph_launches(self) -> int:
+        """Pairs that ebvo_stereo_submit launched as a captured hipGraph."""
+        return int(self.lib.ebvo_graph_launches(self._ctx))
+
+    @property
     def toed_mode(self) -> str:
         return "hybrid" if self.lib.ebvo_get_toed_mode(self._ctx) == _lib.TOED_HYBRID else "strict"
 

@@ -38,6 +38,7 @@ int ebvo_grow(ebvo_ctx *ctx, Slot &s, GrowBuf &b, size_t bytes)
     b.p = nullptr;
     b.bytes = 0;
     const size_t want = bytes + bytes / 4 + 256;
+    ++ctx->graph_gen; // a captured chain may hold the old address
     hipError_t e = hipMalloc(&b.p, want);
     if (e != hipSuccess)
     {
@@ -138,6 +139,8 @@ static void slot_destroy(Slot *s)
         return;
     if (s->own_stream) // (a pair still running on a lane is drained by ebvo_ctx_destroy before any slot goes)
         (void)hipStreamSynchronize(s->own_stream);
+    if (s->pair_graph)
+        (void)hipGraphExecDestroy(s->pair_graph);
     for (ProfEvent &pe : s->prof_pending)
     {
         (void)hipEventDestroy(pe.a);
@@ -304,6 +307,7 @@ extern "C" int ebvo_set_toed_mode(ebvo_ctx *ctx, int mode)
 {
     if (!ctx || (mode != EBVO_TOED_STRICT && mode != EBVO_TOED_HYBRID))
         return EBVO_ERR_ARG;
+    ++ctx->graph_gen;
     ctx->toed_mode = mode;
     return EBVO_OK;
 }
@@ -311,6 +315,8 @@ extern "C" int ebvo_set_toed_mode(ebvo_ctx *ctx, int mode)
 extern "C" int ebvo_get_toed_mode(const ebvo_ctx *ctx) { return ctx ? ctx->toed_mode : EBVO_ERR_ARG; }
 
 extern "C" int64_t ebvo_toed_fallbacks(const ebvo_ctx *ctx) { return ctx ? ctx->toed_fallbacks : -1; }
+
+extern "C" int64_t ebvo_graph_launches(const ebvo_ctx *ctx) { return ctx ? ctx->graph_launches : -1; }
 
 extern "C" int ebvo_toed_stats(ebvo_ctx *ctx, int slot, int32_t out[8])
 {
@@ -385,6 +391,8 @@ extern "C" int ebvo_ctx_create(int device, int max_h, int max_w, ebvo_ctx **out)
         // both modes return the same bits (every TOED parity test runs in both); hybrid does a third of the work
         const char *m = getenv("EBVO_TOED_MODE");
         ctx->toed_mode = (m && strcmp(m, "strict") == 0) ? EBVO_TOED_STRICT : EBVO_TOED_HYBRID;
+        const char *g = getenv("EBVO_GRAPHS"); // "0": the pair chain as direct launches (hipGraph capture is the default)
+        ctx->use_graphs = (g && strcmp(g, "0") == 0) ? 0 : 1;
     }
     int rc;
     auto fail = [&](int code) {
@@ -1127,7 +1135,101 @@ static int enqueue_matching(ebvo_ctx *ctx, Slot &s, int toed_mode = -1)
     // a hybrid TOED run reports candidate lists that did not fit through the result record (bit 2 of `overflow`)
     if ((rc = match_pair_result_enqueue(ctx, s, (toed_mode < 0 ? ctx->toed_mode : toed_mode) == EBVO_TOED_HYBRID ? ce : 0)))
         return rc;
-    EBVO_HIP(ctx, hipEventRecord(s.ev_done, s.stream));
+    return EBVO_OK; // the caller records s.ev_done behind it (outside a stream capture)
+}
+
+// undistortion (if the pair was uploaded raw) + TOED of both images + matching: every launch of one pair
+static int enqueue_pair_chain(ebvo_ctx *ctx, Slot &s)
+{
+    int rc;
+    if (s.undist_pair) // cv::undistort of both raw images (src/Pipeline.cpp:78-79); TOED runs on the result (:93, :97)
+    {
+        const ebvo_undistort_params &u = ctx->undist;
+        if ((rc = refine_undistort_enqueue(ctx, s, s.im[0].raw, s.cur_w, s.cur_h, s.cur_w, u.K_left, u.dist_left, u.n_dist,
+                                           s.im[0].undist_xs, s.im[0].img, s.cur_w)) ||
+            (rc = refine_undistort_enqueue(ctx, s, s.im[1].raw, s.cur_w, s.cur_h, s.cur_w, u.K_right, u.dist_right, u.n_dist,
+                                           s.im[1].undist_xs, s.im[1].img, s.cur_w)))
+            return rc;
+    }
+    if ((rc = toed_enqueue(ctx, s, 2, s.cur_h, s.cur_w, nullptr, nullptr, nullptr)))
+        return rc;
+    return enqueue_matching(ctx, s);
+}
+
+static void pair_graph_drop(Slot &s)
+{
+    if (s.pair_graph)
+        (void)hipGraphExecDestroy(s.pair_graph);
+    s.pair_graph = nullptr;
+}
+
+// The chain of one pair is ~31 launches whose arguments depend only on PairGraphKey and on the slot's buffers (the sizes
+// of everything live on the device): the second submission with an unchanged key captures it, later ones launch the graph
+// (measured, tools/ubench/graph_launch.hip: 7-20 us of host time for a 30-kernel chain against 86 us of direct launches,
+// and ~2 us instead of ~2.9 us between dependent kernels on the device).  Anything unusual -- profiling markers, a key
+// that changed, a capture that fails -- takes the direct path; `first` reports that to the caller for its statistics.
+static int submit_pair_chain(ebvo_ctx *ctx, Slot &s)
+{
+    PairGraphKey key;
+    memset(&key, 0, sizeof key);
+    key.h = s.cur_h;
+    key.w = s.cur_w;
+    key.toed_mode = ctx->toed_mode;
+    key.undist = s.undist_pair ? 1 : 0;
+    key.cap_pairs = s.cap_pairs;
+    key.gen = ctx->graph_gen;
+    key.epi_thr = s.params.epi_thr;
+    key.max_disp = s.params.max_disp;
+    key.orient_thr_deg = s.params.orient_thr_deg;
+    key.ncc_thr = s.params.ncc_thr;
+    key.stage_mask = s.params.stage_mask;
+    const bool same = memcmp(&key, &s.pair_key, sizeof key) == 0;
+    const bool eligible = ctx->use_graphs && !s.pair_graph_off && !ctx->prof && !s.prof_now;
+    if (!same)
+    {
+        pair_graph_drop(s);
+        s.pair_key = key;
+        s.pair_key_warm = false;
+    }
+    int rc;
+    if (eligible && s.pair_graph)
+    {
+        EBVO_HIP(ctx, hipGraphLaunch(s.pair_graph, s.stream));
+        ++ctx->graph_launches;
+        return EBVO_OK;
+    }
+    if (eligible && s.pair_key_warm)
+    {
+        // capture: thread-local mode, so that other host threads keep using their own streams meanwhile
+        hipGraph_t g = nullptr;
+        hipError_t e = hipStreamBeginCapture(s.stream, hipStreamCaptureModeThreadLocal);
+        if (e == hipSuccess)
+        {
+            const uint64_t gen_before = ctx->graph_gen;
+            rc = enqueue_pair_chain(ctx, s);
+            e = hipStreamEndCapture(s.stream, &g); // always: the stream must leave capture mode
+            if (rc == EBVO_OK && e == hipSuccess && g && ctx->graph_gen == gen_before)
+                e = hipGraphInstantiate(&s.pair_graph, g, nullptr, nullptr, 0);
+            else if (e == hipSuccess)
+                e = hipErrorUnknown;
+            if (g)
+                (void)hipGraphDestroy(g);
+        }
+        if (e == hipSuccess && s.pair_graph)
+        {
+            EBVO_HIP(ctx, hipGraphLaunch(s.pair_graph, s.stream));
+            ++ctx->graph_launches;
+            return EBVO_OK;
+        }
+        (void)hipGetLastError();
+        pair_graph_drop(s);
+        s.pair_graph_off = true; // and fall through to the direct launches
+        s.pair_key.gen = ctx->graph_gen;
+    }
+    if ((rc = enqueue_pair_chain(ctx, s)))
+        return rc;
+    if (ctx->graph_gen == s.pair_key.gen)
+        s.pair_key_warm = true; // nothing was (re)allocated on the way: the next submission may capture
     return EBVO_OK;
 }
 
@@ -1190,19 +1292,9 @@ extern "C" int ebvo_stereo_submit(ebvo_ctx *ctx, int slot, const ebvo_stereo_par
             return rc;
     }
     EBVO_HIP(ctx, hipMemcpyAsync(s.d_F, s.params.F21, sizeof(double) * 9, hipMemcpyHostToDevice, s.stream));
-    if (s.undist_pair) // cv::undistort of both raw images (src/Pipeline.cpp:78-79); TOED runs on the result (:93, :97)
-    {
-        const ebvo_undistort_params &u = ctx->undist;
-        if ((rc = refine_undistort_enqueue(ctx, s, s.im[0].raw, s.cur_w, s.cur_h, s.cur_w, u.K_left, u.dist_left, u.n_dist,
-                                           s.im[0].undist_xs, s.im[0].img, s.cur_w)) ||
-            (rc = refine_undistort_enqueue(ctx, s, s.im[1].raw, s.cur_w, s.cur_h, s.cur_w, u.K_right, u.dist_right, u.n_dist,
-                                           s.im[1].undist_xs, s.im[1].img, s.cur_w)))
-            return rc;
-    }
-    if ((rc = toed_enqueue(ctx, s, 2, s.cur_h, s.cur_w, nullptr, nullptr, nullptr)))
+    if ((rc = submit_pair_chain(ctx, s)))
         return rc;
-    if ((rc = enqueue_matching(ctx, s)))
-        return rc;
+    EBVO_HIP(ctx, hipEventRecord(s.ev_done, s.stream));
     s.in_flight = true;
     return EBVO_OK;
 }
@@ -1249,6 +1341,7 @@ extern "C" int ebvo_stereo_wait(ebvo_ctx *ctx, int slot, ebvo_stereo_counts *cou
                 s.in_flight = false;
                 return rc;
             }
+            EBVO_HIP(ctx, hipEventRecord(s.ev_done, s.stream));
             continue;
         }
         if (r.n_total_left > ctx->cap_edges || r.n_total_right > ctx->cap_edges)
@@ -1276,6 +1369,7 @@ extern "C" int ebvo_stereo_wait(ebvo_ctx *ctx, int slot, ebvo_stereo_counts *cou
             s.in_flight = false;
             return rc;
         }
+        EBVO_HIP(ctx, hipEventRecord(s.ev_done, s.stream));
     }
     if (!have_result)
     {
@@ -2424,6 +2518,9 @@ extern "C" int ebvo_undistort(ebvo_ctx *ctx, const uint8_t *img, int h, int w, p
 
 extern "C" int ebvo_stereo_set_undistort(ebvo_ctx *ctx, const ebvo_undistort_params *p)
 {
+    if (ctx)
+        ++ctx->graph_gen; // the coefficients are launch arguments of a captured chain
+
     if (!ctx || (p && (p->n_dist < 0 || p->n_dist > 5)))
         return EBVO_ERR_ARG;
     for (Slot *s : ctx->slots)
@@ -3179,7 +3276,10 @@ extern "C" int ebvo_debug_set(ebvo_ctx *ctx, int key, int value)
 {
     if (!ctx || value < 0)
         return EBVO_ERR_ARG;
-    if (key == 0)
+    ++ctx->graph_gen;
+    if (key == 10 && value <= 1)
+        ctx->use_graphs = value; // the pair chain as a hipGraph (default) or as direct launches
+    else if (key == 0)
         ctx->wait_attempts = value;
     else if (key == 1)
         ctx->force_overflow = value;

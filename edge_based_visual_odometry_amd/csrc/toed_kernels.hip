@@ -1030,29 +1030,43 @@ __device__ inline Row24 fetch_row(const uint8_t *__restrict__ img, int h, int w,
     return r;
 }
 
-// `fast`: wave-uniform promise that the whole 19 x 19 window of every lane lies inside the image (no masking)
-__device__ inline void unpack_row(const Row24 &r, int h, int w, int ii, int j, bool fast, int v[19])
+// Which of the 19 bytes of a fetched run lie inside the image row: one mask per 32-bit word, once per point.
+struct ColMask
 {
-    if (fast)
-    {
+    unsigned m[5];
+};
+__device__ inline ColMask column_mask(int w, int j)
+{
+    // byte k of the run is column j - 9 + k: valid for k in [lo, hi)
+    const int lo = max(0, HALO - j), hi = min(19, w + HALO - j);
+    ColMask c;
 #pragma unroll
-        for (int k = 0; k < 19; ++k)
-        {
-            const unsigned long long word = k < 8 ? r.w0 : (k < 16 ? r.w1 : r.w2);
-            v[18 - k] = (int)((word >> (8 * (k & 7))) & 0xffull);
-        }
-        return;
-    }
-    const bool rok = ii >= 0 && ii < h;
-#pragma unroll
-    for (int k = 0; k < 19; ++k)
+    for (int d = 0; d < 5; ++d)
     {
-        // byte k of the run is column j - 9 + k, i.e. tap q = 9 - k
-        const unsigned long long word = k < 8 ? r.w0 : (k < 16 ? r.w1 : r.w2);
-        const int b = (int)((word >> (8 * (k & 7))) & 0xffull);
-        const int col = j - HALO + k;
-        v[18 - k] = (rok && col >= 0 && col < w) ? b : 0;
+        const int a = min(max(lo - 4 * d, 0), 4), b = min(max(hi - 4 * d, 0), 4); // bytes [a, b) of word d
+        const unsigned upto_b = b >= 4 ? 0xffffffffu : ((1u << (8 * b)) - 1u);
+        const unsigned upto_a = a >= 4 ? 0xffffffffu : ((1u << (8 * a)) - 1u);
+        c.m[d] = upto_b & ~upto_a;
     }
+    return c;
+}
+
+// `fast`: wave-uniform promise that the whole 19 x 19 window of every lane lies inside the image (no masking).
+// Otherwise the five words are masked BEFORE the bytes are taken apart (ten instructions a row): selecting per byte
+// cost one instruction per pixel on both paths (the unmasked path paid them as register copies where the two paths merge).
+__device__ inline void unpack_row(const Row24 &r, int h, int ii, const ColMask &cm, bool fast, int v[19])
+{
+    unsigned d[5] = {(unsigned)r.w0, (unsigned)(r.w0 >> 32), (unsigned)r.w1, (unsigned)(r.w1 >> 32), (unsigned)r.w2};
+    if (!fast)
+    {
+        const bool rok = ii >= 0 && ii < h;
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+            d[k] = rok ? (d[k] & cm.m[k]) : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < 19; ++k) // byte k of the run is column j - 9 + k, i.e. tap q = 9 - k
+        v[18 - k] = (int)((d[k >> 2] >> (8 * (k & 3))) & 0xffu);
 }
 
 __device__ inline bool window_inside(int h, int w, int i, int j)
@@ -1101,6 +1115,7 @@ __device__ inline void exact9(const uint8_t *__restrict__ img, int h, int w, con
         f[r] = 0.0;
     constexpr int PM = IP ? 8 : 9;
     const bool fast = __all(window_inside(h, w, i, j));
+    const ColMask cm = column_mask(w, j);
     Row24 nxt = fetch_row(img, h, w, i + PM, j);
 #pragma unroll 1
     for (int p = -PM; p <= PM; ++p)
@@ -1108,7 +1123,7 @@ __device__ inline void exact9(const uint8_t *__restrict__ img, int h, int w, con
         const Row24 cur = nxt;
         nxt = fetch_row(img, h, w, i - min(p + 1, PM), j); // next row in flight while this one is accumulated
         int vb[19];
-        unpack_row(cur, h, w, i - p, j, fast, vb);
+        unpack_row(cur, h, i - p, cm, fast, vb);
         double rr[4];
 #pragma unroll
         for (int d = 0; d < 4; ++d)
@@ -1158,6 +1173,7 @@ __device__ inline double exact_mag(const uint8_t *__restrict__ img, int h, int w
     double fx = 0.0, fy = 0.0;
     constexpr int PM = IP ? 8 : 9;
     const bool fast = __all(window_inside(h, w, i, j));
+    const ColMask cm = column_mask(w, j);
     Row24 nxt = fetch_row(img, h, w, i + PM, j);
 #pragma unroll 1
     for (int p = -PM; p <= PM; ++p)
@@ -1165,7 +1181,7 @@ __device__ inline double exact_mag(const uint8_t *__restrict__ img, int h, int w
         const Row24 cur = nxt;
         nxt = fetch_row(img, h, w, i - min(p + 1, PM), j);
         int vb[19];
-        unpack_row(cur, h, w, i - p, j, fast, vb);
+        unpack_row(cur, h, i - p, cm, fast, vb);
         const double r0 = rk[p + 9][0], r1 = rk[p + 9][1];
         int lz = 0;
         asm volatile("" : "+v"(lz)); // keeps the column-tap reads in the row loop (see exact9)

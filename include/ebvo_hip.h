@@ -102,6 +102,10 @@ enum
 int ebvo_set_toed_mode(ebvo_ctx *ctx, int mode);
 int ebvo_get_toed_mode(const ebvo_ctx *ctx);
 int64_t ebvo_toed_fallbacks(const ebvo_ctx *ctx); /* hybrid runs the library repeated on the strict path so far */
+/* ebvo_stereo_submit captures the ~31 launches of a pair into a hipGraph at the second submission of a slot with unchanged
+ * size, parameters and buffers, and launches that graph afterwards (environment EBVO_GRAPHS=0 or ebvo_debug_set(ctx, 10, 0):
+ * direct launches).  Number of pairs submitted as a graph launch so far: */
+int64_t ebvo_graph_launches(const ebvo_ctx *ctx);
 /* diagnostics of the last TOED run on a slot: per image {all NMS maxima, kept edges, screened candidates (hybrid),
  * distinct neighbour grid points whose exact magnitude was evaluated (hybrid)} */
 int ebvo_toed_stats(ebvo_ctx *ctx, int slot, int32_t out[8]);
@@ -631,7 +635,8 @@ int ebvo_profile_get(ebvo_ctx *ctx, ebvo_kernel_time *out /* EBVO_MAX_KERNELS */
  * key 7: 1 = the stereo refinement's eight-lanes layout as a launch per iteration instead of one persistent launch;
  * key 8: waves per SIMD the persistent launch is built for (2 or 3).  Same bits either way.
  * key 6: set the candidate-quad capacity of every slot's temporal stage to `value` (>= 1): the next ebvo_temporal_match
- *        finds more quads than its buffers hold and takes the regrow path. */
+ *        finds more quads than its buffers hold and takes the regrow path.
+ * key 10: 0 = ebvo_stereo_submit enqueues the pair as direct launches, 1 = as a captured hipGraph (default). */
 int ebvo_debug_set(ebvo_ctx *ctx, int key, int value);
 
 /* Raw FP64 vector-ALU microbenchmark (mul + add, no FMA) used to anchor the compute roofline:
