@@ -1320,7 +1320,14 @@ __device__ inline void centre_run(const ExactBatch &E, const ExactTaps &L, int h
 // candidate needs.  Adjacent candidates along a contour share two of their four neighbours and 14 % of the
 // neighbours are candidates themselves (whose |g| is computed right here): marking every distinct point once in a
 // bitmap (no-return atomicOr; one row of the bitmap per grid row) leaves 54 % of the neighbour evaluations.
+#ifndef EBVO_CENTRE_WPS
+#define EBVO_CENTRE_WPS 0 // tuning macro: waves per SIMD the centre kernel is compiled for (0 = what its registers allow: 4)
+#endif
+#if EBVO_CENTRE_WPS > 0
+__global__ __launch_bounds__(256, EBVO_CENTRE_WPS) void toed_exact_centre_kernel(ExactBatch E, const ToedTables *__restrict__ T, int h,
+#else
 __global__ __launch_bounds__(256) void toed_exact_centre_kernel(ExactBatch E, const ToedTables *__restrict__ T, int h,
+#endif
                                                                 int w, int cap, int n_img)
 {
     __shared__ ExactTaps L;
