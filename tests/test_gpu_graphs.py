@@ -108,3 +108,33 @@ def test_graphs_on_several_slots_and_lanes():
                 got.append((c, g.stereo_fetch(c, slot=sl)))
             _same(got, ref)
         assert g.graph_launches == 5 * (rounds - 2)
+
+
+def test_graph_capture_in_two_host_threads():
+    """One context per host thread (the library's threading model): a capture in one thread (thread-local capture mode)
+    must not be disturbed by the launches of the other, and both must produce the bits of the direct launches."""
+    import threading
+    from edge_based_visual_odometry_amd.api import Context
+    pairs = _pairs(4)
+    with Context(H, W) as direct:
+        direct.debug_set(10, 0)
+        ref = _run(direct, pairs * 3)
+    out, errs = {}, []
+
+    def worker(tid):
+        try:
+            with Context(H, W) as c:
+                out[tid] = (_run(c, pairs * 3), c.graph_launches)
+        except Exception as exc:  # pragma: no cover - reported below
+            errs.append((tid, repr(exc)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errs, errs
+    for tid in range(2):
+        got, launches = out[tid]
+        assert launches == len(pairs) * 3 - 2, launches
+        _same(got, ref)
