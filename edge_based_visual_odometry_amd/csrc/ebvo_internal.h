@@ -360,8 +360,10 @@ int ebvo_clear_enqueue(ebvo_ctx *ctx, Slot &s, int32_t *const ptrs[], const int 
 // up to four scans (device-side lengths) in one pair of launches
 int ebvo_device_scan4(ebvo_ctx *ctx, Slot &s, const int32_t *const in[4], int32_t *const out[4],
                       const int32_t *const n_dev[4], int nb, int cap_n);
+// n_add = 1: the scan covers one more element that counts as zero whatever the memory behind `in` holds (out[n] = total);
+// d_total (optional, n_add = 1): the total is stored there as well
 int ebvo_device_scan(ebvo_ctx *ctx, Slot &s, const int32_t *in, int32_t *out, int n_host, const int32_t *n_dev, int n_add,
-                     int cap_n);
+                     int cap_n, int32_t *d_total = nullptr);
 // glue_kernels.hip
 int glue_bnb_enqueue(ebvo_ctx *ctx, Slot &s, const int32_t *d_row_ptr, int nL, const double *d_scores, double thr,
                      int higher_is_better, int32_t *d_new_count, int32_t *d_order);

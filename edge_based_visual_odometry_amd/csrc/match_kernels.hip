@@ -542,7 +542,8 @@ struct ScanBatch
     const int32_t *in[SCAN_BATCH];
     int32_t *out[SCAN_BATCH];
     DevN n[SCAN_BATCH];
-    int n_add;      // scan n + n_add elements (the candidate counts carry one trailing zero: out[n] = total)
+    int n_add;      // scan n + n_add elements; the extra element counts as zero whatever the memory holds: out[n] = total
+    int32_t *total[SCAN_BATCH]; // optional (n_add == 1): the total is stored here as well
     int32_t *sums;  // [SCAN_BATCH][tiles]
     int tiles;
 };
@@ -561,7 +562,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void scan_reduce_kernel(ScanBatch S)
 {
     __shared__ int32_t wsum[SCAN_BLOCK / 64];
     const int a = blockIdx.y;
-    const int n = devn(S.n[a]) + S.n_add;
+    const int n_in = devn(S.n[a]), n = n_in + S.n_add;
     const int base = blockIdx.x * SCAN_TILE;
     if (base >= n)
         return;
@@ -571,7 +572,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void scan_reduce_kernel(ScanBatch S)
     for (int t = 0; t < SCAN_ITEMS; ++t)
     {
         const int k = base + t * SCAN_BLOCK + threadIdx.x; // coalesced; the order inside a tile does not matter here
-        v += (k < n) ? in[k] : 0;
+        v += (k < n_in) ? in[k] : 0;
     }
     const int32_t tot = block_sum_256(v, wsum);
     if (threadIdx.x == 0)
@@ -582,7 +583,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void scan_apply_kernel(ScanBatch S)
 {
     __shared__ int32_t wsum[SCAN_BLOCK / 64], wpre[SCAN_BLOCK / 64];
     const int a = blockIdx.y;
-    const int n = devn(S.n[a]) + S.n_add;
+    const int n_in = devn(S.n[a]), n = n_in + S.n_add;
     const int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
     if (blockIdx.x * SCAN_TILE >= n)
         return;
@@ -595,7 +596,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void scan_apply_kernel(ScanBatch S)
     const int32_t tile_off = block_sum_256(o, wpre);
     int32_t v[SCAN_ITEMS];
     int32_t s = 0;
-    if (base + SCAN_ITEMS <= n && (reinterpret_cast<uintptr_t>(in + base) & 15) == 0)
+    if (base + SCAN_ITEMS <= n_in && (reinterpret_cast<uintptr_t>(in + base) & 15) == 0)
     {
         const int4 *p = reinterpret_cast<const int4 *>(in + base);
 #pragma unroll
@@ -609,7 +610,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void scan_apply_kernel(ScanBatch S)
     {
 #pragma unroll
         for (int t = 0; t < SCAN_ITEMS; ++t)
-            v[t] = (base + t < n) ? in[base + t] : 0;
+            v[t] = (base + t < n_in) ? in[base + t] : 0;
     }
 #pragma unroll
     for (int t = 0; t < SCAN_ITEMS; ++t)
@@ -636,6 +637,8 @@ __global__ __launch_bounds__(SCAN_BLOCK) void scan_apply_kernel(ScanBatch S)
     {
         if (base + t < n)
             out[base + t] = run;
+        if (S.n_add == 1 && base + t == n_in && S.total[a])
+            *S.total[a] = run; // the total, for callers that keep it apart from the offsets
         run += v[t];
     }
 }
@@ -1726,13 +1729,15 @@ int device_exclusive_scan_batch(ebvo_ctx *ctx, Slot &s, ScanBatch S, int nb, int
     return EBVO_OK;
 }
 
-int device_exclusive_scan(ebvo_ctx *ctx, Slot &s, const int32_t *in, int32_t *out, DevN n, int n_add, int cap_n)
+int device_exclusive_scan(ebvo_ctx *ctx, Slot &s, const int32_t *in, int32_t *out, DevN n, int n_add, int cap_n,
+                          int32_t *total = nullptr)
 {
     ScanBatch S{};
     S.in[0] = in;
     S.out[0] = out;
     S.n[0] = n;
     S.n_add = n_add;
+    S.total[0] = total;
     return device_exclusive_scan_batch(ctx, s, S, 1, cap_n);
 }
 
@@ -1782,10 +1787,10 @@ int ebvo_device_scan4(ebvo_ctx *ctx, Slot &s, const int32_t *const in[4], int32_
 }
 
 int ebvo_device_scan(ebvo_ctx *ctx, Slot &s, const int32_t *in, int32_t *out, int n_host, const int32_t *n_dev, int n_add,
-                     int cap_n)
+                     int cap_n, int32_t *d_total)
 {
     ProfScope ps(ctx, s, K_SCAN);
-    int rc = device_exclusive_scan(ctx, s, in, out, DevN{n_host, n_dev}, n_add, cap_n);
+    int rc = device_exclusive_scan(ctx, s, in, out, DevN{n_host, n_dev}, n_add, cap_n, d_total);
     if (rc)
         return rc;
     EBVO_HIP(ctx, hipGetLastError());
