@@ -544,7 +544,8 @@ def sequence_bench(args, wl, H, W, F, device, rank, world, dist, reduce_device):
     frame(0, first=True)                               # keyframe = frame 0 (src/Pipeline.cpp:133-138)
     for k in range(min(args.warmup, n_frames)):
         frame(k)
-    frame_pipeline(list(range(min(8, n_frames))))      # untimed: sizes the quad buffers of these slots, warms the pipeline
+    for _ in range(3):                                 # untimed: sizes the quad buffers of every slot, brings the clocks up, and
+        frame_pipeline(list(range(n_frames)))          # gives every slot the three submissions after which its pair chain is a graph
 
     def barrier():
         torch.cuda.synchronize()

@@ -38,7 +38,7 @@ int ebvo_grow(ebvo_ctx *ctx, Slot &s, GrowBuf &b, size_t bytes)
     b.p = nullptr;
     b.bytes = 0;
     const size_t want = bytes + bytes / 4 + 256;
-    ++ctx->graph_gen; // a captured chain may hold the old address
+    ++s.buf_gen; // a captured chain of this slot may hold the old address
     hipError_t e = hipMalloc(&b.p, want);
     if (e != hipSuccess)
     {
@@ -1177,7 +1177,7 @@ static int submit_pair_chain(ebvo_ctx *ctx, Slot &s)
     key.toed_mode = ctx->toed_mode;
     key.undist = s.undist_pair ? 1 : 0;
     key.cap_pairs = s.cap_pairs;
-    key.gen = ctx->graph_gen;
+    key.gen = ctx->graph_gen + (s.buf_gen << 20);
     key.epi_thr = s.params.epi_thr;
     key.max_disp = s.params.max_disp;
     key.orient_thr_deg = s.params.orient_thr_deg;
@@ -1205,10 +1205,10 @@ static int submit_pair_chain(ebvo_ctx *ctx, Slot &s)
         hipError_t e = hipStreamBeginCapture(s.stream, hipStreamCaptureModeThreadLocal);
         if (e == hipSuccess)
         {
-            const uint64_t gen_before = ctx->graph_gen;
+            const uint64_t gen_before = s.buf_gen;
             rc = enqueue_pair_chain(ctx, s);
             e = hipStreamEndCapture(s.stream, &g); // always: the stream must leave capture mode
-            if (rc == EBVO_OK && e == hipSuccess && g && ctx->graph_gen == gen_before)
+            if (rc == EBVO_OK && e == hipSuccess && g && s.buf_gen == gen_before)
                 e = hipGraphInstantiate(&s.pair_graph, g, nullptr, nullptr, 0);
             else if (e == hipSuccess)
                 e = hipErrorUnknown;
@@ -1224,11 +1224,10 @@ static int submit_pair_chain(ebvo_ctx *ctx, Slot &s)
         (void)hipGetLastError();
         pair_graph_drop(s);
         s.pair_graph_off = true; // and fall through to the direct launches
-        s.pair_key.gen = ctx->graph_gen;
     }
     if ((rc = enqueue_pair_chain(ctx, s)))
         return rc;
-    if (ctx->graph_gen == s.pair_key.gen)
+    if (ctx->graph_gen + (s.buf_gen << 20) == s.pair_key.gen)
         s.pair_key_warm = true; // nothing was (re)allocated on the way: the next submission may capture
     return EBVO_OK;
 }

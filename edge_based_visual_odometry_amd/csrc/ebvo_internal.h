@@ -105,8 +105,9 @@ constexpr int EBVO_MATCH_PARTS = 4096; // most blocks ncc_tile_kernel is launche
 
 // Everything that belongs to one HIP stream: a stereo pair in flight (or the workspace of a host-buffer call).
 // What a captured pair chain (ebvo_stereo_submit) depends on besides the slot's buffers: every value a launch carries as an
-// argument.  `gen` is the context's allocation / settings generation (any buffer re-allocated, any mode or debug switch
-// changed since the capture makes the graph stale).
+// argument.  `gen` is the context's settings generation (a mode or debug switch changed since the capture) plus the slot's
+// own allocation generation (one of ITS buffers re-allocated): either makes the graph stale.  Another slot's first
+// allocations do not.
 struct PairGraphKey
 {
     int32_t h, w, toed_mode, undist;
@@ -123,6 +124,7 @@ struct Slot
     // performs every allocation), launched from then on -- ~7 us of host time instead of ~90 for the 31 launches
     hipGraphExec_t pair_graph = nullptr;
     PairGraphKey pair_key{};
+    uint64_t buf_gen = 1;         // bumped whenever one of this slot's buffers is (re)allocated: part of the key
     bool pair_key_warm = false;   // a direct submission with pair_key has run
     bool pair_graph_off = false;  // capture failed once on this slot: stay on direct launches
     hipStream_t own_stream = nullptr; // created with the slot
@@ -235,7 +237,7 @@ struct ebvo_ctx
     int gn_rows_below = 0;     // developer key (ebvo_debug_set 5): active-pair count below which an iteration uses it, 0 = default
     int wait_attempts = 0;     // test hook (ebvo_debug_set): attempts of ebvo_stereo_wait's regrow loop, 0 = default (4)
     int force_overflow = 0;    // test hook: treat the next N results as overflowed
-    uint64_t graph_gen = 1;     // bumped by every (re)allocation and every mode / debug change: invalidates captured graphs
+    uint64_t graph_gen = 1;     // bumped by every mode / debug change: invalidates the captured graphs of every slot
     int use_graphs = 1;         // EBVO_GRAPHS=0 or ebvo_debug_set(10, 0): direct launches only
     int64_t graph_launches = 0; // pairs submitted as a graph launch
     int64_t toed_fallbacks = 0; // hybrid TOED runs repeated on the strict path (more screened candidates than cap_edges)
