@@ -536,6 +536,7 @@ constexpr int SCAN_ITEMS = 16;
 constexpr int SCAN_BLOCK = 256;
 constexpr int SCAN_TILE = SCAN_ITEMS * SCAN_BLOCK;
 constexpr int SCAN_BATCH = 4;
+constexpr int SCAN_DIRECT_TILES = 16; // up to 65,536 elements the scan is ONE launch (scan_apply_kernel, ScanBatch::direct)
 
 struct ScanBatch
 {
@@ -546,6 +547,7 @@ struct ScanBatch
     int32_t *total[SCAN_BATCH]; // optional (n_add == 1): the total is stored here as well
     int32_t *sums;  // [SCAN_BATCH][tiles]
     int tiles;
+    int direct;     // few tiles: every block adds up the elements before its tile itself (one launch instead of two)
 };
 
 __device__ inline int32_t block_sum_256(int32_t v, int32_t *wsum)
@@ -589,10 +591,30 @@ __global__ __launch_bounds__(SCAN_BLOCK) void scan_apply_kernel(ScanBatch S)
         return;
     const int32_t *__restrict__ in = S.in[a];
     int32_t *__restrict__ out = S.out[a];
-    // offset of this tile = sum of the tiles before it
+    // offset of this tile = sum of the tiles before it: from the reduce kernel's per-tile sums, or -- up to SCAN_DIRECT_TILES
+    // tiles, i.e. at most 60 sixteen-byte loads per thread -- straight from the elements (the launch it saves costs more)
     int32_t o = 0;
-    for (int k = threadIdx.x; k < (int)blockIdx.x; k += SCAN_BLOCK)
-        o += S.sums[(size_t)a * S.tiles + k];
+    if (S.direct)
+    {
+        const int before = min((int)blockIdx.x * SCAN_TILE, n_in);
+        if ((reinterpret_cast<uintptr_t>(in) & 15) == 0)
+        {
+            const int4 *p4 = reinterpret_cast<const int4 *>(in);
+            for (int k = threadIdx.x; k < (before >> 2); k += SCAN_BLOCK)
+            {
+                const int4 q = p4[k];
+                o += (q.x + q.y) + (q.z + q.w);
+            }
+            for (int k = (before & ~3) + threadIdx.x; k < before; k += SCAN_BLOCK)
+                o += in[k];
+        }
+        else
+            for (int k = threadIdx.x; k < before; k += SCAN_BLOCK)
+                o += in[k];
+    }
+    else
+        for (int k = threadIdx.x; k < (int)blockIdx.x; k += SCAN_BLOCK)
+            o += S.sums[(size_t)a * S.tiles + k];
     const int32_t tile_off = block_sum_256(o, wpre);
     int32_t v[SCAN_ITEMS];
     int32_t s = 0;
@@ -1723,7 +1745,8 @@ int device_exclusive_scan_batch(ebvo_ctx *ctx, Slot &s, ScanBatch S, int nb, int
     if (rc)
         return rc;
     S.sums = (int32_t *)s.scan_tmp.p;
-    if (S.tiles > 1)
+    S.direct = S.tiles <= SCAN_DIRECT_TILES ? 1 : 0;
+    if (S.tiles > 1 && !S.direct)
         hipLaunchKernelGGL(scan_reduce_kernel, dim3(S.tiles - 1, nb), dim3(SCAN_BLOCK), 0, s.stream, S);
     hipLaunchKernelGGL(scan_apply_kernel, dim3(S.tiles, nb), dim3(SCAN_BLOCK), 0, s.stream, S);
     return EBVO_OK;
