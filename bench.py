@@ -757,6 +757,7 @@ def main():
     ctx.profile_enable(False)
     seen = set()
     barrier()
+    graphs_before = ctx.graph_launches
     t0 = time.perf_counter()
     submitted = completed = 0
     while submitted < min(nslots, args.steps):
@@ -774,6 +775,7 @@ def main():
             submitted += 1
     barrier()
     dt = time.perf_counter() - t0
+    graph_pairs = ctx.graph_launches - graphs_before   # timed pairs whose ~31 launches went out as one hipGraphLaunch
     per_rank = sharding.gather_over_ranks(args.steps / dt, dist, reduce_device)
     dt = sharding.max_over_ranks(dt, dist, reduce_device)
 
@@ -928,8 +930,8 @@ def main():
             # column pass with 2 x (17 | 19) taps, FMA form (the screen is not bound to the reference's arithmetic)
             tiles = 2 * ((H + 11) // 12) * ((W + 29) // 30)
             ops = executed = tiles * (32 * 32 * 76 + 14 * 32 * (2 * 17 + 3 * 2 * 19)) * 2.0
-            ops_note = "flops of the separable fp64 screen (FMA = 2), relaxed NMS not counted"
-            fp64_peak, fp64_bound = 2 * FP64_VALU_PEAK_NOFMA_TF, "valu_fp64_fma"
+            ops_note = "flops of the separable FP32 screen (FMA = 2), relaxed NMS not counted"
+            fp64_peak, fp64_bound = 4 * FP64_VALU_PEAK_NOFMA_TF, "valu_fp32_fma"   # 157 TFLOP/s: FP32 vector FMA (MI355X_MICROARCH.md)
         else:
             ops, executed, ops_note = None, None, "not an fp64-ALU kernel"
         result = {
@@ -949,6 +951,7 @@ def main():
                        "candidate_pairs": counts.n_pairs, "ncc_matches": counts.n_matches,
                        "pairs_in_flight_per_gpu": nslots,
                        "streams_per_gpu": nslots if nslots < 4 else min(4, nslots - 1),
+                       "pairs_submitted_as_hipgraph": graph_pairs, "toed_strict_fallbacks": ctx.toed_fallbacks,
                        "parallelism": f"{world} independent sequence(s), one per GPU, no collective"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved_gbs, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, args.toed_mode),
