@@ -164,7 +164,10 @@ def cpu_baseline(left, right, F):
     # NCC of every surviving pair with the left patches (:555-616), serial as written and parallel as intended
     cand = R[ci3]
     _, t_ncc_serial = wall(orc.ncc_pairs, left, right, L, cand, rp3, math_mode=orc.LIBM, nthreads=1)
-    _, t_ncc_par = wall(orc.ncc_pairs, left, right, L, cand, rp3, math_mode=orc.LIBM, nthreads=cores)
+    libm_ncc, t_ncc_par = wall(orc.ncc_pairs, left, right, L, cand, rp3, math_mode=orc.LIBM, nthreads=cores)
+    # what the baseline computed, in the reference's own arithmetic (glibc atan2 / sin / cos): kept for the check after it
+    libm = dict(left=L, right=R, stage1=(rp1, ci1), stage2=(rp2, ci2), stage3=(rp3, ci3), sims=libm_ncc[0], best=libm_ncc[1],
+                keep=libm_ncc[2])
     # one thread throughout: TOED of one image timed once (x 2); the brute-force stage scaled from every 64th left edge
     _, t1 = wall(orc.toed, left, math_mode=orc.LIBM, nthreads=1)
     s1 = 64
@@ -193,7 +196,21 @@ def cpu_baseline(left, right, F):
                    "`value_as_written` counts them serially (what the reference executes: both pragmas are orphaned, "
                    "src/Stereo_Matches.cpp:536, :573)"),
     }
-    return record, dict(left=Lp, right=Rp, stride=1, row_ptr=rp3, col_idx=ci3, sims=sims, keep=keep, xy_equal_libm=bool(same_xy))
+    return record, dict(left=Lp, right=Rp, stride=1, row_ptr=rp3, col_idx=ci3, sims=sims, keep=keep, xy_equal_libm=bool(same_xy),
+                        libm=libm)
+
+
+def reference_arithmetic_report(ctx, out, libm, F):
+    """The fetched results of the timed pair against the CPU baseline's own (LIBM) results: see tests/reference_arithmetic.py.
+    Stages 1 and 2 (epipolar; epipolar + disparity) are produced here by the library's host-buffer search with the
+    reference's stage masks; stage 3, the scores and keep are what the timed pipeline returned."""
+    from tests import reference_arithmetic as ra
+    lines = ctx.epipolar_lines(F, out["left"])
+    gpu = dict(left=out["left"], right=out["right"], stage3=(out["row_ptr"], out["col_idx"]), sims=out["sims"], best=out["best"],
+               keep=out["keep"])
+    gpu["stage1"] = ctx.epi_candidates(out["left"], out["right"], lines, stage_mask=1)
+    gpu["stage2"] = ctx.epi_candidates(out["left"], out["right"], lines, stage_mask=3)
+    return ra.compare(libm, gpu)
 
 
 def check_against_oracle(out, chk):
@@ -449,7 +466,7 @@ def threaded_sequence(T, args, H, W, F, device, frames, calib, cal, steps):
     return steps / dt
 
 
-def verify_sequence_frame(ctx, frames, k, params, calib, cal, H, W):
+def verify_sequence_frame(ctx, frames, k, params, calib, cal, H, W, F=None):
     """After the timed region of the sequence workload: frame k once more, its results fetched and compared with the CPU oracle
     -- both TOED edge lists (on the undistorted images), every candidate quad against the keyframe, both NCC maxima and the
     keep flag of every quad, and every final quad of the whole temporal chain (tests/oracle_chain.py: temporal_reference).
@@ -481,7 +498,15 @@ def verify_sequence_frame(ctx, frames, k, params, calib, cal, H, W):
             problems.append(f"frame {k}: {side} edge list differs from the oracle")
     ref = oracle_chain.temporal_reference(kfL, kfR, cfL, cfR, t0, tk, W, H)
     problems += [f"frame {k}: {p}" for p in oracle_chain.temporal_problems(counts, q, ref)]
-    return problems, dict(frame=k, n_kf=counts["n_kf"], n_cf=counts["n_cf"], candidate_quads=counts["n_candidates"],
+    ra_rep = None
+    if F is not None:
+        # the frame's stereo stage against the oracle in the reference's OWN arithmetic (glibc atan2 / sin / cos): detector on
+        # the undistorted images, NCC on the raw ones (tests/reference_arithmetic.py)
+        from tests import reference_arithmetic as ra
+        libm = ra.oracle_libm_stages(tk[1], tk[2], frames[k][0], frames[k][1], F, cores=ra.default_cores())
+        ra_rep = reference_arithmetic_report(ctx, out, libm, F)
+        problems += [f"frame {k}: {key} is false: {ra_rep['flips'][:4]}" for key in ra.BOOLEANS if not ra_rep[key]]
+    return problems, dict(reference_arithmetic=ra_rep, frame=k, n_kf=counts["n_kf"], n_cf=counts["n_cf"], candidate_quads=counts["n_candidates"],
                           quads_kept=counts["n_kept"], final_quads=counts["n_final"])
 
 
@@ -624,8 +649,13 @@ def sequence_bench(args, wl, H, W, F, device, rank, world, dist, reduce_device):
                                         "of both cameras, edge clustering): %d final quads per frame" % tcf["n_final"],
         }
         if not args.no_verify:
-            problems, what = verify_sequence_frame(ctx, frames, min(3, n_frames - 1), params, calib, cal, H, W)
+            problems, what = verify_sequence_frame(ctx, frames, min(3, n_frames - 1), params, calib, cal, H, W, F)
             result["verified"] = not problems
+            ra_rep = what.pop("reference_arithmetic")
+            if ra_rep is not None:
+                from tests.reference_arithmetic import BOOLEANS
+                result["reference_arithmetic"] = ra_rep
+                result.update({key: ra_rep[key] for key in BOOLEANS})
             result["verified_what"] = dict(what, note="both edge lists, every candidate quad (row_ptr / col_idx), both NCC maxima "
                                                       "and the keep flag of every quad, every final quad of the temporal chain: bit "
                                                       "for bit against the CPU oracle (tests/oracle_chain.py)")
@@ -993,6 +1023,14 @@ def main():
                 if bad:
                     problems.append(bad)
                 result["verified_against_cpu_baseline"] = bad is None
+                # ... and against the baseline's results in the reference's OWN arithmetic (glibc), north_star's bar
+                rep = reference_arithmetic_report(ctx, out, chk["libm"], F)
+                result["reference_arithmetic"] = rep
+                from tests.reference_arithmetic import BOOLEANS
+                for key in BOOLEANS:
+                    result[key] = rep[key]
+                    if not rep[key]:
+                        problems.append(f"{key} is false: {rep['flips'][:4]}")
         if not args.no_verify:
             result["verified"] = not problems
             if problems:

@@ -34,7 +34,7 @@ TOED_STRICT, TOED_HYBRID = 0, 1
 # every symbol include/ebvo_hip.h declares (checked by tests/test_abi_symbols.py)
 ABI_SYMBOLS = (
     "ebvo_strerror", "ebvo_last_error", "ebvo_abi_version", "ebvo_ctx_create", "ebvo_ctx_destroy",
-    "ebvo_set_toed_mode", "ebvo_get_toed_mode", "ebvo_toed_fallbacks", "ebvo_graph_launches", "ebvo_toed_stats",
+    "ebvo_set_toed_mode", "ebvo_get_toed_mode", "ebvo_toed_fallbacks", "ebvo_graph_launches", "ebvo_toed_stats", "ebvo_toed_screen_audit",
     "ebvo_toed", "ebvo_toed_pair", "ebvo_epipolar_lines", "ebvo_epi_candidates", "ebvo_epi_candidates_staged", "ebvo_ncc_pairs",
     "ebvo_edge_patches", "ebvo_ncc_patches", "ebvo_ncc_quads", "ebvo_stereo_default_params", "ebvo_finalize_default_params",
     "ebvo_stereo_upload", "ebvo_stereo_run", "ebvo_stereo_fetch", "ebvo_stereo_set_slots",
@@ -121,6 +121,13 @@ NCC_WANT_LEFT_PATCHES, NCC_WANT_SIMS = 1, 2
 FETCH_EDGES, FETCH_CSR, FETCH_BEST, FETCH_KEEP, FETCH_SIMS, FETCH_DEFAULT, FETCH_ALL = 1, 2, 4, 8, 16, 15, 31
 
 
+class ScreenAudit(C.Structure):
+    _fields_ = [("n_candidates", C.c_int32), ("n_maxima", C.c_int32), ("n_kept", C.c_int32), ("n_neighbour_points", C.c_int32),
+                ("max_err_gx", C.c_double), ("max_err_gy", C.c_double), ("max_err_mag", C.c_double),
+                ("max_err_mag_neighbours", C.c_double), ("bound_g", C.c_double), ("bound_mag", C.c_double),
+                ("bound_slope", C.c_double), ("tol_mag", C.c_double), ("tol_slope", C.c_double)]
+
+
 class KernelTime(C.Structure):
     _fields_ = [("name", C.c_char_p), ("ms", C.c_double), ("launches", C.c_int64)]
 
@@ -162,6 +169,7 @@ def load_library() -> C.CDLL:
     lib.ebvo_graph_launches.argtypes = [vp]
     lib.ebvo_graph_launches.restype = i64
     lib.ebvo_toed_stats.argtypes = [vp, i32, vp]
+    lib.ebvo_toed_screen_audit.argtypes = [vp, vp, i32, i32, ssz, C.POINTER(ScreenAudit)]
     lib.ebvo_toed.argtypes = [vp, vp, i32, i32, ssz, vp, i32, C.POINTER(i32), C.POINTER(i32), vp, i32,
                               C.POINTER(dbl), C.POINTER(dbl)]
     lib.ebvo_toed_pair.argtypes = [vp, vp, vp, i32, i32, ssz, ssz, vp, vp, i32, C.POINTER(i32), C.POINTER(i32)]

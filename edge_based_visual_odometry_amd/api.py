@@ -61,6 +61,15 @@ class Context:
                 "right": dict(n_total=int(out[4]), n_kept=int(out[5]), n_candidates=int(out[6]),
                               n_neighbour_points=int(out[7]))}
 
+    def toed_screen_audit(self, img: np.ndarray) -> dict:
+        """ebvo_toed_screen_audit: max |screen - exact| of the hybrid detector's FP32 screen on this image, with its budget."""
+        img = _u8(img)
+        h, w = img.shape
+        a = _lib.ScreenAudit()
+        self._check(self.lib.ebvo_toed_screen_audit(self._ctx, ptr(img), h, w, img.strides[0], C.byref(a)),
+                    "ebvo_toed_screen_audit")
+        return {name: getattr(a, name) for name, _ in a._fields_}
+
     @property
     def toed_fallbacks(self) -> int:
         """Hybrid TOED runs the library repeated on the strict path (screened candidates > max_h * max_w)."""

@@ -566,6 +566,55 @@ extern "C" int ebvo_toed(ebvo_ctx *ctx, const uint8_t *img, int h, int w, ptrdif
     return EBVO_OK;
 }
 
+extern "C" int ebvo_toed_screen_audit(ebvo_ctx *ctx, const uint8_t *img, int h, int w, ptrdiff_t stride, ebvo_screen_audit *out)
+{
+    if (!ctx || !img || !out)
+        return EBVO_ERR_ARG;
+    EBVO_HIP(ctx, hipSetDevice(ctx->device));
+    int rc;
+    Slot *sp;
+    if ((rc = check_size(ctx, h, w)) || (rc = host_slot(ctx, &sp)))
+        return rc;
+    Slot &s = *sp;
+    ctx->sw_tag[0] = ctx->sw_tag[1] = 0;
+    if ((rc = upload_image(ctx, s, 0, img, h, w, stride)))
+        return rc;
+    ctx->screen_audit = true; // the next toed_enqueue keeps the screen's values and runs the audit kernel behind the exact stage
+    rc = toed_enqueue(ctx, s, 1, h, w, nullptr, nullptr, nullptr, EBVO_TOED_HYBRID);
+    ctx->screen_audit = false;
+    // a diagnostic: drain the stream, then plain synchronous copies into this frame
+    const hipError_t es = hipStreamSynchronize(s.stream);
+    if (rc)
+        return rc;
+    EBVO_HIP(ctx, es);
+    unsigned long long hw[6];
+    int32_t hc[5];
+    EBVO_HIP(ctx, hipMemcpy(hw, toed_screen_audit_result(s, 0, h, w), sizeof hw, hipMemcpyDeviceToHost));
+    EBVO_HIP(ctx, hipMemcpy(hc, s.im[0].counts, sizeof hc, hipMemcpyDeviceToHost));
+    if (hc[4] > ctx->cap_edges)
+    {
+        ctx->last_error = "the screen flagged more grid points than the context holds: nothing to audit";
+        return EBVO_ERR_CAPACITY;
+    }
+    double b[5];
+    toed_screen_budget(b);
+    auto dbl = [](unsigned long long v) { double d; memcpy(&d, &v, sizeof d); return d; };
+    out->n_maxima = hc[0];
+    out->n_kept = hc[1];
+    out->n_candidates = hc[2];
+    out->n_neighbour_points = hc[3];
+    out->max_err_gx = dbl(hw[0]);
+    out->max_err_gy = dbl(hw[1]);
+    out->max_err_mag = dbl(hw[2]);
+    out->max_err_mag_neighbours = dbl(hw[3]);
+    out->bound_g = b[0];
+    out->bound_mag = b[1];
+    out->bound_slope = b[2];
+    out->tol_mag = b[3];
+    out->tol_slope = b[4];
+    return EBVO_OK;
+}
+
 extern "C" int ebvo_toed_pair(ebvo_ctx *ctx, const uint8_t *img_left, const uint8_t *img_right, int h, int w,
                               ptrdiff_t stride_left, ptrdiff_t stride_right, ebvo_edge *out_left,
                               ebvo_edge *out_right, int cap, int n_kept[2], int n_total[2])

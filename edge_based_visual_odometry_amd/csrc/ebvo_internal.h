@@ -240,6 +240,7 @@ struct ebvo_ctx
     uint64_t graph_gen = 1;     // bumped by every mode / debug change: invalidates the captured graphs of every slot
     int use_graphs = 1;         // EBVO_GRAPHS=0 or ebvo_debug_set(10, 0): direct launches only
     int64_t graph_launches = 0; // pairs submitted as a graph launch
+    bool screen_audit = false;  // ebvo_toed_screen_audit is running: the screen keeps its gx, gy, |g| (toed_kernels.hip)
     int64_t toed_fallbacks = 0; // hybrid TOED runs repeated on the strict path (more screened candidates than cap_edges)
 
     // profiling (accumulated over all slots)
@@ -312,6 +313,9 @@ int toed_init_constants(ebvo_ctx *ctx);
 // empty results: the caller re-runs with EBVO_TOED_STRICT.
 int toed_enqueue(ebvo_ctx *ctx, Slot &s, int n_img, int h, int w, hipEvent_t ev_conv_begin, hipEvent_t ev_conv_end,
                  hipEvent_t ev_end, int mode = -1);
+// ebvo_toed_screen_audit: where the audit kernel leaves the 8 words of image k; the screen's budget {E_G, E_M, E_S, TOL_M, TOL_S}
+unsigned long long *toed_screen_audit_result(Slot &s, int k, int h, int w);
+void toed_screen_budget(double out[5]);
 
 // match_kernels.hip
 int match_lines_enqueue(ebvo_ctx *ctx, Slot &s, const double *d_F, const ebvo_edge *d_edges, int n,

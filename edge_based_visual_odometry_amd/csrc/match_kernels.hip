@@ -782,11 +782,19 @@ __global__ void sincos_edges_kernel(const ebvo_edge *__restrict__ e, DevN nd, do
 // patch_inside): no corner tests, no address clamps, a 32-bit offset from the (wave-uniform) image base, one 24-bit
 // multiply-add for the row offset.  Bit-identical to bilinear_nan wherever both apply: the loaded bytes and every
 // floating-point operation are the same; only the integer-coordinate NaN rule remains to be selected.
-__device__ inline double bilinear_inside(const uint8_t *__restrict__ img, int pitch, double x, double y)
+//
+// Round 4: the weights come from v_fract_f64 instead of floor / ceil and four subtractions.  For a positive coordinate x that
+// is not an integer, x - floor(x) is exact (a multiple of ulp(x) below 1), and ceil(x) - x = 1 - (x - floor(x)) is exact
+// too (a multiple of ulp(x) in (0, 1]), so
+//     wxb = x - x1 = fract(x),   wxa = x2 - x = 1 - fract(x),   wya = -(yf - y) = fract(y),   wyb = -(y - yc) = 1 - fract(y)
+// are the reference's weights bit for bit (include/utility.h:101-103) at three instructions per axis instead of five, and
+// the integer-coordinate rule (x2 == x1 or yf == yc: 0/0 -> NaN) is fract == 0.  `ok` reports that rule; the callers select
+// NaN per sample, or (sample_row) once per row when some lane met it.
+__device__ inline double bilinear_inside_raw(const uint8_t *__restrict__ img, int pitch, double x, double y, bool &ok)
 {
-    const double x1 = floor(x), x2 = ceil(x);
-    const double yc = ceil(y), yf = floor(y);
-    const unsigned of = __umul24((unsigned)(int)yf, (unsigned)pitch) + (unsigned)(int)x1; // row floor(y)
+    const double wxb = __builtin_amdgcn_fract(x), wya = __builtin_amdgcn_fract(y);
+    const double wxa = 1.0 - wxb, wyb = 1.0 - wya;
+    const unsigned of = __umul24((unsigned)(int)y, (unsigned)pitch) + (unsigned)(int)x; // row floor(y): (int) truncates, x, y > 0
     const unsigned oc = of + (unsigned)pitch; // row ceil(y) (= floor(y) + 1 unless y is an integer: NaN then, whatever is read)
     unsigned short p1, p2;
     __builtin_memcpy(&p1, img + oc, 2);
@@ -795,14 +803,16 @@ __device__ inline double bilinear_inside(const uint8_t *__restrict__ img, int pi
     const double I21 = (double)(p1 >> 8);
     const double I12 = (double)(p2 & 0xff);
     const double I22 = (double)(p2 >> 8);
-    const double wxa = x2 - x;
-    const double wxb = x - x1;
-    const double wya = -(yf - y);
-    const double wyb = -(y - yc);
     const double f1 = wxa * I11 + wxb * I21;
     const double f2 = wxa * I12 + wxb * I22;
-    const double v = wya * f1 + wyb * f2;
-    const bool ok = (x2 != x1) && (yf != yc); // include/utility.h:101-103: 0/0 for an integer coordinate
+    ok = (wxb != 0.0) && (wya != 0.0); // include/utility.h:101-103: 0/0 for an integer coordinate
+    return wya * f1 + wyb * f2;
+}
+
+__device__ inline double bilinear_inside(const uint8_t *__restrict__ img, int pitch, double x, double y)
+{
+    bool ok;
+    const double v = bilinear_inside_raw(img, pitch, x, y, ok);
     return ok ? v : __builtin_nan("");
 }
 
@@ -811,25 +821,27 @@ __device__ inline double bilinear_inside(const uint8_t *__restrict__ img, int pi
 // The sampling is address-divergent (every lane its own cache line): the texture addresser retires about one lane
 // address per cycle and CU, which is what bounds the sampling kernels (GRBM_TA_BUSY, profiles/), so halving the load
 // count halves that bound.  Same bytes, same arithmetic as bilinear_inside.
-__device__ inline double bilinear_inside2(const uint16_t *__restrict__ pix2, int pitch, double x, double y)
+__device__ inline double bilinear_inside2_raw(const uint16_t *__restrict__ pix2, int pitch, double x, double y, bool &ok)
 {
-    const double x1 = floor(x), x2 = ceil(x);
-    const double yc = ceil(y), yf = floor(y);
-    const unsigned of = __umul24((unsigned)(int)yf, (unsigned)pitch) + (unsigned)(int)x1;
+    const double wxb = __builtin_amdgcn_fract(x), wya = __builtin_amdgcn_fract(y); // see bilinear_inside_raw
+    const double wxa = 1.0 - wxb, wyb = 1.0 - wya;
+    const unsigned of = __umul24((unsigned)(int)y, (unsigned)pitch) + (unsigned)(int)x;
     unsigned q;
     __builtin_memcpy(&q, reinterpret_cast<const uint8_t *>(pix2) + 2u * of, 4);
     const double I12 = (double)(q & 0xffu);         // (floor y, x1)
     const double I11 = (double)((q >> 8) & 0xffu);  // (ceil y,  x1)
     const double I22 = (double)((q >> 16) & 0xffu); // (floor y, x2)
     const double I21 = (double)(q >> 24);           // (ceil y,  x2)
-    const double wxa = x2 - x;
-    const double wxb = x - x1;
-    const double wya = -(yf - y);
-    const double wyb = -(y - yc);
     const double f1 = wxa * I11 + wxb * I21;
     const double f2 = wxa * I12 + wxb * I22;
-    const double v = wya * f1 + wyb * f2;
-    const bool ok = (x2 != x1) && (yf != yc); // include/utility.h:101-103: 0/0 for an integer coordinate
+    ok = (wxb != 0.0) && (wya != 0.0);
+    return wya * f1 + wyb * f2;
+}
+
+__device__ inline double bilinear_inside2(const uint16_t *__restrict__ pix2, int pitch, double x, double y)
+{
+    bool ok;
+    const double v = bilinear_inside2_raw(pix2, pitch, x, y, ok);
     return ok ? v : __builtin_nan("");
 }
 
@@ -909,6 +921,9 @@ __device__ inline void sample_row(const uint8_t *__restrict__ img, int h, int w,
     const int i = row - 3;
     if (__all(!active || patch_inside(h, w, ex, ey)))
     {
+        // the NaN rule of an integer coordinate (measure zero) is applied once per row, and only when some lane met it: no
+        // per-sample selects on the common path
+        bool all_ok = true;
         if (active)
         {
 #pragma unroll
@@ -917,7 +932,24 @@ __device__ inline void sample_row(const uint8_t *__restrict__ img, int h, int w,
                 const int j = c - 3;
                 const double x = cs * (i)-sn * (j) + cx;
                 const double y = sn * (i) + cs * (j) + cy;
-                p[c] = (float)(PIX2 ? bilinear_inside2(pix2, pitch, x, y) : bilinear_inside(img, pitch, x, y));
+                bool ok;
+                p[c] = (float)(PIX2 ? bilinear_inside2_raw(pix2, pitch, x, y, ok) : bilinear_inside_raw(img, pitch, x, y, ok));
+                all_ok = all_ok && ok;
+            }
+        }
+        if (__any(!all_ok))
+        {
+            if (active)
+            {
+#pragma unroll
+                for (int c = 0; c < 7; ++c)
+                {
+                    const int j = c - 3;
+                    const double x = cs * (i)-sn * (j) + cx;
+                    const double y = sn * (i) + cs * (j) + cy;
+                    if (__builtin_amdgcn_fract(x) == 0.0 || __builtin_amdgcn_fract(y) == 0.0)
+                        p[c] = __builtin_nanf("");
+                }
             }
         }
         return;

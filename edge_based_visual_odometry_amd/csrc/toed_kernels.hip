@@ -98,6 +98,7 @@ struct ToedTables
     double tap_half[4][19];
     double prod_fx[17][17];
     double prod_fy[17][17];
+    float screen_dc[4][2]; // FP32 screen: 127.5 * sum(K_row) * sum(K_col) of (gx, gy) per phase (sy << 1 | sx)
 };
 ToedTables *g_tables_dev[16] = {nullptr}; // per HIP device
 
@@ -560,27 +561,41 @@ __global__ __launch_bounds__(256) void toed_finalize_kernel(ImgBatch B, int h, i
 // from those exact values only, so the edge list equals the strict path's bit for bit; a pixel that the relaxed
 // screen rejects is rejected by the exact test too.
 //
-// Round 3: the screen runs in FP32 (it was fp64 with a tolerance of 1e-6).  Error budget, 8-bit pixels, these taps
-// (sum |G| <= 1.000, sum |Gx| <= 0.404 for the integer and the half-pixel tables), u = 2^-24:
-//   row pass     R_G, R_Gx = sums of <= 19 products v * K, v exact, K rounded to float, accumulated by FMA:
-//                |err| <= 20 u * 255 * sum|K|  ->  3.1e-4 on R_G (|R_G| <= 255), 1.3e-4 on R_Gx (|R_Gx| <= 103)
-//   column pass  gx = sum R_Gx * G, gy = sum R_G * Gx:  |err| <= sum|K| * err_R + 20 u * max|R| * sum|K|
-//                ->  1.3e-4 + 1.3e-4 and 0.404 * 3.1e-4 + 1.3e-4:  |d gx|, |d gy| <= 2.6e-4          (E_G)
-//   |g|          sqrt is 1-Lipschitz in (gx, gy): |d m| <= sqrt(2) E_G + u * 361 <= 4.0e-4                 (E_M)
-//   slope        minor / major with |major| >= |g| / sqrt(2) >= 1.41: |d s| <= 2 E_G / 1.41 <= 3.7e-4   (E_S)
-//   neighbours   fp = p1 (1 - s) + p2 s: |d fp| <= E_M + |p2 - p1| E_S (+ 3 u * 361 for the float arithmetic)
-// These are worst-case bounds (every rounding error aligned); on images the screen's |g| is within ~2e-6 of the exact one.
-// A comparison of two screened quantities needs twice the bound.  The relaxed test uses  TOL_M = 1e-3 (2.5 x E_M,
-// 3.8 x E_G)  wherever a magnitude or a gradient component is compared with a constant or with another component, and
-// TOL_M + TOL_S |p2 - p1|,  TOL_S = 5e-4 (1.35 x E_S),  where it is compared with an interpolated neighbour:
+// The screen runs in FP32 (round 3; it was fp64 with a tolerance of 1e-6).  Round 4: the pixels are RECENTRED,
+// x = v - 127.5 (exact in float, |x| <= 127.5; a pixel outside the image is v = 0, i.e. x = -127.5, in every row and column
+// alike), and the constant 127.5 * sum(K_row) * sum(K_col) is added back after the column pass -- every partial sum of the
+// two passes is at most half of what it was, and so is the worst-case rounding error.  The budget below is no longer a
+// hand derivation: tools/screen_error_bound.py computes it from THIS file's tap tables and the kernel's accumulation
+// order (FMA chain s_k = fl(s_{k-1} + x_k fl(K_k)): |error| <= u X (sum|K| + sum_k cum_k), cum_k the running sum of |K| --
+// each step rounds a partial sum of magnitude <= X cum_k; the column pass adds sum|K_col| times the row error), and
+// tests/test_screen_bound.py re-derives it and checks the constants and the static_asserts below.  u = 2^-24:
+//   |d gx|, |d gy| <= 7.66e-5                                                              (SCREEN_E_G)
+//   |d |g||        <= sqrt(2) E_G + 3 u max|g| = 1.22e-4,  max |g| = 72.7                  (SCREEN_E_M)
+//   |d slope|      <= 2 E_G / |major| + u = 1.09e-4,  |major| >= |g| / sqrt(2) >= 1.41    (SCREEN_E_S)
+//   a comparison   m >= f - tol of two screened magnitudes, f = p1 (1 - s) + p2 s:
+//                  tol >= 2 E_M + 6 u max|g| + E_S |p2 - p1| = 2.69e-4 + 1.09e-4 |p2 - p1|
+// These are worst-case bounds (every rounding error aligned); what the screen really does is MEASURED: the diagnostic
+// entry point ebvo_toed_screen_audit runs the detector with a variant of this kernel that keeps its gx, gy, |g| and
+// returns max |screen - exact| over all candidates and neighbour points (tests/test_gpu_screen_audit.py: ~1e-6 on the three
+// full-size workloads and on full-size saturating 0 / 255 stripe and checkerboard images; asserted below the budget).
+// The relaxed test uses TOL_M = 5e-4 (1.9 x what a comparison needs, 4.1 x E_M, 6.5 x E_G) wherever a magnitude or a gradient
+// component is compared with a constant or with another component, and TOL_M + TOL_S |p2 - p1|, TOL_S = 2.5e-4
+// (2.3 x E_S), where it is compared with an interpolated neighbour:
 //   |g| > 2 - TOL_M, and either the gradient sector is ambiguous (|gx|, |gy| or ||gx| - |gy|| below TOL_M: the exact
 //   sector could differ from the screen's) or |g| >= fm - tol and |g| >= fp - tol with the screen's own neighbours; the
 //   |s*| <= sqrt(2) test is left to the exact stage.
-// A wider tolerance only adds candidates (KITTI S2 pair: 130,5xx per image for 130,489 / 130,734 maxima, see
-// ebvo_toed_stats), never removes one; every TOED parity test runs in this mode.
+// A wider tolerance only adds candidates, never removes one (round 3: 1e-3 / 5e-4 against twice these error bounds,
+// +2.1 % candidates; now +1.0 %); every TOED parity test runs in this mode.
 // ==========================================================================================
-constexpr float SCREEN_TOL_M = 1e-3f;
-constexpr float SCREEN_TOL_S = 5e-4f;
+constexpr float SCREEN_TOL_M = 5e-4f;
+constexpr float SCREEN_TOL_S = 2.5e-4f;
+constexpr float SCREEN_CENTRE = 127.5f;
+// tools/screen_error_bound.py (rounded up)
+constexpr double SCREEN_E_G = 7.67e-5, SCREEN_E_M = 1.22e-4, SCREEN_E_S = 1.09e-4, SCREEN_G_MAX = 72.8;
+constexpr double SCREEN_U = 5.9604644775390625e-08; // 2^-24
+static_assert(SCREEN_TOL_M >= 1.5 * (2.0 * SCREEN_E_M + 6.0 * SCREEN_U * SCREEN_G_MAX), "a comparison of two screened magnitudes");
+static_assert(SCREEN_TOL_M >= 3.0 * (2.0 * SCREEN_E_G), "the sector tests compare two screened gradient components");
+static_assert(SCREEN_TOL_S >= 2.0 * SCREEN_E_S, "the interpolation weight");
 
 // S1+S2 fused -------------------------------------------------------------------------------
 // The screen in one kernel: the separable planes never leave LDS.  One block screens the four phases of a
@@ -612,7 +627,18 @@ struct FusedLds
 };
 static_assert(sizeof(FusedLds) <= 27306, "six blocks per CU (160 KB of LDS)");
 
-__global__ __launch_bounds__(256) void toed_screen_fused_kernel(ImgBatch B, const ToedTables *__restrict__ T, int h, int w)
+// DIAG (ebvo_toed_screen_audit only): the screen's gx, gy, |g| of every grid point it decides are also written to three float
+// planes of 2H x 2W, for the audit kernel below to compare with the exact stage's values.
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+struct ScreenDiag
+{
+    float *plane[MAX_BATCH]; // [3][2H][2W]
+};
+
+template <bool DIAG>
+__global__ __launch_bounds__(256) void toed_screen_fused_kernel(ImgBatch B, const ToedTables *__restrict__ T, int h, int w,
+                                                                ScreenDiag D)
 {
     __shared__ __attribute__((aligned(16))) FusedLds L;
     const uint8_t *__restrict__ img = B.img[blockIdx.z];
@@ -656,39 +682,47 @@ __global__ __launch_bounds__(256) void toed_screen_fused_kernel(ImgBatch B, cons
             const uint32_t wq = L.img[r][(c0 >> 2) + q];
 #pragma unroll
             for (int b = 0; b < 4; ++b)
-                if (4 * q + b < 22)
-                    v[4 * q + b] = (float)((wq >> (8 * b)) & 0xffu);
+                if (4 * q + b < 22) // recentred: |x| <= 127.5 halves every partial sum (error budget above)
+                    v[4 * q + b] = (float)((wq >> (8 * b)) & 0xffu) - SCREEN_CENTRE;
         }
-        float a17[4][2], ah[4][2];
+        // (G, Gx) pairs as packed floats: one v_pk_fma_f32 updates both accumulators of a column (same IEEE fused operations,
+        // same order: the error budget is per component; half the instructions)
+        v2f a17[4], ah[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c)
-            a17[c][0] = a17[c][1] = ah[c][0] = ah[c][1] = 0.0f;
+            a17[c] = ah[c] = (v2f){0.0f, 0.0f};
 #pragma unroll
         for (int q = -8; q <= 8; ++q)
         {
-            const float g = L.tap[0][q + 9][0], gx = L.tap[0][q + 9][1];
-            const float hg = L.tap[1][q + 9][0], hgx = L.tap[1][q + 9][1];
+            const v2f ti = *reinterpret_cast<const v2f *>(L.tap[0][q + 9]); // {G, Gx}, integer table
+            const v2f th = *reinterpret_cast<const v2f *>(L.tap[1][q + 9]); // half-pixel table
 #pragma unroll
             for (int c = 0; c < 4; ++c)
             {
                 const float x = v[c + HALO - q];
-                a17[c][0] = __builtin_fmaf(x, g, a17[c][0]);
-                a17[c][1] = __builtin_fmaf(x, gx, a17[c][1]);
-                ah[c][0] = __builtin_fmaf(x, hg, ah[c][0]);
-                ah[c][1] = __builtin_fmaf(x, hgx, ah[c][1]);
+                const v2f xx = (v2f){x, x};
+                a17[c] = __builtin_elementwise_fma(xx, ti, a17[c]);
+                ah[c] = __builtin_elementwise_fma(xx, th, ah[c]);
             }
         }
         float o[6][4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
         {
-            const float xl = v[c + HALO + 9], xr = v[c + HALO - 9]; // taps q = -9 and q = +9
-            o[0][c] = a17[c][0];
-            o[1][c] = a17[c][1];
-            o[2][c] = __builtin_fmaf(xr, L.tap[0][18][0], __builtin_fmaf(xl, L.tap[0][0][0], a17[c][0]));
-            o[3][c] = __builtin_fmaf(xr, L.tap[0][18][1], __builtin_fmaf(xl, L.tap[0][0][1], a17[c][1]));
-            o[4][c] = __builtin_fmaf(xr, L.tap[1][18][0], __builtin_fmaf(xl, L.tap[1][0][0], ah[c][0]));
-            o[5][c] = __builtin_fmaf(xr, L.tap[1][18][1], __builtin_fmaf(xl, L.tap[1][0][1], ah[c][1]));
+            const v2f ti0 = *reinterpret_cast<const v2f *>(L.tap[0][0]), ti18 = *reinterpret_cast<const v2f *>(L.tap[0][18]);
+            const v2f th0 = *reinterpret_cast<const v2f *>(L.tap[1][0]), th18 = *reinterpret_cast<const v2f *>(L.tap[1][18]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+            {
+                const float xl = v[c + HALO + 9], xr = v[c + HALO - 9]; // taps q = -9 and q = +9
+                const v2f l2 = (v2f){xl, xl}, r2 = (v2f){xr, xr};
+                const v2f i19 = __builtin_elementwise_fma(r2, ti18, __builtin_elementwise_fma(l2, ti0, a17[c]));
+                const v2f h19 = __builtin_elementwise_fma(r2, th18, __builtin_elementwise_fma(l2, th0, ah[c]));
+                o[0][c] = a17[c].x;
+                o[1][c] = a17[c].y;
+                o[2][c] = i19.x;
+                o[3][c] = i19.y;
+                o[4][c] = h19.x;
+                o[5][c] = h19.y;
+            }
         }
 #pragma unroll
         for (int k = 0; k < 6; ++k) // one 16-byte store per plane (a wave: 8 rows x 8 column groups = 1 KB, eight bank passes)
@@ -702,32 +736,38 @@ __global__ __launch_bounds__(256) void toed_screen_fused_kernel(ImgBatch B, cons
         // x kernel: sx ? half : integer (17 taps for phase (0,0), 19 otherwise); y kernel: sy ? half : integer
         const int base = sx ? 4 : (sy ? 2 : 0);
         const int pm = (ph == 0) ? 8 : 9;
-        float rg[25], rgx[25]; // R filtered with G / Gx along x, image-tile rows e0 .. e0 + 24
+        v2f rr[25]; // {R filtered with Gx along x, R filtered with G along x}, image-tile rows e0 .. e0 + 24
 #pragma unroll
         for (int k = 0; k < 25; ++k)
-        {
-            rg[k] = L.R[base][e0 + k][c];
-            rgx[k] = L.R[base + 1][e0 + k][c];
-        }
+            rr[k] = (v2f){L.R[base + 1][e0 + k][c], L.R[base][e0 + k][c]};
+        v2f acc[7];
 #pragma unroll
         for (int e = 0; e < 7; ++e)
-            fx[e] = fy[e] = 0.0f;
+            acc[e] = (v2f){0.0f, 0.0f};
 #pragma unroll
         for (int p = -9; p <= 9; ++p)
         {
             if (p < -pm || p > pm) // uniform per wave half: phase (0,0) has no +-9 taps
                 continue;
-            const float kg = L.tap[sy][p + 9][0], kgx = L.tap[sy][p + 9][1];
+            const v2f kk = *reinterpret_cast<const v2f *>(L.tap[sy][p + 9]); // {G, Gx} along y
 #pragma unroll
-            for (int e = 0; e < 7; ++e)
-            {
-                fx[e] = __builtin_fmaf(rgx[e + HALO - p], kg, fx[e]);  // Gx along x, G along y
-                fy[e] = __builtin_fmaf(rg[e + HALO - p], kgx, fy[e]);  // G along x, Gx along y
-            }
+            for (int e = 0; e < 7; ++e) // fx: Gx along x, G along y; fy: G along x, Gx along y -- one packed FMA
+                acc[e] = __builtin_elementwise_fma(rr[e + HALO - p], kk, acc[e]);
         }
 #pragma unroll
         for (int e = 0; e < 7; ++e)
+        {
+            fx[e] = acc[e].x;
+            fy[e] = acc[e].y;
+        }
+        const float dcx = T->screen_dc[ph][0], dcy = T->screen_dc[ph][1]; // 127.5 * sum(K_row) * sum(K_col)
+#pragma unroll
+        for (int e = 0; e < 7; ++e)
+        {
+            fx[e] += dcx;
+            fy[e] += dcy;
             mg[e] = __builtin_sqrtf(__builtin_fmaf(fx[e], fx[e], fy[e] * fy[e]));
+        }
     }
     __syncthreads(); // every thread is done with R: M may overwrite it
 #pragma unroll
@@ -784,6 +824,14 @@ __global__ __launch_bounds__(256) void toed_screen_fused_kernel(ImgBatch B, cons
                 }
             }
             B.flag[blockIdx.z][(size_t)I * W2 + J] = (uint8_t)f;
+            if (DIAG)
+            {
+                float *dp = D.plane[blockIdx.z];
+                const size_t plane = (size_t)H2 * W2, o = (size_t)I * W2 + J;
+                dp[o] = fx[e];
+                dp[plane + o] = fy[e];
+                dp[2 * plane + o] = mg[e];
+            }
         }
         // candidates of grid row I by column parity: a wave holds 32 columns x (sx = 0, 1) of ONE sy and one row group,
         // so all its lanes share I; lanes 0-31 are even columns (sx = 0), lanes 32-63 odd
@@ -1546,6 +1594,46 @@ __global__ __launch_bounds__(256) void toed_exact_decide_kernel(ExactBatch E, in
     }
 }
 
+// Audit (ebvo_toed_screen_audit): max |screen - exact| of gx, gy, |g| over the candidates, and of |g| over the distinct
+// neighbour points that lie inside the screened interior -- the quantities the error budget above bounds.  Non-negative
+// doubles order like their bit patterns, so the maxima are integer atomicMax on out[0..3]; out[4] counts the candidates
+// whose exact sector differs from the screen's unambiguous reading (none may, by the budget), out[5] the candidates audited.
+__global__ __launch_bounds__(256) void toed_screen_audit_kernel(ExactBatch E, ScreenDiag D, int h, int w, int cap, int im,
+                                                                unsigned long long *out)
+{
+    const int W2 = 2 * w, H2 = 2 * h;
+    const size_t plane = (size_t)H2 * W2;
+    const float *__restrict__ dp = D.plane[im];
+    const int n = min(E.counts[im][2], cap);
+    double e[4] = {0, 0, 0, 0};
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x)
+    {
+        const int o = E.src[im][2 * t];
+        const CandExact ce = E.cd[im][t];
+        e[0] = fmax(e[0], fabs((double)dp[o] - ce.gx));
+        e[1] = fmax(e[1], fabs((double)dp[plane + o] - ce.gy));
+        e[2] = fmax(e[2], fabs((double)dp[2 * plane + o] - ce.m));
+    }
+    for (int ph = 0; ph < 4; ++ph)
+    {
+        const int32_t *__restrict__ list = E.lists[im] + (size_t)(4 + ph) * cap;
+        const int np = min(E.lcount[im][4 + ph], cap);
+        for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < np; k += gridDim.x * blockDim.x)
+        {
+            const int o = list[k];
+            const int I = o / W2, J = o - I * W2;
+            if (I >= 10 && I < H2 - 10 && J >= 10 && J < W2 - 10) // the screen decides (and the audit planes hold) these only
+                e[3] = fmax(e[3], fabs((double)dp[2 * plane + o] - E.magmap[im][mag_index(I, J, W2)]));
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (e[k] > 0)
+            atomicMax(&out[k], (unsigned long long)__double_as_longlong(e[k]));
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        out[5] = (unsigned long long)n;
+}
+
 // S4 ---------------------------------------------------------------------------------------
 // write the edge records at their scanned ranks (raster order is the candidate order)
 __global__ __launch_bounds__(256) void toed_cand_scatter_kernel(ImgBatch B, int cap)
@@ -1608,6 +1696,24 @@ int toed_init_constants(ebvo_ctx *ctx)
             host.prod_fx[p + 8][q + 8] = h_TAP_INT[1][q + 9] * h_TAP_INT[0][p + 9];
             host.prod_fy[p + 8][q + 8] = h_TAP_INT[0][q + 9] * h_TAP_INT[1][p + 9];
         }
+    // FP32 screen: the constant its recentred pixels leave out, per phase; row / column tap ranges as the kernel uses them
+    // (phase (0, 0): 17 integer taps both ways; otherwise 19 taps, the half-pixel table along a shifted axis)
+    for (int sy = 0; sy < 2; ++sy)
+        for (int sx = 0; sx < 2; ++sx)
+        {
+            const int pm = (sy == 0 && sx == 0) ? 8 : 9;
+            const double(*xt)[19] = sx ? h_TAP_HALF : h_TAP_INT, (*yt)[19] = sy ? h_TAP_HALF : h_TAP_INT;
+            double sxg = 0, sxgx = 0, syg = 0, sygx = 0;
+            for (int q = -pm; q <= pm; ++q)
+            {
+                sxg += xt[0][q + 9];
+                sxgx += xt[1][q + 9];
+                syg += yt[0][q + 9];
+                sygx += yt[1][q + 9];
+            }
+            host.screen_dc[(sy << 1) | sx][0] = (float)(127.5 * sxgx * syg); // gx: Gx along x, G along y
+            host.screen_dc[(sy << 1) | sx][1] = (float)(127.5 * sxg * sygx); // gy: G along x, Gx along y
+        }
     if (ctx->device < 0 || ctx->device >= 16)
         return EBVO_ERR_ARG;
     if (!g_tables_dev[ctx->device])
@@ -1637,6 +1743,24 @@ static int resident_blocks(ebvo_ctx *ctx, int which)
         c = (per_cu > 0 ? per_cu : 4) * (cus > 0 ? cus : 256);
     }
     return c;
+}
+
+// where the audit of image k of the slot leaves its 8 words: behind the three audit planes
+unsigned long long *toed_screen_audit_result(Slot &s, int k, int h, int w)
+{
+    const int H2 = 2 * h, W2 = 2 * w;
+    const int need_words = H2 * ((W2 + 31) / 32);
+    float *planes = (float *)((int32_t *)(s.im[k].maps + mag_map_doubles(H2, W2)) + need_words + 4 * H2);
+    return (unsigned long long *)(planes + 3 * (size_t)H2 * W2);
+}
+
+void toed_screen_budget(double out[5])
+{
+    out[0] = SCREEN_E_G;
+    out[1] = SCREEN_E_M;
+    out[2] = SCREEN_E_S;
+    out[3] = SCREEN_TOL_M;
+    out[4] = SCREEN_TOL_S;
 }
 
 int toed_enqueue(ebvo_ctx *ctx, Slot &s, int n_img, int h, int w, hipEvent_t ev_conv_begin, hipEvent_t ev_conv_end,
@@ -1690,13 +1814,23 @@ int toed_enqueue(ebvo_ctx *ctx, Slot &s, int n_img, int h, int w, hipEvent_t ev_
     if (mode == EBVO_TOED_HYBRID)
     {
         const int cap = ctx->cap_edges;
+        ScreenDiag D{};
         if (ev_conv_begin)
             EBVO_HIP(ctx, hipEventRecord(ev_conv_begin, s.stream));
         {
             ProfScope ps(ctx, s, K_NMS);
             const dim3 ftiles((w + FT_W - 1) / FT_W, (h + FT_H - 1) / FT_H, n_img);
-            hipLaunchKernelGGL(toed_screen_fused_kernel, ftiles, dim3(256), 0, s.stream, B,
-                               (const ToedTables *)g_tables_dev[ctx->device], h, w);
+            if (ctx->screen_audit)
+            {
+                // audit planes: behind the need bitmap and its counters in the plane buffer (free in hybrid mode)
+                for (int k = 0; k < n_img; ++k)
+                    D.plane[k] = (float *)((int32_t *)(s.im[k].maps + mag_map_doubles(H2, W2)) + need_words + 4 * H2);
+                hipLaunchKernelGGL(toed_screen_fused_kernel<true>, ftiles, dim3(256), 0, s.stream, B,
+                                   (const ToedTables *)g_tables_dev[ctx->device], h, w, D);
+            }
+            else
+                hipLaunchKernelGGL(toed_screen_fused_kernel<false>, ftiles, dim3(256), 0, s.stream, B,
+                                   (const ToedTables *)g_tables_dev[ctx->device], h, w, D);
         }
         {
             ProfScope ps(ctx, s, K_ROWSCAN);
@@ -1748,6 +1882,13 @@ int toed_enqueue(ebvo_ctx *ctx, Slot &s, int n_img, int h, int w, hipEvent_t ev_
                                    w, cap, n_img);
                 hipLaunchKernelGGL(toed_exact_decide_kernel, dim3(512, n_img), dim3(256), 0, s.stream, E, h, w, cap);
             }
+            if (ctx->screen_audit)
+                for (int k = 0; k < n_img; ++k)
+                {
+                    unsigned long long *out = toed_screen_audit_result(s, k, h, w);
+                    EBVO_HIP(ctx, hipMemsetAsync(out, 0, 8 * sizeof(unsigned long long), s.stream));
+                    hipLaunchKernelGGL(toed_screen_audit_kernel, dim3(512), dim3(256), 0, s.stream, E, D, h, w, cap, k, out);
+                }
         }
         if (ev_conv_end)
             EBVO_HIP(ctx, hipEventRecord(ev_conv_end, s.stream));

@@ -31,10 +31,10 @@
 extern "C" {
 #endif
 
-#define EBVO_ABI_VERSION 5 /* 2: photometric refinement, stage glue, finalisation, resident chain; 3: pinned result views,
+#define EBVO_ABI_VERSION 6 /* 2: photometric refinement, stage glue, finalisation, resident chain; 3: pinned result views,
                               undistortion, SIFT descriptors, SIFT stages of the chain; 4: the temporal chain after the
                               NCC filter (ebvo_temporal_params / _counts grew, ebvo_temporal_fetch_final); 5: the resident
-                              stage-wise calls (ebvo_toed_resident, ebvo_epi_candidates_resident, ebvo_ncc_pairs_resident) */
+                              stage-wise calls (ebvo_toed_resident, ebvo_epi_candidates_resident, ebvo_ncc_pairs_resident); 6: ebvo_toed_screen_audit */
 
 typedef struct ebvo_ctx ebvo_ctx;
 
@@ -87,8 +87,10 @@ void ebvo_ctx_destroy(ebvo_ctx *ctx);
 
 /* How the third-order detector reaches its (identical) result:
  *   EBVO_TOED_STRICT  the reference's direct-form convolution at every pixel (27.6 k fp64 operations per pixel);
- *   EBVO_TOED_HYBRID  a separable fp32 screen selects a superset of the NMS maxima (tolerances two orders of
- *                     magnitude above the screen's error bound), and only those pixels are evaluated in the
+ *   EBVO_TOED_HYBRID  a separable fp32 screen selects a superset of the NMS maxima (tolerances 1.9 - 2.3 x the screen's
+ *                     WORST-CASE rounding-error bound, which tools/screen_error_bound.py derives from the tap tables and
+ *                     toed_kernels.hip asserts at compile time; two orders of magnitude above the error observed on
+ *                     images, see ebvo_toed_screen_audit), and only those pixels are evaluated in the
  *                     reference's exact arithmetic.  Same bits out, ~3x less work; see toed_kernels.hip.  An image on
  *                     which the screen flags more grid points than the context's max_h * max_w (possible only when
  *                     most of the image is exact ties, e.g. a one-pixel checkerboard) is re-run on the strict path by
@@ -109,6 +111,24 @@ int64_t ebvo_graph_launches(const ebvo_ctx *ctx);
 /* diagnostics of the last TOED run on a slot: per image {all NMS maxima, kept edges, screened candidates (hybrid),
  * distinct neighbour grid points whose exact magnitude was evaluated (hybrid)} */
 int ebvo_toed_stats(ebvo_ctx *ctx, int slot, int32_t out[8]);
+
+/* Diagnostic of the hybrid detector's FP32 screen (not on any hot path): runs the detector on one image with a variant of the
+ * screen kernel that keeps its gx, gy, |g|, and compares them with the exact stage's values at every candidate (and |g| at
+ * every neighbour grid point of the screened interior).  The superset property of the screen (hybrid == strict, bit for bit:
+ * src/toed/cpu_toed.cpp:406-483 decided from exact values only) rests on max_err_* <= bound_*; tests assert it on full-size
+ * images.  Returns EBVO_ERR_CAPACITY when the screen flagged more grid points than the context holds (nothing to audit). */
+typedef struct ebvo_screen_audit
+{
+    int32_t n_candidates;       /* grid points the screen selected */
+    int32_t n_maxima;           /* ... of which the exact NMS accepted (Total_Num_Of_TOED) */
+    int32_t n_kept;             /* ... inside the 10-px border (toed_edges.size()) */
+    int32_t n_neighbour_points; /* distinct neighbour grid points evaluated exactly */
+    double max_err_gx, max_err_gy, max_err_mag; /* over the candidates: |screen - exact| */
+    double max_err_mag_neighbours;              /* over the neighbour points */
+    double bound_g, bound_mag, bound_slope;     /* worst-case budget E_G, E_M, E_S (tools/screen_error_bound.py) */
+    double tol_mag, tol_slope;                  /* the relaxed test's tolerances TOL_M, TOL_S */
+} ebvo_screen_audit;
+int ebvo_toed_screen_audit(ebvo_ctx *ctx, const uint8_t *img, int h, int w, ptrdiff_t stride, ebvo_screen_audit *out);
 
 /*
  * Replaces ThirdOrderEdgeDetectionCPU::get_Third_Order_Edges(cv::Mat)

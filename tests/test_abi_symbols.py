@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for name in header_symbols():
         assert hasattr(lib, name), name
     header = open(os.path.join(ROOT, "include", "ebvo_hip.h")).read()
-    assert lib.ebvo_abi_version() == int(re.search(r"#define EBVO_ABI_VERSION (\d+)", header).group(1)) == 5
+    assert lib.ebvo_abi_version() == int(re.search(r"#define EBVO_ABI_VERSION (\d+)", header).group(1)) == 6
     assert lib.ebvo_strerror(-2) == b"output capacity too small"
 
 
