@@ -347,6 +347,70 @@ def frame_loop(ctx, params, pool, nslots, steps, upload, fetch):
     return time.perf_counter() - t0, nbytes / max(1, steps)
 
 
+def ingest_loop(ctx, params, ring, nslots, steps, fetch=None):
+    """A streamed sequence at the resident rate (round 4): `nslots` pairs in flight on `nslots + 1` slots; the images of step
+    i + 1 are uploaded (ebvo_stereo_upload_async: DMA from the page-locked frame ring on the context's upload stream, the host
+    does not wait) while step i is still being matched, so that a submission never waits for its images -- what a frame loop
+    that reads frame k + 1 while frame k is matched does (src/Pipeline.cpp:77-99, cmd/main_VO.cpp:99-113).  fetch: None, or
+    "compact" (ebvo_stereo_fetch_compact_begin / _end: (x, y) pairs, CSR, best, keep bits through page-locked staging, the
+    copy overlaps the other slots' kernels), or an EBVO_FETCH_* selection.  Requires ctx.set_slots(nslots + 1) or more.
+    Returns (seconds, bytes fetched per pair)."""
+    S = nslots + 1
+    t0 = time.perf_counter()
+    nbytes = 0
+    uploaded = submitted = done = 0
+
+    def upload(slot):
+        nonlocal uploaded
+        ctx.stereo_upload_async(*ring[uploaded % len(ring)], slot=slot)
+        uploaded += 1
+
+    def begin(slot):
+        if fetch == "compact":
+            ctx.stereo_fetch_compact_begin(slot=slot)
+        else:
+            ctx.stereo_fetch_begin(slot=slot, what=fetch)
+
+    def consume(slot):
+        nonlocal nbytes
+        out = ctx.stereo_fetch_compact_end(slot=slot) if fetch == "compact" else ctx.stereo_fetch_end(slot=slot)
+        nbytes += sum(v.nbytes for v in out.values() if isinstance(v, np.ndarray))
+        if fetch == "compact":
+            if int(out["keep_bits"][0]) < 0 or out["n_matches"] > out["n_pairs"]:      # touch the data
+                raise RuntimeError("compact results out of range")
+        elif out["keep"] is not None and int(out["keep"][-1]) > 1:
+            raise RuntimeError("keep flag out of range")
+
+    for k in range(min(nslots, steps)):
+        upload(k)
+        ctx.stereo_submit(params, slot=k)
+        submitted += 1
+    ahead = None                                   # the slot whose images are uploaded and not yet submitted
+    if uploaded < steps:
+        ahead = uploaded % S
+        upload(ahead)
+    pending = None
+    while done < steps:
+        k = done % S
+        ctx.stereo_wait(slot=k)
+        done += 1
+        if ahead is not None:                      # its upload was enqueued a whole pair earlier
+            ctx.stereo_submit(params, slot=ahead)
+            submitted += 1
+            ahead = None
+        if fetch:
+            begin(k)
+            if pending is not None:
+                consume(pending)
+            pending = k
+        if uploaded < steps:                       # the images the slot will be submitted with at the next turn
+            ahead = k
+            upload(k)
+    if pending is not None:
+        consume(pending)
+    return time.perf_counter() - t0, nbytes / max(1, steps)
+
+
 def boundary_bench_cpp(left, right, H, W, iters=10, toed_mode="hybrid"):
     """Builds and runs tools/boundary_bench.cpp (g++ against include/ebvo/adapters.hpp and the in-tree library) as a child
     process; returns its JSON object, or None when there is no compiler / the build or the run fails."""
@@ -627,6 +691,7 @@ def sequence_bench(args, wl, H, W, F, device, rank, world, dist, reduce_device):
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "per_rank_frames_per_s": per_rank,
+            **sharding.rank_balance(per_rank, world, sharding.job_throughput(world, args.steps, dt)),
             "config": {"workload": wl["label"], "shape": f"{W}x{H}", "toed_mode": args.toed_mode,
                        "edges_left": c.n_left, "edges_right": c.n_right, "candidate_pairs": c.n_pairs, "ncc_matches": c.n_matches,
                        "final_stereo_mates": fc["n_final"], "temporal_candidate_quads": tc["n_candidates"],
@@ -682,6 +747,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the result check after the timed region (profiling runs)")
     ap.add_argument("--no-transfer-legs", action="store_true", help="skip the with_h2d / with_h2d_d2h loops")
+    ap.add_argument("--no-ingest", action="store_true", help="skip value_with_h2d (the timed loop fed from a page-locked frame ring)")
     ap.add_argument("--toed-mode", default="hybrid", choices=["strict", "hybrid"],
                     help="strict: direct-form convolution at every pixel; hybrid: separable screen + exact "
                          "re-evaluation of the candidates (bit-identical edges, ~3x less work)")
@@ -709,6 +775,10 @@ def main():
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the launcher must start exactly --gpus ranks", file=sys.stderr)
         sys.exit(2)
     dist = None
+    # every rank on its own cores (its GPU's NUMA node when sysfs says which), thread pools capped: before torch starts its own
+    n_dev_sysfs = len([d for d in os.listdir("/sys/class/drm") if d.startswith("renderD")]) if os.path.isdir("/sys/class/drm") else 0
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+    rank_cpus = sharding.pin_rank(local_rank, local_world, max(1, n_dev_sysfs)) if world > 1 and not os.environ.get("EBVO_NO_PIN") else None
     import torch
     ndev = torch.cuda.device_count()             # counting devices does not initialise the GPU
     device = local_rank % max(1, ndev)           # one rank per GPU on a full node; wraps only when rehearsing N > #GPUs
@@ -732,9 +802,11 @@ def main():
         mine = 0.25 * (rank + 1)
         per_rank = sharding.gather_over_ranks(mine, dist, reduce_device)
         dt = sharding.max_over_ranks(mine, dist, reduce_device)
+        cpus = sharding.gather_int_lists(sorted(os.sched_getaffinity(0)), 1024, dist, reduce_device)
         if rank == 0:
             print(json.dumps({"selftest_launch": True, "n_gpus": world, "backend": backend if world > 1 else None,
-                              "per_rank_seconds": per_rank, "max_seconds": dt,
+                              "per_rank_seconds": per_rank, "max_seconds": dt, "rank_cpus": cpus, "pinned": rank_cpus is not None,
+                              "omp_num_threads": os.environ.get("OMP_NUM_THREADS"),
                               "value": sharding.job_throughput(world, args.steps, dt),
                               "sequences": [sharding.rank_workload(r) for r in range(world)]}))
         if dist is not None:
@@ -766,13 +838,27 @@ def main():
     # to, a 20-step timed region read 2730 pairs/s where the same region behind 0.2 s of load reads 2910 and a 300-step
     # region 3040; EBVO_MIN_WARM_PAIRS=0 restores the short form).  The line reports both numbers.
     n_warm = max(max(1, args.warmup) * nslots, int(os.environ.get("EBVO_MIN_WARM_PAIRS", MIN_WARM_PAIRS)))
-    sub = done = 0
-    while done < n_warm:
-        while sub < n_warm and sub - done < nslots:
-            ctx.stereo_submit(params, slot=sub % nslots)
-            sub += 1
-        counts = ctx.stereo_wait(slot=done % nslots)
-        done += 1
+
+    def run_pairs(n):
+        """n pairs through the pipelined submit / wait pattern; returns (seconds, counts of the last pair)"""
+        t_ = time.perf_counter()
+        sub_ = done_ = 0
+        c_ = None
+        while done_ < n:
+            while sub_ < n and sub_ - done_ < nslots:
+                ctx.stereo_submit(params, slot=sub_ % nslots)
+                sub_ += 1
+            c_ = ctx.stereo_wait(slot=done_ % nslots)
+            done_ += 1
+        return time.perf_counter() - t_, c_
+
+    # first the protocol as the command line states it (--warmup W pairs per slot, then K pairs timed; rank-local, no barrier):
+    # `value_short_warmup` next to `value`, so that the two protocols can be compared in one record (ADVICE r3)
+    n_short = max(1, args.warmup) * nslots
+    run_pairs(n_short)
+    t_short, counts = run_pairs(args.steps)
+    if n_warm > n_short + args.steps:
+        _, counts = run_pairs(n_warm - n_short - args.steps)
 
     def barrier():
         torch.cuda.synchronize()
@@ -806,8 +892,11 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     graph_pairs = ctx.graph_launches - graphs_before   # timed pairs whose ~31 launches went out as one hipGraphLaunch
+    # the sustained rate: 300 pairs more, rank-local, straight after the timed region (the same loop)
+    t_sus, _ = run_pairs(300)
     per_rank = sharding.gather_over_ranks(args.steps / dt, dist, reduce_device)
     dt = sharding.max_over_ranks(dt, dist, reduce_device)
+    rank_cpu_counts = [len(c) for c in sharding.gather_int_lists(sorted(os.sched_getaffinity(0)), 1024, dist, reduce_device)]
 
     # ---- what the timed region produced (every rank checks its own sequence) ---------------------------------
     problems = []
@@ -824,6 +913,39 @@ def main():
             for key, want in KITTI_KAT.items():
                 if got[key] != want:
                     problems.append(f"{key}: {got[key]} != known answer {want}")
+
+    # ---- the same pairs/s with every pair's images arriving from host memory (second key; every rank, same barriers) -----
+    ingest = None
+    if not args.no_ingest:
+        ring = [tuple(np.ascontiguousarray(im) for im in synth.stereo_pair("s2", H, W, scene=seq["scene"], noise_base=seq["noise_base"] + 10 * k,
+                                                                            disparity=seq["disparity"])) for k in range(4)]
+        for pair in ring:                                   # the caller's frame ring, page-locked once
+            for im in pair:
+                ctx.host_register(im)
+        ctx.set_slots(nslots + 1)                           # nslots pairs in flight + the slot being uploaded a frame ahead
+        ingest_loop(ctx, params, ring, nslots, 4 * (nslots + 1))      # untimed: sizes the extra slot, every slot's chain becomes a graph
+        barrier()
+        t_ing, _ = ingest_loop(ctx, params, ring, nslots, args.steps)
+        barrier()
+        per_rank_ing = sharding.gather_over_ranks(args.steps / t_ing, dist, reduce_device)
+        t_ing = sharding.max_over_ranks(t_ing, dist, reduce_device)
+        ingest = {"value_with_h2d": sharding.job_throughput(world, args.steps, t_ing), "per_rank_pairs_per_s_with_h2d": per_rank_ing}
+        if rank == 0 and world == 1 and not args.no_transfer_legs:
+            n_leg = max(nslots + 1, min(args.steps, 60))
+            ingest_loop(ctx, params, ring, nslots, nslots + 1, "compact")     # untimed: sizes the page-locked staging
+            t_c, mb_c = ingest_loop(ctx, params, ring, nslots, n_leg, "compact")
+            t_sus_ing, _ = ingest_loop(ctx, params, ring, nslots, 300)
+            ingest.update(with_h2d_d2h_compact=n_leg / t_c, d2h_bytes_per_pair_compact=mb_c, value_with_h2d_sustained_300=300 / t_sus_ing)
+        ingest["ingest_note"] = ("value_with_h2d: the timed loop with a NEW pair per step DMA-ed from a page-locked frame ring "
+                                 "(ebvo_host_register, ebvo_stereo_upload_async on the context's upload stream, issued one pair ahead of "
+                                 "its submission: nslots pairs in flight on nslots + 1 slots), barriers and MAX over ranks as for "
+                                 "`value`; with_h2d_d2h_compact adds the compact result fetch ((x, y) of both edge lists, CSR, fp64 "
+                                 "best, keep as bits) through page-locked staging")
+        for pair in ring:
+            for im in pair:
+                ctx.host_unregister(im)
+        for k in range(nslots):                                               # restore the resident workload
+            ctx.stereo_upload(left, right, slot=k)
 
     # ---- per-kernel device time, pairs one at a time, HIP events around every kernel (outside the timed region) -
     prof = None
@@ -969,11 +1091,17 @@ def main():
             "value": sharding.job_throughput(world, args.steps, dt),
             "unit": "stereo pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "warmup_pairs_run": n_warm,
+            "warmup_pairs_run": max(n_warm, n_short + args.steps), "warmup_overridden": n_warm > n_short,
+            "value_short_warmup": args.steps / t_short, "value_sustained_300": 300 / t_sus,
+            "warmup_note": f"value: {args.steps} pairs timed after {max(n_warm, n_short + args.steps)} untimed ones (the device clocks follow "
+                           f"the load with a delay); value_short_warmup: the same {args.steps} pairs timed after --warmup x slots = "
+                           f"{n_short} pairs only (this rank, no barrier); value_sustained_300: 300 pairs straight after the timed region",
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "per_rank_pairs_per_s": per_rank,
+            **sharding.rank_balance(per_rank, world, sharding.job_throughput(world, args.steps, dt)),
+            "rank_cpus": rank_cpu_counts,
             "config": {"workload": wl["label"], "shape": f"{W}x{H}",
                        "toed_mode": args.toed_mode,
                        "edges_left": counts.n_left, "edges_right": counts.n_right,
@@ -1012,8 +1140,13 @@ def main():
                                        "frac_of_sustained": executed / dom_avg_s / 1e12 / (fp64_peak * FP64_VALU_SUSTAINED_FRAC),
                                        "note": ops_note + "; peak = 78.6 TFLOP/s vendor FP64 vector (FMA), halved where mul "
                                                           "and add must stay separate operations"}
+        if ingest is not None:
+            result.update(ingest)
         if legs is not None:
             result.update(legs)
+        if world > 1:
+            result["cpu_baseline"] = None
+            result["cpu_baseline_note"] = "N > 1: the CPU baseline is timed on rank 0 at N = 1 only"
         if world == 1 and not args.no_cpu_baseline:
             rec, chk = cpu_baseline(left, right, F)
             result["cpu_baseline"] = rec

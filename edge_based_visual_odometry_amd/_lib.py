@@ -34,7 +34,8 @@ TOED_STRICT, TOED_HYBRID = 0, 1
 # every symbol include/ebvo_hip.h declares (checked by tests/test_abi_symbols.py)
 ABI_SYMBOLS = (
     "ebvo_strerror", "ebvo_last_error", "ebvo_abi_version", "ebvo_ctx_create", "ebvo_ctx_destroy",
-    "ebvo_set_toed_mode", "ebvo_get_toed_mode", "ebvo_toed_fallbacks", "ebvo_graph_launches", "ebvo_toed_stats", "ebvo_toed_screen_audit",
+    "ebvo_set_toed_mode", "ebvo_get_toed_mode", "ebvo_toed_fallbacks", "ebvo_graph_launches", "ebvo_toed_stats", "ebvo_toed_screen_audit", "ebvo_stereo_upload_async", "ebvo_host_register", "ebvo_host_unregister",
+    "ebvo_stereo_fetch_compact_begin", "ebvo_stereo_fetch_compact_end",
     "ebvo_toed", "ebvo_toed_pair", "ebvo_epipolar_lines", "ebvo_epi_candidates", "ebvo_epi_candidates_staged", "ebvo_ncc_pairs",
     "ebvo_edge_patches", "ebvo_ncc_patches", "ebvo_ncc_quads", "ebvo_stereo_default_params", "ebvo_finalize_default_params",
     "ebvo_stereo_upload", "ebvo_stereo_run", "ebvo_stereo_fetch", "ebvo_stereo_set_slots",
@@ -121,6 +122,15 @@ NCC_WANT_LEFT_PATCHES, NCC_WANT_SIMS = 1, 2
 FETCH_EDGES, FETCH_CSR, FETCH_BEST, FETCH_KEEP, FETCH_SIMS, FETCH_DEFAULT, FETCH_ALL = 1, 2, 4, 8, 16, 15, 31
 
 
+class CompactView(C.Structure):
+    _fields_ = [("left_xy", C.c_void_p), ("right_xy", C.c_void_p), ("left_theta", C.c_void_p), ("right_theta", C.c_void_p),
+                ("row_ptr", C.c_void_p), ("col_idx", C.c_void_p), ("best", C.c_void_p), ("keep_bits", C.c_void_p),
+                ("n_left", C.c_int32), ("n_right", C.c_int32), ("n_pairs", C.c_int64), ("n_matches", C.c_int64)]
+
+
+COMPACT_XY, COMPACT_THETA, COMPACT_CSR, COMPACT_BEST, COMPACT_KEEP_BITS, COMPACT_DEFAULT, COMPACT_ALL = 1, 2, 4, 8, 16, 29, 31
+
+
 class ScreenAudit(C.Structure):
     _fields_ = [("n_candidates", C.c_int32), ("n_maxima", C.c_int32), ("n_kept", C.c_int32), ("n_neighbour_points", C.c_int32),
                 ("max_err_gx", C.c_double), ("max_err_gy", C.c_double), ("max_err_mag", C.c_double),
@@ -196,6 +206,11 @@ def load_library() -> C.CDLL:
     lib.ebvo_stereo_set_slots.argtypes = [vp, i32]
     lib.ebvo_stereo_upload_slot.argtypes = [vp, i32, vp, vp, i32, i32, ssz, ssz]
     lib.ebvo_stereo_submit.argtypes = [vp, i32, C.POINTER(StereoParams)]
+    lib.ebvo_stereo_upload_async.argtypes = [vp, i32, vp, vp, i32, i32, ssz, ssz]
+    lib.ebvo_host_register.argtypes = [vp, vp, C.c_size_t]
+    lib.ebvo_host_unregister.argtypes = [vp, vp]
+    lib.ebvo_stereo_fetch_compact_begin.argtypes = [vp, i32, i32]
+    lib.ebvo_stereo_fetch_compact_end.argtypes = [vp, i32, C.POINTER(CompactView)]
     lib.ebvo_stereo_wait.argtypes = [vp, i32, C.POINTER(StereoCounts)]
     lib.ebvo_stereo_fetch_slot.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.ebvo_profile_enable.argtypes = [vp, i32]

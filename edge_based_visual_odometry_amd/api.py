@@ -529,6 +529,22 @@ class Context:
         self._check(self.lib.ebvo_stereo_upload_slot(self._ctx, slot, ptr(left), ptr(right), h, w, left.strides[0],
                                                      right.strides[0]), "ebvo_stereo_upload_slot")
 
+    def stereo_upload_async(self, left, right, slot: int = 0):
+        """ebvo_stereo_upload_async: returns once the copies are enqueued (page-locked sources: host_register); the slot's next
+        submission waits for them on the device.  The arrays must stay alive and unchanged until the pair has been waited for."""
+        assert left.dtype == np.uint8 and right.dtype == np.uint8 and left.flags.c_contiguous and right.flags.c_contiguous
+        h, w = left.shape
+        assert right.shape == (h, w)
+        self._check(self.lib.ebvo_stereo_upload_async(self._ctx, slot, ptr(left), ptr(right), h, w, left.strides[0],
+                                                      right.strides[0]), "ebvo_stereo_upload_async")
+
+    def host_register(self, arr: np.ndarray):
+        """page-lock a numpy array (a frame ring) for asynchronous uploads"""
+        self._check(self.lib.ebvo_host_register(self._ctx, ptr(arr), arr.nbytes), "ebvo_host_register")
+
+    def host_unregister(self, arr: np.ndarray):
+        self._check(self.lib.ebvo_host_unregister(self._ctx, ptr(arr)), "ebvo_host_unregister")
+
     def stereo_run(self, params: StereoParams) -> StereoCounts:
         c = StereoCounts()
         self._check(self.lib.ebvo_stereo_run(self._ctx, C.byref(params), C.byref(c)), "ebvo_stereo_run")
@@ -624,6 +640,29 @@ class Context:
                     row_ptr=view(v.row_ptr, v.n_left + 1, np.int32), col_idx=view(v.col_idx, v.n_pairs, np.int32),
                     sims=None if sims is None else sims.reshape(-1, 4), best=view(v.best, v.n_pairs, np.float64),
                     keep=view(v.keep, v.n_pairs, np.uint8))
+
+    def stereo_fetch_compact_begin(self, slot: int = 0, what: int = _lib.COMPACT_DEFAULT):
+        self._check(self.lib.ebvo_stereo_fetch_compact_begin(self._ctx, slot, what), "ebvo_stereo_fetch_compact_begin")
+
+    def stereo_fetch_compact_end(self, slot: int = 0) -> dict:
+        """numpy VIEWS of the compact arrays: (x, y) pairs, orientations, CSR, best, keep as a bit mask (bit k & 31 of word k >> 5)"""
+        v = _lib.CompactView()
+        self._check(self.lib.ebvo_stereo_fetch_compact_end(self._ctx, slot, C.byref(v)), "ebvo_stereo_fetch_compact_end")
+
+        def view(ptr_, count, dtype):
+            if not ptr_:
+                return None
+            nbytes = int(count) * np.dtype(dtype).itemsize
+            if nbytes == 0:
+                return np.zeros(0, dtype=dtype)
+            return np.frombuffer((C.c_ubyte * nbytes).from_address(ptr_), dtype=dtype, count=int(count))
+
+        lxy, rxy = view(v.left_xy, 2 * v.n_left, np.float64), view(v.right_xy, 2 * v.n_right, np.float64)
+        return dict(left_xy=None if lxy is None else lxy.reshape(-1, 2), right_xy=None if rxy is None else rxy.reshape(-1, 2),
+                    left_theta=view(v.left_theta, v.n_left, np.float64), right_theta=view(v.right_theta, v.n_right, np.float64),
+                    row_ptr=view(v.row_ptr, v.n_left + 1, np.int32), col_idx=view(v.col_idx, v.n_pairs, np.int32),
+                    best=view(v.best, v.n_pairs, np.float64), keep_bits=view(v.keep_bits, 2 * ((v.n_pairs + 63) // 64), np.uint32),
+                    n_pairs=int(v.n_pairs), n_matches=int(v.n_matches))
 
     def debug_set(self, key: int, value: int):
         """Test hooks (ebvo_debug_set): 0 = attempts of the regrow loop, 1 = force N overflowed results, 2 = number of

@@ -172,7 +172,7 @@ static void slot_destroy(Slot *s)
                        &s->scan_tmp,     &s->col_idx,      &s->rc_edges,       &s->sims,           &s->best,
                        &s->keep,         &s->patches_raw,  &s->patches_norm,   &s->patches_flag,   &s->patches_norm_r,
                        &s->patches_flag_r, &s->pair_left,  &s->sincos,         &s->scratch_b,      &s->scratch_c,
-                       &s->scratch_d};
+                       &s->scratch_d,    &s->fetch_pack};
     for (GrowBuf *b : bufs)
         free_buf(*b);
     (void)hipFree(s->d_total);
@@ -188,6 +188,8 @@ static void slot_destroy(Slot *s)
         (void)hipEventDestroy(s->ev_done);
     if (s->ev_rebind)
         (void)hipEventDestroy(s->ev_rebind);
+    if (s->ev_upload)
+        (void)hipEventDestroy(s->ev_upload);
     (void)hipFree(s->d_fin_tot);
     if (s->h_fin_tot)
         (void)hipHostFree(s->h_fin_tot);
@@ -209,6 +211,9 @@ static int drain_fetch(ebvo_ctx *ctx, Slot &s)
 {
     if (s.fetch_pending)
         EBVO_HIP(ctx, hipEventSynchronize(s.ev_rebind));
+    if (s.upload_pending) // an asynchronous upload (ebvo_stereo_upload_async) still writes the slot's image buffers
+        EBVO_HIP(ctx, hipEventSynchronize(s.ev_upload));
+    s.upload_pending = false;
     return EBVO_OK;
 }
 
@@ -232,6 +237,7 @@ static int slot_create(ebvo_ctx *ctx, Slot **out)
     s->stream = s->own_stream;
     CK(hipEventCreateWithFlags(&s->ev_done, hipEventDisableTiming));
     CK(hipEventCreateWithFlags(&s->ev_rebind, hipEventDisableTiming));
+    CK(hipEventCreateWithFlags(&s->ev_upload, hipEventDisableTiming));
     const size_t H2 = 2 * (size_t)ctx->max_h, W2 = 2 * (size_t)ctx->max_w, np2 = H2 * W2;
     for (int k = 0; k < 2; ++k)
     {
@@ -341,8 +347,12 @@ extern "C" void ebvo_ctx_destroy(ebvo_ctx *ctx)
         (void)hipStreamSynchronize(st);
     if (ctx->copy_stream)
         (void)hipStreamSynchronize(ctx->copy_stream);
+    if (ctx->upload_stream)
+        (void)hipStreamSynchronize(ctx->upload_stream);
     for (Slot *s : ctx->slots)
         slot_destroy(s);
+    if (ctx->upload_stream)
+        (void)hipStreamDestroy(ctx->upload_stream);
     for (hipStream_t st : ctx->lane_streams)
         (void)hipStreamDestroy(st);
     if (ctx->copy_stream)
@@ -422,18 +432,20 @@ static int check_size(ebvo_ctx *ctx, int h, int w)
     return EBVO_OK;
 }
 
-static int upload_image(ebvo_ctx *ctx, Slot &s, int k, const uint8_t *img, int h, int w, ptrdiff_t stride, bool to_raw = false)
+static int upload_image(ebvo_ctx *ctx, Slot &s, int k, const uint8_t *img, int h, int w, ptrdiff_t stride, bool to_raw = false,
+                        hipStream_t on = nullptr)
 {
     if (stride < w)
         return EBVO_ERR_ARG;
     uint8_t *dst = to_raw ? s.im[k].raw : s.im[k].img;
+    const hipStream_t st = on ? on : s.stream;
     // a tightly packed image is ONE linear copy: the 2-D copy of pageable memory is staged row by row (measured 3 ms
     // per KITTI image against 0.1 ms)
     if (stride == (ptrdiff_t)w)
-        EBVO_HIP(ctx, hipMemcpyAsync(dst, img, (size_t)w * h, hipMemcpyHostToDevice, s.stream));
+        EBVO_HIP(ctx, hipMemcpyAsync(dst, img, (size_t)w * h, hipMemcpyHostToDevice, st));
     else
         EBVO_HIP(ctx, hipMemcpy2DAsync(dst, (size_t)w, img, (size_t)stride, (size_t)w, (size_t)h,
-                                       hipMemcpyHostToDevice, s.stream));
+                                       hipMemcpyHostToDevice, st));
     return EBVO_OK;
 }
 
@@ -1111,8 +1123,8 @@ extern "C" int ebvo_stereo_upload_slot(ebvo_ctx *ctx, int slot, const uint8_t *i
     s.tq_n = -1;
     s.tq_final.n = -1;
     s.sift_left_valid = false;
-    if (s.fetch_pending) // a result copy of the previous pair is still reading the buffers
-        EBVO_HIP(ctx, hipEventSynchronize(s.ev_rebind));
+    if ((rc = drain_fetch(ctx, s))) // a result copy of the previous pair still reads the buffers / an asynchronous upload writes them
+        return rc;
     s.fetch_pending = false;
     s.fetch_what = 0;
     s.undist_pair = ctx->undist_on; // the pair goes to the raw buffers; submit undistorts it into img
@@ -1124,6 +1136,69 @@ extern "C" int ebvo_stereo_upload_slot(ebvo_ctx *ctx, int slot, const uint8_t *i
     s.cur_h = h;
     s.cur_w = w;
     s.have_pair = true;
+    return EBVO_OK;
+}
+
+// The same upload without blocking the calling thread: the two copies go to the context's UPLOAD stream (its own hardware
+// queue: they never sit in front of a pair's kernels), an event marks their end, and the slot's next submission makes its
+// stream wait for that event -- satisfied long before when the caller uploads a slot a frame ahead of submitting it
+// (src/Pipeline.cpp:77-99 reads frame k + 1 while frame k is matched).  Asynchronous only for page-locked sources
+// (ebvo_host_register / hipHostMalloc); from pageable memory the runtime stages the copy and returns when it has read the source.
+extern "C" int ebvo_stereo_upload_async(ebvo_ctx *ctx, int slot, const uint8_t *img_left, const uint8_t *img_right, int h, int w,
+                                        ptrdiff_t stride_left, ptrdiff_t stride_right)
+{
+    Slot *sp;
+    int rc;
+    if (!img_left || !img_right || (rc = get_slot(ctx, slot, &sp)))
+        return EBVO_ERR_ARG;
+    EBVO_HIP(ctx, hipSetDevice(ctx->device));
+    if ((rc = check_size(ctx, h, w)))
+        return rc;
+    Slot &s = *sp;
+    if (s.in_flight || s.fin_in_flight || s.tq_in_flight)
+        return EBVO_ERR_STATE;
+    if (!ctx->upload_stream)
+        EBVO_HIP(ctx, hipStreamCreateWithFlags(&ctx->upload_stream, hipStreamNonBlocking));
+    s.have_pair = s.have_run = s.have_refined = s.have_final = false;
+    if (slot == 0)
+        ctx->sw_tag[0] = ctx->sw_tag[1] = 0;
+    s.tq_n = -1;
+    s.tq_final.n = -1;
+    s.sift_left_valid = false;
+    // ordering on the device, not on the host: result copies of the previous pair (copy stream) still read the edge lists --
+    // not the images -- so only a previous asynchronous upload of this slot (same stream: ordered) and the slot's own stream
+    // (later stages of the previous pair sample the images) matter
+    EBVO_HIP(ctx, hipEventRecord(s.ev_upload, s.own_stream));
+    EBVO_HIP(ctx, hipStreamWaitEvent(ctx->upload_stream, s.ev_upload, 0));
+    s.undist_pair = ctx->undist_on;
+    if ((rc = upload_image(ctx, s, 0, img_left, h, w, stride_left, s.undist_pair, ctx->upload_stream)) ||
+        (rc = upload_image(ctx, s, 1, img_right, h, w, stride_right, s.undist_pair, ctx->upload_stream)))
+        return rc;
+    EBVO_HIP(ctx, hipEventRecord(s.ev_upload, ctx->upload_stream));
+    s.upload_pending = true;
+    s.cur_h = h;
+    s.cur_w = w;
+    s.have_pair = true;
+    return EBVO_OK;
+}
+
+// Page-locks caller memory (a frame ring, say) so that uploads from it are asynchronous DMA and result copies into it need no
+// staging.  Thin wrappers: the host side of the boundary needs no HIP header.
+extern "C" int ebvo_host_register(ebvo_ctx *ctx, void *p, size_t bytes)
+{
+    if (!ctx || !p || !bytes)
+        return EBVO_ERR_ARG;
+    EBVO_HIP(ctx, hipSetDevice(ctx->device));
+    EBVO_HIP(ctx, hipHostRegister(p, bytes, hipHostRegisterDefault));
+    return EBVO_OK;
+}
+
+extern "C" int ebvo_host_unregister(ebvo_ctx *ctx, void *p)
+{
+    if (!ctx || !p)
+        return EBVO_ERR_ARG;
+    EBVO_HIP(ctx, hipSetDevice(ctx->device));
+    EBVO_HIP(ctx, hipHostUnregister(p));
     return EBVO_OK;
 }
 
@@ -1323,6 +1398,9 @@ extern "C" int ebvo_stereo_submit(ebvo_ctx *ctx, int slot, const ebvo_stereo_par
     }
     if (fetch_was_pending) // result copies of the previous pair (on the copy stream) still read the buffers
         EBVO_HIP(ctx, hipStreamWaitEvent(s.stream, s.ev_rebind, 0));
+    if (s.upload_pending) // the pair's images arrive on the upload stream (ebvo_stereo_upload_async)
+        EBVO_HIP(ctx, hipStreamWaitEvent(s.stream, s.ev_upload, 0));
+    s.upload_pending = false;
     struct Unbind // a submission that fails leaves the slot on its own stream
     {
         Slot &s;
@@ -3228,6 +3306,7 @@ extern "C" int ebvo_stereo_fetch_begin(ebvo_ctx *ctx, int slot, int what)
             EBVO_HIP(ctx, hipMemcpyAsync(base + s.fetch_off[k], src[k], sizes[k], hipMemcpyDeviceToHost, ctx->copy_stream));
     EBVO_HIP(ctx, hipEventRecord(s.ev_rebind, ctx->copy_stream));
     s.fetch_what = what;
+    s.fetch_compact = false;
     s.fetch_pending = true;
     return EBVO_OK;
 }
@@ -3238,7 +3317,7 @@ extern "C" int ebvo_stereo_fetch_end(ebvo_ctx *ctx, int slot, ebvo_stereo_view *
     if (!view || get_slot(ctx, slot, &sp))
         return EBVO_ERR_ARG;
     Slot &s = *sp;
-    if (!s.have_run || s.in_flight || !s.fetch_what)
+    if (!s.have_run || s.in_flight || !s.fetch_what || s.fetch_compact)
         return EBVO_ERR_STATE;
     EBVO_HIP(ctx, hipSetDevice(ctx->device));
     if (s.fetch_pending)
@@ -3266,6 +3345,175 @@ extern "C" int ebvo_stereo_fetch_end(ebvo_ctx *ctx, int slot, ebvo_stereo_view *
         view->best = reinterpret_cast<const double *>(base + s.fetch_off[5]);
     if (what & EBVO_FETCH_KEEP)
         view->keep = reinterpret_cast<const uint8_t *>(base + s.fetch_off[6]);
+    return EBVO_OK;
+}
+
+// ---- compact results: what a consumer of the NCC stage reads, in fewer bytes (round 4) -------------------------------------
+// The 32-byte ABI record of an edge carries its index (= its position in the list) and padding; (x, y) as 16 bytes and the
+// orientation as a separate array on demand halve the edge traffic, and the keep flag of a pair is one bit.  best stays fp64.
+namespace
+{
+__global__ __launch_bounds__(256) void pack_results_kernel(const ebvo_edge *__restrict__ L, int nL, const ebvo_edge *__restrict__ R,
+                                                           int nR, const uint8_t *__restrict__ keep, int64_t np,
+                                                           double2 *__restrict__ xyL, double2 *__restrict__ xyR,
+                                                           double *__restrict__ thL, double *__restrict__ thR,
+                                                           uint32_t *__restrict__ bits)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int64_t i = t0; i < nL; i += stride)
+    {
+        const ebvo_edge e = L[i];
+        xyL[i] = make_double2(e.x, e.y);
+        if (thL)
+            thL[i] = e.theta;
+    }
+    for (int64_t i = t0; i < nR; i += stride)
+    {
+        const ebvo_edge e = R[i];
+        xyR[i] = make_double2(e.x, e.y);
+        if (thR)
+            thR[i] = e.theta;
+    }
+    if (bits) // one 64-lane ballot = two words; every wave walks whole 64-pair groups (uniform trip count)
+    {
+        const int64_t groups = (np + 63) >> 6;
+        const int64_t wave = t0 >> 6, waves = stride >> 6;
+        const int lane = threadIdx.x & 63;
+        for (int64_t g = wave; g < groups; g += waves)
+        {
+            const int64_t k = (g << 6) + lane;
+            const unsigned long long m = __ballot(k < np && keep[k] != 0);
+            if (lane == 0)
+            {
+                bits[2 * g] = (uint32_t)m;
+                bits[2 * g + 1] = (uint32_t)(m >> 32);
+            }
+        }
+    }
+}
+} // namespace
+
+extern "C" int ebvo_stereo_fetch_compact_begin(ebvo_ctx *ctx, int slot, int what)
+{
+    Slot *sp;
+    if (get_slot(ctx, slot, &sp) || what <= 0 || (what & ~EBVO_COMPACT_ALL))
+        return EBVO_ERR_ARG;
+    Slot &s = *sp;
+    if (!s.have_run || s.in_flight)
+        return EBVO_ERR_STATE;
+    EBVO_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t nL = (size_t)s.result.n_left, nR = (size_t)s.result.n_right, np = (size_t)s.result.n_pairs;
+    const size_t nwords = 2 * ((np + 63) >> 6);
+    const bool xy = what & EBVO_COMPACT_XY, th = what & EBVO_COMPACT_THETA, kb = what & EBVO_COMPACT_KEEP_BITS;
+    const size_t sizes[8] = {xy ? 16 * nL : 0, xy ? 16 * nR : 0, th ? 8 * nL : 0, th ? 8 * nR : 0,
+                             (what & EBVO_COMPACT_CSR) ? sizeof(int32_t) * (nL + 1) : 0,
+                             (what & EBVO_COMPACT_CSR) ? sizeof(int32_t) * np : 0,
+                             (what & EBVO_COMPACT_BEST) ? sizeof(double) * np : 0, kb ? sizeof(uint32_t) * nwords : 0};
+    size_t total = 0;
+    for (int k = 0; k < 8; ++k)
+    {
+        s.fetch_off[k] = total;
+        total += (sizes[k] + 63) & ~(size_t)63;
+    }
+    if (total > s.h_arena_bytes)
+    {
+        if (s.fetch_pending)
+            EBVO_HIP(ctx, hipEventSynchronize(s.ev_rebind));
+        if (s.h_arena)
+            (void)hipHostFree(s.h_arena);
+        s.h_arena = nullptr;
+        s.h_arena_bytes = 0;
+        const size_t want = total + total / 4 + 4096;
+        if (hipHostMalloc(&s.h_arena, want) != hipSuccess)
+        {
+            (void)hipGetLastError();
+            ctx->last_error = "hipHostMalloc failed (page-locked result staging)";
+            return EBVO_ERR_NOMEM;
+        }
+        s.h_arena_bytes = want;
+    }
+    if (!ctx->copy_stream)
+        EBVO_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    // device staging of the packed arrays, laid out like the first four and the last array of the arena
+    size_t poff[5], ptotal = 0;
+    const size_t psizes[5] = {sizes[0], sizes[1], sizes[2], sizes[3], sizes[7]};
+    for (int k = 0; k < 5; ++k)
+    {
+        poff[k] = ptotal;
+        ptotal += (psizes[k] + 63) & ~(size_t)63;
+    }
+    if (ptotal > s.fetch_pack.bytes && s.fetch_pending) // (re)allocation: the previous copies out of the old buffer must be over
+        EBVO_HIP(ctx, hipEventSynchronize(s.ev_rebind));
+    int rc;
+    if (ptotal && (rc = ebvo_grow(ctx, s, s.fetch_pack, ptotal)))
+        return rc;
+    char *pk = static_cast<char *>(s.fetch_pack.p);
+    if (xy || th || kb)
+    {
+        const size_t work = nL > nR ? nL : nR;
+        const size_t most = work > ((np + 63) >> 6) * 64 ? work : ((np + 63) >> 6) * 64;
+        int blocks = (int)((most + 255) / 256);
+        blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+        // the pair is complete (the host has waited for it) and the copy stream orders the kernel behind the previous copies
+        // out of the staging buffer
+        hipLaunchKernelGGL(pack_results_kernel, dim3(blocks), dim3(256), 0, ctx->copy_stream, (const ebvo_edge *)s.im[0].edges,
+                           xy || th ? (int)nL : 0, (const ebvo_edge *)s.im[1].edges, xy || th ? (int)nR : 0,
+                           (const uint8_t *)s.keep.p, kb ? (int64_t)np : 0, (double2 *)(pk + poff[0]), (double2 *)(pk + poff[1]),
+                           th ? (double *)(pk + poff[2]) : nullptr, th ? (double *)(pk + poff[3]) : nullptr,
+                           kb ? (uint32_t *)(pk + poff[4]) : nullptr);
+        EBVO_HIP(ctx, hipGetLastError());
+    }
+    const void *src[8] = {pk + poff[0], pk + poff[1], pk + poff[2], pk + poff[3], s.row_ptr.p, s.col_idx.p, s.best.p, pk + poff[4]};
+    char *base = static_cast<char *>(s.h_arena);
+    for (int k = 0; k < 8; ++k)
+        if (sizes[k])
+            EBVO_HIP(ctx, hipMemcpyAsync(base + s.fetch_off[k], src[k], sizes[k], hipMemcpyDeviceToHost, ctx->copy_stream));
+    EBVO_HIP(ctx, hipEventRecord(s.ev_rebind, ctx->copy_stream));
+    s.fetch_what = what;
+    s.fetch_compact = true;
+    s.fetch_pending = true;
+    return EBVO_OK;
+}
+
+extern "C" int ebvo_stereo_fetch_compact_end(ebvo_ctx *ctx, int slot, ebvo_stereo_compact_view *view)
+{
+    Slot *sp;
+    if (!view || get_slot(ctx, slot, &sp))
+        return EBVO_ERR_ARG;
+    Slot &s = *sp;
+    if (!s.have_run || s.in_flight || !s.fetch_what || !s.fetch_compact)
+        return EBVO_ERR_STATE;
+    EBVO_HIP(ctx, hipSetDevice(ctx->device));
+    if (s.fetch_pending)
+        EBVO_HIP(ctx, hipEventSynchronize(s.ev_rebind));
+    s.fetch_pending = false;
+    const char *base = static_cast<const char *>(s.h_arena);
+    const int what = s.fetch_what;
+    memset(view, 0, sizeof *view);
+    view->n_left = s.result.n_left;
+    view->n_right = s.result.n_right;
+    view->n_pairs = s.result.n_pairs;
+    view->n_matches = s.result.n_matches;
+    if (what & EBVO_COMPACT_XY)
+    {
+        view->left_xy = reinterpret_cast<const double *>(base + s.fetch_off[0]);
+        view->right_xy = reinterpret_cast<const double *>(base + s.fetch_off[1]);
+    }
+    if (what & EBVO_COMPACT_THETA)
+    {
+        view->left_theta = reinterpret_cast<const double *>(base + s.fetch_off[2]);
+        view->right_theta = reinterpret_cast<const double *>(base + s.fetch_off[3]);
+    }
+    if (what & EBVO_COMPACT_CSR)
+    {
+        view->row_ptr = reinterpret_cast<const int32_t *>(base + s.fetch_off[4]);
+        view->col_idx = reinterpret_cast<const int32_t *>(base + s.fetch_off[5]);
+    }
+    if (what & EBVO_COMPACT_BEST)
+        view->best = reinterpret_cast<const double *>(base + s.fetch_off[6]);
+    if (what & EBVO_COMPACT_KEEP_BITS)
+        view->keep_bits = reinterpret_cast<const uint32_t *>(base + s.fetch_off[7]);
     return EBVO_OK;
 }
 

@@ -130,6 +130,8 @@ struct Slot
     hipStream_t own_stream = nullptr; // created with the slot
     hipEvent_t ev_done = nullptr;     // recorded behind the last kernel of a submitted pair
     hipEvent_t ev_rebind = nullptr;   // orders a slot's earlier work before its first work on another lane
+    hipEvent_t ev_upload = nullptr;   // end of the slot's asynchronous image upload (ebvo_stereo_upload_async, the context's upload stream)
+    bool upload_pending = false;      // ... recorded and not yet waited for by a submission or a host call
     ImageWS im[2];
     int cur_h = 0, cur_w = 0;
     bool have_pair = false, have_run = false, in_flight = false, have_refined = false;
@@ -182,7 +184,9 @@ struct Slot
     size_t h_arena_bytes = 0;
     int fetch_what = 0;                  // arrays in flight to / present in h_arena
     bool fetch_pending = false;          // copies enqueued, not yet waited for
-    size_t fetch_off[7] = {0};           // left, right, row_ptr, col_idx, sims, best, keep
+    size_t fetch_off[8] = {0};           // left, right, row_ptr, col_idx, sims, best, keep (compact: xyL, xyR, thL, thR, row_ptr, col_idx, best, keep bits)
+    bool fetch_compact = false;          // the arena holds the arrays of ebvo_stereo_fetch_compact_begin
+    GrowBuf fetch_pack;                  // device staging of the compact fetch: (x, y) pairs, orientations, keep bits
     ebvo_stereo_params params{};
     PairResult result{};                 // last completed result
 
@@ -224,6 +228,7 @@ struct ebvo_ctx
     uint64_t submit_seq = 0;
     std::vector<hipStream_t> lane_streams; // created on first use, owned by the context
     hipStream_t copy_stream = nullptr;     // result copies of ebvo_stereo_fetch_begin (all slots), created on first use
+    hipStream_t upload_stream = nullptr;   // image uploads of ebvo_stereo_upload_async (all slots), created on first use
     // resident stage-wise path (ebvo_toed_resident / ebvo_epi_candidates_resident / ebvo_ncc_pairs_resident): the TOED results
     // of the last two images stay in slot 0's image workspaces; tag 0 = that workspace holds nothing a caller may refer to
     uint64_t sw_seq = 0;

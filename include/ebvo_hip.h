@@ -34,7 +34,7 @@ extern "C" {
 #define EBVO_ABI_VERSION 6 /* 2: photometric refinement, stage glue, finalisation, resident chain; 3: pinned result views,
                               undistortion, SIFT descriptors, SIFT stages of the chain; 4: the temporal chain after the
                               NCC filter (ebvo_temporal_params / _counts grew, ebvo_temporal_fetch_final); 5: the resident
-                              stage-wise calls (ebvo_toed_resident, ebvo_epi_candidates_resident, ebvo_ncc_pairs_resident); 6: ebvo_toed_screen_audit */
+                              stage-wise calls (ebvo_toed_resident, ebvo_epi_candidates_resident, ebvo_ncc_pairs_resident); 6: ebvo_toed_screen_audit, ebvo_stereo_upload_async, ebvo_host_register, ebvo_stereo_fetch_compact_begin / _end */
 
 typedef struct ebvo_ctx ebvo_ctx;
 
@@ -594,6 +594,17 @@ int ebvo_stereo_fetch(ebvo_ctx *ctx, ebvo_edge *left, ebvo_edge *right, int32_t 
 int ebvo_stereo_set_slots(ebvo_ctx *ctx, int n_slots);
 int ebvo_stereo_upload_slot(ebvo_ctx *ctx, int slot, const uint8_t *img_left, const uint8_t *img_right, int h, int w,
                             ptrdiff_t stride_left, ptrdiff_t stride_right);
+/* The same upload without blocking the caller (round 4): the copies run on the context's upload stream and the slot's next
+ * ebvo_stereo_submit waits for them ON THE DEVICE.  Meant to be called a frame ahead of the submission (a frame loop reads
+ * frame k + 1 while frame k is matched: src/Pipeline.cpp:77-99, cmd/main_VO.cpp:99-113), so that the wait is already satisfied.
+ * Truly asynchronous only when both images lie in page-locked memory (ebvo_host_register on the caller's frame ring, or
+ * hipHostMalloc); the images must then stay unchanged until the pair's ebvo_stereo_wait has returned.  From pageable memory
+ * the call behaves like ebvo_stereo_upload_slot. */
+int ebvo_stereo_upload_async(ebvo_ctx *ctx, int slot, const uint8_t *img_left, const uint8_t *img_right, int h, int w,
+                             ptrdiff_t stride_left, ptrdiff_t stride_right);
+/* page-lock / release caller memory (hipHostRegister / hipHostUnregister): no HIP header needed on the host side */
+int ebvo_host_register(ebvo_ctx *ctx, void *p, size_t bytes);
+int ebvo_host_unregister(ebvo_ctx *ctx, void *p);
 int ebvo_stereo_submit(ebvo_ctx *ctx, int slot, const ebvo_stereo_params *p);
 int ebvo_stereo_wait(ebvo_ctx *ctx, int slot, ebvo_stereo_counts *counts);
 int ebvo_stereo_fetch_slot(ebvo_ctx *ctx, int slot, ebvo_edge *left, ebvo_edge *right, int32_t *row_ptr,
@@ -628,6 +639,34 @@ typedef struct ebvo_stereo_view
 } ebvo_stereo_view; /* pointers of arrays that were not selected are NULL */
 int ebvo_stereo_fetch_begin(ebvo_ctx *ctx, int slot, int what);
 int ebvo_stereo_fetch_end(ebvo_ctx *ctx, int slot, ebvo_stereo_view *view);
+
+/* The same results in fewer bytes (round 4): (x, y) of every edge as 16 bytes (an edge's index is its position in the list),
+ * the orientations as separate arrays on demand, the keep flag of pair k as bit k & 31 of word k >> 5; best stays fp64.
+ * 11.6 MB instead of 16.2 MB per KITTI pair for the default selection.  Same protocol as ebvo_stereo_fetch_begin / _end (the two
+ * share the slot's page-locked arena: one selection at a time). */
+enum
+{
+    EBVO_COMPACT_XY = 1,
+    EBVO_COMPACT_THETA = 2,
+    EBVO_COMPACT_CSR = 4,
+    EBVO_COMPACT_BEST = 8,
+    EBVO_COMPACT_KEEP_BITS = 16,
+    EBVO_COMPACT_DEFAULT = 1 | 4 | 8 | 16,
+    EBVO_COMPACT_ALL = 31
+};
+typedef struct ebvo_stereo_compact_view
+{
+    const double *left_xy, *right_xy;       /* n_left x 2, n_right x 2 */
+    const double *left_theta, *right_theta; /* n_left, n_right */
+    const int32_t *row_ptr;                 /* n_left + 1 */
+    const int32_t *col_idx;                 /* n_pairs */
+    const double *best;                     /* n_pairs */
+    const uint32_t *keep_bits;              /* 2 * ceil(n_pairs / 64) words */
+    int32_t n_left, n_right;
+    int64_t n_pairs, n_matches;
+} ebvo_stereo_compact_view; /* pointers of arrays that were not selected are NULL */
+int ebvo_stereo_fetch_compact_begin(ebvo_ctx *ctx, int slot, int what);
+int ebvo_stereo_fetch_compact_end(ebvo_ctx *ctx, int slot, ebvo_stereo_compact_view *view);
 
 /* Per-kernel device timing (HIP events on the slots' streams, accumulated). */
 #define EBVO_MAX_KERNELS 24 /* >= the number of kernel ids (ebvo_internal.h) */

@@ -40,6 +40,50 @@ def test_bench_gpus_2_starts_two_ranks_by_itself():
     assert r["sequences"][0] != r["sequences"][1]            # one sequence per rank
 
 
+def test_four_ranks_are_pinned_to_disjoint_cores():
+    """configs[4] readiness: every rank of `bench.py --gpus N` runs on its own cores (sharding.pin_rank), thread pools capped"""
+    avail = sorted(os.sched_getaffinity(0))
+    if len(avail) < 4:
+        pytest.skip("fewer than four cores")
+    out = subprocess.run([sys.executable, BENCH, "--gpus", "4", "--selftest-launch", "--dist-backend", "gloo", "--steps", "4"],
+                         env=_clean_env(), capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = _json_lines(out.stdout)[0]
+    assert r["n_gpus"] == 4 and r["pinned"] is True
+    sets = [set(c) for c in r["rank_cpus"]]
+    assert len(sets) == 4 and all(sets)
+    for a in range(4):
+        assert sets[a] <= set(avail)
+        for b in range(a + 1, 4):
+            assert not (sets[a] & sets[b]), (a, b, sets)
+    assert len({len(x) for x in sets}) == 1                  # equal shares
+    assert int(r["omp_num_threads"]) == len(sets[0])         # the rank's thread pools are capped to its share
+
+
+def test_rank_cpu_sets_follow_the_gpus_numa_nodes(tmp_path):
+    """a node with two NUMA domains, four GPUs each: ranks 0-3 share node 0's cores, ranks 4-7 node 1's, all disjoint"""
+    sysfs = tmp_path
+    for d in range(8):
+        p = sysfs / "class" / "drm" / f"renderD{128 + d}" / "device"
+        p.mkdir(parents=True)
+        (p / "numa_node").write_text(f"{d // 4}\n")
+    for n, cpulist in ((0, "0-15,32-47"), (1, "16-31,48-63")):
+        p = sysfs / "devices" / "system" / "node" / f"node{n}"
+        p.mkdir(parents=True)
+        (p / "cpulist").write_text(cpulist + "\n")
+    sets = sharding.rank_cpu_sets(8, 8, available=range(64), sysfs=str(sysfs))
+    node0 = set(range(0, 16)) | set(range(32, 48))
+    assert all(len(s) == 8 for s in sets)
+    assert all(set(sets[r]) <= node0 for r in range(4)) and all(not (set(sets[r]) & node0) for r in range(4, 8))
+    assert len(set().union(*map(set, sets))) == 64           # disjoint and complete
+    # a cgroup that leaves 16 cores: shares shrink, still disjoint, still on the right node
+    sets = sharding.rank_cpu_sets(8, 8, available=list(range(0, 8)) + list(range(16, 24)), sysfs=str(sysfs))
+    assert [len(s) for s in sets] == [2] * 8 and set(sets[5]) <= set(range(16, 24))
+    # no NUMA information (this container): equal contiguous shares of what is available; more ranks than cores: not pinned
+    assert sharding.rank_cpu_sets(2, 1, available=range(8), sysfs=str(tmp_path / "none")) == [[0, 1, 2, 3], [4, 5, 6, 7]]
+    assert sharding.rank_cpu_sets(4, 4, available=range(2), sysfs=str(tmp_path / "none")) == [None] * 4
+
+
 def test_bench_under_an_external_launcher_uses_its_ranks():
     """what the driver does: torch.distributed.run sets RANK / WORLD_SIZE; bench.py must not launch again"""
     env = _clean_env()

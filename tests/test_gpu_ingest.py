@@ -1,0 +1,140 @@
+"""Sequence-realistic ingest (round 4): ebvo_stereo_upload_async from a page-locked frame ring, issued a pair ahead of its
+submission, and the compact result fetch.  Both must hand back exactly what the synchronous upload and the full fetch do
+(the frame loop of cmd/main_VO.cpp:99-113 / src/Pipeline.cpp:77-99 around the same per-pair path)."""
+import numpy as np
+import pytest
+
+from edge_based_visual_odometry_amd import _lib, synth
+from edge_based_visual_odometry_amd.api import Context
+from tests.util import assert_bit_equal, assert_edges_equal
+
+pytestmark = pytest.mark.gpu
+
+H, W = 200, 320
+F = synth.fundamental_for("kitti")
+
+
+@pytest.fixture(scope="module", params=["strict", "hybrid"])
+def c(request):
+    ctx = Context(H, W, device=0, toed_mode=request.param)
+    ctx.set_slots(4)
+    yield ctx
+    ctx.close()
+
+
+def _ring(n):
+    return [tuple(np.ascontiguousarray(im) for im in synth.stereo_pair("s2", H, W, scene=3 + k, noise_base=20 * k, disparity=10))
+            for k in range(n)]
+
+
+def _reference(c, ring):
+    """every pair of the ring through the synchronous upload and the full fetch on slot 0"""
+    p = c.default_params(F)
+    ref = []
+    for l, r in ring:
+        c.stereo_upload(l, r, slot=0)
+        c.stereo_submit(p, slot=0)
+        cnt = c.stereo_wait(slot=0)
+        ref.append((cnt, c.stereo_fetch(cnt, slot=0)))
+    return ref
+
+
+def _same(out, ref):
+    cnt, full = ref
+    assert_edges_equal(out["left"], full["left"])
+    assert_edges_equal(out["right"], full["right"])
+    assert_bit_equal(out["row_ptr"], full["row_ptr"], "row_ptr")
+    assert_bit_equal(out["col_idx"], full["col_idx"], "col_idx")
+    assert_bit_equal(out["sims"], full["sims"], "sims")
+    assert_bit_equal(out["keep"], full["keep"], "keep")
+
+
+@pytest.mark.parametrize("registered", [True, False])
+def test_async_upload_a_pair_ahead_equals_synchronous_upload(c, registered):
+    ring = _ring(5)
+    ref = _reference(c, ring)
+    if registered:
+        for pair in ring:
+            for im in pair:
+                c.host_register(im)
+    try:
+        p = c.default_params(F)
+        S, inflight, steps = 4, 3, 14
+        # three pairs in flight on four slots; the images of step i + 1 go up while step i runs
+        for k in range(inflight):
+            c.stereo_upload_async(*ring[k % 5], slot=k)
+            c.stereo_submit(p, slot=k)
+        uploaded, ahead = inflight, inflight % S
+        c.stereo_upload_async(*ring[uploaded % 5], slot=ahead)
+        uploaded += 1
+        for done in range(steps):
+            k = done % S
+            cnt = c.stereo_wait(slot=k)
+            if ahead is not None:
+                c.stereo_submit(p, slot=ahead)
+                ahead = None
+            out = c.stereo_fetch(cnt, slot=k)
+            _same(out, ref[done % 5])
+            assert (cnt.n_pairs, cnt.n_matches) == (ref[done % 5][0].n_pairs, ref[done % 5][0].n_matches)
+            if uploaded < steps:
+                c.stereo_upload_async(*ring[uploaded % 5], slot=k)
+                uploaded += 1
+                ahead = k
+    finally:
+        if registered:
+            for pair in ring:
+                for im in pair:
+                    c.host_unregister(im)
+
+
+def test_async_upload_then_host_buffer_call_on_slot_0_is_ordered(c):
+    """a host-buffer entry point (slot 0's workspace) right behind an asynchronous upload into slot 0: the library drains the
+    upload before it overwrites the image buffers"""
+    ring = _ring(2)
+    c.stereo_upload_async(*ring[0], slot=0)
+    e = c.toed(ring[1][0]).edges                      # uploads ring[1][0] into slot 0's first image buffer
+    c.stereo_upload(*ring[1], slot=0)
+    cnt = c.stereo_run(c.default_params(F))
+    out = c.stereo_fetch(cnt)
+    assert_edges_equal(out["left"], e)
+
+
+def test_compact_fetch_equals_full_fetch(c):
+    ring = _ring(2)
+    ref = _reference(c, ring)
+    p = c.default_params(F)
+    for what in (_lib.COMPACT_DEFAULT, _lib.COMPACT_ALL, _lib.COMPACT_KEEP_BITS, _lib.COMPACT_XY | _lib.COMPACT_THETA):
+        for k, (l, r) in enumerate(ring):
+            c.stereo_upload(l, r, slot=1)
+            c.stereo_submit(p, slot=1)
+            cnt = c.stereo_wait(slot=1)
+            c.stereo_fetch_compact_begin(slot=1, what=what)
+            with pytest.raises(_lib.EbvoError):        # the arena holds the compact selection: the full view is refused
+                c.stereo_fetch_end(slot=1)
+            v = c.stereo_fetch_compact_end(slot=1)
+            full = ref[k][1]
+            assert v["n_pairs"] == cnt.n_pairs and v["n_matches"] == cnt.n_matches == int(full["keep"].sum())
+            if what & _lib.COMPACT_XY:
+                for side in ("left", "right"):
+                    assert_bit_equal(v[side + "_xy"][:, 0], full[side]["x"], side + ".x")
+                    assert_bit_equal(v[side + "_xy"][:, 1], full[side]["y"], side + ".y")
+            else:
+                assert v["left_xy"] is None
+            if what & _lib.COMPACT_THETA:
+                assert_bit_equal(v["left_theta"], full["left"]["theta"], "left.theta")
+                assert_bit_equal(v["right_theta"], full["right"]["theta"], "right.theta")
+            else:
+                assert v["left_theta"] is None
+            if what & _lib.COMPACT_CSR:
+                assert_bit_equal(v["row_ptr"], full["row_ptr"], "row_ptr")
+                assert_bit_equal(v["col_idx"], full["col_idx"], "col_idx")
+            if what & _lib.COMPACT_BEST:
+                assert_bit_equal(v["best"], full["best"], "best")
+            if what & _lib.COMPACT_KEEP_BITS:
+                bits = np.unpackbits(v["keep_bits"].view(np.uint8), bitorder="little")[: cnt.n_pairs]
+                assert_bit_equal(bits, full["keep"], "keep bits")
+                assert int(v["keep_bits"].view(np.uint8)[(cnt.n_pairs + 7) // 8:].sum()) == 0     # padding bits are clear
+    # the full fetch still works on the same slot afterwards
+    c.stereo_fetch_begin(slot=1)
+    out = c.stereo_fetch_end(slot=1)
+    assert_bit_equal(out["keep"], ref[1][1]["keep"], "keep")

@@ -2,7 +2,7 @@
 # Run ON the GPU box: samples the shader clock and the power while the resident pair loop runs (25,000 pairs, ~8 s).
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd "$ROOT"
-python3 bench.py --steps 25000 --warmup 5 --no-cpu-baseline --no-transfer-legs --no-verify > gpurun_out/clock_bench.json 2> gpurun_out/clock_bench.err &
+python3 bench.py --steps 25000 --warmup 5 --no-cpu-baseline --no-transfer-legs --no-ingest --no-verify > gpurun_out/clock_bench.json 2> gpurun_out/clock_bench.err &
 BP=$!
 sleep 2.5   # import + warm-up
 for i in 1 2 3 4 5 6 7 8 9 10 11 12; do

@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-COMMON="--no-cpu-baseline --no-verify --no-transfer-legs --toed-mode hybrid --streams 1"
+COMMON="--no-cpu-baseline --no-verify --no-transfer-legs --no-ingest --toed-mode hybrid --streams 1"
 for pass in "trace_hybrid 40 --kernel-trace --stats" "pmc_fetch_hybrid 8 --kernel-trace --pmc FETCH_SIZE" "pmc_write_hybrid 8 --kernel-trace --pmc WRITE_SIZE"; do
     set -- $pass
     name=$1; steps=$2; shift 2

@@ -13,9 +13,9 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-# --no-transfer-legs: the trace covers the resident loop only (the boundary leg would start g++ and a GPU child under the
+# --no-transfer-legs --no-ingest: the trace covers the resident loop only (the boundary leg would start g++ and a GPU child under the
 # profiler's preload)
-COMMON="--no-cpu-baseline --no-verify --no-transfer-legs --toed-mode $MODE --streams 1 $*"
+COMMON="--no-cpu-baseline --no-verify --no-transfer-legs --no-ingest --toed-mode $MODE --streams 1 $*"
 FAILED=0
 pass() { # name, bench steps, rocprofv3 options ...
     local name=$1 steps=$2
