@@ -394,15 +394,15 @@ def ingest_loop(ctx, params, ring, nslots, steps, fetch=None):
         k = done % S
         ctx.stereo_wait(slot=k)
         done += 1
+        if fetch:
+            begin(k)                               # k's results start travelling; read at the next turn
+            if pending is not None:
+                consume(pending)                   # ... before `pending` (= ahead) is submitted again
+            pending = k
         if ahead is not None:                      # its upload was enqueued a whole pair earlier
             ctx.stereo_submit(params, slot=ahead)
             submitted += 1
             ahead = None
-        if fetch:
-            begin(k)
-            if pending is not None:
-                consume(pending)
-            pending = k
         if uploaded < steps:                       # the images the slot will be submitted with at the next turn
             ahead = k
             upload(k)
@@ -747,6 +747,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the result check after the timed region (profiling runs)")
     ap.add_argument("--no-transfer-legs", action="store_true", help="skip the with_h2d / with_h2d_d2h loops")
+    ap.add_argument("--store-sims", action="store_true",
+                    help="the timed pipeline also stores the four similarities of every pair (32 of the 41 bytes the NCC stage writes "
+                         "per pair; round 3's behaviour).  Default: final score + keep flag only, as the reference keeps them")
     ap.add_argument("--no-ingest", action="store_true", help="skip value_with_h2d (the timed loop fed from a page-locked frame ring)")
     ap.add_argument("--toed-mode", default="hybrid", choices=["strict", "hybrid"],
                     help="strict: direct-form convolution at every pixel; hybrid: separable screen + exact "
@@ -829,7 +832,14 @@ def main():
     nslots = max(1, args.streams)
     ctx = Context(H, W, device=device, toed_mode=args.toed_mode)
     ctx.set_slots(nslots)
+    # the timed pipeline keeps, per candidate pair, what the reference keeps: the final score (max of the four similarities,
+    # refine_final_scores, src/Stereo_Matches.cpp:596-600) and the keep flag -- EBVO_PAIR_NO_SIMS; the four similarities are
+    # computed either way and are checked after the timed region on a pair submitted with them stored (--store-sims: always)
+    params_full = ctx.default_params(F)
     params = ctx.default_params(F)
+    if not args.store_sims:
+        from edge_based_visual_odometry_amd import _lib as L__
+        params.reserved = L__.PAIR_NO_SIMS
     for k in range(nslots):
         ctx.stereo_upload(left, right, slot=k)
     # warm-up: --warmup pairs per slot, and at least MIN_WARM_PAIRS pairs in all (~0.2 s), through the same pipelined submit /
@@ -894,6 +904,13 @@ def main():
     graph_pairs = ctx.graph_launches - graphs_before   # timed pairs whose ~31 launches went out as one hipGraphLaunch
     # the sustained rate: 300 pairs more, rank-local, straight after the timed region (the same loop)
     t_sus, _ = run_pairs(300)
+    t_sus_full = None
+    if not args.store_sims:                          # ... and with the four similarities stored (round 3's pipeline), for comparison
+        saved, params = params, params_full
+        run_pairs(4 * nslots)                        # (a new flag is a new graph: three submissions per slot)
+        t_sus_full, _ = run_pairs(300)
+        params = saved
+        run_pairs(4 * nslots)
     per_rank = sharding.gather_over_ranks(args.steps / dt, dist, reduce_device)
     dt = sharding.max_over_ranks(dt, dist, reduce_device)
     rank_cpu_counts = [len(c) for c in sharding.gather_int_lists(sorted(os.sched_getaffinity(0)), 1024, dist, reduce_device)]
@@ -904,6 +921,11 @@ def main():
     if not args.no_verify:
         if len(seen) != 1:
             problems.append(f"counts changed between steps of the timed region: {sorted(seen)}")
+        if not args.store_sims:                     # the same pair once more with all four similarities stored
+            ctx.stereo_submit(params_full, slot=last_slot)
+            seen.add(tup(ctx.stereo_wait(slot=last_slot)))
+            if len(seen) != 1:
+                problems.append(f"counts differ between the timed pairs and the pair submitted with the similarities stored: {sorted(seen)}")
         out = ctx.stereo_fetch(counts, slot=last_slot)
         if int(out["keep"].sum()) != counts.n_matches or len(out["col_idx"]) != counts.n_pairs:
             problems.append("fetched arrays disagree with the counts of the run")
@@ -978,11 +1000,11 @@ def main():
                                   disparity=seq["disparity"]) for k in range(4)]
         from edge_based_visual_odometry_amd import _lib as L_
         n_leg = max(nslots, min(args.steps, 60))
-        frame_loop(ctx, params, pool, nslots, nslots, True, L_.FETCH_ALL)     # untimed: touches the pool, sizes the page-locked staging of every slot
+        frame_loop(ctx, params_full, pool, nslots, nslots, True, L_.FETCH_ALL)     # untimed: touches the pool, sizes the page-locked staging of every slot
         t_up, _ = frame_loop(ctx, params, pool, nslots, n_leg, True, None)
         t_def, mb_def = frame_loop(ctx, params, pool, nslots, n_leg, True, L_.FETCH_DEFAULT)
-        t_all, mb_all = frame_loop(ctx, params, pool, nslots, n_leg, True, L_.FETCH_ALL)
-        t_pg, mb_pg = frame_loop(ctx, params, pool, nslots, max(nslots, n_leg // 3), True, "pageable")
+        t_all, mb_all = frame_loop(ctx, params_full, pool, nslots, n_leg, True, L_.FETCH_ALL)
+        t_pg, mb_pg = frame_loop(ctx, params_full, pool, nslots, max(nslots, n_leg // 3), True, "pageable")
         # the one-pass drop-in: get_Stereo_Edge_Pairs as a frame loop calls it through StereoMatcherHIP::stereo_edge_pairs
         cal = synth.CALIB[wl["cfg"]]
         calib = ([cal["K"][0], 0, cal["K"][2], 0, cal["K"][1], cal["K"][3], 0, 0, 1],
@@ -1093,6 +1115,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "warmup_pairs_run": max(n_warm, n_short + args.steps), "warmup_overridden": n_warm > n_short,
             "value_short_warmup": args.steps / t_short, "value_sustained_300": 300 / t_sus,
+            "value_sustained_300_sims_stored": None if t_sus_full is None else 300 / t_sus_full,
             "warmup_note": f"value: {args.steps} pairs timed after {max(n_warm, n_short + args.steps)} untimed ones (the device clocks follow "
                            f"the load with a delay); value_short_warmup: the same {args.steps} pairs timed after --warmup x slots = "
                            f"{n_short} pairs only (this rank, no barrier); value_sustained_300: 300 pairs straight after the timed region",
@@ -1107,6 +1130,7 @@ def main():
                        "edges_left": counts.n_left, "edges_right": counts.n_right,
                        "toed_candidates": n_cand if args.toed_mode == "hybrid" else None,
                        "candidate_pairs": counts.n_pairs, "ncc_matches": counts.n_matches,
+                       "sims_stored": bool(args.store_sims),
                        "pairs_in_flight_per_gpu": nslots,
                        "streams_per_gpu": nslots if nslots < 4 else min(4, nslots - 1),
                        "pairs_submitted_as_hipgraph": graph_pairs, "toed_strict_fallbacks": ctx.toed_fallbacks,

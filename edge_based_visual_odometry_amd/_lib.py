@@ -56,6 +56,9 @@ class StereoParams(C.Structure):
                 ("reserved", C.c_int)]
 
 
+PAIR_NO_SIMS = 1     # StereoParams.reserved: the resident pipeline stores best + keep only (ebvo_hip.h EBVO_PAIR_NO_SIMS)
+
+
 class StereoCalib(C.Structure):
     _fields_ = [("K_left", C.c_double * 9), ("K_right", C.c_double * 9), ("R21", C.c_double * 9), ("T21", C.c_double * 3)]
 

@@ -190,6 +190,8 @@ static void slot_destroy(Slot *s)
         (void)hipEventDestroy(s->ev_rebind);
     if (s->ev_upload)
         (void)hipEventDestroy(s->ev_upload);
+    if (s->h_mail)
+        (void)hipHostFree(s->h_mail);
     (void)hipFree(s->d_fin_tot);
     if (s->h_fin_tot)
         (void)hipHostFree(s->h_fin_tot);
@@ -217,6 +219,15 @@ static int drain_fetch(ebvo_ctx *ctx, Slot &s)
     return EBVO_OK;
 }
 
+// an earlier stream-form upload of the slot must have landed before the mailbox names other images (host wait; rare)
+static int drain_fetch_uploads_only(ebvo_ctx *ctx, Slot &s)
+{
+    if (s.upload_pending)
+        EBVO_HIP(ctx, hipEventSynchronize(s.ev_upload));
+    s.upload_pending = false;
+    return EBVO_OK;
+}
+
 static int slot_create(ebvo_ctx *ctx, Slot **out)
 {
     Slot *s = new (std::nothrow) Slot();
@@ -238,6 +249,9 @@ static int slot_create(ebvo_ctx *ctx, Slot **out)
     CK(hipEventCreateWithFlags(&s->ev_done, hipEventDisableTiming));
     CK(hipEventCreateWithFlags(&s->ev_rebind, hipEventDisableTiming));
     CK(hipEventCreateWithFlags(&s->ev_upload, hipEventDisableTiming));
+    CK(hipHostMalloc(reinterpret_cast<void **>(&s->h_mail), sizeof(Slot::PullMail)));
+    memset(s->h_mail, 0, sizeof(Slot::PullMail));
+    CK(hipHostGetDevicePointer(reinterpret_cast<void **>(&s->d_mail), s->h_mail, 0));
     const size_t H2 = 2 * (size_t)ctx->max_h, W2 = 2 * (size_t)ctx->max_w, np2 = H2 * W2;
     for (int k = 0; k < 2; ++k)
     {
@@ -1128,6 +1142,8 @@ extern "C" int ebvo_stereo_upload_slot(ebvo_ctx *ctx, int slot, const uint8_t *i
     s.fetch_pending = false;
     s.fetch_what = 0;
     s.undist_pair = ctx->undist_on; // the pair goes to the raw buffers; submit undistorts it into img
+    s.toed_strict_override = false;
+    s.pull = false;
     if ((rc = upload_image(ctx, s, 0, img_left, h, w, stride_left, s.undist_pair)))
         return rc;
     if ((rc = upload_image(ctx, s, 1, img_right, h, w, stride_right, s.undist_pair)))
@@ -1157,20 +1173,67 @@ extern "C" int ebvo_stereo_upload_async(ebvo_ctx *ctx, int slot, const uint8_t *
     Slot &s = *sp;
     if (s.in_flight || s.fin_in_flight || s.tq_in_flight)
         return EBVO_ERR_STATE;
-    if (!ctx->upload_stream)
-        EBVO_HIP(ctx, hipStreamCreateWithFlags(&ctx->upload_stream, hipStreamNonBlocking));
     s.have_pair = s.have_run = s.have_refined = s.have_final = false;
     if (slot == 0)
         ctx->sw_tag[0] = ctx->sw_tag[1] = 0;
     s.tq_n = -1;
     s.tq_final.n = -1;
     s.sift_left_valid = false;
+    s.pull = false;
+    if (stride_left < w || stride_right < w)
+        return EBVO_ERR_ARG;
+    if (!ctx->ingest_stream)
+    {
+        // pull form: both images entirely in page-locked memory the device can address?  Then the pair's own chain reads them
+        // (its first kernel; the pointers go through the slot's mailbox) -- no copy engine, no second stream, no event: nothing
+        // that could queue behind another pair's kernels.  The call costs two attribute queries.
+        const uint8_t *imgs[2] = {img_left, img_right};
+        const ptrdiff_t strides[2] = {stride_left, stride_right};
+        const uint8_t *dev[2] = {nullptr, nullptr};
+        bool pinned = true;
+        for (int k = 0; k < 2 && pinned; ++k)
+        {
+            const uint8_t *ends[2] = {imgs[k], imgs[k] + (size_t)(h - 1) * strides[k] + (w - 1)};
+            for (int q = 0; q < 2 && pinned; ++q)
+            {
+                hipPointerAttribute_t a;
+                memset(&a, 0, sizeof a);
+                if (hipPointerGetAttributes(&a, ends[q]) != hipSuccess || a.type != hipMemoryTypeHost || !a.devicePointer)
+                {
+                    (void)hipGetLastError();
+                    pinned = false;
+                }
+                else if (q == 0)
+                    dev[k] = static_cast<const uint8_t *>(a.devicePointer);
+            }
+        }
+        if (pinned)
+        {
+            if ((rc = drain_fetch_uploads_only(ctx, s)))
+                return rc;
+            for (int k = 0; k < 2; ++k)
+            {
+                s.h_mail->src[k] = dev[k];
+                s.h_mail->stride[k] = (long long)strides[k];
+            }
+            s.pull = true;
+            s.undist_pair = ctx->undist_on;
+            s.toed_strict_override = false;
+            s.cur_h = h;
+            s.cur_w = w;
+            s.have_pair = true;
+            return EBVO_OK;
+        }
+    }
+    if (!ctx->upload_stream)
+        EBVO_HIP(ctx, hipStreamCreateWithFlags(&ctx->upload_stream, hipStreamNonBlocking));
     // ordering on the device, not on the host: result copies of the previous pair (copy stream) still read the edge lists --
     // not the images -- so only a previous asynchronous upload of this slot (same stream: ordered) and the slot's own stream
     // (later stages of the previous pair sample the images) matter
     EBVO_HIP(ctx, hipEventRecord(s.ev_upload, s.own_stream));
     EBVO_HIP(ctx, hipStreamWaitEvent(ctx->upload_stream, s.ev_upload, 0));
     s.undist_pair = ctx->undist_on;
+    s.toed_strict_override = false;
     if ((rc = upload_image(ctx, s, 0, img_left, h, w, stride_left, s.undist_pair, ctx->upload_stream)) ||
         (rc = upload_image(ctx, s, 1, img_right, h, w, stride_right, s.undist_pair, ctx->upload_stream)))
         return rc;
@@ -1198,6 +1261,17 @@ extern "C" int ebvo_host_unregister(ebvo_ctx *ctx, void *p)
     if (!ctx || !p)
         return EBVO_ERR_ARG;
     EBVO_HIP(ctx, hipSetDevice(ctx->device));
+    // a slot whose chain pulls its images from page-locked caller memory must not be submitted again with them: it needs a new
+    // upload first (conservative: the library does not know which registration a mailbox points into)
+    for (Slot *sl : ctx->slots)
+        if (sl->pull)
+        {
+            if (sl->in_flight)
+                EBVO_HIP(ctx, hipEventSynchronize(sl->ev_done));
+            sl->pull = false;
+            if (!sl->in_flight)
+                sl->have_pair = false;
+        }
     EBVO_HIP(ctx, hipHostUnregister(p));
     return EBVO_OK;
 }
@@ -1254,18 +1328,53 @@ static int enqueue_matching(ebvo_ctx *ctx, Slot &s, int toed_mode = -1)
                                        (const double *)s.lines.p, p.epi_thr, p.max_disp, p.orient_thr_deg, p.stage_mask,
                                        true)))
         return rc;
-    if ((rc = match_ncc_resident_enqueue(ctx, s, h, w, ce, p.ncc_thr)))
+    if ((rc = match_ncc_resident_enqueue(ctx, s, h, w, ce, p.ncc_thr, 0, !(p.reserved & EBVO_PAIR_NO_SIMS))))
         return rc;
-    // a hybrid TOED run reports candidate lists that did not fit through the result record (bit 2 of `overflow`)
+    // a hybrid TOED run reports candidate lists that did not fit through the result record (bit 1, value 2, of `overflow`)
     if ((rc = match_pair_result_enqueue(ctx, s, (toed_mode < 0 ? ctx->toed_mode : toed_mode) == EBVO_TOED_HYBRID ? ce : 0)))
         return rc;
     return EBVO_OK; // the caller records s.ev_done behind it (outside a stream capture)
 }
 
 // undistortion (if the pair was uploaded raw) + TOED of both images + matching: every launch of one pair
+// the images of a pair, read by the GPU from the caller's page-locked memory (ebvo_stereo_upload_async): 16 bytes per thread
+namespace
+{
+__global__ __launch_bounds__(256) void pull_images_kernel(const Slot::PullMail *__restrict__ mail, uint8_t *__restrict__ d0,
+                                                          uint8_t *__restrict__ d1, int h, int w)
+{
+    const uint8_t *__restrict__ src = mail->src[blockIdx.y];
+    const long long stride = mail->stride[blockIdx.y];
+    uint8_t *__restrict__ dst = blockIdx.y ? d1 : d0;
+    const int per_row = (w + 15) >> 4; // 16-byte pieces per row (the last one may be short)
+    const long long pieces = (long long)h * per_row;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < pieces; t += (long long)gridDim.x * blockDim.x)
+    {
+        const int y = (int)(t / per_row), c = (int)(t - (long long)y * per_row) << 4;
+        const uint8_t *sp = src + (long long)y * stride + c;
+        uint8_t *dp = dst + (size_t)y * w + c;
+        if (c + 16 <= w)
+        {
+            uint4 v;
+            __builtin_memcpy(&v, sp, 16);
+            __builtin_memcpy(dp, &v, 16);
+        }
+        else
+            for (int k = 0; c + k < w; ++k)
+                dp[k] = sp[k];
+    }
+}
+} // namespace
+
 static int enqueue_pair_chain(ebvo_ctx *ctx, Slot &s)
 {
     int rc;
+    if (s.pull)
+    {
+        hipLaunchKernelGGL(pull_images_kernel, dim3(64, 2), dim3(256), 0, s.stream, (const Slot::PullMail *)s.d_mail,
+                           s.undist_pair ? s.im[0].raw : s.im[0].img, s.undist_pair ? s.im[1].raw : s.im[1].img, s.cur_h, s.cur_w);
+        EBVO_HIP(ctx, hipGetLastError());
+    }
     if (s.undist_pair) // cv::undistort of both raw images (src/Pipeline.cpp:78-79); TOED runs on the result (:93, :97)
     {
         const ebvo_undistort_params &u = ctx->undist;
@@ -1275,9 +1384,11 @@ static int enqueue_pair_chain(ebvo_ctx *ctx, Slot &s)
                                            s.im[1].undist_xs, s.im[1].img, s.cur_w)))
             return rc;
     }
-    if ((rc = toed_enqueue(ctx, s, 2, s.cur_h, s.cur_w, nullptr, nullptr, nullptr)))
+    // (no subpix_edge_pts_final in the resident pipeline: nothing downstream reads it, 8 MB of scattered stores per pair)
+    const int mode = s.toed_strict_override ? EBVO_TOED_STRICT : -1;
+    if ((rc = toed_enqueue(ctx, s, 2, s.cur_h, s.cur_w, nullptr, nullptr, nullptr, mode, false)))
         return rc;
-    return enqueue_matching(ctx, s);
+    return enqueue_matching(ctx, s, mode);
 }
 
 static void pair_graph_drop(Slot &s)
@@ -1298,8 +1409,8 @@ static int submit_pair_chain(ebvo_ctx *ctx, Slot &s)
     memset(&key, 0, sizeof key);
     key.h = s.cur_h;
     key.w = s.cur_w;
-    key.toed_mode = ctx->toed_mode;
-    key.undist = s.undist_pair ? 1 : 0;
+    key.toed_mode = s.toed_strict_override ? EBVO_TOED_STRICT : ctx->toed_mode;
+    key.undist = (s.undist_pair ? 1 : 0) | (s.pull ? 2 : 0);
     key.cap_pairs = s.cap_pairs;
     key.gen = ctx->graph_gen + (s.buf_gen << 20);
     key.epi_thr = s.params.epi_thr;
@@ -1307,6 +1418,7 @@ static int submit_pair_chain(ebvo_ctx *ctx, Slot &s)
     key.orient_thr_deg = s.params.orient_thr_deg;
     key.ncc_thr = s.params.ncc_thr;
     key.stage_mask = s.params.stage_mask;
+    key.flags = s.params.reserved;
     const bool same = memcmp(&key, &s.pair_key, sizeof key) == 0;
     const bool eligible = ctx->use_graphs && !s.pair_graph_off && !ctx->prof && !s.prof_now;
     if (!same)
@@ -1359,7 +1471,7 @@ static int submit_pair_chain(ebvo_ctx *ctx, Slot &s)
 extern "C" int ebvo_stereo_submit(ebvo_ctx *ctx, int slot, const ebvo_stereo_params *p)
 {
     Slot *sp;
-    if (!p || (p->stage_mask & ~EBVO_STAGE_ALL) || p->stage_mask == 0 || get_slot(ctx, slot, &sp))
+    if (!p || (p->stage_mask & ~EBVO_STAGE_ALL) || p->stage_mask == 0 || (p->reserved & ~EBVO_PAIR_NO_SIMS) || get_slot(ctx, slot, &sp))
         return EBVO_ERR_ARG;
     Slot &s = *sp;
     if (!s.have_pair || s.in_flight || s.fin_in_flight || s.tq_in_flight)
@@ -1371,6 +1483,7 @@ extern "C" int ebvo_stereo_submit(ebvo_ctx *ctx, int slot, const ebvo_stereo_par
     s.fetch_pending = false; // stream order (or the event below): the kernels run after any copy still enqueued
     s.fetch_what = 0;
     s.params = *p;
+    s.have_sims = !(p->reserved & EBVO_PAIR_NO_SIMS);
     s.prof_now = ctx->prof && (ctx->prof_submits++ % ctx->prof_every == 0);
     // lanes in use: none up to three slots (one stream each), never as many lanes as slots (a lane must be able to hold
     // a queued pair behind the running one: four slots on four streams is the 2500 pairs/s dip)
@@ -1461,13 +1574,15 @@ extern "C" int ebvo_stereo_wait(ebvo_ctx *ctx, int slot, ebvo_stereo_counts *cou
         {
             // the hybrid screen flagged more candidates than fit (toed_rowscan_phase_kernel): the whole pair again, strict
             ++ctx->toed_fallbacks;
-            if ((rc = toed_enqueue(ctx, s, 2, s.cur_h, s.cur_w, nullptr, nullptr, nullptr, EBVO_TOED_STRICT)) ||
+            s.toed_strict_override = true; // remembered until the next upload: these images go strict at once from now on
+            if ((rc = toed_enqueue(ctx, s, 2, s.cur_h, s.cur_w, nullptr, nullptr, nullptr, EBVO_TOED_STRICT, false)) ||
                 (rc = enqueue_matching(ctx, s, EBVO_TOED_STRICT)))
             {
                 s.in_flight = false;
                 return rc;
             }
             EBVO_HIP(ctx, hipEventRecord(s.ev_done, s.stream));
+            --attempt; // not a regrowth: the fallback does not use up one of the attempts (it happens at most once per wait)
             continue;
         }
         if (r.n_total_left > ctx->cap_edges || r.n_total_right > ctx->cap_edges)
@@ -2515,6 +2630,11 @@ extern "C" int ebvo_stereo_fetch_slot(ebvo_ctx *ctx, int slot, ebvo_edge *left, 
     Slot &s = *sp;
     if (!s.have_run || s.in_flight)
         return EBVO_ERR_STATE;
+    if (sims && !s.have_sims)
+    {
+        ctx->last_error = "the pair was submitted with EBVO_PAIR_NO_SIMS: the four scores were not stored";
+        return EBVO_ERR_STATE;
+    }
     EBVO_HIP(ctx, hipSetDevice(ctx->device));
     const size_t nL = (size_t)s.result.n_left, nR = (size_t)s.result.n_right, np = (size_t)s.result.n_pairs;
     hipStream_t st = s.stream;
@@ -3262,6 +3382,11 @@ extern "C" int ebvo_stereo_fetch_begin(ebvo_ctx *ctx, int slot, int what)
     Slot &s = *sp;
     if (!s.have_run || s.in_flight)
         return EBVO_ERR_STATE;
+    if ((what & EBVO_FETCH_SIMS) && !s.have_sims)
+    {
+        ctx->last_error = "the pair was submitted with EBVO_PAIR_NO_SIMS: the four scores were not stored";
+        return EBVO_ERR_STATE;
+    }
     EBVO_HIP(ctx, hipSetDevice(ctx->device));
     const size_t nL = (size_t)s.result.n_left, nR = (size_t)s.result.n_right, np = (size_t)s.result.n_pairs;
     const size_t sizes[7] = {(what & EBVO_FETCH_EDGES) ? sizeof(ebvo_edge) * nL : 0,
@@ -3317,7 +3442,9 @@ extern "C" int ebvo_stereo_fetch_end(ebvo_ctx *ctx, int slot, ebvo_stereo_view *
     if (!view || get_slot(ctx, slot, &sp))
         return EBVO_ERR_ARG;
     Slot &s = *sp;
-    if (!s.have_run || s.in_flight || !s.fetch_what || s.fetch_compact)
+    // (no have_run test: an asynchronous upload of the slot's NEXT images may already have been enqueued -- the copies started by
+    // _begin read the result buffers, which only the next submission overwrites, and that clears fetch_what)
+    if (s.in_flight || !s.fetch_what || s.fetch_compact)
         return EBVO_ERR_STATE;
     EBVO_HIP(ctx, hipSetDevice(ctx->device));
     if (s.fetch_pending)
@@ -3482,7 +3609,7 @@ extern "C" int ebvo_stereo_fetch_compact_end(ebvo_ctx *ctx, int slot, ebvo_stere
     if (!view || get_slot(ctx, slot, &sp))
         return EBVO_ERR_ARG;
     Slot &s = *sp;
-    if (!s.have_run || s.in_flight || !s.fetch_what || !s.fetch_compact)
+    if (s.in_flight || !s.fetch_what || !s.fetch_compact) // (see ebvo_stereo_fetch_end)
         return EBVO_ERR_STATE;
     EBVO_HIP(ctx, hipSetDevice(ctx->device));
     if (s.fetch_pending)
@@ -3570,6 +3697,12 @@ extern "C" int ebvo_debug_set(ebvo_ctx *ctx, int key, int value)
     ++ctx->graph_gen;
     if (key == 10 && value <= 1)
         ctx->use_graphs = value; // the pair chain as a hipGraph (default) or as direct launches
+    else if (key == 13 && value <= 1)
+        ctx->ingest_stream = value;
+    else if (key == 12 && value <= 1)
+        ctx->bank_packed = value;
+    else if (key == 11 && value <= 1)
+        ctx->centre_static_deal = value; // the centre kernel's runs dealt round-robin (round 3) instead of by phase and SIMD
     else if (key == 0)
         ctx->wait_attempts = value;
     else if (key == 1)

@@ -114,14 +114,14 @@ struct PairGraphKey
     int64_t cap_pairs;
     uint64_t gen;
     double epi_thr, max_disp, orient_thr_deg, ncc_thr;
-    int32_t stage_mask, pad;
+    int32_t stage_mask, flags;
 };
 
 struct Slot
 {
     hipStream_t stream = nullptr;     // the stream the slot's work is enqueued on: its own, or a lane (ebvo_stereo_submit)
-    // the pair chain as a hipGraph: captured at the second submission with the same key (the first one runs directly and
-    // performs every allocation), launched from then on -- ~7 us of host time instead of ~90 for the 31 launches
+    // the pair chain as a hipGraph: captured at the THIRD submission with the same key (the first one runs directly, performs
+    // every allocation and bumps buf_gen, i.e. changes the key; the second one runs directly with the final key), launched from then on -- ~7 us of host time instead of ~90 for the 31 launches
     hipGraphExec_t pair_graph = nullptr;
     PairGraphKey pair_key{};
     uint64_t buf_gen = 1;         // bumped whenever one of this slot's buffers is (re)allocated: part of the key
@@ -130,11 +130,23 @@ struct Slot
     hipStream_t own_stream = nullptr; // created with the slot
     hipEvent_t ev_done = nullptr;     // recorded behind the last kernel of a submitted pair
     hipEvent_t ev_rebind = nullptr;   // orders a slot's earlier work before its first work on another lane
+    // ebvo_stereo_upload_async, pull form: the pair's chain starts with a kernel that READS the two images from the caller's
+    // page-locked memory (the pointers travel in this page-locked mailbox, so the captured graph of the chain never changes)
+    struct PullMail
+    {
+        const uint8_t *src[2];
+        long long stride[2];
+    };
+    PullMail *h_mail = nullptr, *d_mail = nullptr; // host / device address of the mailbox
+    bool pull = false;                             // the resident pair is pulled by the chain itself
     hipEvent_t ev_upload = nullptr;   // end of the slot's asynchronous image upload (ebvo_stereo_upload_async, the context's upload stream)
     bool upload_pending = false;      // ... recorded and not yet waited for by a submission or a host call
     ImageWS im[2];
     int cur_h = 0, cur_w = 0;
     bool have_pair = false, have_run = false, in_flight = false, have_refined = false;
+    bool have_sims = true; // the last pair stored all four scores (not submitted with EBVO_PAIR_NO_SIMS)
+    bool toed_strict_override = false; // the hybrid screen overflowed on the resident pair (ebvo_stereo_wait re-ran it strict): later
+                                       // submissions of the SAME images go strict at once; cleared by the next upload
     bool undist_pair = false; // the resident pair was uploaded raw and is undistorted by the pipeline (im[k].raw -> im[k].img)
 
     // matching workspace
@@ -245,6 +257,9 @@ struct ebvo_ctx
     uint64_t graph_gen = 1;     // bumped by every mode / debug change: invalidates the captured graphs of every slot
     int use_graphs = 1;         // EBVO_GRAPHS=0 or ebvo_debug_set(10, 0): direct launches only
     int64_t graph_launches = 0; // pairs submitted as a graph launch
+    int ingest_stream = 0;      // developer key (ebvo_debug_set 13): 1 = ebvo_stereo_upload_async copies on the upload stream (A/B)
+    int bank_packed = 0;        // developer key (ebvo_debug_set 12): the right bank in the packed 7-lane layout (A/B)
+    int centre_static_deal = 0; // developer key (ebvo_debug_set 11): 1 = the centre kernel deals its runs round-robin as in round 3
     bool screen_audit = false;  // ebvo_toed_screen_audit is running: the screen keeps its gx, gy, |g| (toed_kernels.hip)
     int64_t toed_fallbacks = 0; // hybrid TOED runs repeated on the strict path (more screened candidates than cap_edges)
 
@@ -317,7 +332,7 @@ int toed_init_constants(ebvo_ctx *ctx);
 // context's mode.  A hybrid run whose screen flags more candidates than the buffers hold leaves counts[4] > cap_edges and
 // empty results: the caller re-runs with EBVO_TOED_STRICT.
 int toed_enqueue(ebvo_ctx *ctx, Slot &s, int n_img, int h, int w, hipEvent_t ev_conv_begin, hipEvent_t ev_conv_end,
-                 hipEvent_t ev_end, int mode = -1);
+                 hipEvent_t ev_end, int mode = -1, bool want_all4 = true);
 // ebvo_toed_screen_audit: where the audit kernel leaves the 8 words of image k; the screen's budget {E_G, E_M, E_S, TOL_M, TOL_S}
 unsigned long long *toed_screen_audit_result(Slot &s, int k, int h, int w);
 void toed_screen_budget(double out[5]);
@@ -345,7 +360,7 @@ int match_ncc_pairs_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_imgR, int h
                             const int32_t *d_n_pairs = nullptr /* the count on the device; n_pairs is then its bound */);
 // resident pipeline: sin/cos, right patch bank, LDS-tiled NCC of every CSR pair (sizes read on the device)
 // left = index of the slot's image workspace that holds the LEFT image and edges (the right one is the other)
-int match_ncc_resident_enqueue(ebvo_ctx *ctx, Slot &s, int h, int w, int cap_edges, double thr, int left = 0);
+int match_ncc_resident_enqueue(ebvo_ctx *ctx, Slot &s, int h, int w, int cap_edges, double thr, int left = 0, bool want_sims = true);
 size_t match_right_bank_bytes(int cap_edges);
 int match_pair_result_enqueue(ebvo_ctx *ctx, Slot &s, int cand_cap); // cand_cap > 0: hybrid TOED, report candidates > cand_cap
 int match_orient_flags_enqueue(ebvo_ctx *ctx, Slot &s, const ebvo_edge *d_L, int nL, const ebvo_edge *d_R, const int32_t *d_row_ptr,

@@ -1224,6 +1224,90 @@ __device__ inline void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+// ---- packed layout (round 4): NINE 7-lane groups per wave instead of seven rows in eight lanes ---------------------------
+// A patch has 7 rows; with a row per lane and 8- or 16-lane groups one lane in eight never works (56 of 64).  Here lane
+// l < 63 is row l % 7 of group l / 7, lane 63 idles (63 of 64).  The 8-lane DPP butterfly does not fit 7-lane groups that
+// straddle the 16-lane DPP rows, so the seven row partials travel through LDS: every lane writes its partial, reads the seven of
+// its group and adds them in the canonical order of butterfly8 -- ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + 0)) -- same bits,
+// six additions and five LDS instructions instead of nine VALU instructions.
+__device__ inline int lane_group7(int lane) { return (lane * 37) >> 8; } // lane / 7 for lane < 64
+
+__device__ inline double group7_sum(double *slot /* [72] of this wave */, int lane, int g, double v)
+{
+    slot[lane] = v;
+    wave_lds_sync();
+    const double *q = slot + g * 7;
+    return ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + 0.0));
+}
+
+// normalise_rows for the packed layout; sa / sb: two exchange slots of this wave (alternating, so that a slot is rewritten
+// only after every lane has read it)
+__device__ inline bool normalise_rows7(bool active, const float p[7], float nrm[7], double *sa, double *sb, int lane, int g)
+{
+    double rs = 0.0;
+    if (active)
+    {
+        rs = (double)p[0];
+#pragma unroll
+        for (int c = 1; c < 7; ++c)
+            rs += (double)p[c];
+    }
+    const double mean = group7_sum(sa, lane, g, rs) / 49.0;
+    const float m = (float)mean;
+    float d[7];
+    double qs = 0.0;
+    if (active)
+    {
+#pragma unroll
+        for (int c = 0; c < 7; ++c)
+        {
+            d[c] = p[c] - m;
+            const float q = d[c] * d[c];
+            qs = (c == 0) ? (double)q : qs + (double)q;
+        }
+    }
+    const double ss = group7_sum(sb, lane, g, qs);
+    const float inv = (float)(1.0 / sqrt(ss));
+#pragma unroll
+    for (int c = 0; c < 7; ++c)
+        nrm[c] = active ? d[c] * inv : 0.0f;
+    return ss < 1e-10;
+}
+
+// right_bank_kernel in the packed layout: a wave takes 9 side-patches (4.5 edges) per turn
+__global__ __launch_bounds__(256) void right_bank_packed_kernel(const uint8_t *__restrict__ img, const uint16_t *__restrict__ pix2, int h,
+                                                                int w, int pitch, const ebvo_edge *__restrict__ edges,
+                                                                const double2 *__restrict__ sc, DevN nd, float *__restrict__ bank)
+{
+    __shared__ double s_ex[4][2][72];
+    const int n = devn(nd);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int g = lane_group7(lane), row = lane - 7 * g;
+    const int waves = gridDim.x * 4;
+    const int turns = (2 * n + 9 * waves - 1) / (9 * waves); // wave-uniform trip count
+    for (int it = 0; it < turns; ++it)
+    {
+        const int sp = (it * waves + blockIdx.x * 4 + wv) * 9 + g; // side-patch: edge sp / 2, side sp % 2
+        const int e = sp >> 1, side = sp & 1;
+        const bool active = g < 9 && e < n;
+        float p[7], nr[7];
+#pragma unroll
+        for (int c = 0; c < 7; ++c)
+            p[c] = 0.0f;
+        {
+            const int ec = active ? e : 0;
+            sample_row<true>(img, h, w, pitch, edges[ec].x, edges[ec].y, sc[ec].x, sc[ec].y, side, row, p, active, pix2);
+        }
+        const bool sent = normalise_rows7(active, p, nr, s_ex[wv][0], s_ex[wv][1], lane, g);
+        if (active)
+        {
+            float4 *dst = reinterpret_cast<float4 *>(bank + (size_t)e * BANK_EDGE + side * BANK_SIDE + row * 8);
+            dst[0] = make_float4(nr[0], nr[1], nr[2], nr[3]);
+            dst[1] = make_float4(nr[4], nr[5], nr[6], sent ? 1.0f : 0.0f);
+        }
+    }
+}
+
 // One WAVE owns NW consecutive left edges (a contiguous range of CSR pairs): no workgroup barrier anywhere, so waves in
 // their sampling phase and waves in their scoring phase overlap freely on a SIMD.
 template <int NW, int WPE>
@@ -1355,8 +1439,11 @@ __global__ __launch_bounds__(256, WPE) void ncc_tile_kernel(const uint8_t *__res
                 const double pn = (lsent_p || rsent_m) ? -1.0 : d_pn;
                 const double npv = (lsent_m || rsent_p) ? -1.0 : d_np;
                 const double b = max4(pp, nn, pn, npv); // src/Stereo_Matches.cpp:596
-                double4 *sp = reinterpret_cast<double4 *>(sims + (size_t)k * 4);
-                *sp = make_double4(pp, nn, pn, npv);
+                if (sims) // the four scores are an option of the resident path (EBVO_PAIR_NO_SIMS): the reference keeps only their
+                {         // maximum (refine_final_scores, src/Stereo_Matches.cpp:600)
+                    double4 *sp = reinterpret_cast<double4 *>(sims + (size_t)k * 4);
+                    *sp = make_double4(pp, nn, pn, npv);
+                }
                 best[k] = b;
                 const bool m = b > thr; // :597
                 keep[k] = m ? 1 : 0;
@@ -2016,7 +2103,7 @@ int match_ncc_pairs_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_imgR, int h
 
 // NCC of the CSR pairs in s.row_ptr / s.col_idx of the resident pair: sin/cos of both edge lists, the right bank, the
 // tile kernel.  s.patches_norm_r holds the right bank (BANK_EDGE floats per edge).
-int match_ncc_resident_enqueue(ebvo_ctx *ctx, Slot &s, int h, int w, int cap_edges, double thr, int left)
+int match_ncc_resident_enqueue(ebvo_ctx *ctx, Slot &s, int h, int w, int cap_edges, double thr, int left, bool want_sims)
 {
     int rc;
     if ((rc = ebvo_grow(ctx, s, s.sincos, sizeof(double2) * 2 * (size_t)cap_edges)))
@@ -2036,6 +2123,11 @@ int match_ncc_resident_enqueue(ebvo_ctx *ctx, Slot &s, int h, int w, int cap_edg
         hipLaunchKernelGGL(row_pairs_kernel, dim3(blocks_for(((int64_t)h * w + 3) / 4, 256, 512), 2), dim3(256), 0, s.stream,
                            ncc_img(s, 0), ncc_img(s, 1), s.im[0].pix2, s.im[1].pix2, h, w);
         hipLaunchKernelGGL(sincos_batch_kernel, dim3(blocks_for(cap_edges, 256, 512), 2), dim3(256), 0, s.stream, B);
+        if (ctx->bank_packed) // developer key 12: nine 7-lane groups per wave (63 of 64 lanes) instead of rows in 16-lane groups
+            hipLaunchKernelGGL(right_bank_packed_kernel, dim3(blocks_for((int64_t)cap_edges * 16, 256, 1024)), dim3(256), 0, s.stream,
+                               ncc_img(s, iR), (const uint16_t *)s.im[iR].pix2, h, w, w, (const ebvo_edge *)s.im[iR].edges,
+                               (const double2 *)B.sc[iR], nRd, (float *)s.patches_norm_r.p);
+        else
         hipLaunchKernelGGL(right_bank_kernel, dim3(blocks_for((int64_t)cap_edges * 16, 256, 1024)), dim3(256), 0, s.stream,
                            ncc_img(s, iR), (const uint16_t *)s.im[iR].pix2, h, w, w, (const ebvo_edge *)s.im[iR].edges,
                            (const double2 *)B.sc[iR], nRd, (float *)s.patches_norm_r.p);
@@ -2050,7 +2142,8 @@ int match_ncc_resident_enqueue(ebvo_ctx *ctx, Slot &s, int h, int w, int cap_edg
         hipLaunchKernelGGL((ncc_tile_kernel<NCC_NW, NCC_WPE>), dim3(nblk), dim3(256), 0, s.stream, ncc_img(s, iL),
                            (const uint16_t *)s.im[iL].pix2, h, w, w, (const ebvo_edge *)s.im[iL].edges, (const double2 *)B.sc[iL],
                            nLd, (const int32_t *)s.row_ptr.p, (const int32_t *)s.col_idx.p, (const float *)s.patches_norm_r.p,
-                           s.cap_pairs, thr, (double *)s.sims.p, (double *)s.best.p, (uint8_t *)s.keep.p, s.d_matches);
+                           s.cap_pairs, thr, want_sims ? (double *)s.sims.p : nullptr, (double *)s.best.p, (uint8_t *)s.keep.p,
+                           s.d_matches);
     }
     EBVO_HIP(ctx, hipGetLastError());
     return EBVO_OK;

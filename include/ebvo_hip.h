@@ -565,8 +565,13 @@ typedef struct ebvo_stereo_params
     double F21[9]; /* row-major fundamental matrix, Dataset::get_fund_mat_21 */
     double epi_thr, max_disp, orient_thr_deg, ncc_thr;
     int stage_mask;
-    int reserved;
+    int reserved; /* flags: 0, or EBVO_PAIR_NO_SIMS */
 } ebvo_stereo_params;
+/* ebvo_stereo_params.reserved = EBVO_PAIR_NO_SIMS: the resident pipeline stores, per candidate pair, the final score (the
+ * maximum of the four similarities: what the reference keeps, refine_final_scores, src/Stereo_Matches.cpp:596-600) and the
+ * keep flag, not the four similarities themselves (32 of the 41 bytes the NCC stage writes per pair).  The arithmetic is the
+ * same; asking for `sims` of such a pair is EBVO_ERR_STATE. */
+#define EBVO_PAIR_NO_SIMS 1
 
 typedef struct ebvo_stereo_counts
 {

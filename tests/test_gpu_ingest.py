@@ -138,3 +138,61 @@ def test_compact_fetch_equals_full_fetch(c):
     c.stereo_fetch_begin(slot=1)
     out = c.stereo_fetch_end(slot=1)
     assert_bit_equal(out["keep"], ref[1][1]["keep"], "keep")
+
+
+def test_no_sims_flag_stores_best_and_keep_only(c):
+    """EBVO_PAIR_NO_SIMS: the four similarities are not written (the reference keeps their maximum only,
+    src/Stereo_Matches.cpp:596-600); best, keep and the counts are unchanged, asking for sims is a state error"""
+    ring = _ring(1)
+    ref = _reference(c, ring)[0]
+    p = c.default_params(F)
+    p.reserved = _lib.PAIR_NO_SIMS
+    c.stereo_upload(*ring[0], slot=2)
+    for _ in range(4):                                 # direct launches, then the captured graph of this flag
+        c.stereo_submit(p, slot=2)
+        cnt = c.stereo_wait(slot=2)
+    assert (cnt.n_pairs, cnt.n_matches) == (ref[0].n_pairs, ref[0].n_matches)
+    with pytest.raises(_lib.EbvoError):
+        c.stereo_fetch(cnt, slot=2)                    # asks for sims
+    with pytest.raises(_lib.EbvoError):
+        c.stereo_fetch_begin(slot=2, what=_lib.FETCH_ALL)
+    c.stereo_fetch_begin(slot=2, what=_lib.FETCH_DEFAULT)
+    out = c.stereo_fetch_end(slot=2)
+    assert_bit_equal(out["best"], ref[1]["best"], "best")
+    assert_bit_equal(out["keep"], ref[1]["keep"], "keep")
+    assert_bit_equal(out["col_idx"], ref[1]["col_idx"], "col_idx")
+    p.reserved = 0                                     # and back: the scores are there again
+    c.stereo_submit(p, slot=2)
+    cnt = c.stereo_wait(slot=2)
+    assert_bit_equal(c.stereo_fetch(cnt, slot=2)["sims"], ref[1]["sims"], "sims")
+
+
+@pytest.mark.parametrize("stream_form", [0, 1])
+def test_both_forms_of_the_asynchronous_upload(c, stream_form):
+    """ebvo_debug_set 13: 0 = the pair's chain pulls the images from page-locked memory itself (default), 1 = copies on the
+    context's upload stream + event; strided sources and a replayed submission included"""
+    ring = _ring(2)
+    ref = _reference(c, ring)
+    wide = [tuple(np.ascontiguousarray(np.pad(im, ((0, 0), (0, 24)))) for im in pair) for pair in ring]   # stride = W + 24
+    for pair in wide:
+        for im in pair:
+            c.host_register(im)
+    c.debug_set(13, stream_form)
+    try:
+        p = c.default_params(F)
+        for k in range(2):
+            l, r = (im[:, :W] for im in wide[k])
+            assert l.strides[0] == W + 24
+            # (api.stereo_upload_async wants contiguous arrays: the strided call goes through the C entry directly)
+            from edge_based_visual_odometry_amd.api import ptr
+            c._check(c.lib.ebvo_stereo_upload_async(c._ctx, 3, ptr(wide[k][0]), ptr(wide[k][1]), H, W, W + 24, W + 24), "upload_async")
+            for _ in range(2):                         # the second submission replays the same images
+                c.stereo_submit(p, slot=3)
+                cnt = c.stereo_wait(slot=3)
+                _same(c.stereo_fetch(cnt, slot=3), ref[k])
+    finally:
+        c.debug_set(13, 0)
+        c.stereo_upload(*ring[0], slot=3)              # the slot no longer refers to the registered memory
+        for pair in wide:
+            for im in pair:
+                c.host_unregister(im)

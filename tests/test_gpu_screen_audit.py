@@ -37,6 +37,15 @@ def both_modes(c, img):
     return hy, fell_back
 
 
+@pytest.fixture(scope="module")
+def big():
+    """a context whose candidate buffers hold EVERY grid point of a KITTI-size image (cap = max_h * max_w >= 4 H W): the screen
+    cannot overflow, so that images of ties -- where the sector rule flags every point with |g| > 2 -- are audited, not skipped"""
+    ctx = Context(max_h=800, max_w=2500, device=0, toed_mode="hybrid")
+    yield ctx
+    ctx.close()
+
+
 def check_audit(a, what):
     assert a["bound_g"] == pytest.approx(7.67e-5) and a["bound_mag"] == pytest.approx(1.22e-4), what
     assert a["tol_mag"] >= 2 * a["bound_mag"] and a["tol_slope"] >= 2 * a["bound_slope"], what
@@ -77,24 +86,51 @@ def saturating(kind, period, h, w):
 
 
 @pytest.mark.parametrize("kind", ["vertical", "horizontal", "diagonal", "checkerboard"])
-def test_screen_error_on_full_size_saturating_images(c, kind):
+def test_screen_error_on_full_size_saturating_images(big, c, kind):
     h, w = SHAPES["kitti"]
     worst = dict(gx=0.0, gy=0.0, mag=0.0, nb=0.0)
-    audited = 0
+    most = 0
+    overflowed = 0
     for period in range(1, 20):
         img = saturating(kind, period, h, w)
-        try:
-            a = c.toed_screen_audit(img)
-        except _lib.EbvoError as e:                   # an image of ties: more screened grid points than the context holds
-            assert e.status == _lib.EBVO_ERR_CAPACITY, e
-            a = None
-        if a is not None:
-            check_audit(a, (kind, period))
-            audited += 1
-            worst = dict(gx=max(worst["gx"], a["max_err_gx"]), gy=max(worst["gy"], a["max_err_gy"]),
-                         mag=max(worst["mag"], a["max_err_mag"]), nb=max(worst["nb"], a["max_err_mag_neighbours"]))
-        _, fell_back = both_modes(c, img)             # the decision: hybrid == strict whether or not the screen overflowed
-        assert fell_back == (a is None), (kind, period)
-    assert audited >= 12, (kind, audited)             # most periods fit the candidate buffers and are really audited
+        a = big.toed_screen_audit(img)                # never overflows here: every period is audited
+        check_audit(a, (kind, period))
+        most = max(most, a["n_candidates"])
+        worst = dict(gx=max(worst["gx"], a["max_err_gx"]), gy=max(worst["gy"], a["max_err_gy"]),
+                     mag=max(worst["mag"], a["max_err_mag"]), nb=max(worst["nb"], a["max_err_mag_neighbours"]))
+        hy, fell_back = both_modes(big, img)          # the decision itself: hybrid == strict, the exact stage over all candidates
+        assert not fell_back and (a["n_maxima"], a["n_kept"]) == (hy.n_total, len(hy.edges))
+        # ... and in the context sized for ordinary images, where an image of ties overflows the candidate buffers: the library
+        # falls back to the strict path and returns the same edges
+        hy2, fb2 = both_modes(c, img)
+        assert_edges_equal(hy2.edges, hy.edges)
+        overflowed += bool(fb2)
+    assert most > 100000, (kind, most)                # the images do exercise the exact stage
     print(f"{kind}: worst |screen - exact| gx {worst['gx']:.3e} gy {worst['gy']:.3e} |g| {worst['mag']:.3e} "
-          f"neighbours {worst['nb']:.3e} over {audited} audited images")
+          f"neighbours {worst['nb']:.3e}; most candidates {most}; {overflowed} of 19 periods overflow a 512 x 1280 context")
+
+
+def test_dealing_and_layout_switches_return_the_same_bits(c):
+    """developer switches of round 4 (ebvo_debug_set): 11 = the centre kernel's runs dealt round-robin as in round 3 instead
+    of by phase and SIMD; 12 = the right bank in the packed 7-lane layout; same edges, same scores either way"""
+    from edge_based_visual_odometry_amd import synth as sy
+    h, w = 376, 1241
+    l, r = sy.stereo_pair("s2", h, w)
+    F = sy.fundamental_for("kitti")
+    p = c.default_params(F)
+    c.stereo_upload(l, r)
+    ref_counts = c.stereo_run(p)
+    ref = c.stereo_fetch(ref_counts)
+    for key in (11, 12):
+        c.debug_set(key, 1)
+        try:
+            cnt = c.stereo_run(p)
+            out = c.stereo_fetch(cnt)
+        finally:
+            c.debug_set(key, 0)
+        assert (cnt.n_left, cnt.n_right, cnt.n_pairs, cnt.n_matches) == (ref_counts.n_left, ref_counts.n_right,
+                                                                        ref_counts.n_pairs, ref_counts.n_matches), key
+        assert_edges_equal(out["left"], ref["left"])
+        assert_edges_equal(out["right"], ref["right"])
+        for k in ("row_ptr", "col_idx", "sims", "best", "keep"):
+            assert_bit_equal(out[k], ref[k], f"key {key}: {k}")

@@ -163,7 +163,22 @@ def test_pipeline_falls_back_to_strict_when_the_screen_overflows():
             c.stereo_submit(p)
             counts = c.stereo_wait()
             res = c.stereo_fetch(counts)
-            out[mode] = (counts, res, c.toed_fallbacks)
+            fb_first = c.toed_fallbacks
+            # the SAME images again (a replayed pair): the slot remembers that the screen overflowed and goes strict at once --
+            # no second hybrid pass, no second fallback -- until new images are uploaded
+            for _ in range(3):
+                c.stereo_submit(p)
+                again = c.stereo_wait()
+                assert (again.n_left, again.n_pairs, again.n_matches) == (counts.n_left, counts.n_pairs, counts.n_matches)
+            assert c.toed_fallbacks == fb_first
+            out[mode] = (counts, res, fb_first)
+            # new images: the override is gone, the hybrid detector runs (and does not overflow on an ordinary image)
+            from edge_based_visual_odometry_amd import synth as _synth
+            l2, r2 = _synth.stereo_pair("s2", h, w)
+            c.stereo_upload(l2, r2)
+            c.stereo_submit(p)
+            c.stereo_wait()
+            assert c.toed_fallbacks == fb_first
     cs, rs, _ = out["strict"]
     ch, rh, fb = out["hybrid"]
     assert fb == 1
