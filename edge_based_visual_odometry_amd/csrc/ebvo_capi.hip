@@ -192,6 +192,8 @@ static void slot_destroy(Slot *s)
         (void)hipEventDestroy(s->ev_upload);
     if (s->h_mail)
         (void)hipHostFree(s->h_mail);
+    if (s->h_push)
+        (void)hipHostFree(s->h_push);
     (void)hipFree(s->d_fin_tot);
     if (s->h_fin_tot)
         (void)hipHostFree(s->h_fin_tot);
@@ -1337,6 +1339,110 @@ static int enqueue_matching(ebvo_ctx *ctx, Slot &s, int toed_mode = -1)
 }
 
 // undistortion (if the pair was uploaded raw) + TOED of both images + matching: every launch of one pair
+// EBVO_PAIR_PUSH: the compact results of a pair written by the device into page-locked host memory, as the last kernel of the
+// pair's chain (same arrays as ebvo_stereo_fetch_compact_begin; the sizes are read on the device).  Coalesced 16-byte stores
+// over PCIe; the kernel holds a handful of CUs while the lanes' other pairs compute.
+namespace
+{
+struct PushArrays
+{
+    double2 *xyL, *xyR;
+    double *thL, *thR; // nullptr: not selected
+    int32_t *row_ptr, *col_idx;
+    double *best;
+    uint32_t *bits;
+};
+
+__global__ __launch_bounds__(256) void push_results_kernel(const ebvo_edge *__restrict__ L, const ebvo_edge *__restrict__ R,
+                                                           const int32_t *__restrict__ nLp, const int32_t *__restrict__ nRp, int cap_edges,
+                                                           const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ col_idx,
+                                                           const double *__restrict__ best, const uint8_t *__restrict__ keep,
+                                                           int64_t cap_pairs, PushArrays P)
+{
+    const int nL = min(*nLp, cap_edges), nR = min(*nRp, cap_edges);
+    int64_t np = nL > 0 ? (int64_t)row_ptr[nL] : 0;
+    np = np < cap_pairs ? np : cap_pairs;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int64_t i = t0; i < nL; i += stride)
+    {
+        const ebvo_edge e = L[i];
+        P.xyL[i] = make_double2(e.x, e.y);
+        if (P.thL)
+            P.thL[i] = e.theta;
+    }
+    for (int64_t i = t0; i < nR; i += stride)
+    {
+        const ebvo_edge e = R[i];
+        P.xyR[i] = make_double2(e.x, e.y);
+        if (P.thR)
+            P.thR[i] = e.theta;
+    }
+    for (int64_t i = t0; i <= nL; i += stride)
+        P.row_ptr[i] = row_ptr[i];
+    // four CSR entries / two scores per thread: 16-byte stores
+    const int64_t n4 = np >> 2;
+    for (int64_t i = t0; i < n4; i += stride)
+        reinterpret_cast<int4 *>(P.col_idx)[i] = reinterpret_cast<const int4 *>(col_idx)[i];
+    for (int64_t i = (n4 << 2) + t0; i < np; i += stride)
+        P.col_idx[i] = col_idx[i];
+    const int64_t n2 = np >> 1;
+    for (int64_t i = t0; i < n2; i += stride)
+        reinterpret_cast<double2 *>(P.best)[i] = reinterpret_cast<const double2 *>(best)[i];
+    if ((np & 1) && t0 == 0)
+        P.best[np - 1] = best[np - 1];
+    const int64_t groups = (np + 63) >> 6, wave = t0 >> 6, waves = stride >> 6;
+    const int lane = threadIdx.x & 63;
+    for (int64_t g = wave; g < groups; g += waves)
+    {
+        const int64_t k = (g << 6) + lane;
+        const unsigned long long m = __ballot(k < np && keep[k] != 0);
+        if (lane == 0)
+        {
+            P.bits[2 * g] = (uint32_t)m;
+            P.bits[2 * g + 1] = (uint32_t)(m >> 32);
+        }
+    }
+}
+} // namespace
+
+// (re)sizes the slot's push arena for the capacities of the chain about to be enqueued; a re-allocation bumps buf_gen (the
+// arena's address is an argument of a captured launch)
+static int ensure_push_arena(ebvo_ctx *ctx, Slot &s, bool with_theta)
+{
+    const size_t ce = (size_t)ctx->cap_edges, cp = (size_t)s.cap_pairs;
+    const size_t sizes[8] = {16 * ce, 16 * ce, with_theta ? 8 * ce : 0, with_theta ? 8 * ce : 0, 4 * (ce + 1), 4 * cp, 8 * cp, 8 * ((cp + 63) >> 6)};
+    size_t total = 0, off[8];
+    for (int k = 0; k < 8; ++k)
+    {
+        off[k] = total;
+        total += (sizes[k] + 255) & ~(size_t)255;
+    }
+    if (total > s.push_bytes || s.push_cap_edges != (int)ce || s.push_cap_pairs != (int64_t)cp || (with_theta && s.push_off[2] == s.push_off[3]))
+    {
+        if (total > s.push_bytes)
+        {
+            if (s.h_push)
+                (void)hipHostFree(s.h_push);
+            s.h_push = s.d_push = nullptr;
+            s.push_bytes = 0;
+            if (hipHostMalloc(&s.h_push, total) != hipSuccess)
+            {
+                (void)hipGetLastError();
+                ctx->last_error = "hipHostMalloc failed (page-locked result arena of EBVO_PAIR_PUSH)";
+                return EBVO_ERR_NOMEM;
+            }
+            EBVO_HIP(ctx, hipHostGetDevicePointer(&s.d_push, s.h_push, 0));
+            s.push_bytes = total;
+        }
+        memcpy(s.push_off, off, sizeof off);
+        s.push_cap_edges = (int)ce;
+        s.push_cap_pairs = (int64_t)cp;
+        ++s.buf_gen;
+    }
+    return EBVO_OK;
+}
+
 // the images of a pair, read by the GPU from the caller's page-locked memory (ebvo_stereo_upload_async): 16 bytes per thread
 namespace
 {
@@ -1366,6 +1472,29 @@ __global__ __launch_bounds__(256) void pull_images_kernel(const Slot::PullMail *
 }
 } // namespace
 
+static int enqueue_push(ebvo_ctx *ctx, Slot &s)
+{
+    if (!(s.params.reserved & EBVO_PAIR_PUSH))
+        return EBVO_OK;
+    const bool th = s.params.reserved & EBVO_PAIR_PUSH_THETA;
+    char *b = static_cast<char *>(s.d_push);
+    PushArrays P;
+    P.xyL = (double2 *)(b + s.push_off[0]);
+    P.xyR = (double2 *)(b + s.push_off[1]);
+    P.thL = th ? (double *)(b + s.push_off[2]) : nullptr;
+    P.thR = th ? (double *)(b + s.push_off[3]) : nullptr;
+    P.row_ptr = (int32_t *)(b + s.push_off[4]);
+    P.col_idx = (int32_t *)(b + s.push_off[5]);
+    P.best = (double *)(b + s.push_off[6]);
+    P.bits = (uint32_t *)(b + s.push_off[7]);
+    hipLaunchKernelGGL(push_results_kernel, dim3(64), dim3(256), 0, s.stream, (const ebvo_edge *)s.im[0].edges,
+                       (const ebvo_edge *)s.im[1].edges, (const int32_t *)(s.im[0].counts + 1), (const int32_t *)(s.im[1].counts + 1),
+                       ctx->cap_edges, (const int32_t *)s.row_ptr.p, (const int32_t *)s.col_idx.p, (const double *)s.best.p,
+                       (const uint8_t *)s.keep.p, s.cap_pairs, P);
+    EBVO_HIP(ctx, hipGetLastError());
+    return EBVO_OK;
+}
+
 static int enqueue_pair_chain(ebvo_ctx *ctx, Slot &s)
 {
     int rc;
@@ -1388,7 +1517,9 @@ static int enqueue_pair_chain(ebvo_ctx *ctx, Slot &s)
     const int mode = s.toed_strict_override ? EBVO_TOED_STRICT : -1;
     if ((rc = toed_enqueue(ctx, s, 2, s.cur_h, s.cur_w, nullptr, nullptr, nullptr, mode, false)))
         return rc;
-    return enqueue_matching(ctx, s, mode);
+    if ((rc = enqueue_matching(ctx, s, mode)))
+        return rc;
+    return enqueue_push(ctx, s);
 }
 
 static void pair_graph_drop(Slot &s)
@@ -1471,7 +1602,7 @@ static int submit_pair_chain(ebvo_ctx *ctx, Slot &s)
 extern "C" int ebvo_stereo_submit(ebvo_ctx *ctx, int slot, const ebvo_stereo_params *p)
 {
     Slot *sp;
-    if (!p || (p->stage_mask & ~EBVO_STAGE_ALL) || p->stage_mask == 0 || (p->reserved & ~EBVO_PAIR_NO_SIMS) || get_slot(ctx, slot, &sp))
+    if (!p || (p->stage_mask & ~EBVO_STAGE_ALL) || p->stage_mask == 0 || (p->reserved & ~(EBVO_PAIR_NO_SIMS | EBVO_PAIR_PUSH | EBVO_PAIR_PUSH_THETA)) || get_slot(ctx, slot, &sp))
         return EBVO_ERR_ARG;
     Slot &s = *sp;
     if (!s.have_pair || s.in_flight || s.fin_in_flight || s.tq_in_flight)
@@ -1530,6 +1661,9 @@ extern "C" int ebvo_stereo_submit(ebvo_ctx *ctx, int slot, const ebvo_stereo_par
         if ((rc = ensure_pipeline_buffers(ctx, s, want)))
             return rc;
     }
+    s.have_push = false;
+    if ((s.params.reserved & EBVO_PAIR_PUSH) && (rc = ensure_push_arena(ctx, s, s.params.reserved & EBVO_PAIR_PUSH_THETA)))
+        return rc;
     EBVO_HIP(ctx, hipMemcpyAsync(s.d_F, s.params.F21, sizeof(double) * 9, hipMemcpyHostToDevice, s.stream));
     if ((rc = submit_pair_chain(ctx, s)))
         return rc;
@@ -1576,7 +1710,7 @@ extern "C" int ebvo_stereo_wait(ebvo_ctx *ctx, int slot, ebvo_stereo_counts *cou
             ++ctx->toed_fallbacks;
             s.toed_strict_override = true; // remembered until the next upload: these images go strict at once from now on
             if ((rc = toed_enqueue(ctx, s, 2, s.cur_h, s.cur_w, nullptr, nullptr, nullptr, EBVO_TOED_STRICT, false)) ||
-                (rc = enqueue_matching(ctx, s, EBVO_TOED_STRICT)))
+                (rc = enqueue_matching(ctx, s, EBVO_TOED_STRICT)) || (rc = enqueue_push(ctx, s)))
             {
                 s.in_flight = false;
                 return rc;
@@ -3701,8 +3835,6 @@ extern "C" int ebvo_debug_set(ebvo_ctx *ctx, int key, int value)
         ctx->ingest_stream = value;
     else if (key == 12 && value <= 1)
         ctx->bank_packed = value;
-    else if (key == 11 && value <= 1)
-        ctx->centre_static_deal = value; // the centre kernel's runs dealt round-robin (round 3) instead of by phase and SIMD
     else if (key == 0)
         ctx->wait_attempts = value;
     else if (key == 1)

@@ -198,6 +198,13 @@ struct Slot
     bool fetch_pending = false;          // copies enqueued, not yet waited for
     size_t fetch_off[8] = {0};           // left, right, row_ptr, col_idx, sims, best, keep (compact: xyL, xyR, thL, thR, row_ptr, col_idx, best, keep bits)
     bool fetch_compact = false;          // the arena holds the arrays of ebvo_stereo_fetch_compact_begin
+    // EBVO_PAIR_PUSH: the pair's chain ends with a kernel that WRITES the compact results into this page-locked arena (sized for
+    // the capacities the chain was enqueued with); no copy, no event: they are there when the pair's ebvo_stereo_wait returns
+    void *h_push = nullptr, *d_push = nullptr;
+    size_t push_bytes = 0, push_off[8] = {0};
+    int push_cap_edges = 0;
+    int64_t push_cap_pairs = 0;
+    bool have_push = false;              // the last completed pair pushed its results (ebvo_stereo_pushed_view)
     GrowBuf fetch_pack;                  // device staging of the compact fetch: (x, y) pairs, orientations, keep bits
     ebvo_stereo_params params{};
     PairResult result{};                 // last completed result
@@ -259,7 +266,6 @@ struct ebvo_ctx
     int64_t graph_launches = 0; // pairs submitted as a graph launch
     int ingest_stream = 0;      // developer key (ebvo_debug_set 13): 1 = ebvo_stereo_upload_async copies on the upload stream (A/B)
     int bank_packed = 0;        // developer key (ebvo_debug_set 12): the right bank in the packed 7-lane layout (A/B)
-    int centre_static_deal = 0; // developer key (ebvo_debug_set 11): 1 = the centre kernel deals its runs round-robin as in round 3
     bool screen_audit = false;  // ebvo_toed_screen_audit is running: the screen keeps its gx, gy, |g| (toed_kernels.hip)
     int64_t toed_fallbacks = 0; // hybrid TOED runs repeated on the strict path (more screened candidates than cap_edges)
 

@@ -1321,38 +1321,6 @@ __device__ inline bool exact_task(const ExactBatch &E, int n_img, int cap, int l
     return false;
 }
 
-// ---- which SIMD a wave runs on (round 4: phase-aware dealing of the centre kernel's runs) -------------------------------
-// HW_REG_HW_ID: [5:4] simd, [11:8] cu, [12] sh, [15:13] se; HW_REG_XCC_ID: the XCD.  The (se, cu) ids of an XCD have holes
-// (36 slots, 32 CUs); a one-time probe (toed_simd_probe_kernel, at the first context of a device) records the ids that exist
-// and the host ranks them: rank[xcc][se << 4 | cu] = 0 .. 31, 0xff = never seen.
-struct SimdTable
-{
-    uint8_t rank[16][128];
-};
-SimdTable *g_simd_table_dev[16] = {nullptr}; // per HIP device; nullptr = no table (static dealing)
-
-__device__ inline unsigned hw_simd_key(unsigned &xcc, unsigned &simd)
-{
-    const unsigned hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));  // HW_REG_HW_ID
-    xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)) & 0xfu;        // HW_REG_XCC_ID
-    simd = (hw >> 4) & 3u;
-    return (((hw >> 13) & 7u) << 4) | ((hw >> 8) & 0xfu);
-}
-
-__global__ __launch_bounds__(256) void toed_simd_probe_kernel(unsigned *seen /* [16][4] bit masks of 128 keys */, int spin)
-{
-    if ((threadIdx.x & 63) == 0)
-    {
-        unsigned xcc, simd;
-        const unsigned key = hw_simd_key(xcc, simd);
-        atomicOr(&seen[xcc * 4 + (key >> 5)], 1u << (key & 31));
-    }
-    // stay resident for a moment so that the grid spreads over every CU instead of re-using the first ones
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)spin)
-        __builtin_amdgcn_s_sleep(8);
-}
-
 template <int SY, int SX>
 __device__ inline void centre_run(const ExactBatch &E, const ExactTaps &L, int h, int w, int cap, int im, int k, int n)
 {
@@ -1413,8 +1381,7 @@ __global__ __launch_bounds__(256, EBVO_CENTRE_WPS) void toed_exact_centre_kernel
 #else
 __global__ __launch_bounds__(256) void toed_exact_centre_kernel(ExactBatch E, const ToedTables *__restrict__ T, int h,
 #endif
-                                                                int w, int cap, int n_img, const SimdTable *simd_table,
-                                                                int32_t *cursors /* [2], zero at launch */)
+                                                                int w, int cap, int n_img)
 {
     __shared__ ExactTaps L;
     EBVO_TRACE_BEGIN();
@@ -1422,7 +1389,11 @@ __global__ __launch_bounds__(256) void toed_exact_centre_kernel(ExactBatch E, co
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
     ExactTask q;
-    auto run = [&](const ExactTask &q) {
+    // (Round 4 tried to deal the runs by phase and SIMD -- five 289-tap runs cost what four 361-tap runs cost -- through two
+    // run queues: the thousands of same-address atomics of a launch serialise at ~18 ns each across the XCDs, 100 -> 282 us.
+    // DESIGN.md 6c.  The runs are dealt round-robin.)
+    for (int t = wave; exact_task(E, n_img, cap, 0, t, q); t += gridDim.x * 4)
+    {
         EBVO_TRACE_TASK();
         switch (q.ph)
         {
@@ -1430,53 +1401,6 @@ __global__ __launch_bounds__(256) void toed_exact_centre_kernel(ExactBatch E, co
         case 1: centre_run<0, 1>(E, L, h, w, cap, q.im, q.k0 + lane, q.n); break;
         case 2: centre_run<1, 0>(E, L, h, w, cap, q.im, q.k0 + lane, q.n); break;
         default: centre_run<1, 1>(E, L, h, w, cap, q.im, q.k0 + lane, q.n); break;
-        }
-    };
-    if (!simd_table)
-    {
-        for (int t = wave; exact_task(E, n_img, cap, 0, t, q); t += gridDim.x * 4)
-            run(q);
-        EBVO_TRACE_END(0);
-        return;
-    }
-    // Phase-aware dealing.  A run of the integer phase has 17 x 17 taps, a run of a half-pixel phase 19 x 19: FIVE of the
-    // former cost what FOUR of the latter cost (1445 : 1444 tap steps).  With round-robin dealing every SIMD holds a mix, and
-    // as soon as the launch has more runs than resident waves (4,176 for 4,096 at KITTI size) some SIMDs hold a fifth run of 361
-    // taps: 110 us where the balanced time is 95 (profiles/r03_wave_trace.txt).  Here the SIMDs are split into two classes in
-    // proportion to the two kinds of work; a wave draws runs of its SIMD's kind from a queue (one atomic per run) and, when
-    // that queue is empty, from the other one -- so every run is done whatever the placement of the waves, a class-0 SIMD
-    // ends up with five short runs, a class-1 SIMD with four long ones.
-    int n0 = 0, n1 = 0;
-    for (int im = 0; im < n_img; ++im)
-    {
-        n0 += (min(E.lcount[im][0], cap) + 63) >> 6;
-        for (int ph = 1; ph < 4; ++ph)
-            n1 += (min(E.lcount[im][ph], cap) + 63) >> 6;
-    }
-    const int n_simd = gridDim.x; // the launch holds exactly the resident waves: four blocks per CU = one block per SIMD's worth
-    const long long w0 = 289ll * n0, w1 = 361ll * n1;
-    int s0 = (w0 + w1) > 0 ? (int)((n_simd * w0 + (w0 + w1) - 1) / (w0 + w1)) : 0;
-    if (n1 > 0 && s0 >= n_simd)
-        s0 = n_simd - 1;
-    unsigned xcc, simd;
-    const unsigned key = hw_simd_key(xcc, simd);
-    const unsigned r = simd_table->rank[xcc & 15][key & 127];
-    const int per_xcc0 = (s0 + 7) >> 3;                         // class-0 SIMDs per XCD (every XCD the same share)
-    const int cls = (r != 0xffu && (int)(r * 4 + simd) < per_xcc0) ? 0 : 1;
-    const int first = __builtin_amdgcn_readfirstlane(cls);
-    for (int turn = 0; turn < 2; ++turn)
-    {
-        const int which = turn == 0 ? first : 1 - first;        // own kind first, then the other queue
-        const int nq = which == 0 ? n0 : n1, base = which == 0 ? 0 : n0;
-        for (;;)
-        {
-            int t = 0;
-            if (lane == 0)
-                t = atomicAdd(&cursors[which], 1);
-            t = __builtin_amdgcn_readfirstlane(t);
-            if (t >= nq || !exact_task(E, n_img, cap, 0, base + t, q))
-                break;
-            run(q);
         }
     }
     EBVO_TRACE_END(0);
@@ -1803,50 +1727,6 @@ int toed_init_constants(ebvo_ctx *ctx)
         }
     if (ctx->device < 0 || ctx->device >= 16)
         return EBVO_ERR_ARG;
-    if (!g_simd_table_dev[ctx->device] && !getenv("EBVO_NO_SIMD_TABLE"))
-    {
-        // which (XCD, SE, CU) ids exist on this device: every wave of a chip-filling launch reports its own
-        unsigned *d_seen = nullptr;
-        unsigned h_seen[64] = {0};
-        int cus = 0;
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
-        bool ok = hipMalloc(&d_seen, sizeof h_seen) == hipSuccess && hipMemset(d_seen, 0, sizeof h_seen) == hipSuccess;
-        if (ok)
-        {
-            hipLaunchKernelGGL(toed_simd_probe_kernel, dim3(8 * (cus > 0 ? cus : 256)), dim3(256), 0, 0, d_seen, 2000 /* 20 us */);
-            ok = hipDeviceSynchronize() == hipSuccess && hipMemcpy(h_seen, d_seen, sizeof h_seen, hipMemcpyDeviceToHost) == hipSuccess;
-        }
-        if (d_seen)
-            (void)hipFree(d_seen);
-        static SimdTable tab;
-        memset(&tab, 0xff, sizeof tab);
-        int total = 0, xcds = 0, per_first = -1;
-        bool even = true;
-        for (int x = 0; x < 16 && ok; ++x)
-        {
-            int r = 0;
-            for (int key = 0; key < 128; ++key)
-                if (h_seen[x * 4 + (key >> 5)] >> (key & 31) & 1u)
-                    tab.rank[x][key] = (uint8_t)r++;
-            if (r)
-            {
-                ++xcds;
-                even = even && (per_first < 0 || per_first == r);
-                per_first = per_first < 0 ? r : per_first;
-            }
-            total += r;
-        }
-        // trust the table only when it accounts for every CU and the XCDs are alike (the dealing gives each XCD the same share)
-        if (ok && total == cus && xcds == 8 && even)
-        {
-            SimdTable *d = nullptr;
-            if (hipMalloc(&d, sizeof(SimdTable)) == hipSuccess && hipMemcpy(d, &tab, sizeof tab, hipMemcpyHostToDevice) == hipSuccess)
-                g_simd_table_dev[ctx->device] = d; // lives for the process
-            else if (d)
-                (void)hipFree(d);
-        }
-        (void)hipGetLastError();
-    }
     if (!g_tables_dev[ctx->device])
     {
         ToedTables *d = nullptr;
@@ -1994,15 +1874,12 @@ int toed_enqueue(ebvo_ctx *ctx, Slot &s, int n_img, int h, int w, hipEvent_t ev_
             const ToedTables *T = (const ToedTables *)g_tables_dev[ctx->device];
             {
                 hipEvent_t k_begin, k_end; // the dominant kernel: timed by its own dispatch when the profiler is on
-                // run queues of the phase-aware dealing: lcount[8], [9] of image 0 (zeroed by toed_rowscan_phase_kernel)
-                const SimdTable *st = ctx->centre_static_deal ? nullptr : g_simd_table_dev[ctx->device];
-                int32_t *cursors = s.im[0].cand_lcount + 8;
                 if (ebvo_prof_kernel(ctx, s, K_EXACT_CENTRE, &k_begin, &k_end))
                     hipExtLaunchKernelGGL(toed_exact_centre_kernel, dim3(resident_blocks(ctx, 0)), dim3(256), 0, s.stream,
-                                          k_begin, k_end, 0, E, T, h, w, cap, n_img, st, cursors);
+                                          k_begin, k_end, 0, E, T, h, w, cap, n_img);
                 else
                     hipLaunchKernelGGL(toed_exact_centre_kernel, dim3(resident_blocks(ctx, 0)), dim3(256), 0, s.stream, E,
-                                       T, h, w, cap, n_img, st, cursors);
+                                       T, h, w, cap, n_img);
             }
             {
                 ProfScope ps(ctx, s, K_COMPACT); // the lists of the distinct neighbour points

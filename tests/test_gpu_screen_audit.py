@@ -26,10 +26,11 @@ def c():
 def both_modes(c, img):
     c.set_toed_mode("hybrid")
     f0 = c.toed_fallbacks
-    hy = c.toed(img, want_all=True)
+    cap = 4 * img.size                              # an image of ties has more maxima than pixels
+    hy = c.toed(img, want_all=True, cap=cap)
     fell_back = c.toed_fallbacks != f0
     c.set_toed_mode("strict")
-    st = c.toed(img, want_all=True)
+    st = c.toed(img, want_all=True, cap=cap)
     c.set_toed_mode("hybrid")
     assert_edges_equal(hy.edges, st.edges)
     assert hy.n_total == st.n_total
@@ -102,7 +103,12 @@ def test_screen_error_on_full_size_saturating_images(big, c, kind):
         assert not fell_back and (a["n_maxima"], a["n_kept"]) == (hy.n_total, len(hy.edges))
         # ... and in the context sized for ordinary images, where an image of ties overflows the candidate buffers: the library
         # falls back to the strict path and returns the same edges
-        hy2, fb2 = both_modes(c, img)
+        try:
+            hy2, fb2 = both_modes(c, img)
+        except _lib.EbvoError as e:                   # more maxima than the small context holds at all (max_h * max_w): both
+            assert e.status == _lib.EBVO_ERR_CAPACITY, e   # modes refuse alike; the roomy context above has covered the image
+            overflowed += 1
+            continue
         assert_edges_equal(hy2.edges, hy.edges)
         overflowed += bool(fb2)
     assert most > 100000, (kind, most)                # the images do exercise the exact stage
@@ -111,8 +117,8 @@ def test_screen_error_on_full_size_saturating_images(big, c, kind):
 
 
 def test_dealing_and_layout_switches_return_the_same_bits(c):
-    """developer switches of round 4 (ebvo_debug_set): 11 = the centre kernel's runs dealt round-robin as in round 3 instead
-    of by phase and SIMD; 12 = the right bank in the packed 7-lane layout; same edges, same scores either way"""
+    """developer switch of round 4 (ebvo_debug_set 12): the right bank and the NCC tile kernel in the packed 7-lane layout;
+    same edges, same scores either way"""
     from edge_based_visual_odometry_amd import synth as sy
     h, w = 376, 1241
     l, r = sy.stereo_pair("s2", h, w)
@@ -121,7 +127,7 @@ def test_dealing_and_layout_switches_return_the_same_bits(c):
     c.stereo_upload(l, r)
     ref_counts = c.stereo_run(p)
     ref = c.stereo_fetch(ref_counts)
-    for key in (11, 12):
+    for key in (12,):
         c.debug_set(key, 1)
         try:
             cnt = c.stereo_run(p)
