@@ -353,7 +353,8 @@ def ingest_loop(ctx, params, ring, nslots, steps, fetch=None):
     does not wait) while step i is still being matched, so that a submission never waits for its images -- what a frame loop
     that reads frame k + 1 while frame k is matched does (src/Pipeline.cpp:77-99, cmd/main_VO.cpp:99-113).  fetch: None, or
     "compact" (ebvo_stereo_fetch_compact_begin / _end: (x, y) pairs, CSR, best, keep bits through page-locked staging, the
-    copy overlaps the other slots' kernels), or an EBVO_FETCH_* selection.  Requires ctx.set_slots(nslots + 1) or more.
+    copy overlaps the other slots' kernels), "push" (the same arrays written by the pair's own chain into page-locked host
+    memory: `params` must carry EBVO_PAIR_PUSH), or an EBVO_FETCH_* selection.  Requires ctx.set_slots(nslots + 1) or more.
     Returns (seconds, bytes fetched per pair)."""
     S = nslots + 1
     t0 = time.perf_counter()
@@ -366,6 +367,8 @@ def ingest_loop(ctx, params, ring, nslots, steps, fetch=None):
         uploaded += 1
 
     def begin(slot):
+        if fetch == "push":                       # nothing to start: the pair's own chain has written the results to host memory
+            return
         if fetch == "compact":
             ctx.stereo_fetch_compact_begin(slot=slot)
         else:
@@ -373,9 +376,10 @@ def ingest_loop(ctx, params, ring, nslots, steps, fetch=None):
 
     def consume(slot):
         nonlocal nbytes
-        out = ctx.stereo_fetch_compact_end(slot=slot) if fetch == "compact" else ctx.stereo_fetch_end(slot=slot)
+        out = (ctx.stereo_pushed_view(slot=slot) if fetch == "push" else
+               ctx.stereo_fetch_compact_end(slot=slot) if fetch == "compact" else ctx.stereo_fetch_end(slot=slot))
         nbytes += sum(v.nbytes for v in out.values() if isinstance(v, np.ndarray))
-        if fetch == "compact":
+        if fetch in ("compact", "push"):
             if int(out["keep_bits"][0]) < 0 or out["n_matches"] > out["n_pairs"]:      # touch the data
                 raise RuntimeError("compact results out of range")
         elif out["keep"] is not None and int(out["keep"][-1]) > 1:
@@ -394,7 +398,9 @@ def ingest_loop(ctx, params, ring, nslots, steps, fetch=None):
         k = done % S
         ctx.stereo_wait(slot=k)
         done += 1
-        if fetch:
+        if fetch == "push":
+            consume(k)                             # already in host memory
+        elif fetch:
             begin(k)                               # k's results start travelling; read at the next turn
             if pending is not None:
                 consume(pending)                   # ... before `pending` (= ahead) is submitted again
@@ -954,15 +960,24 @@ def main():
         ingest = {"value_with_h2d": sharding.job_throughput(world, args.steps, t_ing), "per_rank_pairs_per_s_with_h2d": per_rank_ing}
         if rank == 0 and world == 1 and not args.no_transfer_legs:
             n_leg = max(nslots + 1, min(args.steps, 60))
+            t_sus_ing, _ = ingest_loop(ctx, params, ring, nslots, 300)
             ingest_loop(ctx, params, ring, nslots, nslots + 1, "compact")     # untimed: sizes the page-locked staging
             t_c, mb_c = ingest_loop(ctx, params, ring, nslots, n_leg, "compact")
-            t_sus_ing, _ = ingest_loop(ctx, params, ring, nslots, 300)
-            ingest.update(with_h2d_d2h_compact=n_leg / t_c, d2h_bytes_per_pair_compact=mb_c, value_with_h2d_sustained_300=300 / t_sus_ing)
+            # ... and with the results PUSHED by the pair's own chain (EBVO_PAIR_PUSH): no copy call, no copy stream
+            from edge_based_visual_odometry_amd import _lib as L3
+            params_push = ctx.default_params(F)
+            params_push.reserved = params.reserved | L3.PAIR_PUSH
+            ingest_loop(ctx, params_push, ring, nslots, 4 * (nslots + 1), "push")   # untimed: arenas, graphs of the new flag
+            t_p, mb_p = ingest_loop(ctx, params_push, ring, nslots, n_leg, "push")
+            t_p300, _ = ingest_loop(ctx, params_push, ring, nslots, 300, "push")
+            ingest.update(with_h2d_d2h_compact=n_leg / t_c, d2h_bytes_per_pair_compact=mb_c, value_with_h2d_sustained_300=300 / t_sus_ing,
+                          with_h2d_d2h_push=n_leg / t_p, d2h_bytes_per_pair_push=mb_p, with_h2d_d2h_push_sustained_300=300 / t_p300)
         ingest["ingest_note"] = ("value_with_h2d: the timed loop with a NEW pair per step DMA-ed from a page-locked frame ring "
                                  "(ebvo_host_register, ebvo_stereo_upload_async on the context's upload stream, issued one pair ahead of "
                                  "its submission: nslots pairs in flight on nslots + 1 slots), barriers and MAX over ranks as for "
                                  "`value`; with_h2d_d2h_compact adds the compact result fetch ((x, y) of both edge lists, CSR, fp64 "
-                                 "best, keep as bits) through page-locked staging")
+                                 "best, keep as bits) through page-locked staging; with_h2d_d2h_push: the same arrays written into "
+                                 "page-locked host memory by the pair's own chain (EBVO_PAIR_PUSH, ebvo_stereo_pushed_view)")
         for pair in ring:
             for im in pair:
                 ctx.host_unregister(im)

@@ -35,7 +35,7 @@ TOED_STRICT, TOED_HYBRID = 0, 1
 ABI_SYMBOLS = (
     "ebvo_strerror", "ebvo_last_error", "ebvo_abi_version", "ebvo_ctx_create", "ebvo_ctx_destroy",
     "ebvo_set_toed_mode", "ebvo_get_toed_mode", "ebvo_toed_fallbacks", "ebvo_graph_launches", "ebvo_toed_stats", "ebvo_toed_screen_audit", "ebvo_stereo_upload_async", "ebvo_host_register", "ebvo_host_unregister",
-    "ebvo_stereo_fetch_compact_begin", "ebvo_stereo_fetch_compact_end",
+    "ebvo_stereo_fetch_compact_begin", "ebvo_stereo_fetch_compact_end", "ebvo_stereo_pushed_view",
     "ebvo_toed", "ebvo_toed_pair", "ebvo_epipolar_lines", "ebvo_epi_candidates", "ebvo_epi_candidates_staged", "ebvo_ncc_pairs",
     "ebvo_edge_patches", "ebvo_ncc_patches", "ebvo_ncc_quads", "ebvo_stereo_default_params", "ebvo_finalize_default_params",
     "ebvo_stereo_upload", "ebvo_stereo_run", "ebvo_stereo_fetch", "ebvo_stereo_set_slots",
@@ -56,6 +56,7 @@ class StereoParams(C.Structure):
                 ("reserved", C.c_int)]
 
 
+PAIR_PUSH, PAIR_PUSH_THETA = 2, 4   # ... the chain ends by writing the compact results into page-locked host memory
 PAIR_NO_SIMS = 1     # StereoParams.reserved: the resident pipeline stores best + keep only (ebvo_hip.h EBVO_PAIR_NO_SIMS)
 
 
@@ -214,6 +215,7 @@ def load_library() -> C.CDLL:
     lib.ebvo_host_unregister.argtypes = [vp, vp]
     lib.ebvo_stereo_fetch_compact_begin.argtypes = [vp, i32, i32]
     lib.ebvo_stereo_fetch_compact_end.argtypes = [vp, i32, C.POINTER(CompactView)]
+    lib.ebvo_stereo_pushed_view.argtypes = [vp, i32, C.POINTER(CompactView)]
     lib.ebvo_stereo_wait.argtypes = [vp, i32, C.POINTER(StereoCounts)]
     lib.ebvo_stereo_fetch_slot.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.ebvo_profile_enable.argtypes = [vp, i32]

@@ -644,10 +644,20 @@ class Context:
     def stereo_fetch_compact_begin(self, slot: int = 0, what: int = _lib.COMPACT_DEFAULT):
         self._check(self.lib.ebvo_stereo_fetch_compact_begin(self._ctx, slot, what), "ebvo_stereo_fetch_compact_begin")
 
+    def stereo_pushed_view(self, slot: int = 0) -> dict:
+        """the compact results a pair submitted with PAIR_PUSH left in the slot's page-locked arena (no copy, no wait)"""
+        v = _lib.CompactView()
+        self._check(self.lib.ebvo_stereo_pushed_view(self._ctx, slot, C.byref(v)), "ebvo_stereo_pushed_view")
+        return self._compact_dict(v)
+
     def stereo_fetch_compact_end(self, slot: int = 0) -> dict:
         """numpy VIEWS of the compact arrays: (x, y) pairs, orientations, CSR, best, keep as a bit mask (bit k & 31 of word k >> 5)"""
         v = _lib.CompactView()
         self._check(self.lib.ebvo_stereo_fetch_compact_end(self._ctx, slot, C.byref(v)), "ebvo_stereo_fetch_compact_end")
+        return self._compact_dict(v)
+
+    @staticmethod
+    def _compact_dict(v) -> dict:
 
         def view(ptr_, count, dtype):
             if not ptr_:

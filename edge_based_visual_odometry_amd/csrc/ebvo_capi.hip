@@ -1134,6 +1134,7 @@ extern "C" int ebvo_stereo_upload_slot(ebvo_ctx *ctx, int slot, const uint8_t *i
     if (s.in_flight || s.fin_in_flight || s.tq_in_flight)
         return EBVO_ERR_STATE;
     s.have_pair = s.have_run = s.have_refined = s.have_final = false; // results of the previous pair are gone
+    s.have_push = false;
     if (slot == 0)
         ctx->sw_tag[0] = ctx->sw_tag[1] = 0; // ... and so are the TOED results of the resident stage-wise calls
     s.tq_n = -1;
@@ -1739,7 +1740,9 @@ extern "C" int ebvo_stereo_wait(ebvo_ctx *ctx, int slot, ebvo_stereo_counts *cou
         }
         // more candidates than the buffers hold: grow them and redo the matching half (TOED results are intact)
         int64_t want = r.n_pairs + r.n_pairs / 4 + 1024;
-        if ((rc = ensure_pipeline_buffers(ctx, s, want)) || (rc = enqueue_matching(ctx, s)))
+        if ((rc = ensure_pipeline_buffers(ctx, s, want)) ||
+            ((s.params.reserved & EBVO_PAIR_PUSH) && (rc = ensure_push_arena(ctx, s, s.params.reserved & EBVO_PAIR_PUSH_THETA))) ||
+            (rc = enqueue_matching(ctx, s)) || (rc = enqueue_push(ctx, s)))
         {
             s.in_flight = false;
             return rc;
@@ -1767,6 +1770,37 @@ extern "C" int ebvo_stereo_wait(ebvo_ctx *ctx, int slot, ebvo_stereo_counts *cou
     counts->n_pairs = s.result.n_pairs;
     counts->n_matches = s.result.n_matches;
     s.have_run = true;
+    s.have_push = (s.params.reserved & EBVO_PAIR_PUSH) != 0;
+    return EBVO_OK;
+}
+
+// the compact results a pair submitted with EBVO_PAIR_PUSH left in the slot's page-locked arena: valid from the pair's
+// ebvo_stereo_wait until the slot's next submission
+extern "C" int ebvo_stereo_pushed_view(ebvo_ctx *ctx, int slot, ebvo_stereo_compact_view *view)
+{
+    Slot *sp;
+    if (!view || get_slot(ctx, slot, &sp))
+        return EBVO_ERR_ARG;
+    Slot &s = *sp;
+    if (s.in_flight || !s.have_push || !s.h_push)
+        return EBVO_ERR_STATE;
+    const char *b = static_cast<const char *>(s.h_push);
+    memset(view, 0, sizeof *view);
+    view->n_left = s.result.n_left;
+    view->n_right = s.result.n_right;
+    view->n_pairs = s.result.n_pairs;
+    view->n_matches = s.result.n_matches;
+    view->left_xy = reinterpret_cast<const double *>(b + s.push_off[0]);
+    view->right_xy = reinterpret_cast<const double *>(b + s.push_off[1]);
+    if (s.params.reserved & EBVO_PAIR_PUSH_THETA)
+    {
+        view->left_theta = reinterpret_cast<const double *>(b + s.push_off[2]);
+        view->right_theta = reinterpret_cast<const double *>(b + s.push_off[3]);
+    }
+    view->row_ptr = reinterpret_cast<const int32_t *>(b + s.push_off[4]);
+    view->col_idx = reinterpret_cast<const int32_t *>(b + s.push_off[5]);
+    view->best = reinterpret_cast<const double *>(b + s.push_off[6]);
+    view->keep_bits = reinterpret_cast<const uint32_t *>(b + s.push_off[7]);
     return EBVO_OK;
 }
 
@@ -3833,8 +3867,6 @@ extern "C" int ebvo_debug_set(ebvo_ctx *ctx, int key, int value)
         ctx->use_graphs = value; // the pair chain as a hipGraph (default) or as direct launches
     else if (key == 13 && value <= 1)
         ctx->ingest_stream = value;
-    else if (key == 12 && value <= 1)
-        ctx->bank_packed = value;
     else if (key == 0)
         ctx->wait_attempts = value;
     else if (key == 1)

@@ -1224,90 +1224,6 @@ __device__ inline void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-// ---- packed layout (round 4): NINE 7-lane groups per wave instead of seven rows in eight lanes ---------------------------
-// A patch has 7 rows; with a row per lane and 8- or 16-lane groups one lane in eight never works (56 of 64).  Here lane
-// l < 63 is row l % 7 of group l / 7, lane 63 idles (63 of 64).  The 8-lane DPP butterfly does not fit 7-lane groups that
-// straddle the 16-lane DPP rows, so the seven row partials travel through LDS: every lane writes its partial, reads the seven of
-// its group and adds them in the canonical order of butterfly8 -- ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + 0)) -- same bits,
-// six additions and five LDS instructions instead of nine VALU instructions.
-__device__ inline int lane_group7(int lane) { return (lane * 37) >> 8; } // lane / 7 for lane < 64
-
-__device__ inline double group7_sum(double *slot /* [72] of this wave */, int lane, int g, double v)
-{
-    slot[lane] = v;
-    wave_lds_sync();
-    const double *q = slot + g * 7;
-    return ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + 0.0));
-}
-
-// normalise_rows for the packed layout; sa / sb: two exchange slots of this wave (alternating, so that a slot is rewritten
-// only after every lane has read it)
-__device__ inline bool normalise_rows7(bool active, const float p[7], float nrm[7], double *sa, double *sb, int lane, int g)
-{
-    double rs = 0.0;
-    if (active)
-    {
-        rs = (double)p[0];
-#pragma unroll
-        for (int c = 1; c < 7; ++c)
-            rs += (double)p[c];
-    }
-    const double mean = group7_sum(sa, lane, g, rs) / 49.0;
-    const float m = (float)mean;
-    float d[7];
-    double qs = 0.0;
-    if (active)
-    {
-#pragma unroll
-        for (int c = 0; c < 7; ++c)
-        {
-            d[c] = p[c] - m;
-            const float q = d[c] * d[c];
-            qs = (c == 0) ? (double)q : qs + (double)q;
-        }
-    }
-    const double ss = group7_sum(sb, lane, g, qs);
-    const float inv = (float)(1.0 / sqrt(ss));
-#pragma unroll
-    for (int c = 0; c < 7; ++c)
-        nrm[c] = active ? d[c] * inv : 0.0f;
-    return ss < 1e-10;
-}
-
-// right_bank_kernel in the packed layout: a wave takes 9 side-patches (4.5 edges) per turn
-__global__ __launch_bounds__(256) void right_bank_packed_kernel(const uint8_t *__restrict__ img, const uint16_t *__restrict__ pix2, int h,
-                                                                int w, int pitch, const ebvo_edge *__restrict__ edges,
-                                                                const double2 *__restrict__ sc, DevN nd, float *__restrict__ bank)
-{
-    __shared__ double s_ex[4][2][72];
-    const int n = devn(nd);
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int g = lane_group7(lane), row = lane - 7 * g;
-    const int waves = gridDim.x * 4;
-    const int turns = (2 * n + 9 * waves - 1) / (9 * waves); // wave-uniform trip count
-    for (int it = 0; it < turns; ++it)
-    {
-        const int sp = (it * waves + blockIdx.x * 4 + wv) * 9 + g; // side-patch: edge sp / 2, side sp % 2
-        const int e = sp >> 1, side = sp & 1;
-        const bool active = g < 9 && e < n;
-        float p[7], nr[7];
-#pragma unroll
-        for (int c = 0; c < 7; ++c)
-            p[c] = 0.0f;
-        {
-            const int ec = active ? e : 0;
-            sample_row<true>(img, h, w, pitch, edges[ec].x, edges[ec].y, sc[ec].x, sc[ec].y, side, row, p, active, pix2);
-        }
-        const bool sent = normalise_rows7(active, p, nr, s_ex[wv][0], s_ex[wv][1], lane, g);
-        if (active)
-        {
-            float4 *dst = reinterpret_cast<float4 *>(bank + (size_t)e * BANK_EDGE + side * BANK_SIDE + row * 8);
-            dst[0] = make_float4(nr[0], nr[1], nr[2], nr[3]);
-            dst[1] = make_float4(nr[4], nr[5], nr[6], sent ? 1.0f : 0.0f);
-        }
-    }
-}
-
 // One WAVE owns NW consecutive left edges (a contiguous range of CSR pairs): no workgroup barrier anywhere, so waves in
 // their sampling phase and waves in their scoring phase overlap freely on a SIMD.
 template <int NW, int WPE>
@@ -2103,164 +2019,6 @@ int match_ncc_pairs_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_imgR, int h
 
 // NCC of the CSR pairs in s.row_ptr / s.col_idx of the resident pair: sin/cos of both edge lists, the right bank, the
 // tile kernel.  s.patches_norm_r holds the right bank (BANK_EDGE floats per edge).
-// ncc_tile_kernel in the packed layout (see lane_group7): a wave owns NW = 9 left edges = 18 side-patches = two sampling turns of
-// nine 7-lane groups, and scores NINE pairs per turn, seven lanes per pair (lane = row of all four patches); the four
-// 49-term dots are reduced through LDS in butterfly8's order.  Same arithmetic, same bits as ncc_tile_kernel.
-template <int NW, int WPE>
-__global__ __launch_bounds__(256, WPE) void ncc_tile7_kernel(const uint8_t *__restrict__ imgL, const uint16_t *__restrict__ pix2L, int h,
-                                                             int w, int pitch, const ebvo_edge *__restrict__ L,
-                                                             const double2 *__restrict__ scL, DevN nLd,
-                                                             const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ col_idx,
-                                                             const float *__restrict__ rbank, int64_t cap, double thr,
-                                                             double *__restrict__ sims, double *__restrict__ best,
-                                                             uint8_t *__restrict__ keep, int32_t *__restrict__ match_part)
-{
-    static_assert(NW == 9, "two sampling turns of nine side-patches");
-    __shared__ __attribute__((aligned(16))) float s_left_all[4][NW * 2 * 7 * 8];
-    __shared__ double s_ex_all[4][4][72];
-    __shared__ int s_mc;
-    const int nL = devn(nLd);
-    const int ntiles = (nL + NW - 1) / NW;
-    const int per_xcd = (ntiles + 7) >> 3;
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
-    const int t_begin = xcd * per_xcd, t_end = t_begin + per_xcd < ntiles ? t_begin + per_xcd : ntiles;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int g = lane_group7(lane), row = lane - 7 * g;
-    float *s_left = s_left_all[wave];
-    double(*s_ex)[72] = s_ex_all[wave];
-    if (threadIdx.x == 0)
-        s_mc = 0;
-    int mc = 0;
-    for (int tile = t_begin + slot * 4 + wave; tile < t_end; tile += slots * 4)
-    {
-        const int e0 = tile * NW;
-        const int rows = nL - e0 < NW ? nL - e0 : NW;
-        int rp_l = 0;
-        if (lane <= NW)
-        {
-            const int64_t v = row_ptr[e0 + (lane < rows ? lane : rows)];
-            rp_l = (int)(v < cap ? v : cap);
-        }
-        // phase 1: the tile's left patches, two turns of nine side-patches
-#pragma unroll 1
-        for (int q = 0; q < 2; ++q)
-        {
-            const int sp = q * 9 + g, el = sp >> 1, side = sp & 1, e = e0 + el;
-            const bool active = g < 9 && el < rows;
-            float p[7], nr[7];
-#pragma unroll
-            for (int c = 0; c < 7; ++c)
-                p[c] = 0.0f;
-            {
-                const int ec = active ? e : 0;
-                sample_row<true>(imgL, h, w, pitch, L[ec].x, L[ec].y, scL[ec].x, scL[ec].y, side, row, p, active, pix2L);
-            }
-            const bool sent = normalise_rows7(active, p, nr, s_ex[0], s_ex[1], lane, g);
-            if (active)
-            {
-                float4 *dst = reinterpret_cast<float4 *>(&s_left[((el * 2 + side) * 7 + row) * 8]);
-                dst[0] = make_float4(nr[0], nr[1], nr[2], nr[3]);
-                dst[1] = make_float4(nr[4], nr[5], nr[6], sent ? 1.0f : 0.0f);
-            }
-        }
-        wave_lds_sync();
-        int rps[NW + 1];
-#pragma unroll
-        for (int t = 0; t <= NW; ++t)
-            rps[t] = __builtin_amdgcn_readlane(rp_l, t);
-        const int k0 = rps[0], k1 = rps[NW];
-        // phase 2: nine pairs per turn, seven lanes per pair
-        for (int kb = k0; kb < k1; kb += 9)
-        {
-            const int k = kb + g;
-            const bool active = g < 9 && k < k1;
-            int el = 0;
-#pragma unroll
-            for (int t = 1; t < NW; ++t)
-                el += (t < rows && k >= rps[t]) ? 1 : 0;
-            float4 a0 = make_float4(0, 0, 0, 0), a1 = a0, b0 = a0, b1 = a0, p0 = a0, p1 = a0, m0 = a0, m1 = a0;
-            if (active)
-            {
-                const int ri = col_idx[k];
-                const float4 *rr = reinterpret_cast<const float4 *>(rbank + (size_t)ri * BANK_EDGE + row * 8);
-                a0 = rr[0];
-                a1 = rr[1];
-                b0 = rr[BANK_SIDE / 4];
-                b1 = rr[BANK_SIDE / 4 + 1];
-                const float4 *lp4 = reinterpret_cast<const float4 *>(&s_left[((el * 2 + 0) * 7 + row) * 8]);
-                const float4 *lm4 = reinterpret_cast<const float4 *>(&s_left[((el * 2 + 1) * 7 + row) * 8]);
-                p0 = lp4[0];
-                p1 = lp4[1];
-                m0 = lm4[0];
-                m1 = lm4[1];
-            }
-            const float rp_[7] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z};
-            const float rm_[7] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z};
-            const float lp[7] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z};
-            const float lm[7] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z};
-            double s_pp, s_nn, s_pn, s_np;
-            {
-                const double lpd = (double)lp[0], lmd = (double)lm[0], rpd = (double)rp_[0], rmd = (double)rm_[0];
-                s_pp = lpd * rpd;
-                s_nn = lmd * rmd;
-                s_pn = lpd * rmd;
-                s_np = lmd * rpd;
-            }
-#pragma unroll
-            for (int c = 1; c < 7; ++c)
-            {
-                const double lpd = (double)lp[c], lmd = (double)lm[c], rpd = (double)rp_[c], rmd = (double)rm_[c];
-                s_pp = __builtin_fma(lpd, rpd, s_pp);
-                s_nn = __builtin_fma(lmd, rmd, s_nn);
-                s_pn = __builtin_fma(lpd, rmd, s_pn);
-                s_np = __builtin_fma(lmd, rpd, s_np);
-            }
-            // the four reductions through LDS: four writes, one exchange point, 28 reads (butterfly8's order)
-            s_ex[0][lane] = active ? s_pp : 0.0;
-            s_ex[1][lane] = active ? s_nn : 0.0;
-            s_ex[2][lane] = active ? s_pn : 0.0;
-            s_ex[3][lane] = active ? s_np : 0.0;
-            wave_lds_sync();
-            double d4[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-            {
-                const double *q = s_ex[r] + g * 7;
-                d4[r] = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + 0.0));
-            }
-            wave_lds_sync(); // the next turn rewrites the slots
-            if (active && row == 0)
-            {
-                const bool lsent_p = p1.w != 0.0f, lsent_m = m1.w != 0.0f;
-                const bool rsent_p = a1.w != 0.0f, rsent_m = b1.w != 0.0f;
-                const double pp = (lsent_p || rsent_p) ? -1.0 : d4[0];
-                const double nn = (lsent_m || rsent_m) ? -1.0 : d4[1];
-                const double pn = (lsent_p || rsent_m) ? -1.0 : d4[2];
-                const double npv = (lsent_m || rsent_p) ? -1.0 : d4[3];
-                const double b = max4(pp, nn, pn, npv);
-                if (sims)
-                {
-                    double4 *sp = reinterpret_cast<double4 *>(sims + (size_t)k * 4);
-                    *sp = make_double4(pp, nn, pn, npv);
-                }
-                best[k] = b;
-                const bool m = b > thr;
-                keep[k] = m ? 1 : 0;
-                mc += m ? 1 : 0;
-            }
-        }
-        wave_lds_sync();
-    }
-    for (int d = 32; d > 0; d >>= 1)
-        mc += __shfl_down(mc, d);
-    __syncthreads();
-    if (lane == 0 && mc)
-        atomicAdd(&s_mc, mc);
-    __syncthreads();
-    if (threadIdx.x == 0)
-        match_part[blockIdx.x] = s_mc;
-}
-
 int match_ncc_resident_enqueue(ebvo_ctx *ctx, Slot &s, int h, int w, int cap_edges, double thr, int left, bool want_sims)
 {
     int rc;
@@ -2281,11 +2039,6 @@ int match_ncc_resident_enqueue(ebvo_ctx *ctx, Slot &s, int h, int w, int cap_edg
         hipLaunchKernelGGL(row_pairs_kernel, dim3(blocks_for(((int64_t)h * w + 3) / 4, 256, 512), 2), dim3(256), 0, s.stream,
                            ncc_img(s, 0), ncc_img(s, 1), s.im[0].pix2, s.im[1].pix2, h, w);
         hipLaunchKernelGGL(sincos_batch_kernel, dim3(blocks_for(cap_edges, 256, 512), 2), dim3(256), 0, s.stream, B);
-        if (ctx->bank_packed) // developer key 12: nine 7-lane groups per wave (63 of 64 lanes) instead of rows in 16-lane groups
-            hipLaunchKernelGGL(right_bank_packed_kernel, dim3(blocks_for((int64_t)cap_edges * 16, 256, 1024)), dim3(256), 0, s.stream,
-                               ncc_img(s, iR), (const uint16_t *)s.im[iR].pix2, h, w, w, (const ebvo_edge *)s.im[iR].edges,
-                               (const double2 *)B.sc[iR], nRd, (float *)s.patches_norm_r.p);
-        else
         hipLaunchKernelGGL(right_bank_kernel, dim3(blocks_for((int64_t)cap_edges * 16, 256, 1024)), dim3(256), 0, s.stream,
                            ncc_img(s, iR), (const uint16_t *)s.im[iR].pix2, h, w, w, (const ebvo_edge *)s.im[iR].edges,
                            (const double2 *)B.sc[iR], nRd, (float *)s.patches_norm_r.p);
@@ -2297,18 +2050,6 @@ int match_ncc_resident_enqueue(ebvo_ctx *ctx, Slot &s, int h, int w, int cap_edg
         s.n_match_part = nblk;
         // NW = 4 left edges per wave, at most 5 waves per SIMD: measured best of {4, 8, 16} x {4, 5, 6, 8} (a bigger tile
         // serialises more sampling rounds in one wave; a higher occupancy target spills)
-        if (ctx->bank_packed)
-        {
-            int nb7 = (int)blocks_for(cap_edges, 9 * 4, EBVO_MATCH_PARTS);
-            nb7 = nb7 < 8 ? 8 : (nb7 & ~7);
-            s.n_match_part = nb7;
-            hipLaunchKernelGGL((ncc_tile7_kernel<9, NCC_WPE>), dim3(nb7), dim3(256), 0, s.stream, ncc_img(s, iL),
-                               (const uint16_t *)s.im[iL].pix2, h, w, w, (const ebvo_edge *)s.im[iL].edges, (const double2 *)B.sc[iL],
-                               nLd, (const int32_t *)s.row_ptr.p, (const int32_t *)s.col_idx.p, (const float *)s.patches_norm_r.p,
-                               s.cap_pairs, thr, want_sims ? (double *)s.sims.p : nullptr, (double *)s.best.p, (uint8_t *)s.keep.p,
-                               s.d_matches);
-        }
-        else
         hipLaunchKernelGGL((ncc_tile_kernel<NCC_NW, NCC_WPE>), dim3(nblk), dim3(256), 0, s.stream, ncc_img(s, iL),
                            (const uint16_t *)s.im[iL].pix2, h, w, w, (const ebvo_edge *)s.im[iL].edges, (const double2 *)B.sc[iL],
                            nLd, (const int32_t *)s.row_ptr.p, (const int32_t *)s.col_idx.p, (const float *)s.patches_norm_r.p,

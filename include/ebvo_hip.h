@@ -34,7 +34,7 @@ extern "C" {
 #define EBVO_ABI_VERSION 6 /* 2: photometric refinement, stage glue, finalisation, resident chain; 3: pinned result views,
                               undistortion, SIFT descriptors, SIFT stages of the chain; 4: the temporal chain after the
                               NCC filter (ebvo_temporal_params / _counts grew, ebvo_temporal_fetch_final); 5: the resident
-                              stage-wise calls (ebvo_toed_resident, ebvo_epi_candidates_resident, ebvo_ncc_pairs_resident); 6: ebvo_toed_screen_audit, ebvo_stereo_upload_async, ebvo_host_register, ebvo_stereo_fetch_compact_begin / _end */
+                              stage-wise calls (ebvo_toed_resident, ebvo_epi_candidates_resident, ebvo_ncc_pairs_resident); 6: ebvo_toed_screen_audit, ebvo_stereo_upload_async, ebvo_host_register, ebvo_stereo_fetch_compact_begin / _end, ebvo_stereo_pushed_view */
 
 typedef struct ebvo_ctx ebvo_ctx;
 
@@ -565,13 +565,20 @@ typedef struct ebvo_stereo_params
     double F21[9]; /* row-major fundamental matrix, Dataset::get_fund_mat_21 */
     double epi_thr, max_disp, orient_thr_deg, ncc_thr;
     int stage_mask;
-    int reserved; /* flags: 0, or EBVO_PAIR_NO_SIMS */
+    int reserved; /* flags: 0, or EBVO_PAIR_NO_SIMS | EBVO_PAIR_PUSH | EBVO_PAIR_PUSH_THETA */
 } ebvo_stereo_params;
 /* ebvo_stereo_params.reserved = EBVO_PAIR_NO_SIMS: the resident pipeline stores, per candidate pair, the final score (the
  * maximum of the four similarities: what the reference keeps, refine_final_scores, src/Stereo_Matches.cpp:596-600) and the
  * keep flag, not the four similarities themselves (32 of the 41 bytes the NCC stage writes per pair).  The arithmetic is the
  * same; asking for `sims` of such a pair is EBVO_ERR_STATE. */
 #define EBVO_PAIR_NO_SIMS 1
+/* EBVO_PAIR_PUSH: the pair's chain ENDS with a kernel that writes the compact results (the arrays of
+ * ebvo_stereo_fetch_compact_begin's default selection; + EBVO_PAIR_PUSH_THETA: the orientations too) straight into a page-locked
+ * arena of the slot, over PCIe: when ebvo_stereo_wait returns they are in host memory -- no copy call, no second stream, no event.
+ * ebvo_stereo_pushed_view hands out the pointers; they stay valid until the slot's next submission.  What a frame loop that
+ * consumes the first NCC pass on the host wants (src/Stereo_Matches.cpp:1427 onwards run there). */
+#define EBVO_PAIR_PUSH 2
+#define EBVO_PAIR_PUSH_THETA 4
 
 typedef struct ebvo_stereo_counts
 {
@@ -670,6 +677,7 @@ typedef struct ebvo_stereo_compact_view
     int32_t n_left, n_right;
     int64_t n_pairs, n_matches;
 } ebvo_stereo_compact_view; /* pointers of arrays that were not selected are NULL */
+int ebvo_stereo_pushed_view(ebvo_ctx *ctx, int slot, ebvo_stereo_compact_view *view); /* after a pair submitted with EBVO_PAIR_PUSH */
 int ebvo_stereo_fetch_compact_begin(ebvo_ctx *ctx, int slot, int what);
 int ebvo_stereo_fetch_compact_end(ebvo_ctx *ctx, int slot, ebvo_stereo_compact_view *view);
 

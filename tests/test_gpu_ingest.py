@@ -196,3 +196,40 @@ def test_both_forms_of_the_asynchronous_upload(c, stream_form):
         for pair in wide:
             for im in pair:
                 c.host_unregister(im)
+
+
+@pytest.mark.parametrize("theta", [False, True])
+def test_pushed_results_equal_full_fetch(c, theta):
+    """EBVO_PAIR_PUSH: the pair's chain writes the compact results into page-locked host memory itself; what the host finds there
+    after ebvo_stereo_wait equals the full fetch -- over direct launches, the captured graph, a regrown pair buffer"""
+    ring = _ring(3)
+    ref = _reference(c, ring)
+    p = c.default_params(F)
+    p.reserved = _lib.PAIR_PUSH | _lib.PAIR_NO_SIMS | (_lib.PAIR_PUSH_THETA if theta else 0)
+    for rep in range(5):                               # the third submission of a slot is a graph launch
+        for k, (l, r) in enumerate(ring):
+            c.stereo_upload(l, r, slot=1)
+            if rep == 3 and k == 1:
+                c.debug_set(1, 1)                      # the next result is treated as overflowed: matching half re-enqueued, arena kept in step
+            c.stereo_submit(p, slot=1)
+            cnt = c.stereo_wait(slot=1)
+            v = c.stereo_pushed_view(slot=1)
+            full = ref[k][1]
+            assert (v["n_pairs"], v["n_matches"]) == (cnt.n_pairs, cnt.n_matches) == (ref[k][0].n_pairs, ref[k][0].n_matches)
+            for side in ("left", "right"):
+                assert_bit_equal(v[side + "_xy"][:, 0], full[side]["x"], side + ".x")
+                assert_bit_equal(v[side + "_xy"][:, 1], full[side]["y"], side + ".y")
+                if theta:
+                    assert_bit_equal(v[side + "_theta"], full[side]["theta"], side + ".theta")
+                else:
+                    assert v[side + "_theta"] is None
+            assert_bit_equal(v["row_ptr"], full["row_ptr"], "row_ptr")
+            assert_bit_equal(v["col_idx"], full["col_idx"], "col_idx")
+            assert_bit_equal(v["best"], full["best"], "best")
+            bits = np.unpackbits(v["keep_bits"].view(np.uint8), bitorder="little")[: cnt.n_pairs]
+            assert_bit_equal(bits, full["keep"], "keep bits")
+    p.reserved = 0                                     # a pair without the flag leaves no pushed view
+    c.stereo_submit(p, slot=1)
+    c.stereo_wait(slot=1)
+    with pytest.raises(_lib.EbvoError):
+        c.stereo_pushed_view(slot=1)

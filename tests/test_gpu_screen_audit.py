@@ -114,29 +114,3 @@ def test_screen_error_on_full_size_saturating_images(big, c, kind):
     assert most > 100000, (kind, most)                # the images do exercise the exact stage
     print(f"{kind}: worst |screen - exact| gx {worst['gx']:.3e} gy {worst['gy']:.3e} |g| {worst['mag']:.3e} "
           f"neighbours {worst['nb']:.3e}; most candidates {most}; {overflowed} of 19 periods overflow a 512 x 1280 context")
-
-
-def test_dealing_and_layout_switches_return_the_same_bits(c):
-    """developer switch of round 4 (ebvo_debug_set 12): the right bank and the NCC tile kernel in the packed 7-lane layout;
-    same edges, same scores either way"""
-    from edge_based_visual_odometry_amd import synth as sy
-    h, w = 376, 1241
-    l, r = sy.stereo_pair("s2", h, w)
-    F = sy.fundamental_for("kitti")
-    p = c.default_params(F)
-    c.stereo_upload(l, r)
-    ref_counts = c.stereo_run(p)
-    ref = c.stereo_fetch(ref_counts)
-    for key in (12,):
-        c.debug_set(key, 1)
-        try:
-            cnt = c.stereo_run(p)
-            out = c.stereo_fetch(cnt)
-        finally:
-            c.debug_set(key, 0)
-        assert (cnt.n_left, cnt.n_right, cnt.n_pairs, cnt.n_matches) == (ref_counts.n_left, ref_counts.n_right,
-                                                                        ref_counts.n_pairs, ref_counts.n_matches), key
-        assert_edges_equal(out["left"], ref["left"])
-        assert_edges_equal(out["right"], ref["right"])
-        for k in ("row_ptr", "col_idx", "sims", "best", "keep"):
-            assert_bit_equal(out[k], ref[k], f"key {key}: {k}")

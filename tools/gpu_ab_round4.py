@@ -1,5 +1,4 @@
 """A/B of round 4's switches on ONE box (run ON the GPU box): the resident pair loop and the streamed-ingest loop with
-  key 12 = 1  the right bank and the NCC tile kernel in the packed 7-lane layout,
   key 13 = 1  ebvo_stereo_upload_async through the upload stream instead of the pull kernel,
   NO_SIMS off the four similarities stored (round 3),
 each against the defaults, interleaved and repeated (box-to-box and minute-to-minute drift is ~1 %)."""
@@ -54,7 +53,7 @@ def ingest(params, n, fetch=None):
 
 
 resident(p_nosims, 600)                      # clocks up
-configs = [("default", None, p_nosims), ("packed layout (12)", 12, p_nosims),
+configs = [("default", None, p_nosims),
            ("sims stored", None, p_full)]
 rows = {name: [] for name, _, _ in configs}
 for rep in range(4):
