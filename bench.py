@@ -970,6 +970,13 @@ def main():
             ingest_loop(ctx, params_push, ring, nslots, 4 * (nslots + 1), "push")   # untimed: arenas, graphs of the new flag
             t_p, mb_p = ingest_loop(ctx, params_push, ring, nslots, n_leg, "push")
             t_p300, _ = ingest_loop(ctx, params_push, ring, nslots, 300, "push")
+            # ... or PACKED by the chain into device staging and fetched by ONE copy of the copy engine (EBVO_PAIR_PACK)
+            params_pack = ctx.default_params(F)
+            params_pack.reserved = params.reserved | L3.PAIR_PACK
+            ingest_loop(ctx, params_pack, ring, nslots, 4 * (nslots + 1), "compact")
+            t_k, mb_k = ingest_loop(ctx, params_pack, ring, nslots, n_leg, "compact")
+            t_k300, _ = ingest_loop(ctx, params_pack, ring, nslots, 300, "compact")
+            ingest.update(with_h2d_d2h_pack=n_leg / t_k, d2h_bytes_per_pair_pack=mb_k, with_h2d_d2h_pack_sustained_300=300 / t_k300)
             ingest.update(with_h2d_d2h_compact=n_leg / t_c, d2h_bytes_per_pair_compact=mb_c, value_with_h2d_sustained_300=300 / t_sus_ing,
                           with_h2d_d2h_push=n_leg / t_p, d2h_bytes_per_pair_push=mb_p, with_h2d_d2h_push_sustained_300=300 / t_p300)
         ingest["ingest_note"] = ("value_with_h2d: the timed loop with a NEW pair per step DMA-ed from a page-locked frame ring "
@@ -977,7 +984,8 @@ def main():
                                  "its submission: nslots pairs in flight on nslots + 1 slots), barriers and MAX over ranks as for "
                                  "`value`; with_h2d_d2h_compact adds the compact result fetch ((x, y) of both edge lists, CSR, fp64 "
                                  "best, keep as bits) through page-locked staging; with_h2d_d2h_push: the same arrays written into "
-                                 "page-locked host memory by the pair's own chain (EBVO_PAIR_PUSH, ebvo_stereo_pushed_view)")
+                                 "page-locked host memory by the pair's own chain (EBVO_PAIR_PUSH, ebvo_stereo_pushed_view); with_h2d_d2h_pack: packed by "
+                                 "the chain into device staging and fetched by one copy (EBVO_PAIR_PACK)")
         for pair in ring:
             for im in pair:
                 ctx.host_unregister(im)

@@ -56,6 +56,7 @@ class StereoParams(C.Structure):
                 ("reserved", C.c_int)]
 
 
+PAIR_PACK = 8                         # ... into device staging: the compact fetch is one copy
 PAIR_PUSH, PAIR_PUSH_THETA = 2, 4   # ... the chain ends by writing the compact results into page-locked host memory
 PAIR_NO_SIMS = 1     # StereoParams.reserved: the resident pipeline stores best + keep only (ebvo_hip.h EBVO_PAIR_NO_SIMS)
 

@@ -369,6 +369,9 @@ extern "C" void ebvo_ctx_destroy(ebvo_ctx *ctx)
         slot_destroy(s);
     if (ctx->upload_stream)
         (void)hipStreamDestroy(ctx->upload_stream);
+    for (const ebvo_ctx::HostRange &r : ctx->host_ranges) // (the caller should have unregistered them)
+        if (r.ours)
+            (void)hipHostUnregister(const_cast<uint8_t *>(r.host));
     for (hipStream_t st : ctx->lane_streams)
         (void)hipStreamDestroy(st);
     if (ctx->copy_stream)
@@ -1189,26 +1192,22 @@ extern "C" int ebvo_stereo_upload_async(ebvo_ctx *ctx, int slot, const uint8_t *
     {
         // pull form: both images entirely in page-locked memory the device can address?  Then the pair's own chain reads them
         // (its first kernel; the pointers go through the slot's mailbox) -- no copy engine, no second stream, no event: nothing
-        // that could queue behind another pair's kernels.  The call costs two attribute queries.
+        // that could queue behind another pair's kernels.  Page-locked = inside a range registered with ebvo_host_register.
         const uint8_t *imgs[2] = {img_left, img_right};
         const ptrdiff_t strides[2] = {stride_left, stride_right};
         const uint8_t *dev[2] = {nullptr, nullptr};
         bool pinned = true;
         for (int k = 0; k < 2 && pinned; ++k)
         {
-            const uint8_t *ends[2] = {imgs[k], imgs[k] + (size_t)(h - 1) * strides[k] + (w - 1)};
-            for (int q = 0; q < 2 && pinned; ++q)
-            {
-                hipPointerAttribute_t a;
-                memset(&a, 0, sizeof a);
-                if (hipPointerGetAttributes(&a, ends[q]) != hipSuccess || a.type != hipMemoryTypeHost || !a.devicePointer)
+            const size_t span = (size_t)(h - 1) * (size_t)strides[k] + (size_t)w;
+            pinned = false;
+            for (const ebvo_ctx::HostRange &r : ctx->host_ranges)
+                if (imgs[k] >= r.host && imgs[k] + span <= r.host + r.bytes)
                 {
-                    (void)hipGetLastError();
-                    pinned = false;
+                    dev[k] = r.dev + (imgs[k] - r.host);
+                    pinned = true;
+                    break;
                 }
-                else if (q == 0)
-                    dev[k] = static_cast<const uint8_t *>(a.devicePointer);
-            }
         }
         if (pinned)
         {
@@ -1255,7 +1254,35 @@ extern "C" int ebvo_host_register(ebvo_ctx *ctx, void *p, size_t bytes)
     if (!ctx || !p || !bytes)
         return EBVO_ERR_ARG;
     EBVO_HIP(ctx, hipSetDevice(ctx->device));
-    EBVO_HIP(ctx, hipHostRegister(p, bytes, hipHostRegisterDefault));
+    ebvo_ctx::HostRange r;
+    r.host = static_cast<const uint8_t *>(p);
+    r.bytes = bytes;
+    hipError_t e = hipHostRegister(p, bytes, hipHostRegisterDefault);
+    if (e == hipSuccess)
+        r.ours = true;
+    else
+    {
+        // memory that is page-locked already (hipHostMalloc, an earlier registration) is accepted as it is
+        (void)hipGetLastError();
+        hipPointerAttribute_t a;
+        memset(&a, 0, sizeof a);
+        if (hipPointerGetAttributes(&a, p) != hipSuccess || a.type != hipMemoryTypeHost)
+        {
+            (void)hipGetLastError();
+            return ebvo_fail_hip(ctx, e, "hipHostRegister", __FILE__, __LINE__);
+        }
+    }
+    void *d = nullptr;
+    if (hipHostGetDevicePointer(&d, p, 0) != hipSuccess || !d)
+    {
+        (void)hipGetLastError();
+        if (r.ours)
+            (void)hipHostUnregister(p);
+        ctx->last_error = "hipHostGetDevicePointer failed for the registered range";
+        return EBVO_ERR_HIP;
+    }
+    r.dev = static_cast<const uint8_t *>(d);
+    ctx->host_ranges.push_back(r);
     return EBVO_OK;
 }
 
@@ -1275,7 +1302,19 @@ extern "C" int ebvo_host_unregister(ebvo_ctx *ctx, void *p)
             if (!sl->in_flight)
                 sl->have_pair = false;
         }
-    EBVO_HIP(ctx, hipHostUnregister(p));
+    bool ours = false, found = false;
+    for (size_t k = 0; k < ctx->host_ranges.size(); ++k)
+        if (ctx->host_ranges[k].host == p)
+        {
+            ours = ctx->host_ranges[k].ours;
+            found = true;
+            ctx->host_ranges.erase(ctx->host_ranges.begin() + (ptrdiff_t)k);
+            break;
+        }
+    if (!found)
+        return EBVO_ERR_ARG;
+    if (ours)
+        EBVO_HIP(ctx, hipHostUnregister(p));
     return EBVO_OK;
 }
 
@@ -1345,53 +1384,70 @@ static int enqueue_matching(ebvo_ctx *ctx, Slot &s, int toed_mode = -1)
 // over PCIe; the kernel holds a handful of CUs while the lanes' other pairs compute.
 namespace
 {
-struct PushArrays
+// where the eight arrays lie in a packed result block, from the ACTUAL counts (the device reads them where the host computes
+// the same offsets after ebvo_stereo_wait): xyL, xyR, thL, thR, row_ptr, col_idx, best, keep bits; 256-byte aligned
+struct PackLayout
 {
-    double2 *xyL, *xyR;
-    double *thL, *thR; // nullptr: not selected
-    int32_t *row_ptr, *col_idx;
-    double *best;
-    uint32_t *bits;
+    size_t off[8], total;
 };
+__host__ __device__ inline PackLayout pack_layout(size_t nL, size_t nR, size_t np, bool theta)
+{
+    const size_t sizes[8] = {16 * nL, 16 * nR, theta ? 8 * nL : 0, theta ? 8 * nR : 0, 4 * (nL + 1), 4 * np, 8 * np, 8 * ((np + 63) >> 6)};
+    PackLayout l;
+    size_t t = 0;
+    for (int k = 0; k < 8; ++k)
+    {
+        l.off[k] = t;
+        t += (sizes[k] + 255) & ~(size_t)255;
+    }
+    l.total = t;
+    return l;
+}
 
 __global__ __launch_bounds__(256) void push_results_kernel(const ebvo_edge *__restrict__ L, const ebvo_edge *__restrict__ R,
                                                            const int32_t *__restrict__ nLp, const int32_t *__restrict__ nRp, int cap_edges,
                                                            const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ col_idx,
                                                            const double *__restrict__ best, const uint8_t *__restrict__ keep,
-                                                           int64_t cap_pairs, PushArrays P)
+                                                           int64_t cap_pairs, char *__restrict__ base, int theta)
 {
     const int nL = min(*nLp, cap_edges), nR = min(*nRp, cap_edges);
     int64_t np = nL > 0 ? (int64_t)row_ptr[nL] : 0;
     np = np < cap_pairs ? np : cap_pairs;
+    const PackLayout lay = pack_layout((size_t)nL, (size_t)nR, (size_t)np, theta != 0);
+    double2 *xyL = (double2 *)(base + lay.off[0]), *xyR = (double2 *)(base + lay.off[1]);
+    double *thL = theta ? (double *)(base + lay.off[2]) : nullptr, *thR = theta ? (double *)(base + lay.off[3]) : nullptr;
+    int32_t *o_rp = (int32_t *)(base + lay.off[4]), *o_ci = (int32_t *)(base + lay.off[5]);
+    double *o_best = (double *)(base + lay.off[6]);
+    uint32_t *o_bits = (uint32_t *)(base + lay.off[7]);
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     for (int64_t i = t0; i < nL; i += stride)
     {
         const ebvo_edge e = L[i];
-        P.xyL[i] = make_double2(e.x, e.y);
-        if (P.thL)
-            P.thL[i] = e.theta;
+        xyL[i] = make_double2(e.x, e.y);
+        if (thL)
+            thL[i] = e.theta;
     }
     for (int64_t i = t0; i < nR; i += stride)
     {
         const ebvo_edge e = R[i];
-        P.xyR[i] = make_double2(e.x, e.y);
-        if (P.thR)
-            P.thR[i] = e.theta;
+        xyR[i] = make_double2(e.x, e.y);
+        if (thR)
+            thR[i] = e.theta;
     }
     for (int64_t i = t0; i <= nL; i += stride)
-        P.row_ptr[i] = row_ptr[i];
+        o_rp[i] = row_ptr[i];
     // four CSR entries / two scores per thread: 16-byte stores
     const int64_t n4 = np >> 2;
     for (int64_t i = t0; i < n4; i += stride)
-        reinterpret_cast<int4 *>(P.col_idx)[i] = reinterpret_cast<const int4 *>(col_idx)[i];
+        reinterpret_cast<int4 *>(o_ci)[i] = reinterpret_cast<const int4 *>(col_idx)[i];
     for (int64_t i = (n4 << 2) + t0; i < np; i += stride)
-        P.col_idx[i] = col_idx[i];
+        o_ci[i] = col_idx[i];
     const int64_t n2 = np >> 1;
     for (int64_t i = t0; i < n2; i += stride)
-        reinterpret_cast<double2 *>(P.best)[i] = reinterpret_cast<const double2 *>(best)[i];
+        reinterpret_cast<double2 *>(o_best)[i] = reinterpret_cast<const double2 *>(best)[i];
     if ((np & 1) && t0 == 0)
-        P.best[np - 1] = best[np - 1];
+        o_best[np - 1] = best[np - 1];
     const int64_t groups = (np + 63) >> 6, wave = t0 >> 6, waves = stride >> 6;
     const int lane = threadIdx.x & 63;
     for (int64_t g = wave; g < groups; g += waves)
@@ -1400,26 +1456,21 @@ __global__ __launch_bounds__(256) void push_results_kernel(const ebvo_edge *__re
         const unsigned long long m = __ballot(k < np && keep[k] != 0);
         if (lane == 0)
         {
-            P.bits[2 * g] = (uint32_t)m;
-            P.bits[2 * g + 1] = (uint32_t)(m >> 32);
+            o_bits[2 * g] = (uint32_t)m;
+            o_bits[2 * g + 1] = (uint32_t)(m >> 32);
         }
     }
 }
 } // namespace
 
-// (re)sizes the slot's push arena for the capacities of the chain about to be enqueued; a re-allocation bumps buf_gen (the
-// arena's address is an argument of a captured launch)
-static int ensure_push_arena(ebvo_ctx *ctx, Slot &s, bool with_theta)
+// (re)sizes the destination of the chain's pack kernel for the capacities the chain is enqueued with: the slot's page-locked
+// arena (EBVO_PAIR_PUSH) or its device staging (EBVO_PAIR_PACK).  A re-allocation bumps buf_gen (the address is an argument of
+// a captured launch).
+static int ensure_push_arena(ebvo_ctx *ctx, Slot &s)
 {
-    const size_t ce = (size_t)ctx->cap_edges, cp = (size_t)s.cap_pairs;
-    const size_t sizes[8] = {16 * ce, 16 * ce, with_theta ? 8 * ce : 0, with_theta ? 8 * ce : 0, 4 * (ce + 1), 4 * cp, 8 * cp, 8 * ((cp + 63) >> 6)};
-    size_t total = 0, off[8];
-    for (int k = 0; k < 8; ++k)
-    {
-        off[k] = total;
-        total += (sizes[k] + 255) & ~(size_t)255;
-    }
-    if (total > s.push_bytes || s.push_cap_edges != (int)ce || s.push_cap_pairs != (int64_t)cp || (with_theta && s.push_off[2] == s.push_off[3]))
+    const bool theta = s.params.reserved & EBVO_PAIR_PUSH_THETA;
+    const size_t total = pack_layout((size_t)ctx->cap_edges, (size_t)ctx->cap_edges, (size_t)s.cap_pairs, theta).total;
+    if (s.params.reserved & EBVO_PAIR_PUSH)
     {
         if (total > s.push_bytes)
         {
@@ -1435,13 +1486,13 @@ static int ensure_push_arena(ebvo_ctx *ctx, Slot &s, bool with_theta)
             }
             EBVO_HIP(ctx, hipHostGetDevicePointer(&s.d_push, s.h_push, 0));
             s.push_bytes = total;
+            ++s.buf_gen;
         }
-        memcpy(s.push_off, off, sizeof off);
-        s.push_cap_edges = (int)ce;
-        s.push_cap_pairs = (int64_t)cp;
-        ++s.buf_gen;
+        return EBVO_OK;
     }
-    return EBVO_OK;
+    if (total > s.fetch_pack.bytes && s.fetch_pending) // copies out of the old staging must be over before it is replaced
+        EBVO_HIP(ctx, hipEventSynchronize(s.ev_rebind));
+    return ebvo_grow(ctx, s, s.fetch_pack, total);
 }
 
 // the images of a pair, read by the GPU from the caller's page-locked memory (ebvo_stereo_upload_async): 16 bytes per thread
@@ -1475,23 +1526,13 @@ __global__ __launch_bounds__(256) void pull_images_kernel(const Slot::PullMail *
 
 static int enqueue_push(ebvo_ctx *ctx, Slot &s)
 {
-    if (!(s.params.reserved & EBVO_PAIR_PUSH))
+    if (!(s.params.reserved & (EBVO_PAIR_PUSH | EBVO_PAIR_PACK)))
         return EBVO_OK;
-    const bool th = s.params.reserved & EBVO_PAIR_PUSH_THETA;
-    char *b = static_cast<char *>(s.d_push);
-    PushArrays P;
-    P.xyL = (double2 *)(b + s.push_off[0]);
-    P.xyR = (double2 *)(b + s.push_off[1]);
-    P.thL = th ? (double *)(b + s.push_off[2]) : nullptr;
-    P.thR = th ? (double *)(b + s.push_off[3]) : nullptr;
-    P.row_ptr = (int32_t *)(b + s.push_off[4]);
-    P.col_idx = (int32_t *)(b + s.push_off[5]);
-    P.best = (double *)(b + s.push_off[6]);
-    P.bits = (uint32_t *)(b + s.push_off[7]);
+    char *base = static_cast<char *>((s.params.reserved & EBVO_PAIR_PUSH) ? s.d_push : s.fetch_pack.p);
     hipLaunchKernelGGL(push_results_kernel, dim3(64), dim3(256), 0, s.stream, (const ebvo_edge *)s.im[0].edges,
                        (const ebvo_edge *)s.im[1].edges, (const int32_t *)(s.im[0].counts + 1), (const int32_t *)(s.im[1].counts + 1),
                        ctx->cap_edges, (const int32_t *)s.row_ptr.p, (const int32_t *)s.col_idx.p, (const double *)s.best.p,
-                       (const uint8_t *)s.keep.p, s.cap_pairs, P);
+                       (const uint8_t *)s.keep.p, s.cap_pairs, base, (s.params.reserved & EBVO_PAIR_PUSH_THETA) ? 1 : 0);
     EBVO_HIP(ctx, hipGetLastError());
     return EBVO_OK;
 }
@@ -1603,7 +1644,8 @@ static int submit_pair_chain(ebvo_ctx *ctx, Slot &s)
 extern "C" int ebvo_stereo_submit(ebvo_ctx *ctx, int slot, const ebvo_stereo_params *p)
 {
     Slot *sp;
-    if (!p || (p->stage_mask & ~EBVO_STAGE_ALL) || p->stage_mask == 0 || (p->reserved & ~(EBVO_PAIR_NO_SIMS | EBVO_PAIR_PUSH | EBVO_PAIR_PUSH_THETA)) || get_slot(ctx, slot, &sp))
+    if (!p || (p->stage_mask & ~EBVO_STAGE_ALL) || p->stage_mask == 0 || (p->reserved & ~(EBVO_PAIR_NO_SIMS | EBVO_PAIR_PUSH | EBVO_PAIR_PUSH_THETA | EBVO_PAIR_PACK)) ||
+        ((p->reserved & EBVO_PAIR_PUSH) && (p->reserved & EBVO_PAIR_PACK)) || get_slot(ctx, slot, &sp))
         return EBVO_ERR_ARG;
     Slot &s = *sp;
     if (!s.have_pair || s.in_flight || s.fin_in_flight || s.tq_in_flight)
@@ -1662,8 +1704,8 @@ extern "C" int ebvo_stereo_submit(ebvo_ctx *ctx, int slot, const ebvo_stereo_par
         if ((rc = ensure_pipeline_buffers(ctx, s, want)))
             return rc;
     }
-    s.have_push = false;
-    if ((s.params.reserved & EBVO_PAIR_PUSH) && (rc = ensure_push_arena(ctx, s, s.params.reserved & EBVO_PAIR_PUSH_THETA)))
+    s.have_push = s.have_pack = false;
+    if ((s.params.reserved & (EBVO_PAIR_PUSH | EBVO_PAIR_PACK)) && (rc = ensure_push_arena(ctx, s)))
         return rc;
     EBVO_HIP(ctx, hipMemcpyAsync(s.d_F, s.params.F21, sizeof(double) * 9, hipMemcpyHostToDevice, s.stream));
     if ((rc = submit_pair_chain(ctx, s)))
@@ -1741,7 +1783,7 @@ extern "C" int ebvo_stereo_wait(ebvo_ctx *ctx, int slot, ebvo_stereo_counts *cou
         // more candidates than the buffers hold: grow them and redo the matching half (TOED results are intact)
         int64_t want = r.n_pairs + r.n_pairs / 4 + 1024;
         if ((rc = ensure_pipeline_buffers(ctx, s, want)) ||
-            ((s.params.reserved & EBVO_PAIR_PUSH) && (rc = ensure_push_arena(ctx, s, s.params.reserved & EBVO_PAIR_PUSH_THETA))) ||
+            ((s.params.reserved & (EBVO_PAIR_PUSH | EBVO_PAIR_PACK)) && (rc = ensure_push_arena(ctx, s))) ||
             (rc = enqueue_matching(ctx, s)) || (rc = enqueue_push(ctx, s)))
         {
             s.in_flight = false;
@@ -1771,7 +1813,28 @@ extern "C" int ebvo_stereo_wait(ebvo_ctx *ctx, int slot, ebvo_stereo_counts *cou
     counts->n_matches = s.result.n_matches;
     s.have_run = true;
     s.have_push = (s.params.reserved & EBVO_PAIR_PUSH) != 0;
+    s.have_pack = (s.params.reserved & EBVO_PAIR_PACK) != 0;
     return EBVO_OK;
+}
+
+static void fill_compact_view(ebvo_stereo_compact_view *view, const char *b, const PackLayout &lay, const PairResult &r, bool theta)
+{
+    memset(view, 0, sizeof *view);
+    view->n_left = r.n_left;
+    view->n_right = r.n_right;
+    view->n_pairs = r.n_pairs;
+    view->n_matches = r.n_matches;
+    view->left_xy = reinterpret_cast<const double *>(b + lay.off[0]);
+    view->right_xy = reinterpret_cast<const double *>(b + lay.off[1]);
+    if (theta)
+    {
+        view->left_theta = reinterpret_cast<const double *>(b + lay.off[2]);
+        view->right_theta = reinterpret_cast<const double *>(b + lay.off[3]);
+    }
+    view->row_ptr = reinterpret_cast<const int32_t *>(b + lay.off[4]);
+    view->col_idx = reinterpret_cast<const int32_t *>(b + lay.off[5]);
+    view->best = reinterpret_cast<const double *>(b + lay.off[6]);
+    view->keep_bits = reinterpret_cast<const uint32_t *>(b + lay.off[7]);
 }
 
 // the compact results a pair submitted with EBVO_PAIR_PUSH left in the slot's page-locked arena: valid from the pair's
@@ -1785,22 +1848,9 @@ extern "C" int ebvo_stereo_pushed_view(ebvo_ctx *ctx, int slot, ebvo_stereo_comp
     if (s.in_flight || !s.have_push || !s.h_push)
         return EBVO_ERR_STATE;
     const char *b = static_cast<const char *>(s.h_push);
-    memset(view, 0, sizeof *view);
-    view->n_left = s.result.n_left;
-    view->n_right = s.result.n_right;
-    view->n_pairs = s.result.n_pairs;
-    view->n_matches = s.result.n_matches;
-    view->left_xy = reinterpret_cast<const double *>(b + s.push_off[0]);
-    view->right_xy = reinterpret_cast<const double *>(b + s.push_off[1]);
-    if (s.params.reserved & EBVO_PAIR_PUSH_THETA)
-    {
-        view->left_theta = reinterpret_cast<const double *>(b + s.push_off[2]);
-        view->right_theta = reinterpret_cast<const double *>(b + s.push_off[3]);
-    }
-    view->row_ptr = reinterpret_cast<const int32_t *>(b + s.push_off[4]);
-    view->col_idx = reinterpret_cast<const int32_t *>(b + s.push_off[5]);
-    view->best = reinterpret_cast<const double *>(b + s.push_off[6]);
-    view->keep_bits = reinterpret_cast<const uint32_t *>(b + s.push_off[7]);
+    const bool theta = s.params.reserved & EBVO_PAIR_PUSH_THETA;
+    const PackLayout lay = pack_layout((size_t)s.result.n_left, (size_t)s.result.n_right, (size_t)s.result.n_pairs, theta);
+    fill_compact_view(view, b, lay, s.result, theta);
     return EBVO_OK;
 }
 
@@ -3699,6 +3749,40 @@ extern "C" int ebvo_stereo_fetch_compact_begin(ebvo_ctx *ctx, int slot, int what
         return EBVO_ERR_STATE;
     EBVO_HIP(ctx, hipSetDevice(ctx->device));
     const size_t nL = (size_t)s.result.n_left, nR = (size_t)s.result.n_right, np = (size_t)s.result.n_pairs;
+    s.fetch_packed = false;
+    if (s.have_pack && (!(what & EBVO_COMPACT_THETA) || (s.params.reserved & EBVO_PAIR_PUSH_THETA)))
+    {
+        // the pair's own chain has packed the arrays (EBVO_PAIR_PACK): ONE copy of the block, sized by the actual counts
+        const PackLayout lay = pack_layout(nL, nR, np, s.params.reserved & EBVO_PAIR_PUSH_THETA);
+        if (lay.total > s.h_arena_bytes)
+        {
+            if (s.fetch_pending)
+                EBVO_HIP(ctx, hipEventSynchronize(s.ev_rebind));
+            if (s.h_arena)
+                (void)hipHostFree(s.h_arena);
+            s.h_arena = nullptr;
+            s.h_arena_bytes = 0;
+            const size_t want = lay.total + lay.total / 4 + 4096;
+            if (hipHostMalloc(&s.h_arena, want) != hipSuccess)
+            {
+                (void)hipGetLastError();
+                ctx->last_error = "hipHostMalloc failed (page-locked result staging)";
+                return EBVO_ERR_NOMEM;
+            }
+            s.h_arena_bytes = want;
+        }
+        if (!ctx->copy_stream)
+            EBVO_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+        EBVO_HIP(ctx, hipMemcpyAsync(s.h_arena, s.fetch_pack.p, lay.total, hipMemcpyDeviceToHost, ctx->copy_stream));
+        EBVO_HIP(ctx, hipEventRecord(s.ev_rebind, ctx->copy_stream));
+        s.fetch_what = what;
+        s.fetch_compact = true;
+        s.fetch_packed = true;
+        s.fetch_packed_theta = (s.params.reserved & EBVO_PAIR_PUSH_THETA) != 0;
+        s.fetch_result = s.result;
+        s.fetch_pending = true;
+        return EBVO_OK;
+    }
     const size_t nwords = 2 * ((np + 63) >> 6);
     const bool xy = what & EBVO_COMPACT_XY, th = what & EBVO_COMPACT_THETA, kb = what & EBVO_COMPACT_KEEP_BITS;
     const size_t sizes[8] = {xy ? 16 * nL : 0, xy ? 16 * nR : 0, th ? 8 * nL : 0, th ? 8 * nR : 0,
@@ -3785,6 +3869,23 @@ extern "C" int ebvo_stereo_fetch_compact_end(ebvo_ctx *ctx, int slot, ebvo_stere
     s.fetch_pending = false;
     const char *base = static_cast<const char *>(s.h_arena);
     const int what = s.fetch_what;
+    if (s.fetch_packed)
+    {
+        const bool theta = s.fetch_packed_theta;
+        const PackLayout lay = pack_layout((size_t)s.fetch_result.n_left, (size_t)s.fetch_result.n_right, (size_t)s.fetch_result.n_pairs, theta);
+        fill_compact_view(view, base, lay, s.fetch_result, theta);
+        if (!(what & EBVO_COMPACT_XY))
+            view->left_xy = view->right_xy = nullptr;
+        if (!(what & EBVO_COMPACT_THETA))
+            view->left_theta = view->right_theta = nullptr;
+        if (!(what & EBVO_COMPACT_CSR))
+            view->row_ptr = view->col_idx = nullptr;
+        if (!(what & EBVO_COMPACT_BEST))
+            view->best = nullptr;
+        if (!(what & EBVO_COMPACT_KEEP_BITS))
+            view->keep_bits = nullptr;
+        return EBVO_OK;
+    }
     memset(view, 0, sizeof *view);
     view->n_left = s.result.n_left;
     view->n_right = s.result.n_right;

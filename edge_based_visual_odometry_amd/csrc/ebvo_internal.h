@@ -201,10 +201,11 @@ struct Slot
     // EBVO_PAIR_PUSH: the pair's chain ends with a kernel that WRITES the compact results into this page-locked arena (sized for
     // the capacities the chain was enqueued with); no copy, no event: they are there when the pair's ebvo_stereo_wait returns
     void *h_push = nullptr, *d_push = nullptr;
-    size_t push_bytes = 0, push_off[8] = {0};
-    int push_cap_edges = 0;
-    int64_t push_cap_pairs = 0;
+    size_t push_bytes = 0;
     bool have_push = false;              // the last completed pair pushed its results (ebvo_stereo_pushed_view)
+    bool fetch_packed = false, fetch_packed_theta = false; // the arena holds one packed block (layout from fetch_result's counts)
+    PairResult fetch_result{};
+    bool have_pack = false;              // ... packed them into fetch_pack (EBVO_PAIR_PACK): the compact fetch is ONE copy
     GrowBuf fetch_pack;                  // device staging of the compact fetch: (x, y) pairs, orientations, keep bits
     ebvo_stereo_params params{};
     PairResult result{};                 // last completed result
@@ -247,6 +248,16 @@ struct ebvo_ctx
     uint64_t submit_seq = 0;
     std::vector<hipStream_t> lane_streams; // created on first use, owned by the context
     hipStream_t copy_stream = nullptr;     // result copies of ebvo_stereo_fetch_begin (all slots), created on first use
+    // memory page-locked through ebvo_host_register: host range and the address the device uses for it.  ebvo_stereo_upload_async
+    // takes its pull form only for images inside one of these ranges (a lookup in this list: no runtime call per frame --
+    // hipPointerGetAttributes costs 5 us in a bare process and 300 us in one where PyTorch has initialised the device)
+    struct HostRange
+    {
+        const uint8_t *host = nullptr, *dev = nullptr;
+        size_t bytes = 0;
+        bool ours = false; // registered by the library (to be unregistered by it)
+    };
+    std::vector<HostRange> host_ranges;
     hipStream_t upload_stream = nullptr;   // image uploads of ebvo_stereo_upload_async (all slots), created on first use
     // resident stage-wise path (ebvo_toed_resident / ebvo_epi_candidates_resident / ebvo_ncc_pairs_resident): the TOED results
     // of the last two images stay in slot 0's image workspaces; tag 0 = that workspace holds nothing a caller may refer to

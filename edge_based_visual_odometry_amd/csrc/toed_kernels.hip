@@ -35,6 +35,7 @@
 #include <hip/hip_ext.h>
 
 #include "ebvo_internal.h"
+#include <atomic>
 #include "ebvo_math.h"
 
 namespace
@@ -1741,8 +1742,10 @@ int toed_init_constants(ebvo_ctx *ctx)
 // are exactly that large, see exact_task
 static int resident_blocks(ebvo_ctx *ctx, int which)
 {
-    static int cached[16][2];
-    int &c = cached[ctx->device & 15][which];
+    // (two host threads with their own contexts may get here together: the value they compute is the same, the store is atomic)
+    static std::atomic<int> cached[16][2];
+    std::atomic<int> &slot = cached[ctx->device & 15][which];
+    int c = slot.load(std::memory_order_relaxed);
     if (c == 0)
     {
         int per_cu = 0, cus = 0;
@@ -1752,6 +1755,7 @@ static int resident_blocks(ebvo_ctx *ctx, int which)
             (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, toed_exact_mags_kernel, 256, 0);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
         c = (per_cu > 0 ? per_cu : 4) * (cus > 0 ? cus : 256);
+        slot.store(c, std::memory_order_relaxed);
     }
     return c;
 }
@@ -1861,7 +1865,7 @@ int toed_enqueue(ebvo_ctx *ctx, Slot &s, int n_img, int h, int w, hipEvent_t ev_
                 E.counts[k] = ws.counts;
                 E.lists[k] = ws.cand_lists;
                 E.lcount[k] = ws.cand_lcount;
-                E.cd[k] = (CandExact *)ws.cand_data; // 64 of the buffer's 72 bytes per candidate
+                E.cd[k] = (CandExact *)ws.cand_data; // one 64-byte record per candidate
                 E.rec[k] = (CandRec *)ws.cand_rec;
                 E.cand_flag[k] = ws.cand_flag;
                 // the planes of the strict path are free in hybrid mode: |g| map, need bitmap, per-row counters

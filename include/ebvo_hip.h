@@ -104,7 +104,7 @@ enum
 int ebvo_set_toed_mode(ebvo_ctx *ctx, int mode);
 int ebvo_get_toed_mode(const ebvo_ctx *ctx);
 int64_t ebvo_toed_fallbacks(const ebvo_ctx *ctx); /* hybrid runs the library repeated on the strict path so far */
-/* ebvo_stereo_submit captures the ~31 launches of a pair into a hipGraph at the second submission of a slot with unchanged
+/* ebvo_stereo_submit captures the ~31 launches of a pair into a hipGraph at the THIRD submission of a slot with unchanged
  * size, parameters and buffers, and launches that graph afterwards (environment EBVO_GRAPHS=0 or ebvo_debug_set(ctx, 10, 0):
  * direct launches).  Number of pairs submitted as a graph launch so far: */
 int64_t ebvo_graph_launches(const ebvo_ctx *ctx);
@@ -565,7 +565,7 @@ typedef struct ebvo_stereo_params
     double F21[9]; /* row-major fundamental matrix, Dataset::get_fund_mat_21 */
     double epi_thr, max_disp, orient_thr_deg, ncc_thr;
     int stage_mask;
-    int reserved; /* flags: 0, or EBVO_PAIR_NO_SIMS | EBVO_PAIR_PUSH | EBVO_PAIR_PUSH_THETA */
+    int reserved; /* flags: 0, or EBVO_PAIR_NO_SIMS | EBVO_PAIR_PUSH / EBVO_PAIR_PACK | EBVO_PAIR_PUSH_THETA */
 } ebvo_stereo_params;
 /* ebvo_stereo_params.reserved = EBVO_PAIR_NO_SIMS: the resident pipeline stores, per candidate pair, the final score (the
  * maximum of the four similarities: what the reference keeps, refine_final_scores, src/Stereo_Matches.cpp:596-600) and the
@@ -579,6 +579,10 @@ typedef struct ebvo_stereo_params
  * consumes the first NCC pass on the host wants (src/Stereo_Matches.cpp:1427 onwards run there). */
 #define EBVO_PAIR_PUSH 2
 #define EBVO_PAIR_PUSH_THETA 4
+/* EBVO_PAIR_PACK: the chain ends with the same kernel, writing the block into DEVICE staging; ebvo_stereo_fetch_compact_begin is
+ * then ONE device-to-host copy of exactly the bytes the pair produced (the copy engine moves a contiguous block ~1.3x faster than
+ * a kernel's stores cross PCIe on the boxes measured).  Exclusive with EBVO_PAIR_PUSH; EBVO_PAIR_PUSH_THETA adds the orientations. */
+#define EBVO_PAIR_PACK 8
 
 typedef struct ebvo_stereo_counts
 {

@@ -199,13 +199,15 @@ def test_both_forms_of_the_asynchronous_upload(c, stream_form):
 
 
 @pytest.mark.parametrize("theta", [False, True])
-def test_pushed_results_equal_full_fetch(c, theta):
-    """EBVO_PAIR_PUSH: the pair's chain writes the compact results into page-locked host memory itself; what the host finds there
-    after ebvo_stereo_wait equals the full fetch -- over direct launches, the captured graph, a regrown pair buffer"""
+@pytest.mark.parametrize("mode", ["push", "pack"])
+def test_pushed_results_equal_full_fetch(c, theta, mode):
+    """EBVO_PAIR_PUSH: the pair's chain writes the compact results into page-locked host memory itself; EBVO_PAIR_PACK: into
+    device staging, fetched by ONE copy (ebvo_stereo_fetch_compact_begin / _end).  Either way what the host reads equals the
+    full fetch -- over direct launches, the captured graph, a regrown pair buffer"""
     ring = _ring(3)
     ref = _reference(c, ring)
     p = c.default_params(F)
-    p.reserved = _lib.PAIR_PUSH | _lib.PAIR_NO_SIMS | (_lib.PAIR_PUSH_THETA if theta else 0)
+    p.reserved = (_lib.PAIR_PUSH if mode == "push" else _lib.PAIR_PACK) | _lib.PAIR_NO_SIMS | (_lib.PAIR_PUSH_THETA if theta else 0)
     for rep in range(5):                               # the third submission of a slot is a graph launch
         for k, (l, r) in enumerate(ring):
             c.stereo_upload(l, r, slot=1)
@@ -213,7 +215,11 @@ def test_pushed_results_equal_full_fetch(c, theta):
                 c.debug_set(1, 1)                      # the next result is treated as overflowed: matching half re-enqueued, arena kept in step
             c.stereo_submit(p, slot=1)
             cnt = c.stereo_wait(slot=1)
-            v = c.stereo_pushed_view(slot=1)
+            if mode == "push":
+                v = c.stereo_pushed_view(slot=1)
+            else:
+                c.stereo_fetch_compact_begin(slot=1, what=_lib.COMPACT_ALL if theta else _lib.COMPACT_DEFAULT)
+                v = c.stereo_fetch_compact_end(slot=1)
             full = ref[k][1]
             assert (v["n_pairs"], v["n_matches"]) == (cnt.n_pairs, cnt.n_matches) == (ref[k][0].n_pairs, ref[k][0].n_matches)
             for side in ("left", "right"):
@@ -230,6 +236,12 @@ def test_pushed_results_equal_full_fetch(c, theta):
             assert_bit_equal(bits, full["keep"], "keep bits")
     p.reserved = 0                                     # a pair without the flag leaves no pushed view
     c.stereo_submit(p, slot=1)
-    c.stereo_wait(slot=1)
+    cnt = c.stereo_wait(slot=1)
     with pytest.raises(_lib.EbvoError):
         c.stereo_pushed_view(slot=1)
+    c.stereo_fetch_compact_begin(slot=1)               # ... and the compact fetch packs on the copy stream as before
+    v = c.stereo_fetch_compact_end(slot=1)
+    assert_bit_equal(v["best"], ref[2][1]["best"], "best")
+    p.reserved = _lib.PAIR_PUSH | _lib.PAIR_PACK       # one destination at a time
+    with pytest.raises(_lib.EbvoError):
+        c.stereo_submit(p, slot=1)

@@ -9,6 +9,10 @@ from edge_based_visual_odometry_amd import _lib, synth  # noqa: E402
 from edge_based_visual_odometry_amd.api import Context  # noqa: E402
 import bench  # noqa: E402
 
+if "torch" in sys.argv:                        # bench.py's process: torch has initialised the device before the library does
+    import torch
+    torch.cuda.synchronize()
+    print("torch initialised the device first", flush=True)
 H, W = synth.SHAPES["kitti"]
 F = synth.fundamental_for("kitti")
 NS = 6
@@ -47,14 +51,21 @@ for pair in ring:
     for im in pair:
         ctx.host_register(im)
 ctx.set_slots(NS + 1)
-flags = ("push" if len(sys.argv) > 1 and sys.argv[1] == "push" else "compact")
+flags = ("push" if "push" in sys.argv else "compact")
+PACK = "pack" in sys.argv
+pf = ctx.default_params(F)                    # the fetch loops: with EBVO_PAIR_PUSH when the results are pushed
+pf.reserved = p.reserved | (_lib.PAIR_PUSH if flags == "push" else (_lib.PAIR_PACK if PACK else 0))
 
 
 def ing(n, fetch=None):
-    t, _ = bench.ingest_loop(ctx, p, ring, NS, n, fetch)
+    t, _ = bench.ingest_loop(ctx, pf if fetch else p, ring, NS, n, fetch)
     return n / t
 
 
+t0 = time.perf_counter()
+for _ in range(200):
+    ctx.stereo_upload_async(*ring[0], slot=NS)
+print(f"host time of ebvo_stereo_upload_async (pull form): {(time.perf_counter() - t0) / 200 * 1e6:.1f} us per call", flush=True)
 show("ingest warm 28", lambda: ing(28))
 show("ingest 20", lambda: ing(20))
 show("ingest 300", lambda: ing(300))
