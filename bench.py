@@ -347,7 +347,7 @@ def frame_loop(ctx, params, pool, nslots, steps, upload, fetch):
     return time.perf_counter() - t0, nbytes / max(1, steps)
 
 
-def ingest_loop(ctx, params, ring, nslots, steps, fetch=None):
+def ingest_loop(ctx, params, ring, nslots, steps, fetch=None, host_us=None):
     """A streamed sequence at the resident rate (round 4): `nslots` pairs in flight on `nslots + 1` slots; the images of step
     i + 1 are uploaded (ebvo_stereo_upload_async: DMA from the page-locked frame ring on the context's upload stream, the host
     does not wait) while step i is still being matched, so that a submission never waits for its images -- what a frame loop
@@ -363,8 +363,18 @@ def ingest_loop(ctx, params, ring, nslots, steps, fetch=None):
 
     def upload(slot):
         nonlocal uploaded
+        t_ = time.perf_counter()
         ctx.stereo_upload_async(*ring[uploaded % len(ring)], slot=slot)
+        if host_us is not None:
+            host_us["upload_async"] = host_us.get("upload_async", 0.0) + (time.perf_counter() - t_) * 1e6 / steps
         uploaded += 1
+
+    def timed(name, fn, *a, **k):
+        t_ = time.perf_counter()
+        r = fn(*a, **k)
+        if host_us is not None:
+            host_us[name] = host_us.get(name, 0.0) + (time.perf_counter() - t_) * 1e6 / steps
+        return r
 
     def begin(slot):
         if fetch == "push":                       # nothing to start: the pair's own chain has written the results to host memory
@@ -396,7 +406,7 @@ def ingest_loop(ctx, params, ring, nslots, steps, fetch=None):
     pending = None
     while done < steps:
         k = done % S
-        ctx.stereo_wait(slot=k)
+        timed("wait", ctx.stereo_wait, slot=k)
         done += 1
         if fetch == "push":
             consume(k)                             # already in host memory
@@ -406,7 +416,7 @@ def ingest_loop(ctx, params, ring, nslots, steps, fetch=None):
                 consume(pending)                   # ... before `pending` (= ahead) is submitted again
             pending = k
         if ahead is not None:                      # its upload was enqueued a whole pair earlier
-            ctx.stereo_submit(params, slot=ahead)
+            timed("submit", ctx.stereo_submit, params, slot=ahead)
             submitted += 1
             ahead = None
         if uploaded < steps:                       # the images the slot will be submitted with at the next turn
@@ -960,7 +970,9 @@ def main():
         ingest = {"value_with_h2d": sharding.job_throughput(world, args.steps, t_ing), "per_rank_pairs_per_s_with_h2d": per_rank_ing}
         if rank == 0 and world == 1 and not args.no_transfer_legs:
             n_leg = max(nslots + 1, min(args.steps, 60))
-            t_sus_ing, _ = ingest_loop(ctx, params, ring, nslots, 300)
+            ingest_host_us = {}
+            t_sus_ing, _ = ingest_loop(ctx, params, ring, nslots, 300, host_us=ingest_host_us)
+            ingest["ingest_host_us_per_pair"] = ingest_host_us
             ingest_loop(ctx, params, ring, nslots, nslots + 1, "compact")     # untimed: sizes the page-locked staging
             t_c, mb_c = ingest_loop(ctx, params, ring, nslots, n_leg, "compact")
             # ... and with the results PUSHED by the pair's own chain (EBVO_PAIR_PUSH): no copy call, no copy stream

@@ -68,7 +68,16 @@ for _ in range(200):
 print(f"host time of ebvo_stereo_upload_async (pull form): {(time.perf_counter() - t0) / 200 * 1e6:.1f} us per call", flush=True)
 show("ingest warm 28", lambda: ing(28))
 show("ingest 20", lambda: ing(20))
-show("ingest 300", lambda: ing(300))
+hu = {}
+show("ingest 300", lambda: 300 / bench.ingest_loop(ctx, p, ring, NS, 300, None, hu)[0])
+print("   host us per pair:", {k: round(v, 1) for k, v in hu.items()}, flush=True)
+if "torchlate" in sys.argv:                    # bench.py's order: the library's context exists before torch touches the device
+    import torch
+    torch.cuda.synchronize()
+    print("torch initialised the device now", flush=True)
+    hu = {}
+    show("ingest 300 (torch now active)", lambda: 300 / bench.ingest_loop(ctx, p, ring, NS, 300, None, hu)[0])
+    print("   host us per pair:", {k: round(v, 1) for k, v in hu.items()}, flush=True)
 show(f"ingest + {flags} warm 7", lambda: ing(7, flags))
 show(f"ingest + {flags} 60", lambda: ing(60, flags))
 show(f"ingest + {flags} 300", lambda: ing(300, flags))
