@@ -190,8 +190,6 @@ static void slot_destroy(Slot *s)
         (void)hipEventDestroy(s->ev_rebind);
     if (s->ev_upload)
         (void)hipEventDestroy(s->ev_upload);
-    if (s->h_mail)
-        (void)hipHostFree(s->h_mail);
     if (s->h_push)
         (void)hipHostFree(s->h_push);
     (void)hipFree(s->d_fin_tot);
@@ -251,9 +249,6 @@ static int slot_create(ebvo_ctx *ctx, Slot **out)
     CK(hipEventCreateWithFlags(&s->ev_done, hipEventDisableTiming));
     CK(hipEventCreateWithFlags(&s->ev_rebind, hipEventDisableTiming));
     CK(hipEventCreateWithFlags(&s->ev_upload, hipEventDisableTiming));
-    CK(hipHostMalloc(reinterpret_cast<void **>(&s->h_mail), sizeof(Slot::PullMail)));
-    memset(s->h_mail, 0, sizeof(Slot::PullMail));
-    CK(hipHostGetDevicePointer(reinterpret_cast<void **>(&s->d_mail), s->h_mail, 0));
     const size_t H2 = 2 * (size_t)ctx->max_h, W2 = 2 * (size_t)ctx->max_w, np2 = H2 * W2;
     for (int k = 0; k < 2; ++k)
     {
@@ -291,7 +286,8 @@ static int slot_create(ebvo_ctx *ctx, Slot **out)
     CK(hipMalloc(&s->d_total, sizeof(unsigned long long) * (1 + EBVO_TOTAL_PARTS)));
     CK(hipMalloc(&s->d_matches, sizeof(int32_t) * EBVO_MATCH_PARTS));
     CK(hipMalloc(&s->d_sizes, sizeof(int32_t) * 4));
-    CK(hipMalloc(&s->d_F, sizeof(double) * 9));
+    CK(hipMalloc(&s->d_F, sizeof(double) * 9 + sizeof(Slot::PullMail)));
+    s->d_mail = reinterpret_cast<Slot::PullMail *>(s->d_F + 9);
     CK(hipMalloc(&s->d_result, sizeof(PairResult)));
     CK(hipHostMalloc(&s->h_result, sizeof(PairResult)));
     CK(hipMalloc(&s->d_fin_tot, sizeof(int32_t) * 8));
@@ -1173,7 +1169,6 @@ extern "C" int ebvo_stereo_upload_async(ebvo_ctx *ctx, int slot, const uint8_t *
     int rc;
     if (!img_left || !img_right || (rc = get_slot(ctx, slot, &sp)))
         return EBVO_ERR_ARG;
-    EBVO_HIP(ctx, hipSetDevice(ctx->device));
     if ((rc = check_size(ctx, h, w)))
         return rc;
     Slot &s = *sp;
@@ -1188,7 +1183,7 @@ extern "C" int ebvo_stereo_upload_async(ebvo_ctx *ctx, int slot, const uint8_t *
     s.pull = false;
     if (stride_left < w || stride_right < w)
         return EBVO_ERR_ARG;
-    if (!ctx->ingest_stream)
+    if (!ctx->ingest_stream) // (the pull form makes no runtime call at all)
     {
         // pull form: both images entirely in page-locked memory the device can address?  Then the pair's own chain reads them
         // (its first kernel; the pointers go through the slot's mailbox) -- no copy engine, no second stream, no event: nothing
@@ -1215,8 +1210,8 @@ extern "C" int ebvo_stereo_upload_async(ebvo_ctx *ctx, int slot, const uint8_t *
                 return rc;
             for (int k = 0; k < 2; ++k)
             {
-                s.h_mail->src[k] = dev[k];
-                s.h_mail->stride[k] = (long long)strides[k];
+                s.mail.src[k] = dev[k];
+                s.mail.stride[k] = (long long)strides[k];
             }
             s.pull = true;
             s.undist_pair = ctx->undist_on;
@@ -1227,6 +1222,7 @@ extern "C" int ebvo_stereo_upload_async(ebvo_ctx *ctx, int slot, const uint8_t *
             return EBVO_OK;
         }
     }
+    EBVO_HIP(ctx, hipSetDevice(ctx->device));
     if (!ctx->upload_stream)
         EBVO_HIP(ctx, hipStreamCreateWithFlags(&ctx->upload_stream, hipStreamNonBlocking));
     // ordering on the device, not on the host: result copies of the previous pair (copy stream) still read the edge lists --
@@ -1707,7 +1703,19 @@ extern "C" int ebvo_stereo_submit(ebvo_ctx *ctx, int slot, const ebvo_stereo_par
     s.have_push = s.have_pack = false;
     if ((s.params.reserved & (EBVO_PAIR_PUSH | EBVO_PAIR_PACK)) && (rc = ensure_push_arena(ctx, s)))
         return rc;
-    EBVO_HIP(ctx, hipMemcpyAsync(s.d_F, s.params.F21, sizeof(double) * 9, hipMemcpyHostToDevice, s.stream));
+    {
+        // the fundamental matrix and the pull mailbox in ONE small copy (the runtime takes a copy of a pageable source this small
+        // before the call returns)
+        struct
+        {
+            double F[9];
+            Slot::PullMail mail;
+        } blk;
+        static_assert(sizeof blk == sizeof(double) * 9 + sizeof(Slot::PullMail), "d_F layout");
+        memcpy(blk.F, s.params.F21, sizeof blk.F);
+        blk.mail = s.mail;
+        EBVO_HIP(ctx, hipMemcpyAsync(s.d_F, &blk, s.pull ? sizeof blk : sizeof blk.F, hipMemcpyHostToDevice, s.stream));
+    }
     if ((rc = submit_pair_chain(ctx, s)))
         return rc;
     EBVO_HIP(ctx, hipEventRecord(s.ev_done, s.stream));

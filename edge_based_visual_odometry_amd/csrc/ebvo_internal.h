@@ -131,13 +131,15 @@ struct Slot
     hipEvent_t ev_done = nullptr;     // recorded behind the last kernel of a submitted pair
     hipEvent_t ev_rebind = nullptr;   // orders a slot's earlier work before its first work on another lane
     // ebvo_stereo_upload_async, pull form: the pair's chain starts with a kernel that READS the two images from the caller's
-    // page-locked memory (the pointers travel in this page-locked mailbox, so the captured graph of the chain never changes)
+    // page-locked memory (the pointers travel in a small device mailbox that every submission refreshes together with the
+    // fundamental matrix -- one 104-byte copy on the pair's stream -- so the captured graph of the chain never changes)
     struct PullMail
     {
         const uint8_t *src[2];
         long long stride[2];
     };
-    PullMail *h_mail = nullptr, *d_mail = nullptr; // host / device address of the mailbox
+    PullMail mail{};                               // host copy; travels to d_mail with the fundamental matrix at every submission
+    PullMail *d_mail = nullptr;                    // device address of the mailbox (behind d_F's nine doubles, one allocation)
     bool pull = false;                             // the resident pair is pulled by the chain itself
     hipEvent_t ev_upload = nullptr;   // end of the slot's asynchronous image upload (ebvo_stereo_upload_async, the context's upload stream)
     bool upload_pending = false;      // ... recorded and not yet waited for by a submission or a host call
@@ -190,7 +192,7 @@ struct Slot
     int32_t *d_matches = nullptr; // [EBVO_MATCH_PARTS] per-block kept-pair counts of ncc_tile_kernel
     int n_match_part = 0;
     int32_t *d_sizes = nullptr;          // [4] host-provided sizes for the host-buffer entry points
-    double *d_F = nullptr;               // 9 doubles
+    double *d_F = nullptr;               // 9 doubles, then the pull mailbox (Slot::PullMail): ONE host-to-device copy per submission
     PairResult *d_result = nullptr, *h_result = nullptr; // h_result is pinned
     void *h_arena = nullptr;             // pinned staging of ebvo_stereo_fetch_begin / _end
     size_t h_arena_bytes = 0;
