@@ -991,6 +991,7 @@ def main():
             ingest.update(with_h2d_d2h_pack=n_leg / t_k, d2h_bytes_per_pair_pack=mb_k, with_h2d_d2h_pack_sustained_300=300 / t_k300)
             ingest.update(with_h2d_d2h_compact=n_leg / t_c, d2h_bytes_per_pair_compact=mb_c, value_with_h2d_sustained_300=300 / t_sus_ing,
                           with_h2d_d2h_push=n_leg / t_p, d2h_bytes_per_pair_push=mb_p, with_h2d_d2h_push_sustained_300=300 / t_p300)
+        ingest["ingest_uploads_by_form"] = ctx.ingest_stats()
         ingest["ingest_note"] = ("value_with_h2d: the timed loop with a NEW pair per step DMA-ed from a page-locked frame ring "
                                  "(ebvo_host_register, ebvo_stereo_upload_async on the context's upload stream, issued one pair ahead of "
                                  "its submission: nslots pairs in flight on nslots + 1 slots), barriers and MAX over ranks as for "

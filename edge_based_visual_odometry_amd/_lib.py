@@ -34,7 +34,7 @@ TOED_STRICT, TOED_HYBRID = 0, 1
 # every symbol include/ebvo_hip.h declares (checked by tests/test_abi_symbols.py)
 ABI_SYMBOLS = (
     "ebvo_strerror", "ebvo_last_error", "ebvo_abi_version", "ebvo_ctx_create", "ebvo_ctx_destroy",
-    "ebvo_set_toed_mode", "ebvo_get_toed_mode", "ebvo_toed_fallbacks", "ebvo_graph_launches", "ebvo_toed_stats", "ebvo_toed_screen_audit", "ebvo_stereo_upload_async", "ebvo_host_register", "ebvo_host_unregister",
+    "ebvo_set_toed_mode", "ebvo_get_toed_mode", "ebvo_toed_fallbacks", "ebvo_graph_launches", "ebvo_toed_stats", "ebvo_toed_screen_audit", "ebvo_stereo_upload_async", "ebvo_host_register", "ebvo_host_unregister", "ebvo_ingest_stats",
     "ebvo_stereo_fetch_compact_begin", "ebvo_stereo_fetch_compact_end", "ebvo_stereo_pushed_view",
     "ebvo_toed", "ebvo_toed_pair", "ebvo_epipolar_lines", "ebvo_epi_candidates", "ebvo_epi_candidates_staged", "ebvo_ncc_pairs",
     "ebvo_edge_patches", "ebvo_ncc_patches", "ebvo_ncc_quads", "ebvo_stereo_default_params", "ebvo_finalize_default_params",
@@ -214,6 +214,7 @@ def load_library() -> C.CDLL:
     lib.ebvo_stereo_upload_async.argtypes = [vp, i32, vp, vp, i32, i32, ssz, ssz]
     lib.ebvo_host_register.argtypes = [vp, vp, C.c_size_t]
     lib.ebvo_host_unregister.argtypes = [vp, vp]
+    lib.ebvo_ingest_stats.argtypes = [vp, vp]
     lib.ebvo_stereo_fetch_compact_begin.argtypes = [vp, i32, i32]
     lib.ebvo_stereo_fetch_compact_end.argtypes = [vp, i32, C.POINTER(CompactView)]
     lib.ebvo_stereo_pushed_view.argtypes = [vp, i32, C.POINTER(CompactView)]

@@ -542,6 +542,11 @@ class Context:
         """page-lock a numpy array (a frame ring) for asynchronous uploads"""
         self._check(self.lib.ebvo_host_register(self._ctx, ptr(arr), arr.nbytes), "ebvo_host_register")
 
+    def ingest_stats(self) -> dict:
+        out = np.zeros(2, dtype=np.int64)
+        self._check(self.lib.ebvo_ingest_stats(self._ctx, ptr(out)), "ebvo_ingest_stats")
+        return {"pull_uploads": int(out[0]), "stream_uploads": int(out[1])}
+
     def host_unregister(self, arr: np.ndarray):
         self._check(self.lib.ebvo_host_unregister(self._ctx, ptr(arr)), "ebvo_host_unregister")
 

@@ -1214,6 +1214,7 @@ extern "C" int ebvo_stereo_upload_async(ebvo_ctx *ctx, int slot, const uint8_t *
                 s.mail.stride[k] = (long long)strides[k];
             }
             s.pull = true;
+            ++ctx->pull_uploads;
             s.undist_pair = ctx->undist_on;
             s.toed_strict_override = false;
             s.cur_h = h;
@@ -1222,6 +1223,7 @@ extern "C" int ebvo_stereo_upload_async(ebvo_ctx *ctx, int slot, const uint8_t *
             return EBVO_OK;
         }
     }
+    ++ctx->stream_uploads;
     EBVO_HIP(ctx, hipSetDevice(ctx->device));
     if (!ctx->upload_stream)
         EBVO_HIP(ctx, hipStreamCreateWithFlags(&ctx->upload_stream, hipStreamNonBlocking));
@@ -1279,6 +1281,17 @@ extern "C" int ebvo_host_register(ebvo_ctx *ctx, void *p, size_t bytes)
     }
     r.dev = static_cast<const uint8_t *>(d);
     ctx->host_ranges.push_back(r);
+    return EBVO_OK;
+}
+
+// how many ebvo_stereo_upload_async calls took the pull form / the upload stream so far (a frame loop checks that its ring is
+// really registered: a pageable source silently takes the slow form)
+extern "C" int ebvo_ingest_stats(const ebvo_ctx *ctx, int64_t out[2])
+{
+    if (!ctx || !out)
+        return EBVO_ERR_ARG;
+    out[0] = ctx->pull_uploads;
+    out[1] = ctx->stream_uploads;
     return EBVO_OK;
 }
 

@@ -260,6 +260,7 @@ struct ebvo_ctx
         bool ours = false; // registered by the library (to be unregistered by it)
     };
     std::vector<HostRange> host_ranges;
+    int64_t pull_uploads = 0, stream_uploads = 0; // ebvo_stereo_upload_async calls by form (ebvo_ingest_stats)
     hipStream_t upload_stream = nullptr;   // image uploads of ebvo_stereo_upload_async (all slots), created on first use
     // resident stage-wise path (ebvo_toed_resident / ebvo_epi_candidates_resident / ebvo_ncc_pairs_resident): the TOED results
     // of the last two images stay in slot 0's image workspaces; tag 0 = that workspace holds nothing a caller may refer to

@@ -621,6 +621,8 @@ int ebvo_stereo_upload_async(ebvo_ctx *ctx, int slot, const uint8_t *img_left, c
 /* page-lock / release caller memory (hipHostRegister / hipHostUnregister): no HIP header needed on the host side */
 int ebvo_host_register(ebvo_ctx *ctx, void *p, size_t bytes);
 int ebvo_host_unregister(ebvo_ctx *ctx, void *p);
+/* diagnostics: ebvo_stereo_upload_async calls so far that took {the pull form, the upload stream} */
+int ebvo_ingest_stats(const ebvo_ctx *ctx, int64_t out[2]);
 int ebvo_stereo_submit(ebvo_ctx *ctx, int slot, const ebvo_stereo_params *p);
 int ebvo_stereo_wait(ebvo_ctx *ctx, int slot, ebvo_stereo_counts *counts);
 int ebvo_stereo_fetch_slot(ebvo_ctx *ctx, int slot, ebvo_edge *left, ebvo_edge *right, int32_t *row_ptr,

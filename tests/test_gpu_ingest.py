@@ -57,6 +57,7 @@ def test_async_upload_a_pair_ahead_equals_synchronous_upload(c, registered):
         for pair in ring:
             for im in pair:
                 c.host_register(im)
+    before = c.ingest_stats()
     try:
         p = c.default_params(F)
         S, inflight, steps = 4, 3, 14
@@ -80,6 +81,10 @@ def test_async_upload_a_pair_ahead_equals_synchronous_upload(c, registered):
                 c.stereo_upload_async(*ring[uploaded % 5], slot=k)
                 uploaded += 1
                 ahead = k
+        after = c.ingest_stats()
+        form = "pull_uploads" if registered else "stream_uploads"       # registered memory takes the pull form, pageable the stream
+        other = "stream_uploads" if registered else "pull_uploads"
+        assert after[form] - before[form] == uploaded and after[other] == before[other]
     finally:
         if registered:
             for pair in ring:

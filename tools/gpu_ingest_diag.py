@@ -65,7 +65,7 @@ def ing(n, fetch=None):
 t0 = time.perf_counter()
 for _ in range(200):
     ctx.stereo_upload_async(*ring[0], slot=NS)
-print(f"host time of ebvo_stereo_upload_async (pull form): {(time.perf_counter() - t0) / 200 * 1e6:.1f} us per call", flush=True)
+print(f"host time of ebvo_stereo_upload_async: {(time.perf_counter() - t0) / 200 * 1e6:.1f} us per call; by form: {ctx.ingest_stats()}", flush=True)
 show("ingest warm 28", lambda: ing(28))
 show("ingest 20", lambda: ing(20))
 hu = {}
@@ -83,6 +83,7 @@ show(f"ingest + {flags} 60", lambda: ing(60, flags))
 show(f"ingest + {flags} 300", lambda: ing(300, flags))
 show("ingest 300 (after the fetch loops)", lambda: ing(300))
 show("ingest 300 again", lambda: ing(300))
+print("uploads by form:", ctx.ingest_stats(), flush=True)
 show("resident 300 (7 slots exist now)", lambda: resident(300))
 for k in range(NS + 1):
     ctx.stereo_upload(left, right, slot=k)
