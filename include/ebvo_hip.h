@@ -610,12 +610,14 @@ int ebvo_stereo_fetch(ebvo_ctx *ctx, ebvo_edge *left, ebvo_edge *right, int32_t 
 int ebvo_stereo_set_slots(ebvo_ctx *ctx, int n_slots);
 int ebvo_stereo_upload_slot(ebvo_ctx *ctx, int slot, const uint8_t *img_left, const uint8_t *img_right, int h, int w,
                             ptrdiff_t stride_left, ptrdiff_t stride_right);
-/* The same upload without blocking the caller (round 4): the copies run on the context's upload stream and the slot's next
- * ebvo_stereo_submit waits for them ON THE DEVICE.  Meant to be called a frame ahead of the submission (a frame loop reads
- * frame k + 1 while frame k is matched: src/Pipeline.cpp:77-99, cmd/main_VO.cpp:99-113), so that the wait is already satisfied.
- * Truly asynchronous only when both images lie in page-locked memory (ebvo_host_register on the caller's frame ring, or
- * hipHostMalloc); the images must then stay unchanged until the pair's ebvo_stereo_wait has returned.  From pageable memory
- * the call behaves like ebvo_stereo_upload_slot. */
+/* The same upload without blocking the caller (round 4), for a frame loop that reads frame k + 1 while frame k is matched
+ * (src/Pipeline.cpp:77-99, cmd/main_VO.cpp:99-113).
+ * PULL FORM (both images inside a range registered with ebvo_host_register -- the caller's frame ring, registered once;
+ * memory that is page-locked already, hipHostMalloc, may be registered too): the call only records where the images lie (no
+ * runtime call, < 1 us) and the pair's own chain starts with a kernel that READS them from the caller's memory -- no copy
+ * engine, no second stream, no event.  The images must stay unchanged until the pair's ebvo_stereo_wait has returned, and
+ * registered as long as the slot is submitted with them.  Images anywhere else take the staged copy on the context's upload
+ * stream (ebvo_ingest_stats tells which form the calls took). */
 int ebvo_stereo_upload_async(ebvo_ctx *ctx, int slot, const uint8_t *img_left, const uint8_t *img_right, int h, int w,
                              ptrdiff_t stride_left, ptrdiff_t stride_right);
 /* page-lock / release caller memory (hipHostRegister / hipHostUnregister): no HIP header needed on the host side */
