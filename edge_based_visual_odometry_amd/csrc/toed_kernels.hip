@@ -803,7 +803,43 @@ __global__ __launch_bounds__(256) void toed_screen_fused_kernel(ImgBatch B, cons
             {
                 const float gx = fx[e], gy = fy[e], ax = fabsf(gx), ay = fabsf(gy);
                 if (ax < SCREEN_TOL_M || ay < SCREEN_TOL_M || fabsf(ax - ay) < SCREEN_TOL_M)
-                    f = 1; // the exact sector could differ from the screen's: let the exact stage decide
+                {
+                    // The exact sector could differ from the screen's.  Round 3 flagged every such point (an axis-aligned
+                    // synthetic image -- gy == 0 exactly -- then flags every point with |g| > 2 and overflows the candidate
+                    // buffers).  Round 4: the point is tested against BOTH sectors the exact gradient can lie in.  They share
+                    // one neighbour pair and differ in the other, which enters with a weight of at most w_up:
+                    //   |gy| < T (or |gx| < T): the two sectors next to the x (y) axis.  Axis neighbours in common; the diagonal
+                    //     is the one above or the one below; exact slope <= (T + E_G) / (|major| - E_G) <= 2 T / |major|, so
+                    //     fp lies within w_up * max|diagonal - axis| of the axis neighbour;
+                    //   ||gx| - |gy|| < T: the two sectors next to the diagonal.  Diagonal neighbours in common; the axis
+                    //     neighbour is the horizontal or the vertical one; 1 - slope <= (T + 2 E_G) / (major - E_G) <= 2 T / major.
+                    // The signs of the components the case relies on are certain (|component| >= T > E_G).  T_M covers the rest
+                    // as in the unambiguous test below (two screened magnitudes, the float arithmetic).
+                    const bool px = gx >= 0, py = gy >= 0;
+                    const int ctr = (ph * FE_H + er) * FE_W + c;
+                    const int rP = py ? rup : rdn, rM = py ? rdn : rup, cP = px ? cup : cdn, cM = px ? cdn : cup;
+                    float np, nm, dp, dm, w_up; // shared neighbour (+ / - side), largest distance of the uncertain ones from it
+                    if (ay < SCREEN_TOL_M || ax < SCREEN_TOL_M)
+                    {
+                        const bool xd = ay < SCREEN_TOL_M; // x dominates
+                        const int aP = xd ? cP : rP, aM = xd ? cM : rM, o1 = xd ? rup : cup, o2 = xd ? rdn : cdn;
+                        np = Mflat[ctr + aP];
+                        nm = Mflat[ctr + aM];
+                        dp = fmaxf(fabsf(Mflat[ctr + aP + o1] - np), fabsf(Mflat[ctr + aP + o2] - np));
+                        dm = fmaxf(fabsf(Mflat[ctr + aM + o1] - nm), fabsf(Mflat[ctr + aM + o2] - nm));
+                        w_up = 2.0f * SCREEN_TOL_M / (xd ? ax : ay);
+                    }
+                    else
+                    {
+                        np = Mflat[ctr + rP + cP];
+                        nm = Mflat[ctr + rM + cM];
+                        dp = fmaxf(fabsf(Mflat[ctr + cP] - np), fabsf(Mflat[ctr + rP] - np));
+                        dm = fmaxf(fabsf(Mflat[ctr + cM] - nm), fabsf(Mflat[ctr + rM] - nm));
+                        w_up = 2.0f * SCREEN_TOL_M / fmaxf(ax, ay);
+                    }
+                    if (m >= np - (SCREEN_TOL_M + w_up * dp) && m >= nm - (SCREEN_TOL_M + w_up * dm))
+                        f = 1;
+                }
                 else
                 {
                     // the sector table of nms_core, by selects:
