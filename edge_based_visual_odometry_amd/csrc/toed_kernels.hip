@@ -587,9 +587,9 @@ __global__ __launch_bounds__(256) void toed_finalize_kernel(ImgBatch B, int h, i
 // The relaxed test uses TOL_M = 5e-4 (1.9 x what a comparison needs, 4.1 x E_M, 6.5 x E_G) wherever a magnitude or a gradient
 // component is compared with a constant or with another component, and TOL_M + TOL_S |p2 - p1|, TOL_S = 2.5e-4
 // (2.3 x E_S), where it is compared with an interpolated neighbour:
-//   |g| > 2 - TOL_M, and either the gradient sector is ambiguous (|gx|, |gy| or ||gx| - |gy|| below TOL_M: the exact
-//   sector could differ from the screen's) or |g| >= fm - tol and |g| >= fp - tol with the screen's own neighbours; the
-//   |s*| <= sqrt(2) test is left to the exact stage.
+//   |g| > 2 - TOL_M, and |g| >= fm - tol and |g| >= fp - tol with the screen's own interpolated neighbours; where the gradient
+//   sector is ambiguous (|gx|, |gy| or ||gx| - |gy|| below TOL_M: the exact sector could be either of two) the point is tested
+//   against both of them (see the kernel); the |s*| <= sqrt(2) test is left to the exact stage.
 // A wider tolerance only adds candidates, never removes one (round 3: 1e-3 / 5e-4 against twice these error bounds,
 // +2.1 % candidates; now +1.0 %); every TOED parity test runs in this mode.
 // ==========================================================================================
