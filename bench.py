@@ -242,13 +242,14 @@ KERNEL_GROUPS = {
                "toed_compact": "toed_compact_phase + toed_need_count / _rowscan / _compact",
                "toed_exact_centre": "toed_exact_centre", "toed_exact_mags": "toed_exact_mags + toed_exact_decide",
                "toed_finalize": "toed_cand_scatter", "scan": "scan_reduce + scan_apply (flag scans of both images, row_ptr)",
-               "cand_boxes": "boxes + clears", "epi_lines": "lines", "cand_count": "candidates<count>",
-               "cand_fill": "candidates_copy + candidates<fill>", "edge_patches": "sincos_batch + row_pairs + right_bank",
+               "cand_boxes": "match_prep (lines + boxes + sincos + row_pairs in one launch)", "cand_count": "candidates<count>",
+               "cand_fill": "candidates<fill> (with the copy of the staged rows as its prologue)", "edge_patches": "right_bank",
                "ncc_pairs": "ncc_tile + pair_result"},
     "strict": {"toed_conv": "toed_conv", "toed_nms": "toed_nms", "toed_rowscan": "toed_rowscan", "toed_compact": "toed_compact",
-               "toed_finalize": "toed_finalize", "scan": "scan_reduce + scan_apply", "cand_boxes": "boxes + clears",
-               "epi_lines": "lines", "cand_count": "candidates<count>", "cand_fill": "candidates_copy + candidates<fill>",
-               "edge_patches": "sincos_batch + row_pairs + right_bank", "ncc_pairs": "ncc_tile + pair_result"},
+               "toed_finalize": "toed_finalize", "scan": "scan_reduce + scan_apply",
+               "cand_boxes": "match_prep (lines + boxes + sincos + row_pairs in one launch)",
+               "cand_count": "candidates<count>", "cand_fill": "candidates<fill> (with the copy of the staged rows as its prologue)",
+               "edge_patches": "right_bank", "ncc_pairs": "ncc_tile + pair_result"},
 }
 
 
@@ -1120,7 +1121,7 @@ def main():
             ctx.stereo_upload(left, right, slot=k)
 
     if rank == 0:
-        n_ser = max(1, prof["epi_lines"][1])
+        n_ser = max(1, prof["cand_count"][1])                   # (one launch of the counting pass per pair)
         kernels = {k: {"ms_per_step": v[0] / n_ser, "launches_per_step": v[1] / n_ser} for k, v in prof.items() if v[1]}
         dom = dom_name
         dom_avg_s = prof_dom[0] * 1e-3 / max(1, prof_dom[1])

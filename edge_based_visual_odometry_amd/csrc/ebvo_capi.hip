@@ -192,6 +192,8 @@ static void slot_destroy(Slot *s)
         (void)hipEventDestroy(s->ev_upload);
     if (s->h_push)
         (void)hipHostFree(s->h_push);
+    if (s->h_mail)
+        (void)hipHostFree(s->h_mail);
     (void)hipFree(s->d_fin_tot);
     if (s->h_fin_tot)
         (void)hipHostFree(s->h_fin_tot);
@@ -286,10 +288,13 @@ static int slot_create(ebvo_ctx *ctx, Slot **out)
     CK(hipMalloc(&s->d_total, sizeof(unsigned long long) * (1 + EBVO_TOTAL_PARTS)));
     CK(hipMalloc(&s->d_matches, sizeof(int32_t) * EBVO_MATCH_PARTS));
     CK(hipMalloc(&s->d_sizes, sizeof(int32_t) * 4));
-    CK(hipMalloc(&s->d_F, sizeof(double) * 9 + sizeof(Slot::PullMail)));
-    s->d_mail = reinterpret_cast<Slot::PullMail *>(s->d_F + 9);
+    CK(hipMalloc(&s->d_F, sizeof(double) * 9));
+    CK(hipHostMalloc(reinterpret_cast<void **>(&s->h_mail), sizeof(Slot::PullMail)));
+    memset(s->h_mail, 0, sizeof(Slot::PullMail));
+    CK(hipHostGetDevicePointer(reinterpret_cast<void **>(&s->d_mail), s->h_mail, 0));
     CK(hipMalloc(&s->d_result, sizeof(PairResult)));
     CK(hipHostMalloc(&s->h_result, sizeof(PairResult)));
+    CK(hipHostGetDevicePointer(reinterpret_cast<void **>(&s->d_result_host), s->h_result, 0));
     CK(hipMalloc(&s->d_fin_tot, sizeof(int32_t) * 8));
     CK(hipHostMalloc(&s->h_fin_tot, sizeof(int32_t) * 8));
     CK(hipEventCreateWithFlags(&s->ev_fin, hipEventDisableTiming));
@@ -1210,8 +1215,8 @@ extern "C" int ebvo_stereo_upload_async(ebvo_ctx *ctx, int slot, const uint8_t *
                 return rc;
             for (int k = 0; k < 2; ++k)
             {
-                s.mail.src[k] = dev[k];
-                s.mail.stride[k] = (long long)strides[k];
+                s.h_mail->src[k] = dev[k];
+                s.h_mail->stride[k] = (long long)strides[k];
             }
             s.pull = true;
             ++ctx->pull_uploads;
@@ -1373,13 +1378,14 @@ static int enqueue_matching(ebvo_ctx *ctx, Slot &s, int toed_mode = -1)
     const int h = s.cur_h, w = s.cur_w, ce = ctx->cap_edges;
     const int32_t *d_nL = s.im[0].counts + 1, *d_nR = s.im[1].counts + 1;
     int rc;
-    if ((rc = match_lines_enqueue(ctx, s, s.d_F, s.im[0].edges, 0, d_nL, ce, (double *)s.lines.p)))
+    // lines, boxes, sin / cos and row-pair images in one launch (round 4: four launches of ~5 us each before)
+    if ((rc = match_prep_enqueue(ctx, s, h, w, ce)))
         return rc;
     if ((rc = match_candidates_enqueue(ctx, s, s.im[0].edges, 0, d_nL, s.im[1].edges, 0, d_nR, ce,
                                        (const double *)s.lines.p, p.epi_thr, p.max_disp, p.orient_thr_deg, p.stage_mask,
-                                       true)))
+                                       true, true)))
         return rc;
-    if ((rc = match_ncc_resident_enqueue(ctx, s, h, w, ce, p.ncc_thr, 0, !(p.reserved & EBVO_PAIR_NO_SIMS))))
+    if ((rc = match_ncc_resident_enqueue(ctx, s, h, w, ce, p.ncc_thr, 0, !(p.reserved & EBVO_PAIR_NO_SIMS), true)))
         return rc;
     // a hybrid TOED run reports candidate lists that did not fit through the result record (bit 1, value 2, of `overflow`)
     if ((rc = match_pair_result_enqueue(ctx, s, (toed_mode < 0 ? ctx->toed_mode : toed_mode) == EBVO_TOED_HYBRID ? ce : 0)))
@@ -1716,18 +1722,13 @@ extern "C" int ebvo_stereo_submit(ebvo_ctx *ctx, int slot, const ebvo_stereo_par
     s.have_push = s.have_pack = false;
     if ((s.params.reserved & (EBVO_PAIR_PUSH | EBVO_PAIR_PACK)) && (rc = ensure_push_arena(ctx, s)))
         return rc;
+    // the fundamental matrix goes up only when it differs from what the device holds (a sequence has ONE; the copy of 72 bytes
+    // from pageable memory is a blit kernel of ~5 us at the head of the chain otherwise)
+    if (!s.F_dev_valid || memcmp(s.F_dev, s.params.F21, sizeof s.F_dev) != 0)
     {
-        // the fundamental matrix and the pull mailbox in ONE small copy (the runtime takes a copy of a pageable source this small
-        // before the call returns)
-        struct
-        {
-            double F[9];
-            Slot::PullMail mail;
-        } blk;
-        static_assert(sizeof blk == sizeof(double) * 9 + sizeof(Slot::PullMail), "d_F layout");
-        memcpy(blk.F, s.params.F21, sizeof blk.F);
-        blk.mail = s.mail;
-        EBVO_HIP(ctx, hipMemcpyAsync(s.d_F, &blk, s.pull ? sizeof blk : sizeof blk.F, hipMemcpyHostToDevice, s.stream));
+        EBVO_HIP(ctx, hipMemcpyAsync(s.d_F, s.params.F21, sizeof(double) * 9, hipMemcpyHostToDevice, s.stream));
+        memcpy(s.F_dev, s.params.F21, sizeof s.F_dev);
+        s.F_dev_valid = true;
     }
     if ((rc = submit_pair_chain(ctx, s)))
         return rc;

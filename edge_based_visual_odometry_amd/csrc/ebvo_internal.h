@@ -131,15 +131,14 @@ struct Slot
     hipEvent_t ev_done = nullptr;     // recorded behind the last kernel of a submitted pair
     hipEvent_t ev_rebind = nullptr;   // orders a slot's earlier work before its first work on another lane
     // ebvo_stereo_upload_async, pull form: the pair's chain starts with a kernel that READS the two images from the caller's
-    // page-locked memory (the pointers travel in a small device mailbox that every submission refreshes together with the
-    // fundamental matrix -- one 104-byte copy on the pair's stream -- so the captured graph of the chain never changes)
+    // page-locked memory (the pointers travel in this page-locked mailbox, which the kernel reads over PCIe -- 32 bytes -- so
+    // the captured graph of the chain never changes and a submission issues no copy for it)
     struct PullMail
     {
         const uint8_t *src[2];
         long long stride[2];
     };
-    PullMail mail{};                               // host copy; travels to d_mail with the fundamental matrix at every submission
-    PullMail *d_mail = nullptr;                    // device address of the mailbox (behind d_F's nine doubles, one allocation)
+    PullMail *h_mail = nullptr, *d_mail = nullptr; // page-locked mailbox: host address / the address the pull kernel reads it at
     bool pull = false;                             // the resident pair is pulled by the chain itself
     hipEvent_t ev_upload = nullptr;   // end of the slot's asynchronous image upload (ebvo_stereo_upload_async, the context's upload stream)
     bool upload_pending = false;      // ... recorded and not yet waited for by a submission or a host call
@@ -192,8 +191,12 @@ struct Slot
     int32_t *d_matches = nullptr; // [EBVO_MATCH_PARTS] per-block kept-pair counts of ncc_tile_kernel
     int n_match_part = 0;
     int32_t *d_sizes = nullptr;          // [4] host-provided sizes for the host-buffer entry points
-    double *d_F = nullptr;               // 9 doubles, then the pull mailbox (Slot::PullMail): ONE host-to-device copy per submission
+    double *d_F = nullptr;               // 9 doubles
     PairResult *d_result = nullptr, *h_result = nullptr; // h_result is pinned
+    PairResult *d_result_host = nullptr;                 // the device's address of h_result: pair_result_kernel writes the record
+                                                         // straight into host memory (round 4: no copy node behind it)
+    double F_dev[9] = {0};                               // what d_F holds (uploaded again only when the caller's matrix changes)
+    bool F_dev_valid = false;
     void *h_arena = nullptr;             // pinned staging of ebvo_stereo_fetch_begin / _end
     size_t h_arena_bytes = 0;
     int fetch_what = 0;                  // arrays in flight to / present in h_arena
@@ -363,7 +366,7 @@ int match_lines_enqueue(ebvo_ctx *ctx, Slot &s, const double *d_F, const ebvo_ed
 // s.d_total receives the 64-bit number of pairs found
 int match_candidates_enqueue(ebvo_ctx *ctx, Slot &s, const ebvo_edge *d_L, int nL, const int32_t *d_nL,
                              const ebvo_edge *d_R, int nR, const int32_t *d_nR, int cap_edges, const double *d_lines,
-                             double epi_thr, double max_disp, double orient_thr_deg, int stage_mask, bool fill);
+                             double epi_thr, double max_disp, double orient_thr_deg, int stage_mask, bool fill, bool prep_done = false);
 int match_candidates_fill_enqueue(ebvo_ctx *ctx, Slot &s, const ebvo_edge *d_L, int nL, const int32_t *d_nL,
                                   const ebvo_edge *d_R, int nR, const int32_t *d_nR, int cap_edges,
                                   const double *d_lines, double epi_thr, double max_disp, double orient_thr_deg,
@@ -379,7 +382,11 @@ int match_ncc_pairs_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_imgR, int h
                             const int32_t *d_n_pairs = nullptr /* the count on the device; n_pairs is then its bound */);
 // resident pipeline: sin/cos, right patch bank, LDS-tiled NCC of every CSR pair (sizes read on the device)
 // left = index of the slot's image workspace that holds the LEFT image and edges (the right one is the other)
-int match_ncc_resident_enqueue(ebvo_ctx *ctx, Slot &s, int h, int w, int cap_edges, double thr, int left = 0, bool want_sims = true);
+int match_ncc_resident_enqueue(ebvo_ctx *ctx, Slot &s, int h, int w, int cap_edges, double thr, int left = 0, bool want_sims = true,
+                               bool prep_done = false);
+// epipolar lines, right-edge boxes (+ tile flags), sin / cos of both edge lists and both row-pair images of a resident pair in
+// ONE launch; pass prep_done = true to the two calls above / below afterwards
+int match_prep_enqueue(ebvo_ctx *ctx, Slot &s, int h, int w, int cap_edges);
 size_t match_right_bank_bytes(int cap_edges);
 int match_pair_result_enqueue(ebvo_ctx *ctx, Slot &s, int cand_cap); // cand_cap > 0: hybrid TOED, report candidates > cand_cap
 int match_orient_flags_enqueue(ebvo_ctx *ctx, Slot &s, const ebvo_edge *d_L, int nL, const ebvo_edge *d_R, const int32_t *d_row_ptr,

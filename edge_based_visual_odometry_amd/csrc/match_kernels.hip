@@ -84,17 +84,24 @@ struct CandParams
 };
 
 // ------------------------------------------------------------------------------------------
-__global__ void lines_kernel(const double *__restrict__ F, const ebvo_edge *__restrict__ e, DevN nd,
-                             double *__restrict__ lines)
+// (the small per-pair kernels below have their bodies as device functions of a VIRTUAL block index / grid size: the resident
+// pipeline runs four of them -- lines, boxes, sincos, row pairs -- as block ranges of ONE launch, match_prep_kernel)
+__device__ inline void lines_body(const double *__restrict__ F, const ebvo_edge *__restrict__ e, int n, double *__restrict__ lines,
+                                  int vb, int vg)
 {
-    const int n = devn(nd);
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x)
+    for (int k = vb * blockDim.x + threadIdx.x; k < n; k += vg * blockDim.x)
     {
         const double x = e[k].x, y = e[k].y;
 #pragma unroll
         for (int r = 0; r < 3; ++r)
             lines[(size_t)k * 3 + r] = (F[r * 3 + 0] * x + F[r * 3 + 1] * y) + F[r * 3 + 2];
     }
+}
+
+__global__ void lines_kernel(const double *__restrict__ F, const ebvo_edge *__restrict__ e, DevN nd,
+                             double *__restrict__ lines)
+{
+    lines_body(F, e, devn(nd), lines, blockIdx.x, gridDim.x);
 }
 
 __device__ inline double wave_min(double v)
@@ -112,14 +119,17 @@ __device__ inline double wave_max(double v)
 
 // Bounding boxes of the index ranges: one thread per chunk (CHUNK edges), one wave per group (64 chunks), so the group
 // box is a wave reduction of the chunk boxes it has just produced.
-__global__ __launch_bounds__(256) void boxes_kernel(const ebvo_edge *__restrict__ R, DevN nRd, Box *__restrict__ cb,
-                                                    Box *__restrict__ gb)
+__device__ inline void boxes_body(const ebvo_edge *__restrict__ R, int nR, Box *__restrict__ cb, Box *__restrict__ gb,
+                                  int32_t *__restrict__ tile_flag, int ntiles, int vb, int vg)
 {
     static_assert(GROUP == 64, "one wave per group");
-    const int nR = devn(nRd), nchunks = (nR + CHUNK - 1) / CHUNK, ngroups = (nchunks + GROUP - 1) / GROUP;
+    // the tile flags of the counting pass that follows (round 4: zeroed here instead of by a launch of their own)
+    for (int t = vb * blockDim.x + threadIdx.x; t < ntiles; t += vg * blockDim.x)
+        tile_flag[t] = 0;
+    const int nchunks = (nR + CHUNK - 1) / CHUNK, ngroups = (nchunks + GROUP - 1) / GROUP;
     const int lane = threadIdx.x & 63;
     const double inf = __builtin_inf();
-    for (int g = blockIdx.x * 4 + (threadIdx.x >> 6); g < ngroups; g += gridDim.x * 4)
+    for (int g = vb * 4 + (threadIdx.x >> 6); g < ngroups; g += vg * 4)
     {
         const int c = g * GROUP + lane;
         Box b;
@@ -144,6 +154,12 @@ __global__ __launch_bounds__(256) void boxes_kernel(const ebvo_edge *__restrict_
         if (lane == 0)
             gb[g] = u;
     }
+}
+
+__global__ __launch_bounds__(256) void boxes_kernel(const ebvo_edge *__restrict__ R, DevN nRd, Box *__restrict__ cb,
+                                                    Box *__restrict__ gb, int32_t *__restrict__ tile_flag, int ntiles)
+{
+    boxes_body(R, devn(nRd), cb, gb, tile_flag, ntiles, blockIdx.x, gridDim.x);
 }
 
 // Can any point of the box satisfy the enabled epipolar / disparity predicates?  Conservative.
@@ -324,6 +340,23 @@ __global__ __launch_bounds__(256) void candidates_kernel(const ebvo_edge *__rest
 
     if (!FILL && blockIdx.x == 0 && tid == 0)
         cnt[nL] = 0; // the scan covers nL + 1 counts: row_ptr[nL] = total
+    if (FILL)
+    {
+        // rows with at most STAGE candidates are completed from the staging area (round 4: here, as the prologue of the fill
+        // pass, instead of in a launch of their own; the tiles below only redo rows that are longer -- disjoint writes)
+        const int e16 = tid & 15;
+        const int rows = (gridDim.x * 256) >> 4;
+        for (int i = (blockIdx.x * 256 + tid) >> 4; i < nL; i += rows)
+        {
+            const int64_t o = row_ptr[i];
+            const int n = row_ptr[i + 1] - row_ptr[i];
+            if (n > STAGE)
+                continue;
+            for (int k = e16; k < n; k += 16)
+                if (o + k < P.cap)
+                    col_idx[o + k] = P.stage[(size_t)i * STAGE + k];
+        }
+    }
     // grid-stride over the tiles so the launch does not depend on nL
     for (int tile = blockIdx.x; tile * TILE < nL; tile += gridDim.x)
     {
@@ -748,12 +781,9 @@ struct PatchBatch
     uint8_t *flag[2];
 };
 
-__global__ void sincos_batch_kernel(PatchBatch B)
+__device__ inline void sincos_body(const ebvo_edge *__restrict__ e, int n, double2 *__restrict__ sc, int vb, int vg)
 {
-    const ebvo_edge *__restrict__ e = B.edges[blockIdx.y];
-    double2 *__restrict__ sc = B.sc[blockIdx.y];
-    const int n = devn(B.n[blockIdx.y]);
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x)
+    for (int k = vb * blockDim.x + threadIdx.x; k < n; k += vg * blockDim.x)
     {
         double sn, cs;
         ebvo_sincos(e[k].theta, &sn, &cs);
@@ -762,6 +792,11 @@ __global__ void sincos_batch_kernel(PatchBatch B)
         v.y = cs;
         sc[k] = v;
     }
+}
+
+__global__ void sincos_batch_kernel(PatchBatch B)
+{
+    sincos_body(B.edges[blockIdx.y], devn(B.n[blockIdx.y]), B.sc[blockIdx.y], blockIdx.x, gridDim.x);
 }
 
 __global__ void sincos_edges_kernel(const ebvo_edge *__restrict__ e, DevN nd, double2 *__restrict__ sc)
@@ -845,15 +880,11 @@ __device__ inline double bilinear_inside2(const uint16_t *__restrict__ pix2, int
     return ok ? v : __builtin_nan("");
 }
 
-__global__ __launch_bounds__(256) void row_pairs_kernel(const uint8_t *__restrict__ img0, const uint8_t *__restrict__ img1,
-                                                        uint16_t *__restrict__ out0, uint16_t *__restrict__ out1, int h,
-                                                        int w)
+__device__ inline void row_pairs_body(const uint8_t *__restrict__ img, uint16_t *__restrict__ out, int h, int w, int vb, int vg)
 {
-    const uint8_t *__restrict__ img = blockIdx.y ? img1 : img0;
-    uint16_t *__restrict__ out = blockIdx.y ? out1 : out0;
     const int n = h * w;
     // four pixels per thread; the image buffers have readable padding behind the last pixel (ebvo_capi.hip: img_base)
-    for (int o = (blockIdx.x * blockDim.x + threadIdx.x) * 4; o < n; o += gridDim.x * blockDim.x * 4)
+    for (int o = (vb * blockDim.x + threadIdx.x) * 4; o < n; o += vg * blockDim.x * 4)
     {
         unsigned a, b = 0;
         __builtin_memcpy(&a, img + o, 4);
@@ -875,6 +906,59 @@ __global__ __launch_bounds__(256) void row_pairs_kernel(const uint8_t *__restric
             for (int t = 0; t < 4 && o + t < n; ++t)
                 out[o + t] = (uint16_t)(t < 2 ? (r.x >> (16 * t)) : (r.y >> (16 * (t - 2))));
     }
+}
+
+__global__ __launch_bounds__(256) void row_pairs_kernel(const uint8_t *__restrict__ img0, const uint8_t *__restrict__ img1,
+                                                        uint16_t *__restrict__ out0, uint16_t *__restrict__ out1, int h,
+                                                        int w)
+{
+    row_pairs_body(blockIdx.y ? img1 : img0, blockIdx.y ? out1 : out0, h, w, blockIdx.x, gridDim.x);
+}
+
+// The four small preparations of the matching half of a resident pair as block ranges of ONE launch (round 4; each was a
+// launch of ~5 us behind a ~1 us body): epipolar lines of the left edges, chunk / group boxes of the right edges (+ the tile
+// flags of the counting pass), sin / cos of both edge lists, the row-pair images of both NCC images.  Nothing in one range
+// depends on another.
+struct PrepArgs
+{
+    const double *F;
+    const ebvo_edge *L, *R;
+    DevN nL, nR;
+    double *lines;
+    Box *cb, *gb;
+    int32_t *tile_flag;
+    int ntiles;
+    double2 *scL, *scR;
+    const uint8_t *img0, *img1;
+    uint16_t *pix0, *pix1;
+    int h, w;
+    int b_lines, b_boxes, b_sincos, b_rows; // blocks per range (sincos and rows: per image)
+};
+
+__global__ __launch_bounds__(256) void match_prep_kernel(PrepArgs A)
+{
+    int b = blockIdx.x;
+    if (b < A.b_lines)
+    {
+        lines_body(A.F, A.L, devn(A.nL), A.lines, b, A.b_lines);
+        return;
+    }
+    b -= A.b_lines;
+    if (b < A.b_boxes)
+    {
+        boxes_body(A.R, devn(A.nR), A.cb, A.gb, A.tile_flag, A.ntiles, b, A.b_boxes);
+        return;
+    }
+    b -= A.b_boxes;
+    if (b < 2 * A.b_sincos)
+    {
+        const int im = b >= A.b_sincos;
+        sincos_body(im ? A.R : A.L, devn(im ? A.nR : A.nL), im ? A.scR : A.scL, b - im * A.b_sincos, A.b_sincos);
+        return;
+    }
+    b -= 2 * A.b_sincos;
+    const int im = b >= A.b_rows;
+    row_pairs_body(im ? A.img1 : A.img0, im ? A.pix1 : A.pix0, A.h, A.w, b - im * A.b_rows, A.b_rows);
 }
 
 // True if every sample of both patches of an edge at (ex, ey) has its four corners inside the image: a sample lies within
@@ -1890,9 +1974,6 @@ int match_candidates_fill_enqueue(ebvo_ctx *ctx, Slot &s, const ebvo_edge *d_L, 
 {
     const CandParams P = cand_params(s, nL, d_nL, nR, d_nR, epi_thr, max_disp, orient_thr_deg, stage_mask, s.cap_pairs);
     ProfScope ps(ctx, s, K_CAND_FILL);
-    hipLaunchKernelGGL(candidates_copy_kernel, dim3(blocks_for((int64_t)(d_nL ? cap_edges : nL) * 16, 256, 2048)), dim3(256), 0, s.stream,
-                       (const int32_t *)s.row_ptr.p, (const int32_t *)s.cand_stage.p, DevN{nL, d_nL}, s.cap_pairs,
-                       (int32_t *)s.col_idx.p);
     hipLaunchKernelGGL(candidates_kernel<true>, dim3(blocks_for(d_nL ? cap_edges : nL, TILE, 4096)), dim3(256), 0,
                        s.stream, d_L, d_R, d_lines, (const Box *)s.boxes_chunk.p, (const Box *)s.boxes_group.p, P,
                        (int32_t *)nullptr, (const int32_t *)s.row_ptr.p, (int32_t *)s.col_idx.p,
@@ -1901,11 +1982,9 @@ int match_candidates_fill_enqueue(ebvo_ctx *ctx, Slot &s, const ebvo_edge *d_L, 
     return EBVO_OK;
 }
 
-int match_candidates_enqueue(ebvo_ctx *ctx, Slot &s, const ebvo_edge *d_L, int nL, const int32_t *d_nL,
-                             const ebvo_edge *d_R, int nR, const int32_t *d_nR, int cap_edges, const double *d_lines,
-                             double epi_thr, double max_disp, double orient_thr_deg, int stage_mask, bool fill)
+// the buffers of the candidate search for capL left and capR right edges; *ntiles_out, *capgroups_out: what the launches need
+static int candidates_buffers(ebvo_ctx *ctx, Slot &s, int capL, int capR, size_t *ntiles_out, int *capgroups_out)
 {
-    const int capL = d_nL ? cap_edges : nL, capR = d_nR ? cap_edges : nR;
     int rc;
     if ((rc = ebvo_grow(ctx, s, s.row_ptr, sizeof(int32_t) * ((size_t)capL + 1))))
         return rc;
@@ -1921,18 +2000,68 @@ int match_candidates_enqueue(ebvo_ctx *ctx, Slot &s, const ebvo_edge *d_L, int n
         return rc;
     if ((rc = ebvo_grow(ctx, s, s.cand_tileflag, sizeof(int32_t) * ntiles)))
         return rc;
+    *ntiles_out = ntiles;
+    *capgroups_out = capgroups;
+    return EBVO_OK;
+}
+
+// lines + boxes (+ tile flags) + sincos + row pairs of a resident pair in one launch (match_prep_kernel); the later
+// match_candidates_enqueue / match_ncc_resident_enqueue calls are told that their preparations have run
+int match_prep_enqueue(ebvo_ctx *ctx, Slot &s, int h, int w, int cap_edges)
+{
+    int rc;
+    size_t ntiles = 0;
+    int capgroups = 0;
+    if ((rc = candidates_buffers(ctx, s, cap_edges, cap_edges, &ntiles, &capgroups)) ||
+        (rc = ebvo_grow(ctx, s, s.sincos, sizeof(double2) * 2 * (size_t)cap_edges)))
+        return rc;
+    PrepArgs A{};
+    A.F = s.d_F;
+    A.L = s.im[0].edges;
+    A.R = s.im[1].edges;
+    A.nL = DevN{0, s.im[0].counts + 1};
+    A.nR = DevN{0, s.im[1].counts + 1};
+    A.lines = (double *)s.lines.p;
+    A.cb = (Box *)s.boxes_chunk.p;
+    A.gb = (Box *)s.boxes_group.p;
+    A.tile_flag = (int32_t *)s.cand_tileflag.p;
+    A.ntiles = (int)ntiles;
+    A.scL = (double2 *)s.sincos.p;
+    A.scR = A.scL + cap_edges;
+    A.img0 = ncc_img(s, 0);
+    A.img1 = ncc_img(s, 1);
+    A.pix0 = s.im[0].pix2;
+    A.pix1 = s.im[1].pix2;
+    A.h = h;
+    A.w = w;
+    A.b_lines = (int)blocks_for(cap_edges, 256, 1024);
+    A.b_boxes = (int)blocks_for(capgroups, 4, 1024);
+    A.b_sincos = (int)blocks_for(cap_edges, 256, 512);
+    A.b_rows = (int)blocks_for(((int64_t)h * w + 3) / 4, 256, 512);
+    ProfScope ps(ctx, s, K_BOXES);
+    hipLaunchKernelGGL(match_prep_kernel, dim3(A.b_lines + A.b_boxes + 2 * A.b_sincos + 2 * A.b_rows), dim3(256), 0, s.stream, A);
+    EBVO_HIP(ctx, hipGetLastError());
+    return EBVO_OK;
+}
+
+int match_candidates_enqueue(ebvo_ctx *ctx, Slot &s, const ebvo_edge *d_L, int nL, const int32_t *d_nL,
+                             const ebvo_edge *d_R, int nR, const int32_t *d_nR, int cap_edges, const double *d_lines,
+                             double epi_thr, double max_disp, double orient_thr_deg, int stage_mask, bool fill, bool prep_done)
+{
+    const int capL = d_nL ? cap_edges : nL, capR = d_nR ? cap_edges : nR;
+    int rc;
+    size_t ntiles = 0;
+    int capgroups = 0;
+    if ((rc = candidates_buffers(ctx, s, capL, capR, &ntiles, &capgroups)))
+        return rc;
     int32_t *cnt = (int32_t *)s.cand_cnt.p;
+    if (!prep_done)
     {
-        // tile flags; cnt[nL] (the scan's trailing zero) and the per-block totals are written by the counting kernel
-        int32_t *ptrs[1] = {(int32_t *)s.cand_tileflag.p};
-        const int counts[1] = {(int)ntiles};
-        if ((rc = ebvo_clear_enqueue(ctx, s, ptrs, counts, 1)))
-            return rc;
-    }
-    {
+        // chunk / group boxes; the kernel also zeroes the tile flags (cnt[nL], the scan's trailing zero, and the per-block
+        // totals are written by the counting kernel)
         ProfScope ps(ctx, s, K_BOXES);
         hipLaunchKernelGGL(boxes_kernel, dim3(blocks_for(capgroups, 4, 1024)), dim3(256), 0, s.stream, d_R, DevN{nR, d_nR},
-                           (Box *)s.boxes_chunk.p, (Box *)s.boxes_group.p);
+                           (Box *)s.boxes_chunk.p, (Box *)s.boxes_group.p, (int32_t *)s.cand_tileflag.p, (int)ntiles);
     }
     const CandParams P = cand_params(s, nL, d_nL, nR, d_nR, epi_thr, max_disp, orient_thr_deg, stage_mask, s.cap_pairs);
     {
@@ -2019,7 +2148,8 @@ int match_ncc_pairs_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_imgR, int h
 
 // NCC of the CSR pairs in s.row_ptr / s.col_idx of the resident pair: sin/cos of both edge lists, the right bank, the
 // tile kernel.  s.patches_norm_r holds the right bank (BANK_EDGE floats per edge).
-int match_ncc_resident_enqueue(ebvo_ctx *ctx, Slot &s, int h, int w, int cap_edges, double thr, int left, bool want_sims)
+int match_ncc_resident_enqueue(ebvo_ctx *ctx, Slot &s, int h, int w, int cap_edges, double thr, int left, bool want_sims,
+                               bool prep_done)
 {
     int rc;
     if ((rc = ebvo_grow(ctx, s, s.sincos, sizeof(double2) * 2 * (size_t)cap_edges)))
@@ -2036,9 +2166,12 @@ int match_ncc_resident_enqueue(ebvo_ctx *ctx, Slot &s, int h, int w, int cap_edg
     const DevN nLd{0, s.im[iL].counts + 1}, nRd{0, s.im[iR].counts + 1};
     {
         ProfScope ps(ctx, s, K_PATCHES);
-        hipLaunchKernelGGL(row_pairs_kernel, dim3(blocks_for(((int64_t)h * w + 3) / 4, 256, 512), 2), dim3(256), 0, s.stream,
-                           ncc_img(s, 0), ncc_img(s, 1), s.im[0].pix2, s.im[1].pix2, h, w);
-        hipLaunchKernelGGL(sincos_batch_kernel, dim3(blocks_for(cap_edges, 256, 512), 2), dim3(256), 0, s.stream, B);
+        if (!prep_done) // (the resident pair's chain has run both in match_prep_kernel)
+        {
+            hipLaunchKernelGGL(row_pairs_kernel, dim3(blocks_for(((int64_t)h * w + 3) / 4, 256, 512), 2), dim3(256), 0, s.stream,
+                               ncc_img(s, 0), ncc_img(s, 1), s.im[0].pix2, s.im[1].pix2, h, w);
+            hipLaunchKernelGGL(sincos_batch_kernel, dim3(blocks_for(cap_edges, 256, 512), 2), dim3(256), 0, s.stream, B);
+        }
         hipLaunchKernelGGL(right_bank_kernel, dim3(blocks_for((int64_t)cap_edges * 16, 256, 1024)), dim3(256), 0, s.stream,
                            ncc_img(s, iR), (const uint16_t *)s.im[iR].pix2, h, w, w, (const ebvo_edge *)s.im[iR].edges,
                            (const double2 *)B.sc[iR], nRd, (float *)s.patches_norm_r.p);
@@ -2169,9 +2302,10 @@ int match_pair_result_enqueue(ebvo_ctx *ctx, Slot &s, int cand_cap)
 {
     hipLaunchKernelGGL(pair_result_kernel, dim3(1), dim3(1024), 0, s.stream, (const int32_t *)s.im[0].counts,
                        (const int32_t *)s.im[1].counts, (const unsigned long long *)(s.d_total + 1), s.n_total_part,
-                       (const int32_t *)s.d_matches, s.n_match_part, s.cap_pairs, cand_cap, s.d_result);
+                       (const int32_t *)s.d_matches, s.n_match_part, s.cap_pairs, cand_cap, s.d_result_host);
     EBVO_HIP(ctx, hipGetLastError());
-    EBVO_HIP(ctx, hipMemcpyAsync(s.h_result, s.d_result, sizeof(PairResult), hipMemcpyDeviceToHost, s.stream));
+    // (the record is written straight into the slot's page-locked h_result: it is visible to the host when the event behind the
+    // chain has fired; round 3 copied it with one more node)
     return EBVO_OK;
 }
 
