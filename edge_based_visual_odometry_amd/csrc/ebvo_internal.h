@@ -281,6 +281,7 @@ struct ebvo_ctx
     uint64_t graph_gen = 1;     // bumped by every mode / debug change: invalidates the captured graphs of every slot
     int use_graphs = 1;         // EBVO_GRAPHS=0 or ebvo_debug_set(10, 0): direct launches only
     int64_t graph_launches = 0; // pairs submitted as a graph launch
+    int no_prep = 0;            // developer key (ebvo_debug_set 14): 1 = lines, boxes, sincos and row pairs as four launches (A/B)
     int ingest_stream = 0;      // developer key (ebvo_debug_set 13): 1 = ebvo_stereo_upload_async copies on the upload stream (A/B)
     bool screen_audit = false;  // ebvo_toed_screen_audit is running: the screen keeps its gx, gy, |g| (toed_kernels.hip)
     int64_t toed_fallbacks = 0; // hybrid TOED runs repeated on the strict path (more screened candidates than cap_edges)

@@ -1,4 +1,5 @@
 """A/B of round 4's switches on ONE box (run ON the GPU box): the resident pair loop and the streamed-ingest loop with
+  key 14 = 1  lines, boxes, sincos and row pairs as four launches instead of one (match_prep_kernel),
   key 13 = 1  ebvo_stereo_upload_async through the upload stream instead of the pull kernel,
   NO_SIMS off the four similarities stored (round 3),
 each against the defaults, interleaved and repeated (box-to-box and minute-to-minute drift is ~1 %)."""
@@ -53,7 +54,7 @@ def ingest(params, n, fetch=None):
 
 
 resident(p_nosims, 600)                      # clocks up
-configs = [("default", None, p_nosims),
+configs = [("default", None, p_nosims), ("four prep launches (14)", 14, p_nosims),
            ("sims stored", None, p_full)]
 rows = {name: [] for name, _, _ in configs}
 for rep in range(4):
