@@ -222,7 +222,7 @@ static int drain_fetch(ebvo_ctx *ctx, Slot &s)
 }
 
 // an earlier stream-form upload of the slot must have landed before the mailbox names other images (host wait; rare)
-static int drain_fetch_uploads_only(ebvo_ctx *ctx, Slot &s)
+static int drain_stream_upload(ebvo_ctx *ctx, Slot &s)
 {
     if (s.upload_pending)
         EBVO_HIP(ctx, hipEventSynchronize(s.ev_upload));
@@ -1211,7 +1211,7 @@ extern "C" int ebvo_stereo_upload_async(ebvo_ctx *ctx, int slot, const uint8_t *
         }
         if (pinned)
         {
-            if ((rc = drain_fetch_uploads_only(ctx, s)))
+            if ((rc = drain_stream_upload(ctx, s)))
                 return rc;
             for (int k = 0; k < 2; ++k)
             {
@@ -3615,6 +3615,28 @@ extern "C" int ebvo_temporal_fetch(ebvo_ctx *ctx, int slot, int32_t *row_ptr, in
     return EBVO_OK;
 }
 
+// the slot's page-locked result arena holds at least `bytes` (a re-allocation waits for copies still heading into the old one)
+static int ensure_arena(ebvo_ctx *ctx, Slot &s, size_t bytes)
+{
+    if (bytes <= s.h_arena_bytes)
+        return EBVO_OK;
+    if (s.fetch_pending)
+        EBVO_HIP(ctx, hipEventSynchronize(s.ev_rebind));
+    if (s.h_arena)
+        (void)hipHostFree(s.h_arena);
+    s.h_arena = nullptr;
+    s.h_arena_bytes = 0;
+    const size_t want = bytes + bytes / 4 + 4096;
+    if (hipHostMalloc(&s.h_arena, want) != hipSuccess)
+    {
+        (void)hipGetLastError();
+        ctx->last_error = "hipHostMalloc failed (page-locked result staging)";
+        return EBVO_ERR_NOMEM;
+    }
+    s.h_arena_bytes = want;
+    return EBVO_OK;
+}
+
 // ---- results through page-locked memory, no staging copy on the host ------------------------------------------------
 extern "C" int ebvo_stereo_fetch_begin(ebvo_ctx *ctx, int slot, int what)
 {
@@ -3644,23 +3666,8 @@ extern "C" int ebvo_stereo_fetch_begin(ebvo_ctx *ctx, int slot, int what)
         s.fetch_off[k] = total;
         total += (sizes[k] + 63) & ~(size_t)63;
     }
-    if (total > s.h_arena_bytes)
-    {
-        if (s.fetch_pending)
-            EBVO_HIP(ctx, hipEventSynchronize(s.ev_rebind));
-        if (s.h_arena)
-            (void)hipHostFree(s.h_arena);
-        s.h_arena = nullptr;
-        s.h_arena_bytes = 0;
-        const size_t want = total + total / 4 + 4096;
-        if (hipHostMalloc(&s.h_arena, want) != hipSuccess)
-        {
-            (void)hipGetLastError();
-            ctx->last_error = "hipHostMalloc failed (page-locked result staging)";
-            return EBVO_ERR_NOMEM;
-        }
-        s.h_arena_bytes = want;
-    }
+    if (int rc_arena = ensure_arena(ctx, s, total))
+        return rc_arena;
     const void *src[7] = {s.im[0].edges, s.im[1].edges, s.row_ptr.p, s.col_idx.p, s.sims.p, s.best.p, s.keep.p};
     char *base = static_cast<char *>(s.h_arena);
     // One copy stream for all slots: the pair is complete (the host has waited for it), so the copies need no ordering
@@ -3778,23 +3785,8 @@ extern "C" int ebvo_stereo_fetch_compact_begin(ebvo_ctx *ctx, int slot, int what
     {
         // the pair's own chain has packed the arrays (EBVO_PAIR_PACK): ONE copy of the block, sized by the actual counts
         const PackLayout lay = pack_layout(nL, nR, np, s.params.reserved & EBVO_PAIR_PUSH_THETA);
-        if (lay.total > s.h_arena_bytes)
-        {
-            if (s.fetch_pending)
-                EBVO_HIP(ctx, hipEventSynchronize(s.ev_rebind));
-            if (s.h_arena)
-                (void)hipHostFree(s.h_arena);
-            s.h_arena = nullptr;
-            s.h_arena_bytes = 0;
-            const size_t want = lay.total + lay.total / 4 + 4096;
-            if (hipHostMalloc(&s.h_arena, want) != hipSuccess)
-            {
-                (void)hipGetLastError();
-                ctx->last_error = "hipHostMalloc failed (page-locked result staging)";
-                return EBVO_ERR_NOMEM;
-            }
-            s.h_arena_bytes = want;
-        }
+        if (int rc_arena = ensure_arena(ctx, s, lay.total))
+            return rc_arena;
         if (!ctx->copy_stream)
             EBVO_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
         EBVO_HIP(ctx, hipMemcpyAsync(s.h_arena, s.fetch_pack.p, lay.total, hipMemcpyDeviceToHost, ctx->copy_stream));
@@ -3819,23 +3811,8 @@ extern "C" int ebvo_stereo_fetch_compact_begin(ebvo_ctx *ctx, int slot, int what
         s.fetch_off[k] = total;
         total += (sizes[k] + 63) & ~(size_t)63;
     }
-    if (total > s.h_arena_bytes)
-    {
-        if (s.fetch_pending)
-            EBVO_HIP(ctx, hipEventSynchronize(s.ev_rebind));
-        if (s.h_arena)
-            (void)hipHostFree(s.h_arena);
-        s.h_arena = nullptr;
-        s.h_arena_bytes = 0;
-        const size_t want = total + total / 4 + 4096;
-        if (hipHostMalloc(&s.h_arena, want) != hipSuccess)
-        {
-            (void)hipGetLastError();
-            ctx->last_error = "hipHostMalloc failed (page-locked result staging)";
-            return EBVO_ERR_NOMEM;
-        }
-        s.h_arena_bytes = want;
-    }
+    if (int rc_arena = ensure_arena(ctx, s, total))
+        return rc_arena;
     if (!ctx->copy_stream)
         EBVO_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
     // device staging of the packed arrays, laid out like the first four and the last array of the arena
