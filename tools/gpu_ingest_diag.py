@@ -4,7 +4,8 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # (a profiler may start the tool from /tmp)
 from edge_based_visual_odometry_amd import _lib, synth  # noqa: E402
 from edge_based_visual_odometry_amd.api import Context  # noqa: E402
 import bench  # noqa: E402
