@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libebvo_hip.so")
+LIB_PATH = os.environ.get("EBVO_LIB") or os.path.join(_HERE, "libebvo_hip.so")   # EBVO_LIB: another build of the same ABI (A/B runs)
 
 EDGE_DTYPE = np.dtype([("x", "<f8"), ("y", "<f8"), ("theta", "<f8"), ("index", "<i4"), ("pad", "<i4")])
 assert EDGE_DTYPE.itemsize == 32

@@ -1380,15 +1380,24 @@ static int enqueue_matching(ebvo_ctx *ctx, Slot &s, int toed_mode = -1)
     int rc;
     // lines, boxes, sin / cos and row-pair images in one launch (round 4: four launches of ~5 us each before)
     const bool prep = !ctx->no_prep;
+    const int stop = ctx->stop_stage; // (developer key 16: the counts of the last whole run stay in the pair's record)
+    if (stop && stop <= 7)
+        return EBVO_OK;
     if (prep ? (rc = match_prep_enqueue(ctx, s, h, w, ce))
              : (rc = match_lines_enqueue(ctx, s, s.d_F, s.im[0].edges, 0, d_nL, ce, (double *)s.lines.p)))
         return rc;
+    if (stop == 8)
+        return EBVO_OK;
     if ((rc = match_candidates_enqueue(ctx, s, s.im[0].edges, 0, d_nL, s.im[1].edges, 0, d_nR, ce,
                                        (const double *)s.lines.p, p.epi_thr, p.max_disp, p.orient_thr_deg, p.stage_mask,
                                        true, prep)))
         return rc;
+    if (stop && stop <= 11)
+        return EBVO_OK;
     if ((rc = match_ncc_resident_enqueue(ctx, s, h, w, ce, p.ncc_thr, 0, !(p.reserved & EBVO_PAIR_NO_SIMS), prep)))
         return rc;
+    if (stop)
+        return EBVO_OK;
     // a hybrid TOED run reports candidate lists that did not fit through the result record (bit 1, value 2, of `overflow`)
     if ((rc = match_pair_result_enqueue(ctx, s, (toed_mode < 0 ? ctx->toed_mode : toed_mode) == EBVO_TOED_HYBRID ? ce : 0)))
         return rc;
@@ -3969,6 +3978,14 @@ extern "C" int ebvo_debug_set(ebvo_ctx *ctx, int key, int value)
         ctx->use_graphs = value; // the pair chain as a hipGraph (default) or as direct launches
     else if (key == 14 && value <= 1)
         ctx->no_prep = value;
+    else if (key == 11 || key == 12)
+        ctx->exact_blocks[key - 11] = value;
+    else if (key == 15)
+        ctx->repeat_mask = value;
+    else if (key == 16)
+        ctx->stop_stage = value;
+    else if (key == 17)
+        ctx->ncc_blocks = value;
     else if (key == 13 && value <= 1)
         ctx->ingest_stream = value;
     else if (key == 0)

@@ -281,6 +281,12 @@ struct ebvo_ctx
     uint64_t graph_gen = 1;     // bumped by every mode / debug change: invalidates the captured graphs of every slot
     int use_graphs = 1;         // EBVO_GRAPHS=0 or ebvo_debug_set(10, 0): direct launches only
     int64_t graph_launches = 0; // pairs submitted as a graph launch
+    int exact_blocks[2] = {0, 0}; // developer keys (ebvo_debug_set 11, 12): grid of the exact centre / mags kernel in blocks (0 = what the device keeps resident)
+    int ncc_blocks = 0;         // developer key (ebvo_debug_set 17): grid of ncc_tile_kernel in blocks (0 = what the device keeps resident)
+    int stop_stage = 0;         // developer key (ebvo_debug_set 16): the resident pair's chain ends after stage N (tools/gpu_prefix_chain.py:
+                                // the pair rate of every prefix of the chain = what each stage costs in the steady state); 0 = whole chain
+    int repeat_mask = 0;        // developer key (ebvo_debug_set 15): bit 0 centre, 1 mags, 2 right bank, 3 NCC tile launched TWICE (idempotent kernels: what
+                                // one more launch of each costs the pair rate, tools/gpu_marginal_cost.py)
     int no_prep = 0;            // developer key (ebvo_debug_set 14): 1 = lines, boxes, sincos and row pairs as four launches (A/B)
     int ingest_stream = 0;      // developer key (ebvo_debug_set 13): 1 = ebvo_stereo_upload_async copies on the upload stream (A/B)
     bool screen_audit = false;  // ebvo_toed_screen_audit is running: the screen keeps its gx, gy, |g| (toed_kernels.hip)

@@ -28,6 +28,7 @@
 // patches in LDS and scores their CSR pairs eight lanes per pair (ncc_tile_kernel).
 //
 // Compiled with -ffp-contract=off: no FMA contraction anywhere; the explicit fma of dot7 is exact-product accumulation.
+#include <atomic>
 #include <cstdlib>
 
 #include "ebvo_internal.h"
@@ -1265,7 +1266,7 @@ __global__ void expand_rows_kernel(const int32_t *__restrict__ row_ptr, DevN nLd
 constexpr int BANK_SIDE = 56;   // floats per side of a bank entry: 7 rows x 8 floats (224 B, 16-byte aligned rows)
 constexpr int BANK_EDGE = 112;  // floats per edge (448 B)
 constexpr int NCC_NW = 4;       // left edges per wave (one sampling round: four 16-lane groups)
-constexpr int NCC_WPE = 5;      // waves per SIMD the tile kernel is compiled for
+constexpr int NCC_WPE = 4;      // waves per SIMD the tile kernel is compiled for (the prefetched loads need the registers)
 
 __global__ __launch_bounds__(256) void right_bank_kernel(const uint8_t *__restrict__ img,
                                                          const uint16_t *__restrict__ pix2, int h, int w, int pitch,
@@ -1320,7 +1321,7 @@ __global__ __launch_bounds__(256, WPE) void ncc_tile_kernel(const uint8_t *__res
                                                        double *__restrict__ sims, double *__restrict__ best,
                                                        uint8_t *__restrict__ keep, int32_t *__restrict__ match_part)
 {
-    static_assert(NW % 4 == 0 && NW <= 32, "four 16-lane groups sample the tile");
+    static_assert(NW == 4, "one sampling round: four 16-lane groups, one per left edge of the tile");
     __shared__ __attribute__((aligned(16))) float s_left_all[4][NW * 2 * 7 * 8];
     __shared__ int s_mc;
     const int nL = devn(nLd);
@@ -1337,31 +1338,65 @@ __global__ __launch_bounds__(256, WPE) void ncc_tile_kernel(const uint8_t *__res
     if (threadIdx.x == 0)
         s_mc = 0;
     int mc = 0; // kept pairs seen by this lane
-    for (int tile = t_begin + slot * 4 + wave; tile < t_end; tile += slots * 4)
+    // A tile is a chain of DEPENDENT loads -- row starts -> column indices -> bank rows, edge -> pixels -- around ~1.3 us of
+    // arithmetic, and the kernel's registers leave no room for another kernel's waves beside its own: with every load issued
+    // where its address became known the waves spent half their time parked (SQ_WAIT_ANY 51 %) and the kernel cost the pair
+    // rate 60 us for 41 us of VALU time (tools/gpu_prefix_chain.py).  So the loads are issued EARLY:
+    //   * the head of the NEXT tile (row starts, the lane's edge and its sin / cos) while this tile is scored;
+    //   * the tile's first 64 column indices, one per lane, as soon as its row starts are known, i.e. before the sampling
+    //     (a pair's index then comes from a lane, ds_bpermute; longer tiles read the rest from memory);
+    //   * the bank rows of the NEXT eight pairs before the current eight are scored.
+    struct Head
     {
+        int rp_l;      // lane t <= NW: row_ptr[e0 + min(t, rows)], clamped to the capacity of the pair buffers
+        double2 xy, sc; // the lane's left edge (16-lane group el = lane >> 4) and sin / cos of its orientation
+    };
+    auto load_head = [&](int tile) {
+        Head hd;
         const int e0 = tile * NW;
         const int rows = nL - e0 < NW ? nL - e0 : NW;
-        // CSR offsets of the tile's rows, clamped to the capacity of the pair buffers; lane t holds rp[t]
-        int rp_l = 0;
+        hd.rp_l = 0;
         if (lane <= NW)
         {
             const int64_t v = row_ptr[e0 + (lane < rows ? lane : rows)];
-            rp_l = (int)(v < cap ? v : cap);
+            hd.rp_l = (int)(v < cap ? v : cap);
         }
+        const int el = lane >> 4;
+        const int ec = (el < rows && row < 7) ? e0 + el : 0; // inactive lanes read edge 0 (always present when the kernel has work)
+        hd.xy = *reinterpret_cast<const double2 *>(&L[ec].x);
+        hd.sc = scL[ec];
+        return hd;
+    };
+    int tile = t_begin + slot * 4 + wave;
+    Head cur{};
+    if (tile < t_end)
+        cur = load_head(tile);
+    while (tile < t_end)
+    {
+        const int e0 = tile * NW;
+        const int rows = nL - e0 < NW ? nL - e0 : NW;
+        // row starts as wave-uniform scalars (v_readlane; __shfl would be a ds_bpermute through the LDS pipe each)
+        int rps[NW + 1];
+#pragma unroll
+        for (int t = 0; t <= NW; ++t)
+            rps[t] = __builtin_amdgcn_readlane(cur.rp_l, t);
+        const int k0 = rps[0], k1 = rps[NW]; // lanes beyond `rows` hold rp[rows]
+        // the tile's first 128 column indices, two per lane (an average tile has 18 pairs; one with more than 128 reads them
+        // where it needs them)
+        int ci_l = 0, ci_h = 0;
+        if (k0 + lane < k1)
+            ci_l = col_idx[k0 + lane];
+        if (k0 + 64 + lane < k1)
+            ci_h = col_idx[k0 + 64 + lane];
         // phase 1: the tile's left patches (src/Stereo_Matches.cpp:578), normalised as get_patch_similarity does
-#pragma unroll 1
-        for (int q = 0; q < NW / 4; ++q)
         {
-            const int el = q * 4 + (lane >> 4), e = e0 + el;
+            const int el = lane >> 4;
             const bool active = el < rows && row < 7;
             float p[7], nr[7];
 #pragma unroll
             for (int c = 0; c < 7; ++c)
                 p[c] = 0.0f;
-            {
-                const int ec = active ? e : 0;
-                sample_row<true>(imgL, h, w, pitch, L[ec].x, L[ec].y, scL[ec].x, scL[ec].y, side, row, p, active, pix2L);
-            }
+            sample_row<true>(imgL, h, w, pitch, cur.xy.x, cur.xy.y, cur.sc.x, cur.sc.y, side, row, p, active, pix2L);
             const bool sent = normalise_rows(active, p, nr);
             if (active)
             {
@@ -1370,74 +1405,93 @@ __global__ __launch_bounds__(256, WPE) void ncc_tile_kernel(const uint8_t *__res
                 dst[1] = make_float4(nr[4], nr[5], nr[6], sent ? 1.0f : 0.0f);
             }
         }
+        const int next_tile = tile + slots * 4;
+        Head nxt{};
+        if (next_tile < t_end)
+            nxt = load_head(next_tile);
         wave_lds_sync();
-        // row starts as wave-uniform scalars (v_readlane; __shfl would be a ds_bpermute through the LDS pipe each)
-        int rps[NW + 1];
-#pragma unroll
-        for (int t = 0; t <= NW; ++t)
-            rps[t] = __builtin_amdgcn_readlane(rp_l, t);
-        const int k0 = rps[0], k1 = rps[NW]; // lanes beyond `rows` hold rp[rows]
-        // phase 2: EIGHT lanes per pair (src/Stereo_Matches.cpp:585-608): lane r holds row r of R+, R-, L+, L-
-        for (int kb = k0; kb < k1; kb += 8)
-        {
+        // phase 2: EIGHT lanes per pair (src/Stereo_Matches.cpp:585-608): lane r holds row r of R+, R-, L+, L-.
+        // The four 49-term dots are reduced TRANSPOSED: lane r ends up owning ONE of them, L(u) . R(v) with u = bit 1 of r ^ bit 2,
+        // v = bit 0 ^ bit 2 (0 = the + patch, 1 = the - patch), and names its rows accordingly: la / lb = its own / the other
+        // left patch, ra / rb likewise.  Of its four row dots it keeps K = la.ra throughout, keeps S = lb.ra for one step, and
+        // hands T1 = la.rb, T2 = lb.rb to its xor-1 partner (whose v is the opposite: they are ITS K and S terms):
+        //     K += T1', S += T2' (xor 1);   K += S' (xor 2: the partner's u is the opposite);   K += K' (lane 7 - r: same u, v)
+        // Every dot is still ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7)) of the same seven-term row sums -- IEEE addition is
+        // commutative, so which lane of a pair does the adding does not matter -- at 12 cross-lane instructions instead of 36.
+        // Lanes 0..3 of a group then hold L+.R+, L+.R-, L-.R+, L-.R-.
+        int r8l = r8;
+        asm volatile("" : "+v"(r8l)); // the offsets below are rebuilt per tile: kept live across the sampling phase they spill
+        const int own_u = ((r8l >> 1) ^ (r8l >> 2)) & 1, own_v = (r8l ^ (r8l >> 2)) & 1;
+        const int row7 = r8l < 7 ? r8l : 6; // the eighth lane reads row 6 again (in bounds) and contributes zeros
+        const int off_a = own_v * BANK_SIDE + row7 * 8, off_b = (own_v ^ 1) * BANK_SIDE + row7 * 8;
+        // bank rows of the eight pairs starting at kb: lanes past the end read the last pair again and store nothing.  The eight
+        // pairs lie in one 64-pair chunk (kb - k0 is a multiple of 8), so which of the two index registers holds them is
+        // wave-uniform; `preloaded` is false only for a tile of more than 128 pairs.
+        auto bank_rows = [&](auto preloaded, int kb, float4 &a0, float4 &a1, float4 &b0, float4 &b1) {
+            const int k = kb + (lane >> 3);
+            const int kc = k < k1 ? k : k1 - 1;
+            int ri;
+            if (decltype(preloaded)::value)
+            {
+                const int kbc = kb < k1 ? kb : k1 - 1;
+                ri = __shfl(kbc - k0 < 64 ? ci_l : ci_h, (kc - k0) & 63);
+            }
+            else
+                ri = col_idx[kc];
+            const float *base = rbank + (size_t)ri * BANK_EDGE;
+            const float4 *ra4 = reinterpret_cast<const float4 *>(base + off_a);
+            const float4 *rb4 = reinterpret_cast<const float4 *>(base + off_b);
+            a0 = ra4[0];
+            a1 = ra4[1];
+            b0 = rb4[0];
+            b1 = rb4[1];
+        };
+        auto score = [&](int kb, const float4 &a0, const float4 &a1, const float4 &b0, const float4 &b1) {
             const int k = kb + (lane >> 3);
             const bool valid = k < k1;
-            const bool active = valid && r8 < 7;
+            const int kc = valid ? k : k1 - 1;
             // local row of pair k: the number of row starts rp[1 .. rows - 1] at or below k
             int el = 0;
 #pragma unroll
             for (int t = 1; t < NW; ++t)
-                el += (t < rows && k >= rps[t]) ? 1 : 0;
-            float4 a0 = make_float4(0, 0, 0, 0), a1 = a0, b0 = a0, b1 = a0, p0 = a0, p1 = a0, m0 = a0, m1 = a0;
-            if (active)
-            {
-                const int ri = col_idx[k];
-                const float4 *rr = reinterpret_cast<const float4 *>(rbank + (size_t)ri * BANK_EDGE + r8 * 8);
-                a0 = rr[0];
-                a1 = rr[1];
-                b0 = rr[BANK_SIDE / 4];
-                b1 = rr[BANK_SIDE / 4 + 1];
-                const float4 *lp4 = reinterpret_cast<const float4 *>(&s_left[((el * 2 + 0) * 7 + r8) * 8]);
-                const float4 *lm4 = reinterpret_cast<const float4 *>(&s_left[((el * 2 + 1) * 7 + r8) * 8]);
-                p0 = lp4[0];
-                p1 = lp4[1];
-                m0 = lm4[0];
-                m1 = lm4[1];
-            }
-            const float rp_[7] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z};
-            const float rm_[7] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z};
-            const float lp[7] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z};
-            const float lm[7] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z};
+                el += (t < rows && kc >= rps[t]) ? 1 : 0;
+            const float4 *la4 = reinterpret_cast<const float4 *>(&s_left[((el * 2 + own_u) * 7 + row7) * 8]);
+            const float4 *lb4 = reinterpret_cast<const float4 *>(&s_left[((el * 2 + (own_u ^ 1)) * 7 + row7) * 8]);
+            const float4 p0 = la4[0], p1 = la4[1], m0 = lb4[0], m1 = lb4[1];
+            const float ra[7] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z};
+            const float rb[7] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z};
+            const float la[7] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z};
+            const float lb[7] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z};
             // four dots of this lane's rows, column by column (each accumulator sees its terms left to right, as dot7)
-            double s_pp, s_nn, s_pn, s_np;
+            double K, S, T1, T2;
             {
-                const double lpd = (double)lp[0], lmd = (double)lm[0], rpd = (double)rp_[0], rmd = (double)rm_[0];
-                s_pp = lpd * rpd; // L+ . R+
-                s_nn = lmd * rmd; // L- . R-
-                s_pn = lpd * rmd; // L+ . R-
-                s_np = lmd * rpd; // L- . R+
+                const double lad = (double)la[0], lbd = (double)lb[0], rad = (double)ra[0], rbd = (double)rb[0];
+                K = lad * rad;
+                S = lbd * rad;
+                T1 = lad * rbd;
+                T2 = lbd * rbd;
             }
 #pragma unroll
             for (int c = 1; c < 7; ++c)
             {
-                const double lpd = (double)lp[c], lmd = (double)lm[c], rpd = (double)rp_[c], rmd = (double)rm_[c];
-                s_pp = __builtin_fma(lpd, rpd, s_pp);
-                s_nn = __builtin_fma(lmd, rmd, s_nn);
-                s_pn = __builtin_fma(lpd, rmd, s_pn);
-                s_np = __builtin_fma(lmd, rpd, s_np);
+                const double lad = (double)la[c], lbd = (double)lb[c], rad = (double)ra[c], rbd = (double)rb[c];
+                K = __builtin_fma(lad, rad, K);
+                S = __builtin_fma(lbd, rad, S);
+                T1 = __builtin_fma(lad, rbd, T1);
+                T2 = __builtin_fma(lbd, rbd, T2);
             }
-            const double d_pp = butterfly8(active ? s_pp : 0.0);
-            const double d_nn = butterfly8(active ? s_nn : 0.0);
-            const double d_pn = butterfly8(active ? s_pn : 0.0);
-            const double d_np = butterfly8(active ? s_np : 0.0);
-            if (valid && r8 == 0)
+            if (r8l == 7)
+                K = S = T1 = T2 = 0.0;
+            K += dpp_f64<0xB1>(T1);  // quad_perm:[1,0,3,2]
+            S += dpp_f64<0xB1>(T2);
+            K += dpp_f64<0x4E>(S);   // quad_perm:[2,3,0,1]
+            K += dpp_f64<0x141>(K);  // row_half_mirror
+            // src/utility.cpp:170-172: a flat patch on either side scores -1 (the flag is the eighth float of every row)
+            const double mine = (p1.w != 0.0f || a1.w != 0.0f) ? -1.0 : K;
+            const double pn = dpp_f64<0x55>(mine), npv = dpp_f64<0xAA>(mine), nn = dpp_f64<0xFF>(mine); // lanes 1, 2, 3 of the quad
+            if (valid && r8l == 0)
             {
-                const bool lsent_p = p1.w != 0.0f, lsent_m = m1.w != 0.0f;
-                const bool rsent_p = a1.w != 0.0f, rsent_m = b1.w != 0.0f;
-                const double pp = (lsent_p || rsent_p) ? -1.0 : d_pp; // src/utility.cpp:170-172
-                const double nn = (lsent_m || rsent_m) ? -1.0 : d_nn;
-                const double pn = (lsent_p || rsent_m) ? -1.0 : d_pn;
-                const double npv = (lsent_m || rsent_p) ? -1.0 : d_np;
+                const double pp = mine;
                 const double b = max4(pp, nn, pn, npv); // src/Stereo_Matches.cpp:596
                 if (sims) // the four scores are an option of the resident path (EBVO_PAIR_NO_SIMS): the reference keeps only their
                 {         // maximum (refine_final_scores, src/Stereo_Matches.cpp:600)
@@ -1449,8 +1503,30 @@ __global__ __launch_bounds__(256, WPE) void ncc_tile_kernel(const uint8_t *__res
                 keep[k] = m ? 1 : 0;
                 mc += m ? 1 : 0;
             }
-        }
+        };
+        // two register sets of bank rows, used alternately (a loop that renames "next" to "current" makes the compiler copy the
+        // rows -- and wait for a load it has just issued).  The loads of the following eight pairs are issued UNCONDITIONALLY
+        // (past the end: the last pair again, a cache hit): behind a branch the compiler's wait for the current rows becomes a
+        // wait for every load in flight, the prefetched ones included.
+        auto score_tile = [&](auto preloaded) {
+            float4 xa0, xa1, xb0, xb1, ya0, ya1, yb0, yb1;
+            bank_rows(preloaded, k0, xa0, xa1, xb0, xb1);
+            for (int kb = k0; kb < k1; kb += 16)
+            {
+                bank_rows(preloaded, kb + 8, ya0, ya1, yb0, yb1);
+                score(kb, xa0, xa1, xb0, xb1);
+                bank_rows(preloaded, kb + 16, xa0, xa1, xb0, xb1);
+                if (kb + 8 < k1) // wave-uniform
+                    score(kb + 8, ya0, ya1, yb0, yb1);
+            }
+        };
+        if (k1 - k0 > 128)
+            score_tile(std::false_type{});
+        else if (k0 < k1)
+            score_tile(std::true_type{});
         wave_lds_sync(); // the next tile's patches overwrite s_left
+        tile = next_tile;
+        cur = nxt;
     }
     for (int d = 32; d > 0; d >>= 1)
         mc += __shfl_down(mc, d);
@@ -2075,12 +2151,16 @@ int match_candidates_enqueue(ebvo_ctx *ctx, Slot &s, const ebvo_edge *d_L, int n
             hipLaunchKernelGGL(total_sum_kernel, dim3(1), dim3(64), 0, s.stream,
                                (const unsigned long long *)(s.d_total + 1), nblk, s.d_total);
     }
+    if (ctx->stop_stage == 9)
+        return EBVO_OK;
     {
         ProfScope ps(ctx, s, K_SCAN);
         if ((rc = device_exclusive_scan(ctx, s, cnt, (int32_t *)s.row_ptr.p, DevN{nL, d_nL}, 1, capL + 1)))
             return rc;
     }
     EBVO_HIP(ctx, hipGetLastError());
+    if (ctx->stop_stage == 10)
+        return EBVO_OK;
     if (fill)
         return match_candidates_fill_enqueue(ctx, s, d_L, nL, d_nL, d_R, nR, d_nR, cap_edges, d_lines, epi_thr, max_disp,
                                              orient_thr_deg, stage_mask);
@@ -2172,22 +2252,44 @@ int match_ncc_resident_enqueue(ebvo_ctx *ctx, Slot &s, int h, int w, int cap_edg
                                ncc_img(s, 0), ncc_img(s, 1), s.im[0].pix2, s.im[1].pix2, h, w);
             hipLaunchKernelGGL(sincos_batch_kernel, dim3(blocks_for(cap_edges, 256, 512), 2), dim3(256), 0, s.stream, B);
         }
-        hipLaunchKernelGGL(right_bank_kernel, dim3(blocks_for((int64_t)cap_edges * 16, 256, 1024)), dim3(256), 0, s.stream,
-                           ncc_img(s, iR), (const uint16_t *)s.im[iR].pix2, h, w, w, (const ebvo_edge *)s.im[iR].edges,
-                           (const double2 *)B.sc[iR], nRd, (float *)s.patches_norm_r.p);
+        for (int rep = 0; rep < ((ctx->repeat_mask & 4) ? 2 : 1); ++rep)
+            hipLaunchKernelGGL(right_bank_kernel, dim3(blocks_for((int64_t)cap_edges * 16, 256, 1024)), dim3(256), 0, s.stream,
+                               ncc_img(s, iR), (const uint16_t *)s.im[iR].pix2, h, w, w, (const ebvo_edge *)s.im[iR].edges,
+                               (const double2 *)B.sc[iR], nRd, (float *)s.patches_norm_r.p);
     }
+    if (ctx->stop_stage == 12)
+        return EBVO_OK;
     {
         ProfScope ps(ctx, s, K_NCC_PAIRS);
         int nblk = (int)blocks_for(cap_edges, NCC_NW * 4, EBVO_MATCH_PARTS);
+        // no more blocks than the device keeps resident: a wave then walks ~8 tiles with the next tile's loads in flight instead
+        // of two, and no block waits for a slot (developer key 17: a grid of that many blocks)
+        {
+            static std::atomic<int> resident[16];
+            int r = resident[ctx->device & 15].load(std::memory_order_relaxed);
+            if (r == 0)
+            {
+                int per_cu = 0, cus = 0;
+                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ncc_tile_kernel<NCC_NW, NCC_WPE>, 256, 0);
+                (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
+                r = (per_cu > 0 ? per_cu : NCC_WPE) * (cus > 0 ? cus : 256);
+                resident[ctx->device & 15].store(r, std::memory_order_relaxed);
+            }
+            if (ctx->ncc_blocks > 0)
+                r = ctx->ncc_blocks;
+            nblk = nblk < r ? nblk : r;
+        }
         nblk = nblk < 8 ? 8 : (nblk & ~7); // the XCD-aware order needs a multiple of 8 (tiles are walked grid-stride)
+        nblk = nblk < EBVO_MATCH_PARTS ? nblk : EBVO_MATCH_PARTS;
         s.n_match_part = nblk;
         // NW = 4 left edges per wave, at most 5 waves per SIMD: measured best of {4, 8, 16} x {4, 5, 6, 8} (a bigger tile
         // serialises more sampling rounds in one wave; a higher occupancy target spills)
-        hipLaunchKernelGGL((ncc_tile_kernel<NCC_NW, NCC_WPE>), dim3(nblk), dim3(256), 0, s.stream, ncc_img(s, iL),
-                           (const uint16_t *)s.im[iL].pix2, h, w, w, (const ebvo_edge *)s.im[iL].edges, (const double2 *)B.sc[iL],
-                           nLd, (const int32_t *)s.row_ptr.p, (const int32_t *)s.col_idx.p, (const float *)s.patches_norm_r.p,
-                           s.cap_pairs, thr, want_sims ? (double *)s.sims.p : nullptr, (double *)s.best.p, (uint8_t *)s.keep.p,
-                           s.d_matches);
+        for (int rep = 0; rep < ((ctx->repeat_mask & 8) ? 2 : 1); ++rep)
+            hipLaunchKernelGGL((ncc_tile_kernel<NCC_NW, NCC_WPE>), dim3(nblk), dim3(256), 0, s.stream, ncc_img(s, iL),
+                               (const uint16_t *)s.im[iL].pix2, h, w, w, (const ebvo_edge *)s.im[iL].edges,
+                               (const double2 *)B.sc[iL], nLd, (const int32_t *)s.row_ptr.p, (const int32_t *)s.col_idx.p,
+                               (const float *)s.patches_norm_r.p, s.cap_pairs, thr, want_sims ? (double *)s.sims.p : nullptr,
+                               (double *)s.best.p, (uint8_t *)s.keep.p, s.d_matches);
     }
     EBVO_HIP(ctx, hipGetLastError());
     return EBVO_OK;

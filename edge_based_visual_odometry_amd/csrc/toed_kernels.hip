@@ -1778,6 +1778,8 @@ int toed_init_constants(ebvo_ctx *ctx)
 // are exactly that large, see exact_task
 static int resident_blocks(ebvo_ctx *ctx, int which)
 {
+    if (ctx->exact_blocks[which] > 0)
+        return ctx->exact_blocks[which];
     // (two host threads with their own contexts may get here together: the value they compute is the same, the store is atomic)
     static std::atomic<int> cached[16][2];
     std::atomic<int> &slot = cached[ctx->device & 15][which];
@@ -1883,6 +1885,9 @@ int toed_enqueue(ebvo_ctx *ctx, Slot &s, int n_img, int h, int w, hipEvent_t ev_
                 hipLaunchKernelGGL(toed_screen_fused_kernel<false>, ftiles, dim3(256), 0, s.stream, B,
                                    (const ToedTables *)g_tables_dev[ctx->device], h, w, D);
         }
+        const int stop = ctx->stop_stage; // developer key 16
+        if (stop == 1)
+            return EBVO_OK;
         {
             ProfScope ps(ctx, s, K_ROWSCAN);
             hipLaunchKernelGGL(toed_rowscan_phase_kernel, dim3(n_img), dim3(192), 0, s.stream, B, H2, cap);
@@ -1891,6 +1896,8 @@ int toed_enqueue(ebvo_ctx *ctx, Slot &s, int n_img, int h, int w, hipEvent_t ev_
             ProfScope ps(ctx, s, K_COMPACT);
             hipLaunchKernelGGL(toed_compact_phase_kernel, dim3(H2 - 20, n_img), dim3(256), 0, s.stream, B, h, w, cap);
         }
+        if (stop == 2)
+            return EBVO_OK;
         {
             ExactBatch E{};
             for (int k = 0; k < n_img; ++k)
@@ -1920,19 +1927,33 @@ int toed_enqueue(ebvo_ctx *ctx, Slot &s, int n_img, int h, int w, hipEvent_t ev_
                 else
                     hipLaunchKernelGGL(toed_exact_centre_kernel, dim3(resident_blocks(ctx, 0)), dim3(256), 0, s.stream, E,
                                        T, h, w, cap, n_img);
+                if (ctx->repeat_mask & 1)
+                    hipLaunchKernelGGL(toed_exact_centre_kernel, dim3(resident_blocks(ctx, 0)), dim3(256), 0, s.stream, E,
+                                       T, h, w, cap, n_img);
             }
+            if (stop == 3)
+                return EBVO_OK;
             {
                 ProfScope ps(ctx, s, K_COMPACT); // the lists of the distinct neighbour points
                 hipLaunchKernelGGL(toed_need_count_kernel, dim3((H2 + 3) / 4, n_img), dim3(256), 0, s.stream, E, h, w);
                 hipLaunchKernelGGL(toed_need_rowscan_kernel, dim3(n_img), dim3(128), 0, s.stream, E, H2);
                 hipLaunchKernelGGL(toed_need_compact_kernel, dim3(H2, n_img), dim3(256), 0, s.stream, E, h, w, cap);
             }
+            if (stop == 4)
+                return EBVO_OK;
             {
                 ProfScope ps(ctx, s, K_EXACT_MAGS);
                 hipLaunchKernelGGL(toed_exact_mags_kernel, dim3(resident_blocks(ctx, 1)), dim3(256), 0, s.stream, E, T, h,
                                    w, cap, n_img);
+                if (ctx->repeat_mask & 2)
+                    hipLaunchKernelGGL(toed_exact_mags_kernel, dim3(resident_blocks(ctx, 1)), dim3(256), 0, s.stream, E, T, h,
+                                       w, cap, n_img);
+                if (stop == 5)
+                    return EBVO_OK;
                 hipLaunchKernelGGL(toed_exact_decide_kernel, dim3(512, n_img), dim3(256), 0, s.stream, E, h, w, cap);
             }
+            if (stop == 6)
+                return EBVO_OK;
             if (ctx->screen_audit)
                 for (int k = 0; k < n_img; ++k)
                 {
