@@ -172,6 +172,7 @@ struct Slot
     hipEvent_t ev_tq = nullptr;
     bool tq_in_flight = false, tq_empty = false;
     ebvo_temporal_params tq_params{};
+    GrowBuf sift_used; // [2] list lengths, then the lists of the left / right edges that appear in a candidate pair, then nR flag bytes
     GrowBuf sift_img, sift_desc, sift_f32, sift_dist; // SIFT: blurred levels, descriptor banks, per-pair distances (sift_kernels.hip)
     GrowBuf fin_i32, fin_edges, fin_f64, fin_u8, fin_out; // ebvo_stereo_finalize: CSRs, candidate lists, scores, final rows
     int n_final = 0;
@@ -282,6 +283,7 @@ struct ebvo_ctx
     int use_graphs = 1;         // EBVO_GRAPHS=0 or ebvo_debug_set(10, 0): direct launches only
     int64_t graph_launches = 0; // pairs submitted as a graph launch
     int exact_blocks[2] = {0, 0}; // developer keys (ebvo_debug_set 11, 12): grid of the exact centre / mags kernel in blocks (0 = what the device keeps resident)
+    int small_div = 0;          // developer key (ebvo_debug_set 18): grids of decide / cand_scatter / candidates<fill> divided by this (A/B)
     int ncc_blocks = 0;         // developer key (ebvo_debug_set 17): grid of ncc_tile_kernel in blocks (0 = what the device keeps resident)
     int stop_stage = 0;         // developer key (ebvo_debug_set 16): the resident pair's chain ends after stage N (tools/gpu_prefix_chain.py:
                                 // the pair rate of every prefix of the chain = what each stage costs in the steady state); 0 = whole chain
@@ -494,6 +496,13 @@ int refine_gn_temporal_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_imgK, co
 int sift_base_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_img, int h, int w, int pitch, float *d_tmp, float *d_base);
 int sift_descriptors_enqueue(ebvo_ctx *ctx, Slot &s, const float *d_base, int h, int w, const ebvo_edge *d_edges, int n,
                              float *d_desc_f, uint8_t *d_desc_u8);
+// the descriptors of the edges list[0 .. *d_n) only (n_max bounds the launch), written at the edges' own places in d_desc_u8
+int sift_descriptors_listed_enqueue(ebvo_ctx *ctx, Slot &s, const float *d_base, int h, int w, const ebvo_edge *d_edges,
+                                    const int32_t *d_list, const int32_t *d_n, int n_max, uint8_t *d_desc_u8);
+// which left (a row of the CSR with at least one pair) and right (named by some pair) edges need a descriptor: two index lists,
+// unordered, and their lengths in d_counts[0 .. 1]; d_flags: nR scratch bytes
+int sift_used_edges_enqueue(ebvo_ctx *ctx, Slot &s, const int32_t *d_row_ptr, int nL, const int32_t *d_col_idx, int64_t n_pairs,
+                            int nR, int32_t *d_counts, int32_t *d_list_left, int32_t *d_list_right, uint8_t *d_flags);
 int sift_gather_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_src, const int32_t *d_index, int n, uint8_t *d_dst);
 int sift_to_u8_enqueue(ebvo_ctx *ctx, Slot &s, const float *d_f, int64_t n, uint8_t *d_u8);
 int sift_distances_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_left, const uint8_t *d_cand, const int32_t *d_pair_left,

@@ -116,19 +116,24 @@ __device__ inline float sift_fast_atan2_sel(float y, float x)
 }
 
 // calcSIFTDescriptor (modules/features2d/src/sift.simd.hpp), one thread per keypoint (edge e, side sd)
+// `list` (with its length on the device, *n_list): the descriptors of those edges only, each written at its edge's own place.
 __global__ __launch_bounds__(64) void sift_desc_kernel(const float *__restrict__ base, int rows, int cols,
                                                        const ebvo_edge *__restrict__ edges, int n_edges,
-                                                       float *__restrict__ desc_f, uint8_t *__restrict__ desc_u8)
+                                                       float *__restrict__ desc_f, uint8_t *__restrict__ desc_u8,
+                                                       const int32_t *__restrict__ list, const int32_t *__restrict__ n_list)
 {
     __shared__ float hist[SHIST * 64];
     const int lane = threadIdx.x;
+    if (list)
+        n_edges = min(*n_list, n_edges);
     const int n_kp = n_edges * 2;
     for (int base_kp = blockIdx.x * 64; base_kp < n_kp; base_kp += gridDim.x * 64)
     {
-        const int kp = base_kp + lane;
-        if (kp >= n_kp)
+        const int kp_in = base_kp + lane;
+        if (kp_in >= n_kp)
             continue; // no barrier below: every lane owns its own histogram column
-        const int e = kp >> 1, sd = kp & 1;
+        const int e = list ? list[kp_in >> 1] : kp_in >> 1, sd = kp_in & 1;
+        const int kp = 2 * e + sd; // where the descriptor goes
         const ebvo_edge ed = edges[e];
         double sn, cs;
         ebvo_sincos(ed.theta, &sn, &cs);
@@ -470,7 +475,82 @@ int sift_descriptors_enqueue(ebvo_ctx *ctx, Slot &s, const float *d_base, int h,
         return EBVO_OK;
     ProfScope ps(ctx, s, K_SIFT);
     hipLaunchKernelGGL(sift_desc_kernel, dim3(grid1d((int64_t)n * 2, 64, 1 << 20)), dim3(64), 0, s.stream, d_base, h, w, d_edges,
-                       n, d_desc_f, d_desc_u8);
+                       n, d_desc_f, d_desc_u8, (const int32_t *)nullptr, (const int32_t *)nullptr);
+    EBVO_HIP(ctx, hipGetLastError());
+    return EBVO_OK;
+}
+
+int sift_descriptors_listed_enqueue(ebvo_ctx *ctx, Slot &s, const float *d_base, int h, int w, const ebvo_edge *d_edges,
+                                    const int32_t *d_list, const int32_t *d_n, int n_max, uint8_t *d_desc_u8)
+{
+    if (n_max <= 0)
+        return EBVO_OK;
+    ProfScope ps(ctx, s, K_SIFT);
+    // one keypoint per thread, one wave per SIMD (the histograms fill the LDS): a grid of what the device holds, strided
+    hipLaunchKernelGGL(sift_desc_kernel, dim3(grid1d((int64_t)n_max * 2, 64, 4096)), dim3(64), 0, s.stream, d_base, h, w, d_edges,
+                       n_max, (float *)nullptr, d_desc_u8, d_list, d_n);
+    EBVO_HIP(ctx, hipGetLastError());
+    return EBVO_OK;
+}
+
+namespace
+{
+// flags[j] = 1 for every right edge some pair names (benign race: every writer stores 1)
+__global__ __launch_bounds__(256) void sift_mark_right_kernel(const int32_t *__restrict__ col_idx, int64_t n_pairs, uint8_t *__restrict__ flags)
+{
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n_pairs; k += (int64_t)gridDim.x * 256)
+        flags[col_idx[k]] = 1;
+}
+
+// blockIdx.y = 0: left edges whose CSR row is not empty; 1: flagged right edges.  One atomic per block and list (the order of a
+// list does not matter: every descriptor is written at its edge's own place).
+__global__ __launch_bounds__(256) void sift_used_lists_kernel(const int32_t *__restrict__ row_ptr, int nL, const uint8_t *__restrict__ flags,
+                                                              int nR, int32_t *__restrict__ counts, int32_t *__restrict__ list_left,
+                                                              int32_t *__restrict__ list_right)
+{
+    __shared__ int s_w[4], s_base;
+    const int side = blockIdx.y, n = side ? nR : nL;
+    int32_t *list = side ? list_right : list_left;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    for (int i0 = blockIdx.x * 256; i0 < n; i0 += gridDim.x * 256)
+    {
+        const int i = i0 + threadIdx.x;
+        const bool used = i < n && (side ? flags[i] != 0 : row_ptr[i + 1] > row_ptr[i]);
+        const unsigned long long m = __ballot(used);
+        if (lane == 0)
+            s_w[wid] = __popcll(m);
+        __syncthreads();
+        if (threadIdx.x == 0)
+        {
+            const int tot = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+            s_base = tot ? atomicAdd(&counts[side], tot) : 0;
+        }
+        __syncthreads();
+        if (used)
+        {
+            int pre = 0;
+            for (int k = 0; k < wid; ++k)
+                pre += s_w[k];
+            list[s_base + pre + __popcll(m & ((1ull << lane) - 1ull))] = i;
+        }
+        __syncthreads();
+    }
+}
+} // namespace
+
+int sift_used_edges_enqueue(ebvo_ctx *ctx, Slot &s, const int32_t *d_row_ptr, int nL, const int32_t *d_col_idx, int64_t n_pairs,
+                            int nR, int32_t *d_counts, int32_t *d_list_left, int32_t *d_list_right, uint8_t *d_flags)
+{
+    ProfScope ps(ctx, s, K_SIFT);
+    EBVO_HIP(ctx, hipMemsetAsync(d_counts, 0, 2 * sizeof(int32_t), s.stream));
+    if (nR > 0)
+        EBVO_HIP(ctx, hipMemsetAsync(d_flags, 0, (size_t)nR, s.stream));
+    if (n_pairs > 0)
+        hipLaunchKernelGGL(sift_mark_right_kernel, dim3(grid1d(n_pairs, 256, 1024)), dim3(256), 0, s.stream, d_col_idx, n_pairs, d_flags);
+    const int nmax = nL > nR ? nL : nR;
+    if (nmax > 0)
+        hipLaunchKernelGGL(sift_used_lists_kernel, dim3(grid1d(nmax, 256, 256), 2), dim3(256), 0, s.stream, d_row_ptr, nL,
+                           (const uint8_t *)d_flags, nR, d_counts, d_list_left, d_list_right);
     EBVO_HIP(ctx, hipGetLastError());
     return EBVO_OK;
 }

@@ -1066,6 +1066,7 @@ struct ExactBatch
     CandExact *cd[MAX_BATCH]; // [cap]
     CandRec *rec[MAX_BATCH];
     int32_t *cand_flag[MAX_BATCH];
+    int2 *chunk_cnt[MAX_BATCH];  // [ceil(cap / 256)] maxima / kept maxima among the 256 candidates of a chunk (toed_exact_decide_kernel)
     // neighbour magnitudes, every distinct grid point once
     const uint8_t *flag[MAX_BATCH]; // screen flags: 1 = candidate (its own exact |g| goes to magmap)
     uint32_t *needbits[MAX_BATCH];  // [2H][ceil(2W / 32)] bit J of row I: the exact |g| of grid point (I, J) is needed
@@ -1598,46 +1599,66 @@ __global__ __launch_bounds__(256) void toed_exact_mags_kernel(ExactBatch E, cons
     EBVO_TRACE_END(1);
 }
 
-// S3d: the exact NMS decision of every candidate, from exact values only
+// S3d: the exact NMS decision of every candidate, from exact values only.  A block takes CHUNKS of 256 consecutive candidates
+// and leaves, besides every candidate's record and flags, the chunk's number of maxima and of kept maxima: the ranks of the
+// edges then need no scan over the 264 k flags (two launches per pair in round 3) -- toed_cand_scatter_kernel adds up the
+// counts of the chunks in front of its own (at most a few hundred pairs of ints, every block for itself).
 __global__ __launch_bounds__(256) void toed_exact_decide_kernel(ExactBatch E, int h, int w, int cap)
 {
+    __shared__ int s_cnt[4][2];
     const int im = blockIdx.y, W2 = 2 * w;
     const CandExact *__restrict__ cd = E.cd[im];
     CandRec *__restrict__ rec = E.rec[im];
     int32_t *__restrict__ ft = E.cand_flag[im], *__restrict__ fk = ft + cap;
     const int n = min(E.counts[im][2], cap);
-    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x)
+    for (int c = blockIdx.x; c * 256 < n; c += gridDim.x)
     {
-        const int o = E.src[im][2 * t];
-        const int I = o / W2, J = o - I * W2;
-        const CandExact ce = cd[t];
-        const double gx = ce.gx, gy = ce.gy, m = ce.m;
-        NmsSector S;
+        const int t = c * 256 + threadIdx.x;
         bool is_max = false;
-        double px = 0, py = 0, sm = 0;
-        if (ce.sector >= 0 && nms_sector(m, gx, gy, S))
-        {
-            const double *__restrict__ mm = E.magmap[im];
-            is_max = nms_finish(m, S, I, J, mm[mag_index(I + S.a1, J + S.b1, W2)], mm[mag_index(I + S.a2, J + S.b2, W2)],
-                                mm[mag_index(I - S.a1, J - S.b1, W2)], mm[mag_index(I - S.a2, J - S.b2, W2)], px, py, sm);
-        }
         int kept = 0;
-        CandRec r;
-        r.x = r.y = r.smag = 0.0;
-        r.tox = ce.tox;
-        r.toy = ce.toy;
-        if (is_max)
+        if (t < n)
         {
-            r.x = (px - 1) / 2; // :538,542
-            r.y = (py - 1) / 2;
-            r.smag = sm;
-            kept = (r.x > 10 && r.x < w - 10 && r.y > 10 && r.y < h - 10) ? 1 : 0; // :553-554
+            const int o = E.src[im][2 * t];
+            const int I = o / W2, J = o - I * W2;
+            const CandExact ce = cd[t];
+            const double gx = ce.gx, gy = ce.gy, m = ce.m;
+            NmsSector S;
+            double px = 0, py = 0, sm = 0;
+            if (ce.sector >= 0 && nms_sector(m, gx, gy, S))
+            {
+                const double *__restrict__ mm = E.magmap[im];
+                is_max = nms_finish(m, S, I, J, mm[mag_index(I + S.a1, J + S.b1, W2)], mm[mag_index(I + S.a2, J + S.b2, W2)],
+                                    mm[mag_index(I - S.a1, J - S.b1, W2)], mm[mag_index(I - S.a2, J - S.b2, W2)], px, py, sm);
+            }
+            CandRec r;
+            r.x = r.y = r.smag = 0.0;
+            r.tox = ce.tox;
+            r.toy = ce.toy;
+            if (is_max)
+            {
+                r.x = (px - 1) / 2; // :538,542
+                r.y = (py - 1) / 2;
+                r.smag = sm;
+                kept = (r.x > 10 && r.x < w - 10 && r.y > 10 && r.y < h - 10) ? 1 : 0; // :553-554
+            }
+            rec[t] = r;
+            ft[t] = is_max ? 1 : 0;
+            fk[t] = kept;
         }
-        rec[t] = r;
-        ft[t] = is_max ? 1 : 0;
-        fk[t] = kept;
+        const unsigned long long bm = __ballot(is_max), bk = __ballot(kept != 0);
+        if ((threadIdx.x & 63) == 0)
+        {
+            s_cnt[threadIdx.x >> 6][0] = __popcll(bm);
+            s_cnt[threadIdx.x >> 6][1] = __popcll(bk);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0)
+            E.chunk_cnt[im][c] = make_int2(s_cnt[0][0] + s_cnt[1][0] + s_cnt[2][0] + s_cnt[3][0],
+                                           s_cnt[0][1] + s_cnt[1][1] + s_cnt[2][1] + s_cnt[3][1]);
+        __syncthreads();
     }
 }
+
 
 // Audit (ebvo_toed_screen_audit): max |screen - exact| of gx, gy, |g| over the candidates, and of |g| over the distinct
 // neighbour points that lie inside the screened interior -- the quantities the error budget above bounds.  Non-negative
@@ -1680,29 +1701,69 @@ __global__ __launch_bounds__(256) void toed_screen_audit_kernel(ExactBatch E, Sc
 }
 
 // S4 ---------------------------------------------------------------------------------------
-// write the edge records at their scanned ranks (raster order is the candidate order)
+// write the edge records at their ranks (raster order is the candidate order).  The rank of a candidate = the maxima (kept
+// maxima) of the chunks in front of its chunk -- summed here by every block for itself from toed_exact_decide_kernel's chunk
+// counts -- plus those in front of it inside the chunk (ballots).
 __global__ __launch_bounds__(256) void toed_cand_scatter_kernel(ImgBatch B, int cap)
 {
+    __shared__ int s_base[4][2], s_in[4][2];
     const CandRec *__restrict__ rec = B.rec[blockIdx.y];
-    const int32_t *__restrict__ ft = B.cand_flag[blockIdx.y], *__restrict__ fk = ft + cap;
-    const int32_t *__restrict__ ot = B.cand_off[blockIdx.y], *__restrict__ ok = ot + (cap + 1);
+    const int32_t *__restrict__ ftp = B.cand_flag[blockIdx.y], *__restrict__ fkp = ftp + cap;
+    const int2 *__restrict__ chunk_cnt = reinterpret_cast<const int2 *>(B.cand_off[blockIdx.y]);
     ebvo_edge *__restrict__ edges = B.edges[blockIdx.y];
     double *__restrict__ all4 = B.all4[blockIdx.y];
     int32_t *counts = B.counts[blockIdx.y];
     const int n = min(counts[2], cap);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     if (n == 0 && blockIdx.x == 0 && threadIdx.x == 0)
     {
         counts[0] = 0;
         counts[1] = 0;
     }
-    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x)
+    for (int c = blockIdx.x; c * 256 < n; c += gridDim.x)
     {
+        int a0 = 0, a1 = 0;
+        for (int k = threadIdx.x; k < c; k += 256)
+        {
+            const int2 v = chunk_cnt[k];
+            a0 += v.x;
+            a1 += v.y;
+        }
+        for (int d = 32; d > 0; d >>= 1)
+        {
+            a0 += __shfl_down(a0, d);
+            a1 += __shfl_down(a1, d);
+        }
+        const int t = c * 256 + threadIdx.x;
+        const int f_t = t < n ? ftp[t] : 0, f_k = t < n ? fkp[t] : 0;
+        const unsigned long long bm = __ballot(f_t != 0), bk = __ballot(f_k != 0);
+        if (lane == 0)
+        {
+            s_base[wid][0] = a0;
+            s_base[wid][1] = a1;
+            s_in[wid][0] = __popcll(bm);
+            s_in[wid][1] = __popcll(bk);
+        }
+        __syncthreads();
+        int o_t = s_base[0][0] + s_base[1][0] + s_base[2][0] + s_base[3][0];
+        int o_k = s_base[0][1] + s_base[1][1] + s_base[2][1] + s_base[3][1];
+        for (int k = 0; k < wid; ++k)
+        {
+            o_t += s_in[k][0];
+            o_k += s_in[k][1];
+        }
+        const unsigned long long below = (1ull << lane) - 1ull;
+        o_t += __popcll(bm & below);
+        o_k += __popcll(bk & below);
+        __syncthreads(); // (s_base / s_in are rewritten by the block's next chunk)
+        if (t >= n)
+            continue;
         if (t == n - 1)
         {
-            counts[0] = ot[t] + ft[t]; // Total_Num_Of_TOED
-            counts[1] = ok[t] + fk[t]; // toed_edges.size()
+            counts[0] = o_t + f_t; // Total_Num_Of_TOED
+            counts[1] = o_k + f_k; // toed_edges.size()
         }
-        if (!ft[t] || (!all4 && !fk[t])) // (the resident pipeline keeps no subpix_edge_pts_final, see toed_enqueue)
+        if (!f_t || (!all4 && !f_k)) // (the resident pipeline keeps no subpix_edge_pts_final, see toed_enqueue)
             continue;
         const CandRec r = rec[t];
         double TO_Ix = r.tox, TO_Iy = r.toy; // src/toed/cpu_toed.cpp:226-229
@@ -1712,19 +1773,19 @@ __global__ __launch_bounds__(256) void toed_cand_scatter_kernel(ImgBatch B, int 
         const double th = ebvo_atan2(TO_Ix, -TO_Iy);
         if (all4)
         {
-            const int ra = ot[t];
+            const int ra = o_t;
             all4[(size_t)ra * 4 + 0] = r.x;
             all4[(size_t)ra * 4 + 1] = r.y;
             all4[(size_t)ra * 4 + 2] = th;
             all4[(size_t)ra * 4 + 3] = r.smag;
         }
-        if (fk[t])
+        if (f_k)
         {
             ebvo_edge e;
             e.x = r.x;
             e.y = r.y;
             e.theta = th;
-            e.index = ok[t];
+            e.index = o_k;
             e.pad = 0;
             edges[e.index] = e;
         }
@@ -1911,6 +1972,7 @@ int toed_enqueue(ebvo_ctx *ctx, Slot &s, int n_img, int h, int w, hipEvent_t ev_
                 E.cd[k] = (CandExact *)ws.cand_data; // one 64-byte record per candidate
                 E.rec[k] = (CandRec *)ws.cand_rec;
                 E.cand_flag[k] = ws.cand_flag;
+                E.chunk_cnt[k] = reinterpret_cast<int2 *>(ws.cand_off);
                 // the planes of the strict path are free in hybrid mode: |g| map, need bitmap, per-row counters
                 E.flag[k] = ws.flag;
                 E.magmap[k] = ws.maps;
@@ -1950,7 +2012,7 @@ int toed_enqueue(ebvo_ctx *ctx, Slot &s, int n_img, int h, int w, hipEvent_t ev_
                                        w, cap, n_img);
                 if (stop == 5)
                     return EBVO_OK;
-                hipLaunchKernelGGL(toed_exact_decide_kernel, dim3(512, n_img), dim3(256), 0, s.stream, E, h, w, cap);
+                hipLaunchKernelGGL(toed_exact_decide_kernel, dim3(512 / (ctx->small_div > 0 ? ctx->small_div : 1), n_img), dim3(256), 0, s.stream, E, h, w, cap);
             }
             if (stop == 6)
                 return EBVO_OK;
@@ -1964,29 +2026,9 @@ int toed_enqueue(ebvo_ctx *ctx, Slot &s, int n_img, int h, int w, hipEvent_t ev_
         }
         if (ev_conv_end)
             EBVO_HIP(ctx, hipEventRecord(ev_conv_end, s.stream));
-        for (int k0 = 0; k0 < n_img; k0 += 2)
-        {
-            // "is a maximum" and "is a kept maximum" flags of up to two images: four scans, one pair of launches
-            const int32_t *in[4];
-            int32_t *out[4];
-            const int32_t *nd[4];
-            int nb = 0;
-            for (int k = k0; k < n_img && k < k0 + 2; ++k)
-            {
-                in[nb] = s.im[k].cand_flag;
-                out[nb] = s.im[k].cand_off;
-                nd[nb++] = s.im[k].counts + 2;
-                in[nb] = s.im[k].cand_flag + cap;
-                out[nb] = s.im[k].cand_off + (cap + 1);
-                nd[nb++] = s.im[k].counts + 2;
-            }
-            int rc;
-            if ((rc = ebvo_device_scan4(ctx, s, in, out, nd, nb, cap)))
-                return rc;
-        }
         {
             ProfScope ps(ctx, s, K_FINALIZE);
-            hipLaunchKernelGGL(toed_cand_scatter_kernel, dim3(512, n_img), dim3(256), 0, s.stream, B, cap);
+            hipLaunchKernelGGL(toed_cand_scatter_kernel, dim3(512 / (ctx->small_div > 0 ? ctx->small_div : 1), n_img), dim3(256), 0, s.stream, B, cap);
         }
         if (ev_end)
             EBVO_HIP(ctx, hipEventRecord(ev_end, s.stream));

@@ -13,7 +13,7 @@ from edge_based_visual_odometry_amd.api import Context  # noqa: E402
 
 H, W = synth.SHAPES["kitti"]
 F = synth.fundamental_for("kitti")
-NS = 6
+NS = int(os.environ.get("EBVO_AB_SLOTS", "6"))   # pairs in flight
 left, right = synth.stereo_pair("s2", H, W, scene=7, noise_base=0, disparity=12)
 settings = sys.argv[1:] or ["default"]
 
