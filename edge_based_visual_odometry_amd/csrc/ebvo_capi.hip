@@ -1782,7 +1782,7 @@ extern "C" int ebvo_stereo_wait(ebvo_ctx *ctx, int slot, ebvo_stereo_counts *cou
         const PairResult r = *s.h_result;
         if (r.overflow & 2)
         {
-            // the hybrid screen flagged more candidates than fit (toed_rowscan_phase_kernel): the whole pair again, strict
+            // the hybrid screen flagged more candidates than fit (toed_compact_phase_kernel): the whole pair again, strict
             ++ctx->toed_fallbacks;
             s.toed_strict_override = true; // remembered until the next upload: these images go strict at once from now on
             if ((rc = toed_enqueue(ctx, s, 2, s.cur_h, s.cur_w, nullptr, nullptr, nullptr, EBVO_TOED_STRICT, false)) ||

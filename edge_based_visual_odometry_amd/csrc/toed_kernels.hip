@@ -23,11 +23,11 @@
 //   toed_finalize_kernel K3c: dense per-edge epilogue (sub-pixel position, atan2, records)
 // Hybrid mode (second half of the file; same bits out):
 //   toed_screen_fused_kernel   S1+S2: separable fp32 screen and relaxed NMS of a 12 x 30-pixel tile, all in LDS
-//   toed_rowscan_phase_kernel / toed_compact_phase_kernel
+//   toed_compact_phase_kernel (offsets of a row: the counts of the rows in front of it, summed by the row's own block)
 //                              S2b/c: candidate ranks and the four phase lists, ordered, no atomics
 //   toed_exact_centre_kernel   S3b: the nine exact responses of every candidate; marks its NMS neighbours
-//   toed_need_{count,rowscan,compact}_kernel
-//                              S3c-0..2: the distinct neighbour grid points, by phase
+//   toed_need_{count,compact}_kernel
+//                              S3c-0..1: the distinct neighbour grid points, by phase
 //   toed_exact_mags_kernel     S3c-3: exact gradient magnitude of every distinct neighbour point
 //   toed_exact_decide_kernel   S3d: exact NMS + sub-pixel fit;  toed_cand_scatter_kernel S4: edge records
 #include <cstring>
@@ -889,86 +889,17 @@ __global__ __launch_bounds__(256) void toed_screen_fused_kernel(ImgBatch B, cons
     }
 }
 
-// S2b: one block of three waves per image.  Wave 0: exclusive scan over the rows of all candidates (a candidate's rank
-// t); waves 1, 2: candidates in even / odd columns, scanned separately over the even and the odd rows, which gives
-// every row its offset in the list of its phase.  Totals -> counts[2] and lcount[0..3]; lcount[4..11] are zeroed for
-// the (phase, axis) lists appended by the centre kernel.
+// S2c: one block per interpolated row: ordered compaction of the candidates (rank t -> pixel) and, in the same pass,
+// the four phase lists in raster order (no atomics: every row knows its offset in its phase's list).
+// Round 4: the offsets are no longer a launch of their own (toed_rowscan_phase_kernel: one block per image, ~5 us of latency
+// in front of this kernel): every block adds up the per-row counts in front of its row itself (a few hundred ints, four sums:
+// row parity x column parity), and the block of the first row also adds up ALL rows and publishes what the scan kernel did:
+// counts[2] (candidates; 0 if they do not fit), counts[3] = 0, counts[4] (their real number), the lengths of the four phase
+// lists, and zeroed lengths for the lists the exact stage appends to.
 // The candidate arrays hold `cap` (= max_h * max_w) entries; the screen can flag up to four times that on an image made of
 // ties (a fine checkerboard).  Then counts[4] keeps the real total and every list length is published as zero: the exact
 // stage runs empty, nothing is written past a buffer, and the host re-runs the image on the strict path (toed_sync,
 // ebvo_stereo_wait).
-__global__ __launch_bounds__(192) void toed_rowscan_phase_kernel(ImgBatch B, int H2, int cap)
-{
-    __shared__ int s_over;
-    const int32_t *cnt = B.row_cnt[blockIdx.x];
-    int32_t *off = B.row_off[blockIdx.x];
-    int32_t *lcount = B.lcount[blockIdx.x];
-    const int lane = threadIdx.x & 63, which = threadIdx.x >> 6;
-    const int per = (H2 + 63) / 64;
-    const int beg = lane * per, end = min(H2, beg + per);
-    if (which == 0)
-    {
-        int s = 0;
-        for (int r = beg; r < end; ++r)
-            s += cnt[r] + cnt[H2 + r];
-        int incl = s;
-        for (int d = 1; d < 64; d <<= 1)
-        {
-            const int t = __shfl_up(incl, d);
-            if (lane >= d)
-                incl += t;
-        }
-        int run = incl - s;
-        for (int r = beg; r < end; ++r)
-        {
-            off[r] = run;
-            run += cnt[r] + cnt[H2 + r];
-        }
-        if (lane == 63)
-        {
-            off[H2] = incl;
-            s_over = incl > cap;
-            B.counts[blockIdx.x][2] = incl > cap ? 0 : incl;
-            B.counts[blockIdx.x][3] = 0;
-            B.counts[blockIdx.x][4] = incl;
-        }
-        if (lane >= 4 && lane < 12)
-            lcount[lane] = 0;
-        __syncthreads();
-        return;
-    }
-    const int sx = which - 1;
-    const int32_t *c = cnt + sx * H2;
-    int32_t *o = off + (1 + sx) * (H2 + 1);
-    int s[2] = {0, 0};
-    for (int r = beg; r < end; ++r)
-        s[r & 1] += c[r];
-    int incl[2] = {s[0], s[1]};
-    for (int d = 1; d < 64; d <<= 1)
-    {
-        const int t0 = __shfl_up(incl[0], d), t1 = __shfl_up(incl[1], d);
-        if (lane >= d)
-        {
-            incl[0] += t0;
-            incl[1] += t1;
-        }
-    }
-    int run[2] = {incl[0] - s[0], incl[1] - s[1]};
-    for (int r = beg; r < end; ++r)
-    {
-        o[r] = run[r & 1];
-        run[r & 1] += c[r];
-    }
-    __syncthreads();
-    if (lane == 63)
-    {
-        lcount[sx] = s_over ? 0 : incl[0];     // phase (SY 0, SX sx)
-        lcount[2 + sx] = s_over ? 0 : incl[1]; // phase (SY 1, SX sx)
-    }
-}
-
-// S2c: one block per interpolated row: ordered compaction of the candidates (rank t -> pixel) and, in the same pass,
-// the four phase lists in raster order (no atomics: every row knows its offset in its phase's list).
 __global__ __launch_bounds__(256) void toed_compact_phase_kernel(ImgBatch B, int h, int w, int cap)
 {
     const int W2 = 2 * w, H2 = 2 * h;
@@ -976,13 +907,55 @@ __global__ __launch_bounds__(256) void toed_compact_phase_kernel(ImgBatch B, int
     if (i >= H2 - 10)
         return;
     const uint8_t *flag = B.flag[blockIdx.y] + (size_t)i * W2;
-    const int32_t *off = B.row_off[blockIdx.y];
+    const int32_t *cnt = B.row_cnt[blockIdx.y]; // [2][H2]: candidates of a row in even / odd columns
     int32_t *src = B.src[blockIdx.y];
     int32_t *lists = B.lists[blockIdx.y];
-    int base_all = off[i];
-    int base_ph[2] = {off[(H2 + 1) + i], off[2 * (H2 + 1) + i]};
-    __shared__ int w_all[4], w_par[2][4];
+    __shared__ int w_all[4], w_par[2][4], s_sum[4][4];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    // sums over the rows in front of this one (and, in the first block, over all rows): [row parity][column parity]
+    auto sum_rows = [&](int r_end, int out[4]) {
+        int a[4] = {0, 0, 0, 0};
+        for (int r = threadIdx.x; r < r_end; r += 256)
+        {
+            a[(r & 1) * 2 + 0] += cnt[r];
+            a[(r & 1) * 2 + 1] += cnt[H2 + r];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            for (int d = 32; d > 0; d >>= 1)
+                a[k] += __shfl_down(a[k], d);
+        __syncthreads(); // (s_sum may still be read from the previous call)
+        if (lane == 0)
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                s_sum[wid][k] = a[k];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            out[k] = s_sum[0][k] + s_sum[1][k] + s_sum[2][k] + s_sum[3][k];
+    };
+    int pre[4];
+    sum_rows(i, pre);
+    if (blockIdx.x == 0)
+    {
+        int tot[4];
+        sum_rows(H2, tot);
+        if (threadIdx.x == 0)
+        {
+            const int all = tot[0] + tot[1] + tot[2] + tot[3];
+            const bool over = all > cap;
+            int32_t *counts = B.counts[blockIdx.y], *lcount = B.lcount[blockIdx.y];
+            counts[2] = over ? 0 : all;
+            counts[3] = 0;
+            counts[4] = all;
+            for (int ph = 0; ph < 4; ++ph)
+                lcount[ph] = over ? 0 : tot[ph]; // phase = (row parity << 1) | column parity
+            for (int k = 4; k < 12; ++k)
+                lcount[k] = 0;
+        }
+    }
+    int base_all = pre[0] + pre[1] + pre[2] + pre[3];
+    int base_ph[2] = {pre[(i & 1) * 2], pre[(i & 1) * 2 + 1]};
     const int par = threadIdx.x & 1; // column parity (j0 is even)
     const unsigned long long pmask = par ? 0xaaaaaaaaaaaaaaaaull : 0x5555555555555555ull;
     for (int j0 = 10; j0 < W2 - 10; j0 += 256)
@@ -1071,7 +1044,6 @@ struct ExactBatch
     const uint8_t *flag[MAX_BATCH]; // screen flags: 1 = candidate (its own exact |g| goes to magmap)
     uint32_t *needbits[MAX_BATCH];  // [2H][ceil(2W / 32)] bit J of row I: the exact |g| of grid point (I, J) is needed
     int32_t *need_cnt[MAX_BATCH];   // [2][2H] marked points per grid row, even / odd columns
-    int32_t *need_off[MAX_BATCH];   // [2][2H] their offsets in the phase lists (lists 4..7, lengths lcount[4..7])
     double *magmap[MAX_BATCH];      // exact |g| at candidates and at marked points, 2 x 4 tiles (mag_index)
 };
 
@@ -1474,56 +1446,51 @@ __global__ __launch_bounds__(256) void toed_need_count_kernel(ExactBatch E, int 
     }
 }
 
-// S3c-1: offsets of the marked points of every grid row in the list of their phase (two waves: even / odd columns,
-// each scanned separately over the even and the odd rows); list lengths -> lcount[4..7]
-__global__ __launch_bounds__(128) void toed_need_rowscan_kernel(ExactBatch E, int H2)
-{
-    const int im = blockIdx.x;
-    const int lane = threadIdx.x & 63, sx = threadIdx.x >> 6;
-    const int32_t *c = E.need_cnt[im] + sx * H2;
-    int32_t *o = E.need_off[im] + sx * H2;
-    const int per = (H2 + 63) / 64;
-    const int beg = lane * per, end = min(H2, beg + per);
-    int s[2] = {0, 0};
-    for (int r = beg; r < end; ++r)
-        s[r & 1] += c[r];
-    int incl[2] = {s[0], s[1]};
-    for (int d = 1; d < 64; d <<= 1)
-    {
-        const int t0 = __shfl_up(incl[0], d), t1 = __shfl_up(incl[1], d);
-        if (lane >= d)
-        {
-            incl[0] += t0;
-            incl[1] += t1;
-        }
-    }
-    int run[2] = {incl[0] - s[0], incl[1] - s[1]};
-    for (int r = beg; r < end; ++r)
-    {
-        o[r] = run[r & 1];
-        run[r & 1] += c[r];
-    }
-    if (lane == 63)
-    {
-        E.lcount[im][4 + sx] = incl[0];     // phase (row parity 0, column parity sx)
-        E.lcount[im][4 + 2 + sx] = incl[1]; // phase (row parity 1, column parity sx)
-        // diagnostics: counts[3] = distinct neighbour grid points evaluated (zeroed by toed_rowscan_phase_kernel)
-        atomicAdd(const_cast<int32_t *>(E.counts[im]) + 3, incl[0] + incl[1]);
-    }
-}
-
-// S3c-2: one block per grid row: the marked points of the row, in column order, into the list of their phase
+// S3c-1: one block per grid row: the marked points of the row, in column order, into the list of their phase.  The row's
+// offsets in the two lists (even / odd columns) of its row parity are the marked points of the rows of that parity in front
+// of it -- added up here by the block itself from toed_need_count_kernel's per-row counts (round 3: a scan launch of one
+// block per image between the two).  The blocks of the last two rows (one per row parity) also publish the list lengths,
+// lcount[4..7], and add them to counts[3] (diagnostics: distinct neighbour points; zeroed by toed_compact_phase_kernel).
 __global__ __launch_bounds__(256) void toed_need_compact_kernel(ExactBatch E, int h, int w, int cap)
 {
     const int W2 = 2 * w, H2 = 2 * h, wpr = (W2 + 31) >> 5;
     const int I = blockIdx.x, im = blockIdx.y;
-    if (E.need_cnt[im][I] + E.need_cnt[im][H2 + I] == 0)
+    const int32_t *__restrict__ cnt = E.need_cnt[im];
+    const bool last = I >= H2 - 2; // wave-uniform, block-uniform
+    const int mine0 = cnt[I], mine1 = cnt[H2 + I];
+    if (!last && mine0 + mine1 == 0)
         return;
     const uint32_t *__restrict__ bits = E.needbits[im];
     int32_t *__restrict__ lists = E.lists[im];
-    int base_ph[2] = {E.need_off[im][I], E.need_off[im][H2 + I]};
-    __shared__ int w_par[2][4];
+    __shared__ int w_par[2][4], s_sum[4][2];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    int a0 = 0, a1 = 0;
+    for (int r = (I & 1) + 2 * threadIdx.x; r < I; r += 512)
+    {
+        a0 += cnt[r];
+        a1 += cnt[H2 + r];
+    }
+    for (int d = 32; d > 0; d >>= 1)
+    {
+        a0 += __shfl_down(a0, d);
+        a1 += __shfl_down(a1, d);
+    }
+    if (lane == 0)
+    {
+        s_sum[wid][0] = a0;
+        s_sum[wid][1] = a1;
+    }
+    __syncthreads();
+    int base_ph[2] = {s_sum[0][0] + s_sum[1][0] + s_sum[2][0] + s_sum[3][0], s_sum[0][1] + s_sum[1][1] + s_sum[2][1] + s_sum[3][1]};
+    if (last && threadIdx.x == 0)
+    {
+        const int n0 = base_ph[0] + mine0, n1 = base_ph[1] + mine1;
+        E.lcount[im][4 + 2 * (I & 1) + 0] = n0; // phase (row parity I & 1, column parity 0)
+        E.lcount[im][4 + 2 * (I & 1) + 1] = n1;
+        atomicAdd(const_cast<int32_t *>(E.counts[im]) + 3, n0 + n1);
+    }
+    if (mine0 + mine1 == 0)
+        return;
     const int par = threadIdx.x & 1; // column parity (J0 is a multiple of 256)
     const unsigned long long pmask = par ? 0xaaaaaaaaaaaaaaaaull : 0x5555555555555555ull;
     for (int J0 = 0; J0 < W2; J0 += 256)
@@ -1950,10 +1917,6 @@ int toed_enqueue(ebvo_ctx *ctx, Slot &s, int n_img, int h, int w, hipEvent_t ev_
         if (stop == 1)
             return EBVO_OK;
         {
-            ProfScope ps(ctx, s, K_ROWSCAN);
-            hipLaunchKernelGGL(toed_rowscan_phase_kernel, dim3(n_img), dim3(192), 0, s.stream, B, H2, cap);
-        }
-        {
             ProfScope ps(ctx, s, K_COMPACT);
             hipLaunchKernelGGL(toed_compact_phase_kernel, dim3(H2 - 20, n_img), dim3(256), 0, s.stream, B, h, w, cap);
         }
@@ -1978,7 +1941,6 @@ int toed_enqueue(ebvo_ctx *ctx, Slot &s, int n_img, int h, int w, hipEvent_t ev_
                 E.magmap[k] = ws.maps;
                 E.needbits[k] = (uint32_t *)(ws.maps + mag_map_doubles(H2, W2));
                 E.need_cnt[k] = (int32_t *)(E.needbits[k] + need_words);
-                E.need_off[k] = E.need_cnt[k] + 2 * H2;
             }
             const ToedTables *T = (const ToedTables *)g_tables_dev[ctx->device];
             {
@@ -1998,7 +1960,6 @@ int toed_enqueue(ebvo_ctx *ctx, Slot &s, int n_img, int h, int w, hipEvent_t ev_
             {
                 ProfScope ps(ctx, s, K_COMPACT); // the lists of the distinct neighbour points
                 hipLaunchKernelGGL(toed_need_count_kernel, dim3((H2 + 3) / 4, n_img), dim3(256), 0, s.stream, E, h, w);
-                hipLaunchKernelGGL(toed_need_rowscan_kernel, dim3(n_img), dim3(128), 0, s.stream, E, H2);
                 hipLaunchKernelGGL(toed_need_compact_kernel, dim3(H2, n_img), dim3(256), 0, s.stream, E, h, w, cap);
             }
             if (stop == 4)

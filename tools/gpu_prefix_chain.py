@@ -15,8 +15,8 @@ H, W = synth.SHAPES["kitti"]
 F = synth.fundamental_for("kitti")
 NS = 6
 left, right = synth.stereo_pair("s2", H, W, scene=7, noise_base=0, disparity=12)
-STAGES = [(1, "clear + screen"), (2, "rowscan_phase + compact_phase"), (3, "exact centre"), (4, "need count / rowscan / compact"),
-          (5, "exact mags"), (6, "exact decide"), (7, "flag scans + cand_scatter"), (8, "match_prep"), (9, "candidates<count>"),
+STAGES = [(1, "clear + screen"), (2, "compact_phase"), (3, "exact centre"), (4, "need count / compact"),
+          (5, "exact mags"), (6, "exact decide"), (7, "cand_scatter"), (8, "match_prep"), (9, "candidates<count>"),
           (10, "row scan"), (11, "candidates<fill>"), (12, "right bank"), (13, "NCC tile"), (0, "pair_result (whole chain)")]
 
 
