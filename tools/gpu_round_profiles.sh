@@ -37,6 +37,8 @@ bash tools/gpu_boundary_trace.sh 20 3 >> "$EBVO_PROFILES_DST/${TAG}_stagewise_ca
 python3 tools/gpu_chain_time.py > "$EBVO_PROFILES_DST/${TAG}_chain_time.txt" 2>&1
 python3 tools/gpu_streams_sweep.py > "$EBVO_PROFILES_DST/${TAG}_slots_sweep.txt" 2>&1
 python3 tools/gpu_ab_round4.py > "$EBVO_PROFILES_DST/${TAG}_ab_switches.txt" 2>&1
+python3 tools/gpu_prefix_chain.py > "$EBVO_PROFILES_DST/${TAG}_prefix_chain.txt" 2>&1      # what every stage costs with six pairs in flight
+python3 tools/gpu_marginal_cost.py > "$EBVO_PROFILES_DST/${TAG}_marginal_cost.txt" 2>&1
 python3 tools/gpu_ingest_diag.py pack > "$EBVO_PROFILES_DST/${TAG}_ingest_forms.txt" 2>&1
 python3 tools/gpu_ingest_diag.py push >> "$EBVO_PROFILES_DST/${TAG}_ingest_forms.txt" 2>&1
 ls -la "$EBVO_PROFILES_DST"
