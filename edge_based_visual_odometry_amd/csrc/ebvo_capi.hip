@@ -2676,13 +2676,13 @@ static int finalize_enqueue(ebvo_ctx *ctx, Slot &s, const ebvo_finalize_params *
         // applied to the NCC-scored pairs of the run selects the reference's SIFT-then-NCC survivors.
         const int nR = s.result.n_right;
         const size_t npx = (size_t)h * w;
-        if ((rc = ebvo_grow(ctx, s, s.sift_img, sizeof(float) * 2 * npx)) ||
+        if ((rc = ebvo_grow(ctx, s, s.sift_img, sizeof(float) * 3 * npx)) ||
             (rc = ebvo_grow(ctx, s, s.sift_desc, 256 * ((size_t)nL + (size_t)nR))) ||
             (rc = ebvo_grow(ctx, s, s.sift_dist, sizeof(double) * nz + 2 * nz)) ||
             (rc = ebvo_grow(ctx, s, s.pair_left, sizeof(int32_t) * nz)) ||
             (rc = ebvo_grow(ctx, s, s.sift_used, sizeof(int32_t) * (4 + (size_t)nL + (size_t)nR) + (size_t)nR)))
             return rc;
-        float *tmp = (float *)s.sift_img.p, *base = tmp + npx;
+        float *tmp = (float *)s.sift_img.p, *base = tmp + npx, *base1 = base + npx; // (both octave bases: one descriptor launch)
         uint8_t *dL = (uint8_t *)s.sift_desc.p, *dR = dL + 256 * (size_t)nL;
         double *dist = (double *)s.sift_dist.p;
         uint8_t *ok = (uint8_t *)(dist + nz), *both = ok + nz;
@@ -2693,9 +2693,9 @@ static int finalize_enqueue(ebvo_ctx *ctx, Slot &s, const ebvo_finalize_params *
         uint8_t *used_flags = (uint8_t *)(usedR + nR);
         if ((rc = sift_used_edges_enqueue(ctx, s, rp0, nL, (const int32_t *)s.col_idx.p, n0, nR, used_cnt, usedL, usedR, used_flags)) ||
             (rc = sift_base_enqueue(ctx, s, s.im[0].img, h, w, w, tmp, base)) ||
-            (rc = sift_descriptors_listed_enqueue(ctx, s, base, h, w, s.im[0].edges, usedL, used_cnt, nL, dL)) ||
-            (rc = sift_base_enqueue(ctx, s, s.im[1].img, h, w, w, tmp, base)) ||
-            (rc = sift_descriptors_listed_enqueue(ctx, s, base, h, w, s.im[1].edges, usedR, used_cnt + 1, nR, dR)) ||
+            (rc = sift_base_enqueue(ctx, s, s.im[1].img, h, w, w, tmp, base1)) ||
+            (rc = sift_descriptors_listed_pair_enqueue(ctx, s, base, base1, h, w, s.im[0].edges, s.im[1].edges, usedL, usedR, used_cnt, nL,
+                                                       nR, dL, dR)) ||
             (rc = match_expand_rows_enqueue(ctx, s, rp0, nL, n0, (int32_t *)s.pair_left.p)) ||
             (rc = sift_distances_enqueue(ctx, s, dL, dR, (const int32_t *)s.pair_left.p, (const int32_t *)s.col_idx.p, n0,
                                          p->sift_thr, dist, ok)) ||

@@ -499,6 +499,10 @@ int sift_descriptors_enqueue(ebvo_ctx *ctx, Slot &s, const float *d_base, int h,
 // the descriptors of the edges list[0 .. *d_n) only (n_max bounds the launch), written at the edges' own places in d_desc_u8
 int sift_descriptors_listed_enqueue(ebvo_ctx *ctx, Slot &s, const float *d_base, int h, int w, const ebvo_edge *d_edges,
                                     const int32_t *d_list, const int32_t *d_n, int n_max, uint8_t *d_desc_u8);
+int sift_descriptors_listed_pair_enqueue(ebvo_ctx *ctx, Slot &s, const float *d_base0, const float *d_base1, int h, int w,
+                                         const ebvo_edge *d_edges0, const ebvo_edge *d_edges1, const int32_t *d_list0,
+                                         const int32_t *d_list1, const int32_t *d_n, int n_max0, int n_max1, uint8_t *d_desc0,
+                                         uint8_t *d_desc1);
 // which left (a row of the CSR with at least one pair) and right (named by some pair) edges need a descriptor: two index lists,
 // unordered, and their lengths in d_counts[0 .. 1]; d_flags: nR scratch bytes
 int sift_used_edges_enqueue(ebvo_ctx *ctx, Slot &s, const int32_t *d_row_ptr, int nL, const int32_t *d_col_idx, int64_t n_pairs,

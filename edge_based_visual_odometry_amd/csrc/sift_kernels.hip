@@ -117,17 +117,16 @@ __device__ inline float sift_fast_atan2_sel(float y, float x)
 
 // calcSIFTDescriptor (modules/features2d/src/sift.simd.hpp), one thread per keypoint (edge e, side sd)
 // `list` (with its length on the device, *n_list): the descriptors of those edges only, each written at its edge's own place.
-__global__ __launch_bounds__(64) void sift_desc_kernel(const float *__restrict__ base, int rows, int cols,
-                                                       const ebvo_edge *__restrict__ edges, int n_edges,
-                                                       float *__restrict__ desc_f, uint8_t *__restrict__ desc_u8,
-                                                       const int32_t *__restrict__ list, const int32_t *__restrict__ n_list)
+__device__ __forceinline__ void sift_desc_body(float *__restrict__ hist, const float *__restrict__ base, int rows, int cols,
+                                               const ebvo_edge *__restrict__ edges, int n_edges, float *__restrict__ desc_f,
+                                               uint8_t *__restrict__ desc_u8, const int32_t *__restrict__ list,
+                                               const int32_t *__restrict__ n_list, int vb, int vg)
 {
-    __shared__ float hist[SHIST * 64];
     const int lane = threadIdx.x;
     if (list)
         n_edges = min(*n_list, n_edges);
     const int n_kp = n_edges * 2;
-    for (int base_kp = blockIdx.x * 64; base_kp < n_kp; base_kp += gridDim.x * 64)
+    for (int base_kp = vb * 64; base_kp < n_kp; base_kp += vg * 64)
     {
         const int kp_in = base_kp + lane;
         if (kp_in >= n_kp)
@@ -353,6 +352,33 @@ if ((unsigned)rr_ < (unsigned)SD && (unsigned)cc_ < (unsigned)SD)               
     }
 }
 
+__global__ __launch_bounds__(64) void sift_desc_kernel(const float *__restrict__ base, int rows, int cols,
+                                                       const ebvo_edge *__restrict__ edges, int n_edges,
+                                                       float *__restrict__ desc_f, uint8_t *__restrict__ desc_u8,
+                                                       const int32_t *__restrict__ list, const int32_t *__restrict__ n_list)
+{
+    __shared__ float hist[SHIST * 64];
+    sift_desc_body(hist, base, rows, cols, edges, n_edges, desc_f, desc_u8, list, n_list, blockIdx.x, gridDim.x);
+}
+
+// the listed descriptors of BOTH images of a pair in one launch (blockIdx.y = image): a launch per image ran ~1.2 rounds of
+// the 1,024 waves the device holds (one per SIMD: the histograms fill the LDS), i.e. two rounds with the second a fifth full
+struct SiftPairArgs
+{
+    const float *base[2];
+    const ebvo_edge *edges[2];
+    const int32_t *list[2], *n_list[2];
+    uint8_t *desc_u8[2];
+    int n_max[2];
+};
+__global__ __launch_bounds__(64) void sift_desc_pair_kernel(SiftPairArgs A, int rows, int cols)
+{
+    __shared__ float hist[SHIST * 64];
+    const int im = blockIdx.y;
+    sift_desc_body(hist, A.base[im], rows, cols, A.edges[im], A.n_max[im], nullptr, A.desc_u8[im], A.list[im], A.n_list[im],
+                   blockIdx.x, gridDim.x);
+}
+
 // float descriptors (host-buffer call) -> bytes
 __global__ void sift_to_u8_kernel(const float *__restrict__ f, int64_t n, uint8_t *__restrict__ u)
 {
@@ -489,6 +515,27 @@ int sift_descriptors_listed_enqueue(ebvo_ctx *ctx, Slot &s, const float *d_base,
     // one keypoint per thread, one wave per SIMD (the histograms fill the LDS): a grid of what the device holds, strided
     hipLaunchKernelGGL(sift_desc_kernel, dim3(grid1d((int64_t)n_max * 2, 64, 4096)), dim3(64), 0, s.stream, d_base, h, w, d_edges,
                        n_max, (float *)nullptr, d_desc_u8, d_list, d_n);
+    EBVO_HIP(ctx, hipGetLastError());
+    return EBVO_OK;
+}
+
+int sift_descriptors_listed_pair_enqueue(ebvo_ctx *ctx, Slot &s, const float *d_base0, const float *d_base1, int h, int w,
+                                         const ebvo_edge *d_edges0, const ebvo_edge *d_edges1, const int32_t *d_list0,
+                                         const int32_t *d_list1, const int32_t *d_n, int n_max0, int n_max1, uint8_t *d_desc0,
+                                         uint8_t *d_desc1)
+{
+    const int nm = n_max0 > n_max1 ? n_max0 : n_max1;
+    if (nm <= 0)
+        return EBVO_OK;
+    ProfScope ps(ctx, s, K_SIFT);
+    SiftPairArgs A;
+    A.base[0] = d_base0, A.base[1] = d_base1;
+    A.edges[0] = d_edges0, A.edges[1] = d_edges1;
+    A.list[0] = d_list0, A.list[1] = d_list1;
+    A.n_list[0] = d_n, A.n_list[1] = d_n + 1;
+    A.desc_u8[0] = d_desc0, A.desc_u8[1] = d_desc1;
+    A.n_max[0] = n_max0, A.n_max[1] = n_max1;
+    hipLaunchKernelGGL(sift_desc_pair_kernel, dim3(grid1d((int64_t)nm * 2, 64, 4096), 2), dim3(64), 0, s.stream, A, h, w);
     EBVO_HIP(ctx, hipGetLastError());
     return EBVO_OK;
 }
