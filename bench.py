@@ -625,26 +625,30 @@ def sequence_bench(args, wl, H, W, F, device, rank, world, dist, reduce_device):
         tc, _ = ctx.temporal_match(slot=k, fetch=False, stages=stages)
         return c, fc, tc
 
-    def frame_pipeline(slots, stages=0):
+    DEFAULT_LAGS = (1, 3, 4)   # steps between a frame's A and its B, C, D: five frames in flight (tools/gpu_pipeline_hosttime.py:
+                               # 957 / 1009 / 1020 frames/s for (1, 2, 3) / (1, 3, 4) / (1, 4, 5); round 3 ran (1, 2, 3))
+
+    def frame_pipeline(slots, stages=0, lags=None):
         """The frames `slots` (one per step, each resident in its slot) as a software pipeline over four enqueue-only steps --
         A: TOED + candidates + NCC submitted; B: its counts read, the stereo chain enqueued (ebvo_stereo_finalize_submit); C: the
         chain's counts read, the temporal stages enqueued (ebvo_temporal_match_submit); D: their counts read -- so the host
-        never waits for the frame it has just enqueued and the chains of up to four frames overlap on the device.  Returns the
+        never waits for the frame it has just enqueued and the chains of up to five frames overlap on the device.  Returns the
         per-frame (stereo counts, chain counts, temporal counts), in order."""
         n = len(slots)
+        LAG_B, LAG_C, LAG_D = lags or DEFAULT_LAGS
         res = [[None, None, None] for _ in range(n)]
-        for i in range(n + 3):
+        for i in range(n + LAG_D):
             if i < n:
-                assert slots[i] not in slots[max(0, i - 3):i], "a slot re-enters the pipeline before it has left it"
+                assert slots[i] not in slots[max(0, i - LAG_D):i], "a slot re-enters the pipeline before it has left it"
                 ctx.stereo_submit(params, slot=slots[i])                                      # A
-            if 0 <= i - 1 < n:
-                res[i - 1][0] = ctx.stereo_wait(slot=slots[i - 1])                            # B
-                ctx.stereo_finalize_submit(calib, slot=slots[i - 1], use_sift=True)
-            if 0 <= i - 2 < n:
-                res[i - 2][1] = ctx.stereo_finalize_wait(slot=slots[i - 2], fetch=False)[0]   # C
-                ctx.temporal_match_submit(slot=slots[i - 2], stages=stages)
-            if 0 <= i - 3 < n:
-                res[i - 3][2] = ctx.temporal_match_wait(slot=slots[i - 3], fetch=False)[0]    # D
+            if 0 <= i - LAG_B < n:
+                res[i - LAG_B][0] = ctx.stereo_wait(slot=slots[i - LAG_B])                    # B
+                ctx.stereo_finalize_submit(calib, slot=slots[i - LAG_B], use_sift=True)
+            if 0 <= i - LAG_C < n:
+                res[i - LAG_C][1] = ctx.stereo_finalize_wait(slot=slots[i - LAG_C], fetch=False)[0]   # C
+                ctx.temporal_match_submit(slot=slots[i - LAG_C], stages=stages)
+            if 0 <= i - LAG_D < n:
+                res[i - LAG_D][2] = ctx.temporal_match_wait(slot=slots[i - LAG_D], fetch=False)[0]    # D
         return [tuple(r) for r in res]
 
     frame(0, first=True)                               # keyframe = frame 0 (src/Pipeline.cpp:133-138)
@@ -688,7 +692,7 @@ def sequence_bench(args, wl, H, W, F, device, rank, world, dist, reduce_device):
         n_full = min(16, n_frames)
         frame(1, stages=1)
         t1 = time.perf_counter()
-        tcf = frame_pipeline([k % n_frames for k in range(n_full)], stages=1)[-1][2]
+        tcf = frame_pipeline([k % n_frames for k in range(n_full)], stages=1, lags=(1, 2, 3))[-1][2]   # (its step D runs the tail synchronously: a deeper pipeline only delays it -- 415 against 475 frames/s with (1, 3, 4))
         t_full = (time.perf_counter() - t1) / n_full
         # ... and frame after frame, every stage waited for (what the loop was before the enqueue-only chains)
         t1 = time.perf_counter()
@@ -724,7 +728,7 @@ def sequence_bench(args, wl, H, W, F, device, rank, world, dist, reduce_device):
             "full_temporal_chain_frames_per_s": 1.0 / t_full,
             "one_frame_at_a_time_frames_per_s": 1.0 / t_serial,
             "pipeline_note": "value: the frame loop as a software pipeline of enqueue-only steps (TOED + matching | stereo chain | "
-                             "temporal stages | counts), up to four frames in flight in their own slots from one host thread and "
+                             "temporal stages | counts), up to five frames in flight in their own slots from one host thread and "
                              "one context; one_frame_at_a_time: every stage waited for before the next is enqueued",
             "full_temporal_chain_note": "the same frame loop with the rest of get_Temporal_Edge_Pairs_from_Quads after the NCC "
                                         "filter (SIFT filter, Best-Nearly-Best on NCC and SIFT scores, photometric refinement "
