@@ -683,7 +683,9 @@ class Context:
         """Test hooks (ebvo_debug_set): 0 = attempts of the regrow loop, 1 = force N overflowed results, 2 = number of
         lanes (streams the submitted pairs are dealt to when more slots are in use; 0 = one stream per slot), 3 = the
         profiler instruments one stage alone (index in profile_get()'s order + 1; 0 = every stage), 4 / 5 = launch layout
-        of the refinements (1 = one thread per pair always / threshold of the eight-lanes layout)."""
+        of the refinements (1 = one thread per pair always / threshold of the eight-lanes layout); 10 = pair chain as a
+        hipGraph; 11 / 12 / 17 = grids of the exact centre / mags / NCC tile kernels in blocks; 13 / 14 / 18 = A/B switches;
+        15 = bit mask of kernels launched twice, 16 = the chain ends after stage N (measurement only): include/ebvo_hip.h."""
         self._check(self.lib.ebvo_debug_set(self._ctx, key, value), "ebvo_debug_set")
 
     # -- profiling -----------------------------------------------------------------------------

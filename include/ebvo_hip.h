@@ -104,7 +104,7 @@ enum
 int ebvo_set_toed_mode(ebvo_ctx *ctx, int mode);
 int ebvo_get_toed_mode(const ebvo_ctx *ctx);
 int64_t ebvo_toed_fallbacks(const ebvo_ctx *ctx); /* hybrid runs the library repeated on the strict path so far */
-/* ebvo_stereo_submit captures the ~31 launches of a pair into a hipGraph at the THIRD submission of a slot with unchanged
+/* ebvo_stereo_submit captures the 18 launches of a pair into a hipGraph at the THIRD submission of a slot with unchanged
  * size, parameters and buffers, and launches that graph afterwards (environment EBVO_GRAPHS=0 or ebvo_debug_set(ctx, 10, 0):
  * direct launches).  Number of pairs submitted as a graph launch so far: */
 int64_t ebvo_graph_launches(const ebvo_ctx *ctx);
@@ -716,7 +716,16 @@ int ebvo_profile_get(ebvo_ctx *ctx, ebvo_kernel_time *out /* EBVO_MAX_KERNELS */
  * key 8: waves per SIMD the persistent launch is built for (2 or 3).  Same bits either way.
  * key 6: set the candidate-quad capacity of every slot's temporal stage to `value` (>= 1): the next ebvo_temporal_match
  *        finds more quads than its buffers hold and takes the regrow path.
- * key 10: 0 = ebvo_stereo_submit enqueues the pair as direct launches, 1 = as a captured hipGraph (default). */
+ * key 10: 0 = ebvo_stereo_submit enqueues the pair as direct launches, 1 = as a captured hipGraph (default).
+ * keys 11, 12: grid of toed_exact_centre / toed_exact_mags in blocks (0 = what the device keeps resident);
+ * key 13: 1 = ebvo_stereo_upload_async copies on the upload stream instead of the pull kernel; key 14: 1 = lines, boxes,
+ *        sin / cos and row pairs as four launches instead of one; key 17: grid of ncc_tile_kernel in blocks (0 = resident);
+ *        key 18: grids of decide / cand_scatter / candidates<fill> divided by `value`.  Same bits either way (A/B switches).
+ * key 15: bit mask -- an idempotent kernel of the resident pair's chain is launched TWICE (1 centre, 2 mags, 4 right bank,
+ *        8 NCC tile): what one more launch costs the pair rate (tools/gpu_marginal_cost.py).
+ * key 16: the resident pair's chain ENDS after stage `value` (0 = whole chain; the pair's record keeps the counts of the last
+ *        whole run, the buffers behind the stage are stale): the pair rate of every prefix of the chain
+ *        (tools/gpu_prefix_chain.py).  Measurement only. */
 int ebvo_debug_set(ebvo_ctx *ctx, int key, int value);
 
 /* Raw FP64 vector-ALU microbenchmark (mul + add, no FMA) used to anchor the compute roofline:
