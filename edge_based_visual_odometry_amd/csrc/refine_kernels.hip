@@ -810,26 +810,25 @@ __global__ __launch_bounds__(256, WAVES) void gn_rows_persistent_kernel(GnArgs A
     if (n_in > A.rows_below) // the one-thread-per-pair launches ran this list (and it was the last iteration, or nothing survived)
         return;
     const int32_t *__restrict__ lin = A.list[it0 & 1];
-    int32_t *head = &A.counts[A.max_iter + 1]; // next list entry to hand out (zeroed with the counts)
     const int lane = threadIdx.x & 63, row = lane & 7, gbase = lane & ~7;
     bool have = false;
     int it = it0;
     int64_t k = lin[0]; // a group without a pair computes on pair lin[0] and writes nothing
     GnRowsState S;
     gn_rows_load(A, k, S);
+    // Every 8-lane group walks its own arithmetic sequence of list entries (group g: g, g + G, g + 2 G, ...).  Round 3 drew
+    // the entries from a shared cursor, one returning atomic per wave and loop turn: with one wave per SIMD its round trip
+    // (and the serialisation of thousands of same-address atomics across the XCDs) sat in every turn of the loop.
+    const int n_groups = (int)gridDim.x * 32;
+    int my_next = ((int)blockIdx.x * 4 + (int)(threadIdx.x >> 6)) * 8 + (lane >> 3);
     for (;;)
     {
-        // groups without a pair draw the next list entries: one atomic per wave
-        const unsigned long long need = __ballot(!have && row == 0);
-        int base = 0;
-        if (lane == 0 && need)
-            base = atomicAdd(head, __popcll(need));
-        base = __shfl(base, 0);
         if (!have)
         {
-            const int idx = base + __popcll(need & ((1ull << gbase) - 1ull)); // rank of this group among the drawing ones
+            const int idx = my_next;
             if (idx < n_in)
             {
+                my_next += n_groups;
                 k = lin[idx];
                 gn_rows_load(A, k, S);
                 it = it0;
@@ -1396,8 +1395,11 @@ int refine_gn_stereo_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_imgL, cons
                 hipLaunchKernelGGL(gn_iter_kernel, dim3(blocks), dim3(256), 0, s.stream, A, it, 1);
         const int64_t most = n_pairs < A.rows_below ? n_pairs : A.rows_below; // pairs the persistent launch can be handed
         // at most gn_persist_blocks workgroups (4 waves each; 256 = one wave per SIMD): with fewer groups than pairs a group
-        // draws several pairs one after the other, which evens out the 1 .. max_iter iterations the pairs need
-        const int64_t bcap = ctx->gn_persist_blocks > 0 ? ctx->gn_persist_blocks : 256; // tools/gpu_gn_ab.py: 256 < 512 < 768 ... at both sizes
+        // takes several pairs one after the other, which evens out the 1 .. max_iter iterations the pairs need.  With the
+        // groups walking their own sequences (no shared cursor) more groups balance better: tools/gpu_gn_ab.py,
+        // refinement stage at 256 / 512 / 1024 / 8192 blocks: 0.477 / 0.405 / 0.391 / 0.390 ms (EuRoC size), 1.10 / 0.99 / 1.00 / 1.02
+        // (KITTI size); with the cursor 256 had been the optimum
+        const int64_t bcap = ctx->gn_persist_blocks > 0 ? ctx->gn_persist_blocks : 1024;
         const unsigned pblocks = (unsigned)((most + 31) / 32 < bcap ? (most + 31) / 32 : bcap);
         if (ctx->gn_per_iteration_rows) // developer key: the row layout as a launch per iteration (the form before the persistent kernel)
             for (int it = 0; it < max_iter; ++it)
