@@ -1069,9 +1069,110 @@ __global__ __launch_bounds__(256) void gn2_iter_kernel(Gn2Args A, int it)
 
 // Eight lanes per item for small batches, as gn_iter_rows_kernel: lane r < 7 = patch row r of both sides; the nine
 // running sums (H gets its 1e-6 I after every sample, :809) visit the lanes in row order.  Bit-identical to gn2_iter_kernel.
-__global__ __launch_bounds__(256, 2) void gn2_iter_rows_kernel(Gn2Args A, int it)
+// One Gauss-Newton iteration of item k on the eight lanes of a group (lane `row` = patch row; `live` and k uniform in the
+// group).  (d0, d1) is the item's state, held by the caller; lane 0 of the group updates it, stores it, records the verdict
+// when the item has finished, and returns whether it goes on (the other lanes return false: the caller broadcasts).
+__device__ __forceinline__ bool gn2_rows_iteration(const Gn2Args &A, int64_t k, bool live, int it, int row, int gbase, double &d0,
+                                                   double &d1)
 {
     const int h = A.h, w = A.w;
+    bool survives = false;
+    const ebvo_edge ke = A.kf[k];
+    const bool second = k >= A.n_first;
+    const uint4 *__restrict__ recC = second ? A.recC2 : A.recC;
+    const double stc = A.sc[2 * A.n + k], ctc = A.sc[3 * A.n + k];
+    const double ncx = -stc, ncy = ctc, side = (7 / 2.0) + 1.0;
+    const double meanL[2] = {A.mean_l[k], A.mean_l[A.n + k]};
+    const double lx = ke.x - d0, ly = ke.y - d1; // :786
+    const int i = min(row, 6) - 3; // this lane's patch row (lane 7 repeats row 6 and is never selected)
+    double H00 = 0, H10 = 0, H11 = 0, b0 = 0, b1 = 0, cost = 0;
+#pragma unroll 1
+    for (int sd = 0; sd < 2; ++sd)
+    {
+        const float *__restrict__ lrec = A.lrec + (size_t)k * 98 + sd * 49 + (i + 3) * 7;
+        const double cx = sd ? lx - ncx * side : lx + ncx * side, cy = sd ? ly - ncy * side : ly + ncy * side;
+        GnTap tp[7]; // this lane's row of the side: every point tapped once (intensity and both gradients)
+#pragma unroll
+        for (int j = -3; j <= 3; ++j)
+            tp[j + 3] = gn_tap(recC, w, h, cx + ctc * i - stc * j, cy + stc * i + ctc * j);
+        double sum = 0;
+#pragma unroll 1
+        for (int r = 0; r < 7; ++r)
+        {
+            double t = sum;
+#pragma unroll
+            for (int j = 0; j < 7; ++j)
+                t += (double)tp[j].v;
+            sum = __shfl(t, gbase | r);
+        }
+        const double meanR = sum / 49;
+        double t00[7], t10[7], t11[7], tb0[7], tb1[7], tc[7];
+#pragma unroll
+        for (int j = 0; j < 7; ++j)
+        {
+            const double Lf = (double)lrec[j]; // sampled once by gn2_init_kernel
+            const double Rf = (double)tp[j].v, J0 = (double)tp[j].gx, J1 = (double)tp[j].gy;
+            const double r = (Lf - meanL[sd]) - (Rf - meanR);
+            const double absr = fabs(r);
+            const double wgt = (absr < A.huber) ? 1.0 : A.huber / absr; // strict, :806
+            const double wJ0 = wgt * J0, wJ1 = wgt * J1;
+            t00[j] = wJ0 * J0; // the addends of gn2_iter_kernel's sums, formed by the same operations
+            t10[j] = wJ1 * J0;
+            t11[j] = wJ1 * J1;
+            tb0[j] = wJ0 * r;
+            tb1[j] = wJ1 * r;
+            tc[j] = wgt * r * r;
+        }
+#pragma unroll 1
+        for (int r = 0; r < 7; ++r)
+        {
+            double u00 = H00, u10 = H10, u11 = H11, ub0 = b0, ub1 = b1, uc = cost;
+#pragma unroll
+            for (int j = 0; j < 7; ++j)
+            {
+                u00 += t00[j];
+                u10 += t10[j];
+                u11 += t11[j];
+                u00 += 1e-6; // H += 1e-6 * I (:809)
+                u10 += 0.0;
+                u11 += 1e-6;
+                ub0 += tb0[j];
+                ub1 += tb1[j];
+                uc += tc[j];
+            }
+            H00 = __shfl(u00, gbase | r);
+            H10 = __shfl(u10, gbase | r);
+            H11 = __shfl(u11, gbase | r);
+            b0 = __shfl(ub0, gbase | r);
+            b1 = __shfl(ub1, gbase | r);
+            cost = __shfl(uc, gbase | r);
+        }
+    }
+    if (live && row == 0)
+    {
+        double s0, s1;
+        ldlt2_solve(H00, H10, H11, b0, b1, s0, s1);
+        const double delta0 = -s0, delta1 = -s1;
+        d0 += delta0;
+        d1 += delta1;
+        const double rms = sqrt(cost / 98);
+        const bool is_outlier = (rms > A.huber * 2.0) || (it + 1 < 2);
+        const bool finished = sqrt(delta0 * delta0 + delta1 * delta1) < A.tol || it == A.max_iter - 1;
+        A.disp[2 * k] = d0;
+        A.disp[2 * k + 1] = d1;
+        if (finished)
+        {
+            A.valid[k] = is_outlier ? 0 : 1;
+            A.score[k] = rms;
+            A.iters[k] = it + 1;
+        }
+        survives = !finished;
+    }
+    return survives;
+}
+
+__global__ __launch_bounds__(256, 2) void gn2_iter_rows_kernel(Gn2Args A, int it)
+{
     const int n_in = A.counts[it];
     const int32_t *__restrict__ lin = A.list[it & 1];
     int32_t *__restrict__ lout = A.list[(it + 1) & 1];
@@ -1082,99 +1183,8 @@ __global__ __launch_bounds__(256, 2) void gn2_iter_rows_kernel(Gn2Args A, int it
         const int idx = base + (threadIdx.x >> 3);
         const bool live = idx < n_in; // uniform in the group
         const int64_t k = live ? lin[idx] : 0;
-        bool survives = false;
-        const ebvo_edge ke = A.kf[k];
-        const bool second = k >= A.n_first;
-        const uint4 *__restrict__ recC = second ? A.recC2 : A.recC;
-        const double stc = A.sc[2 * A.n + k], ctc = A.sc[3 * A.n + k];
-        const double ncx = -stc, ncy = ctc, side = (7 / 2.0) + 1.0;
-        const double meanL[2] = {A.mean_l[k], A.mean_l[A.n + k]};
         double d0 = A.disp[2 * k], d1 = A.disp[2 * k + 1];
-        const double lx = ke.x - d0, ly = ke.y - d1; // :786
-        const int i = min(row, 6) - 3; // this lane's patch row (lane 7 repeats row 6 and is never selected)
-        double H00 = 0, H10 = 0, H11 = 0, b0 = 0, b1 = 0, cost = 0;
-#pragma unroll 1
-        for (int sd = 0; sd < 2; ++sd)
-        {
-            const float *__restrict__ lrec = A.lrec + (size_t)k * 98 + sd * 49 + (i + 3) * 7;
-            const double cx = sd ? lx - ncx * side : lx + ncx * side, cy = sd ? ly - ncy * side : ly + ncy * side;
-            GnTap tp[7]; // this lane's row of the side: every point tapped once (intensity and both gradients)
-#pragma unroll
-            for (int j = -3; j <= 3; ++j)
-                tp[j + 3] = gn_tap(recC, w, h, cx + ctc * i - stc * j, cy + stc * i + ctc * j);
-            double sum = 0;
-#pragma unroll 1
-            for (int r = 0; r < 7; ++r)
-            {
-                double t = sum;
-#pragma unroll
-                for (int j = 0; j < 7; ++j)
-                    t += (double)tp[j].v;
-                sum = __shfl(t, gbase | r);
-            }
-            const double meanR = sum / 49;
-            double t00[7], t10[7], t11[7], tb0[7], tb1[7], tc[7];
-#pragma unroll
-            for (int j = 0; j < 7; ++j)
-            {
-                const double Lf = (double)lrec[j]; // sampled once by gn2_init_kernel
-                const double Rf = (double)tp[j].v, J0 = (double)tp[j].gx, J1 = (double)tp[j].gy;
-                const double r = (Lf - meanL[sd]) - (Rf - meanR);
-                const double absr = fabs(r);
-                const double wgt = (absr < A.huber) ? 1.0 : A.huber / absr; // strict, :806
-                const double wJ0 = wgt * J0, wJ1 = wgt * J1;
-                t00[j] = wJ0 * J0; // the addends of gn2_iter_kernel's sums, formed by the same operations
-                t10[j] = wJ1 * J0;
-                t11[j] = wJ1 * J1;
-                tb0[j] = wJ0 * r;
-                tb1[j] = wJ1 * r;
-                tc[j] = wgt * r * r;
-            }
-#pragma unroll 1
-            for (int r = 0; r < 7; ++r)
-            {
-                double u00 = H00, u10 = H10, u11 = H11, ub0 = b0, ub1 = b1, uc = cost;
-#pragma unroll
-                for (int j = 0; j < 7; ++j)
-                {
-                    u00 += t00[j];
-                    u10 += t10[j];
-                    u11 += t11[j];
-                    u00 += 1e-6; // H += 1e-6 * I (:809)
-                    u10 += 0.0;
-                    u11 += 1e-6;
-                    ub0 += tb0[j];
-                    ub1 += tb1[j];
-                    uc += tc[j];
-                }
-                H00 = __shfl(u00, gbase | r);
-                H10 = __shfl(u10, gbase | r);
-                H11 = __shfl(u11, gbase | r);
-                b0 = __shfl(ub0, gbase | r);
-                b1 = __shfl(ub1, gbase | r);
-                cost = __shfl(uc, gbase | r);
-            }
-        }
-        if (live && row == 0)
-        {
-            double s0, s1;
-            ldlt2_solve(H00, H10, H11, b0, b1, s0, s1);
-            const double delta0 = -s0, delta1 = -s1;
-            d0 += delta0;
-            d1 += delta1;
-            const double rms = sqrt(cost / 98);
-            const bool is_outlier = (rms > A.huber * 2.0) || (it + 1 < 2);
-            const bool finished = sqrt(delta0 * delta0 + delta1 * delta1) < A.tol || it == A.max_iter - 1;
-            A.disp[2 * k] = d0;
-            A.disp[2 * k + 1] = d1;
-            if (finished)
-            {
-                A.valid[k] = is_outlier ? 0 : 1;
-                A.score[k] = rms;
-                A.iters[k] = it + 1;
-            }
-            survives = !finished;
-        }
+        const bool survives = gn2_rows_iteration(A, k, live, it, row, gbase, d0, d1);
         const unsigned long long m = __ballot(survives);
         int wbase = 0;
         if (lane == 0 && m)
@@ -1182,6 +1192,41 @@ __global__ __launch_bounds__(256, 2) void gn2_iter_rows_kernel(Gn2Args A, int it
         wbase = __shfl(wbase, 0);
         if (survives)
             lout[wbase + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)k;
+    }
+}
+
+// The same iterations as ONE launch (round 4): every 8-lane group walks its own sequence of items (group g: g, g + G, ...)
+// and runs each to its convergence, its state in registers; no lists, no counters, no atomics (a launch per iteration had
+// been ~20 launches of ~18 us for a few thousand items, each appending its survivors to a list through an atomic).
+__global__ __launch_bounds__(256, 2) void gn2_rows_persistent_kernel(Gn2Args A)
+{
+    const int lane = threadIdx.x & 63, row = lane & 7, gbase = lane & ~7;
+    const int64_t n = A.n, n_groups = (int64_t)gridDim.x * 32;
+    int64_t my_next = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (lane >> 3);
+    bool have = false;
+    int64_t k = 0;
+    int it = 0;
+    double d0 = 0, d1 = 0;
+    for (;;)
+    {
+        if (!have && my_next < n)
+        {
+            k = my_next;
+            my_next += n_groups;
+            d0 = A.disp[2 * k];
+            d1 = A.disp[2 * k + 1];
+            it = 0;
+            have = true;
+        }
+        if (!__ballot(have))
+            break;
+        const bool goes_on = gn2_rows_iteration(A, have ? k : 0, have, it, row, gbase, d0, d1);
+        const bool on_g = __shfl((int)goes_on, gbase) != 0; // the group's verdict (formed on its lane 0)
+        d0 = __shfl(d0, gbase);
+        d1 = __shfl(d1, gbase);
+        if (have && !on_g)
+            have = false;
+        ++it;
     }
 }
 
@@ -1476,11 +1521,14 @@ int refine_gn_temporal_enqueue(ebvo_ctx *ctx, Slot &s, const uint8_t *d_imgK, co
     hipLaunchKernelGGL(gn2_init_kernel, dim3((unsigned)((n + 31) / 32 < 8192 ? (n + 31) / 32 : 8192)), dim3(256), 0, s.stream, A);
     const bool rows = n <= GN_ROWS_MAX_PAIRS && !ctx->gn_no_rows; // small batch: eight lanes per item
     const unsigned rblocks = (unsigned)((n + 31) / 32 < 8192 ? (n + 31) / 32 : 8192);
-    for (int it = 0; it < max_iter; ++it)
-        if (rows)
-            hipLaunchKernelGGL(gn2_iter_rows_kernel, dim3(rblocks), dim3(256), 0, s.stream, A, it);
-        else
-            hipLaunchKernelGGL(gn2_iter_kernel, dim3(blocks), dim3(256), 0, s.stream, A, it);
+    if (rows && !ctx->gn_per_iteration_rows) // (developer key 7: the row layout as a launch per iteration, the form before)
+        hipLaunchKernelGGL(gn2_rows_persistent_kernel, dim3(rblocks < 1024 ? rblocks : 1024), dim3(256), 0, s.stream, A);
+    else
+        for (int it = 0; it < max_iter; ++it)
+            if (rows)
+                hipLaunchKernelGGL(gn2_iter_rows_kernel, dim3(rblocks), dim3(256), 0, s.stream, A, it);
+            else
+                hipLaunchKernelGGL(gn2_iter_kernel, dim3(blocks), dim3(256), 0, s.stream, A, it);
     EBVO_HIP(ctx, hipGetLastError());
     return EBVO_OK;
 }
