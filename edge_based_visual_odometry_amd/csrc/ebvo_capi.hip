@@ -3250,14 +3250,19 @@ static int temporal_chain(ebvo_ctx *ctx, Slot &s, const ebvo_temporal_params &P,
     int32_t *cnt = (int32_t *)(base + o_cnt), *order = (int32_t *)(base + o_order), *idx = (int32_t *)(base + o_idx);
     uint8_t *okL = (uint8_t *)(base + o_ok), *okR = okL + nK, *ok = okR + nK;
     uint8_t *cf_Ld = (uint8_t *)(base + o_desc), *cf_Rd = cf_Ld + 256 * ncz;
-    auto scan_counts = [&](int32_t *rp_out, int32_t *total) -> int {
+    auto scan_counts = [&](int32_t *rp_out, int32_t *total, int64_t known = -1) -> int {
         int r = ebvo_device_scan(ctx, s, cnt, rp_out, n_kf, nullptr, 1, n_kf + 1);
-        return r ? r : read_i32(ctx, s, rp_out + n_kf, total);
+        if (r || known >= 0) // (a total the host already holds is not read back: one synchronisation less)
+        {
+            *total = (int32_t)(known >= 0 ? known : 0);
+            return r;
+        }
+        return read_i32(ctx, s, rp_out + n_kf, total);
     };
     // select rows of `from` (counts / order just formed against from.rp) into `to`
-    auto compact = [&](const QuadSet &from, QuadSet &to, int32_t *total, bool with_sift) -> int {
+    auto compact = [&](const QuadSet &from, QuadSet &to, int32_t *total, bool with_sift, int64_t known = -1) -> int {
         int r;
-        if ((r = scan_counts(to.rp, total)) || *total == 0)
+        if ((r = scan_counts(to.rp, total, known)) || *total == 0)
             return r;
         if ((r = glue_row_index_enqueue(ctx, s, from.rp, cnt, order, to.rp, n_kf, idx)))
             return r;
@@ -3284,7 +3289,8 @@ static int temporal_chain(ebvo_ctx *ctx, Slot &s, const ebvo_temporal_params &P,
     {
         QuadSet G0{const_cast<int32_t *>(rp), const_cast<int32_t *>(col), const_cast<int32_t *>(quad_kf), const_cast<double *>(sim_l),
                    nullptr, nullptr};
-        if ((rc = glue_rows_from_flags_enqueue(ctx, s, rp, n_kf, keep, cnt, order)) || (rc = compact(G0, A, &n0, false)))
+        // (their number came with the NCC counts: n_kept)
+        if ((rc = glue_rows_from_flags_enqueue(ctx, s, rp, n_kf, keep, cnt, order)) || (rc = compact(G0, A, &n0, false, n_kept)))
             return rc;
     }
     if (n0 == 0)

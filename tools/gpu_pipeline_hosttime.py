@@ -13,6 +13,8 @@ from edge_based_visual_odometry_amd import synth  # noqa: E402
 from edge_based_visual_odometry_amd.api import Context  # noqa: E402
 
 cfg = sys.argv[1] if len(sys.argv) > 1 else "euroc"
+STAGES = int(sys.argv[2]) if len(sys.argv) > 2 else 0   # 1: every stage of the temporal chain (its tail runs inside temporal_wait)
+ONLY = tuple(int(v) for v in sys.argv[3].split(",")) if len(sys.argv) > 3 else None   # one lag setting (for a kernel trace)
 H, W = synth.SHAPES[cfg]
 cal = synth.CALIB[cfg]
 F = synth.fundamental_for(cfg)
@@ -51,7 +53,7 @@ def pipeline(slots, lag_b=1, lag_c=2, lag_d=3):
             timed("finalize_submit", ctx.stereo_finalize_submit, calib, slot=slots[i - lag_b], use_sift=True)
         if 0 <= i - lag_c < n:
             timed("finalize_wait", ctx.stereo_finalize_wait, slot=slots[i - lag_c], fetch=False)
-            timed("temporal_submit", ctx.temporal_match_submit, slot=slots[i - lag_c], stages=0)
+            timed("temporal_submit", ctx.temporal_match_submit, slot=slots[i - lag_c], stages=STAGES)
         if 0 <= i - lag_d < n:
             timed("temporal_wait", ctx.temporal_match_wait, slot=slots[i - lag_d], fetch=False)
 
@@ -60,7 +62,7 @@ pipeline(list(range(n_frames)))
 for k in acc:
     acc[k] = 0.0
 steps = 96
-for lags in ((1, 2, 3), (1, 3, 4), (1, 4, 5), (2, 4, 5), (2, 5, 6), (2, 6, 8), (3, 8, 10)):
+for lags in ((ONLY,) if ONLY else ((1, 2, 3), (1, 3, 4), (1, 4, 5), (2, 4, 5), (2, 5, 6), (2, 6, 8), (3, 8, 10))):
     for k in acc:
         acc[k] = 0.0
     t0 = time.perf_counter()
