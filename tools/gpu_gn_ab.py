@@ -19,7 +19,7 @@ for cfg, disp in (("kitti", 12), ("euroc", 9)):
         c.stereo_run(c.default_params(F))
         c.stereo_finalize(calib, use_sift=True)
         variants = [("eight-lanes layout as a launch per iteration (round 2's form)", ((7, 1), (8, 2), (9, 0), (5, 49152))),
-                    ("persistent launch (default: <= 256 blocks, below 65536)", ((7, 0), (8, 2), (9, 0), (5, 0))),
+                    ("persistent launch (default: <= 1024 blocks, below 65536)", ((7, 0), (8, 2), (9, 0), (5, 0))),
                     ("persistent, built for 3 waves / SIMD", ((7, 0), (8, 3), (9, 0), (5, 0)))]
         for blocks in (512, 1024, 8192):
             variants.append((f"persistent, <= {blocks} blocks", ((7, 0), (8, 2), (9, blocks), (5, 0))))
