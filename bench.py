@@ -689,16 +689,20 @@ def sequence_bench(args, wl, H, W, F, device, rank, world, dist, reduce_device):
         dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
         c, fc, tc = frame(1)
         # the same loop with every stage of the temporal chain (never `value`: the config names the NCC quads)
-        n_full = min(16, n_frames)
+        # (64 frames behind an untimed pass over the 16 slots: a 16-frame burst spent a fifth of its time filling and draining
+        # the pipeline -- 525-550 frames/s where tools/gpu_pipeline_hosttime.py euroc 1 measures 670-730 over 96 frames)
+        n_full = 64
         frame(1, stages=1)
+        frame_pipeline(list(range(n_frames)), stages=1)
         t1 = time.perf_counter()
-        tcf = frame_pipeline([k % n_frames for k in range(n_full)], stages=1, lags=(1, 2, 3))[-1][2]   # (its step D runs the tail synchronously: a deeper pipeline only delays it -- 415 against 475 frames/s with (1, 3, 4))
+        tcf = frame_pipeline([k % n_frames for k in range(n_full)], stages=1)[-1][2]
         t_full = (time.perf_counter() - t1) / n_full
         # ... and frame after frame, every stage waited for (what the loop was before the enqueue-only chains)
+        n_serial = min(16, n_frames)
         t1 = time.perf_counter()
-        for k in range(n_full):
+        for k in range(n_serial):
             frame(k % n_frames)
-        t_serial = (time.perf_counter() - t1) / n_full
+        t_serial = (time.perf_counter() - t1) / n_serial
         # the same frames through T contexts driven by T host threads (the library's model: one ebvo_ctx per host thread):
         # a frame is a host-sequenced chain of ~180 short launches, so several chains share the device well
         threaded = {}
@@ -730,7 +734,7 @@ def sequence_bench(args, wl, H, W, F, device, rank, world, dist, reduce_device):
             "pipeline_note": "value: the frame loop as a software pipeline of enqueue-only steps (TOED + matching | stereo chain | "
                              "temporal stages | counts), up to five frames in flight in their own slots from one host thread and "
                              "one context; one_frame_at_a_time: every stage waited for before the next is enqueued",
-            "full_temporal_chain_note": "the same frame loop with the rest of get_Temporal_Edge_Pairs_from_Quads after the NCC "
+            "full_temporal_chain_note": "64 frames behind an untimed pass over the 16 slots: the same frame loop with the rest of get_Temporal_Edge_Pairs_from_Quads after the NCC "
                                         "filter (SIFT filter, Best-Nearly-Best on NCC and SIFT scores, photometric refinement "
                                         "of both cameras, edge clustering): %d final quads per frame" % tcf["n_final"],
         }
