@@ -90,6 +90,27 @@ KERNEL_SYMBOLS = {
 }
 
 
+def sift_roofline():
+    """VALU-issue roofline of the SIFT descriptor kernel (one wave per SIMD: its histograms fill the LDS) from the COMMITTED
+    rocprofv3 counter passes of the KITTI-size chain (profiles/r04_chain_pmc_sq_chain.txt: launch duration, waves, VALU
+    instructions per wave); not measured in this run.  Peak: 1,024 SIMDs x 2.4 GHz / 4 cycles per wave-instruction."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r04_chain_pmc_sq_chain.txt")
+    try:
+        for line in open(path):
+            if line.startswith("sift_desc_pair_kernel ") or line.startswith("sift_desc_kernel "):
+                f = line.split()
+                avg_us, waves, valu = float(f[1]), float(f[2]), float(f[3])
+                achieved = waves * valu / (avg_us * 1e-6) / 1e9
+                peak = 1024 * 2.4e9 / 4 / 1e9
+                return {"bound": "valu_issue", "kernel": f[0], "achieved": achieved, "peak": peak, "unit": "G wave-instructions/s",
+                        "frac": achieved / peak, "waves": int(waves), "valu_instructions_per_wave": valu, "avg_launch_ms": avg_us * 1e-3,
+                        "source": "profiles/r04_chain_pmc_sq_chain.txt (committed rocprofv3 SQ counter passes of the KITTI-size "
+                                  "chain, both images in one launch; not measured in this run)"}
+    except OSError:
+        pass
+    return None
+
+
 def pmc_traffic(kernel_id, toed_mode):
     """HBM bytes per launch of a kernel id from the COMMITTED rocprofv3 PMC passes (FETCH_SIZE x 2 + WRITE_SIZE,
     profiles/kernel_pmc_<mode>.json, written by tools/rocprof_summary.py) -- not measured in this run; None if that
@@ -728,6 +749,7 @@ def sequence_bench(args, wl, H, W, F, device, rank, world, dist, reduce_device):
                          "note": "the stereo hot path's algorithmic bytes (SURVEY.md 8(d)) over the dominant kernel id's launch "
                                  "duration (HIP events, frames one at a time, after the timed region)"},
             "kernels": kernels,
+            "roofline_sift": sift_roofline(),
             "frames_per_s_by_host_threads": threaded,
             "full_temporal_chain_frames_per_s": 1.0 / t_full,
             "one_frame_at_a_time_frames_per_s": 1.0 / t_serial,
