@@ -1261,8 +1261,10 @@ __global__ void expand_rows_kernel(const int32_t *__restrict__ row_ptr, DevN nLd
 //   ncc_tile   : a WAVE owns NW consecutive left edges = a contiguous range of CSR pairs.  Phase 1 samples and
 //                normalises their patches into LDS (same layout as a bank entry, 7 rows), phase 2 walks the pairs of the
 //                tile, eight lanes per pair (lane r = row r of all four patches): four 16-byte loads of the right rows,
-//                four ds_read_b128 of the left rows, four 49-term dots in the canonical order (dot7 + butterfly8).  Arithmetic identical to
-//                ncc_pairs_kernel / the oracle: the normalised rows are the same floats, the reductions the same order.
+//                four ds_read_b128 of the left rows, four 49-term dots in the canonical order (dot7 per row, then the
+//                tree of butterfly8 -- round 4: reduced transposed, every lane ending up with ONE of the four dots, and with
+//                the tile's loads issued early; see the kernel).  Arithmetic identical to ncc_pairs_kernel / the oracle:
+//                the normalised rows are the same floats, the reductions the same additions.
 constexpr int BANK_SIDE = 56;   // floats per side of a bank entry: 7 rows x 8 floats (224 B, 16-byte aligned rows)
 constexpr int BANK_EDGE = 112;  // floats per edge (448 B)
 constexpr int NCC_NW = 4;       // left edges per wave (one sampling round: four 16-lane groups)
