@@ -259,10 +259,10 @@ def check_against_oracle(out, chk):
 
 # what the timing ids of `kernels` bracket (the ids are stages, HIP events around the launches of a stage)
 KERNEL_GROUPS = {
-    "hybrid": {"toed_nms": "toed_screen_fused", "toed_rowscan": "toed_rowscan_phase",
-               "toed_compact": "toed_compact_phase + toed_need_count / _rowscan / _compact",
+    "hybrid": {"toed_nms": "toed_screen_fused",
+               "toed_compact": "toed_compact_phase + toed_need_count / _compact (row offsets summed by the compaction blocks)",
                "toed_exact_centre": "toed_exact_centre", "toed_exact_mags": "toed_exact_mags + toed_exact_decide",
-               "toed_finalize": "toed_cand_scatter", "scan": "scan_reduce + scan_apply (flag scans of both images, row_ptr)",
+               "toed_finalize": "toed_cand_scatter (ranks from per-chunk counts)", "scan": "scan_reduce + scan_apply (row_ptr)",
                "cand_boxes": "match_prep (lines + boxes + sincos + row_pairs in one launch)", "cand_count": "candidates<count>",
                "cand_fill": "candidates<fill> (with the copy of the staged rows as its prologue)", "edge_patches": "right_bank",
                "ncc_pairs": "ncc_tile + pair_result"},
@@ -956,7 +956,7 @@ def main():
             submitted += 1
     barrier()
     dt = time.perf_counter() - t0
-    graph_pairs = ctx.graph_launches - graphs_before   # timed pairs whose ~31 launches went out as one hipGraphLaunch
+    graph_pairs = ctx.graph_launches - graphs_before   # timed pairs whose 18 launches went out as one hipGraphLaunch
     # the sustained rate: 300 pairs more, rank-local, straight after the timed region (the same loop)
     t_sus, _ = run_pairs(300)
     t_sus_full = None

@@ -1597,7 +1597,7 @@ static void pair_graph_drop(Slot &s)
     s.pair_graph = nullptr;
 }
 
-// The chain of one pair is ~31 launches whose arguments depend only on PairGraphKey and on the slot's buffers (the sizes
+// The chain of one pair is 18 launches whose arguments depend only on PairGraphKey and on the slot's buffers (the sizes
 // of everything live on the device): the second submission with an unchanged key captures it, later ones launch the graph
 // (measured, tools/ubench/graph_launch.hip: 7-20 us of host time for a 30-kernel chain against 86 us of direct launches,
 // and ~2 us instead of ~2.9 us between dependent kernels on the device).  Anything unusual -- profiling markers, a key

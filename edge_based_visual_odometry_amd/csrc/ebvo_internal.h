@@ -418,9 +418,6 @@ int match_ncc_quads_indexed_enqueue(ebvo_ctx *ctx, Slot &s, const float *kfLn, c
 // exclusive scan of n (+ n_add) int32 on the slot's stream; n_dev != nullptr: the count lives on the device, cap_n bounds it
 // zero n (<= EBVO_CLEAR_MAX) int32 arrays with one launch
 int ebvo_clear_enqueue(ebvo_ctx *ctx, Slot &s, int32_t *const ptrs[], const int counts[], int n);
-// up to four scans (device-side lengths) in one pair of launches
-int ebvo_device_scan4(ebvo_ctx *ctx, Slot &s, const int32_t *const in[4], int32_t *const out[4],
-                      const int32_t *const n_dev[4], int nb, int cap_n);
 // n_add = 1: the scan covers one more element that counts as zero whatever the memory behind `in` holds (out[n] = total);
 // d_total (optional, n_add = 1): the total is stored there as well
 int ebvo_device_scan(ebvo_ctx *ctx, Slot &s, const int32_t *in, int32_t *out, int n_host, const int32_t *n_dev, int n_add,

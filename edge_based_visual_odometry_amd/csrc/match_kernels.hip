@@ -1988,24 +1988,6 @@ int ebvo_clear_enqueue(ebvo_ctx *ctx, Slot &s, int32_t *const ptrs[], const int 
     return EBVO_OK;
 }
 
-int ebvo_device_scan4(ebvo_ctx *ctx, Slot &s, const int32_t *const in[4], int32_t *const out[4],
-                      const int32_t *const n_dev[4], int nb, int cap_n)
-{
-    ProfScope ps(ctx, s, K_SCAN);
-    ScanBatch S{};
-    for (int k = 0; k < nb && k < SCAN_BATCH; ++k)
-    {
-        S.in[k] = in[k];
-        S.out[k] = out[k];
-        S.n[k] = DevN{0, n_dev[k]};
-    }
-    int rc = device_exclusive_scan_batch(ctx, s, S, nb, cap_n);
-    if (rc)
-        return rc;
-    EBVO_HIP(ctx, hipGetLastError());
-    return EBVO_OK;
-}
-
 int ebvo_device_scan(ebvo_ctx *ctx, Slot &s, const int32_t *in, int32_t *out, int n_host, const int32_t *n_dev, int n_add,
                      int cap_n, int32_t *d_total)
 {
