@@ -2034,7 +2034,7 @@ int match_candidates_fill_enqueue(ebvo_ctx *ctx, Slot &s, const ebvo_edge *d_L, 
 {
     const CandParams P = cand_params(s, nL, d_nL, nR, d_nR, epi_thr, max_disp, orient_thr_deg, stage_mask, s.cap_pairs);
     ProfScope ps(ctx, s, K_CAND_FILL);
-    hipLaunchKernelGGL(candidates_kernel<true>, dim3(blocks_for(d_nL ? cap_edges : nL, TILE, 4096 / (ctx->small_div > 0 ? ctx->small_div : 1))), dim3(256), 0,
+    hipLaunchKernelGGL(candidates_kernel<true>, dim3(blocks_for(d_nL ? cap_edges : nL, TILE, 4096 / (ctx->small_div > 0 ? ctx->small_div : 4))), dim3(256), 0,
                        s.stream, d_L, d_R, d_lines, (const Box *)s.boxes_chunk.p, (const Box *)s.boxes_group.p, P,
                        (int32_t *)nullptr, (const int32_t *)s.row_ptr.p, (int32_t *)s.col_idx.p,
                        (unsigned long long *)nullptr);

@@ -1973,7 +1973,7 @@ int toed_enqueue(ebvo_ctx *ctx, Slot &s, int n_img, int h, int w, hipEvent_t ev_
                                        w, cap, n_img);
                 if (stop == 5)
                     return EBVO_OK;
-                hipLaunchKernelGGL(toed_exact_decide_kernel, dim3(512 / (ctx->small_div > 0 ? ctx->small_div : 1), n_img), dim3(256), 0, s.stream, E, h, w, cap);
+                hipLaunchKernelGGL(toed_exact_decide_kernel, dim3(512 / (ctx->small_div > 0 ? ctx->small_div : 4), n_img), dim3(256), 0, s.stream, E, h, w, cap);
             }
             if (stop == 6)
                 return EBVO_OK;
@@ -1989,7 +1989,7 @@ int toed_enqueue(ebvo_ctx *ctx, Slot &s, int n_img, int h, int w, hipEvent_t ev_
             EBVO_HIP(ctx, hipEventRecord(ev_conv_end, s.stream));
         {
             ProfScope ps(ctx, s, K_FINALIZE);
-            hipLaunchKernelGGL(toed_cand_scatter_kernel, dim3(512 / (ctx->small_div > 0 ? ctx->small_div : 1), n_img), dim3(256), 0, s.stream, B, cap);
+            hipLaunchKernelGGL(toed_cand_scatter_kernel, dim3(512 / (ctx->small_div > 0 ? ctx->small_div : 4), n_img), dim3(256), 0, s.stream, B, cap);
         }
         if (ev_end)
             EBVO_HIP(ctx, hipEventRecord(ev_end, s.stream));
