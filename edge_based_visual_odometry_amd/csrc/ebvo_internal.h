@@ -68,7 +68,7 @@ struct ImageWS
     double *maps = nullptr;     // PL_NUM planes of 4 x H x W
     uint8_t *flag = nullptr;    // 2H x 2W: 0 none, 1 NMS maximum, 3 maximum inside the 10-px border
     int32_t *row_cnt = nullptr; // [2][H2]   per interpolated row: all maxima, kept maxima (hybrid: even / odd column candidates)
-    int32_t *row_off = nullptr; // [3][H2+1] exclusive prefix of row_cnt (hybrid: all, even-column, odd-column per row parity)
+    int32_t *row_off = nullptr; // [3][H2+1] exclusive prefix of row_cnt (strict path; the hybrid compaction sums the counts itself)
     int32_t *counts = nullptr;  // [8] n_total, n_kept (device-side sizes of everything downstream), n_candidates (0 when they
                                 // did not fit), neighbour points, screened candidates before the capacity check
     int32_t *src = nullptr;     // [cap][2] (pixel offset, kept rank or -1) per maximum, raster order
@@ -76,7 +76,7 @@ struct ImageWS
     double *all4 = nullptr;     // [cap][4] every maximum (x, y, theta, mag)
     void *cand_rec = nullptr;       // hybrid TOED: [cap] exact records of the screened candidates
     int32_t *cand_flag = nullptr;   // [2][cap]   is-maximum / is-kept flags per candidate
-    int32_t *cand_off = nullptr;    // [2][cap+1] exclusive scans of the flags
+    int32_t *cand_off = nullptr;    // [2][cap+1] ints; hybrid: (maxima, kept maxima) per chunk of 256 candidates (toed_exact_decide_kernel)
     double *cand_data = nullptr;    // [cap] 64-byte records: exact gx, gy, |g|, TOx, TOy and the packed NMS sector of a candidate
     int32_t *cand_lists = nullptr;  // [12][cap] candidate indices by phase (4) and by (phase, axis) (8)
     int32_t *cand_lcount = nullptr; // [12]
