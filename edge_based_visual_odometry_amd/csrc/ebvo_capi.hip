@@ -4001,6 +4001,8 @@ extern "C" int ebvo_debug_set(ebvo_ctx *ctx, int key, int value)
         ctx->ncc_blocks = value;
     else if (key == 18)
         ctx->small_div = value;
+    else if (key == 19 && value <= EBVO_TOTAL_PARTS)
+        ctx->cand_blocks = value;
     else if (key == 13 && value <= 1)
         ctx->ingest_stream = value;
     else if (key == 0)

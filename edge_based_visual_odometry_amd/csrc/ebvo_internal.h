@@ -283,6 +283,7 @@ struct ebvo_ctx
     int use_graphs = 1;         // EBVO_GRAPHS=0 or ebvo_debug_set(10, 0): direct launches only
     int64_t graph_launches = 0; // pairs submitted as a graph launch
     int exact_blocks[2] = {0, 0}; // developer keys (ebvo_debug_set 11, 12): grid of the exact centre / mags kernel in blocks (0 = what the device keeps resident)
+    int cand_blocks = 0;        // developer key (ebvo_debug_set 19): most blocks of candidates<count> (0 = 1024; at most EBVO_TOTAL_PARTS)
     int small_div = 0;          // developer key (ebvo_debug_set 18): the grids of the latency-bound decide / cand_scatter / candidates<fill> are
                                 // 512 / 512 / 4096 blocks divided by this (0 = 4: +1.0 % pairs/s against 1, +0.7 % for 2, two runs; 8: -0.3 %)
     int ncc_blocks = 0;         // developer key (ebvo_debug_set 17): grid of ncc_tile_kernel in blocks (0 = what the device keeps resident)

@@ -2126,7 +2126,11 @@ int match_candidates_enqueue(ebvo_ctx *ctx, Slot &s, const ebvo_edge *d_L, int n
     const CandParams P = cand_params(s, nL, d_nL, nR, d_nR, epi_thr, max_disp, orient_thr_deg, stage_mask, s.cap_pairs);
     {
         ProfScope ps(ctx, s, K_CAND_COUNT);
-        const int nblk = blocks_for(capL, TILE, EBVO_TOTAL_PARTS);
+        // at most 1,024 blocks (what the device keeps resident, four waves of 116 registers per SIMD), each walking ~2 tiles at
+        // KITTI size: a capacity-sized grid of 4,096 (half of its blocks without a tile) cost 1.4 % of the pair rate
+        // (tools/gpu_ab_keys.py, key 19: 3410 / 3459 / 3456 / 3455 pairs/s for 4096 / 512 / 768 / 1024 blocks; one pair in
+        // flight: 437 / 463 / 445 / 440 us)
+        const int nblk = blocks_for(capL, TILE, ctx->cand_blocks > 0 ? ctx->cand_blocks : 1024);
         s.n_total_part = nblk;
         hipLaunchKernelGGL(candidates_kernel<false>, dim3(nblk), dim3(256), 0, s.stream, d_L, d_R, d_lines,
                            (const Box *)s.boxes_chunk.p, (const Box *)s.boxes_group.p, P, cnt, (const int32_t *)nullptr,

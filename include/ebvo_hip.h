@@ -721,7 +721,7 @@ int ebvo_profile_get(ebvo_ctx *ctx, ebvo_kernel_time *out /* EBVO_MAX_KERNELS */
  * key 13: 1 = ebvo_stereo_upload_async copies on the upload stream instead of the pull kernel; key 14: 1 = lines, boxes,
  *        sin / cos and row pairs as four launches instead of one; key 17: grid of ncc_tile_kernel in blocks (0 = resident);
  *        key 18: grids of decide / cand_scatter / candidates<fill> (512 / 512 / 4096 blocks) divided by `value` (0 = the
- *        default, 4).  Same bits either way (A/B switches).
+ *        default, 4); key 19: most blocks of candidates<count> (0 = the default, 1024).  Same bits either way (A/B switches).
  * key 15: bit mask -- an idempotent kernel of the resident pair's chain is launched TWICE (1 centre, 2 mags, 4 right bank,
  *        8 NCC tile): what one more launch costs the pair rate (tools/gpu_marginal_cost.py).
  * key 16: the resident pair's chain ENDS after stage `value` (0 = whole chain; the pair's record keeps the counts of the last
