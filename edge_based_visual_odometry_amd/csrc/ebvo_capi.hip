@@ -194,6 +194,8 @@ static void slot_destroy(Slot *s)
         (void)hipHostFree(s->h_push);
     if (s->h_mail)
         (void)hipHostFree(s->h_mail);
+    if (s->h_up)
+        (void)hipHostFree(s->h_up);
     (void)hipFree(s->d_fin_tot);
     if (s->h_fin_tot)
         (void)hipHostFree(s->h_fin_tot);
@@ -1166,7 +1168,7 @@ extern "C" int ebvo_stereo_upload_slot(ebvo_ctx *ctx, int slot, const uint8_t *i
 // queue: they never sit in front of a pair's kernels), an event marks their end, and the slot's next submission makes its
 // stream wait for that event -- satisfied long before when the caller uploads a slot a frame ahead of submitting it
 // (src/Pipeline.cpp:77-99 reads frame k + 1 while frame k is matched).  Asynchronous only for page-locked sources
-// (ebvo_host_register / hipHostMalloc); from pageable memory the runtime stages the copy and returns when it has read the source.
+// (ebvo_host_register / hipHostMalloc); pageable images are copied into the slot's page-locked staging before the call returns.
 extern "C" int ebvo_stereo_upload_async(ebvo_ctx *ctx, int slot, const uint8_t *img_left, const uint8_t *img_right, int h, int w,
                                         ptrdiff_t stride_left, ptrdiff_t stride_right)
 {
@@ -1235,12 +1237,61 @@ extern "C" int ebvo_stereo_upload_async(ebvo_ctx *ctx, int slot, const uint8_t *
     // ordering on the device, not on the host: result copies of the previous pair (copy stream) still read the edge lists --
     // not the images -- so only a previous asynchronous upload of this slot (same stream: ordered) and the slot's own stream
     // (later stages of the previous pair sample the images) matter
+    // The copies below wait ON THE DEVICE for the slot's earlier work, so the runtime cannot read a pageable source while this
+    // call runs: it would read it whenever the copy gets its turn -- after the caller has, rightly, freed the images (seen as
+    // a GPU memory fault at a host heap address in a later test, once in five full test runs).  Images that are not inside a
+    // registered range are therefore copied into the slot's own page-locked staging first (a host memcpy of 2 h w bytes); the
+    // previous asynchronous upload of the slot has left the staging when drain_stream_upload returns.
+    const uint8_t *src[2] = {img_left, img_right};
+    ptrdiff_t sstride[2] = {stride_left, stride_right};
+    {
+        const size_t npx = (size_t)h * w;
+        bool staged = false;
+        for (int k = 0; k < 2; ++k)
+        {
+            const size_t span = (size_t)(h - 1) * (size_t)sstride[k] + (size_t)w;
+            bool pinned = false;
+            for (const ebvo_ctx::HostRange &r : ctx->host_ranges)
+                if (src[k] >= r.host && src[k] + span <= r.host + r.bytes)
+                    pinned = true;
+            if (pinned)
+                continue;
+            if (!staged)
+            {
+                if ((rc = drain_stream_upload(ctx, s)))
+                    return rc;
+                if (s.h_up_bytes < 2 * npx)
+                {
+                    if (s.h_up)
+                        (void)hipHostFree(s.h_up);
+                    s.h_up = nullptr;
+                    s.h_up_bytes = 0;
+                    if (hipHostMalloc(reinterpret_cast<void **>(&s.h_up), 2 * npx) != hipSuccess)
+                    {
+                        (void)hipGetLastError();
+                        ctx->last_error = "hipHostMalloc failed (staging of ebvo_stereo_upload_async)";
+                        return EBVO_ERR_NOMEM;
+                    }
+                    s.h_up_bytes = 2 * npx;
+                }
+                staged = true;
+            }
+            uint8_t *stage = s.h_up + (size_t)k * npx;
+            if (sstride[k] == (ptrdiff_t)w)
+                memcpy(stage, src[k], npx);
+            else
+                for (int y = 0; y < h; ++y)
+                    memcpy(stage + (size_t)y * w, src[k] + (size_t)y * sstride[k], (size_t)w);
+            src[k] = stage;
+            sstride[k] = w;
+        }
+    }
     EBVO_HIP(ctx, hipEventRecord(s.ev_upload, s.own_stream));
     EBVO_HIP(ctx, hipStreamWaitEvent(ctx->upload_stream, s.ev_upload, 0));
     s.undist_pair = ctx->undist_on;
     s.toed_strict_override = false;
-    if ((rc = upload_image(ctx, s, 0, img_left, h, w, stride_left, s.undist_pair, ctx->upload_stream)) ||
-        (rc = upload_image(ctx, s, 1, img_right, h, w, stride_right, s.undist_pair, ctx->upload_stream)))
+    if ((rc = upload_image(ctx, s, 0, src[0], h, w, sstride[0], s.undist_pair, ctx->upload_stream)) ||
+        (rc = upload_image(ctx, s, 1, src[1], h, w, sstride[1], s.undist_pair, ctx->upload_stream)))
         return rc;
     EBVO_HIP(ctx, hipEventRecord(s.ev_upload, ctx->upload_stream));
     s.upload_pending = true;

@@ -142,6 +142,8 @@ struct Slot
     bool pull = false;                             // the resident pair is pulled by the chain itself
     hipEvent_t ev_upload = nullptr;   // end of the slot's asynchronous image upload (ebvo_stereo_upload_async, the context's upload stream)
     bool upload_pending = false;      // ... recorded and not yet waited for by a submission or a host call
+    uint8_t *h_up = nullptr;          // page-locked staging of the stream form: a pair of images from PAGEABLE caller memory is copied
+    size_t h_up_bytes = 0;            // here before the call returns (the caller may free its images; the runtime reads pageable sources late)
     ImageWS im[2];
     int cur_h = 0, cur_w = 0;
     bool have_pair = false, have_run = false, in_flight = false, have_refined = false;

@@ -616,8 +616,9 @@ int ebvo_stereo_upload_slot(ebvo_ctx *ctx, int slot, const uint8_t *img_left, co
  * memory that is page-locked already, hipHostMalloc, may be registered too): the call only records where the images lie (no
  * runtime call, < 1 us) and the pair's own chain starts with a kernel that READS them from the caller's memory -- no copy
  * engine, no second stream, no event.  The images must stay unchanged until the pair's ebvo_stereo_wait has returned, and
- * registered as long as the slot is submitted with them.  Images anywhere else take the staged copy on the context's upload
- * stream (ebvo_ingest_stats tells which form the calls took). */
+ * registered as long as the slot is submitted with them.  Images anywhere else (pageable memory) are copied into the slot's
+ * own page-locked staging BEFORE the call returns -- the caller may free or overwrite them at once -- and go up from there on
+ * the context's upload stream (ebvo_ingest_stats tells which form the calls took). */
 int ebvo_stereo_upload_async(ebvo_ctx *ctx, int slot, const uint8_t *img_left, const uint8_t *img_right, int h, int w,
                              ptrdiff_t stride_left, ptrdiff_t stride_right);
 /* page-lock / release caller memory (hipHostRegister / hipHostUnregister): no HIP header needed on the host side */

@@ -104,6 +104,30 @@ def test_async_upload_then_host_buffer_call_on_slot_0_is_ordered(c):
     assert_edges_equal(out["left"], e)
 
 
+def test_pageable_images_may_be_overwritten_as_soon_as_the_async_upload_returns(c):
+    """Images outside every registered range are read BEFORE ebvo_stereo_upload_async returns (into the slot's page-locked
+    staging): the caller may overwrite or free them at once.  (Round 4: the runtime read a pageable source when the copy got
+    its turn on the device -- a GPU memory fault at a freed host address, once in five full test runs.)"""
+    ring = _ring(3)
+    ref = _reference(c, ring)
+    p = c.default_params(F)
+    before = c.ingest_stats()
+    for k, (l, r) in enumerate(ring):
+        slot = 1 + (k & 1)
+        lt, rt = l.copy(), r.copy()                    # pageable, never registered
+        c.stereo_upload_async(lt, rt, slot=slot)
+        lt[:] = 0                                      # overwritten ...
+        rt[:] = 255
+        del lt, rt                                     # ... and dropped before the pair is even submitted
+        c.stereo_submit(p, slot=slot)
+        cnt = c.stereo_wait(slot=slot)
+        assert (cnt.n_left, cnt.n_right, cnt.n_pairs, cnt.n_matches) == \
+            (ref[k][0].n_left, ref[k][0].n_right, ref[k][0].n_pairs, ref[k][0].n_matches)
+        _same(c.stereo_fetch(cnt, slot=slot), ref[k])
+    after = c.ingest_stats()
+    assert after["stream_uploads"] - before["stream_uploads"] == 3 and after["pull_uploads"] == before["pull_uploads"]
+
+
 def test_compact_fetch_equals_full_fetch(c):
     ring = _ring(2)
     ref = _reference(c, ring)
